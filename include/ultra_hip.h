@@ -1,0 +1,261 @@
+/*
+ * ultra_hip.h — C-ABI of the MI355X-native batched OFDM-demodulate + LDPC-decode
+ * receive path (libultra_hip.so).
+ *
+ * This is the drop-in boundary for the hot path of secup/ProjectUltra.  The
+ * reference has no FFI of its own: its "plugin surface" is the C++ abstract
+ * class ultra::IWaveform (src/waveform/waveform_interface.hpp:47-157) plus the
+ * two concrete classes every caller uses, ultra::OFDMDemodulator
+ * (include/ultra/ofdm.hpp:58-127) and ultra::LDPCDecoder
+ * (include/ultra/fec.hpp:48-77).  Each entry point below names the reference
+ * interface it replaces.  Host C++ (include/ultra_hip_waveform.hpp) and Python
+ * (projectultra_amd/) bind these symbols; INTEGRATION.md shows the binding a
+ * reference maintainer would add.
+ *
+ * Conventions
+ *   - plain pointers and sizes only; no C++/torch types cross the boundary
+ *   - every function returns ULTRA_HIP_OK (0) or a negative ultra_hip_status
+ *   - "d_" pointers are DEVICE pointers (HBM), "h_" pointers are HOST pointers
+ *   - one context per device per host thread; a context is not thread-safe
+ *     (same rule as the reference: one demodulator instance per stream,
+ *     docs/INVARIANTS.md:239-258)
+ *   - all launches go to the context's stream; *_batch calls are asynchronous
+ *     with respect to the host unless documented otherwise
+ *   - LLR sign convention: LLR > 0  <=>  bit 0 (docs/INVARIANTS.md:213-222)
+ */
+#ifndef ULTRA_HIP_H
+#define ULTRA_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define ULTRA_HIP_ABI_VERSION 1
+
+/* ultra::Modulation (include/ultra/types.hpp:27-39) — same numeric values. */
+enum ultra_hip_modulation {
+    ULTRA_MOD_DBPSK = 0, ULTRA_MOD_BPSK = 1, ULTRA_MOD_DQPSK = 2, ULTRA_MOD_QPSK = 3,
+    ULTRA_MOD_D8PSK = 4, ULTRA_MOD_QAM8 = 5, ULTRA_MOD_QAM16 = 6, ULTRA_MOD_QAM32 = 7,
+    ULTRA_MOD_QAM64 = 8, ULTRA_MOD_QAM256 = 10
+};
+
+/* ultra::CodeRate (include/ultra/types.hpp:91-100) — same numeric values. */
+enum ultra_hip_code_rate {
+    ULTRA_RATE_R1_4 = 0, ULTRA_RATE_R1_3 = 1, ULTRA_RATE_R1_2 = 2, ULTRA_RATE_R2_3 = 3,
+    ULTRA_RATE_R3_4 = 4, ULTRA_RATE_R5_6 = 5, ULTRA_RATE_R7_8 = 6
+};
+
+/* ultra::CyclicPrefixMode (include/ultra/types.hpp:76-80). */
+enum ultra_hip_cp_mode { ULTRA_CP_SHORT = 0, ULTRA_CP_MEDIUM = 1, ULTRA_CP_LONG = 2 };
+
+/* Where in the reference's receive state machine a batch frame enters. */
+enum ultra_hip_entry {
+    /* State on entering SYNCED from the Schmidl-Cox search on a freshly
+     * constructed demodulator (src/ofdm/demodulator.cpp:26-43,533-591): audio
+     * starts at the first data symbol, H=(1,0), mixer phase 0. */
+    ULTRA_ENTRY_SYNCED = 0,
+    /* OFDMDemodulator::processPresynced (src/ofdm/demodulator.cpp:854-985):
+     * audio starts at the first of `training_symbols` LTS symbols. */
+    ULTRA_ENTRY_PRESYNCED = 1
+};
+
+enum ultra_hip_status {
+    ULTRA_HIP_OK = 0,
+    ULTRA_HIP_ERR_INVALID_ARG = -1,   /* bad pointer / size / enum                */
+    ULTRA_HIP_ERR_UNSUPPORTED = -2,   /* configuration outside the built path      */
+    ULTRA_HIP_ERR_NO_DEVICE = -3,     /* no HIP device / device index out of range */
+    ULTRA_HIP_ERR_HIP = -4,           /* a HIP runtime call failed                 */
+    ULTRA_HIP_ERR_OOM = -5            /* device or host allocation failed          */
+};
+
+/*
+ * POD mirror of the ultra::ModemConfig fields the receive path reads
+ * (include/ultra/types.hpp:139-234) + the decoder knobs of
+ * ultra::LDPCDecoder (include/ultra/fec.hpp:48-77).
+ */
+typedef struct ultra_hip_config {
+    uint32_t sample_rate;      /* ModemConfig::sample_rate (48000)                 */
+    uint32_t center_freq;      /* ModemConfig::center_freq (1500)                  */
+    uint32_t fft_size;         /* 512 or 1024                                      */
+    uint32_t num_carriers;     /* 30 / 59                                          */
+    uint32_t cp_mode;          /* ultra_hip_cp_mode                                */
+    uint32_t symbol_guard;     /* guard samples after each symbol                  */
+    uint32_t pilot_spacing;    /* every pilot_spacing-th carrier is a pilot        */
+    uint32_t use_pilots;       /* 0/1                                              */
+    uint32_t modulation;       /* ultra_hip_modulation                             */
+    uint32_t code_rate;        /* ultra_hip_code_rate                              */
+    uint32_t max_iterations;   /* LDPCDecoder::setMaxIterations (default 50)       */
+    uint32_t n_data_symbols;   /* data symbols per frame fed to the demodulator    */
+    uint32_t entry;            /* ultra_hip_entry                                  */
+    uint32_t training_symbols; /* ULTRA_ENTRY_PRESYNCED only (reference default 2) */
+} ultra_hip_config;
+
+/* Geometry derived from a config (ModemConfig::getCyclicPrefix /
+ * getSymbolDuration, include/ultra/types.hpp:197-213; code parameters
+ * src/fec/ldpc_decoder.cpp:22-36). */
+typedef struct ultra_hip_geometry {
+    uint32_t cp_len;            /* cyclic prefix samples                            */
+    uint32_t symbol_samples;    /* fft + cp + guard                                 */
+    uint32_t frame_samples;     /* (training + data symbols) * symbol_samples       */
+    uint32_t n_data_carriers;
+    uint32_t n_pilot_carriers;
+    uint32_t bits_per_carrier;
+    uint32_t llrs_per_symbol;   /* n_data_carriers * bits_per_carrier               */
+    uint32_t llrs_per_frame;    /* llrs_per_symbol * n_data_symbols                 */
+    uint32_t ldpc_n;            /* 648                                              */
+    uint32_t ldpc_k;            /* info bits                                        */
+    uint32_t ldpc_m;            /* parity bits / check rows                         */
+    uint32_t ldpc_edges;        /* edges of H = [H_data | I]                        */
+    uint32_t decoded_bytes;     /* ceil(k / 8): bytes LDPCDecoder::decodeSoft returns */
+} ultra_hip_geometry;
+
+/* Device-side Monte-Carlo counters.  Reduced on device by
+ * ultra_hip_count_errors and summed across ranks by the caller's collective. */
+typedef struct ultra_hip_counters {
+    uint64_t frames;
+    uint64_t frame_errors;      /* !success or payload mismatch                    */
+    uint64_t bit_errors;        /* payload bit errors                              */
+    uint64_t info_bits;         /* payload bits compared                           */
+    uint64_t ldpc_fail;         /* frames whose parity check never passed          */
+    uint64_t iters_sum;         /* sum of lastIterations()                         */
+    uint64_t undetected_errors; /* parity passed but payload differs               */
+    uint64_t reserved;
+} ultra_hip_counters;
+
+typedef struct ultra_hip_ctx ultra_hip_ctx;
+
+/* ABI version of the loaded library (== ULTRA_HIP_ABI_VERSION). */
+int ultra_hip_abi_version(void);
+
+/* Human-readable text for a status code. */
+const char* ultra_hip_strerror(int status);
+
+/* Number of visible HIP devices, or a negative status.  Does not create a
+ * HIP context on any device. */
+int ultra_hip_device_count(void);
+
+/* Pure host arithmetic: fill *geo for *cfg.  No device needed.
+ * Replaces: ModemConfig::getCyclicPrefix/getSymbolDuration
+ * (include/ultra/types.hpp:197-213), OFDMDemodulator::Impl::setupCarriers
+ * (src/ofdm/demodulator.cpp:46-69) carrier counts, getCodeParams
+ * (src/fec/ldpc_decoder.cpp:22-36). */
+int ultra_hip_geometry_for(const ultra_hip_config* cfg, ultra_hip_geometry* geo);
+
+/* Create a context on `device`: builds the per-configuration constant tables
+ * on the host exactly as the reference constructors do (NCO table
+ * src/dsp/filters.cpp:228-238, FFT twiddles src/dsp/fft.cpp:75-82, carrier map
+ * and pilot signs src/ofdm/demodulator.cpp:46-85, interpolation table
+ * :137-193, Zadoff-Chu sequence :70-78, Tanner graph
+ * src/fec/ldpc_decoder.cpp:64-137) and uploads them.
+ * `stream` is a hipStream_t (may be NULL for the default stream).
+ * Replaces: OFDMDemodulator::OFDMDemodulator(const ModemConfig&)
+ * (src/ofdm/demodulator.cpp:455-458) + LDPCDecoder::LDPCDecoder(CodeRate)
+ * (src/fec/ldpc_decoder.cpp:262-265) + WaveformFactory::create
+ * (src/waveform/waveform_factory.cpp:11-61). */
+int ultra_hip_create(const ultra_hip_config* cfg, int device, void* stream, ultra_hip_ctx** out);
+
+/* Replaces the destructors of the two classes above. */
+void ultra_hip_destroy(ultra_hip_ctx* ctx);
+
+/* Geometry of a live context. */
+int ultra_hip_get_geometry(const ultra_hip_ctx* ctx, ultra_hip_geometry* geo);
+
+/* Copy the Tanner graph the context decodes with to the host (for parity
+ * tests): row_ptr[m+1], col_idx[edges] — row-major edge order of
+ * LDPCDecoder::Impl::H_rows (src/fec/ldpc_decoder.cpp:64-137). */
+int ultra_hip_get_tanner_graph(const ultra_hip_ctx* ctx, uint32_t* h_row_ptr, uint32_t* h_col_idx);
+
+/*
+ * Batched LDPC decode: n_cw codewords of 648 LLRs each.
+ *   d_llr      [n_cw][648] f32 (device)
+ *   d_bytes    [n_cw][decoded_bytes] u8 (device): info bits packed MSB-first
+ *   d_iters    [n_cw] i32: LDPCDecoder::lastIterations() per codeword
+ *   d_ok       [n_cw] u8 : LDPCDecoder::lastDecodeSuccess() per codeword
+ *   d_llr_total[n_cw][648] f32 or NULL: final a-posteriori LLRs (parity tests)
+ * Replaces: LDPCDecoder::decodeSoft (src/fec/ldpc_decoder.cpp:283-428) →
+ * Impl::decodeBP (:153-259), lastDecodeSuccess (:430), lastIterations (:434).
+ */
+int ultra_hip_ldpc_decode_batch(ultra_hip_ctx* ctx, const float* d_llr, size_t n_cw,
+                                uint8_t* d_bytes, int32_t* d_iters, uint8_t* d_ok,
+                                float* d_llr_total);
+
+/*
+ * Batched OFDM demodulation: n_frames frames, each frame_samples f32 audio
+ * samples starting at the configured entry point.
+ *   d_audio    [n_frames] rows of `frame_stride` floats (>= frame_samples)
+ *   d_cfo_hz   [n_frames] f32 or NULL (=0): initial freq_offset_hz
+ *              (OFDMDemodulator::setFrequencyOffset / coarse CFO from sync)
+ *   d_cfo_phase[n_frames] f32 or NULL (=0): initial freq_correction_phase
+ *              (OFDMDemodulator::setFrequencyOffsetWithPhase)
+ *   d_llr      [n_frames][llrs_per_frame] f32: soft bits in the order
+ *              OFDMDemodulator::getSoftBits hands them out
+ *   d_state    [n_frames][ULTRA_HIP_STATE_FLOATS] f32 or NULL: final tracker
+ *              state (see ULTRA_HIP_STATE_* indices)
+ * Replaces: OFDMDemodulator::process SYNCED loop (src/ofdm/demodulator.cpp:
+ * 672-697) / processPresynced (:854-985) + getSoftBits (:766-791), i.e.
+ * toBaseband, extractSymbol, updateChannelEstimate, interpolateChannel,
+ * equalize (src/ofdm/channel_equalizer.cpp:19-71,330-631,728-840) and
+ * demodulateSymbol (src/ofdm/demodulator.cpp:199-435).
+ */
+int ultra_hip_demod_batch(ultra_hip_ctx* ctx, const float* d_audio, size_t frame_stride,
+                          const float* d_cfo_hz, const float* d_cfo_phase, size_t n_frames,
+                          float* d_llr, float* d_state);
+
+#define ULTRA_HIP_STATE_FLOATS 8
+#define ULTRA_HIP_STATE_FREQ_OFFSET_HZ 0   /* OFDMDemodulator::getFrequencyOffset     */
+#define ULTRA_HIP_STATE_NOISE_VARIANCE 1   /* Impl::noise_variance                    */
+#define ULTRA_HIP_STATE_SNR_LINEAR     2   /* Impl::estimated_snr_linear              */
+#define ULTRA_HIP_STATE_TIMING_OFFSET  3   /* Impl::timing_offset_samples             */
+#define ULTRA_HIP_STATE_CFO_PHASE      4   /* Impl::freq_correction_phase             */
+#define ULTRA_HIP_STATE_MIXER_PHASE    5   /* NCO::phase_                             */
+#define ULTRA_HIP_STATE_SYMBOLS        6   /* Impl::snr_symbol_count (as float)       */
+#define ULTRA_HIP_STATE_RESERVED       7
+
+/*
+ * Fused receive path: demodulate, keep the first 648 LLRs of each frame on
+ * chip, LDPC-decode them.  Same arguments as the two calls above; d_llr may be
+ * NULL (LLRs are then never written to HBM).
+ * Replaces the per-frame body of the reference's Monte-Carlo harnesses
+ * (tools/test_nvis_mode.cpp:88-113): demod.process → getSoftBits → first 648
+ * → decoder.decodeSoft.
+ */
+int ultra_hip_demod_decode_batch(ultra_hip_ctx* ctx, const float* d_audio, size_t frame_stride,
+                                 const float* d_cfo_hz, const float* d_cfo_phase, size_t n_frames,
+                                 float* d_llr, uint8_t* d_bytes, int32_t* d_iters, uint8_t* d_ok);
+
+/*
+ * Compare decoded bytes with the transmitted payloads and accumulate the
+ * Monte-Carlo counters on device (one atomic block-reduction per launch).
+ *   d_payload [n_frames][payload_bytes] u8 reference payloads
+ *   d_counters  device ultra_hip_counters, accumulated into (caller zeroes)
+ * Frame OK iff ok && first payload_bytes bytes equal
+ * (tools/test_nvis_mode.cpp:104-113).
+ */
+int ultra_hip_count_errors(ultra_hip_ctx* ctx, const uint8_t* d_bytes, const int32_t* d_iters,
+                           const uint8_t* d_ok, const uint8_t* d_payload, size_t payload_bytes,
+                           size_t n_frames, ultra_hip_counters* d_counters);
+
+/* Block the host until everything queued on the context's stream is done. */
+int ultra_hip_synchronize(ultra_hip_ctx* ctx);
+
+/* Time the next *_batch launches with HIP events on the context's stream:
+ * begin() records a start event, end() records a stop event, synchronizes it
+ * and returns the elapsed milliseconds in *ms. */
+int ultra_hip_timer_begin(ultra_hip_ctx* ctx);
+int ultra_hip_timer_end(ultra_hip_ctx* ctx, float* ms);
+
+/* Convenience for hosts without their own device allocator (the C++ adapter
+ * and the ctypes tests): hipMalloc/hipFree/hipMemcpy on the context's device. */
+int ultra_hip_malloc(ultra_hip_ctx* ctx, size_t bytes, void** d_ptr);
+int ultra_hip_free(ultra_hip_ctx* ctx, void* d_ptr);
+int ultra_hip_memcpy_h2d(ultra_hip_ctx* ctx, void* d_dst, const void* h_src, size_t bytes);
+int ultra_hip_memcpy_d2h(ultra_hip_ctx* ctx, void* h_dst, const void* d_src, size_t bytes);
+int ultra_hip_memset(ultra_hip_ctx* ctx, void* d_dst, int value, size_t bytes);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* ULTRA_HIP_H */

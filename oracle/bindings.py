@@ -1,0 +1,379 @@
+"""ctypes bindings for the two CHECKERS — test infrastructure, never product code.
+
+  * ``Oracle``  → oracle/libultra_oracle.so  (C restatement, oracle/ultra_oracle.c)
+  * ``Ref``     → oracle/_ref/libultra_ref.so (the compiled reference + ref_shim.cpp)
+
+Only tests/, ``__graft_entry__.smoke()`` and ``bench.py``'s cpu_baseline leg may
+import this module.  The product package (projectultra_amd) never does.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import subprocess
+from pathlib import Path
+
+import numpy as np
+
+HERE = Path(__file__).resolve().parent
+ORACLE_SO = HERE / "libultra_oracle.so"
+REF_SO = HERE / "_ref" / "libultra_ref.so"
+REFERENCE_ROOT = Path("/root/reference")
+
+
+class Config(C.Structure):
+    """ultra_hip_config (include/ultra_hip.h) — POD shared with the product ABI."""
+    _fields_ = [(n, C.c_uint32) for n in (
+        "sample_rate", "center_freq", "fft_size", "num_carriers", "cp_mode", "symbol_guard",
+        "pilot_spacing", "use_pilots", "modulation", "code_rate", "max_iterations",
+        "n_data_symbols", "entry", "training_symbols")]
+
+    def copy(self, **kw):
+        c = Config()
+        C.memmove(C.byref(c), C.byref(self), C.sizeof(Config))
+        for k, v in kw.items():
+            setattr(c, k, v)
+        return c
+
+
+class Geometry(C.Structure):
+    _fields_ = [(n, C.c_uint32) for n in (
+        "cp_len", "symbol_samples", "frame_samples", "n_data_carriers", "n_pilot_carriers",
+        "bits_per_carrier", "llrs_per_symbol", "llrs_per_frame", "ldpc_n", "ldpc_k", "ldpc_m",
+        "ldpc_edges", "decoded_bytes")]
+
+
+MOD = dict(DBPSK=0, BPSK=1, DQPSK=2, QPSK=3, D8PSK=4, QAM8=5, QAM16=6, QAM32=7, QAM64=8, QAM256=10)
+RATE = dict(R1_4=0, R1_3=1, R1_2=2, R2_3=3, R3_4=4, R5_6=5)
+DIFFERENTIAL = (MOD["DBPSK"], MOD["DQPSK"], MOD["D8PSK"])
+BITS = {0: 1, 1: 1, 2: 2, 3: 2, 4: 3, 5: 3, 6: 4, 7: 5, 8: 6, 10: 8}
+INFO_BITS = {0: 162, 1: 324, 2: 324, 3: 432, 4: 486, 5: 540}
+
+
+def make_config(fft=1024, mod="QAM16", rate="R3_4", *, carriers=None, pilot_spacing=None,
+                use_pilots=None, guard=None, entry=0, training=2, n_data_symbols=None,
+                max_iterations=50, cp_mode=1):
+    """ModemConfig as the reference harnesses build it (tools/test_nvis_mode.cpp:35-41,
+    198-212): 512-FFT = ModemConfig defaults (30 carriers, guard 4, spacing 2);
+    1024-FFT = presets::nvis_mode() with pilot_spacing 4; use_pilots = !differential."""
+    m = MOD[mod] if isinstance(mod, str) else mod
+    r = RATE[rate] if isinstance(rate, str) else rate
+    c = Config()
+    c.sample_rate, c.center_freq, c.fft_size = 48000, 1500, fft
+    c.num_carriers = carriers if carriers is not None else (30 if fft == 512 else 59)
+    c.cp_mode = cp_mode
+    c.symbol_guard = guard if guard is not None else (4 if fft == 512 else 0)
+    c.pilot_spacing = pilot_spacing if pilot_spacing is not None else (2 if fft == 512 else 4)
+    c.use_pilots = int(m not in DIFFERENTIAL) if use_pilots is None else int(use_pilots)
+    c.modulation, c.code_rate, c.max_iterations = m, r, max_iterations
+    c.entry, c.training_symbols = entry, (training if entry == 1 else 0)
+    if n_data_symbols is None:
+        n_pil = -(-c.num_carriers // c.pilot_spacing) if c.use_pilots else 0
+        bps = (c.num_carriers - n_pil) * BITS[m]
+        n_data_symbols = -(-648 // bps)
+    c.n_data_symbols = n_data_symbols
+    return c
+
+
+def _f32(a):
+    return np.ascontiguousarray(a, dtype=np.float32)
+
+
+def _ptr(a, t=C.c_float):
+    return a.ctypes.data_as(C.POINTER(t))
+
+
+def build_oracle(force=False):
+    """Compile oracle/libultra_oracle.so (and oracle/_ref when /root/reference exists)."""
+    if force or not ORACLE_SO.exists() or ORACLE_SO.stat().st_mtime < (HERE / "ultra_oracle.c").stat().st_mtime:
+        subprocess.check_call(["make", "-C", str(HERE), "libultra_oracle.so"], stdout=subprocess.DEVNULL)
+    if REFERENCE_ROOT.is_dir() and (force or not REF_SO.exists()
+                                    or REF_SO.stat().st_mtime < (HERE / "ref_shim.cpp").stat().st_mtime):
+        subprocess.check_call(["make", "-C", str(HERE), "_ref/libultra_ref.so"], stdout=subprocess.DEVNULL)
+
+
+class _Base:
+    prefix = ""
+
+    def __init__(self, path):
+        self.lib = C.CDLL(str(path))
+
+    def _fn(self, name):
+        return getattr(self.lib, self.prefix + name)
+
+    # -------------------------------------------------------------- FEC
+    def ldpc_encode(self, rate, data: bytes) -> bytes:
+        out = (C.c_uint8 * 4096)()
+        n = self._fn("ldpc_encode")(C.c_uint32(rate), data, C.c_uint32(len(data)), out, C.c_uint32(4096))
+        assert n >= 0
+        return bytes(out[:n])
+
+    def ldpc_decode_soft(self, rate, llr, max_iters=50):
+        llr = _f32(llr)
+        out = (C.c_uint8 * 4096)()
+        ok, it = C.c_int(0), C.c_int(0)
+        n = self._fn("ldpc_decode_soft")(C.c_uint32(rate), C.c_int(max_iters), _ptr(llr), C.c_uint32(llr.size),
+                                         out, C.c_uint32(4096), C.byref(ok), C.byref(it))
+        assert n >= 0
+        return bytes(out[:n]), bool(ok.value), it.value
+
+    def ldpc_decode_batch(self, rate, llr, max_iters=50, want_total=False):
+        llr = _f32(llr).reshape(-1, 648)
+        n = llr.shape[0]
+        nbytes = (INFO_BITS[rate] + 7) // 8
+        out = np.zeros((n, nbytes), np.uint8)
+        iters = np.zeros(n, np.int32)
+        ok = np.zeros(n, np.uint8)
+        args = [C.c_uint32(rate), C.c_int(max_iters), _ptr(llr), C.c_uint32(n), _ptr(out, C.c_uint8),
+                C.c_uint32(nbytes), _ptr(iters, C.c_int32), _ptr(ok, C.c_uint8)]
+        total = None
+        if self.prefix == "uo_":
+            total = np.zeros((n, 648), np.float32) if want_total else None
+            args.append(_ptr(total) if want_total else None)
+        rc = self._fn("ldpc_decode_batch")(*args)
+        assert rc == 0
+        return (out, iters, ok, total) if want_total else (out, iters, ok)
+
+    # -------------------------------------------------------------- DSP
+    def fft_forward(self, x):
+        x = np.ascontiguousarray(x, np.complex64)
+        out = np.zeros_like(x)
+        self._fn("fft_forward")(C.c_uint32(x.size), _ptr(x.view(np.float32)), _ptr(out.view(np.float32)))
+        return out
+
+    def fft_inverse(self, x):
+        x = np.ascontiguousarray(x, np.complex64)
+        out = np.zeros_like(x)
+        self._fn("fft_inverse")(C.c_uint32(x.size), _ptr(x.view(np.float32)), _ptr(out.view(np.float32)))
+        return out
+
+    def nco(self, freq, fs, n):
+        out = np.zeros(n, np.complex64)
+        self._fn("nco")(C.c_float(freq), C.c_float(fs), C.c_uint32(n), _ptr(out.view(np.float32)))
+        return out
+
+    # ------------------------------------------------------ demodulator
+    def demod_tables(self, cfg):
+        di = np.zeros(128, np.int32); pi = np.zeros(128, np.int32)
+        ps = np.zeros(128, np.complex64); ii = np.zeros((128, 3), np.int32)
+        ia = np.zeros(128, np.float32); ss = np.zeros(128, np.complex64)
+        cnt = np.zeros(4, np.uint32)
+        rc = self._fn("demod_tables")(C.byref(cfg), _ptr(di, C.c_int32), _ptr(pi, C.c_int32),
+                                      _ptr(ps.view(np.float32)), _ptr(ii, C.c_int32), _ptr(ia),
+                                      _ptr(ss.view(np.float32)), _ptr(cnt, C.c_uint32))
+        assert rc == 0
+        nd, np_, ni, ns = (int(v) for v in cnt)
+        return dict(data_idx=di[:nd].copy(), pilot_idx=pi[:np_].copy(), pilot_seq=ps[:np_].copy(),
+                    interp=ii[:ni].copy(), interp_alpha=ia[:ni].copy(), sync_seq=ss[:ns].copy())
+
+    def demod_synced(self, cfg, audio, cfo_hz=0.0, stages=False):
+        """SYNCED-entry symbol loop.  Returns (llr, stage dict | None)."""
+        audio = _f32(audio)
+        g = geometry(cfg)
+        S, N, nd = g.symbol_samples, cfg.fft_size, g.n_data_carriers
+        nsym = audio.size // S
+        cap = nsym * g.llrs_per_symbol
+        llr = np.zeros(cap, np.float32)
+        per = 2 * S + 2 * N + 2 * N + 2 * nd + nd + 8
+        st = np.zeros(nsym * per, np.float32) if stages else None
+        n = self._fn("demod_synced")(C.byref(cfg), _ptr(audio), C.c_uint32(nsym), C.c_float(cfo_hz),
+                                     _ptr(llr), C.c_uint32(cap), _ptr(st) if stages else None)
+        assert n == cap, (n, cap)
+        if not stages:
+            return llr, None
+        st = st.reshape(nsym, per)
+        o = 0
+        d = {}
+        for name, ln, cx in (("bb", S, True), ("freq", N, True), ("H", N, True), ("eq", nd, True),
+                             ("nv", nd, False), ("scal", 8, False)):
+            w = 2 * ln if cx else ln
+            blk = np.ascontiguousarray(st[:, o:o + w])
+            d[name] = blk.view(np.complex64) if cx else blk
+            o += w
+        return llr, d
+
+    def demod_presynced(self, cfg, audio, cfo_hz=0.0, cfo_phase=0.0):
+        audio = _f32(audio)
+        g = geometry(cfg)
+        cap = g.llrs_per_frame + 4096
+        llr = np.zeros(cap, np.float32)
+        H = np.zeros(cfg.fft_size, np.complex64)
+        scal = np.zeros(8, np.float32)
+        n = self._fn("demod_presynced")(C.byref(cfg), _ptr(audio), C.c_uint32(audio.size), C.c_int(1),
+                                        C.c_float(cfo_hz), C.c_float(cfo_phase), _ptr(llr), C.c_uint32(cap),
+                                        _ptr(H.view(np.float32)), _ptr(scal))
+        assert n >= 0
+        return llr[:n].copy(), H, scal
+
+    # -------------------------------------------------------- modulator
+    def modulate_frame(self, cfg, encoded: bytes):
+        cap = 1 << 20
+        out = np.zeros(cap, np.float32)
+        pre = C.c_uint32(0)
+        n = self._fn("modulate_frame")(C.byref(cfg), encoded, C.c_uint32(len(encoded)), _ptr(out),
+                                       C.c_uint32(cap), C.byref(pre))
+        assert n > 0
+        return out[:n].copy(), pre.value
+
+    def modulate_presynced(self, cfg, encoded: bytes):
+        cap = 1 << 20
+        out = np.zeros(cap, np.float32)
+        n = self._fn("modulate_presynced")(C.byref(cfg), encoded, C.c_uint32(len(encoded)), _ptr(out), C.c_uint32(cap))
+        assert n > 0
+        return out[:n].copy()
+
+
+class Oracle(_Base):
+    prefix = "uo_"
+
+    def __init__(self):
+        build_oracle()
+        super().__init__(ORACLE_SO)
+        self.lib.uo_geometry.argtypes = [C.POINTER(Config), C.POINTER(Geometry)]
+
+    def ldpc_graph(self, rate):
+        rp = np.zeros(487, np.uint32); ci = np.zeros(4096, np.uint32)
+        k, m = C.c_uint32(0), C.c_uint32(0)
+        e = self.lib.uo_ldpc_graph(C.c_uint32(rate), _ptr(rp, C.c_uint32), _ptr(ci, C.c_uint32), C.byref(k), C.byref(m))
+        return rp[:m.value + 1].copy(), ci[:e].copy(), k.value, m.value
+
+    def channel_interleaver_perm(self, bits_per_symbol, total=648):
+        p = np.zeros(total, np.uint32); inv = np.zeros(total, np.uint32)
+        self.lib.uo_channel_interleaver_perm(C.c_uint32(bits_per_symbol), C.c_uint32(total),
+                                             _ptr(p, C.c_uint32), _ptr(inv, C.c_uint32))
+        return p, inv
+
+    def interleaver_deinterleave(self, rows, cols, x):
+        x = _f32(x); out = np.zeros_like(x)
+        self.lib.uo_interleaver_deinterleave(C.c_uint32(rows), C.c_uint32(cols), _ptr(x), C.c_uint32(x.size), _ptr(out))
+        return out
+
+    def demod_decode_batch(self, cfg, audio, cfo_hz=None, cfo_phase=None, n_threads=1, decode=True,
+                           want_llr=True, want_state=True):
+        audio = _f32(audio)
+        g = geometry(cfg)
+        audio = audio.reshape(-1, audio.shape[-1]) if audio.ndim > 1 else audio.reshape(-1, g.frame_samples)
+        n, stride = audio.shape
+        llr = np.zeros((n, g.llrs_per_frame), np.float32) if want_llr else None
+        state = np.zeros((n, 8), np.float32) if want_state else None
+        by = np.zeros((n, g.decoded_bytes), np.uint8) if decode else None
+        it = np.zeros(n, np.int32) if decode else None
+        ok = np.zeros(n, np.uint8) if decode else None
+        cfo = _f32(cfo_hz) if cfo_hz is not None else None
+        cph = _f32(cfo_phase) if cfo_phase is not None else None
+        rc = self.lib.uo_demod_decode_batch(
+            C.byref(cfg), _ptr(audio), C.c_size_t(stride), _ptr(cfo) if cfo is not None else None,
+            _ptr(cph) if cph is not None else None, C.c_size_t(n), C.c_int(n_threads),
+            _ptr(llr) if want_llr else None, _ptr(state) if want_state else None,
+            _ptr(by, C.c_uint8) if decode else None, _ptr(it, C.c_int32) if decode else None,
+            _ptr(ok, C.c_uint8) if decode else None)
+        assert rc == 0
+        return dict(llr=llr, state=state, bytes=by, iters=it, ok=ok)
+
+    def watterson(self, x, snr_db, delay_ms, doppler_hz, seed, g1=0.707, g2=0.707, fading=1, multipath=1, noise=1):
+        x = _f32(x); out = np.zeros_like(x)
+        self.lib.uo_watterson(C.c_float(snr_db), C.c_float(delay_ms), C.c_float(doppler_hz), C.c_float(g1),
+                              C.c_float(g2), C.c_int(fading), C.c_int(multipath), C.c_int(noise),
+                              C.c_uint64(seed), _ptr(x), C.c_uint32(x.size), _ptr(out))
+        return out
+
+    def make_batch(self, cfg, n, seed=0x5EED, f0=0, n_threads=None, channel="awgn", snr_db=30.0,
+                   delay_ms=0.5, doppler_hz=0.1):
+        """Synthetic frames at the configured entry point → (audio [n][frame_samples], payload [n][k//8])."""
+        g = geometry(cfg)
+        pb = g.ldpc_k // 8
+        audio = np.zeros((n, g.frame_samples), np.float32)
+        payload = np.zeros((n, pb), np.uint8)
+        kind = dict(none=0, awgn=1, watterson=2)[channel]
+        nt = n_threads or min(os.cpu_count() or 1, 16)
+        rc = self.lib.uo_make_batch(C.byref(cfg), C.c_uint64(seed), C.c_uint64(f0), C.c_uint32(n), C.c_int(nt),
+                                    C.c_int(kind), C.c_float(snr_db), C.c_float(delay_ms), C.c_float(doppler_hz),
+                                    _ptr(audio), _ptr(payload, C.c_uint8), C.c_uint32(pb))
+        assert rc == 0, rc
+        return audio, payload
+
+
+class Ref(_Base):
+    prefix = "ref_"
+
+    def __init__(self):
+        build_oracle()
+        if not REF_SO.exists():
+            raise FileNotFoundError(f"{REF_SO} not built (needs /root/reference in this container)")
+        super().__init__(REF_SO)
+
+    def watterson(self, x, snr_db, delay_ms, doppler_hz, seed, g1=0.707, g2=0.707, fading=1, multipath=1, noise=1):
+        x = _f32(x); out = np.zeros_like(x)
+        self.lib.ref_watterson(C.c_float(snr_db), C.c_float(delay_ms), C.c_float(doppler_hz), C.c_float(g1),
+                               C.c_float(g2), C.c_int(fading), C.c_int(multipath), C.c_int(noise),
+                               C.c_uint32(seed), _ptr(x), C.c_uint32(x.size), _ptr(out))
+        return out
+
+    def demod_process(self, cfg, audio, chunk=960):
+        """Full reference receive incl. Schmidl-Cox search → (llr, sync_offset, cfo_hz)."""
+        audio = _f32(audio)
+        cap = 1 << 16
+        llr = np.zeros(cap, np.float32)
+        so, cfo = C.c_uint32(0), C.c_float(0)
+        n = self.lib.ref_demod_process(C.byref(cfg), _ptr(audio), C.c_uint32(audio.size), C.c_uint32(chunk),
+                                       _ptr(llr), C.c_uint32(cap), C.byref(so), C.byref(cfo))
+        return llr[:n].copy(), so.value, cfo.value
+
+    def demod_synced_public(self, cfg, audio, cfo_hz=0.0):
+        audio = _f32(audio)
+        g = geometry(cfg)
+        nsym = audio.size // g.symbol_samples
+        cap = nsym * g.llrs_per_symbol
+        llr = np.zeros(cap, np.float32)
+        n = self.lib.ref_demod_synced_public(C.byref(cfg), _ptr(audio), C.c_uint32(nsym), C.c_float(cfo_hz),
+                                             _ptr(llr), C.c_uint32(cap))
+        assert n == cap
+        return llr
+
+    def harness_awgn(self, cfg, payload: bytes, snr_db, noise_seed):
+        cap = 1 << 20
+        out = np.zeros(cap, np.float32)
+        n = C.c_uint32(0)
+        pre = self.lib.ref_harness_awgn(C.byref(cfg), payload, C.c_uint32(len(payload)), C.c_float(snr_db),
+                                        C.c_uint32(noise_seed), _ptr(out), C.c_uint32(cap), C.byref(n))
+        assert pre > 0
+        return out[:n.value].copy(), pre
+
+    def channel_interleaver(self, bits_per_symbol, x, total=648, inverse=True):
+        x = _f32(x); out = np.zeros(total, np.float32)
+        fn = self.lib.ref_channel_interleaver_deinterleave if inverse else self.lib.ref_channel_interleaver_interleave
+        fn(C.c_uint32(bits_per_symbol), C.c_uint32(total), _ptr(x), C.c_uint32(x.size), _ptr(out))
+        return out
+
+    def interleaver_deinterleave(self, rows, cols, x):
+        x = _f32(x); out = np.zeros_like(x)
+        self.lib.ref_interleaver_deinterleave(C.c_uint32(rows), C.c_uint32(cols), _ptr(x), C.c_uint32(x.size), _ptr(out))
+        return out
+
+
+_ORACLE = None
+
+
+def oracle() -> Oracle:
+    global _ORACLE
+    if _ORACLE is None:
+        _ORACLE = Oracle()
+    return _ORACLE
+
+
+def geometry(cfg) -> Geometry:
+    g = Geometry()
+    rc = oracle().lib.uo_geometry(C.byref(cfg), C.byref(g))
+    assert rc == 0, rc
+    return g
+
+
+def have_ref() -> bool:
+    if REF_SO.exists():
+        return True
+    if REFERENCE_ROOT.is_dir():
+        try:
+            build_oracle()
+        except Exception:
+            return False
+    return REF_SO.exists()

@@ -1,0 +1,439 @@
+// oracle/ref_shim.cpp — TEST INFRASTRUCTURE, NOT PRODUCT CODE.
+//
+// Thin extern "C" shim over the *compiled reference* (secup/ProjectUltra built
+// from the sources where they lie under /root/reference by oracle/Makefile,
+// output oracle/_ref/libultra_ref.so).  It exists so the tests can
+//   (1) pin the C restatement in oracle/ultra_oracle.c stage by stage, and
+//   (2) generate the golden fixtures under tests/golden/ (tests/golden/make_golden.py).
+// Nothing here is copied from the reference: this file only *calls* it.
+// Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may load
+// the resulting library.
+//
+// Stage-level access: OFDMDemodulator::Impl is fully declared in the
+// reference's private header src/ofdm/demodulator_impl.hpp:18-168; we reach
+// impl_ by compiling this TU with `private` redefined around the public header.
+
+#include <algorithm>
+#include <atomic>
+#include <cmath>
+#include <complex>
+#include <cstdint>
+#include <cstdio>
+#include <cstring>
+#include <memory>
+#include <mutex>
+#include <random>
+#include <span>
+#include <vector>
+#include <unistd.h>
+#include <fcntl.h>
+
+#define private public
+#include "ultra/ofdm.hpp"
+#undef private
+#include "ultra/dsp.hpp"
+#include "ultra/fec.hpp"
+#include "ofdm/demodulator_impl.hpp"
+#include "sim/hf_channel.hpp"
+
+#include "../include/ultra_hip.h"
+
+using namespace ultra;
+
+namespace {
+
+ModemConfig to_cfg(const ultra_hip_config* c) {
+    ModemConfig m;
+    m.sample_rate = c->sample_rate;
+    m.center_freq = c->center_freq;
+    m.fft_size = c->fft_size;
+    m.num_carriers = c->num_carriers;
+    m.cp_mode = static_cast<CyclicPrefixMode>(c->cp_mode);
+    m.symbol_guard = c->symbol_guard;
+    m.pilot_spacing = c->pilot_spacing;
+    m.use_pilots = c->use_pilots != 0;
+    m.modulation = static_cast<Modulation>(c->modulation);
+    m.code_rate = static_cast<CodeRate>(c->code_rate);
+    return m;
+}
+
+// The reference prints unconditionally to stderr inside the hot path
+// (channel_equalizer.cpp:26-32,96-135,...).  Silence it around calls.
+struct StderrMute {
+    int saved = -1;
+    StderrMute() {
+        fflush(stderr);
+        saved = dup(2);
+        int nul = open("/dev/null", O_WRONLY);
+        if (nul >= 0) { dup2(nul, 2); close(nul); }
+    }
+    ~StderrMute() {
+        fflush(stderr);
+        if (saved >= 0) { dup2(saved, 2); close(saved); }
+    }
+};
+
+}  // namespace
+
+extern "C" {
+
+// ---------------------------------------------------------------- primitives
+
+// FFT::forward (src/dsp/fft.cpp:124-133), built-in radix-2 path.
+int ref_fft_forward(uint32_t n, const float* in_ri, float* out_ri) {
+    FFT fft(n);
+    std::vector<Complex> in(n), out;
+    for (uint32_t i = 0; i < n; ++i) in[i] = Complex(in_ri[2 * i], in_ri[2 * i + 1]);
+    fft.forward(in, out);
+    for (uint32_t i = 0; i < n; ++i) { out_ri[2 * i] = out[i].real(); out_ri[2 * i + 1] = out[i].imag(); }
+    return 0;
+}
+
+int ref_fft_inverse(uint32_t n, const float* in_ri, float* out_ri) {
+    FFT fft(n);
+    std::vector<Complex> in(n), out;
+    for (uint32_t i = 0; i < n; ++i) in[i] = Complex(in_ri[2 * i], in_ri[2 * i + 1]);
+    fft.inverse(in, out);
+    for (uint32_t i = 0; i < n; ++i) { out_ri[2 * i] = out[i].real(); out_ri[2 * i + 1] = out[i].imag(); }
+    return 0;
+}
+
+// NCO::next sequence (src/dsp/filters.cpp:228-238).
+int ref_nco(float freq, float fs, uint32_t n, float* out_ri) {
+    NCO nco(freq, fs);
+    for (uint32_t i = 0; i < n; ++i) {
+        Complex c = nco.next();
+        out_ri[2 * i] = c.real();
+        out_ri[2 * i + 1] = c.imag();
+    }
+    return 0;
+}
+
+// ---------------------------------------------------------------------- FEC
+
+// LDPCEncoder::encode (src/fec/ldpc_encoder.cpp:193-257).
+int ref_ldpc_encode(uint32_t rate, const uint8_t* data, uint32_t n, uint8_t* out, uint32_t cap) {
+    LDPCEncoder enc(static_cast<CodeRate>(rate));
+    Bytes r = enc.encode(ByteSpan(data, n));
+    if (r.size() > cap) return -1;
+    std::memcpy(out, r.data(), r.size());
+    return static_cast<int>(r.size());
+}
+
+// LDPCDecoder::decodeSoft (src/fec/ldpc_decoder.cpp:283-428).
+int ref_ldpc_decode_soft(uint32_t rate, int max_iters, const float* llr, uint32_t n_llr,
+                         uint8_t* out, uint32_t cap, int* success, int* iters) {
+    LDPCDecoder dec(static_cast<CodeRate>(rate));
+    dec.setMaxIterations(max_iters);
+    Bytes r = dec.decodeSoft(std::span<const float>(llr, n_llr));
+    if (r.size() > cap) return -1;
+    std::memcpy(out, r.data(), r.size());
+    *success = dec.lastDecodeSuccess() ? 1 : 0;
+    *iters = dec.lastIterations();
+    return static_cast<int>(r.size());
+}
+
+// Batched decode of n_cw independent 648-LLR codewords with ONE decoder
+// object (the tools hold one decoder per run; rx_pipeline.cpp:499-511 rebuilds
+// it per codeword — results are identical, H is deterministic).
+int ref_ldpc_decode_batch(uint32_t rate, int max_iters, const float* llr, uint32_t n_cw,
+                          uint8_t* out, uint32_t bytes_per_cw, int32_t* iters, uint8_t* ok) {
+    LDPCDecoder dec(static_cast<CodeRate>(rate));
+    dec.setMaxIterations(max_iters);
+    for (uint32_t c = 0; c < n_cw; ++c) {
+        Bytes r = dec.decodeSoft(std::span<const float>(llr + 648ull * c, 648));
+        if (r.size() != bytes_per_cw) return -1;
+        std::memcpy(out + (size_t)bytes_per_cw * c, r.data(), r.size());
+        iters[c] = dec.lastIterations();
+        ok[c] = dec.lastDecodeSuccess() ? 1 : 0;
+    }
+    return 0;
+}
+
+// Interleaver / ChannelInterleaver soft-bit permutations
+// (src/fec/ldpc_decoder.cpp:454-540,547-620).
+int ref_interleaver_deinterleave(uint32_t rows, uint32_t cols, const float* in, uint32_t n, float* out) {
+    Interleaver il(rows, cols);
+    auto r = il.deinterleave(std::span<const float>(in, n));
+    std::memcpy(out, r.data(), r.size() * sizeof(float));
+    return (int)r.size();
+}
+int ref_channel_interleaver_deinterleave(uint32_t bits_per_symbol, uint32_t total, const float* in,
+                                         uint32_t n, float* out) {
+    ChannelInterleaver il(bits_per_symbol, total);
+    auto r = il.deinterleave(std::span<const float>(in, n));
+    std::memcpy(out, r.data(), r.size() * sizeof(float));
+    return (int)r.size();
+}
+int ref_channel_interleaver_interleave(uint32_t bits_per_symbol, uint32_t total, const float* in,
+                                       uint32_t n, float* out) {
+    ChannelInterleaver il(bits_per_symbol, total);
+    auto r = il.interleave(std::span<const float>(in, n));
+    std::memcpy(out, r.data(), r.size() * sizeof(float));
+    return (int)r.size();
+}
+
+// ---------------------------------------------------------------- modulator
+
+// preamble + modulate(encoded) exactly as the harness does
+// (tools/test_nvis_mode.cpp:60-71).  Returns total samples; *preamble_len set.
+int ref_modulate_frame(const ultra_hip_config* c, const uint8_t* encoded, uint32_t n_enc,
+                       float* out, uint32_t cap, uint32_t* preamble_len) {
+    StderrMute mute;
+    ModemConfig cfg = to_cfg(c);
+    OFDMModulator mod(cfg);
+    Samples pre = mod.generatePreamble();
+    Samples dat = mod.modulate(ByteSpan(encoded, n_enc), cfg.modulation);
+    if (pre.size() + dat.size() > cap) return -1;
+    std::memcpy(out, pre.data(), pre.size() * sizeof(float));
+    std::memcpy(out + pre.size(), dat.data(), dat.size() * sizeof(float));
+    *preamble_len = (uint32_t)pre.size();
+    return (int)(pre.size() + dat.size());
+}
+
+// generateTrainingSymbols(count) + modulate(encoded) — the chirp-synced TX
+// order (src/ofdm/modulator.cpp:534-580, ofdm_chirp_waveform.cpp).
+int ref_modulate_presynced(const ultra_hip_config* c, const uint8_t* encoded, uint32_t n_enc,
+                           float* out, uint32_t cap) {
+    StderrMute mute;
+    ModemConfig cfg = to_cfg(c);
+    OFDMModulator mod(cfg);
+    Samples tr = mod.generateTrainingSymbols((int)c->training_symbols);
+    Samples dat = mod.modulate(ByteSpan(encoded, n_enc), cfg.modulation);
+    if (tr.size() + dat.size() > cap) return -1;
+    std::memcpy(out, tr.data(), tr.size() * sizeof(float));
+    std::memcpy(out + tr.size(), dat.data(), dat.size() * sizeof(float));
+    return (int)(tr.size() + dat.size());
+}
+
+// ------------------------------------------------------------------ channel
+
+// WattersonChannel::process (src/sim/hf_channel.hpp:106-168).
+int ref_watterson(float snr_db, float delay_ms, float doppler_hz, float g1, float g2,
+                  int fading, int multipath, int noise, uint32_t seed,
+                  const float* in, uint32_t n, float* out) {
+    sim::WattersonChannel::Config cc;
+    cc.snr_db = snr_db;
+    cc.delay_spread_ms = delay_ms;
+    cc.doppler_spread_hz = doppler_hz;
+    cc.path1_gain = g1;
+    cc.path2_gain = g2;
+    cc.sample_rate = 48000;
+    cc.fading_enabled = fading != 0;
+    cc.multipath_enabled = multipath != 0;
+    cc.noise_enabled = noise != 0;
+    sim::WattersonChannel ch(cc, seed);
+    Samples r = ch.process(SampleSpan(in, n));
+    std::memcpy(out, r.data(), n * sizeof(float));
+    return 0;
+}
+
+// -------------------------------------------------------------- demodulator
+
+// Full reference receive: fresh demodulator, feed `chunk`-sample pieces
+// through OFDMDemodulator::process (Schmidl-Cox search + SYNCED loop), then
+// getSoftBits() once (tools/test_nvis_mode.cpp:88-101).
+int ref_demod_process(const ultra_hip_config* c, const float* audio, uint32_t n, uint32_t chunk,
+                      float* llr_out, uint32_t cap, uint32_t* sync_offset, float* cfo_hz) {
+    StderrMute mute;
+    ModemConfig cfg = to_cfg(c);
+    OFDMDemodulator demod(cfg);
+    for (uint32_t i = 0; i < n; i += chunk) {
+        uint32_t len = std::min(chunk, n - i);
+        demod.process(SampleSpan(audio + i, len));
+    }
+    if (sync_offset) *sync_offset = (uint32_t)demod.getLastSyncOffset();
+    if (cfo_hz) *cfo_hz = demod.getFrequencyOffset();
+    // all soft bits accumulated (not only the first 648) — callers slice
+    auto& sb = demod.impl_->soft_bits;
+    uint32_t m = (uint32_t)std::min<size_t>(sb.size(), cap);
+    std::memcpy(llr_out, sb.data(), m * sizeof(float));
+    return (int)sb.size();
+}
+
+// Per-symbol stage dump layout (floats), see ref_demod_synced:
+//   bb      [symbol_samples][2]
+//   freq    [fft][2]
+//   H       [fft][2]   channel_estimate after updateChannelEstimate
+//   eq      [n_data][2]
+//   nv      [n_data]   carrier_noise_var
+//   scal    [8]        freq_offset_hz, noise_variance, estimated_snr_linear,
+//                      timing_offset_samples, freq_correction_phase,
+//                      pilot_phase_correction.re/.im, snr_symbol_count
+
+// SYNCED-entry symbol loop driven stage by stage on a freshly constructed
+// demodulator put into the state process() leaves it in on sync
+// (src/ofdm/demodulator.cpp:533-591): freq_offset_hz=filtered=cfo,
+// freq_correction_phase=0, symbols_since_sync=0, mixer.reset(), state=SYNCED.
+// The loop body is the reference's own (demodulator.cpp:672-697), calling the
+// reference's Impl member functions.
+int ref_demod_synced(const ultra_hip_config* c, const float* audio, uint32_t n_symbols, float cfo_hz,
+                     float* llr_out, uint32_t llr_cap, float* stage_out /*nullable*/) {
+    StderrMute mute;
+    ModemConfig cfg = to_cfg(c);
+    OFDMDemodulator demod(cfg);
+    auto* im = demod.impl_.get();
+    im->freq_offset_hz = cfo_hz;
+    im->freq_offset_filtered = cfo_hz;
+    im->freq_correction_phase = 0.0f;
+    im->symbols_since_sync = 0;
+    im->state.store(OFDMDemodulator::Impl::State::SYNCED);
+    im->synced_symbol_count.store(0);
+    im->mixer.reset();
+    im->dbpsk_prev_equalized.clear();
+    im->carrier_phase_initialized = false;
+    im->carrier_phase_correction = Complex(1, 0);
+    im->dqpsk_skip_first_symbol = false;
+    im->timing_offset_samples = 0.0f;
+
+    const size_t S = im->symbol_samples;
+    const size_t N = cfg.fft_size;
+    const size_t nd = im->data_carrier_indices.size();
+    float* st = stage_out;
+    for (uint32_t s = 0; s < n_symbols; ++s) {
+        SampleSpan sym(audio + (size_t)s * S, S);
+        auto bb = im->toBaseband(sym);
+        auto fd = im->extractSymbol(bb, 0);
+        im->updateChannelEstimate(fd);
+        auto eq = im->equalize(fd);
+        im->demodulateSymbol(eq, cfg.modulation);
+        if (st) {
+            for (size_t i = 0; i < S; ++i) { *st++ = bb[i].real(); *st++ = bb[i].imag(); }
+            for (size_t i = 0; i < N; ++i) { *st++ = fd[i].real(); *st++ = fd[i].imag(); }
+            for (size_t i = 0; i < N; ++i) { *st++ = im->channel_estimate[i].real(); *st++ = im->channel_estimate[i].imag(); }
+            for (size_t i = 0; i < nd; ++i) { *st++ = eq[i].real(); *st++ = eq[i].imag(); }
+            for (size_t i = 0; i < nd; ++i) *st++ = im->carrier_noise_var[i];
+            *st++ = im->freq_offset_hz;
+            *st++ = im->noise_variance;
+            *st++ = im->estimated_snr_linear;
+            *st++ = im->timing_offset_samples;
+            *st++ = im->freq_correction_phase;
+            *st++ = im->pilot_phase_correction.real();
+            *st++ = im->pilot_phase_correction.imag();
+            *st++ = (float)im->snr_symbol_count;
+        }
+    }
+    auto& sb = im->soft_bits;
+    uint32_t m = (uint32_t)std::min<size_t>(sb.size(), llr_cap);
+    std::memcpy(llr_out, sb.data(), m * sizeof(float));
+    return (int)sb.size();
+}
+
+// Same entry but through the public API only: state forced to SYNCED, then
+// ONE process() call with all data symbols (cross-check of the stage driver).
+int ref_demod_synced_public(const ultra_hip_config* c, const float* audio, uint32_t n_symbols,
+                            float cfo_hz, float* llr_out, uint32_t llr_cap) {
+    StderrMute mute;
+    ModemConfig cfg = to_cfg(c);
+    OFDMDemodulator demod(cfg);
+    auto* im = demod.impl_.get();
+    im->freq_offset_hz = cfo_hz;
+    im->freq_offset_filtered = cfo_hz;
+    im->state.store(OFDMDemodulator::Impl::State::SYNCED);
+    demod.process(SampleSpan(audio, (size_t)n_symbols * im->symbol_samples));
+    auto& sb = im->soft_bits;
+    uint32_t m = (uint32_t)std::min<size_t>(sb.size(), llr_cap);
+    std::memcpy(llr_out, sb.data(), m * sizeof(float));
+    return (int)sb.size();
+}
+
+// OFDMDemodulator::processPresynced (src/ofdm/demodulator.cpp:854-985) after
+// setFrequencyOffsetWithPhase (:816-825) when has_cfo != 0.
+int ref_demod_presynced(const ultra_hip_config* c, const float* audio, uint32_t n_samples,
+                        int has_cfo, float cfo_hz, float cfo_phase,
+                        float* llr_out, uint32_t llr_cap, float* H_out /*[fft][2] nullable*/,
+                        float* scal_out /*[8] nullable*/) {
+    StderrMute mute;
+    ModemConfig cfg = to_cfg(c);
+    OFDMDemodulator demod(cfg);
+    if (has_cfo) demod.setFrequencyOffsetWithPhase(cfo_hz, cfo_phase);
+    demod.processPresynced(SampleSpan(audio, n_samples), (int)c->training_symbols);
+    auto* im = demod.impl_.get();
+    if (H_out) {
+        for (size_t i = 0; i < cfg.fft_size; ++i) {
+            H_out[2 * i] = im->channel_estimate[i].real();
+            H_out[2 * i + 1] = im->channel_estimate[i].imag();
+        }
+    }
+    if (scal_out) {
+        scal_out[0] = im->freq_offset_hz;
+        scal_out[1] = im->noise_variance;
+        scal_out[2] = im->estimated_snr_linear;
+        scal_out[3] = im->timing_offset_samples;
+        scal_out[4] = im->freq_correction_phase;
+        scal_out[5] = im->pilot_phase_correction.real();
+        scal_out[6] = im->pilot_phase_correction.imag();
+        scal_out[7] = (float)im->snr_symbol_count;
+    }
+    auto& sb = im->soft_bits;
+    uint32_t m = (uint32_t)std::min<size_t>(sb.size(), llr_cap);
+    std::memcpy(llr_out, sb.data(), m * sizeof(float));
+    return (int)sb.size();
+}
+
+// Constant tables of a constructed demodulator (carrier map, pilot signs,
+// interpolation table, Zadoff-Chu) for pinning the restated constructors.
+int ref_demod_tables(const ultra_hip_config* c, int32_t* data_idx, int32_t* pilot_idx,
+                     float* pilot_seq_ri, int32_t* interp_i /*[nd][3]*/, float* interp_alpha,
+                     float* sync_seq_ri, uint32_t* counts /*[4]: nd, np, n_interp, n_sync*/) {
+    StderrMute mute;
+    ModemConfig cfg = to_cfg(c);
+    OFDMDemodulator demod(cfg);
+    auto* im = demod.impl_.get();
+    counts[0] = (uint32_t)im->data_carrier_indices.size();
+    counts[1] = (uint32_t)im->pilot_carrier_indices.size();
+    counts[2] = (uint32_t)im->interp_table.size();
+    counts[3] = (uint32_t)im->sync_sequence.size();
+    for (size_t i = 0; i < counts[0]; ++i) data_idx[i] = im->data_carrier_indices[i];
+    for (size_t i = 0; i < counts[1]; ++i) {
+        pilot_idx[i] = im->pilot_carrier_indices[i];
+        pilot_seq_ri[2 * i] = im->pilot_sequence[i].real();
+        pilot_seq_ri[2 * i + 1] = im->pilot_sequence[i].imag();
+    }
+    for (size_t i = 0; i < counts[2]; ++i) {
+        interp_i[3 * i] = im->interp_table[i].fft_idx;
+        interp_i[3 * i + 1] = im->interp_table[i].lower_pilot;
+        interp_i[3 * i + 2] = im->interp_table[i].upper_pilot;
+        interp_alpha[i] = im->interp_table[i].alpha;
+    }
+    for (size_t i = 0; i < counts[3]; ++i) {
+        sync_seq_ri[2 * i] = im->sync_sequence[i].real();
+        sync_seq_ri[2 * i + 1] = im->sync_sequence[i].imag();
+    }
+    return 0;
+}
+
+// End-to-end harness body of tools/test_nvis_mode.cpp:35-114 restated as
+// calls (payload in → ok/iters/decoded out), AWGN drawn exactly as there.
+int ref_harness_awgn(const ultra_hip_config* c, const uint8_t* payload, uint32_t n_payload,
+                     float snr_db, uint32_t noise_seed, float* audio_out, uint32_t cap,
+                     uint32_t* n_audio) {
+    StderrMute mute;
+    ModemConfig cfg = to_cfg(c);
+    OFDMModulator mod(cfg);
+    LDPCEncoder enc(cfg.code_rate);
+    Bytes encoded = enc.encode(ByteSpan(payload, n_payload));
+    Samples pre = mod.generatePreamble();
+    Samples dat = mod.modulate(encoded, cfg.modulation);
+    Samples signal;
+    signal.insert(signal.end(), pre.begin(), pre.end());
+    signal.insert(signal.end(), dat.begin(), dat.end());
+    float max_val = 0;
+    for (float s : signal) max_val = std::max(max_val, std::abs(s));
+    for (float& s : signal) s *= 0.5f / max_val;
+    if (snr_db < 100.0f) {
+        std::mt19937 rng(noise_seed);
+        float sp = 0;
+        for (float s : signal) sp += s * s;
+        sp /= signal.size();
+        float noise_std = std::sqrt(sp / std::pow(10.0f, snr_db / 10.0f));
+        std::normal_distribution<float> noise(0.0f, noise_std);
+        for (float& s : signal) s += noise(rng);
+    }
+    if (signal.size() > cap) return -1;
+    std::memcpy(audio_out, signal.data(), signal.size() * sizeof(float));
+    *n_audio = (uint32_t)signal.size();
+    return (int)pre.size();
+}
+
+}  // extern "C"
