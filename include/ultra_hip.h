@@ -255,6 +255,13 @@ int ultra_hip_memcpy_h2d(ultra_hip_ctx* ctx, void* d_dst, const void* h_src, siz
 int ultra_hip_memcpy_d2h(ultra_hip_ctx* ctx, void* h_dst, const void* d_src, size_t bytes);
 int ultra_hip_memset(ultra_hip_ctx* ctx, void* d_dst, int value, size_t bytes);
 
+/* Device self-test of the pinned libm restatement (projectultra_amd/csrc/
+ * pinned_math.h): out[i] = fn(a[i] [, b[i]]) evaluated on the GPU, so tests
+ * can compare with the host libm the reference calls.
+ * fn: 0 sinf, 1 cosf, 2 atanf, 3 atan2f(a, b), 4 hypotf(a, b). */
+int ultra_hip_selftest_math(ultra_hip_ctx* ctx, int fn, const float* d_a, const float* d_b,
+                            float* d_out, size_t n);
+
 #ifdef __cplusplus
 }
 #endif

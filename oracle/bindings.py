@@ -319,6 +319,18 @@ class Ref(_Base):
                                        _ptr(llr), C.c_uint32(cap), C.byref(so), C.byref(cfo))
         return llr[:n].copy(), so.value, cfo.value
 
+    def demod_process_coarse(self, cfg, audio, chunk=960):
+        """Full reference receive → (llr, sync_offset, coarse_cfo, final_cfo, fed_at_sync)."""
+        audio = _f32(audio)
+        cap = 1 << 16
+        llr = np.zeros(cap, np.float32)
+        so, fs = C.c_uint32(0), C.c_uint32(0)
+        cc, fc = C.c_float(0), C.c_float(0)
+        n = self.lib.ref_demod_process_coarse(C.byref(cfg), _ptr(audio), C.c_uint32(audio.size), C.c_uint32(chunk),
+                                              _ptr(llr), C.c_uint32(cap), C.byref(so), C.byref(cc), C.byref(fc),
+                                              C.byref(fs))
+        return llr[:n].copy(), so.value, cc.value, fc.value, fs.value
+
     def demod_synced_public(self, cfg, audio, cfo_hz=0.0):
         audio = _f32(audio)
         g = geometry(cfg)

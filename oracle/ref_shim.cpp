@@ -251,6 +251,40 @@ int ref_demod_process(const ultra_hip_config* c, const float* audio, uint32_t n,
     return (int)sb.size();
 }
 
+// As ref_demod_process, and additionally recovers the COARSE CFO the search stage set on
+// the sync transition (demodulator.cpp:533-537).  getFrequencyOffset() after the run is the
+// tracked value; the coarse one is a pure function of the buffered audio at the moment of
+// sync (estimateCoarseCFO, ofdm_sync.cpp:229-261) — the buffer is untrimmed for frames this
+// short — so it is re-evaluated on a second demodulator holding the same samples.
+int ref_demod_process_coarse(const ultra_hip_config* c, const float* audio, uint32_t n, uint32_t chunk,
+                             float* llr_out, uint32_t cap, uint32_t* sync_offset, float* coarse_cfo,
+                             float* final_cfo, uint32_t* fed_at_sync) {
+    StderrMute mute;
+    ModemConfig cfg = to_cfg(c);
+    OFDMDemodulator demod(cfg);
+    uint32_t fed = 0, fed_sync = 0;
+    bool was = false;
+    for (uint32_t i = 0; i < n; i += chunk) {
+        uint32_t len = std::min(chunk, n - i);
+        demod.process(SampleSpan(audio + i, len));
+        fed = i + len;
+        if (!was && demod.isSynced()) { was = true; fed_sync = fed; }
+    }
+    *sync_offset = (uint32_t)demod.getLastSyncOffset();
+    *final_cfo = demod.getFrequencyOffset();
+    *fed_at_sync = fed_sync;
+    *coarse_cfo = 0.0f;
+    if (was) {
+        OFDMDemodulator probe(cfg);
+        probe.impl_->rx_buffer.assign(audio, audio + fed_sync);
+        *coarse_cfo = probe.impl_->estimateCoarseCFO(*sync_offset);
+    }
+    auto& sb = demod.impl_->soft_bits;
+    uint32_t m = (uint32_t)std::min<size_t>(sb.size(), cap);
+    std::memcpy(llr_out, sb.data(), m * sizeof(float));
+    return (int)sb.size();
+}
+
 // Per-symbol stage dump layout (floats), see ref_demod_synced:
 //   bb      [symbol_samples][2]
 //   freq    [fft][2]

@@ -1615,16 +1615,22 @@ static void* mk_worker(void* arg) {
     const ultra_hip_config* c = j->c;
     ultra_hip_geometry g;
     if (uo_geometry(c, &g) != 0) { j->rc = -1; return NULL; }
-    uint32_t cap = (7 + c->n_data_symbols + c->training_symbols + 2) * (g.symbol_samples + 64);
+    /* enough codewords to fill n_data_symbols; payload_out keeps the FIRST codeword's payload */
+    uint32_t ncw = (g.llrs_per_frame + LDPC_N - 1) / LDPC_N;
+    uint32_t tx_symbols = (ncw * LDPC_N + 7 + g.llrs_per_symbol - 1) / g.llrs_per_symbol + 1;
+    uint32_t cap = (8 + c->training_symbols + tx_symbols) * (g.symbol_samples + 64);
     float* sig = (float*)malloc(sizeof(float) * cap);
     float* chan = (float*)malloc(sizeof(float) * cap);
-    uint8_t enc[512];
+    uint32_t nraw = ncw * j->payload_bytes;
+    uint8_t* raw = (uint8_t*)malloc(nraw);
+    uint8_t* enc = (uint8_t*)malloc((size_t)(ncw + 1) * 96);
     for (uint32_t q = j->n0; q < j->n1; ++q) {
         uint64_t f = j->f0 + q;
         uint8_t* pl = j->payload_out + (size_t)q * j->payload_bytes;
         uint64_t s = (j->seed ^ f) * 0xD1342543DE82EF95ull + 0x5EEDull;
-        for (uint32_t b = 0; b < j->payload_bytes; ++b) pl[b] = (uint8_t)(splitmix64(&s) >> 56);
-        int ne = uo_ldpc_encode(c->code_rate, pl, j->payload_bytes, enc, sizeof(enc));
+        for (uint32_t b = 0; b < nraw; ++b) raw[b] = (uint8_t)(splitmix64(&s) >> 56);
+        memcpy(pl, raw, j->payload_bytes);
+        int ne = uo_ldpc_encode(c->code_rate, raw, nraw, enc, (ncw + 1) * 96);
         if (ne <= 0) { j->rc = -1; break; }
         uint32_t pre = 0; int total;
         if (c->entry == ULTRA_ENTRY_PRESYNCED) { total = uo_modulate_presynced(c, enc, (uint32_t)ne, sig, cap); pre = 0; }
@@ -1648,7 +1654,7 @@ static void* mk_worker(void* arg) {
         }
         memcpy(j->audio_out + (size_t)q * g.frame_samples, src + pre, sizeof(float) * g.frame_samples);
     }
-    free(sig); free(chan);
+    free(sig); free(chan); free(raw); free(enc);
     return NULL;
 }
 

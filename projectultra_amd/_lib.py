@@ -1,0 +1,115 @@
+"""ctypes binding of the C-ABI in include/ultra_hip.h (libultra_hip.so).
+
+The library holds the hand-written gfx950 kernels; there is NO CPU fallback.
+If the shared object is missing this module raises at import of the symbols —
+the product path fails loudly instead of silently computing somewhere else.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import subprocess
+from pathlib import Path
+
+PKG_DIR = Path(__file__).resolve().parent
+LIB_PATH = PKG_DIR / "libultra_hip.so"
+CSRC_DIR = PKG_DIR / "csrc"
+
+ULTRA_HIP_ABI_VERSION = 1
+STATE_FLOATS = 8
+
+
+class UltraHipError(RuntimeError):
+    def __init__(self, status: int, what: str):
+        self.status = status
+        super().__init__(f"{what}: {status_text(status)} (status {status})")
+
+
+class ultra_hip_config(C.Structure):
+    """POD mirror of the ModemConfig fields the path reads (include/ultra_hip.h)."""
+    _fields_ = [(n, C.c_uint32) for n in (
+        "sample_rate", "center_freq", "fft_size", "num_carriers", "cp_mode", "symbol_guard",
+        "pilot_spacing", "use_pilots", "modulation", "code_rate", "max_iterations",
+        "n_data_symbols", "entry", "training_symbols")]
+
+
+class ultra_hip_geometry(C.Structure):
+    _fields_ = [(n, C.c_uint32) for n in (
+        "cp_len", "symbol_samples", "frame_samples", "n_data_carriers", "n_pilot_carriers",
+        "bits_per_carrier", "llrs_per_symbol", "llrs_per_frame", "ldpc_n", "ldpc_k", "ldpc_m",
+        "ldpc_edges", "decoded_bytes")]
+
+
+class ultra_hip_counters(C.Structure):
+    _fields_ = [(n, C.c_uint64) for n in (
+        "frames", "frame_errors", "bit_errors", "info_bits", "ldpc_fail", "iters_sum",
+        "undetected_errors", "reserved")]
+
+
+COUNTER_NAMES = tuple(n for n, _ in ultra_hip_counters._fields_)
+
+_vp, _sz, _i, _u32p = C.c_void_p, C.c_size_t, C.c_int, C.POINTER(C.c_uint32)
+_cfgp, _geop = C.POINTER(ultra_hip_config), C.POINTER(ultra_hip_geometry)
+
+# name -> (restype, argtypes); exactly the prototypes of include/ultra_hip.h
+PROTOTYPES = {
+    "ultra_hip_abi_version": (_i, []),
+    "ultra_hip_strerror": (C.c_char_p, [_i]),
+    "ultra_hip_device_count": (_i, []),
+    "ultra_hip_geometry_for": (_i, [_cfgp, _geop]),
+    "ultra_hip_create": (_i, [_cfgp, _i, _vp, C.POINTER(_vp)]),
+    "ultra_hip_destroy": (None, [_vp]),
+    "ultra_hip_get_geometry": (_i, [_vp, _geop]),
+    "ultra_hip_get_tanner_graph": (_i, [_vp, _u32p, _u32p]),
+    "ultra_hip_ldpc_decode_batch": (_i, [_vp, _vp, _sz, _vp, _vp, _vp, _vp]),
+    "ultra_hip_demod_batch": (_i, [_vp, _vp, _sz, _vp, _vp, _sz, _vp, _vp]),
+    "ultra_hip_demod_decode_batch": (_i, [_vp, _vp, _sz, _vp, _vp, _sz, _vp, _vp, _vp, _vp]),
+    "ultra_hip_count_errors": (_i, [_vp, _vp, _vp, _vp, _vp, _sz, _sz, _vp]),
+    "ultra_hip_synchronize": (_i, [_vp]),
+    "ultra_hip_timer_begin": (_i, [_vp]),
+    "ultra_hip_timer_end": (_i, [_vp, C.POINTER(C.c_float)]),
+    "ultra_hip_malloc": (_i, [_vp, _sz, C.POINTER(_vp)]),
+    "ultra_hip_free": (_i, [_vp, _vp]),
+    "ultra_hip_memcpy_h2d": (_i, [_vp, _vp, _vp, _sz]),
+    "ultra_hip_memcpy_d2h": (_i, [_vp, _vp, _vp, _sz]),
+    "ultra_hip_memset": (_i, [_vp, _vp, _i, _sz]),
+    "ultra_hip_selftest_math": (_i, [_vp, _i, _vp, _vp, _vp, _sz]),
+}
+
+_LIB = None
+
+
+def build(force: bool = False) -> Path:
+    """Compile libultra_hip.so for gfx950 in-tree (hipcc cross-compiles without a GPU)."""
+    srcs = [CSRC_DIR / n for n in ("ultra_hip.hip", "demod_kernel.h", "ldpc_kernel.h", "pinned_math.h",
+                                   "host_tables.h", "device_types.h")] + [PKG_DIR.parent / "include" / "ultra_hip.h"]
+    stale = (not LIB_PATH.exists()) or any(s.stat().st_mtime > LIB_PATH.stat().st_mtime for s in srcs)
+    if force or stale:
+        subprocess.check_call(["make", "-C", str(CSRC_DIR)] + (["-B"] if force else []))
+    return LIB_PATH
+
+
+def lib() -> C.CDLL:
+    global _LIB
+    if _LIB is None:
+        if not LIB_PATH.exists():
+            raise ImportError(
+                f"{LIB_PATH} is missing: the HIP extension is the product path and there is no CPU "
+                f"fallback. Build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+                f"or `make -C {CSRC_DIR}`.")
+        handle = C.CDLL(str(LIB_PATH))
+        for name, (res, args) in PROTOTYPES.items():
+            fn = getattr(handle, name)   # AttributeError if the .so lacks a declared symbol
+            fn.restype, fn.argtypes = res, args
+        if handle.ultra_hip_abi_version() != ULTRA_HIP_ABI_VERSION:
+            raise ImportError("libultra_hip.so ABI version mismatch")
+        _LIB = handle
+    return _LIB
+
+
+def status_text(status: int) -> str:
+    return lib().ultra_hip_strerror(status).decode()
+
+
+def check(status: int, what: str) -> None:
+    if status != 0:
+        raise UltraHipError(status, what)

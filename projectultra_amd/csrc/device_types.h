@@ -1,0 +1,57 @@
+// device_types.h — PODs shared by the host table builder and the HIP kernels.
+#ifndef ULTRA_DEVICE_TYPES_H
+#define ULTRA_DEVICE_TYPES_H
+
+#include <stdint.h>
+
+namespace ultra_hip {
+
+constexpr int kMaxCarriers = 64;   // num_carriers <= 64 (reference presets use 30 / 59)
+constexpr int kMaxFft = 1024;
+constexpr int kLdpcN = 648;        // LDPC block length (src/fec/ldpc_decoder.cpp:12-14)
+constexpr int kLdpcMaxEdges = 2560;  // R1/4 has 2437 edges
+constexpr int kLdpcMaxChecks = 486;
+
+struct c32 { float re, im; };
+
+// Per-configuration demodulator constants.  One copy in HBM per context; every
+// field is read with wave-uniform addresses (scalar loads) except the tables
+// indexed by lane.  "slot" = position of a carrier in the reference's layout
+// loop (src/ofdm/demodulator.cpp:46-69): slot 0 is k=-neg_limit, DC skipped.
+struct DemodConst {
+    int32_t fft, log2_fft, cp, sym_len;
+    int32_t n_train, n_data_sym, n_carriers, n_data, n_pilot, n_interp;
+    int32_t modulation, bits, differential, presynced;
+    int32_t llrs_per_symbol, llrs_per_frame, frame_samples, _pad0;
+    float ce_margin;            // soft_demap::getCEErrorMargin(mod)
+    float sample_rate;          // (float) config.sample_rate
+    float symbol_duration;      // (float)getSymbolDuration() / (float)sample_rate
+    float max_timing;           // 50.0f * (fft_size / 512.0f)
+    float fft_f;                // (float) fft_size
+    float mixer_phase_end;      // NCO::phase_ after a whole frame
+    double two_pi_symbol_duration;  // 2.0f * M_PI * symbol_duration (double)
+    int16_t bin[kMaxCarriers];        // slot -> fft bin
+    int16_t k_of[kMaxCarriers];       // slot -> signed carrier number (k > fft/2 -> k - fft)
+    int16_t data_slot[kMaxCarriers];  // data carrier i -> slot
+    int16_t pilot_slot[kMaxCarriers]; // pilot i -> slot
+    int16_t interp_slot[kMaxCarriers];
+    int16_t interp_lo[kMaxCarriers];  // slot of lower pilot or -1
+    int16_t interp_hi[kMaxCarriers];
+    float interp_alpha[kMaxCarriers];
+    c32 pilot_seq[kMaxCarriers];      // +-1 + 0j
+    c32 sync_seq[kMaxCarriers];       // Zadoff-Chu
+};
+
+// Per-rate Tanner graph, CSR by check (row-major edge order of H_rows) and CSR
+// by variable (edges of a variable in ascending check order — the order
+// llr_total accumulates in, src/fec/ldpc_decoder.cpp:206-213).
+struct LdpcConst {
+    int32_t k, m, n, edges, max_iterations, decoded_bytes, _pad[2];
+    uint16_t row_ptr[kLdpcMaxChecks + 2];
+    uint16_t col[kLdpcMaxEdges];
+    uint16_t var_ptr[kLdpcN + 2];
+    uint16_t var_edge[kLdpcMaxEdges];
+};
+
+}  // namespace ultra_hip
+#endif

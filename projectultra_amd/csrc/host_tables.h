@@ -1,0 +1,264 @@
+// host_tables.h — host-side construction of the per-configuration constant
+// tables, done once per context exactly as the reference's constructors do it
+// (same RNG walks, same float/double promotions, same libm calls on the host).
+//
+//   NCO sequence          src/dsp/filters.cpp:228-238   (NCO::NCO, NCO::next)
+//   FFT twiddles          src/dsp/fft.cpp:75-82
+//   carrier layout        src/ofdm/demodulator.cpp:46-69 (setupCarriers)
+//   Zadoff-Chu + pilots   src/ofdm/demodulator.cpp:71-85 (generateSequences)
+//   interpolation table   src/ofdm/demodulator.cpp:137-193 (buildInterpTable)
+//   Tanner graph          src/fec/ldpc_decoder.cpp:64-137 (buildMatrix)
+#ifndef ULTRA_HOST_TABLES_H
+#define ULTRA_HOST_TABLES_H
+
+#include <algorithm>
+#include <cmath>
+#include <cstdint>
+#include <random>
+#include <vector>
+
+#include "../../include/ultra_hip.h"
+#include "device_types.h"
+
+namespace ultra_hip {
+
+inline uint32_t bits_per_symbol(uint32_t mod) {  // include/ultra/types.hpp:42-56
+    switch (mod) {
+        case ULTRA_MOD_DBPSK: case ULTRA_MOD_BPSK: return 1;
+        case ULTRA_MOD_DQPSK: case ULTRA_MOD_QPSK: return 2;
+        case ULTRA_MOD_D8PSK: case ULTRA_MOD_QAM8: return 3;
+        case ULTRA_MOD_QAM16: return 4;
+        case ULTRA_MOD_QAM32: return 5;
+        case ULTRA_MOD_QAM64: return 6;
+        case ULTRA_MOD_QAM256: return 8;
+        default: return 1;
+    }
+}
+
+inline uint32_t cyclic_prefix(const ultra_hip_config& c) {  // include/ultra/types.hpp:197-208
+    uint32_t base = 48;
+    if (c.cp_mode == ULTRA_CP_SHORT) base = 32;
+    else if (c.cp_mode == ULTRA_CP_LONG) base = 64;
+    return base * (c.fft_size / 512);
+}
+
+inline void code_params(uint32_t rate, int& k, int& m) {  // src/fec/ldpc_decoder.cpp:22-36
+    switch (rate) {
+        case ULTRA_RATE_R1_4: k = 162; m = 486; break;
+        case ULTRA_RATE_R2_3: k = 432; m = 216; break;
+        case ULTRA_RATE_R3_4: k = 486; m = 162; break;
+        case ULTRA_RATE_R5_6: k = 540; m = 108; break;
+        case ULTRA_RATE_R1_2:
+        default: k = 324; m = 324; break;
+    }
+}
+
+inline float ce_margin(uint32_t mod) {  // src/ofdm/soft_demap.hpp:243-264
+    switch (mod) {
+        case ULTRA_MOD_D8PSK: case ULTRA_MOD_QAM8: return 1.1f;
+        case ULTRA_MOD_QAM16: return 1.2f;
+        case ULTRA_MOD_QAM32: return 1.5f;
+        case ULTRA_MOD_QAM64: return 1.8f;
+        case ULTRA_MOD_QAM256: return 2.5f;
+        default: return 1.0f;
+    }
+}
+
+inline bool known_modulation(uint32_t mod) {
+    switch (mod) {
+        case ULTRA_MOD_DBPSK: case ULTRA_MOD_BPSK: case ULTRA_MOD_DQPSK: case ULTRA_MOD_QPSK:
+        case ULTRA_MOD_D8PSK: case ULTRA_MOD_QAM8: case ULTRA_MOD_QAM16: case ULTRA_MOD_QAM32:
+        case ULTRA_MOD_QAM64: case ULTRA_MOD_QAM256: return true;
+        default: return false;
+    }
+}
+
+// Validate the configuration against what the path was built for.
+inline int validate_config(const ultra_hip_config& c) {
+    if (c.fft_size != 512 && c.fft_size != 1024) return ULTRA_HIP_ERR_UNSUPPORTED;
+    if (c.num_carriers == 0 || c.num_carriers > (uint32_t)kMaxCarriers) return ULTRA_HIP_ERR_UNSUPPORTED;
+    if (c.num_carriers + 1 >= c.fft_size) return ULTRA_HIP_ERR_INVALID_ARG;
+    if (c.pilot_spacing == 0 || c.sample_rate == 0) return ULTRA_HIP_ERR_INVALID_ARG;
+    if (c.cp_mode > ULTRA_CP_LONG || c.use_pilots > 1) return ULTRA_HIP_ERR_INVALID_ARG;
+    if (!known_modulation(c.modulation)) return ULTRA_HIP_ERR_INVALID_ARG;
+    // QAM8 has no mapper/demapper of its own in the reference (falls through to QPSK with a
+    // 3-bit carrier budget: modulator.cpp:104-107, demodulator.cpp:352-356) — not a usable mode
+    if (c.modulation == ULTRA_MOD_QAM8) return ULTRA_HIP_ERR_UNSUPPORTED;
+    if (c.fft_size + 64 * (c.fft_size / 512) + c.symbol_guard > 1280) return ULTRA_HIP_ERR_UNSUPPORTED;
+    if (c.code_rate > ULTRA_RATE_R5_6) return ULTRA_HIP_ERR_UNSUPPORTED;  // R7/8 has no code in the reference either
+    if (c.entry > ULTRA_ENTRY_PRESYNCED) return ULTRA_HIP_ERR_INVALID_ARG;
+    if (c.n_data_symbols == 0 || c.n_data_symbols > 250) return ULTRA_HIP_ERR_INVALID_ARG;  // MAX_SYMBOLS_BEFORE_TIMEOUT
+    if (c.entry == ULTRA_ENTRY_PRESYNCED && c.training_symbols > 8) return ULTRA_HIP_ERR_INVALID_ARG;
+    if (c.max_iterations > 1000) return ULTRA_HIP_ERR_INVALID_ARG;
+    return ULTRA_HIP_OK;
+}
+
+inline int fill_geometry(const ultra_hip_config& c, ultra_hip_geometry& g) {
+    int rc = validate_config(c);
+    if (rc != ULTRA_HIP_OK) return rc;
+    int k, m;
+    code_params(c.code_rate, k, m);
+    g.cp_len = cyclic_prefix(c);
+    g.symbol_samples = c.fft_size + g.cp_len + c.symbol_guard;
+    uint32_t tr = (c.entry == ULTRA_ENTRY_PRESYNCED) ? c.training_symbols : 0;
+    g.frame_samples = (tr + c.n_data_symbols) * g.symbol_samples;
+    uint32_t n_pilot = c.use_pilots ? (c.num_carriers + c.pilot_spacing - 1) / c.pilot_spacing : 0;
+    g.n_pilot_carriers = n_pilot;
+    g.n_data_carriers = c.num_carriers - n_pilot;
+    g.bits_per_carrier = bits_per_symbol(c.modulation);
+    g.llrs_per_symbol = g.n_data_carriers * g.bits_per_carrier;
+    g.llrs_per_frame = g.llrs_per_symbol * c.n_data_symbols;
+    g.ldpc_n = kLdpcN;
+    g.ldpc_k = (uint32_t)k;
+    g.ldpc_m = (uint32_t)m;
+    g.ldpc_edges = 0;  // filled by build_ldpc
+    g.decoded_bytes = (uint32_t)((k + 7) / 8);
+    return ULTRA_HIP_OK;
+}
+
+// ---- Tanner graph ---------------------------------------------------------
+inline void build_ldpc(uint32_t rate, uint32_t max_iterations, LdpcConst& L) {
+    int k, m;
+    code_params(rate, k, m);
+    std::mt19937 rng(0x12345678 + static_cast<int>(rate));
+    std::vector<std::vector<int>> rows(m);
+    const int target_check_degree = 4;
+    int target_var_degree = std::max(3, (target_check_degree * m) / k);
+    target_var_degree = std::min(target_var_degree, m / 2);
+    const int max_check_degree = target_check_degree + 2;
+    std::vector<int> check_degrees(m, 0), pool;
+    for (int j = 0; j < k; ++j) {
+        pool.clear();
+        for (int i = 0; i < m; ++i)
+            if (check_degrees[i] < max_check_degree) pool.push_back(i);
+        for (size_t i = pool.size(); i > 1; --i) {       // Fisher-Yates, rng() % i from the top
+            size_t pick = rng() % i;
+            std::swap(pool[i - 1], pool[pick]);
+        }
+        int links = std::min(target_var_degree, (int)pool.size());
+        for (int d = 0; d < links; ++d) { rows[pool[d]].push_back(j); check_degrees[pool[d]]++; }
+    }
+    for (int i = 0; i < m; ++i)
+        if (rows[i].empty()) rows[i].push_back((int)(rng() % k));
+    for (int i = 0; i < m; ++i) rows[i].push_back(k + i);   // identity part
+
+    L = LdpcConst{};
+    L.k = k; L.m = m; L.n = k + m; L.max_iterations = (int)max_iterations;
+    L.decoded_bytes = (k + 7) / 8;
+    int e = 0;
+    std::vector<std::vector<int>> var_edges(k + m);
+    for (int i = 0; i < m; ++i) {
+        L.row_ptr[i] = (uint16_t)e;
+        for (int v : rows[i]) { L.col[e] = (uint16_t)v; var_edges[v].push_back(e); ++e; }
+    }
+    L.row_ptr[m] = (uint16_t)e;
+    L.edges = e;
+    int q = 0;
+    for (int j = 0; j < k + m; ++j) {
+        L.var_ptr[j] = (uint16_t)q;
+        for (int ed : var_edges[j]) L.var_edge[q++] = (uint16_t)ed;  // ascending check order
+    }
+    L.var_ptr[k + m] = (uint16_t)q;
+}
+
+// ---- demodulator constants ------------------------------------------------
+inline int build_demod(const ultra_hip_config& c, DemodConst& D, std::vector<c32>& nco,
+                       std::vector<c32>& twiddle) {
+    ultra_hip_geometry g;
+    int rc = fill_geometry(c, g);
+    if (rc != ULTRA_HIP_OK) return rc;
+    D = DemodConst{};
+    D.fft = (int)c.fft_size;
+    D.log2_fft = 0;
+    while ((1u << D.log2_fft) < c.fft_size) ++D.log2_fft;
+    D.cp = (int)g.cp_len;
+    D.sym_len = (int)g.symbol_samples;
+    D.n_train = (c.entry == ULTRA_ENTRY_PRESYNCED) ? (int)c.training_symbols : 0;
+    D.n_data_sym = (int)c.n_data_symbols;
+    D.n_carriers = (int)c.num_carriers;
+    D.modulation = (int)c.modulation;
+    D.bits = (int)g.bits_per_carrier;
+    D.differential = (c.modulation == ULTRA_MOD_DBPSK || c.modulation == ULTRA_MOD_DQPSK ||
+                      c.modulation == ULTRA_MOD_D8PSK);
+    D.presynced = (c.entry == ULTRA_ENTRY_PRESYNCED);
+    D.frame_samples = (int)g.frame_samples;
+    D.ce_margin = ce_margin(c.modulation);
+    D.sample_rate = (float)c.sample_rate;
+    D.symbol_duration = static_cast<float>(g.symbol_samples) / static_cast<float>(c.sample_rate);
+    D.max_timing = 50.0f * (c.fft_size / 512.0f);
+    D.fft_f = (float)c.fft_size;
+    D.two_pi_symbol_duration = (2.0 * M_PI) * (double)D.symbol_duration;
+
+    // carrier layout
+    const int neg_limit = (int)c.num_carriers / 2, pos_limit = ((int)c.num_carriers + 1) / 2;
+    std::vector<bool> pilot_pos;   // "pilot position" irrespective of use_pilots (interp table quirk)
+    int slot = 0, count = 0;
+    for (int i = -neg_limit; i <= pos_limit; ++i) {
+        if (i == 0) continue;
+        int bin = (int)((i + c.fft_size) % c.fft_size);
+        D.bin[slot] = (int16_t)bin;
+        D.k_of[slot] = (int16_t)((bin > (int)c.fft_size / 2) ? bin - (int)c.fft_size : bin);
+        bool at_pilot_pos = (count % c.pilot_spacing == 0);
+        pilot_pos.push_back(at_pilot_pos);
+        if (c.use_pilots && at_pilot_pos) D.pilot_slot[D.n_pilot++] = (int16_t)slot;
+        else D.data_slot[D.n_data++] = (int16_t)slot;
+        ++slot; ++count;
+    }
+    D.llrs_per_symbol = D.n_data * D.bits;
+    D.llrs_per_frame = D.llrs_per_symbol * D.n_data_sym;
+
+    // Zadoff-Chu (u = 1) and BPSK pilots
+    const size_t N = c.num_carriers, u = 1;
+    for (size_t n = 0; n < N; ++n) {
+        // the reference's expression is double throughout (M_PI), narrowed once
+        const double zc = (((-M_PI * (double)u) * (double)n) * (double)(n + 1)) / (double)N;
+        const float phase = (float)zc;
+        D.sync_seq[n] = c32{cosf(phase), sinf(phase)};
+    }
+    std::mt19937 prng(0x50494C54u);   // "PILT"
+    for (int i = 0; i < D.n_pilot; ++i) D.pilot_seq[i] = (prng() & 1) ? c32{1.0f, 0.0f} : c32{-1.0f, 0.0f};
+
+    // interpolation table over non-pilot *positions*
+    for (int ci = 0; ci < slot; ++ci) {
+        if (pilot_pos[ci]) continue;
+        int lo = -1, hi = -1;
+        for (int j = ci - 1; j >= 0; --j) if (pilot_pos[j]) { lo = j; break; }
+        for (int j = ci + 1; j < slot; ++j) if (pilot_pos[j]) { hi = j; break; }
+        float alpha = 0.5f;
+        if (lo >= 0 && hi >= 0) {
+            float total_dist = (float)(hi - lo);
+            alpha = (total_dist > 0) ? (float)(ci - lo) / total_dist : 0.5f;
+        }
+        int q = D.n_interp++;
+        D.interp_slot[q] = (int16_t)ci; D.interp_lo[q] = (int16_t)lo; D.interp_hi[q] = (int16_t)hi;
+        D.interp_alpha[q] = alpha;
+    }
+
+    // NCO sequence after reset() for every sample of a frame
+    const size_t total = (size_t)g.frame_samples;
+    nco.resize(total);
+    {
+        // f32 phase accumulator; increment, wrap compare and wrap subtract are
+        // evaluated in f64 (2.0f * M_PI is a double) and narrowed on store
+        const double two_pi = 2.0 * M_PI;
+        const float step = (float)((two_pi * (double)(float)c.center_freq) / (double)(float)c.sample_rate);
+        float acc = 0.0f;
+        for (size_t i = 0; i < total; ++i) {
+            nco[i] = c32{cosf(acc), sinf(acc)};
+            acc += step;
+            if ((double)acc > two_pi) acc = (float)((double)acc - two_pi);
+            if (acc < 0.0f) acc = (float)((double)acc + two_pi);
+        }
+        D.mixer_phase_end = acc;
+    }
+    // radix-2 twiddles
+    twiddle.resize(c.fft_size / 2);
+    for (size_t k = 0; k < c.fft_size / 2; ++k) {
+        const float angle = (float)(((-2.0 * M_PI) * (double)k) / (double)c.fft_size);
+        twiddle[k] = c32{cosf(angle), sinf(angle)};
+    }
+    return ULTRA_HIP_OK;
+}
+
+}  // namespace ultra_hip
+#endif

@@ -1,0 +1,256 @@
+// pinned_math.h — bit-exact device restatement of the libm calls on the
+// reference's receive path.
+//
+// The reference (secup/ProjectUltra) calls, through std::cos/sin/abs/arg/exp on
+// float and std::complex<float>:
+//     cosf, sinf, sincosf (via cexpf), atan2f (-> atanf), hypotf (via cabsf).
+// These live in a third-party dependency that is not part of /root/reference:
+// GNU libc 2.35 libm (Ubuntu GLIBC 2.35-0ubuntu3.11, the libm.so.6 of this
+// image and of the GPU box).  To give bit-identical LLRs the HIP kernels must
+// reproduce those functions bit for bit, so this header restates their
+// published algorithms:
+//   * sinf/cosf/sincosf: ARM optimized-routines single-precision sin/cos as
+//     adopted by glibc >= 2.28 (sysdeps/ieee754/flt-32/s_sincosf.h): reduce in
+//     double, degree-7/8 polynomials in double, ONE rounding to float.  On
+//     x86-64 CPUs with FMA glibc dispatches the `__sinf_fma` build, whose
+//     multiply-adds are fused; the fma() placement below follows that build
+//     instruction for instruction (checked against the disassembly of this
+//     image's libm and exhaustively against libm over all 2^32 inputs:
+//     tests/test_pinned_math.py, tools/pinned_math_check.cpp).
+//   * atan2f/atanf: fdlibm float code (sysdeps/ieee754/flt-32/e_atan2f.c,
+//     s_atanf.c), pure float arithmetic, no FMA.
+//   * hypotf: glibc 2.35 e_hypotf.c — (float)sqrt((double)x*x + (double)y*y).
+// Constants were read from the image's libm.so.6 .rodata and agree with the
+// published sources.
+//
+// The functions are plain C++ (no HIP types) so the same text compiles for the
+// device (hipcc) and for the host exhaustive check (g++).  Compile with
+// -ffp-contract=off: every fused operation is written as an explicit fma().
+#ifndef ULTRA_PINNED_MATH_H
+#define ULTRA_PINNED_MATH_H
+
+#include <stdint.h>
+#include <math.h>
+
+#ifdef __HIPCC__
+#define UM_FN __host__ __device__ __forceinline__
+#else
+#define UM_FN static inline
+#endif
+
+namespace um {
+
+UM_FN uint32_t as_u32(float f) { union { float f; uint32_t u; } v; v.f = f; return v.u; }
+UM_FN float as_f32(uint32_t u) { union { float f; uint32_t u; } v; v.u = u; return v.f; }
+UM_FN uint32_t abstop12(float x) { return (as_u32(x) >> 20) & 0x7ff; }
+
+// __sincosf_table[0] / [1] (s_sincosf_data.c): cosine c0..c4, sine s1..s3.
+struct SinCosTab { double c0, c1, c2, c3, c4, s1, s2, s3; };
+
+#define UM_TAB0 { 0x1p0, -0x1.ffffffd0c621cp-2, 0x1.55553e1068f19p-5, -0x1.6c087e89a359dp-10, \
+                  0x1.99343027bf8c3p-16, -0x1.555545995a603p-3, 0x1.1107605230bc4p-7, -0x1.994eb3774cf24p-13 }
+#define UM_TAB1 { -0x1p0, 0x1.ffffffd0c621cp-2, -0x1.55553e1068f19p-5, 0x1.6c087e89a359dp-10, \
+                  -0x1.99343027bf8c3p-16, -0x1.555545995a603p-3, 0x1.1107605230bc4p-7, -0x1.994eb3774cf24p-13 }
+
+// sinf_poly (s_sincosf.h), FMA build: n even -> sine polynomial, n odd -> cosine.
+UM_FN float sinf_poly(double x, double x2, const SinCosTab& p, int n) {
+    if ((n & 1) == 0) {
+        double x3 = x * x2;
+        double s1 = fma(x2, p.s3, p.s2);
+        double x7 = x3 * x2;
+        double s = fma(x3, p.s1, x);
+        return (float)fma(x7, s1, s);
+    } else {
+        double x4 = x2 * x2;
+        double c2 = fma(x2, p.c4, p.c3);
+        double c1 = fma(x2, p.c1, p.c0);
+        double x6 = x4 * x2;
+        double c = fma(x4, p.c2, c1);
+        return (float)fma(x6, c2, c);
+    }
+}
+
+// reduce_fast (|x| < 120): hpi_inv prescaled by 2^24 (TOINT_INTRINSICS == 0 on x86-64).
+UM_FN double reduce_fast(double x, int* np) {
+    double r = x * 0x1.45F306DC9C883p+23;
+    int n = ((int32_t)r + 0x800000) >> 24;
+    *np = n;
+    return fma(-(double)n, 0x1.921FB54442D18p0, x);
+}
+
+// reduce_large (|x| >= 120), __inv_pio4 table.
+UM_FN double reduce_large(uint32_t xi, int* np) {
+    const uint32_t inv_pio4[24] = {
+        0xa2, 0xa2f9, 0xa2f983, 0xa2f9836e, 0xf9836e4e, 0x836e4e44, 0x6e4e4415, 0x4e441529,
+        0x441529fc, 0x1529fc27, 0x29fc2757, 0xfc2757d1, 0x2757d1f5, 0x57d1f534, 0xd1f534dd, 0xf534ddc0,
+        0x34ddc0db, 0xddc0db62, 0xc0db6295, 0xdb629599, 0x6295993c, 0x95993c43, 0x993c4390, 0x3c439041};
+    const uint32_t* arr = &inv_pio4[(xi >> 26) & 15];
+    int shift = (xi >> 23) & 7;
+    uint64_t n, res0, res1, res2;
+    xi = (xi & 0xffffff) | 0x800000;
+    xi <<= shift;
+    res0 = (uint32_t)(xi * arr[0]);
+    res1 = (uint64_t)xi * arr[4];
+    res2 = (uint64_t)xi * arr[8];
+    res0 = (res2 >> 32) | (res0 << 32);
+    res0 += res1;
+    n = (res0 + (1ULL << 61)) >> 62;
+    res0 -= n << 62;
+    double x = (double)(int64_t)res0;
+    *np = (int)n;
+    return x * 0x1.921FB54442D18p-62;
+}
+
+UM_FN double quadrant_sign(int n) { return ((n + 1) & 2) ? -1.0 : 1.0; }  // {1,-1,-1,1}[n&3]
+
+// glibc sinf (s_sinf.c)
+UM_FN float sinf_(float y) {
+    const SinCosTab t0 = UM_TAB0, t1 = UM_TAB1;
+    double x = y;
+    int n;
+    if (abstop12(y) < 0x3f4) {  // |y| < pi/4   (abstop12(pio4) == 0x3f4)
+        double s = x * x;
+        if (abstop12(y) < 0x398) return y;  // |y| < 2^-12
+        return sinf_poly(x, s, t0, 0);
+    } else if (abstop12(y) < 0x42f) {  // |y| < 120
+        x = reduce_fast(x, &n);
+        double s = quadrant_sign(n);
+        return sinf_poly(x * s, x * x, (n & 2) ? t1 : t0, n);
+    } else if (abstop12(y) < 0x7f8) {
+        uint32_t xi = as_u32(y);
+        int sign = (int)(xi >> 31);
+        x = reduce_large(xi, &n);
+        double s = quadrant_sign(n + sign);
+        return sinf_poly(x * s, x * x, ((n + sign) & 2) ? t1 : t0, n);
+    }
+    return y - y;  // inf/NaN -> NaN
+}
+
+// glibc cosf (s_cosf.c)
+UM_FN float cosf_(float y) {
+    const SinCosTab t0 = UM_TAB0, t1 = UM_TAB1;
+    double x = y;
+    int n;
+    if (abstop12(y) < 0x3f4) {
+        double x2 = x * x;
+        if (abstop12(y) < 0x398) return 1.0f;
+        return sinf_poly(x, x2, t0, 1);
+    } else if (abstop12(y) < 0x42f) {
+        x = reduce_fast(x, &n);
+        double s = quadrant_sign(n);
+        return sinf_poly(x * s, x * x, (n & 2) ? t1 : t0, n ^ 1);
+    } else if (abstop12(y) < 0x7f8) {
+        uint32_t xi = as_u32(y);
+        int sign = (int)(xi >> 31);
+        x = reduce_large(xi, &n);
+        double s = quadrant_sign(n + sign);
+        return sinf_poly(x * s, x * x, ((n + sign) & 2) ? t1 : t0, n ^ 1);
+    }
+    return y - y;
+}
+
+// glibc sincosf: same reduction and polynomials as sinf/cosf (s_sincosf.c);
+// cexpf(0 + i*t) = (cos t, sin t) through it (s_cexp_template.c).
+UM_FN void sincosf_(float y, float* sp, float* cp) { *sp = sinf_(y); *cp = cosf_(y); }
+
+// fdlibm atanf (s_atanf.c)
+UM_FN float atanf_(float x) {
+    const float atanhi[4] = {as_f32(0x3eed6338), as_f32(0x3f490fda), as_f32(0x3f7b985e), as_f32(0x3fc90fda)};
+    const float atanlo[4] = {as_f32(0x31ac3769), as_f32(0x33222168), as_f32(0x33140fb4), as_f32(0x33a22168)};
+    const float aT0 = as_f32(0x3eaaaaab), aT1 = as_f32(0xbe4ccccd), aT2 = as_f32(0x3e124925),
+                aT3 = as_f32(0xbde38e38), aT4 = as_f32(0x3dba2e6e), aT5 = as_f32(0xbd9d8795),
+                aT6 = as_f32(0x3d886b35), aT7 = as_f32(0xbd6ef16b), aT8 = as_f32(0x3d4bda59),
+                aT9 = as_f32(0xbd15a221), aT10 = as_f32(0x3c8569d7);
+    int32_t hx = (int32_t)as_u32(x);
+    int32_t ix = hx & 0x7fffffff;
+    int id;
+    if (ix >= 0x4c000000) {  // |x| >= 2^25
+        if (ix > 0x7f800000) return x + x;
+        if (hx > 0) return atanhi[3] + atanlo[3];
+        return -atanhi[3] - atanlo[3];
+    }
+    if (ix < 0x3ee00000) {       // |x| < 0.4375
+        if (ix < 0x31000000) return x;  // |x| < 2^-29 (huge + x > one always holds)
+        id = -1;
+    } else {
+        x = fabsf(x);
+        if (ix < 0x3f980000) {
+            if (ix < 0x3f300000) { id = 0; x = (2.0f * x - 1.0f) / (2.0f + x); }
+            else { id = 1; x = (x - 1.0f) / (x + 1.0f); }
+        } else {
+            if (ix < 0x401c0000) { id = 2; x = (x - 1.5f) / (1.0f + 1.5f * x); }
+            else { id = 3; x = -1.0f / x; }
+        }
+    }
+    float z = x * x;
+    float w = z * z;
+    float s1 = z * (aT0 + w * (aT2 + w * (aT4 + w * (aT6 + w * (aT8 + w * aT10)))));
+    float s2 = w * (aT1 + w * (aT3 + w * (aT5 + w * (aT7 + w * aT9))));
+    if (id < 0) return x - x * (s1 + s2);
+    z = atanhi[id] - ((x * (s1 + s2) - atanlo[id]) - x);
+    return (hx < 0) ? -z : z;
+}
+
+// fdlibm __ieee754_atan2f (e_atan2f.c); the errno wrapper adds nothing numerically.
+UM_FN float atan2f_(float y, float x) {
+    const float tiny = 1.0e-30f;
+    const float pi_o_4 = as_f32(0x3f490fdb), pi_o_2 = as_f32(0x3fc90fdb), pi = as_f32(0x40490fdb),
+                pi_lo = as_f32(0xb3bbbd2e);
+    int32_t hx = (int32_t)as_u32(x), hy = (int32_t)as_u32(y);
+    int32_t ix = hx & 0x7fffffff, iy = hy & 0x7fffffff;
+    if (ix > 0x7f800000 || iy > 0x7f800000) return x + y;
+    if (hx == 0x3f800000) return atanf_(y);
+    int32_t m = ((hy >> 31) & 1) | ((hx >> 30) & 2);
+    if (iy == 0) {
+        switch (m) {
+            case 0: case 1: return y;
+            case 2: return pi + tiny;
+            default: return -pi - tiny;
+        }
+    }
+    if (ix == 0) return (hy < 0) ? -pi_o_2 - tiny : pi_o_2 + tiny;
+    if (ix == 0x7f800000) {
+        if (iy == 0x7f800000) {
+            switch (m) {
+                case 0: return pi_o_4 + tiny;
+                case 1: return -pi_o_4 - tiny;
+                case 2: return 3.0f * pi_o_4 + tiny;
+                default: return -3.0f * pi_o_4 - tiny;
+            }
+        } else {
+            switch (m) {
+                case 0: return 0.0f;
+                case 1: return -0.0f;
+                case 2: return pi + tiny;
+                default: return -pi - tiny;
+            }
+        }
+    }
+    if (iy == 0x7f800000) return (hy < 0) ? -pi_o_2 - tiny : pi_o_2 + tiny;
+    int32_t k = (iy - ix) >> 23;
+    float z;
+    if (k > 60) z = pi_o_2 + 0.5f * pi_lo;
+    else if (hx < 0 && k < -60) z = 0.0f;
+    else z = atanf_(fabsf(y / x));
+    switch (m) {
+        case 0: return z;
+        case 1: return as_f32(as_u32(z) ^ 0x80000000u);
+        case 2: return pi - (z - pi_lo);
+        default: return (z - pi_lo) - pi;
+    }
+}
+
+// glibc 2.35 hypotf (e_hypotf.c): exact products, one double rounding of the
+// sum, correctly rounded sqrt, one narrowing.
+UM_FN float hypotf_(float x, float y) {
+    uint32_t ax = as_u32(x) & 0x7fffffff, ay = as_u32(y) & 0x7fffffff;
+    if (ax >= 0x7f800000 || ay >= 0x7f800000) {
+        if (ax == 0x7f800000 || ay == 0x7f800000) return as_f32(0x7f800000);
+        return x + y;
+    }
+    double dx = x, dy = y;
+    return (float)sqrt(dx * dx + dy * dy);
+}
+
+}  // namespace um
+#endif

@@ -1,0 +1,346 @@
+// ultra_hip.hip — C-ABI (include/ultra_hip.h) over the gfx950 kernels.
+//
+// Host side of the drop-in boundary: builds the constant tables the way the
+// reference constructors do (host_tables.h), owns the device copies, validates
+// operand shapes before every launch (a faulting kernel can reset the whole
+// host) and launches the hand-written kernels on the context's stream.  No
+// CPU fallback exists: every entry point either runs the HIP path or fails.
+#include <hip/hip_runtime.h>
+
+#include <cstdio>
+#include <cstring>
+#include <new>
+#include <vector>
+
+#include "../../include/ultra_hip.h"
+#include "device_types.h"
+#include "host_tables.h"
+#include "demod_kernel.h"
+#include "ldpc_kernel.h"
+
+using namespace ultra_hip;
+
+struct ultra_hip_ctx {
+    ultra_hip_config cfg{};
+    ultra_hip_geometry geo{};
+    int device = 0;
+    hipStream_t stream = nullptr;
+    DemodConst h_demod{};
+    LdpcConst h_ldpc{};
+    DemodConst* d_demod = nullptr;
+    LdpcConst* d_ldpc = nullptr;
+    c32* d_nco = nullptr;
+    c32* d_twiddle = nullptr;
+    // workspace for the fused call when the caller does not want LLRs
+    float* d_ws_llr = nullptr;
+    size_t ws_llr_frames = 0;
+    hipEvent_t ev_begin = nullptr, ev_end = nullptr;
+    int cu_count = 256;
+};
+
+namespace {
+
+#define UH_HIP(call)                                                                          \
+    do {                                                                                      \
+        hipError_t e_ = (call);                                                               \
+        if (e_ != hipSuccess) {                                                               \
+            std::fprintf(stderr, "ultra_hip: %s failed: %s (%s:%d)\n", #call,                  \
+                         hipGetErrorString(e_), __FILE__, __LINE__);                          \
+            return (e_ == hipErrorOutOfMemory) ? ULTRA_HIP_ERR_OOM : ULTRA_HIP_ERR_HIP;        \
+        }                                                                                     \
+    } while (0)
+
+struct DeviceGuard {
+    int prev = -1;
+    bool ok = false;
+    explicit DeviceGuard(int dev) {
+        if (hipGetDevice(&prev) != hipSuccess) prev = -1;
+        ok = (hipSetDevice(dev) == hipSuccess);
+    }
+    ~DeviceGuard() { if (prev >= 0) (void)hipSetDevice(prev); }
+};
+
+int launch_demod(ultra_hip_ctx* ctx, const float* d_audio, size_t frame_stride, const float* d_cfo_hz,
+                 const float* d_cfo_phase, size_t n_frames, float* d_llr, size_t llr_stride, float* d_state) {
+    if (n_frames == 0) return ULTRA_HIP_OK;
+    // one workgroup per frame; cap the grid and stride so huge batches stay one launch
+    const size_t max_blocks = (size_t)ctx->cu_count * 64;
+    const unsigned grid = (unsigned)std::min(n_frames, max_blocks);
+    hipLaunchKernelGGL(dev::demod_frames_kernel, dim3(grid), dim3(dev::kDemodThreads), 0, ctx->stream,
+                       ctx->d_demod, ctx->d_nco, ctx->d_twiddle, d_audio, frame_stride, d_cfo_hz, d_cfo_phase,
+                       (int)n_frames, d_llr, llr_stride, d_state);
+    UH_HIP(hipGetLastError());
+    return ULTRA_HIP_OK;
+}
+
+int launch_ldpc(ultra_hip_ctx* ctx, const float* d_llr, size_t llr_stride, size_t n_cw, uint8_t* d_bytes,
+                int32_t* d_iters, uint8_t* d_ok, float* d_llr_total) {
+    if (n_cw == 0) return ULTRA_HIP_OK;
+    const size_t max_blocks = (size_t)ctx->cu_count * 256;
+    const unsigned grid = (unsigned)std::min(n_cw, max_blocks);
+    const size_t lds = dev::ldpc_lds_bytes(ctx->h_ldpc.edges);
+    hipLaunchKernelGGL(dev::ldpc_decode_kernel, dim3(grid), dim3(dev::kLdpcThreads), lds, ctx->stream,
+                       ctx->d_ldpc, d_llr, llr_stride, (int)n_cw, d_bytes, d_iters, d_ok, d_llr_total);
+    UH_HIP(hipGetLastError());
+    return ULTRA_HIP_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int ultra_hip_abi_version(void) { return ULTRA_HIP_ABI_VERSION; }
+
+const char* ultra_hip_strerror(int status) {
+    switch (status) {
+        case ULTRA_HIP_OK: return "ok";
+        case ULTRA_HIP_ERR_INVALID_ARG: return "invalid argument";
+        case ULTRA_HIP_ERR_UNSUPPORTED: return "configuration not supported by the HIP path";
+        case ULTRA_HIP_ERR_NO_DEVICE: return "no usable HIP device";
+        case ULTRA_HIP_ERR_HIP: return "HIP runtime call failed";
+        case ULTRA_HIP_ERR_OOM: return "out of memory";
+        default: return "unknown ultra_hip status";
+    }
+}
+
+int ultra_hip_device_count(void) {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return ULTRA_HIP_ERR_NO_DEVICE;
+    return n;
+}
+
+int ultra_hip_geometry_for(const ultra_hip_config* cfg, ultra_hip_geometry* geo) {
+    if (!cfg || !geo) return ULTRA_HIP_ERR_INVALID_ARG;
+    int rc = fill_geometry(*cfg, *geo);
+    if (rc != ULTRA_HIP_OK) return rc;
+    LdpcConst L;
+    build_ldpc(cfg->code_rate, cfg->max_iterations, L);
+    geo->ldpc_edges = (uint32_t)L.edges;
+    return ULTRA_HIP_OK;
+}
+
+int ultra_hip_create(const ultra_hip_config* cfg, int device, void* stream, ultra_hip_ctx** out) {
+    if (!cfg || !out) return ULTRA_HIP_ERR_INVALID_ARG;
+    *out = nullptr;
+    ultra_hip_geometry geo;
+    int rc = fill_geometry(*cfg, geo);
+    if (rc != ULTRA_HIP_OK) return rc;
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess || n <= 0) return ULTRA_HIP_ERR_NO_DEVICE;
+    if (device < 0 || device >= n) return ULTRA_HIP_ERR_NO_DEVICE;
+
+    ultra_hip_ctx* ctx = new (std::nothrow) ultra_hip_ctx();
+    if (!ctx) return ULTRA_HIP_ERR_OOM;
+    ctx->cfg = *cfg;
+    ctx->device = device;
+    ctx->stream = static_cast<hipStream_t>(stream);
+
+    std::vector<c32> nco, tw;
+    rc = build_demod(*cfg, ctx->h_demod, nco, tw);
+    if (rc != ULTRA_HIP_OK) { delete ctx; return rc; }
+    build_ldpc(cfg->code_rate, cfg->max_iterations, ctx->h_ldpc);
+    geo.ldpc_edges = (uint32_t)ctx->h_ldpc.edges;
+    ctx->geo = geo;
+    if (ctx->h_ldpc.edges > kLdpcMaxEdges || ctx->h_ldpc.m > kLdpcMaxChecks) { delete ctx; return ULTRA_HIP_ERR_UNSUPPORTED; }
+
+    DeviceGuard guard(device);
+    if (!guard.ok) { delete ctx; return ULTRA_HIP_ERR_NO_DEVICE; }
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, device) == hipSuccess && prop.multiProcessorCount > 0)
+        ctx->cu_count = prop.multiProcessorCount;
+
+    auto fail = [&](int code) { ultra_hip_destroy(ctx); return code; };
+    if (hipMalloc(&ctx->d_demod, sizeof(DemodConst)) != hipSuccess) return fail(ULTRA_HIP_ERR_OOM);
+    if (hipMalloc(&ctx->d_ldpc, sizeof(LdpcConst)) != hipSuccess) return fail(ULTRA_HIP_ERR_OOM);
+    if (hipMalloc(&ctx->d_nco, nco.size() * sizeof(c32)) != hipSuccess) return fail(ULTRA_HIP_ERR_OOM);
+    if (hipMalloc(&ctx->d_twiddle, tw.size() * sizeof(c32)) != hipSuccess) return fail(ULTRA_HIP_ERR_OOM);
+    if (hipMemcpy(ctx->d_demod, &ctx->h_demod, sizeof(DemodConst), hipMemcpyHostToDevice) != hipSuccess ||
+        hipMemcpy(ctx->d_ldpc, &ctx->h_ldpc, sizeof(LdpcConst), hipMemcpyHostToDevice) != hipSuccess ||
+        hipMemcpy(ctx->d_nco, nco.data(), nco.size() * sizeof(c32), hipMemcpyHostToDevice) != hipSuccess ||
+        hipMemcpy(ctx->d_twiddle, tw.data(), tw.size() * sizeof(c32), hipMemcpyHostToDevice) != hipSuccess)
+        return fail(ULTRA_HIP_ERR_HIP);
+    if (hipEventCreate(&ctx->ev_begin) != hipSuccess || hipEventCreate(&ctx->ev_end) != hipSuccess)
+        return fail(ULTRA_HIP_ERR_HIP);
+    *out = ctx;
+    return ULTRA_HIP_OK;
+}
+
+void ultra_hip_destroy(ultra_hip_ctx* ctx) {
+    if (!ctx) return;
+    DeviceGuard guard(ctx->device);
+    if (ctx->d_demod) (void)hipFree(ctx->d_demod);
+    if (ctx->d_ldpc) (void)hipFree(ctx->d_ldpc);
+    if (ctx->d_nco) (void)hipFree(ctx->d_nco);
+    if (ctx->d_twiddle) (void)hipFree(ctx->d_twiddle);
+    if (ctx->d_ws_llr) (void)hipFree(ctx->d_ws_llr);
+    if (ctx->ev_begin) (void)hipEventDestroy(ctx->ev_begin);
+    if (ctx->ev_end) (void)hipEventDestroy(ctx->ev_end);
+    delete ctx;
+}
+
+int ultra_hip_get_geometry(const ultra_hip_ctx* ctx, ultra_hip_geometry* geo) {
+    if (!ctx || !geo) return ULTRA_HIP_ERR_INVALID_ARG;
+    *geo = ctx->geo;
+    return ULTRA_HIP_OK;
+}
+
+int ultra_hip_get_tanner_graph(const ultra_hip_ctx* ctx, uint32_t* h_row_ptr, uint32_t* h_col_idx) {
+    if (!ctx || !h_row_ptr || !h_col_idx) return ULTRA_HIP_ERR_INVALID_ARG;
+    for (int i = 0; i <= ctx->h_ldpc.m; ++i) h_row_ptr[i] = ctx->h_ldpc.row_ptr[i];
+    for (int e = 0; e < ctx->h_ldpc.edges; ++e) h_col_idx[e] = ctx->h_ldpc.col[e];
+    return ULTRA_HIP_OK;
+}
+
+int ultra_hip_ldpc_decode_batch(ultra_hip_ctx* ctx, const float* d_llr, size_t n_cw, uint8_t* d_bytes,
+                                int32_t* d_iters, uint8_t* d_ok, float* d_llr_total) {
+    if (!ctx) return ULTRA_HIP_ERR_INVALID_ARG;
+    if (n_cw == 0) return ULTRA_HIP_OK;
+    if (!d_llr || !d_bytes || !d_iters || !d_ok || n_cw > 0x7fffffffull) return ULTRA_HIP_ERR_INVALID_ARG;
+    DeviceGuard guard(ctx->device);
+    return launch_ldpc(ctx, d_llr, kLdpcN, n_cw, d_bytes, d_iters, d_ok, d_llr_total);
+}
+
+int ultra_hip_demod_batch(ultra_hip_ctx* ctx, const float* d_audio, size_t frame_stride, const float* d_cfo_hz,
+                          const float* d_cfo_phase, size_t n_frames, float* d_llr, float* d_state) {
+    if (!ctx) return ULTRA_HIP_ERR_INVALID_ARG;
+    if (n_frames == 0) return ULTRA_HIP_OK;
+    if (!d_audio || !d_llr || frame_stride < ctx->geo.frame_samples || n_frames > 0x7fffffffull)
+        return ULTRA_HIP_ERR_INVALID_ARG;
+    DeviceGuard guard(ctx->device);
+    return launch_demod(ctx, d_audio, frame_stride, d_cfo_hz, d_cfo_phase, n_frames, d_llr,
+                        ctx->geo.llrs_per_frame, d_state);
+}
+
+int ultra_hip_demod_decode_batch(ultra_hip_ctx* ctx, const float* d_audio, size_t frame_stride,
+                                 const float* d_cfo_hz, const float* d_cfo_phase, size_t n_frames, float* d_llr,
+                                 uint8_t* d_bytes, int32_t* d_iters, uint8_t* d_ok) {
+    if (!ctx) return ULTRA_HIP_ERR_INVALID_ARG;
+    if (n_frames == 0) return ULTRA_HIP_OK;
+    if (!d_audio || !d_bytes || !d_iters || !d_ok || frame_stride < ctx->geo.frame_samples ||
+        n_frames > 0x7fffffffull)
+        return ULTRA_HIP_ERR_INVALID_ARG;
+    // The harness decodes the first 648 soft bits of a frame; a frame that yields
+    // fewer cannot be decoded (tools/test_nvis_mode.cpp:96-99 returns false).
+    if (ctx->geo.llrs_per_frame < (uint32_t)kLdpcN) return ULTRA_HIP_ERR_UNSUPPORTED;
+    DeviceGuard guard(ctx->device);
+    float* llr = d_llr;
+    if (!llr) {
+        if (ctx->ws_llr_frames < n_frames) {
+            if (ctx->d_ws_llr) { UH_HIP(hipStreamSynchronize(ctx->stream)); (void)hipFree(ctx->d_ws_llr); ctx->d_ws_llr = nullptr; }
+            UH_HIP(hipMalloc(&ctx->d_ws_llr, n_frames * (size_t)ctx->geo.llrs_per_frame * sizeof(float)));
+            ctx->ws_llr_frames = n_frames;
+        }
+        llr = ctx->d_ws_llr;
+    }
+    int rc = launch_demod(ctx, d_audio, frame_stride, d_cfo_hz, d_cfo_phase, n_frames, llr,
+                          ctx->geo.llrs_per_frame, nullptr);
+    if (rc != ULTRA_HIP_OK) return rc;
+    return launch_ldpc(ctx, llr, ctx->geo.llrs_per_frame, n_frames, d_bytes, d_iters, d_ok, nullptr);
+}
+
+int ultra_hip_count_errors(ultra_hip_ctx* ctx, const uint8_t* d_bytes, const int32_t* d_iters, const uint8_t* d_ok,
+                           const uint8_t* d_payload, size_t payload_bytes, size_t n_frames,
+                           ultra_hip_counters* d_counters) {
+    if (!ctx) return ULTRA_HIP_ERR_INVALID_ARG;
+    if (n_frames == 0) return ULTRA_HIP_OK;
+    if (!d_bytes || !d_iters || !d_ok || !d_payload || !d_counters || payload_bytes == 0 ||
+        payload_bytes > ctx->geo.decoded_bytes || n_frames > 0x7fffffffull)
+        return ULTRA_HIP_ERR_INVALID_ARG;
+    DeviceGuard guard(ctx->device);
+    const unsigned grid = (unsigned)std::min<size_t>((n_frames + 255) / 256, (size_t)ctx->cu_count * 8);
+    hipLaunchKernelGGL(dev::count_errors_kernel, dim3(grid), dim3(256), 0, ctx->stream, d_bytes,
+                       (size_t)ctx->geo.decoded_bytes, d_iters, d_ok, d_payload, (int)payload_bytes, (int)n_frames,
+                       reinterpret_cast<unsigned long long*>(d_counters));
+    UH_HIP(hipGetLastError());
+    return ULTRA_HIP_OK;
+}
+
+int ultra_hip_synchronize(ultra_hip_ctx* ctx) {
+    if (!ctx) return ULTRA_HIP_ERR_INVALID_ARG;
+    DeviceGuard guard(ctx->device);
+    UH_HIP(hipStreamSynchronize(ctx->stream));
+    return ULTRA_HIP_OK;
+}
+
+int ultra_hip_timer_begin(ultra_hip_ctx* ctx) {
+    if (!ctx) return ULTRA_HIP_ERR_INVALID_ARG;
+    DeviceGuard guard(ctx->device);
+    UH_HIP(hipEventRecord(ctx->ev_begin, ctx->stream));
+    return ULTRA_HIP_OK;
+}
+
+int ultra_hip_timer_end(ultra_hip_ctx* ctx, float* ms) {
+    if (!ctx || !ms) return ULTRA_HIP_ERR_INVALID_ARG;
+    DeviceGuard guard(ctx->device);
+    UH_HIP(hipEventRecord(ctx->ev_end, ctx->stream));
+    UH_HIP(hipEventSynchronize(ctx->ev_end));
+    UH_HIP(hipEventElapsedTime(ms, ctx->ev_begin, ctx->ev_end));
+    return ULTRA_HIP_OK;
+}
+
+int ultra_hip_malloc(ultra_hip_ctx* ctx, size_t bytes, void** d_ptr) {
+    if (!ctx || !d_ptr) return ULTRA_HIP_ERR_INVALID_ARG;
+    DeviceGuard guard(ctx->device);
+    UH_HIP(hipMalloc(d_ptr, bytes ? bytes : 1));
+    return ULTRA_HIP_OK;
+}
+
+int ultra_hip_free(ultra_hip_ctx* ctx, void* d_ptr) {
+    if (!ctx) return ULTRA_HIP_ERR_INVALID_ARG;
+    DeviceGuard guard(ctx->device);
+    if (d_ptr) UH_HIP(hipFree(d_ptr));
+    return ULTRA_HIP_OK;
+}
+
+int ultra_hip_memcpy_h2d(ultra_hip_ctx* ctx, void* d_dst, const void* h_src, size_t bytes) {
+    if (!ctx || (bytes && (!d_dst || !h_src))) return ULTRA_HIP_ERR_INVALID_ARG;
+    DeviceGuard guard(ctx->device);
+    UH_HIP(hipMemcpyAsync(d_dst, h_src, bytes, hipMemcpyHostToDevice, ctx->stream));
+    UH_HIP(hipStreamSynchronize(ctx->stream));
+    return ULTRA_HIP_OK;
+}
+
+int ultra_hip_memcpy_d2h(ultra_hip_ctx* ctx, void* h_dst, const void* d_src, size_t bytes) {
+    if (!ctx || (bytes && (!h_dst || !d_src))) return ULTRA_HIP_ERR_INVALID_ARG;
+    DeviceGuard guard(ctx->device);
+    UH_HIP(hipMemcpyAsync(h_dst, d_src, bytes, hipMemcpyDeviceToHost, ctx->stream));
+    UH_HIP(hipStreamSynchronize(ctx->stream));
+    return ULTRA_HIP_OK;
+}
+
+int ultra_hip_memset(ultra_hip_ctx* ctx, void* d_dst, int value, size_t bytes) {
+    if (!ctx || (bytes && !d_dst)) return ULTRA_HIP_ERR_INVALID_ARG;
+    DeviceGuard guard(ctx->device);
+    UH_HIP(hipMemsetAsync(d_dst, value, bytes, ctx->stream));
+    return ULTRA_HIP_OK;
+}
+
+// Device self-test of pinned_math.h: evaluates fn over n inputs on the GPU so
+// the tests can compare with the host libm (not part of the reference surface).
+//   fn: 0 sinf, 1 cosf, 2 atanf, 3 atan2f(a, b), 4 hypotf(a, b)
+__global__ void pinned_math_kernel(int fn, const float* a, const float* b, float* out, int n) {
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    float r;
+    switch (fn) {
+        case 0: r = um::sinf_(a[i]); break;
+        case 1: r = um::cosf_(a[i]); break;
+        case 2: r = um::atanf_(a[i]); break;
+        case 3: r = um::atan2f_(a[i], b[i]); break;
+        default: r = um::hypotf_(a[i], b[i]); break;
+    }
+    out[i] = r;
+}
+
+int ultra_hip_selftest_math(ultra_hip_ctx* ctx, int fn, const float* d_a, const float* d_b, float* d_out, size_t n) {
+    if (!ctx || !d_a || !d_out || fn < 0 || fn > 4 || (fn >= 3 && !d_b) || n > 0x7fffffffull)
+        return ULTRA_HIP_ERR_INVALID_ARG;
+    if (n == 0) return ULTRA_HIP_OK;
+    DeviceGuard guard(ctx->device);
+    hipLaunchKernelGGL(pinned_math_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, fn, d_a,
+                       d_b ? d_b : d_a, d_out, (int)n);
+    UH_HIP(hipGetLastError());
+    return ULTRA_HIP_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,205 @@
+"""ReceiveContext — the batched receive path on one MI355X, over the C-ABI.
+
+PyTorch is plumbing here: it owns device memory and the HIP stream; every
+computation is a hand-written gfx950 kernel reached through libultra_hip.so.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Optional
+
+import numpy as np
+
+from . import _lib
+from ._lib import check, ultra_hip_config, ultra_hip_geometry
+from .types import Entry, LDPC_BLOCK_SIZE, ModemConfig, getBitsPerSymbol
+
+
+def make_c_config(config: ModemConfig, *, entry: Entry = Entry.SYNCED, n_data_symbols: Optional[int] = None,
+                  training_symbols: int = 2, max_iterations: int = 50) -> ultra_hip_config:
+    c = ultra_hip_config()
+    c.sample_rate, c.center_freq = config.sample_rate, config.center_freq
+    c.fft_size, c.num_carriers = config.fft_size, config.num_carriers
+    c.cp_mode, c.symbol_guard = int(config.cp_mode), config.symbol_guard
+    c.pilot_spacing, c.use_pilots = config.pilot_spacing, int(bool(config.use_pilots))
+    c.modulation, c.code_rate = int(config.modulation), int(config.code_rate)
+    c.max_iterations = max_iterations
+    c.entry = int(entry)
+    c.training_symbols = training_symbols if Entry(entry) == Entry.PRESYNCED else 0
+    if n_data_symbols is None:
+        # symbols that carry one 648-bit codeword (OFDMNvisWaveform::getMinSamplesForFrame,
+        # src/waveform/ofdm_cox_waveform.cpp:231-258)
+        bps = config.getDataCarriers() * getBitsPerSymbol(config.modulation)
+        n_data_symbols = -(-LDPC_BLOCK_SIZE // bps)
+    c.n_data_symbols = n_data_symbols
+    return c
+
+
+def geometry_for(cfg: ultra_hip_config) -> ultra_hip_geometry:
+    g = ultra_hip_geometry()
+    check(_lib.lib().ultra_hip_geometry_for(C.byref(cfg), C.byref(g)), "ultra_hip_geometry_for")
+    return g
+
+
+def _torch():
+    import torch
+    return torch
+
+
+class ReceiveContext:
+    """One ultra_hip_ctx: constant tables in HBM + launches on a HIP stream."""
+
+    def __init__(self, config: ModemConfig, *, entry: Entry = Entry.SYNCED, n_data_symbols: Optional[int] = None,
+                 training_symbols: int = 2, max_iterations: int = 50, device: Optional[int] = None):
+        if getattr(config, "adaptive_eq_enabled", False):
+            raise _lib.UltraHipError(-2, "adaptive_eq_enabled (LMS/RLS) is not part of the built path")
+        torch = _torch()
+        self.config = config
+        self.cfg = make_c_config(config, entry=entry, n_data_symbols=n_data_symbols,
+                                 training_symbols=training_symbols, max_iterations=max_iterations)
+        self.lib = _lib.lib()
+        if not torch.cuda.is_available():
+            raise _lib.UltraHipError(-3, "ReceiveContext needs a HIP device (no CPU fallback exists)")
+        self.device_index = torch.cuda.current_device() if device is None else int(device)
+        self.device = torch.device("cuda", self.device_index)
+        with torch.cuda.device(self.device):
+            stream = torch.cuda.current_stream().cuda_stream
+        self._ctx = C.c_void_p()
+        check(self.lib.ultra_hip_create(C.byref(self.cfg), self.device_index, C.c_void_p(stream), C.byref(self._ctx)),
+              "ultra_hip_create")
+        self.geometry = ultra_hip_geometry()
+        check(self.lib.ultra_hip_get_geometry(self._ctx, C.byref(self.geometry)), "ultra_hip_get_geometry")
+
+    # ------------------------------------------------------------------ util
+    def close(self):
+        if getattr(self, "_ctx", None) is not None and self._ctx.value:
+            self.lib.ultra_hip_destroy(self._ctx)
+            self._ctx = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _dev(self, t, dtype, what):
+        torch = _torch()
+        if not isinstance(t, torch.Tensor):
+            t = torch.as_tensor(np.ascontiguousarray(t))
+        if t.device != self.device or t.dtype != dtype or not t.is_contiguous():
+            t = t.to(device=self.device, dtype=dtype).contiguous()
+        return t
+
+    def tanner_graph(self):
+        g = self.geometry
+        rp = np.zeros(g.ldpc_m + 1, np.uint32)
+        ci = np.zeros(g.ldpc_edges, np.uint32)
+        check(self.lib.ultra_hip_get_tanner_graph(self._ctx, rp.ctypes.data_as(C.POINTER(C.c_uint32)),
+                                                  ci.ctypes.data_as(C.POINTER(C.c_uint32))), "get_tanner_graph")
+        return rp, ci
+
+    def synchronize(self):
+        check(self.lib.ultra_hip_synchronize(self._ctx), "ultra_hip_synchronize")
+
+    def timer_begin(self):
+        check(self.lib.ultra_hip_timer_begin(self._ctx), "ultra_hip_timer_begin")
+
+    def timer_end(self) -> float:
+        ms = C.c_float(0)
+        check(self.lib.ultra_hip_timer_end(self._ctx, C.byref(ms)), "ultra_hip_timer_end")
+        return float(ms.value)
+
+    # ------------------------------------------------------------ hot path
+    def ldpc_decode(self, llr, want_total: bool = False):
+        """[n][648] f32 LLRs -> dict(bytes [n][ceil(k/8)] u8, iters [n] i32, ok [n] u8[, llr_total])."""
+        torch = _torch()
+        llr = self._dev(llr, torch.float32, "llr").reshape(-1, LDPC_BLOCK_SIZE)
+        n = llr.shape[0]
+        g = self.geometry
+        out = dict(bytes=torch.empty((n, g.decoded_bytes), dtype=torch.uint8, device=self.device),
+                   iters=torch.empty(n, dtype=torch.int32, device=self.device),
+                   ok=torch.empty(n, dtype=torch.uint8, device=self.device))
+        total = torch.empty((n, LDPC_BLOCK_SIZE), dtype=torch.float32, device=self.device) if want_total else None
+        check(self.lib.ultra_hip_ldpc_decode_batch(self._ctx, llr.data_ptr(), n, out["bytes"].data_ptr(),
+                                                   out["iters"].data_ptr(), out["ok"].data_ptr(),
+                                                   total.data_ptr() if want_total else None),
+              "ultra_hip_ldpc_decode_batch")
+        if want_total:
+            out["llr_total"] = total
+        return out
+
+    def _frames(self, audio):
+        torch = _torch()
+        audio = self._dev(audio, torch.float32, "audio")
+        if audio.dim() == 1:
+            audio = audio.reshape(1, -1)
+        if audio.shape[1] < self.geometry.frame_samples:
+            raise _lib.UltraHipError(-1, f"audio rows hold {audio.shape[1]} samples, frame needs "
+                                         f"{self.geometry.frame_samples}")
+        return audio
+
+    def _opt(self, v, n):
+        if v is None:
+            return None
+        torch = _torch()
+        v = self._dev(v, torch.float32, "per-frame scalar").reshape(-1)
+        if v.numel() != n:
+            raise _lib.UltraHipError(-1, "per-frame scalar array has the wrong length")
+        return v
+
+    def demod(self, audio, cfo_hz=None, cfo_phase=None, want_state: bool = False):
+        """audio [n][>=frame_samples] f32 -> LLRs [n][llrs_per_frame] (+ tracker state [n][8])."""
+        torch = _torch()
+        audio = self._frames(audio)
+        n = audio.shape[0]
+        cfo, cph = self._opt(cfo_hz, n), self._opt(cfo_phase, n)
+        llr = torch.empty((n, self.geometry.llrs_per_frame), dtype=torch.float32, device=self.device)
+        state = torch.empty((n, _lib.STATE_FLOATS), dtype=torch.float32, device=self.device) if want_state else None
+        check(self.lib.ultra_hip_demod_batch(self._ctx, audio.data_ptr(), audio.stride(0),
+                                             cfo.data_ptr() if cfo is not None else None,
+                                             cph.data_ptr() if cph is not None else None, n, llr.data_ptr(),
+                                             state.data_ptr() if want_state else None), "ultra_hip_demod_batch")
+        return (llr, state) if want_state else llr
+
+    def demod_decode(self, audio, cfo_hz=None, cfo_phase=None, want_llr: bool = False, out=None):
+        """Fused receive path -> dict(bytes, iters, ok[, llr])."""
+        torch = _torch()
+        audio = self._frames(audio)
+        n = audio.shape[0]
+        cfo, cph = self._opt(cfo_hz, n), self._opt(cfo_phase, n)
+        g = self.geometry
+        if out is None:
+            out = dict(bytes=torch.empty((n, g.decoded_bytes), dtype=torch.uint8, device=self.device),
+                       iters=torch.empty(n, dtype=torch.int32, device=self.device),
+                       ok=torch.empty(n, dtype=torch.uint8, device=self.device))
+        llr = torch.empty((n, g.llrs_per_frame), dtype=torch.float32, device=self.device) if want_llr else None
+        check(self.lib.ultra_hip_demod_decode_batch(self._ctx, audio.data_ptr(), audio.stride(0),
+                                                    cfo.data_ptr() if cfo is not None else None,
+                                                    cph.data_ptr() if cph is not None else None, n,
+                                                    llr.data_ptr() if want_llr else None, out["bytes"].data_ptr(),
+                                                    out["iters"].data_ptr(), out["ok"].data_ptr()),
+              "ultra_hip_demod_decode_batch")
+        if want_llr:
+            out["llr"] = llr
+        return out
+
+    def count_errors(self, result, payload, counters=None):
+        """Accumulate the Monte-Carlo counters (device int64[8]) for a decoded batch."""
+        torch = _torch()
+        payload = self._dev(payload, torch.uint8, "payload")
+        n, pb = payload.shape
+        if counters is None:
+            counters = torch.zeros(8, dtype=torch.int64, device=self.device)
+        check(self.lib.ultra_hip_count_errors(self._ctx, result["bytes"].data_ptr(), result["iters"].data_ptr(),
+                                              result["ok"].data_ptr(), payload.data_ptr(), pb, n,
+                                              counters.data_ptr()), "ultra_hip_count_errors")
+        return counters
+
+    def selftest_math(self, fn: int, a, b=None):
+        torch = _torch()
+        a = self._dev(a, torch.float32, "a")
+        b = self._dev(b, torch.float32, "b") if b is not None else None
+        out = torch.empty_like(a)
+        check(self.lib.ultra_hip_selftest_math(self._ctx, fn, a.data_ptr(), b.data_ptr() if b is not None else None,
+                                               out.data_ptr(), a.numel()), "ultra_hip_selftest_math")
+        return out

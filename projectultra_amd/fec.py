@@ -1,0 +1,85 @@
+"""LDPCDecoder — host-side mirror of ultra::LDPCDecoder (include/ultra/fec.hpp:48-77)
+running on the HIP batch kernel.  Same method names, argument meaning and failure
+behaviour (empty input -> empty result, lastDecodeSuccess() False) as the reference,
+so tests written against the reference class read the same here."""
+from __future__ import annotations
+
+import numpy as np
+
+from .engine import ReceiveContext
+from .types import CodeRate, LDPC_BLOCK_SIZE, ModemConfig, info_bits
+
+
+class LDPCDecoder:
+    def __init__(self, rate: CodeRate, device=None):
+        self._device = device
+        self._max_iterations = 50            # Impl::max_iterations default (ldpc_decoder.cpp:43)
+        self._last_success = False
+        self._last_iters = 0
+        self._ctx = None
+        self.setRate(rate)
+
+    # -- reference API ---------------------------------------------------
+    def setRate(self, rate: CodeRate) -> None:
+        self._rate = CodeRate(rate)
+        self._rebuild()
+
+    def getRate(self) -> CodeRate:
+        return self._rate
+
+    def setMaxIterations(self, max_iter: int) -> None:
+        self._max_iterations = int(max_iter)
+        self._rebuild()
+
+    def lastDecodeSuccess(self) -> bool:
+        return self._last_success
+
+    def lastIterations(self) -> int:
+        return self._last_iters
+
+    def decode(self, coded_data: bytes) -> bytes:
+        """Hard-bit input: +-6.0 LLRs (ldpc_decoder.cpp:267-281)."""
+        bits = np.unpackbits(np.frombuffer(bytes(coded_data), np.uint8))
+        return self.decodeSoft(np.where(bits == 1, -6.0, 6.0).astype(np.float32))
+
+    def decodeSoft(self, llrs) -> bytes:
+        """Bit-level multi-block semantics of LDPCDecoder::decodeSoft (ldpc_decoder.cpp:283-428)."""
+        llrs = np.ascontiguousarray(llrs, dtype=np.float32).reshape(-1)
+        if llrs.size == 0:
+            self._last_success = False
+            return b""
+        n, k = LDPC_BLOCK_SIZE, info_bits(self._rate)
+        nblocks = -(-llrs.size // n)
+        padded = np.zeros(nblocks * n, np.float32)
+        padded[:llrs.size] = llrs                       # short / tail blocks are zero padded
+        r = self.decode_batch(padded.reshape(nblocks, n))
+        ok, iters = r["ok"], r["iters"]
+        has_tail = (llrs.size % n) != 0 and nblocks > 1
+        # multi-block: success = all full blocks; a tail block decoded through decodeBP
+        # overwrites last_success with its own result (ldpc_decoder.cpp:396-407)
+        self._last_success = bool(ok[-1]) if (nblocks == 1 or has_tail) else bool(ok.all())
+        self._last_iters = int(iters[-1])
+        if nblocks == 1:
+            return r["bytes"][0].tobytes()
+        bits = np.unpackbits(r["bytes"], axis=1)[:, :k].reshape(-1)
+        return np.packbits(bits).tobytes()
+
+    # -- batch API (what the reference loops over) ------------------------
+    def decode_batch(self, llr, want_total: bool = False, to_host: bool = True):
+        """[n][648] LLRs -> dict(bytes, iters, ok[, llr_total]); numpy arrays when to_host."""
+        r = self._ctx.ldpc_decode(llr, want_total=want_total)
+        if to_host:
+            self._ctx.synchronize()
+            r = {k: v.cpu().numpy() for k, v in r.items()}
+        return r
+
+    # ---------------------------------------------------------------------
+    def _rebuild(self):
+        if self._ctx is not None:
+            self._ctx.close()
+        cfg = ModemConfig(code_rate=self._rate)
+        self._ctx = ReceiveContext(cfg, max_iterations=self._max_iterations, device=self._device)
+
+    @property
+    def context(self) -> ReceiveContext:
+        return self._ctx

@@ -1,0 +1,153 @@
+"""HipOfdmWaveform — the receive half of ultra::IWaveform (src/waveform/waveform_interface.hpp:
+47-157) on the HIP path, shaped like OFDMChirpWaveform (src/waveform/ofdm_chirp_waveform.cpp):
+an external synchroniser supplies timing + CFO, process() runs the presynced entry.
+
+Transmit-side members (generatePreamble / modulate) and detectSync belong to rows of the
+scope table that are not built (stimulus and acquisition); they raise NotImplementedError
+rather than pretending."""
+from __future__ import annotations
+
+import math
+from dataclasses import dataclass
+
+import numpy as np
+
+from .ofdm import OFDMDemodulator
+from .types import CodeRate, LDPC_BLOCK_SIZE, ModemConfig, Modulation, getBitsPerSymbol, is_differential
+
+
+@dataclass
+class SyncResult:                    # waveform_interface.hpp:33-40
+    detected: bool = False
+    start_sample: int = -1
+    correlation: float = 0.0
+    cfo_hz: float = 0.0
+    snr_estimate: float = 0.0
+    has_training: bool = False
+
+
+class HipOfdmWaveform:
+    def __init__(self, config: ModemConfig = None, device=None):
+        self._config = config or ModemConfig(use_pilots=True)
+        self._device = device
+        self._cfo_hz = 0.0
+        self._training_start_sample = 0
+        self._soft_bits = np.zeros(0, np.float32)
+        self._synced = False
+        self._init_components()
+
+    def _init_components(self):
+        self._demod = OFDMDemodulator(self._config, device=self._device)
+
+    # -- identification / configuration ------------------------------------
+    def getName(self) -> str:
+        return "OFDM_HIP"
+
+    def configure(self, mod: Modulation, rate: CodeRate) -> None:   # ofdm_chirp/cox_waveform.cpp configure()
+        self._config = self._config.with_mode(mod, rate)
+        self._init_components()
+
+    def getModulation(self) -> Modulation:
+        return self._config.modulation
+
+    def getCodeRate(self) -> CodeRate:
+        return self._config.code_rate
+
+    def setFrequencyOffset(self, cfo_hz: float) -> None:
+        self._cfo_hz = float(cfo_hz)
+
+    def getFrequencyOffset(self) -> float:
+        return self._cfo_hz
+
+    # -- RX ------------------------------------------------------------------
+    def detectSync(self, samples, result: SyncResult, threshold: float = 0.3) -> bool:
+        raise NotImplementedError("acquisition (Schmidl-Cox / dual-chirp) is the next scope row; "
+                                  "pass timing and CFO in with accept_sync()")
+
+    def accept_sync(self, result: SyncResult) -> None:
+        """Take the result of an external synchroniser (what detectSync would have filled in)."""
+        self._synced = bool(result.detected)
+        self._cfo_hz = float(result.cfo_hz)
+        self._training_start_sample = max(int(result.start_sample), 0)
+
+    def process(self, samples) -> bool:      # OFDMChirpWaveform::process, ofdm_chirp_waveform.cpp:174-215
+        sr = self._config.sample_rate
+        # float initial_phase_rad = -2.0f * M_PI * cfo_hz_ * training_start_sample_ / sample_rate (double expr)
+        phase = np.float32((((-2.0 * math.pi) * float(np.float32(self._cfo_hz))) * float(self._training_start_sample)) / float(sr))
+        while float(phase) > math.pi:
+            phase = np.float32(float(phase) - 2.0 * math.pi)
+        while float(phase) < -math.pi:
+            phase = np.float32(float(phase) + 2.0 * math.pi)
+        self._demod.reset()
+        self._demod.setFrequencyOffsetWithPhase(self._cfo_hz, float(phase))
+        ready = self._demod.processPresynced(samples, 2)
+        if ready:
+            chunks = []
+            while self._demod.hasPendingData():
+                c = self._demod.getSoftBits()
+                if c.size == 0:
+                    break
+                chunks.append(c)
+            self._soft_bits = np.concatenate(chunks) if chunks else np.zeros(0, np.float32)
+        return ready
+
+    def getSoftBits(self) -> np.ndarray:
+        out, self._soft_bits = self._soft_bits, np.zeros(0, np.float32)
+        return out
+
+    def reset(self) -> None:
+        self._demod.reset()
+        self._soft_bits = np.zeros(0, np.float32)
+        self._synced = False
+
+    def isSynced(self) -> bool:
+        return self._synced
+
+    def hasData(self) -> bool:
+        return self._soft_bits.size > 0 or self._demod.hasPendingData()
+
+    def estimatedSNR(self) -> float:
+        return self._demod.getEstimatedSNR()
+
+    def estimatedCFO(self) -> float:
+        return self._demod.getFrequencyOffset()
+
+    # -- geometry (ofdm_cox_waveform.cpp:214-258) ------------------------------
+    def getCarrierCount(self) -> int:
+        return self._config.num_carriers
+
+    def getSamplesPerSymbol(self) -> int:
+        return self._config.getSymbolDuration()
+
+    def getPreambleSamples(self) -> int:
+        return 2 * self.getSamplesPerSymbol()
+
+    def getMinSamplesForFrame(self) -> int:
+        c = self._config
+        data_carriers = c.num_carriers
+        if c.use_pilots and c.pilot_spacing > 0:
+            data_carriers = c.num_carriers - c.num_carriers // c.pilot_spacing
+        bits_per_symbol = data_carriers * getBitsPerSymbol(c.modulation)
+        data_symbols = (LDPC_BLOCK_SIZE + bits_per_symbol - 1) // bits_per_symbol
+        return 2 * self.getSamplesPerSymbol() + data_symbols * self.getSamplesPerSymbol()
+
+    def getThroughput(self, rate: CodeRate) -> float:
+        c = self._config
+        data_carriers = c.num_carriers
+        if c.use_pilots and c.pilot_spacing > 0:
+            data_carriers = c.num_carriers - c.num_carriers // c.pilot_spacing
+        ratio = {CodeRate.R1_4: 0.25, CodeRate.R1_3: 0.333, CodeRate.R1_2: 0.5, CodeRate.R2_3: 0.667,
+                 CodeRate.R3_4: 0.75, CodeRate.R5_6: 0.833}.get(CodeRate(rate), 0.5)
+        return (c.sample_rate / self.getSamplesPerSymbol()) * data_carriers * getBitsPerSymbol(c.modulation) * ratio
+
+    def getStatusString(self) -> str:
+        c = self._config
+        return f"OFDM-HIP {c.num_carriers} carriers, {Modulation(c.modulation).name} {CodeRate(c.code_rate).name}" + \
+            (" (pilots)" if c.use_pilots else "")
+
+    # -- TX: not part of the receive hot path ---------------------------------
+    def generatePreamble(self):
+        raise NotImplementedError("transmit side is outside the built receive path")
+
+    def modulate(self, encoded_data):
+        raise NotImplementedError("transmit side is outside the built receive path")

@@ -1,0 +1,51 @@
+"""Shared helpers for the parity tests."""
+import ctypes as C
+import numpy as np
+
+from oracle.bindings import Config, INFO_BITS, make_config, geometry  # noqa: F401
+
+
+def cfg_from_array(arr) -> Config:
+    c = Config()
+    for (name, _), v in zip(Config._fields_, arr.tolist()):
+        setattr(c, name, int(v))
+    return c
+
+
+def modem_config_from_c(c):
+    """ultra_hip_config -> projectultra_amd.ModemConfig + ReceiveContext kwargs."""
+    from projectultra_amd import CodeRate, CyclicPrefixMode, Entry, ModemConfig, Modulation
+    mc = ModemConfig(sample_rate=c.sample_rate, center_freq=c.center_freq, fft_size=c.fft_size,
+                     num_carriers=c.num_carriers, cp_mode=CyclicPrefixMode(c.cp_mode), symbol_guard=c.symbol_guard,
+                     pilot_spacing=c.pilot_spacing, use_pilots=bool(c.use_pilots),
+                     modulation=Modulation(c.modulation), code_rate=CodeRate(c.code_rate))
+    kw = dict(entry=Entry(c.entry), n_data_symbols=c.n_data_symbols, training_symbols=c.training_symbols or 2,
+              max_iterations=c.max_iterations)
+    return mc, kw
+
+
+def context_for(c):
+    from projectultra_amd import ReceiveContext
+    mc, kw = modem_config_from_c(c)
+    return ReceiveContext(mc, **kw)
+
+
+def beq(a, b):
+    a = np.ascontiguousarray(a); b = np.ascontiguousarray(b)
+    return a.shape == b.shape and a.dtype == b.dtype and np.array_equal(a.view(np.uint8), b.view(np.uint8))
+
+
+def noisy_codewords(oracle, rate, n, sigmas, seed):
+    """BPSK-over-AWGN LLRs 2y/sigma^2 for random codewords of `rate` (SURVEY.md §8d cfg4 shape)."""
+    rng = np.random.default_rng(seed)
+    k = INFO_BITS[rate]
+    llr = np.zeros((n, 648), np.float32)
+    payloads = np.zeros((n, k // 8), np.uint8)
+    for i in range(n):
+        pl = rng.integers(0, 256, k // 8, dtype=np.uint8)
+        payloads[i] = pl
+        bits = np.unpackbits(np.frombuffer(oracle.ldpc_encode(rate, pl.tobytes()), np.uint8))[:648].astype(np.float32)
+        s = sigmas[i % len(sigmas)]
+        y = (1 - 2 * bits) + rng.normal(0, s, 648)
+        llr[i] = (2 * y / (s * s)).astype(np.float32)
+    return llr, payloads

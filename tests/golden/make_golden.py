@@ -1,0 +1,199 @@
+#!/usr/bin/env python3
+"""Generate the golden fixtures in tests/golden/ from the COMPILED REFERENCE.
+
+Run in the build container (where /root/reference exists):
+    python tests/golden/make_golden.py
+It drives oracle/_ref/libultra_ref.so (secup/ProjectUltra's own sources compiled by
+oracle/Makefile + the extern "C" shim oracle/ref_shim.cpp) and stores only DATA:
+inputs and the reference's outputs.  Nothing from the reference's source text is stored.
+
+Fixtures
+  ldpc.npz     encoder known answers, decoder cases (LLRs in; bytes / success / iterations out)
+  tables.npz   carrier maps, pilot signs, interpolation tables, Zadoff-Chu for the benchmark configs
+  demod.npz    per mode: SYNCED-entry audio (data symbols only), initial CFO, the reference's LLRs,
+               per-symbol tracker scalars, decoded bytes / success / iterations
+  presynced.npz  processPresynced cases (training + data symbols, CFO, initial phase)
+  fullsync.npz full Schmidl-Cox receive of whole frames (OFDMDemodulator::process fed in 960-sample
+               chunks): sync offset, coarse CFO, LLRs, and the data-start offset at which the
+               SYNCED-entry loop reproduces those LLRs bit for bit
+"""
+import sys
+from pathlib import Path
+
+import numpy as np
+
+ROOT = Path(__file__).resolve().parents[2]
+sys.path.insert(0, str(ROOT))
+from oracle.bindings import INFO_BITS, Ref, geometry, make_config  # noqa: E402
+
+OUT = Path(__file__).resolve().parent
+r = Ref()
+rng = np.random.default_rng(20260128)
+
+
+def ldpc():
+    d = {}
+    payload = bytes((i * 7 + 0x42) & 0xFF for i in range(20))   # SURVEY.md §8c known answer
+    d["kat_payload"] = np.frombuffer(payload, np.uint8)
+    for rate in (0, 1, 2, 3, 4, 5):
+        enc = r.ldpc_encode(rate, payload)
+        d[f"kat_encoded_r{rate}"] = np.frombuffer(enc, np.uint8)
+        k = INFO_BITS[rate]
+        llrs, outs, oks, its = [], [], [], []
+        for case in range(24):
+            pl = bytes(rng.integers(0, 256, k // 8, dtype=np.uint8))
+            bits = np.unpackbits(np.frombuffer(r.ldpc_encode(rate, pl), np.uint8))[:648].astype(np.float32)
+            sigma = [0.35, 0.6, 0.8, 1.0, 1.3, 2.5][case % 6]
+            llr = ((2.0 * (1 - 2 * bits) + rng.normal(0, 2 * sigma, 648)) / sigma).astype(np.float32)
+            if case == 20: llr = np.zeros(648, np.float32)                    # erasures
+            if case == 21: llr = -llr                                          # inverted
+            if case == 22: llr = np.where(bits > 0, -6.0, 6.0).astype(np.float32)  # hard-decision input
+            if case == 23: llr = np.clip(llr * 100, -1e4, 1e4).astype(np.float32)  # saturating
+            out, ok, it = r.ldpc_decode_soft(rate, llr)
+            llrs.append(llr); outs.append(np.frombuffer(out, np.uint8)); oks.append(ok); its.append(it)
+        d[f"dec_llr_r{rate}"] = np.stack(llrs)
+        d[f"dec_bytes_r{rate}"] = np.stack(outs)
+        d[f"dec_ok_r{rate}"] = np.array(oks, np.uint8)
+        d[f"dec_iters_r{rate}"] = np.array(its, np.int32)
+        # the +-2.0 / mt19937(7) known answer of SURVEY.md §8c
+        import ctypes as C
+        bits = np.unpackbits(np.frombuffer(enc, np.uint8))[:648]
+        l = np.where(bits > 0, -2.0, 2.0).astype(np.float32)
+        mt = np.random.MT19937(); mt._legacy_seeding(7)
+        g = np.random.Generator(mt)  # raw 32-bit draws == std::mt19937(7)
+        draws = mt.random_raw(40)
+        for v in draws: l[int(v) % 648] *= -0.5
+        out, ok, it = r.ldpc_decode_soft(rate, l)
+        d[f"kat_flip_llr_r{rate}"] = l
+        d[f"kat_flip_iters_r{rate}"] = np.array([it, int(ok)], np.int32)
+        # multi-block (bit-level concatenation) and short input
+        for n in (300, 1296, 1500):
+            llr = rng.normal(0, 4, n).astype(np.float32)
+            out, ok, it = r.ldpc_decode_soft(rate, llr, 10)
+            d[f"mb_llr_r{rate}_{n}"] = llr
+            d[f"mb_out_r{rate}_{n}"] = np.frombuffer(out, np.uint8)
+            d[f"mb_meta_r{rate}_{n}"] = np.array([int(ok), it], np.int32)
+    np.savez_compressed(OUT / "ldpc.npz", **d)
+
+
+MODES = [  # name, fft, mod, rate, extra kwargs
+    ("cfg3_qam16_r34", 1024, "QAM16", "R3_4", {}),
+    ("cfg2_dqpsk_r12", 512, "DQPSK", "R1_2", {}),
+    ("qpsk_r12_512", 512, "QPSK", "R1_2", {}),
+    ("qam32_r34", 1024, "QAM32", "R3_4", {}),
+    ("d8psk_r34", 1024, "D8PSK", "R3_4", dict(pilot_spacing=2)),
+    ("dbpsk_r14", 512, "DBPSK", "R1_4", {}),
+    ("bpsk_r12", 512, "BPSK", "R1_2", {}),
+    ("qam64_r34", 512, "QAM64", "R3_4", {}),
+    ("qam256_r56", 512, "QAM256", "R5_6", {}),
+    ("dqpsk_pilots_r14", 512, "DQPSK", "R1_4", dict(use_pilots=1)),
+    ("qam16_r23_long", 1024, "QAM16", "R2_3", dict(n_data_symbols=12)),
+]
+
+
+def cfg_array(cfg):
+    return np.array([getattr(cfg, n) for n, _ in cfg._fields_], np.uint32)
+
+
+def tables():
+    d = {}
+    for name, fft, mod, rate, kw in MODES:
+        cfg = make_config(fft, mod, rate, **kw)
+        t = r.demod_tables(cfg)
+        d[f"{name}__cfg"] = cfg_array(cfg)
+        for k, v in t.items():
+            d[f"{name}__{k}"] = v
+    np.savez_compressed(OUT / "tables.npz", **d)
+
+
+def demod():
+    d = {}
+    for name, fft, mod, rate, kw in MODES:
+        cfg = make_config(fft, mod, rate, **kw)
+        g = geometry(cfg)
+        audio, cfos, llrs, scals, dec, meta = [], [], [], [], [], []
+        nfr = 4 if g.frame_samples > 6000 else 6
+        for t in range(nfr):
+            snr = [30, 18, 9, 30, 14, 6][t]
+            nbytes = (g.llrs_per_frame // 648 + 1) * (INFO_BITS[cfg.code_rate] // 8)
+            payload = bytes(rng.integers(0, 256, nbytes, dtype=np.uint8))
+            a, pre = r.harness_awgn(cfg, payload, snr, 4000 + t)
+            if t >= 3:   # Watterson good / moderate on top (src/sim/hf_channel.hpp presets)
+                a = r.watterson(a, snr, 0.5 if t < 5 else 1.0, 0.1 if t < 5 else 0.5, 900 + t)
+            shift = [0, 0, -4, 0, 0, -9][t]          # inside the CP: exercises timing tracking
+            x = a[pre + shift: pre + shift + g.frame_samples]
+            cfo = [0.0, 2.5, -0.8, 0.0, 0.004, -14.0][t]
+            l, st = r.demod_synced(cfg, x, cfo, stages=True)
+            out, ok, it = r.ldpc_decode_soft(cfg.code_rate, l[:648])
+            audio.append(x); cfos.append(cfo); llrs.append(l); scals.append(st["scal"])
+            dec.append(np.frombuffer(out, np.uint8)); meta.append([int(ok), it])
+        d[f"{name}__cfg"] = cfg_array(cfg)
+        d[f"{name}__audio"] = np.stack(audio).astype(np.float32)
+        d[f"{name}__cfo"] = np.array(cfos, np.float32)
+        d[f"{name}__llr"] = np.stack(llrs)
+        d[f"{name}__scal"] = np.stack(scals)
+        d[f"{name}__bytes"] = np.stack(dec)
+        d[f"{name}__meta"] = np.array(meta, np.int32)
+    np.savez_compressed(OUT / "demod.npz", **d)
+
+
+def presynced():
+    d = {}
+    from oracle.bindings import oracle
+    for name, fft, mod, rate, kw in [("ps_dqpsk", 512, "DQPSK", "R1_2", {}), ("ps_qam16", 1024, "QAM16", "R3_4", {}),
+                                     ("ps_d8psk", 1024, "D8PSK", "R3_4", dict(pilot_spacing=2)),
+                                     ("ps_qpsk", 512, "QPSK", "R1_2", {})]:
+        cfg = make_config(fft, mod, rate, entry=1, **kw)
+        g = geometry(cfg)
+        audio, par, llrs, scals = [], [], [], []
+        for t in range(4):
+            payload = bytes(rng.integers(0, 256, INFO_BITS[cfg.code_rate] // 8, dtype=np.uint8))
+            enc = r.ldpc_encode(cfg.code_rate, payload)
+            x = r.modulate_presynced(cfg, enc)
+            x = x * np.float32(0.5 / np.abs(x).max())
+            x = r.watterson(x, [30, 16, 9, 24][t], 0.5, 0.1, 300 + t, fading=t % 2, multipath=t % 2)[:g.frame_samples]
+            cfo, ph = [(0.0, 0.0), (3.0, 0.5), (-11.0, -2.0), (0.004, 0.1)][t]
+            l, H, sc = r.demod_presynced(cfg, x, cfo, ph)
+            audio.append(x); par.append([cfo, ph]); llrs.append(l); scals.append(sc)
+        d[f"{name}__cfg"] = cfg_array(cfg)
+        d[f"{name}__audio"] = np.stack(audio).astype(np.float32)
+        d[f"{name}__cfo_phase"] = np.array(par, np.float32)
+        d[f"{name}__llr"] = np.stack(llrs)
+        d[f"{name}__scal"] = np.stack(scals)
+    np.savez_compressed(OUT / "presynced.npz", **d)
+
+
+def fullsync():
+    """Whole frames through OFDMDemodulator::process (Schmidl-Cox search, 960-sample chunks)."""
+    d = {}
+    for name, fft, mod, rate, kw in MODES[:2]:
+        cfg = make_config(fft, mod, rate, **kw)
+        g = geometry(cfg)
+        rows = []
+        for t in range(3):
+            payload = bytes(rng.integers(0, 256, INFO_BITS[cfg.code_rate] // 8, dtype=np.uint8))
+            a, pre = r.harness_awgn(cfg, payload, 30.0, 12345 + t)
+            l_full, sync_off, cfo, final_cfo, fed = r.demod_process_coarse(cfg, a, 960)
+            found = -1
+            if l_full.size >= g.llrs_per_frame:
+                for off in range(pre - 64, pre + 65):
+                    x = a[off: off + g.frame_samples]
+                    if x.size < g.frame_samples: break
+                    l = r.demod_synced_public(cfg, x, cfo)
+                    if np.array_equal(l.view(np.uint32), l_full[:g.llrs_per_frame].view(np.uint32)):
+                        found = off; break
+            rows.append((a, pre, sync_off, cfo, found, l_full[:g.llrs_per_frame]))
+            print(name, "frame", t, "nominal data start", pre, "sync_offset", sync_off, "coarse cfo", cfo, "final", final_cfo,
+                  "SYNCED-entry reproduces process() at data start", found, "n_llr", l_full.size)
+        d[f"{name}__cfg"] = cfg_array(cfg)
+        d[f"{name}__audio"] = np.stack([x[0] for x in rows]).astype(np.float32)
+        d[f"{name}__meta"] = np.array([[x[1], x[2], x[4]] for x in rows], np.int32)
+        d[f"{name}__cfo"] = np.array([x[3] for x in rows], np.float32)
+        d[f"{name}__llr"] = np.stack([x[5] for x in rows])
+    np.savez_compressed(OUT / "fullsync.npz", **d)
+
+
+if __name__ == "__main__":
+    ldpc(); tables(); demod(); presynced(); fullsync()
+    for f in sorted(OUT.glob("*.npz")):
+        print(f.name, f.stat().st_size // 1024, "KiB")

@@ -1,0 +1,167 @@
+"""GPU parity: HIP demodulator (through the C-ABI) vs the committed reference fixtures and
+vs the oracle on seeded synthetic frames.  LLRs are compared BITWISE (stricter than the
+1e-5 tolerance of the north star); decoded bytes / iterations / success exactly."""
+import numpy as np
+import pytest
+
+from _util import INFO_BITS, beq, cfg_from_array, context_for, geometry, make_config
+from conftest import GOLDEN
+
+pytestmark = pytest.mark.gpu
+LLR_TOL = 1e-5     # north_star tolerance for soft LLRs; bitwise equality is asserted first
+
+MODES = ["cfg3_qam16_r34", "cfg2_dqpsk_r12", "qpsk_r12_512", "qam32_r34", "d8psk_r34", "dbpsk_r14", "bpsk_r12",
+         "qam64_r34", "qam256_r56", "dqpsk_pilots_r14", "qam16_r23_long"]
+
+
+def _check_llr(got, want, what):
+    if beq(got, want):
+        return
+    bad = np.flatnonzero(got.view(np.uint32).ravel() != want.view(np.uint32).ravel())
+    err = np.nanmax(np.abs(got.ravel()[bad] - want.ravel()[bad]))
+    raise AssertionError(f"{what}: {bad.size} LLRs differ bitwise (max abs err {err:g}, tol {LLR_TOL}); first {bad[:6]}")
+
+
+@pytest.mark.parametrize("name", MODES)
+def test_golden_reference_frames(name):
+    """Audio in, the compiled reference's LLRs / tracker state / decode results out."""
+    g = np.load(GOLDEN / "demod.npz")
+    cfg = cfg_from_array(g[f"{name}__cfg"])
+    ctx = context_for(cfg)
+    llr, state = ctx.demod(g[f"{name}__audio"], cfo_hz=g[f"{name}__cfo"], want_state=True)
+    ctx.synchronize()
+    llr, state = llr.cpu().numpy(), state.cpu().numpy()
+    _check_llr(llr, g[f"{name}__llr"], name)
+    scal = g[f"{name}__scal"][:, -1, :]             # tracker scalars after the last symbol
+    for col, idx in ((0, 0), (1, 1), (2, 2), (3, 3), (4, 4)):   # cfo, noise var, snr, timing, cfo phase
+        assert beq(state[:, idx], scal[:, col]), (name, "state", idx, state[:, idx], scal[:, col])
+    assert np.array_equal(state[:, 6], scal[:, 7])
+    if ctx.geometry.llrs_per_frame >= 648:
+        r = ctx.demod_decode(g[f"{name}__audio"], cfo_hz=g[f"{name}__cfo"], want_llr=True)
+        ctx.synchronize()
+        assert np.array_equal(r["bytes"].cpu().numpy(), g[f"{name}__bytes"])
+        assert np.array_equal(r["ok"].cpu().numpy(), g[f"{name}__meta"][:, 0])
+        assert np.array_equal(r["iters"].cpu().numpy(), g[f"{name}__meta"][:, 1])
+        _check_llr(r["llr"].cpu().numpy(), g[f"{name}__llr"], name + " fused")
+
+
+@pytest.mark.parametrize("name", ["ps_dqpsk", "ps_qam16", "ps_d8psk", "ps_qpsk"])
+def test_golden_presynced_frames(name):
+    g = np.load(GOLDEN / "presynced.npz")
+    cfg = cfg_from_array(g[f"{name}__cfg"])
+    ctx = context_for(cfg)
+    par = g[f"{name}__cfo_phase"]
+    llr, state = ctx.demod(g[f"{name}__audio"], cfo_hz=par[:, 0], cfo_phase=par[:, 1], want_state=True)
+    ctx.synchronize()
+    _check_llr(llr.cpu().numpy(), g[f"{name}__llr"], name)
+    st, sc = state.cpu().numpy(), g[f"{name}__scal"]
+    for col, idx in ((0, 0), (1, 1), (2, 2), (3, 3), (4, 4)):
+        assert beq(st[:, idx], sc[:, col]), (name, idx)
+
+
+@pytest.mark.parametrize("name", ["cfg3_qam16_r34", "cfg2_dqpsk_r12"])
+def test_full_sync_equivalence(name):
+    """Whole frames the reference received through OFDMDemodulator::process (Schmidl-Cox search,
+    960-sample chunks): entering our SYNCED entry at the data start with the coarse CFO the search
+    produced reproduces those LLRs bit for bit."""
+    g = np.load(GOLDEN / "fullsync.npz")
+    cfg = cfg_from_array(g[f"{name}__cfg"])
+    ctx = context_for(cfg)
+    fs = ctx.geometry.frame_samples
+    meta = g[f"{name}__meta"]
+    assert (meta[:, 2] >= 0).all()
+    audio = np.stack([a[s:s + fs] for a, s in zip(g[f"{name}__audio"], meta[:, 2])])
+    llr = ctx.demod(audio, cfo_hz=g[f"{name}__cfo"])
+    ctx.synchronize()
+    _check_llr(llr.cpu().numpy(), g[f"{name}__llr"], name)
+
+
+SYNTH = [("QAM16", "R3_4", 1024, {}, "watterson"), ("DQPSK", "R1_2", 512, {}, "awgn"),
+         ("QAM32", "R3_4", 1024, {}, "watterson"), ("D8PSK", "R3_4", 1024, dict(pilot_spacing=2), "awgn"),
+         ("QPSK", "R2_3", 512, {}, "watterson"), ("DBPSK", "R1_4", 512, {}, "awgn"),
+         ("QAM64", "R5_6", 512, {}, "awgn"), ("QAM16", "R1_2", 1024, dict(n_data_symbols=10), "watterson")]
+
+
+@pytest.mark.parametrize("mod,rate,fft,kw,chan", SYNTH)
+@pytest.mark.parametrize("snr", [30.0, 12.0, 4.0])
+def test_synthetic_batch_vs_oracle(oracle, mod, rate, fft, kw, chan, snr):
+    cfg = make_config(fft, mod, rate, **kw)
+    n = 192
+    audio, payload = oracle.make_batch(cfg, n, seed=0xABC + int(snr), channel=chan, snr_db=snr)
+    rng = np.random.default_rng(5)
+    cfo = np.where(np.arange(n) % 3 == 0, 0.0, rng.normal(0, 4.0, n)).astype(np.float32)
+    want = oracle.demod_decode_batch(cfg, audio, cfo_hz=cfo, n_threads=8)
+    ctx = context_for(cfg)
+    r = ctx.demod_decode(audio, cfo_hz=cfo, want_llr=True)
+    llr2, state = ctx.demod(audio, cfo_hz=cfo, want_state=True)
+    ctx.synchronize()
+    _check_llr(r["llr"].cpu().numpy(), want["llr"], f"{mod} {rate} {snr}")
+    assert beq(llr2.cpu().numpy(), want["llr"])
+    assert np.array_equal(r["bytes"].cpu().numpy(), want["bytes"])
+    assert np.array_equal(r["iters"].cpu().numpy(), want["iters"])
+    assert np.array_equal(r["ok"].cpu().numpy(), want["ok"])
+    st = state.cpu().numpy()
+    for idx in (0, 1, 2, 3, 4, 5):
+        assert beq(st[:, idx], want["state"][:, idx]), ("state", idx)
+
+
+@pytest.mark.parametrize("mod,rate,fft,kw", [("QAM16", "R3_4", 1024, {}), ("DQPSK", "R1_2", 512, {}),
+                                             ("D8PSK", "R3_4", 1024, dict(pilot_spacing=2)), ("QPSK", "R1_2", 512, {})])
+def test_synthetic_presynced_vs_oracle(oracle, mod, rate, fft, kw):
+    cfg = make_config(fft, mod, rate, entry=1, **kw)
+    n = 96
+    audio, payload = oracle.make_batch(cfg, n, seed=77, channel="awgn", snr_db=18.0)
+    rng = np.random.default_rng(9)
+    cfo = rng.normal(0, 6.0, n).astype(np.float32)
+    ph = rng.uniform(-3.1, 3.1, n).astype(np.float32)
+    want = oracle.demod_decode_batch(cfg, audio, cfo_hz=cfo, cfo_phase=ph, n_threads=8)
+    ctx = context_for(cfg)
+    r = ctx.demod_decode(audio, cfo_hz=cfo, cfo_phase=ph, want_llr=True)
+    ctx.synchronize()
+    _check_llr(r["llr"].cpu().numpy(), want["llr"], f"presynced {mod}")
+    assert np.array_equal(r["bytes"].cpu().numpy(), want["bytes"])
+    assert np.array_equal(r["iters"].cpu().numpy(), want["iters"])
+
+
+def test_ragged_and_strided_inputs(oracle):
+    """Rows longer than a frame (stride > frame_samples), one-frame batches, empty batches."""
+    import torch
+    cfg = make_config(1024, "QAM16", "R3_4")
+    audio, _ = oracle.make_batch(cfg, 5, seed=1, channel="awgn", snr_db=20.0)
+    want = oracle.demod_decode_batch(cfg, audio, n_threads=2)
+    ctx = context_for(cfg)
+    padded = np.concatenate([audio, np.full((5, 37), 9.0, np.float32)], axis=1)   # garbage past the frame
+    r = ctx.demod_decode(torch.from_numpy(padded).cuda(), want_llr=True)
+    one = ctx.demod(audio[2:3])
+    ctx.synchronize()
+    assert beq(r["llr"].cpu().numpy(), want["llr"])
+    assert beq(one.cpu().numpy(), want["llr"][2:3])
+    empty = ctx.demod_decode(torch.zeros((0, ctx.geometry.frame_samples), device="cuda"))
+    assert empty["bytes"].shape[0] == 0
+    from projectultra_amd import UltraHipError
+    with pytest.raises(UltraHipError):
+        ctx.demod(audio[:, :100])
+
+
+def test_device_math_matches_host_libm():
+    """pinned_math.h evaluated ON THE GPU equals the libm the reference calls, bit for bit."""
+    import ctypes, ctypes.util
+    libm = ctypes.CDLL(ctypes.util.find_library("m"))
+    for f in ("sinf", "cosf", "atanf"):
+        getattr(libm, f).restype = ctypes.c_float; getattr(libm, f).argtypes = [ctypes.c_float]
+    for f in ("atan2f", "hypotf"):
+        getattr(libm, f).restype = ctypes.c_float; getattr(libm, f).argtypes = [ctypes.c_float, ctypes.c_float]
+    cfg = make_config(1024, "QAM16", "R3_4")
+    ctx = context_for(cfg)
+    rng = np.random.default_rng(17)
+    n = 200_000
+    a = np.concatenate([rng.uniform(-7, 7, n // 2), rng.normal(0, 100, n // 4), rng.normal(0, 1e-3, n // 4)]).astype(np.float32)
+    a[:8] = [0.0, -0.0, np.pi, -np.pi, 1.0, 120.0, 1e-30, 3e4]
+    b = rng.normal(0, 3, n).astype(np.float32); b[::97] = 0.0; b[1::97] = 1.0
+    for fn, name in enumerate(["sinf", "cosf", "atanf", "atan2f", "hypotf"]):
+        got = ctx.selftest_math(fn, a, b if fn >= 3 else None)
+        ctx.synchronize()
+        got = got.cpu().numpy()
+        f = getattr(libm, name)
+        want = np.array([f(x) if fn < 3 else f(x, y) for x, y in zip(a.tolist(), b.tolist())], np.float32)
+        assert beq(got, want), (name, np.flatnonzero(got.view(np.uint32) != want.view(np.uint32))[:5])

@@ -1,0 +1,76 @@
+// tools/pinned_math_check.cpp — host check of projectultra_amd/csrc/pinned_math.h
+// against the libm of this machine (the functions the reference binary calls).
+//   g++ -O2 -std=c++17 -ffp-contract=off -mfma -pthread tools/pinned_math_check.cpp -o /tmp/pmc -lm
+//   /tmp/pmc full      # all 2^32 floats for sinf/cosf/sincosf/atanf, 2^31 random pairs atan2f/hypotf
+//   /tmp/pmc quick     # strided subset (used by tests/test_pinned_math.py)
+// Prints one line per function: "<name> checked=<n> mismatches=<m>".  Exit code 1 on any mismatch.
+#include <cmath>
+#include <cstdint>
+#include <cstdio>
+#include <cstring>
+#include <thread>
+#include <vector>
+#include <atomic>
+#include "../projectultra_amd/csrc/pinned_math.h"
+
+static inline bool same(float a, float b) {
+    uint32_t x, y; memcpy(&x, &a, 4); memcpy(&y, &b, 4);
+    if (x == y) return true;
+    return (a != a) && (b != b);  // any NaN == any NaN
+}
+static inline uint64_t splitmix(uint64_t& s) {
+    uint64_t z = (s += 0x9E3779B97F4A7C15ull);
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull; z = (z ^ (z >> 27)) * 0x94D049BB133111EBull; return z ^ (z >> 31);
+}
+
+int main(int argc, char** argv) {
+    bool full = argc > 1 && !strcmp(argv[1], "full");
+    const unsigned T = std::max(1u, std::thread::hardware_concurrency());
+    const uint64_t stride = full ? 1 : 1021;            // prime stride for the quick subset
+    const uint64_t pairs = full ? (1ull << 31) : (1ull << 24);
+    std::atomic<uint64_t> bad[6]; for (auto& b : bad) b = 0;
+    std::atomic<uint64_t> cnt[6]; for (auto& c : cnt) c = 0;
+    std::vector<std::thread> th;
+    for (unsigned t = 0; t < T; ++t) th.emplace_back([&, t] {
+        uint64_t lb[6] = {0}, lc[6] = {0};
+        for (uint64_t u = t * stride; u < (1ull << 32); u += (uint64_t)T * stride) {
+            float x = um::as_f32((uint32_t)u);
+            float s, c; sincosf(x, &s, &c);
+            lc[0]++; if (!same(um::sinf_(x), sinf(x))) { if (lb[0]++ < 3) fprintf(stderr, "sinf %08x\n", (unsigned)u); }
+            lc[1]++; if (!same(um::cosf_(x), cosf(x))) { if (lb[1]++ < 3) fprintf(stderr, "cosf %08x\n", (unsigned)u); }
+            lc[2]++; if (!same(um::sinf_(x), s) || !same(um::cosf_(x), c)) lb[2]++;
+            lc[3]++; if (!same(um::atanf_(x), atanf(x))) { if (lb[3]++ < 3) fprintf(stderr, "atanf %08x\n", (unsigned)u); }
+        }
+        uint64_t seed = 0x1234 + t;
+        for (uint64_t i = t; i < pairs; i += T) {
+            uint64_t r = splitmix(seed);
+            uint32_t a = (uint32_t)r, b = (uint32_t)(r >> 32);
+            int mode = (int)(i % 4);
+            float y, x;
+            if (mode == 0) { y = um::as_f32(a); x = um::as_f32(b); }              // any bit patterns
+            else if (mode == 1) { y = ((int32_t)a) * 0x1p-27f; x = ((int32_t)b) * 0x1p-27f; }  // moderate magnitudes
+            else if (mode == 2) { y = ((int32_t)a) * 0x1p-31f; x = ((int32_t)b) * 0x1p-24f; }
+            else { y = um::as_f32((a & 0x807fffffu) | 0x3f000000u); x = um::as_f32((b & 0x807fffffu) | 0x3f800000u); }
+            lc[4]++; if (!same(um::atan2f_(y, x), atan2f(y, x))) { if (lb[4]++ < 3) fprintf(stderr, "atan2f %a %a\n", y, x); }
+            lc[5]++; if (!same(um::hypotf_(y, x), hypotf(y, x))) { if (lb[5]++ < 3) fprintf(stderr, "hypotf %a %a\n", y, x); }
+        }
+        // atan2f/hypotf special values grid
+        if (t == 0) {
+            const float sp[] = {0.0f, -0.0f, 1.0f, -1.0f, INFINITY, -INFINITY, NAN, 1e-45f, -1e-45f, 1e30f, -1e30f,
+                                1e-30f, 3.4e38f, 0.5f, 2.0f, 1.17549435e-38f};
+            for (float y : sp) for (float x : sp) {
+                lc[4]++; if (!same(um::atan2f_(y, x), atan2f(y, x))) lb[4]++;
+                lc[5]++; if (!same(um::hypotf_(y, x), hypotf(y, x))) lb[5]++;
+            }
+        }
+        for (int k = 0; k < 6; ++k) { bad[k] += lb[k]; cnt[k] += lc[k]; }
+    });
+    for (auto& x : th) x.join();
+    const char* names[6] = {"sinf", "cosf", "sincosf", "atanf", "atan2f", "hypotf"};
+    int rc = 0;
+    for (int k = 0; k < 6; ++k) {
+        printf("%s checked=%llu mismatches=%llu\n", names[k], (unsigned long long)cnt[k].load(), (unsigned long long)bad[k].load());
+        if (bad[k].load()) rc = 1;
+    }
+    return rc;
+}
