@@ -331,6 +331,20 @@ class Ref(_Base):
                                               C.byref(fs))
         return llr[:n].copy(), so.value, cc.value, fc.value, fs.value
 
+    def demod_decode_batch(self, cfg, audio, cfo_hz=None):
+        """The reference's own classes over SYNCED-entry frames, one thread → dict(bytes, iters, ok)."""
+        audio = _f32(audio)
+        g = geometry(cfg)
+        n, stride = audio.shape
+        by = np.zeros((n, g.decoded_bytes), np.uint8); it = np.zeros(n, np.int32); ok = np.zeros(n, np.uint8)
+        cfo = _f32(cfo_hz) if cfo_hz is not None else None
+        rc = self.lib.ref_demod_decode_batch(C.byref(cfg), _ptr(audio), C.c_size_t(stride),
+                                             _ptr(cfo) if cfo is not None else None, C.c_uint32(n),
+                                             _ptr(by, C.c_uint8), C.c_uint32(g.decoded_bytes), _ptr(it, C.c_int32),
+                                             _ptr(ok, C.c_uint8))
+        assert rc == 0
+        return dict(bytes=by, iters=it, ok=ok)
+
     def demod_synced_public(self, cfg, audio, cfo_hz=0.0):
         audio = _f32(audio)
         g = geometry(cfg)

@@ -353,6 +353,47 @@ int ref_demod_synced(const ultra_hip_config* c, const float* audio, uint32_t n_s
     return (int)sb.size();
 }
 
+// CPU baseline of kind "reference": the reference's own classes over a batch of SYNCED-entry
+// frames on ONE thread — one OFDMDemodulator and one LDPCDecoder for the whole run (the tools
+// construct them per trial, tools/test_nvis_mode.cpp:43-46; reusing them only removes
+// constructor time), state re-forced per frame as in ref_demod_synced, then the first 648 soft
+// bits decoded (tools/test_nvis_mode.cpp:96-103).
+int ref_demod_decode_batch(const ultra_hip_config* c, const float* audio, size_t frame_stride,
+                           const float* cfo_hz, uint32_t n_frames, uint8_t* bytes_out, uint32_t bytes_per_frame,
+                           int32_t* iters_out, uint8_t* ok_out) {
+    StderrMute mute;
+    ModemConfig cfg = to_cfg(c);
+    OFDMDemodulator demod(cfg);
+    LDPCDecoder dec(cfg.code_rate);
+    dec.setMaxIterations((int)c->max_iterations);
+    auto* im = demod.impl_.get();
+    const size_t S = im->symbol_samples;
+    for (uint32_t f = 0; f < n_frames; ++f) {
+        const float* a = audio + (size_t)f * frame_stride;
+        float cfo = cfo_hz ? cfo_hz[f] : 0.0f;
+        demod.reset();
+        im->freq_offset_hz = cfo; im->freq_offset_filtered = cfo; im->freq_correction_phase = 0.0f;
+        im->symbols_since_sync = 0;
+        im->state.store(OFDMDemodulator::Impl::State::SYNCED);
+        im->carrier_phase_initialized = false; im->carrier_phase_correction = Complex(1, 0);
+        im->timing_offset_samples = 0.0f;
+        for (uint32_t s = 0; s < c->n_data_symbols; ++s) {
+            auto bb = im->toBaseband(SampleSpan(a + (size_t)s * S, S));
+            auto fd = im->extractSymbol(bb, 0);
+            im->updateChannelEstimate(fd);
+            auto eq = im->equalize(fd);
+            im->demodulateSymbol(eq, cfg.modulation);
+        }
+        if (im->soft_bits.size() < 648) { ok_out[f] = 0; iters_out[f] = 0; std::memset(bytes_out + (size_t)f * bytes_per_frame, 0, bytes_per_frame); continue; }
+        Bytes r = dec.decodeSoft(std::span<const float>(im->soft_bits.data(), 648));
+        if (r.size() != bytes_per_frame) return -1;
+        std::memcpy(bytes_out + (size_t)f * bytes_per_frame, r.data(), r.size());
+        iters_out[f] = dec.lastIterations();
+        ok_out[f] = dec.lastDecodeSuccess() ? 1 : 0;
+    }
+    return 0;
+}
+
 // Same entry but through the public API only: state forced to SYNCED, then
 // ONE process() call with all data symbols (cross-check of the stage driver).
 int ref_demod_synced_public(const ultra_hip_config* c, const float* audio, uint32_t n_symbols,
