@@ -1,0 +1,98 @@
+"""Host-side mirror of the reference interface + multi-rank sharding (CPU only)."""
+import os
+import subprocess
+import sys
+from pathlib import Path
+
+import numpy as np
+import pytest
+
+ROOT = Path(__file__).resolve().parent.parent
+
+
+def test_modem_config_mirror():
+    """include/ultra/types.hpp:139-234,262-367 — defaults, helpers and presets."""
+    from projectultra_amd import CodeRate, ModemConfig, Modulation, presets, getBitsPerSymbol
+    c = ModemConfig()
+    assert (c.fft_size, c.num_carriers, c.getCyclicPrefix(), c.getSymbolDuration(), c.getDataCarriers()) == (512, 30, 48, 564, 15)
+    n = presets.nvis_mode()
+    assert (n.fft_size, n.num_carriers, n.getCyclicPrefix(), n.getSymbolDuration(), n.use_pilots) == (1024, 59, 96, 1120, False)
+    q = n.with_mode(Modulation.QAM16, CodeRate.R3_4); q.pilot_spacing = 4
+    assert q.use_pilots and q.getDataCarriers() == 44                 # 59 - ceil(59/4)
+    assert presets.high_throughput().pilot_spacing == 4 and presets.turbo().getCyclicPrefix() == 32
+    assert [getBitsPerSymbol(m) for m in (Modulation.DBPSK, Modulation.DQPSK, Modulation.D8PSK, Modulation.QAM16,
+                                          Modulation.QAM32, Modulation.QAM64, Modulation.QAM256)] == [1, 2, 3, 4, 5, 6, 8]
+    assert abs(q.getTheoreticalThroughput(Modulation.QAM16, CodeRate.R3_4) - 44 * 4 * 0.75 * 48000 / 1120) < 1e-6
+
+
+def test_c_config_matches_harness_config():
+    """make_c_config(ModemConfig) == the POD the oracle tests use for the same mode."""
+    import ctypes as C
+    from oracle.bindings import make_config
+    from projectultra_amd import CodeRate, Entry, ModemConfig, Modulation, presets
+    from projectultra_amd.engine import make_c_config
+    mc = presets.nvis_mode().with_mode(Modulation.QAM16, CodeRate.R3_4); mc.pilot_spacing = 4
+    a, b = make_c_config(mc), make_config(1024, "QAM16", "R3_4")
+    assert bytes(a) == bytes(b)
+    mc = ModemConfig().with_mode(Modulation.DQPSK, CodeRate.R1_2)
+    assert bytes(make_c_config(mc)) == bytes(make_config(512, "DQPSK", "R1_2"))
+    assert bytes(make_c_config(mc, entry=Entry.PRESYNCED)) == bytes(make_config(512, "DQPSK", "R1_2", entry=1))
+
+
+def test_waveform_geometry_getters():
+    """OFDMNvisWaveform geometry (src/waveform/ofdm_cox_waveform.cpp:214-258)."""
+    from projectultra_amd import CodeRate, ModemConfig, Modulation
+    from projectultra_amd.waveform import HipOfdmWaveform
+    w = HipOfdmWaveform.__new__(HipOfdmWaveform)           # geometry needs no device
+    w._config = ModemConfig(use_pilots=True)
+    assert w.getSamplesPerSymbol() == 564 and w.getPreambleSamples() == 1128
+    assert w.getMinSamplesForFrame() == 2 * 564 + 22 * 564   # QPSK, 15 data carriers -> 22 symbols
+    assert w.getCarrierCount() == 30
+
+
+def test_shard_range_partitions_exactly():
+    from projectultra_amd.montecarlo import shard_range
+    for n in (0, 1, 7, 1 << 20, (1 << 22) + 3):
+        for w in (1, 2, 3, 4, 8):
+            spans = [shard_range(n, r, w) for r in range(w)]
+            assert spans[0][0] == 0 and spans[-1][1] == n
+            assert all(a[1] == b[0] for a, b in zip(spans, spans[1:]))
+            assert max(hi - lo for lo, hi in spans) - min(hi - lo for lo, hi in spans) <= 1
+    with pytest.raises(ValueError):
+        shard_range(10, 2, 2)
+
+
+WORKER = r'''
+import os, sys, torch, torch.distributed as dist
+sys.path.insert(0, sys.argv[1])
+from projectultra_amd.montecarlo import run_sharded, counters_dict
+rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+dist.init_process_group("gloo", rank=rank, world_size=world)
+N = 1001
+def run_shard(lo, hi):      # stand-in for the per-rank GPU pass: counters derived from frame ids
+    ids = torch.arange(lo, hi, dtype=torch.int64)
+    return torch.stack([torch.tensor(hi - lo), (ids % 7 == 0).sum(), (ids % 5).sum(), torch.tensor((hi - lo) * 480),
+                        (ids % 11 == 0).sum(), (ids % 3).sum(), torch.tensor(0), torch.tensor(0)]).to(torch.int64)
+c = run_sharded(N, rank, world, run_shard)
+ids = torch.arange(N)
+want = [N, int((ids % 7 == 0).sum()), int((ids % 5).sum()), N * 480, int((ids % 11 == 0).sum()), int((ids % 3).sum()), 0, 0]
+assert c.tolist() == want, (c.tolist(), want)
+d = counters_dict(c)
+assert d["frames"] == N and abs(d["fer"] - want[1] / N) < 1e-12
+dist.destroy_process_group()
+print("rank", rank, "ok")
+'''
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_counter_allreduce_across_ranks_gloo(tmp_path, world):
+    """N>1 path: contiguous shards, one all-reduce of the 8 counters (gloo on CPU; RCCL on the GPUs)."""
+    script = tmp_path / "worker.py"
+    script.write_text(WORKER)
+    port = 29500 + os.getpid() % 2000 + world
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={world}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), str(script), str(ROOT)]
+    env = dict(os.environ, OMP_NUM_THREADS="1")
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=240)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    assert r.stdout.count("ok") == world

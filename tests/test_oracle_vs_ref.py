@@ -1,0 +1,122 @@
+"""Oracle vs the compiled reference, live (needs oracle/_ref, i.e. the build container or a
+box that received the prebuilt .so).  Everything is compared BITWISE, stage by stage."""
+import numpy as np
+import pytest
+
+from _util import beq
+from oracle.bindings import INFO_BITS, geometry, make_config
+
+
+def test_fec(oracle, ref):
+    rng = np.random.default_rng(1)
+    for rate in range(6):
+        pl = bytes(rng.integers(0, 256, 150, dtype=np.uint8))
+        assert oracle.ldpc_encode(rate, pl) == ref.ldpc_encode(rate, pl)
+        k = INFO_BITS[rate]
+        enc = oracle.ldpc_encode(rate, bytes(rng.integers(0, 256, k // 8, dtype=np.uint8)))
+        bits = np.unpackbits(np.frombuffer(enc, np.uint8))[:648].astype(np.float32)
+        for sigma in (0.4, 0.8, 1.2):
+            llr = ((2 * (1 - 2 * bits) + rng.normal(0, 2 * sigma, 648)) / sigma).astype(np.float32)
+            assert oracle.ldpc_decode_soft(rate, llr) == ref.ldpc_decode_soft(rate, llr)
+        for n in (100, 649, 2000):
+            llr = rng.normal(0, 3, n).astype(np.float32)
+            assert oracle.ldpc_decode_soft(rate, llr, 6) == ref.ldpc_decode_soft(rate, llr, 6)
+
+
+def test_interleavers(oracle, ref):
+    x = np.random.default_rng(2).normal(size=648).astype(np.float32)
+    assert beq(oracle.interleaver_deinterleave(6, 108, x), ref.interleaver_deinterleave(6, 108, x))
+    for bps in (60, 116, 176):
+        p, inv = oracle.channel_interleaver_perm(bps)
+        mine = np.zeros(648, np.float32); mine[inv] = x          # out[inverse_permutation[i]] = in[i]
+        assert beq(mine, ref.channel_interleaver(bps, x, inverse=True))
+        mine = np.zeros(648, np.float32); mine[p] = x
+        assert beq(mine, ref.channel_interleaver(bps, x, inverse=False))
+
+
+def test_fft_nco_cdiv(oracle, ref):
+    rng = np.random.default_rng(3)
+    for n in (64, 512, 1024):
+        x = (rng.normal(size=n) + 1j * rng.normal(size=n)).astype(np.complex64)
+        assert beq(oracle.fft_forward(x), ref.fft_forward(x)) and beq(oracle.fft_inverse(x), ref.fft_inverse(x))
+    assert beq(oracle.nco(1500, 48000, 30000), ref.nco(1500, 48000, 30000))
+
+
+CASES = [("QAM16", "R3_4", 1024, {}), ("DQPSK", "R1_2", 512, {}), ("QPSK", "R1_2", 512, {}), ("QAM32", "R3_4", 1024, {}),
+         ("D8PSK", "R3_4", 1024, dict(pilot_spacing=2)), ("DBPSK", "R1_4", 512, {}), ("BPSK", "R1_2", 512, {}),
+         ("QAM64", "R3_4", 512, {}), ("QAM256", "R5_6", 512, {}), ("DQPSK", "R1_4", 512, dict(use_pilots=1)),
+         ("QAM16", "R2_3", 1024, dict(n_data_symbols=12))]
+
+
+@pytest.mark.parametrize("mod,rate,fft,kw", CASES)
+def test_tables_modulator_demodulator(oracle, ref, mod, rate, fft, kw):
+    cfg = make_config(fft, mod, rate, **kw)
+    g = geometry(cfg)
+    ta, tb = oracle.demod_tables(cfg), ref.demod_tables(cfg)
+    assert all(beq(ta[k], tb[k]) for k in ta)
+    rng = np.random.default_rng(hash((mod, rate)) & 0xFFFF)
+    for trial in range(6):
+        nbytes = (g.llrs_per_frame // 648 + 1) * (INFO_BITS[cfg.code_rate] // 8)
+        payload = bytes(rng.integers(0, 256, nbytes, dtype=np.uint8))
+        enc = oracle.ldpc_encode(cfg.code_rate, payload)
+        (a, pa), (b, pb) = oracle.modulate_frame(cfg, enc), ref.modulate_frame(cfg, enc)
+        assert pa == pb and beq(a, b)
+        audio, pre = ref.harness_awgn(cfg, payload, [30, 15, 6][trial % 3], 10 + trial)
+        if trial >= 3:
+            audio = ref.watterson(audio, 20.0, 0.5 if trial < 5 else 2.0, 0.1 if trial < 5 else 1.0, 70 + trial)
+        shift = [0, -5, 0, -11, 0, 3][trial]
+        x = audio[pre + shift: pre + shift + g.frame_samples]
+        cfo = [0.0, 1.7, -3.2, 0.005, 12.5, -0.4][trial]
+        la, sa = oracle.demod_synced(cfg, x, cfo, stages=True)
+        lb, sb = ref.demod_synced(cfg, x, cfo, stages=True)
+        assert beq(lb, ref.demod_synced_public(cfg, x, cfo))       # the stage driver IS process()
+        for k in sa:
+            assert beq(sa[k], sb[k]), (mod, trial, k)
+        assert beq(la, lb)
+
+
+@pytest.mark.parametrize("mod,rate,fft,kw", [("DQPSK", "R1_2", 512, {}), ("QAM16", "R3_4", 1024, {}),
+                                             ("D8PSK", "R3_4", 1024, dict(pilot_spacing=2)), ("QPSK", "R1_2", 512, {}),
+                                             ("DBPSK", "R1_4", 512, {})])
+def test_presynced(oracle, ref, mod, rate, fft, kw):
+    cfg = make_config(fft, mod, rate, entry=1, **kw)
+    g = geometry(cfg)
+    rng = np.random.default_rng(5)
+    for trial in range(6):
+        enc = oracle.ldpc_encode(cfg.code_rate, bytes(rng.integers(0, 256, INFO_BITS[cfg.code_rate] // 8, dtype=np.uint8)))
+        a, b = oracle.modulate_presynced(cfg, enc), ref.modulate_presynced(cfg, enc)
+        assert beq(a, b)
+        x = a * np.float32(0.5 / np.abs(a).max())
+        x = ref.watterson(x, [30, 18, 10][trial % 3], 0.5, 0.1, 5 + trial, fading=trial % 2, multipath=trial % 2)
+        x = x[:g.frame_samples]
+        cfo, ph = [(0, 0), (3.0, 0.5), (-11.0, -2.0), (0.004, 0.1), (45.0, 3.0), (-2.0, -3.1)][trial]
+        la, Ha, sa = oracle.demod_presynced(cfg, x, cfo, ph)
+        lb, Hb, sb = ref.demod_presynced(cfg, x, cfo, ph)
+        assert beq(la, lb) and beq(Ha, Hb) and beq(sa, sb), (mod, trial)
+
+
+def test_reference_batch_baseline_equals_oracle_batch(oracle, ref):
+    cfg = make_config(1024, "QAM16", "R3_4")
+    audio, _ = oracle.make_batch(cfg, 48, seed=9, channel="watterson", snr_db=30.0)
+    a = oracle.demod_decode_batch(cfg, audio, n_threads=4)
+    b = ref.demod_decode_batch(cfg, audio)
+    assert np.array_equal(a["bytes"], b["bytes"]) and np.array_equal(a["iters"], b["iters"]) and np.array_equal(a["ok"], b["ok"])
+
+
+def test_complex_division_is_the_double_formula():
+    """libgcc __divsc3 of this image == the double-precision formula the oracle and kernels use."""
+    import subprocess, tempfile, textwrap, os
+    src = textwrap.dedent(r'''
+        #include <complex>
+        #include <cstdio>
+        #include <cstring>
+        #include <random>
+        typedef std::complex<float> C;
+        int main(){ std::mt19937 r(1); std::uniform_real_distribution<float> u(-20,20); long bad=0;
+          for(long i=0;i<2000000;i++){ C x(u(r),u(r)), y(u(r),u(r)); volatile float yr=y.real(); C q=x/C(yr,y.imag());
+            double a=x.real(),b=x.imag(),c=y.real(),d=y.imag(),den=c*c+d*d; C w((float)((a*c+b*d)/den),(float)((b*c-a*d)/den));
+            if(memcmp(&q,&w,8)) bad++; } printf("%ld\n",bad); }''')
+    with tempfile.TemporaryDirectory() as td:
+        p = os.path.join(td, "d.cpp"); open(p, "w").write(src)
+        subprocess.check_call(["g++", "-O2", "-std=c++17", p, "-o", os.path.join(td, "d")])
+        assert subprocess.check_output([os.path.join(td, "d")]).strip() == b"0"
