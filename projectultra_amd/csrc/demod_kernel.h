@@ -1,4 +1,4 @@
-// demod_kernel.h — batched OFDM demodulation for gfx950 (one workgroup per frame).
+// demod_kernel.h — batched OFDM demodulation for gfx950: ONE WAVEFRONT PER FRAME.
 //
 // Restates, with the reference's exact float/double operation order, the
 // per-symbol chain of OFDMDemodulator (SYNCED loop src/ofdm/demodulator.cpp:
@@ -11,30 +11,37 @@
 //   equalize              src/ofdm/channel_equalizer.cpp:728-840
 //   demodulateSymbol      src/ofdm/demodulator.cpp:199-435 + src/ofdm/soft_demap.hpp
 //
-// Mapping: frames are independent (fresh demodulator per frame in every
-// reference harness), symbols inside a frame are sequential (CFO / channel /
-// noise tracking feed forward), so one 256-thread workgroup owns one frame and
-// walks its symbols in order.  Inside a symbol everything that is
-// data-parallel runs across lanes (mixing, butterflies, per-pilot and
-// per-carrier maths); every reduction the reference performs as a serial float
-// sum (pilot sums, noise, CFO, timing regression, fade average) is summed by
-// ONE lane in the reference's order so results are bit-identical.
-//
-// Bytes: the audio row of a frame is read exactly once, coalesced; the NCO and
-// twiddle tables (tens of KB, shared by all frames) stay in L2; LLRs are
-// written once.  Device code is compiled with -ffp-contract=off.
+// Mapping (MI355X, wave64): frames are independent, symbols inside a frame are
+// sequential (CFO / channel / noise tracking feed forward).  One 64-lane wavefront
+// owns one frame; a CU keeps ~15 frames in flight (LDS-bound, ~10 KB each), so the
+// short serial stretches of one frame hide behind the butterflies of the others.
+//   * mixing: every lane loads the 8/16 time samples it needs for the first FFT
+//     stages straight from HBM (the wave reads 64 consecutive floats per load; the
+//     cyclic prefix and guard are never fetched), multiplies by the NCO table and
+//     by the CFO rotation.  The CFO phase of sample i comes from the exact closed
+//     form of the reference's serial float recurrence (phase_table.h).
+//   * FFT: the reference's radix-2 DIT butterflies with its float twiddle table,
+//     executed in three register-resident groups of stages with two LDS transposes
+//     in between; only the two output bins per lane that the carriers use are
+//     produced by the last stages (pruning changes no surviving value).
+//   * tracking: one lane per pilot / carrier; every float sum the reference forms
+//     serially is accumulated in the same order from lane to lane with
+//     v_readlane (all lanes hold the identical running sum) — bit-identical.
+//   * demap: one lane per data carrier, LLRs stored straight to HBM.
+// Device code is compiled with -ffp-contract=off.
 #ifndef ULTRA_DEMOD_KERNEL_H
 #define ULTRA_DEMOD_KERNEL_H
 
 #include <hip/hip_runtime.h>
 #include "device_types.h"
 #include "pinned_math.h"
+#include "phase_table.h"
 
 namespace ultra_hip {
 namespace dev {
 
-constexpr int kDemodThreads = 256;
-constexpr int kMaxSymLen = 1280;   // 1024 + 2*64*... cp LONG at 1024 = 128, guard <= 128
+constexpr int kWave = 64;
+constexpr int kPhaseCap = 48;      // phase segments per table round (typical symbols need 3..25)
 
 // ---- complex helpers (std::complex<float> semantics of the reference build) ----
 __device__ __forceinline__ c32 mk(float re, float im) { c32 r; r.re = re; r.im = im; return r; }
@@ -76,101 +83,199 @@ __device__ __forceinline__ float timing_phase_of(int k, float timing, int fft) {
     return (float)(((kTwoPi * (double)k) * (double)timing) / (double)fft);
 }
 
-struct DemodShared {
-    c32 X[kMaxFft];
-    float phi[kMaxSymLen];
-    c32 H[kMaxCarriers];        // channel_estimate at the used bins, by slot
-    c32 hls[kMaxCarriers];      // h_ls_all
-    c32 prev[kMaxCarriers];     // prev_pilot_phases
-    c32 dprev[kMaxCarriers];    // dbpsk_prev_equalized
-    c32 lts_acc[kMaxCarriers];  // h_sum_pilot (presynced)
-    c32 eq[kMaxCarriers];
-    c32 unit[kMaxCarriers];     // diff / |diff| per pilot
-    float sp[kMaxCarriers];     // |h|^2 per pilot / |H|^2 per data carrier / signal_power per carrier
-    float nd[kMaxCarriers];     // |h - prev|^2 per pilot
-    float ph[kMaxCarriers];     // arg(h) per pilot
-    float nv[kMaxCarriers];     // carrier_noise_var
-    uint8_t fl[kMaxCarriers];   // per-pilot validity flags
-    // tracker scalars (src/ofdm/demodulator_impl.hpp:18-119)
+// ---- in-order reductions across lanes: every lane ends with the same sum ----
+__device__ __forceinline__ float lane_f(float v, int i) {
+    return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), i));
+}
+__device__ __forceinline__ float ordered_sum(float v, int n) {
+    float s = 0.0f;
+    for (int i = 0; i < n; ++i) s += lane_f(v, i);
+    return s;
+}
+__device__ __forceinline__ float ordered_sum_masked(float v, int n, unsigned long long mask, int* count) {
+    float s = 0.0f;
+    int c = 0;
+    for (int i = 0; i < n; ++i)
+        if ((mask >> i) & 1ull) { s += lane_f(v, i); ++c; }
+    *count = c;
+    return s;
+}
+__device__ __forceinline__ c32 ordered_csum(c32 v, int n) {
+    c32 s = mk(0.0f, 0.0f);
+    for (int i = 0; i < n; ++i) s = cadd(s, mk(lane_f(v.re, i), lane_f(v.im, i)));
+    return s;
+}
+
+// per-frame tracker scalars, identical in all lanes (src/ofdm/demodulator_impl.hpp:18-119)
+struct Track {
     float freq_offset_hz, freq_offset_filtered, cfo_phase;
     float noise_variance, snr_linear, timing;
     c32 ppc, cpc;
     int cpc_init, snr_symbol_count, symbols_since_sync, has_prev, has_dprev;
-    float noise_power_sum, signal_power;
-    int noise_count;
-    float fade_threshold;
 };
 
-// bit 0: noise term valid, bit 1: CFO term valid, bit 2: timing term valid
-constexpr uint8_t kFlNoise = 1, kFlCfo = 2, kFlTiming = 4;
+// per-lane constants of the configuration (loaded once per workgroup)
+struct LaneConst {
+    int pilot_slot, pilot_fq, pilot_k;    // lane = pilot index
+    c32 pilot_seq;
+    int data_slot, data_fq, data_k;       // lane = data-carrier index
+    int i_dst, i_lo, i_hi; float i_alpha; // lane = interpolation-table entry
+    int slot_k;                           // lane = carrier slot
+    c32 zc;                               // sync_sequence[lane % n_carriers] for data carrier `lane`
+};
+
+template <int LOG2N>
+struct DemodShared {
+    static constexpr int N = 1 << LOG2N;
+    static constexpr int P = N / kWave;                     // points per lane: 8 / 16
+    static constexpr int A = (P == 16) ? 4 : 3;             // log2(P)
+    c32 X[N + N / P];                                       // FFT exchange buffer, 1 pad per P entries
+    c32 Fq[128];                                            // used output bins: [0,64) and [N-64,N)
+    c32 H[kMaxCarriers];                                    // channel_estimate by slot
+    um::PhaseSeg seg[kPhaseCap];
+};
+
+template <int A> __device__ __forceinline__ constexpr int bitrev_small(int q) {
+    int r = 0;
+    for (int b = 0; b < A; ++b) r |= ((q >> b) & 1) << (A - 1 - b);
+    return r;
+}
+
+#define UH_BUTTERFLY(a, b, w)            \
+    do {                                 \
+        const c32 t_ = cmul((w), (b));   \
+        (b) = csub((a), t_);             \
+        (a) = cadd((a), t_);             \
+    } while (0)
 
 // ---------------------------------------------------------------------------
-// mix one symbol to baseband, correct CFO, strip CP and FFT it (in LDS, natural
-// order output in sh.X).
-__device__ __forceinline__ void symbol_to_freq(DemodShared& sh, const DemodConst& D,
+// mix one symbol to baseband (with CFO rotation), FFT it, leave the used bins in sh.Fq
+template <int LOG2N>
+__device__ __forceinline__ void symbol_to_freq(DemodShared<LOG2N>& sh, const DemodConst& D, Track& tr,
                                                const float* __restrict__ audio_sym,
                                                const c32* __restrict__ nco_sym,
                                                const c32* __restrict__ twiddle) {
-    const int tid = threadIdx.x;
-    const float cfo = sh.freq_offset_hz;
-    const bool cfo_on = fabsf(cfo) > 0.01f;
-    if (cfo_on && tid == 0) {
-        // serial f32 phase recurrence with f64 wrap (channel_equalizer.cpp:23,43-50)
-        const float inc = (float)(((-kTwoPi) * (double)cfo) / (double)D.sample_rate);
-        float p = sh.cfo_phase;
-        for (int i = 0; i < D.sym_len; ++i) {
-            sh.phi[i] = p;
-            p += inc;
-            if ((double)p > kPi) p = (float)((double)p - kTwoPi);
-            else if ((double)p < -kPi) p = (float)((double)p + kTwoPi);
+    constexpr int N = 1 << LOG2N, P = N / kWave, A = DemodShared<LOG2N>::A;
+    const int lane = threadIdx.x;
+    const int rl = (int)(__brev((unsigned)lane) >> 26);      // bitrev6(lane)
+    const bool cfo_on = fabsf(tr.freq_offset_hz) > 0.01f;
+    c32 v[P];
+
+    // ---- toBaseband for the samples this lane feeds into the first butterflies ----
+    // bit-reversed position P*lane + q holds time sample j = bitrev_A(q)*64 + bitrev6(lane)
+    if (!cfo_on) {
+#pragma unroll
+        for (int qp = 0; qp < P; ++qp) {
+            const int i = D.cp + rl + 64 * qp;
+            const float x = audio_sym[i];
+            const c32 osc = nco_sym[i];
+            v[bitrev_small<A>(qp)] = mk(osc.re * x, (-osc.im) * x);      // samples[i] * conj(osc)
         }
-        sh.cfo_phase = p;
+    } else {
+        const float inc = (float)(((-kTwoPi) * (double)tr.freq_offset_hz) / (double)D.sample_rate);
+        float xs[P];
+        c32 os[P];
+#pragma unroll
+        for (int qp = 0; qp < P; ++qp) {                    // issue the HBM loads before the table walk
+            const int i = D.cp + rl + 64 * qp;
+            xs[qp] = audio_sym[i];
+            os[qp] = nco_sym[i];
+        }
+        int done = 0;
+        float pcur = tr.cfo_phase;
+        while (done < D.sym_len) {                           // one round unless a table overflows
+            int covered;
+            float pnext;
+            const int ns = um::phase_table_build(pcur, inc, D.sym_len - done, sh.seg, kPhaseCap, &covered, &pnext,
+                                                 lane == 0);
+            __syncthreads();
+            int s = 0;
+#pragma unroll
+            for (int qp = 0; qp < P; ++qp) {
+                const int i = D.cp + rl + 64 * qp - done;   // position inside this round
+                if (i >= 0 && i < covered) {
+                    while (s + 1 < ns && sh.seg[s + 1].start <= i) ++s;
+                    const float ph = um::phase_table_eval(sh.seg[s], i);
+                    const c32 mixed = mk(os[qp].re * xs[qp], (-os[qp].im) * xs[qp]);
+                    v[bitrev_small<A>(qp)] = cmul(mixed, mk(um::cosf_(ph), um::sinf_(ph)));
+                }
+            }
+            __syncthreads();
+            done += covered;
+            pcur = pnext;
+        }
+        tr.cfo_phase = pcur;
+    }
+
+    // ---- group A: stages 0..A-1 on the lane's P consecutive (bit-reversed) positions ----
+#pragma unroll
+    for (int s = 0; s < A; ++s) {
+        const int half = 1 << s;
+#pragma unroll
+        for (int q = 0; q < P; ++q) {
+            if (q & half) continue;
+            const c32 w = twiddle[(q & (half - 1)) << (LOG2N - 1 - s)];   // wave-uniform
+            UH_BUTTERFLY(v[q], v[q + half], w);
+        }
+    }
+#pragma unroll
+    for (int q = 0; q < P; ++q) { const int i = P * lane + q; sh.X[i + (i >> A)] = v[q]; }
+    __syncthreads();
+
+    // ---- group B: stages A..2A-1, lane (blk, r) holds X[blk*P*P + r + P*j] ----
+    {
+        const int blk = lane / P, r = lane % P;
+#pragma unroll
+        for (int j = 0; j < P; ++j) { const int i = blk * P * P + r + P * j; v[j] = sh.X[i + (i >> A)]; }
+#pragma unroll
+        for (int s = A; s < 2 * A; ++s) {
+            const int hj = 1 << (s - A);                     // pair distance in j
+#pragma unroll
+            for (int j = 0; j < P; ++j) {
+                if (j & hj) continue;
+                const int k = r + P * (j & (hj - 1));
+                const c32 w = twiddle[k << (LOG2N - 1 - s)];
+                UH_BUTTERFLY(v[j], v[j + hj], w);
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < P; ++j) { const int i = blk * P * P + r + P * j; sh.X[i + (i >> A)] = v[j]; }
     }
     __syncthreads();
-    const int shift = 32 - D.log2_fft;
-    for (int i = tid; i < D.sym_len; i += kDemodThreads) {
-        const int j = i - D.cp;
-        if (j < 0 || j >= D.fft) continue;   // CP / guard samples only advance the oscillators
-        const float x = audio_sym[i];
-        const c32 osc = nco_sym[i];
-        c32 mixed = mk(osc.re * x, (-osc.im) * x);           // samples[i] * conj(osc)
-        if (cfo_on) {
-            const float p = sh.phi[i];
-            mixed = cmul(mixed, mk(um::cosf_(p), um::sinf_(p)));
+
+    // ---- group C: stages 2A..LOG2N-1, lane holds X[lane + 64*t]; only outputs t = 0 and
+    //      t = P-1 (bins `lane` and N-64+lane) are used, the rest is dead code ----
+    {
+#pragma unroll
+        for (int t = 0; t < P; ++t) { const int i = lane + 64 * t; v[t] = sh.X[i + (i >> A)]; }
+#pragma unroll
+        for (int s = 2 * A; s < LOG2N; ++s) {
+            const int ht = 1 << (s - 6);                     // pair distance in t (half = 64 * ht)
+#pragma unroll
+            for (int t = 0; t < P; ++t) {
+                if (t & ht) continue;
+                const int k = lane + 64 * (t & (ht - 1));
+                const c32 w = twiddle[k << (LOG2N - 1 - s)];
+                UH_BUTTERFLY(v[t], v[t + ht], w);
+            }
         }
-        sh.X[__brev((unsigned)j) >> shift] = mixed;          // bit-reversal permutation of fft_impl
+        sh.Fq[lane] = v[0];
+        sh.Fq[64 + lane] = v[P - 1];
     }
     __syncthreads();
-    // radix-2 DIT stages, same butterflies and twiddle table as fft_impl (fft.cpp:99-112)
-    const int half_n = D.fft >> 1;
-    for (int lg = 0; lg < D.log2_fft; ++lg) {
-        const int half = 1 << lg;
-        const int tw_shift = D.log2_fft - 1 - lg;            // step = fft / len
-        for (int b = tid; b < half_n; b += kDemodThreads) {
-            const int k = b & (half - 1);
-            const int i0 = ((b >> lg) << (lg + 1)) + k;
-            const c32 w = twiddle[k << tw_shift];
-            const c32 a = sh.X[i0], d = sh.X[i0 + half];
-            const c32 t = cmul(w, d);
-            sh.X[i0 + half] = csub(a, t);
-            sh.X[i0] = cadd(a, t);
-        }
-        __syncthreads();
-    }
 }
 
 // interpolateChannel (channel_equalizer.cpp:601-631): one lane per table entry
-__device__ __forceinline__ void interpolate_channel(DemodShared& sh, const DemodConst& D) {
-    const int q = threadIdx.x;
-    if (q < D.n_interp) {
-        const int lo = D.interp_lo[q], hi = D.interp_hi[q], dst = D.interp_slot[q];
+template <int LOG2N>
+__device__ __forceinline__ void interpolate_channel(DemodShared<LOG2N>& sh, const DemodConst& D, const LaneConst& lc) {
+    if ((int)threadIdx.x < D.n_interp) {
+        const int lo = lc.i_lo, hi = lc.i_hi, dst = lc.i_dst;
         if (lo >= 0 && hi >= 0) {
             const c32 H1 = sh.H[lo], H2 = sh.H[hi];
             const c32 pd = cmul(H2, cconj(H1));
             const float phase_diff = fabsf(um::atan2f_(pd.im, pd.re));
-            const float alpha = D.interp_alpha[q];
-            if (phase_diff > 1.5708f) sh.H[dst] = (alpha < 0.5f) ? H1 : H2;
-            else sh.H[dst] = cadd(cscale(H1, 1.0f - alpha), cscale(H2, alpha));
+            if (phase_diff > 1.5708f) sh.H[dst] = (lc.i_alpha < 0.5f) ? H1 : H2;
+            else sh.H[dst] = cadd(cscale(H1, 1.0f - lc.i_alpha), cscale(H2, lc.i_alpha));
         } else if (lo >= 0) {
             sh.H[dst] = sh.H[lo];
         } else if (hi >= 0) {
@@ -179,194 +284,132 @@ __device__ __forceinline__ void interpolate_channel(DemodShared& sh, const Demod
     }
 }
 
-// updateChannelEstimate (channel_equalizer.cpp:330-595)
-__device__ __forceinline__ void update_channel_estimate(DemodShared& sh, const DemodConst& D) {
-    const int tid = threadIdx.x;
+// updateChannelEstimate (channel_equalizer.cpp:330-595); prev = prev_pilot_phases[lane]
+template <int LOG2N>
+__device__ __forceinline__ void update_channel_estimate(DemodShared<LOG2N>& sh, const DemodConst& D,
+                                                        const LaneConst& lc, Track& tr, c32& prev) {
+    const int lane = threadIdx.x;
     const int np = D.n_pilot;
-    const float alpha = (sh.snr_symbol_count == 0) ? 1.0f : 0.9f;
+    const bool is_pilot = lane < np;
+    const float alpha = (tr.snr_symbol_count == 0) ? 1.0f : 0.9f;
 
-    if (tid < np) sh.hls[tid] = cdiv(sh.X[D.bin[D.pilot_slot[tid]]], D.pilot_seq[tid]);
-    __syncthreads();
-    if (tid == 0) {
-        c32 h_sum = mk(0, 0);
-        for (int i = 0; i < np; ++i) h_sum = cadd(h_sum, sh.hls[i]);
-        if (!sh.cpc_init && np != 0) {
-            const c32 h_avg = cdivf(h_sum, (float)np);
-            const float avg_mag = cabs_(h_avg);
-            if (avg_mag > 0.01f) { sh.cpc = cdivf(cconj(h_avg), avg_mag); sh.cpc_init = 1; }
-        }
+    c32 h = mk(0.0f, 0.0f);
+    if (is_pilot) h = cdiv(sh.Fq[lc.pilot_fq], lc.pilot_seq);
+    c32 h_sum = ordered_csum(h, np);
+    if (!tr.cpc_init && np != 0) {                              // carrier phase recovery (:348-357)
+        const c32 h_avg = cdivf(h_sum, (float)np);
+        const float avg_mag = cabs_(h_avg);
+        if (avg_mag > 0.01f) { tr.cpc = cdivf(cconj(h_avg), avg_mag); tr.cpc_init = 1; }
     }
-    __syncthreads();
-    if (tid < np) {
-        const c32 h = cmul(sh.hls[tid], sh.cpc);
-        const float n2 = cnorm(h);
-        uint8_t fl = 0;
-        sh.hls[tid] = h;
-        sh.sp[tid] = n2;
-        const int slot = D.pilot_slot[tid];
-        if (sh.has_prev) {
-            const c32 pv = sh.prev[tid];
-            const float pn = cnorm(pv);
+    h = cmul(h, tr.cpc);
+    const float n2 = cnorm(h);
+
+    // per-pilot terms of the serial loops (:385-412, :420-440, :473-490)
+    float nd = 0.0f, ph = 0.0f;
+    c32 unit = mk(0.0f, 0.0f);
+    bool f_noise = false, f_cfo = false, f_tim = false;
+    if (is_pilot) {
+        if (tr.has_prev) {
+            const float pn = cnorm(prev);
             if (pn > 1e-6f && n2 > 1e-6f) {
-                sh.nd[tid] = cnorm(csub(h, pv));
-                fl |= kFlNoise;
-                const c32 diff = cmul(h, cconj(pv));
+                nd = cnorm(csub(h, prev));
+                f_noise = true;
+                const c32 diff = cmul(h, cconj(prev));
                 const float mag = cabs_(diff);
-                if (mag > 1e-6f) { sh.unit[tid] = cdivf(diff, mag); fl |= kFlCfo; }
+                if (mag > 1e-6f) { unit = cdivf(diff, mag); f_cfo = true; }
             }
         }
-        if (sh.snr_symbol_count >= 3 && !(n2 < 1e-6f)) { sh.ph[tid] = carg_(h); fl |= kFlTiming; }
-        sh.fl[tid] = fl;
-        const c32 h_old = sh.H[slot];
-        sh.H[slot] = cadd(cscale(h, alpha), cscale(h_old, 1.0f - alpha));
+        if (tr.snr_symbol_count >= 3 && !(n2 < 1e-6f)) { ph = carg_(h); f_tim = true; }
+        const c32 h_old = sh.H[lc.pilot_slot];
+        sh.H[lc.pilot_slot] = cadd(cscale(h, alpha), cscale(h_old, 1.0f - alpha));
     }
-    __syncthreads();
-    if (tid == 0) {
-        float signal_power_sum = 0.0f;
-        for (int i = 0; i < np; ++i) signal_power_sum += sh.sp[i];
-        const float signal_power = signal_power_sum / (float)np;   // NaN when np == 0 (reference quirk)
-        float noise_power_sum = 0.0f;
-        int noise_count = 0;
-        for (int i = 0; i < np; ++i) if (sh.fl[i] & kFlNoise) { noise_power_sum += sh.nd[i]; noise_count++; }
-        if (noise_count == 0) { noise_power_sum = signal_power / 31.6f; noise_count = 1; }
+    const unsigned long long m_noise = __ballot(f_noise), m_cfo = __ballot(f_cfo), m_tim = __ballot(f_tim);
 
-        if (sh.has_prev && np != 0) {   // prev_pilot_phases non-empty and same size
-            c32 sum = mk(0, 0);
-            int valid = 0;
-            for (int i = 0; i < np; ++i) if (sh.fl[i] & kFlCfo) { sum = cadd(sum, sh.unit[i]); valid++; }
-            if (valid > 0) {
-                const c32 avg = cdivf(sum, (float)valid);
-                const float apd = um::atan2f_(avg.im, avg.re);
-                sh.ppc = mk(um::cosf_(-apd), um::sinf_(-apd));
-                const float residual = (float)((double)apd / D.two_pi_symbol_duration);
-                const float total = sh.freq_offset_hz + residual;
-                float a = 0.3f;
-                if (sh.symbols_since_sync < 10) {
-                    const float progress = (float)sh.symbols_since_sync / 10;
-                    a = 0.9f * (1.0f - progress) + 0.3f * progress;
-                }
-                if (fabsf(residual) > 10.0f) a = fmax_std(a, 0.9f);
-                sh.symbols_since_sync++;
-                sh.freq_offset_filtered = a * total + (1.0f - a) * sh.freq_offset_filtered;
-                sh.freq_offset_hz = fmax_std(-90.0f, fmin_std(90.0f, sh.freq_offset_filtered));
-            }
-        } else {
-            sh.ppc = mk(1, 0);
-        }
+    const float signal_power = ordered_sum(n2, np) / (float)np;     // NaN when np == 0 (reference quirk)
+    int noise_count;
+    float noise_power_sum = ordered_sum_masked(nd, np, m_noise, &noise_count);
+    if (noise_count == 0) { noise_power_sum = signal_power / 31.6f; noise_count = 1; }
 
-        if (sh.snr_symbol_count >= 3) {
-            float sum_k = 0, sum_k2 = 0, sum_phase = 0, sum_k_phase = 0;
-            int tv = 0;
-            for (int i = 0; i < np; ++i) {
-                if (!(sh.fl[i] & kFlTiming)) continue;
-                const int k = D.k_of[D.pilot_slot[i]];
-                const float phase = sh.ph[i];
-                sum_k += (float)k;
-                sum_k2 += (float)(k * k);
-                sum_phase += phase;
-                sum_k_phase += (float)k * phase;
-                tv++;
+    if (tr.has_prev && np != 0) {                               // CFO from pilot phase differences
+        c32 sum = mk(0.0f, 0.0f);
+        int valid = 0;
+        for (int i = 0; i < np; ++i)
+            if ((m_cfo >> i) & 1ull) { sum = cadd(sum, mk(lane_f(unit.re, i), lane_f(unit.im, i))); ++valid; }
+        if (valid > 0) {
+            const c32 avg = cdivf(sum, (float)valid);
+            const float apd = um::atan2f_(avg.im, avg.re);
+            tr.ppc = mk(um::cosf_(-apd), um::sinf_(-apd));
+            const float residual = (float)((double)apd / D.two_pi_symbol_duration);
+            const float total = tr.freq_offset_hz + residual;
+            float a = 0.3f;
+            if (tr.symbols_since_sync < 10) {
+                const float progress = (float)tr.symbols_since_sync / 10;
+                a = 0.9f * (1.0f - progress) + 0.3f * progress;
             }
-            if (tv >= 3) {
-                const float n = (float)tv;
-                const float denom = n * sum_k2 - sum_k * sum_k;
-                if (fabsf(denom) > 1e-6f) {
-                    const float slope = (n * sum_k_phase - sum_k * sum_phase) / denom;
-                    const float inst = (float)((double)(slope * D.fft_f) / kTwoPi);
-                    sh.timing = 0.3f * inst + (1.0f - 0.3f) * sh.timing;
-                    sh.timing = fmax_std(-D.max_timing, fmin_std(D.max_timing, sh.timing));
-                }
+            if (fabsf(residual) > 10.0f) a = fmax_std(a, 0.9f);
+            tr.symbols_since_sync++;
+            tr.freq_offset_filtered = a * total + (1.0f - a) * tr.freq_offset_filtered;
+            tr.freq_offset_hz = fmax_std(-90.0f, fmin_std(90.0f, tr.freq_offset_filtered));
+        }
+    } else {
+        tr.ppc = mk(1.0f, 0.0f);
+    }
+
+    if (tr.snr_symbol_count >= 3) {                             // timing from the pilot phase slope
+        float sum_k = 0, sum_k2 = 0, sum_phase = 0, sum_k_phase = 0;
+        int tv = 0;
+        for (int i = 0; i < np; ++i) {
+            if (!((m_tim >> i) & 1ull)) continue;
+            const int k = __builtin_amdgcn_readlane(lc.pilot_k, i);
+            const float phase = lane_f(ph, i);
+            sum_k += (float)k;
+            sum_k2 += (float)(k * k);
+            sum_phase += phase;
+            sum_k_phase += (float)k * phase;
+            tv++;
+        }
+        if (tv >= 3) {
+            const float n = (float)tv;
+            const float denom = n * sum_k2 - sum_k * sum_k;
+            if (fabsf(denom) > 1e-6f) {
+                const float slope = (n * sum_k_phase - sum_k * sum_phase) / denom;
+                const float inst = (float)((double)(slope * D.fft_f) / kTwoPi);
+                tr.timing = 0.3f * inst + (1.0f - 0.3f) * tr.timing;
+                tr.timing = fmax_std(-D.max_timing, fmin_std(D.max_timing, tr.timing));
             }
         }
-        sh.noise_power_sum = noise_power_sum;
-        sh.noise_count = noise_count;
-        sh.signal_power = signal_power;
+    }
+    if (is_pilot) prev = h;
+    tr.has_prev = (np != 0);
+
+    // coherent timing fix around the interpolation (:514-567)
+    const bool fix = !D.differential && fabsf(tr.timing) > 0.1f;
+    if (fix && is_pilot) {
+        const float tp = timing_phase_of(lc.pilot_k, tr.timing, D.fft);
+        sh.H[lc.pilot_slot] = cmul(sh.H[lc.pilot_slot], cexpj(-tp));
     }
     __syncthreads();
-    if (tid < np) sh.prev[tid] = sh.hls[tid];
-    const bool fix = !D.differential && fabsf(sh.timing) > 0.1f;
-    if (fix && tid < np) {
-        const int slot = D.pilot_slot[tid];
-        const float tp = timing_phase_of(D.k_of[slot], sh.timing, D.fft);
-        sh.H[slot] = cmul(sh.H[slot], cexpj(-tp));
-    }
+    interpolate_channel(sh, D, lc);
     __syncthreads();
-    interpolate_channel(sh, D);
-    __syncthreads();
-    if (fix && tid < D.n_carriers) {
-        // pilots, then data carriers: each used slot is multiplied exactly once
-        const float tp = timing_phase_of(D.k_of[tid], sh.timing, D.fft);
-        sh.H[tid] = cmul(sh.H[tid], cexpj(tp));
+    if (fix && lane < D.n_carriers) {       // pilots then data carriers: every used slot exactly once
+        const float tp = timing_phase_of(lc.slot_k, tr.timing, D.fft);
+        sh.H[lane] = cmul(sh.H[lane], cexpj(tp));
     }
-    if (tid == 0) {
-        sh.has_prev = (np != 0);
-        if (sh.noise_count > 1 && sh.noise_power_sum > 0.0f) {
-            float nv = sh.noise_power_sum / (float)(sh.noise_count - 1);
-            if (nv < 1e-6f) nv = 1e-6f;
-            sh.noise_variance = nv;
-            float inst_snr = sh.signal_power / nv;
-            inst_snr = fmax_std(0.1f, fmin_std(10000.0f, inst_snr));
-            sh.snr_linear = 0.3f * inst_snr + (1.0f - 0.3f) * sh.snr_linear;
-        }
-        sh.snr_symbol_count++;
+    if (noise_count > 1 && noise_power_sum > 0.0f) {            // (:583-592)
+        float nv = noise_power_sum / (float)(noise_count - 1);
+        if (nv < 1e-6f) nv = 1e-6f;
+        tr.noise_variance = nv;
+        float inst_snr = signal_power / nv;
+        inst_snr = fmax_std(0.1f, fmin_std(10000.0f, inst_snr));
+        tr.snr_linear = 0.3f * inst_snr + (1.0f - 0.3f) * tr.snr_linear;
     }
+    tr.snr_symbol_count++;
     __syncthreads();
 }
 
-// equalize (channel_equalizer.cpp:728-840), adaptive_eq_enabled == false
-__device__ __forceinline__ void equalize(DemodShared& sh, const DemodConst& D) {
-    const int i = threadIdx.x;
-    const int nd = D.n_data;
-    if (D.differential) {
-        if (i < nd) {
-            const int slot = D.data_slot[i];
-            const c32 received = sh.X[D.bin[slot]], h = sh.H[slot];
-            const float h_power = cnorm(h);
-            const c32 tc = cexpj(timing_phase_of(D.k_of[slot], sh.timing, D.fft));
-            float nv;
-            if (h_power > 1e-6f) {
-                const c32 t = cdivf(cmul(received, cconj(h)), h_power);
-                sh.eq[i] = cmul(cmul(t, sh.ppc), tc);
-                nv = sh.noise_variance / h_power;
-            } else {
-                sh.eq[i] = cmul(cmul(received, sh.ppc), tc);
-                nv = 100.0f;
-            }
-            sh.nv[i] = fmax_std(1e-6f, fmin_std(100.0f, nv));
-        }
-        __syncthreads();
-        return;
-    }
-    if (i < nd) {
-        const int slot = D.data_slot[i];
-        const c32 received = sh.X[D.bin[slot]], h = sh.H[slot];
-        const float h_power = cnorm(h);
-        sh.sp[i] = h_power;
-        const float mmse_denom = h_power + sh.noise_variance;
-        if (mmse_denom < 1e-10f) {
-            sh.eq[i] = mk(0, 0);
-            sh.nv[i] = 100.0f;
-        } else {
-            sh.eq[i] = cdivf(cmul(cconj(h), received), mmse_denom);
-            const float nv = sh.noise_variance / (h_power + 1e-6f);
-            sh.nv[i] = fmax_std(1e-6f, fmin_std(100.0f, nv));
-        }
-    }
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        float avg = 0.0f;
-        for (int q = 0; q < nd; ++q) avg += sh.sp[q];
-        avg /= (float)nd;
-        sh.fade_threshold = 0.1f * avg;
-    }
-    __syncthreads();
-    if (i < nd && sh.sp[i] < sh.fade_threshold) sh.nv[i] = 100.0f;
-    __syncthreads();
-}
-
-// one carrier's LLRs (soft_demap.hpp), written to out[0..bits)
-__device__ __forceinline__ void demap_carrier(const DemodConst& D, c32 sym, c32 prev, float nv, float* out) {
-    switch (D.modulation) {
+// one carrier's LLRs (soft_demap.hpp), stored to out[0..bits)
+__device__ __forceinline__ void demap_carrier(int modulation, c32 sym, c32 prev, float nv, float* __restrict__ out) {
+    switch (modulation) {
         case ULTRA_MOD_DBPSK: {
             const c32 diff = cmul(sym, cconj(prev));
             const float pd = um::atan2f_(diff.im, diff.re);
@@ -463,154 +506,183 @@ __device__ __forceinline__ void demap_carrier(const DemodConst& D, c32 sym, c32 
     }
 }
 
-// demodulateSymbol (demodulator.cpp:199-435); llr_sym points at this symbol's LLR row
-__device__ __forceinline__ void demodulate_symbol(DemodShared& sh, const DemodConst& D, float* llr_sym) {
-    const int i = threadIdx.x;
+// equalize (channel_equalizer.cpp:728-840, adaptive_eq off) + demodulateSymbol
+// (demodulator.cpp:199-435) for one symbol; dprev = dbpsk_prev_equalized[lane]
+template <int LOG2N>
+__device__ __forceinline__ void equalize_demap(DemodShared<LOG2N>& sh, const DemodConst& D, const LaneConst& lc,
+                                               Track& tr, c32& dprev, float* __restrict__ llr_sym) {
+    const int lane = threadIdx.x;
     const int nd = D.n_data;
-    if (D.differential && !sh.has_dprev && i < nd) sh.dprev[i] = mk(1, 0);   // (1,0) reference, all paths
-    // (no barrier needed: lane i only touches dprev[i])
-    if (i < nd) {
-        const c32 sym = sh.eq[i];
-        const float nv = sh.nv[i] * D.ce_margin;
-        float out[8];
-        demap_carrier(D, sym, sh.dprev[i], nv, out);
-        const int nb = D.bits;
-        for (int b = 0; b < nb; ++b) llr_sym[i * nb + b] = out[b];
-        if (D.differential) sh.dprev[i] = sym;
-    }
-    const bool dd = (D.modulation == ULTRA_MOD_DQPSK || D.modulation == ULTRA_MOD_D8PSK);
-    if (dd && sh.snr_symbol_count >= 1) {
-        // Decision-directed block (demodulator.cpp:362-434).  dbpsk_prev_equalized[i] was
-        // just overwritten with equalized[i], so diff = eq * conj(eq) has phase +0 exactly:
-        // quadrant 0, phase_error 0, phase_correction = (cos(-0), sin(-0)) = (1, -0) and
-        // phase_error_sum = (sum of signal_power, +0) -> avg 0 -> correction (1, -0),
-        // pow(|correction|, a) = 1, rotation (cos(-0), sin(-0)) = (1, -0).  The multiplies
-        // are kept literally (they only touch the sign of exact zeros); the oracle runs the
-        // block with the libm calls and the parity tests compare.
-        if (i < nd) {
-            const c32 e = sh.eq[i];
-            const float a = cabs_(e);
-            const float spw = a * a;
-            sh.fl[i] = (spw > 0.1f) ? 1 : 0;
-            if (spw > 0.1f) {
-                const int slot = D.data_slot[i];
-                sh.H[slot] = cmul(sh.H[slot], mk(1.0f, -0.0f));
+    const bool is_data = lane < nd;
+    c32 eq = mk(0.0f, 0.0f);
+    float nv = 100.0f;
+    if (D.differential) {
+        if (is_data) {
+            const c32 received = sh.Fq[lc.data_fq], h = sh.H[lc.data_slot];
+            const float h_power = cnorm(h);
+            const c32 tc = cexpj(timing_phase_of(lc.data_k, tr.timing, D.fft));
+            if (h_power > 1e-6f) {
+                const c32 t = cdivf(cmul(received, cconj(h)), h_power);
+                eq = cmul(cmul(t, tr.ppc), tc);
+                nv = tr.noise_variance / h_power;
+            } else {
+                eq = cmul(cmul(received, tr.ppc), tc);
+                nv = 100.0f;
+            }
+            nv = fmax_std(1e-6f, fmin_std(100.0f, nv));
+        }
+    } else {
+        float h_power = 0.0f;
+        if (is_data) {
+            const c32 received = sh.Fq[lc.data_fq], h = sh.H[lc.data_slot];
+            h_power = cnorm(h);
+            const float mmse_denom = h_power + tr.noise_variance;
+            if (mmse_denom < 1e-10f) {
+                eq = mk(0.0f, 0.0f);
+                nv = 100.0f;
+            } else {
+                eq = cdivf(cmul(cconj(h), received), mmse_denom);
+                nv = tr.noise_variance / (h_power + 1e-6f);
+                nv = fmax_std(1e-6f, fmin_std(100.0f, nv));
             }
         }
-        __syncthreads();
-        if (threadIdx.x == 0) {
-            int valid = 0;
-            for (int q = 0; q < nd; ++q) valid += sh.fl[q];
-            if (valid >= 5) {
-                c32 p = cmul(cscale(sh.ppc, 1.0f), mk(1.0f, -0.0f));
-                const float mag = cabs_(p);
-                if (mag > 0.01f) p = cdivf(p, mag);
-                sh.ppc = p;
-            }
+        float avg = ordered_sum(h_power, nd);                   // deep-fade soft erasure (:822-837)
+        avg /= (float)nd;
+        if (is_data && h_power < 0.1f * avg) nv = 100.0f;
+    }
+
+    if (D.differential && !tr.has_dprev) dprev = mk(1.0f, 0.0f);   // (1,0) reference on every path
+    if (is_data) {
+        demap_carrier(D.modulation, eq, dprev, nv * D.ce_margin, llr_sym + lane * D.bits);
+        if (D.differential) dprev = eq;
+    }
+    if ((D.modulation == ULTRA_MOD_DQPSK || D.modulation == ULTRA_MOD_D8PSK) && tr.snr_symbol_count >= 1) {
+        // Decision-directed block (demodulator.cpp:362-434).  dbpsk_prev_equalized[i] was just
+        // overwritten with equalized[i], so diff = eq * conj(eq) has phase +0 exactly: quadrant 0,
+        // phase_error 0, phase_correction = (cos(-0), sin(-0)) = (1, -0); phase_error_sum =
+        // (sum of signal_power, +0) -> correction (1, -0), pow(|correction|, a) = 1, rotation
+        // (1, -0).  The multiplies are kept literally (they only touch the sign of exact zeros);
+        // the oracle runs the block with the libm calls and the parity tests compare.
+        bool strong = false;
+        if (is_data) {
+            const float a = cabs_(eq);
+            strong = (a * a) > 0.1f;
+            if (strong) sh.H[lc.data_slot] = cmul(sh.H[lc.data_slot], mk(1.0f, -0.0f));
+        }
+        const int valid = __popcll(__ballot(strong));
+        if (valid >= 5) {
+            c32 p = cmul(cscale(tr.ppc, 1.0f), mk(1.0f, -0.0f));
+            const float mag = cabs_(p);
+            if (mag > 0.01f) p = cdivf(p, mag);
+            tr.ppc = p;
         }
     }
-    if (threadIdx.x == 0 && D.differential) sh.has_dprev = 1;
+    if (D.differential) tr.has_dprev = 1;
     __syncthreads();
 }
 
-// estimateChannelFromLTS (channel_equalizer.cpp:77-328) for one training symbol
-__device__ __forceinline__ void lts_symbol(DemodShared& sh, const DemodConst& D, int sym, int n_train) {
-    const int i = threadIdx.x;
-    if (i < D.n_data) {
-        const c32 tx = D.sync_seq[i % D.n_carriers];
-        if (sym == n_train - 1) {
-            c32 h = mk(0, 0);
-            if (cabs_(tx) > 0.01f) h = cdiv(sh.X[D.bin[D.data_slot[i]]], tx);
-            sh.H[D.data_slot[i]] = h;     // last training symbol's estimate
-        }
+// estimateChannelFromLTS (channel_equalizer.cpp:77-328), one training symbol
+template <int LOG2N>
+__device__ __forceinline__ void lts_symbol(DemodShared<LOG2N>& sh, const DemodConst& D, const LaneConst& lc,
+                                           int sym, int n_train, c32& lts_acc) {
+    const int lane = threadIdx.x;
+    if (lane < D.n_data && sym == n_train - 1) {
+        c32 h = mk(0.0f, 0.0f);
+        if (cabs_(lc.zc) > 0.01f) h = cdiv(sh.Fq[lc.data_fq], lc.zc);
+        sh.H[lc.data_slot] = h;                                   // last training symbol's estimate
     }
-    if (i < D.n_pilot) {
-        const c32 tx = D.pilot_seq[i];
-        c32 acc = (sym == 0) ? mk(0, 0) : sh.lts_acc[i];
-        if (cabs_(tx) > 0.01f) acc = cadd(acc, cdiv(sh.X[D.bin[D.pilot_slot[i]]], tx));
-        sh.lts_acc[i] = acc;
+    if (lane < D.n_pilot) {
+        if (sym == 0) lts_acc = mk(0.0f, 0.0f);
+        if (cabs_(lc.pilot_seq) > 0.01f) lts_acc = cadd(lts_acc, cdiv(sh.Fq[lc.pilot_fq], lc.pilot_seq));
     }
     __syncthreads();
 }
 
-__device__ __forceinline__ void lts_finish(DemodShared& sh, const DemodConst& D, int n_train) {
-    const int i = threadIdx.x;
+template <int LOG2N>
+__device__ __forceinline__ void lts_finish(DemodShared<LOG2N>& sh, const DemodConst& D, const LaneConst& lc,
+                                           Track& tr, int n_train, c32 lts_acc) {
+    const int lane = threadIdx.x;
     const float inv_count = 1.0f / (float)n_train;
-    if (i < D.n_pilot) sh.H[D.pilot_slot[i]] = cscale(sh.lts_acc[i], inv_count);
-    if (i < D.n_data) sh.sp[i] = cabs_(sh.H[D.data_slot[i]]);
+    if (lane < D.n_pilot) sh.H[lc.pilot_slot] = cscale(lts_acc, inv_count);
     __syncthreads();
-    if (i == 0) {
-        float h_mag_sum = 0;
-        for (int q = 0; q < D.n_data; ++q) h_mag_sum += sh.sp[q];
-        const float h_mag_avg = h_mag_sum / (float)D.n_data;
-        if (h_mag_avg > 1e-6f && sh.noise_variance > 1e-10f) {
-            const float s = (h_mag_avg * h_mag_avg) / sh.noise_variance;
-            sh.snr_linear = fmax_std(0.1f, fmin_std(10000.0f, s));
-        }
-        sh.snr_symbol_count = n_train;
+    float mag = 0.0f;
+    if (lane < D.n_data) mag = cabs_(sh.H[lc.data_slot]);
+    const float h_mag_avg = ordered_sum(mag, D.n_data) / (float)D.n_data;
+    if (h_mag_avg > 1e-6f && tr.noise_variance > 1e-10f) {
+        const float s = (h_mag_avg * h_mag_avg) / tr.noise_variance;
+        tr.snr_linear = fmax_std(0.1f, fmin_std(10000.0f, s));
     }
+    tr.snr_symbol_count = n_train;
     __syncthreads();
 }
 
 // ---------------------------------------------------------------------------
-// Kernel: one workgroup per frame.
+// Kernel: one 64-lane workgroup per frame (grid-stride over frames).
 //   audio     [n_frames] rows of frame_stride floats
 //   cfo_hz    [n_frames] or nullptr, cfo_phase [n_frames] or nullptr
 //   llr       [n_frames][llr_stride] (llr_stride >= llrs_per_frame)
 //   state     [n_frames][ULTRA_HIP_STATE_FLOATS] or nullptr
-__global__ __launch_bounds__(kDemodThreads) void demod_frames_kernel(
+template <int LOG2N>
+__global__ __launch_bounds__(kWave, 4) void demod_frames_kernel(
     const DemodConst* __restrict__ Dp, const c32* __restrict__ nco, const c32* __restrict__ twiddle,
     const float* __restrict__ audio, size_t frame_stride, const float* __restrict__ cfo_hz,
     const float* __restrict__ cfo_phase, int n_frames, float* __restrict__ llr, size_t llr_stride,
     float* __restrict__ state) {
-    __shared__ DemodShared sh;
+    __shared__ DemodShared<LOG2N> sh;
     const DemodConst& D = *Dp;
-    const int tid = threadIdx.x;
+    const int lane = threadIdx.x;
+    constexpr int N = 1 << LOG2N;
+
+    LaneConst lc;
+    {
+        auto fq_of = [&](int bin) { return (bin < 64) ? bin : 64 + (bin - (N - 64)); };
+        const int ps = (lane < D.n_pilot) ? D.pilot_slot[lane] : 0;
+        lc.pilot_slot = ps; lc.pilot_fq = fq_of(D.bin[ps]); lc.pilot_k = D.k_of[ps];
+        lc.pilot_seq = (lane < D.n_pilot) ? D.pilot_seq[lane] : mk(1.0f, 0.0f);
+        const int dsl = (lane < D.n_data) ? D.data_slot[lane] : 0;
+        lc.data_slot = dsl; lc.data_fq = fq_of(D.bin[dsl]); lc.data_k = D.k_of[dsl];
+        const int q = (lane < D.n_interp) ? lane : 0;
+        lc.i_dst = D.interp_slot[q]; lc.i_lo = D.interp_lo[q]; lc.i_hi = D.interp_hi[q]; lc.i_alpha = D.interp_alpha[q];
+        lc.slot_k = D.k_of[(lane < D.n_carriers) ? lane : 0];
+        lc.zc = D.sync_seq[lane % D.n_carriers];
+    }
+
     for (int frame = blockIdx.x; frame < n_frames; frame += gridDim.x) {
-        // fresh demodulator state (demodulator.cpp:26-43 + SYNCED transition :533-591
-        // or processPresynced reset block :868-905)
-        if (tid < kMaxCarriers) sh.H[tid] = mk(1, 0);
-        if (tid == 0) {
-            const float cfo = cfo_hz ? cfo_hz[frame] : 0.0f;
-            sh.freq_offset_hz = cfo;
-            sh.freq_offset_filtered = cfo;
-            sh.cfo_phase = cfo_phase ? cfo_phase[frame] : 0.0f;
-            sh.noise_variance = 0.1f;
-            sh.snr_linear = 1.0f;
-            sh.timing = 0.0f;
-            sh.ppc = mk(1, 0);
-            sh.cpc = mk(1, 0);
-            sh.cpc_init = 0;
-            sh.snr_symbol_count = 0;
-            sh.symbols_since_sync = 0;
-            sh.has_prev = 0;
-            sh.has_dprev = 0;
-        }
+        // fresh demodulator (demodulator.cpp:26-43 + SYNCED transition :533-591, or the reset
+        // block of processPresynced :868-905)
+        Track tr;
+        tr.freq_offset_hz = cfo_hz ? cfo_hz[frame] : 0.0f;
+        tr.freq_offset_filtered = tr.freq_offset_hz;
+        tr.cfo_phase = cfo_phase ? cfo_phase[frame] : 0.0f;
+        tr.noise_variance = 0.1f; tr.snr_linear = 1.0f; tr.timing = 0.0f;
+        tr.ppc = mk(1.0f, 0.0f); tr.cpc = mk(1.0f, 0.0f);
+        tr.cpc_init = 0; tr.snr_symbol_count = 0; tr.symbols_since_sync = 0; tr.has_prev = 0; tr.has_dprev = 0;
+        c32 prev = mk(0.0f, 0.0f), dprev = mk(1.0f, 0.0f), lts_acc = mk(0.0f, 0.0f);
+        sh.H[lane] = mk(1.0f, 0.0f);
         __syncthreads();
+
         const float* a = audio + (size_t)frame * frame_stride;
         float* l = llr + (size_t)frame * llr_stride;
-        const int lps = D.llrs_per_symbol;
         int s = 0;
         for (; s < D.n_train; ++s) {
-            symbol_to_freq(sh, D, a + (size_t)s * D.sym_len, nco + (size_t)s * D.sym_len, twiddle);
-            lts_symbol(sh, D, s, D.n_train);
+            symbol_to_freq<LOG2N>(sh, D, tr, a + (size_t)s * D.sym_len, nco + (size_t)s * D.sym_len, twiddle);
+            lts_symbol<LOG2N>(sh, D, lc, s, D.n_train, lts_acc);
         }
-        if (D.n_train > 0) lts_finish(sh, D, D.n_train);
+        if (D.n_train > 0) lts_finish<LOG2N>(sh, D, lc, tr, D.n_train, lts_acc);
         for (int ds = 0; ds < D.n_data_sym; ++ds, ++s) {
-            symbol_to_freq(sh, D, a + (size_t)s * D.sym_len, nco + (size_t)s * D.sym_len, twiddle);
-            if (!D.presynced || D.n_pilot != 0) update_channel_estimate(sh, D);
-            equalize(sh, D);
-            demodulate_symbol(sh, D, l + (size_t)ds * lps);
+            symbol_to_freq<LOG2N>(sh, D, tr, a + (size_t)s * D.sym_len, nco + (size_t)s * D.sym_len, twiddle);
+            if (!D.presynced || D.n_pilot != 0) update_channel_estimate<LOG2N>(sh, D, lc, tr, prev);
+            equalize_demap<LOG2N>(sh, D, lc, tr, dprev, l + (size_t)ds * D.llrs_per_symbol);
         }
-        if (state && tid == 0) {
+        if (state && lane == 0) {
             float* st = state + (size_t)frame * ULTRA_HIP_STATE_FLOATS;
-            st[ULTRA_HIP_STATE_FREQ_OFFSET_HZ] = sh.freq_offset_hz;
-            st[ULTRA_HIP_STATE_NOISE_VARIANCE] = sh.noise_variance;
-            st[ULTRA_HIP_STATE_SNR_LINEAR] = sh.snr_linear;
-            st[ULTRA_HIP_STATE_TIMING_OFFSET] = sh.timing;
-            st[ULTRA_HIP_STATE_CFO_PHASE] = sh.cfo_phase;
+            st[ULTRA_HIP_STATE_FREQ_OFFSET_HZ] = tr.freq_offset_hz;
+            st[ULTRA_HIP_STATE_NOISE_VARIANCE] = tr.noise_variance;
+            st[ULTRA_HIP_STATE_SNR_LINEAR] = tr.snr_linear;
+            st[ULTRA_HIP_STATE_TIMING_OFFSET] = tr.timing;
+            st[ULTRA_HIP_STATE_CFO_PHASE] = tr.cfo_phase;
             st[ULTRA_HIP_STATE_MIXER_PHASE] = D.mixer_phase_end;
-            st[ULTRA_HIP_STATE_SYMBOLS] = (float)sh.snr_symbol_count;
+            st[ULTRA_HIP_STATE_SYMBOLS] = (float)tr.snr_symbol_count;
             st[ULTRA_HIP_STATE_RESERVED] = 0.0f;
         }
         __syncthreads();

@@ -63,12 +63,20 @@ struct DeviceGuard {
 int launch_demod(ultra_hip_ctx* ctx, const float* d_audio, size_t frame_stride, const float* d_cfo_hz,
                  const float* d_cfo_phase, size_t n_frames, float* d_llr, size_t llr_stride, float* d_state) {
     if (n_frames == 0) return ULTRA_HIP_OK;
-    // one workgroup per frame; cap the grid and stride so huge batches stay one launch
-    const size_t max_blocks = (size_t)ctx->cu_count * 64;
+    // one wavefront per frame; the grid is capped (several resident waves per CU, grid-stride over
+    // frames) so a huge batch stays one launch and per-workgroup constants are loaded once
+    const size_t max_blocks = (size_t)ctx->cu_count * 32;
     const unsigned grid = (unsigned)std::min(n_frames, max_blocks);
-    hipLaunchKernelGGL(dev::demod_frames_kernel, dim3(grid), dim3(dev::kDemodThreads), 0, ctx->stream,
-                       ctx->d_demod, ctx->d_nco, ctx->d_twiddle, d_audio, frame_stride, d_cfo_hz, d_cfo_phase,
-                       (int)n_frames, d_llr, llr_stride, d_state);
+    if (ctx->h_demod.log2_fft == 10)
+        hipLaunchKernelGGL(dev::demod_frames_kernel<10>, dim3(grid), dim3(dev::kWave), 0, ctx->stream,
+                           ctx->d_demod, ctx->d_nco, ctx->d_twiddle, d_audio, frame_stride, d_cfo_hz, d_cfo_phase,
+                           (int)n_frames, d_llr, llr_stride, d_state);
+    else if (ctx->h_demod.log2_fft == 9)
+        hipLaunchKernelGGL(dev::demod_frames_kernel<9>, dim3(grid), dim3(dev::kWave), 0, ctx->stream,
+                           ctx->d_demod, ctx->d_nco, ctx->d_twiddle, d_audio, frame_stride, d_cfo_hz, d_cfo_phase,
+                           (int)n_frames, d_llr, llr_stride, d_state);
+    else
+        return ULTRA_HIP_ERR_UNSUPPORTED;
     UH_HIP(hipGetLastError());
     return ULTRA_HIP_OK;
 }
