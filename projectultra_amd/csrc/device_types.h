@@ -53,5 +53,18 @@ struct LdpcConst {
     uint16_t var_edge[kLdpcMaxEdges];
 };
 
+// Execution plan of the LDPC kernel (ldpc_kernel.h): rows padded to 8 slots, slot = 8*row + pos.
+// act_* list the information bits that have at least one check, in ascending bit order; their
+// slot lists are in ascending check order.  Parity bit k+i owns the last slot of row i.
+constexpr int kLdpcPlanDmax = 14;
+constexpr int kLdpcPlanMaxActive = 576;
+struct LdpcPlan {
+    int32_t k, m, n, edges, max_iterations, decoded_bytes, n_active, row_rounds, var_rounds, dmax, _pad[2];
+    uint8_t row_deg[512];
+    uint16_t act_var[kLdpcPlanMaxActive];
+    uint8_t act_deg[kLdpcPlanMaxActive];
+    uint16_t act_slot[kLdpcPlanMaxActive * kLdpcPlanDmax];
+};
+
 }  // namespace ultra_hip
 #endif

@@ -161,6 +161,42 @@ inline void build_ldpc(uint32_t rate, uint32_t max_iterations, LdpcConst& L) {
     L.var_ptr[k + m] = (uint16_t)q;
 }
 
+// Execution plan for the kernel, derived from the CSR graph.
+inline int build_ldpc_plan(const LdpcConst& L, LdpcPlan& P) {
+    P = LdpcPlan{};
+    P.k = L.k; P.m = L.m; P.n = L.n; P.edges = L.edges; P.max_iterations = L.max_iterations;
+    P.decoded_bytes = L.decoded_bytes;
+    if (L.m > 512) return ULTRA_HIP_ERR_UNSUPPORTED;
+    std::vector<int> edge_row(L.edges), edge_pos(L.edges);
+    for (int i = 0; i < L.m; ++i) {
+        const int deg = L.row_ptr[i + 1] - L.row_ptr[i];
+        if (deg < 2 || deg > 8) return ULTRA_HIP_ERR_UNSUPPORTED;          // >= 1 info bit + the parity bit
+        if (L.col[L.row_ptr[i + 1] - 1] != L.k + i) return ULTRA_HIP_ERR_UNSUPPORTED;   // identity part last
+        P.row_deg[i] = (uint8_t)deg;
+        for (int e = L.row_ptr[i]; e < L.row_ptr[i + 1]; ++e) { edge_row[e] = i; edge_pos[e] = e - L.row_ptr[i]; }
+    }
+    int dmax = 0, na = 0;
+    for (int j = 0; j < L.k; ++j) {
+        const int deg = L.var_ptr[j + 1] - L.var_ptr[j];
+        if (deg == 0) continue;
+        if (deg > kLdpcPlanDmax || na >= kLdpcPlanMaxActive) return ULTRA_HIP_ERR_UNSUPPORTED;
+        P.act_var[na] = (uint16_t)j;
+        P.act_deg[na] = (uint8_t)deg;
+        for (int q = 0; q < deg; ++q) {
+            const int e = L.var_edge[L.var_ptr[j] + q];                     // ascending check order
+            P.act_slot[na * kLdpcPlanDmax + q] = (uint16_t)(8 * edge_row[e] + edge_pos[e]);
+        }
+        dmax = std::max(dmax, deg);
+        ++na;
+    }
+    for (int j = L.k; j < L.n; ++j)
+        if (L.var_ptr[j + 1] - L.var_ptr[j] != 1) return ULTRA_HIP_ERR_UNSUPPORTED;
+    P.n_active = na; P.dmax = dmax;
+    P.row_rounds = (L.m + 63) / 64;
+    P.var_rounds = (na + 63) / 64;
+    return ULTRA_HIP_OK;
+}
+
 // ---- demodulator constants ------------------------------------------------
 inline int build_demod(const ultra_hip_config& c, DemodConst& D, std::vector<c32>& nco,
                        std::vector<c32>& twiddle) {

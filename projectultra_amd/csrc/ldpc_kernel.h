@@ -1,6 +1,6 @@
-// ldpc_kernel.h — batched LDPC(648) scaled-min-sum decode for gfx950.
+// ldpc_kernel.h — batched LDPC(648) scaled-min-sum decode for gfx950: one wavefront per codeword.
 //
-// Restates LDPCDecoder::Impl::decodeBP (src/fec/ldpc_decoder.cpp:153-259):
+// Restates LDPCDecoder::Impl::decodeBP (src/fec/ldpc_decoder.cpp:153-259), flooding schedule:
 //   init   v2c[e] = llr_in[col[e]]
 //   iterate (<= max_iterations, 0-based index `it`):
 //     check step   c2v[e] = (prod_{e'!=e} sgn(v2c[e'])) * min_{e'!=e}|v2c[e']| * 0.75f   (:181-202)
@@ -9,16 +9,29 @@
 //     parity       all rows of H xor to 0 over (total < 0)  -> success, stop             (:227-235)
 //   output first k hard bits packed MSB-first, lastIterations = it (or max on failure)
 //
-// Value-identical reformulation of the check step: the brute-force "all others"
-// minimum equals min1 unless edge e holds the minimum, then min2; the sign is
-// the row's total sign parity with edge e's own sign removed (`msg < 0`, so
-// -0.0 counts as positive, as in the reference).  min/abs/compare and the single
-// multiply by 0.75f are exact or correctly rounded, so results are bit-identical.
+// Value-identical reformulations (every float operation the reference performs is performed
+// here on the same operands in the same order):
+//   * check step: the brute-force "all others" minimum is min1 unless edge e holds the minimum,
+//     then min2; the sign is the row's sign parity with edge e's own sign removed (`v < 0`, so
+//     -0.0 counts as positive as in the reference); one multiply by 0.75f.
+//   * H = [H_data | I]: parity variable k+i has exactly one edge, the last one of row i.  Its
+//     total (llr + c2v), its new v2c and its hard bit are formed by the lane that owns row i,
+//     straight from registers.
+//   * variables without any check (R3/4: info bits 325..485, R5/6: 217..539) keep
+//     total = llr_in forever; they are never touched after the load.
+//   * the parity test of iteration it-1 runs at the top of iteration it, from one hard-bit
+//     byte per edge that the variable step left next to the messages.
 //
-// Mapping: one 64-lane wavefront per codeword, the whole message state
-// (one f32 per edge, <= 9.7 KB) and the channel LLRs live in LDS; HBM sees the
-// 648 input LLRs once and ceil(k/8)+5 output bytes.  Codewords exit as soon as
-// their parity check passes (iteration counts vary 0..50 per codeword).
+// Layout in LDS per codeword: rows padded to 8 slots (max row degree is 7):
+//   msg[8*row + pos]  f32   v2c before the check step, c2v after it; pad slots hold +FLT_MAX,
+//                           which is neutral for the min (`a < FLT_MAX` false) and the sign
+//   hb [8*row + pos]  u8    hard bit of the variable on that edge (info edges only, else 0)
+//   hard[648]         u8    hard decision per variable (for the output bytes)
+// so a row is two ds_read_b128 + one ds_read_b64.  The Tanner graph lives in REGISTERS: each lane
+// keeps the degrees of the rows it owns and, for the variables it owns, their slot lists in
+// ascending check order (the order llr_total accumulates in), loaded once per workgroup;
+// workgroups are persistent and pull codewords from an atomic counter, because iteration
+// counts range from 0 to 50 per codeword.
 #ifndef ULTRA_LDPC_KERNEL_H
 #define ULTRA_LDPC_KERNEL_H
 
@@ -29,124 +42,190 @@ namespace ultra_hip {
 namespace dev {
 
 constexpr int kLdpcThreads = 64;
-
-// LDS carve (dynamic, sized per code rate by the host: ldpc_lds_bytes()):
-//   msg[edges]  v2c before the check step, c2v after it
-//   llr_in[648] channel LLRs, total[648] a-posteriori LLRs, hard[648] hard decisions
-struct LdpcShared {
-    float* msg;
-    float* llr_in;
-    float* total;
-    uint8_t* hard;
-};
-__host__ __device__ inline size_t ldpc_lds_bytes(int edges) {
-    return (size_t)((edges + 3) & ~3) * sizeof(float) + 2 * kLdpcN * sizeof(float) + ((kLdpcN + 15) & ~15);
-}
-__device__ __forceinline__ LdpcShared ldpc_carve(unsigned char* base, int edges) {
-    LdpcShared sh;
-    sh.msg = reinterpret_cast<float*>(base);
-    sh.llr_in = sh.msg + ((edges + 3) & ~3);
-    sh.total = sh.llr_in + kLdpcN;
-    sh.hard = reinterpret_cast<uint8_t*>(sh.total + kLdpcN);
-    return sh;
-}
+constexpr float kFltMax = 3.402823466e+38f;
 
 __device__ __forceinline__ float clamp50(float v) {
     const float lo = (v < 50.0f) ? v : 50.0f;        // std::min(50.0f, v)
     return (-50.0f < lo) ? lo : -50.0f;              // std::max(-50.0f, .)
 }
 
-// Decode one codeword held by this wavefront.  Returns through out params.
-__device__ __forceinline__ void ldpc_decode_wave(const LdpcShared& sh, const LdpcConst& L,
-                                                 const float* __restrict__ llr, int* out_iters, int* out_ok) {
-    const int lane = threadIdx.x;
-    const int n = L.n, m = L.m, edges = L.edges;
-    for (int j = lane; j < n; j += kLdpcThreads) {
-        const float v = llr[j];
-        sh.llr_in[j] = v;
-        sh.total[j] = v;
-    }
-    __syncthreads();
-    for (int e = lane; e < edges; e += kLdpcThreads) sh.msg[e] = sh.llr_in[L.col[e]];
-    __syncthreads();
-
-    int it = 0, ok = 0;
-    for (; it < L.max_iterations; ++it) {
-        // ---- check step: one lane per check row ----
-        for (int i = lane; i < m; i += kLdpcThreads) {
-            const int e0 = L.row_ptr[i], e1 = L.row_ptr[i + 1];
-            float min1 = 3.402823466e+38f, min2 = 3.402823466e+38f;
-            int arg = -1, neg = 0;
-            for (int e = e0; e < e1; ++e) {
-                const float v = sh.msg[e];
-                const float a = fabsf(v);
-                neg ^= (v < 0) ? 1 : 0;
-                if (a < min1) { min2 = min1; min1 = a; arg = e; }
-                else if (a < min2) { min2 = a; }
-            }
-            for (int e = e0; e < e1; ++e) {
-                const float v = sh.msg[e];
-                const int s = neg ^ ((v < 0) ? 1 : 0);
-                const float mag = (e == arg) ? min2 : min1;
-                sh.msg[e] = (s ? -mag : mag) * 0.75f;
-            }
-        }
-        __syncthreads();
-        // ---- totals + variable step: one lane per variable ----
-        for (int j = lane; j < n; j += kLdpcThreads) {
-            const int q0 = L.var_ptr[j], q1 = L.var_ptr[j + 1];
-            float t = sh.llr_in[j];
-            for (int q = q0; q < q1; ++q) t += sh.msg[L.var_edge[q]];   // ascending check order
-            sh.total[j] = t;
-            sh.hard[j] = (t < 0) ? 1 : 0;
-            for (int q = q0; q < q1; ++q) {
-                const int e = L.var_edge[q];
-                sh.msg[e] = clamp50(t - sh.msg[e]);
-            }
-        }
-        __syncthreads();
-        // ---- parity ----
-        int bad = 0;
-        for (int i = lane; i < m; i += kLdpcThreads) {
-            const int e0 = L.row_ptr[i], e1 = L.row_ptr[i + 1];
-            int s = 0;
-            for (int e = e0; e < e1; ++e) s ^= sh.hard[L.col[e]];
-            bad |= s;
-        }
-        if (__ballot(bad != 0) == 0ull) { ok = 1; break; }
-    }
-    *out_iters = it;
-    *out_ok = ok;
+__host__ __device__ inline size_t ldpc_lds_bytes(int m) {
+    return (size_t)m * 8 * sizeof(float) + (size_t)m * 8 + 656 + 648 * sizeof(float);
 }
 
-// Kernel: one 64-thread workgroup per codeword (grid-stride over codewords).
-//   llr        rows of llr_stride floats, the first 648 of each row are decoded
-//   bytes      [n_cw][decoded_bytes], iters [n_cw], ok [n_cw]
-//   llr_total  [n_cw][648] or nullptr
+// RR = ceil(m / 64) row rounds, VR = ceil(n_active / 64) variable rounds, DMAX = max variable degree
+template <int RR, int VR, int DMAX, bool WANT_TOTAL>
 __global__ __launch_bounds__(kLdpcThreads) void ldpc_decode_kernel(
-    const LdpcConst* __restrict__ Lp, const float* __restrict__ llr, size_t llr_stride, int n_cw,
+    const LdpcPlan* __restrict__ Pp, const float* __restrict__ llr, size_t llr_stride, int n_cw,
     uint8_t* __restrict__ bytes, int32_t* __restrict__ iters, uint8_t* __restrict__ okv,
-    float* __restrict__ llr_total) {
-    extern __shared__ __attribute__((aligned(16))) unsigned char ldpc_lds[];
-    const LdpcConst& L = *Lp;
-    const LdpcShared sh = ldpc_carve(ldpc_lds, L.edges);
+    float* __restrict__ llr_total, unsigned int* __restrict__ work_counter) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
+    const LdpcPlan& P = *Pp;
     const int lane = threadIdx.x;
-    for (int cw = blockIdx.x; cw < n_cw; cw += gridDim.x) {
-        int it, ok;
-        ldpc_decode_wave(sh, L, llr + (size_t)cw * llr_stride, &it, &ok);
-        // pack the k info bits MSB-first (ldpc_decoder.cpp:238-258)
-        uint8_t* ob = bytes + (size_t)cw * L.decoded_bytes;
-        for (int b = lane; b < L.decoded_bytes; b += kLdpcThreads) {
+    const int m = P.m, k = P.k, n = P.n;
+    float* msg = reinterpret_cast<float*>(lds_raw);                      // [m][8]
+    uint8_t* hb = reinterpret_cast<uint8_t*>(msg + (size_t)m * 8);       // [m][8]
+    uint8_t* hard = hb + (size_t)m * 8;                                  // [648] (+8 pad)
+    float* llr_s = reinterpret_cast<float*>(hard + 656);                 // [648] staging of the input
+
+    // ---- per-lane slice of the Tanner graph, kept in registers for the whole launch ----
+    int row_deg[RR];
+#pragma unroll
+    for (int r = 0; r < RR; ++r) { const int row = r * 64 + lane; row_deg[r] = (row < m) ? P.row_deg[row] : 0; }
+    int var_j[VR], var_deg[VR];
+    unsigned short slot[VR][DMAX];
+#pragma unroll
+    for (int r = 0; r < VR; ++r) {
+        const int a = r * 64 + lane;
+        const bool on = a < P.n_active;
+        var_j[r] = on ? P.act_var[a] : 0;
+        var_deg[r] = on ? P.act_deg[a] : 0;
+#pragma unroll
+        for (int t = 0; t < DMAX; ++t) slot[r][t] = on ? P.act_slot[a * kLdpcPlanDmax + t] : 0;
+    }
+    for (int i = lane; i < m * 2; i += kLdpcThreads) reinterpret_cast<unsigned int*>(hb)[i] = 0u;   // pad / parity slots stay 0
+    __syncthreads();
+
+    for (;;) {
+        int cw = 0;
+        if (lane == 0) cw = (int)atomicAdd(work_counter, 1u);
+        cw = __builtin_amdgcn_readfirstlane(cw);
+        if (cw >= n_cw) break;
+        const float* in = llr + (size_t)cw * llr_stride;
+
+        // ---- load: 648 LLRs once (coalesced), hard decisions of the raw channel values ----
+        for (int j = lane; j < n; j += kLdpcThreads) {
+            const float v = in[j];
+            llr_s[j] = v;
+            hard[j] = (v < 0) ? 1 : 0;
+            if (WANT_TOTAL) llr_total[(size_t)cw * kLdpcN + j] = v;
+        }
+        __syncthreads();
+        float llr_v[VR], llr_p[RR];
+        int hpar[RR];
+#pragma unroll
+        for (int r = 0; r < VR; ++r) {
+            llr_v[r] = llr_s[var_j[r]];
+#pragma unroll
+            for (int t = 0; t < DMAX; ++t)
+                if (t < var_deg[r]) msg[slot[r][t]] = llr_v[r];               // v2c = llr_in[col]
+        }
+#pragma unroll
+        for (int r = 0; r < RR; ++r) {
+            const int row = r * 64 + lane;
+            hpar[r] = 0;
+            llr_p[r] = 0.0f;
+            if (row < m) {
+                llr_p[r] = llr_s[k + row];
+#pragma unroll
+                for (int t = 0; t < 8; ++t) {
+                    if (t == row_deg[r] - 1) msg[row * 8 + t] = llr_p[r];
+                    else if (t >= row_deg[r]) msg[row * 8 + t] = kFltMax;
+                }
+            }
+        }
+        __syncthreads();
+
+        int it = 0, ok = 0;
+        for (;;) {
+            if (it > 0) {
+                // ---- parity of the totals left by iteration it-1 (checkParity :139-151) ----
+                int bad = 0;
+#pragma unroll
+                for (int r = 0; r < RR; ++r) {
+                    const int row = r * 64 + lane;
+                    if (row < m) {
+                        const uint2 b = *reinterpret_cast<const uint2*>(hb + row * 8);
+                        unsigned x = b.x ^ b.y;
+                        x ^= x >> 16;
+                        x ^= x >> 8;
+                        bad |= (int)((x & 1u) ^ (unsigned)hpar[r]);
+                    }
+                }
+                if (__ballot(bad != 0) == 0ull) { ok = 1; --it; break; }
+            }
+            if (it >= P.max_iterations) break;
+
+            // ---- check step + the row's own parity variable: one lane per row ----
+#pragma unroll
+            for (int r = 0; r < RR; ++r) {
+                const int row = r * 64 + lane;
+                if (row < m) {
+                    float4* rowp = reinterpret_cast<float4*>(msg + row * 8);
+                    const float4 lo = rowp[0], hi = rowp[1];
+                    float v[8] = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
+                    float min1 = kFltMax, min2 = kFltMax;
+                    int arg = -1, neg = 0;
+#pragma unroll
+                    for (int t = 0; t < 8; ++t) {
+                        const float a = fabsf(v[t]);
+                        neg ^= (v[t] < 0) ? 1 : 0;
+                        if (a < min1) { min2 = min1; min1 = a; arg = t; }
+                        else if (a < min2) { min2 = a; }
+                    }
+                    const int d = row_deg[r];
+                    float c_last = 0.0f;
+#pragma unroll
+                    for (int t = 0; t < 8; ++t) {
+                        const int s = neg ^ ((v[t] < 0) ? 1 : 0);
+                        const float mag = (t == arg) ? min2 : min1;
+                        const float c = (s ? -mag : mag) * 0.75f;
+                        if (t == d - 1) c_last = c;
+                        v[t] = (t < d - 1) ? c : kFltMax;
+                    }
+                    const float total_p = llr_p[r] + c_last;              // parity variable k+row
+                    hpar[r] = (total_p < 0) ? 1 : 0;
+                    const float v2c_p = clamp50(total_p - c_last);
+#pragma unroll
+                    for (int t = 0; t < 8; ++t)
+                        if (t == d - 1) v[t] = v2c_p;
+                    rowp[0] = make_float4(v[0], v[1], v[2], v[3]);
+                    rowp[1] = make_float4(v[4], v[5], v[6], v[7]);
+                    if (WANT_TOTAL) llr_total[(size_t)cw * kLdpcN + k + row] = total_p;
+                }
+            }
+            __syncthreads();
+            // ---- totals + variable step for the information bits that have checks ----
+#pragma unroll
+            for (int r = 0; r < VR; ++r) {
+                const int d = var_deg[r];
+                if (d > 0) {
+                    float c[DMAX];
+#pragma unroll
+                    for (int t = 0; t < DMAX; ++t) c[t] = (t < d) ? msg[slot[r][t]] : 0.0f;
+                    float tot = llr_v[r];
+#pragma unroll
+                    for (int t = 0; t < DMAX; ++t)
+                        if (t < d) tot += c[t];                            // ascending check order
+                    const uint8_t hbit = (tot < 0) ? 1 : 0;
+                    hard[var_j[r]] = hbit;
+#pragma unroll
+                    for (int t = 0; t < DMAX; ++t) {
+                        if (t < d) {
+                            msg[slot[r][t]] = clamp50(tot - c[t]);
+                            hb[slot[r][t]] = hbit;
+                        }
+                    }
+                    if (WANT_TOTAL) llr_total[(size_t)cw * kLdpcN + var_j[r]] = tot;
+                }
+            }
+            __syncthreads();
+            ++it;
+        }
+        const int iters_out = ok ? it : P.max_iterations;
+
+        // ---- pack the k info bits MSB-first (ldpc_decoder.cpp:238-258) ----
+        uint8_t* ob = bytes + (size_t)cw * P.decoded_bytes;
+        for (int b = lane; b < P.decoded_bytes; b += kLdpcThreads) {
             unsigned v = 0;
+#pragma unroll
             for (int t = 0; t < 8; ++t) {
                 const int j = 8 * b + t;
-                v = (v << 1) | ((j < L.k) ? (sh.total[j] < 0 ? 1u : 0u) : 0u);
+                v = (v << 1) | ((j < k) ? (unsigned)hard[j] : 0u);
             }
             ob[b] = (uint8_t)v;
         }
-        if (llr_total)
-            for (int j = lane; j < L.n; j += kLdpcThreads) llr_total[(size_t)cw * kLdpcN + j] = sh.total[j];
-        if (lane == 0) { iters[cw] = it; okv[cw] = (uint8_t)ok; }
+        if (lane == 0) { iters[cw] = iters_out; okv[cw] = (uint8_t)ok; }
         __syncthreads();
     }
 }

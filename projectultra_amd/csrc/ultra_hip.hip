@@ -28,7 +28,10 @@ struct ultra_hip_ctx {
     DemodConst h_demod{};
     LdpcConst h_ldpc{};
     DemodConst* d_demod = nullptr;
-    LdpcConst* d_ldpc = nullptr;
+    LdpcPlan h_plan{};
+    LdpcPlan* d_plan = nullptr;
+    unsigned int* d_work = nullptr;      // work-queue heads of the LDPC kernel (one per launch slot)
+    int work_slot = 0;
     c32* d_nco = nullptr;
     c32* d_twiddle = nullptr;
     // workspace for the fused call when the caller does not want LLRs
@@ -84,11 +87,33 @@ int launch_demod(ultra_hip_ctx* ctx, const float* d_audio, size_t frame_stride, 
 int launch_ldpc(ultra_hip_ctx* ctx, const float* d_llr, size_t llr_stride, size_t n_cw, uint8_t* d_bytes,
                 int32_t* d_iters, uint8_t* d_ok, float* d_llr_total) {
     if (n_cw == 0) return ULTRA_HIP_OK;
-    const size_t max_blocks = (size_t)ctx->cu_count * 256;
-    const unsigned grid = (unsigned)std::min(n_cw, max_blocks);
-    const size_t lds = dev::ldpc_lds_bytes(ctx->h_ldpc.edges);
-    hipLaunchKernelGGL(dev::ldpc_decode_kernel, dim3(grid), dim3(dev::kLdpcThreads), lds, ctx->stream,
-                       ctx->d_ldpc, d_llr, llr_stride, (int)n_cw, d_bytes, d_iters, d_ok, d_llr_total);
+    // persistent workgroups (one wavefront each) pull codewords from an atomic counter; every
+    // launch uses its own counter word, zeroed on the stream just before the launch
+    const LdpcPlan& P = ctx->h_plan;
+    const size_t lds = dev::ldpc_lds_bytes(P.m);
+    const size_t per_cu = std::max<size_t>(1, std::min<size_t>(16, (size_t)(160 * 1024) / lds));
+    const unsigned grid = (unsigned)std::min(n_cw, (size_t)ctx->cu_count * per_cu);
+    unsigned int* counter = ctx->d_work + (ctx->work_slot++ & 63);
+    UH_HIP(hipMemsetAsync(counter, 0, sizeof(unsigned int), ctx->stream));
+#define UH_LDPC_LAUNCH(RR, VR, DM)                                                                              \
+    do {                                                                                                        \
+        if (d_llr_total)                                                                                        \
+            hipLaunchKernelGGL((dev::ldpc_decode_kernel<RR, VR, DM, true>), dim3(grid), dim3(dev::kLdpcThreads), \
+                               lds, ctx->stream, ctx->d_plan, d_llr, llr_stride, (int)n_cw, d_bytes, d_iters,    \
+                               d_ok, d_llr_total, counter);                                                      \
+        else                                                                                                    \
+            hipLaunchKernelGGL((dev::ldpc_decode_kernel<RR, VR, DM, false>), dim3(grid), dim3(dev::kLdpcThreads),\
+                               lds, ctx->stream, ctx->d_plan, d_llr, llr_stride, (int)n_cw, d_bytes, d_iters,    \
+                               d_ok, d_llr_total, counter);                                                      \
+    } while (0)
+    auto fits = [&](int rr, int vr, int dm) { return P.row_rounds <= rr && P.var_rounds <= vr && P.dmax <= dm; };
+    if (fits(2, 4, 4)) UH_LDPC_LAUNCH(2, 4, 4);            // R5/6
+    else if (fits(3, 6, 4)) UH_LDPC_LAUNCH(3, 6, 4);       // R3/4
+    else if (fits(4, 7, 4)) UH_LDPC_LAUNCH(4, 7, 4);       // R2/3
+    else if (fits(6, 6, 6)) UH_LDPC_LAUNCH(6, 6, 6);       // R1/2, R1/3
+    else if (fits(8, 3, 14)) UH_LDPC_LAUNCH(8, 3, 14);     // R1/4
+    else return ULTRA_HIP_ERR_UNSUPPORTED;
+#undef UH_LDPC_LAUNCH
     UH_HIP(hipGetLastError());
     return ULTRA_HIP_OK;
 }
@@ -150,6 +175,8 @@ int ultra_hip_create(const ultra_hip_config* cfg, int device, void* stream, ultr
     geo.ldpc_edges = (uint32_t)ctx->h_ldpc.edges;
     ctx->geo = geo;
     if (ctx->h_ldpc.edges > kLdpcMaxEdges || ctx->h_ldpc.m > kLdpcMaxChecks) { delete ctx; return ULTRA_HIP_ERR_UNSUPPORTED; }
+    rc = build_ldpc_plan(ctx->h_ldpc, ctx->h_plan);
+    if (rc != ULTRA_HIP_OK) { delete ctx; return rc; }
 
     DeviceGuard guard(device);
     if (!guard.ok) { delete ctx; return ULTRA_HIP_ERR_NO_DEVICE; }
@@ -159,11 +186,12 @@ int ultra_hip_create(const ultra_hip_config* cfg, int device, void* stream, ultr
 
     auto fail = [&](int code) { ultra_hip_destroy(ctx); return code; };
     if (hipMalloc(&ctx->d_demod, sizeof(DemodConst)) != hipSuccess) return fail(ULTRA_HIP_ERR_OOM);
-    if (hipMalloc(&ctx->d_ldpc, sizeof(LdpcConst)) != hipSuccess) return fail(ULTRA_HIP_ERR_OOM);
+    if (hipMalloc(&ctx->d_plan, sizeof(LdpcPlan)) != hipSuccess) return fail(ULTRA_HIP_ERR_OOM);
+    if (hipMalloc(&ctx->d_work, 64 * sizeof(unsigned int)) != hipSuccess) return fail(ULTRA_HIP_ERR_OOM);
     if (hipMalloc(&ctx->d_nco, nco.size() * sizeof(c32)) != hipSuccess) return fail(ULTRA_HIP_ERR_OOM);
     if (hipMalloc(&ctx->d_twiddle, tw.size() * sizeof(c32)) != hipSuccess) return fail(ULTRA_HIP_ERR_OOM);
     if (hipMemcpy(ctx->d_demod, &ctx->h_demod, sizeof(DemodConst), hipMemcpyHostToDevice) != hipSuccess ||
-        hipMemcpy(ctx->d_ldpc, &ctx->h_ldpc, sizeof(LdpcConst), hipMemcpyHostToDevice) != hipSuccess ||
+        hipMemcpy(ctx->d_plan, &ctx->h_plan, sizeof(LdpcPlan), hipMemcpyHostToDevice) != hipSuccess ||
         hipMemcpy(ctx->d_nco, nco.data(), nco.size() * sizeof(c32), hipMemcpyHostToDevice) != hipSuccess ||
         hipMemcpy(ctx->d_twiddle, tw.data(), tw.size() * sizeof(c32), hipMemcpyHostToDevice) != hipSuccess)
         return fail(ULTRA_HIP_ERR_HIP);
@@ -177,7 +205,8 @@ void ultra_hip_destroy(ultra_hip_ctx* ctx) {
     if (!ctx) return;
     DeviceGuard guard(ctx->device);
     if (ctx->d_demod) (void)hipFree(ctx->d_demod);
-    if (ctx->d_ldpc) (void)hipFree(ctx->d_ldpc);
+    if (ctx->d_plan) (void)hipFree(ctx->d_plan);
+    if (ctx->d_work) (void)hipFree(ctx->d_work);
     if (ctx->d_nco) (void)hipFree(ctx->d_nco);
     if (ctx->d_twiddle) (void)hipFree(ctx->d_twiddle);
     if (ctx->d_ws_llr) (void)hipFree(ctx->d_ws_llr);
