@@ -1,0 +1,288 @@
+// ultra_hip_waveform.hpp — header-only C++ adapter over the C-ABI (include/ultra_hip.h).
+//
+// Two classes with the reference's own method names, argument meaning and failure behaviour:
+//   ultra_hip::HipLDPCDecoder   ~ ultra::LDPCDecoder    (include/ultra/fec.hpp:48-77)
+//   ultra_hip::HipOfdmWaveform  ~ the receive half of ultra::IWaveform
+//                                 (src/waveform/waveform_interface.hpp:47-157), shaped like
+//                                 OFDMChirpWaveform::process (src/waveform/ofdm_chirp_waveform.cpp:174-215):
+//                                 an external synchroniser provides timing + CFO, process() runs the
+//                                 presynced entry on the GPU and getSoftBits() hands back the LLRs.
+//
+// Compiled inside the reference tree (-DULTRA_HIP_WITH_REFERENCE, -I<ref>/include -I<ref>/src) the
+// waveform derives from ultra::IWaveform and uses the reference's own types, so RxPipeline /
+// ModemEngine / the Monte-Carlo tools can hold it through a WaveformPtr unchanged.
+// Compiled stand-alone it uses the small mirror types below.  Either way it links only against
+// libultra_hip.so; no HIP headers are needed by the caller.
+#pragma once
+
+#include <cmath>
+#include <complex>
+#include <cstdint>
+#include <cstring>
+#include <memory>
+#include <span>
+#include <stdexcept>
+#include <string>
+#include <vector>
+
+#include "ultra_hip.h"
+
+#ifdef ULTRA_HIP_WITH_REFERENCE
+#include "ultra/types.hpp"
+#include "waveform/waveform_interface.hpp"
+#endif
+
+namespace ultra_hip {
+
+#ifdef ULTRA_HIP_WITH_REFERENCE
+using ultra::Bytes;
+using ultra::CodeRate;
+using ultra::ModemConfig;
+using ultra::Modulation;
+using ultra::SampleSpan;
+using ultra::Samples;
+using ultra::SyncResult;
+using ultra::WaveformCapabilities;
+#else
+using Bytes = std::vector<uint8_t>;
+using Samples = std::vector<float>;
+using SampleSpan = std::span<const float>;
+enum class Modulation : uint8_t { DBPSK = 0, BPSK = 1, DQPSK = 2, QPSK = 3, D8PSK = 4, QAM8 = 5, QAM16 = 6,
+                                  QAM32 = 7, QAM64 = 8, QAM256 = 10 };
+enum class CodeRate : uint8_t { R1_4, R1_3, R1_2, R2_3, R3_4, R5_6, R7_8 };
+enum class CyclicPrefixMode : uint8_t { SHORT = 0, MEDIUM = 1, LONG = 2 };
+struct ModemConfig {                       // receive-path fields of ultra::ModemConfig, same defaults
+    uint32_t sample_rate = 48000, center_freq = 1500, fft_size = 512, num_carriers = 30;
+    CyclicPrefixMode cp_mode = CyclicPrefixMode::MEDIUM;
+    uint32_t symbol_guard = 4, pilot_spacing = 2;
+    bool use_pilots = true;
+    Modulation modulation = Modulation::QPSK;
+    CodeRate code_rate = CodeRate::R1_2;
+};
+struct SyncResult {
+    bool detected = false; int start_sample = -1; float correlation = 0.0f; float cfo_hz = 0.0f;
+    float snr_estimate = 0.0f; bool has_training = false;
+};
+#endif
+
+inline ultra_hip_config to_c_config(const ModemConfig& c, uint32_t entry, uint32_t n_data_symbols,
+                                    uint32_t training_symbols, uint32_t max_iterations = 50) {
+    ultra_hip_config k{};
+    k.sample_rate = c.sample_rate; k.center_freq = c.center_freq; k.fft_size = c.fft_size;
+    k.num_carriers = c.num_carriers; k.cp_mode = static_cast<uint32_t>(c.cp_mode);
+    k.symbol_guard = c.symbol_guard; k.pilot_spacing = c.pilot_spacing; k.use_pilots = c.use_pilots ? 1u : 0u;
+    k.modulation = static_cast<uint32_t>(c.modulation); k.code_rate = static_cast<uint32_t>(c.code_rate);
+    k.max_iterations = max_iterations; k.n_data_symbols = n_data_symbols; k.entry = entry;
+    k.training_symbols = (entry == ULTRA_ENTRY_PRESYNCED) ? training_symbols : 0;
+    return k;
+}
+
+namespace detail {
+struct Ctx {                               // RAII owner of an ultra_hip_ctx
+    ultra_hip_ctx* p = nullptr;
+    Ctx() = default;
+    Ctx(const ultra_hip_config& c, int device) {
+        int rc = ultra_hip_create(&c, device, nullptr, &p);
+        if (rc != ULTRA_HIP_OK) throw std::runtime_error(std::string("ultra_hip_create: ") + ultra_hip_strerror(rc));
+    }
+    Ctx(const Ctx&) = delete;
+    Ctx& operator=(const Ctx&) = delete;
+    Ctx(Ctx&& o) noexcept : p(o.p) { o.p = nullptr; }
+    Ctx& operator=(Ctx&& o) noexcept { if (this != &o) { reset(); p = o.p; o.p = nullptr; } return *this; }
+    ~Ctx() { reset(); }
+    void reset() { if (p) ultra_hip_destroy(p); p = nullptr; }
+};
+struct DevBuf {                            // device allocation tied to a context
+    ultra_hip_ctx* ctx; void* d = nullptr;
+    DevBuf(ultra_hip_ctx* c, size_t bytes) : ctx(c) {
+        if (ultra_hip_malloc(ctx, bytes, &d) != ULTRA_HIP_OK) throw std::bad_alloc();
+    }
+    ~DevBuf() { if (d) ultra_hip_free(ctx, d); }
+    DevBuf(const DevBuf&) = delete;
+    DevBuf& operator=(const DevBuf&) = delete;
+};
+inline void check(int rc, const char* what) {
+    if (rc != ULTRA_HIP_OK) throw std::runtime_error(std::string(what) + ": " + ultra_hip_strerror(rc));
+}
+}  // namespace detail
+
+// ---------------------------------------------------------------------------------------------
+class HipLDPCDecoder {
+public:
+    explicit HipLDPCDecoder(CodeRate rate, int device = 0) : rate_(rate), device_(device) { rebuild(); }
+
+    // Decode from soft bits: bit-level multi-block semantics of LDPCDecoder::decodeSoft
+    // (src/fec/ldpc_decoder.cpp:283-428): <= 648 LLRs one block (zero padded), more -> every full block
+    // contributes exactly k bits, a zero-padded tail block is decoded too, bits packed once at the end.
+    Bytes decodeSoft(std::span<const float> llrs) {
+        if (llrs.empty()) { last_success_ = false; return {}; }
+        ultra_hip_geometry g; detail::check(ultra_hip_get_geometry(ctx_.p, &g), "geometry");
+        const size_t n = 648, nblocks = (llrs.size() + n - 1) / n;
+        std::vector<float> padded(nblocks * n, 0.0f);
+        std::memcpy(padded.data(), llrs.data(), llrs.size() * sizeof(float));
+        std::vector<uint8_t> bytes(nblocks * g.decoded_bytes), ok(nblocks);
+        std::vector<int32_t> iters(nblocks);
+        decodeBatch(padded.data(), nblocks, bytes.data(), iters.data(), ok.data());
+        const bool has_tail = (llrs.size() % n) != 0 && nblocks > 1;
+        bool all = true; for (auto v : ok) all = all && v;
+        last_success_ = (nblocks == 1 || has_tail) ? ok.back() != 0 : all;
+        last_iters_ = iters.back();
+        if (nblocks == 1) return Bytes(bytes.begin(), bytes.end());
+        std::vector<uint8_t> bits;
+        bits.reserve(nblocks * g.ldpc_k);
+        for (size_t b = 0; b < nblocks; ++b)
+            for (uint32_t j = 0; j < g.ldpc_k; ++j)
+                bits.push_back((bytes[b * g.decoded_bytes + j / 8] >> (7 - j % 8)) & 1);
+        Bytes out((bits.size() + 7) / 8, 0);
+        for (size_t i = 0; i < bits.size(); ++i) if (bits[i]) out[i / 8] |= uint8_t(1u << (7 - i % 8));
+        return out;
+    }
+    Bytes decode(std::span<const uint8_t> coded) {                     // ldpc_decoder.cpp:267-281
+        std::vector<float> llrs; llrs.reserve(coded.size() * 8);
+        for (uint8_t byte : coded) for (int b = 7; b >= 0; --b) llrs.push_back(((byte >> b) & 1) ? -6.0f : 6.0f);
+        return decodeSoft(llrs);
+    }
+    // n_cw independent codewords, host buffers: llr [n_cw][648] -> bytes [n_cw][ceil(k/8)], iters, ok
+    void decodeBatch(const float* llr, size_t n_cw, uint8_t* bytes, int32_t* iters, uint8_t* ok) {
+        ultra_hip_geometry g; detail::check(ultra_hip_get_geometry(ctx_.p, &g), "geometry");
+        detail::DevBuf d_llr(ctx_.p, n_cw * 648 * sizeof(float)), d_b(ctx_.p, n_cw * g.decoded_bytes),
+            d_i(ctx_.p, n_cw * sizeof(int32_t)), d_o(ctx_.p, n_cw);
+        detail::check(ultra_hip_memcpy_h2d(ctx_.p, d_llr.d, llr, n_cw * 648 * sizeof(float)), "h2d");
+        detail::check(ultra_hip_ldpc_decode_batch(ctx_.p, static_cast<const float*>(d_llr.d), n_cw,
+                                                  static_cast<uint8_t*>(d_b.d), static_cast<int32_t*>(d_i.d),
+                                                  static_cast<uint8_t*>(d_o.d), nullptr), "ldpc_decode_batch");
+        detail::check(ultra_hip_memcpy_d2h(ctx_.p, bytes, d_b.d, n_cw * g.decoded_bytes), "d2h");
+        detail::check(ultra_hip_memcpy_d2h(ctx_.p, iters, d_i.d, n_cw * sizeof(int32_t)), "d2h");
+        detail::check(ultra_hip_memcpy_d2h(ctx_.p, ok, d_o.d, n_cw), "d2h");
+    }
+    bool lastDecodeSuccess() const { return last_success_; }
+    int lastIterations() const { return last_iters_; }
+    void setRate(CodeRate rate) { rate_ = rate; rebuild(); }
+    CodeRate getRate() const { return rate_; }
+    void setMaxIterations(int max_iter) { max_iter_ = max_iter; rebuild(); }
+
+private:
+    void rebuild() {
+        ModemConfig c; c.code_rate = rate_;
+        ctx_ = detail::Ctx(to_c_config(c, ULTRA_ENTRY_SYNCED, 44, 0, static_cast<uint32_t>(max_iter_)), device_);
+    }
+    CodeRate rate_; int device_; int max_iter_ = 50; bool last_success_ = false; int last_iters_ = 0;
+    detail::Ctx ctx_;
+};
+
+// ---------------------------------------------------------------------------------------------
+class HipOfdmWaveform
+#ifdef ULTRA_HIP_WITH_REFERENCE
+    : public ultra::IWaveform
+#endif
+{
+public:
+    explicit HipOfdmWaveform(const ModemConfig& config = ModemConfig(), int device = 0)
+        : config_(config), device_(device) {}
+
+    std::string getName() const { return "OFDM_HIP"; }
+    void configure(Modulation mod, CodeRate rate) {                     // as OFDMNvisWaveform::configure
+        config_.modulation = mod; config_.code_rate = rate;
+        config_.use_pilots = !(mod == Modulation::DBPSK || mod == Modulation::DQPSK || mod == Modulation::D8PSK);
+        ctx_.reset();
+    }
+    void setFrequencyOffset(float cfo_hz) { cfo_hz_ = cfo_hz; }
+    void setTxFrequencyOffset(float) {}
+    Modulation getModulation() const { return config_.modulation; }
+    CodeRate getCodeRate() const { return config_.code_rate; }
+    float getFrequencyOffset() const { return cfo_hz_; }
+
+    // Acquisition is the next scope row: an external synchroniser hands in what detectSync would fill.
+    bool detectSync(SampleSpan, SyncResult& result, float = 0.3f) { result = last_sync_; return last_sync_.detected; }
+    void acceptSync(const SyncResult& r) {
+        last_sync_ = r; synced_ = r.detected; cfo_hz_ = r.cfo_hz; training_start_ = r.start_sample > 0 ? r.start_sample : 0;
+    }
+
+    // samples start at the first of two training symbols (OFDMChirpWaveform::process)
+    bool process(SampleSpan samples) {
+        const uint32_t sym = symbolSamples();
+        if (samples.size() < size_t(3) * sym) return false;
+        const uint32_t n_data = static_cast<uint32_t>(samples.size() / sym) - 2;
+        if (!ctx_.p || n_data != n_data_) {
+            ctx_ = detail::Ctx(to_c_config(config_, ULTRA_ENTRY_PRESYNCED, n_data, 2), device_);
+            n_data_ = n_data;
+        }
+        ultra_hip_geometry g; detail::check(ultra_hip_get_geometry(ctx_.p, &g), "geometry");
+        // float initial_phase_rad = -2.0f * M_PI * cfo_hz_ * training_start_sample_ / sample_rate (double expr)
+        float phase = static_cast<float>((((-2.0 * M_PI) * double(cfo_hz_)) * double(training_start_)) /
+                                         double(config_.sample_rate));
+        while (double(phase) > M_PI) phase = static_cast<float>(double(phase) - 2.0 * M_PI);
+        while (double(phase) < -M_PI) phase = static_cast<float>(double(phase) + 2.0 * M_PI);
+        detail::DevBuf d_a(ctx_.p, g.frame_samples * sizeof(float)), d_c(ctx_.p, 2 * sizeof(float)),
+            d_l(ctx_.p, g.llrs_per_frame * sizeof(float)), d_s(ctx_.p, ULTRA_HIP_STATE_FLOATS * sizeof(float));
+        const float cp[2] = {cfo_hz_, phase};
+        detail::check(ultra_hip_memcpy_h2d(ctx_.p, d_a.d, samples.data(), g.frame_samples * sizeof(float)), "h2d");
+        detail::check(ultra_hip_memcpy_h2d(ctx_.p, d_c.d, cp, sizeof(cp)), "h2d");
+        detail::check(ultra_hip_demod_batch(ctx_.p, static_cast<const float*>(d_a.d), g.frame_samples,
+                                            static_cast<const float*>(d_c.d), static_cast<const float*>(d_c.d) + 1, 1,
+                                            static_cast<float*>(d_l.d), static_cast<float*>(d_s.d)), "demod_batch");
+        soft_bits_.resize(g.llrs_per_frame);
+        detail::check(ultra_hip_memcpy_d2h(ctx_.p, soft_bits_.data(), d_l.d, g.llrs_per_frame * sizeof(float)), "d2h");
+        detail::check(ultra_hip_memcpy_d2h(ctx_.p, state_, d_s.d, sizeof(state_)), "d2h");
+        return soft_bits_.size() >= 648;
+    }
+    std::vector<float> getSoftBits() { return std::move(soft_bits_); }
+    void reset() { soft_bits_.clear(); synced_ = false; }
+    bool isSynced() const { return synced_; }
+    bool hasData() const { return !soft_bits_.empty(); }
+    float estimatedSNR() const { return 10.0f * std::log10(state_[ULTRA_HIP_STATE_SNR_LINEAR]); }
+    float estimatedCFO() const { return state_[ULTRA_HIP_STATE_FREQ_OFFSET_HZ]; }
+    std::vector<std::complex<float>> getConstellationSymbols() const { return {}; }   // GUI ring: not produced
+
+    std::string getStatusString() const { return "OFDM-HIP " + std::to_string(config_.num_carriers) + " carriers"; }
+    int getCarrierCount() const { return static_cast<int>(config_.num_carriers); }
+    int getSamplesPerSymbol() const { return static_cast<int>(symbolSamples()); }
+    int getPreambleSamples() const { return 2 * getSamplesPerSymbol(); }
+    int getMinSamplesForFrame() const {                                   // ofdm_cox_waveform.cpp:231-258
+        int data_carriers = static_cast<int>(config_.num_carriers);
+        if (config_.use_pilots && config_.pilot_spacing > 0) data_carriers -= config_.num_carriers / config_.pilot_spacing;
+        static const int bpc[] = {1, 1, 2, 2, 3, 3, 4, 5, 6, 2, 8};
+        const int bits_per_symbol = data_carriers * bpc[static_cast<int>(config_.modulation) <= 10 ? static_cast<int>(config_.modulation) : 3];
+        const int data_symbols = (648 + bits_per_symbol - 1) / bits_per_symbol;
+        return (2 + data_symbols) * getSamplesPerSymbol();
+    }
+    float getThroughput(CodeRate rate) const {
+        static const float ratio[] = {0.25f, 0.333f, 0.5f, 0.667f, 0.75f, 0.833f, 0.875f};
+        int data_carriers = static_cast<int>(config_.num_carriers);
+        if (config_.use_pilots && config_.pilot_spacing > 0) data_carriers -= config_.num_carriers / config_.pilot_spacing;
+        static const int bpc[] = {1, 1, 2, 2, 3, 3, 4, 5, 6, 2, 8};
+        return float(config_.sample_rate) / float(getSamplesPerSymbol()) * float(data_carriers) *
+               float(bpc[static_cast<int>(config_.modulation) <= 10 ? static_cast<int>(config_.modulation) : 3]) *
+               ratio[static_cast<int>(rate) <= 6 ? static_cast<int>(rate) : 2];
+    }
+
+#ifdef ULTRA_HIP_WITH_REFERENCE
+    // remaining pure virtuals of ultra::IWaveform: transmit side and capability report are not part
+    // of the receive hot path; they delegate to nothing and say so.
+    ultra::protocol::WaveformMode getMode() const override { return ultra::protocol::WaveformMode::OFDM_CHIRP; }
+    WaveformCapabilities getCapabilities() const override {
+        WaveformCapabilities c; c.supports_cfo_correction = true; c.requires_pilots = config_.use_pilots; return c;
+    }
+    Samples generatePreamble() override { throw std::logic_error("HipOfdmWaveform is receive-only"); }
+    Samples modulate(const Bytes&) override { throw std::logic_error("HipOfdmWaveform is receive-only"); }
+#endif
+
+private:
+    uint32_t symbolSamples() const {
+        const uint32_t base = config_.cp_mode == decltype(config_.cp_mode)(0) ? 32u
+                            : config_.cp_mode == decltype(config_.cp_mode)(2) ? 64u : 48u;
+        return config_.fft_size + base * (config_.fft_size / 512) + config_.symbol_guard;
+    }
+    ModemConfig config_;
+    int device_;
+    detail::Ctx ctx_;
+    uint32_t n_data_ = 0;
+    float cfo_hz_ = 0.0f;
+    int training_start_ = 0;
+    bool synced_ = false;
+    SyncResult last_sync_{};
+    std::vector<float> soft_bits_;
+    float state_[ULTRA_HIP_STATE_FLOATS] = {0, 0, 1, 0, 0, 0, 0, 0};
+};
+
+}  // namespace ultra_hip
