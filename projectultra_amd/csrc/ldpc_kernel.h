@@ -44,10 +44,9 @@ namespace dev {
 constexpr int kLdpcThreads = 64;
 constexpr float kFltMax = 3.402823466e+38f;
 
-__device__ __forceinline__ float clamp50(float v) {
-    const float lo = (v < 50.0f) ? v : 50.0f;        // std::min(50.0f, v)
-    return (-50.0f < lo) ? lo : -50.0f;              // std::max(-50.0f, .)
-}
+// std::max(-50.0f, std::min(50.0f, v)): fminf/fmaxf give the same value for every input, NaN
+// included (std::min(50, NaN) = 50 because `NaN < 50` is false; fminf(50, NaN) = 50)
+__device__ __forceinline__ float clamp50(float v) { return fmaxf(-50.0f, fminf(50.0f, v)); }
 
 __host__ __device__ inline size_t ldpc_lds_bytes(int m) {
     return (size_t)m * 8 * sizeof(float) + (size_t)m * 8 + 656 + 648 * sizeof(float);
@@ -73,7 +72,7 @@ __global__ __launch_bounds__(kLdpcThreads) void ldpc_decode_kernel(
 #pragma unroll
     for (int r = 0; r < RR; ++r) { const int row = r * 64 + lane; row_deg[r] = (row < m) ? P.row_deg[row] : 0; }
     int var_j[VR], var_deg[VR];
-    unsigned short slot[VR][DMAX];
+    int slot[VR][DMAX];          // slot index (8*row + pos) of each edge of the variable, ascending check order
 #pragma unroll
     for (int r = 0; r < VR; ++r) {
         const int a = r * 64 + lane;
@@ -154,22 +153,28 @@ __global__ __launch_bounds__(kLdpcThreads) void ldpc_decode_kernel(
                     float4* rowp = reinterpret_cast<float4*>(msg + row * 8);
                     const float4 lo = rowp[0], hi = rowp[1];
                     float v[8] = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
-                    float min1 = kFltMax, min2 = kFltMax;
-                    int arg = -1, neg = 0;
+                    // min over "all others": prefix/suffix minima of |v| (min is exact and order-free;
+                    // the reference's `abs < min` update ignores NaN exactly like fminf does)
+                    float a[8], pre[8], suf[8];
+                    unsigned sg[8], par = 0u;
 #pragma unroll
                     for (int t = 0; t < 8; ++t) {
-                        const float a = fabsf(v[t]);
-                        neg ^= (v[t] < 0) ? 1 : 0;
-                        if (a < min1) { min2 = min1; min1 = a; arg = t; }
-                        else if (a < min2) { min2 = a; }
+                        a[t] = fabsf(v[t]);
+                        sg[t] = (v[t] < 0) ? 0x80000000u : 0u;     // `msg < 0`: -0.0 and NaN count as positive
+                        par ^= sg[t];
                     }
+                    pre[0] = kFltMax;
+#pragma unroll
+                    for (int t = 1; t < 8; ++t) pre[t] = fminf(pre[t - 1], a[t - 1]);
+                    suf[7] = kFltMax;
+#pragma unroll
+                    for (int t = 6; t >= 0; --t) suf[t] = fminf(suf[t + 1], a[t + 1]);
                     const int d = row_deg[r];
                     float c_last = 0.0f;
 #pragma unroll
                     for (int t = 0; t < 8; ++t) {
-                        const int s = neg ^ ((v[t] < 0) ? 1 : 0);
-                        const float mag = (t == arg) ? min2 : min1;
-                        const float c = (s ? -mag : mag) * 0.75f;
+                        const float mag = fminf(pre[t], suf[t]) * 0.75f;
+                        const float c = __uint_as_float(__float_as_uint(mag) ^ (par ^ sg[t]));   // sign * min * 0.75f
                         if (t == d - 1) c_last = c;
                         v[t] = (t < d - 1) ? c : kFltMax;
                     }
