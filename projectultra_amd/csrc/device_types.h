@@ -53,17 +53,32 @@ struct LdpcConst {
     uint16_t var_edge[kLdpcMaxEdges];
 };
 
-// Execution plan of the LDPC kernel (ldpc_kernel.h): rows padded to 8 slots, slot = 8*row + pos.
-// act_* list the information bits that have at least one check, in ascending bit order; their
-// slot lists are in ascending check order.  Parity bit k+i owns the last slot of row i.
+// Execution plan of the LDPC kernel (ldpc_kernel.h).
+// Messages live in an LDS word array whose addresses are chosen by a proper 32-edge-colouring
+// of the access structure (colour = LDS bank), so that every wave instruction of the check step
+// (lane = row, one edge position) and of the variable step (lane = variable, one edge index)
+// touches 32 distinct banks per half-wave: no bank conflicts by construction.
+//   row_addr[6*i + t]   word address of information edge t of row i (0xFFFF: row has no edge t)
+//   act_*               information bits that have at least one check, full-degree ones first;
+//                       act_addr[a*14 + q] = word address of edge q of the variable, ascending check order
+//   row_mask / act_mask random 32-bit masks of the syndrome filter (act_mask = xor of the row masks
+//                       of the variable's checks)
+//   row_col             variable index of each information edge (exact parity check, rare path)
+// The parity bit k+i of row i never touches LDS: its message stays in a register of the row's lane.
 constexpr int kLdpcPlanDmax = 14;
 constexpr int kLdpcPlanMaxActive = 576;
+constexpr int kLdpcPlanMaxRows = 512;
 struct LdpcPlan {
-    int32_t k, m, n, edges, max_iterations, decoded_bytes, n_active, row_rounds, var_rounds, dmax, _pad[2];
-    uint8_t row_deg[512];
+    int32_t k, m, n, edges, max_iterations, decoded_bytes, n_active, row_rounds, var_rounds, dmax;
+    int32_t var_rounds_full, rows_full, msg_words, _pad;
+    uint8_t row_deg[kLdpcPlanMaxRows];
+    uint16_t row_addr[kLdpcPlanMaxRows * 6];
+    uint16_t row_col[kLdpcPlanMaxRows * 6];
+    uint32_t row_mask[kLdpcPlanMaxRows];
     uint16_t act_var[kLdpcPlanMaxActive];
     uint8_t act_deg[kLdpcPlanMaxActive];
-    uint16_t act_slot[kLdpcPlanMaxActive * kLdpcPlanDmax];
+    uint32_t act_mask[kLdpcPlanMaxActive];
+    uint16_t act_addr[kLdpcPlanMaxActive * kLdpcPlanDmax];
 };
 
 }  // namespace ultra_hip

@@ -161,39 +161,115 @@ inline void build_ldpc(uint32_t rate, uint32_t max_iterations, LdpcConst& L) {
     L.var_ptr[k + m] = (uint16_t)q;
 }
 
+// Proper edge colouring of a bipartite multigraph with maximum degree <= ncolors (Koenig):
+// colour[e] in [0, ncolors), no two edges sharing an endpoint share a colour.
+inline void bipartite_edge_colouring(int n_left, int n_right, const std::vector<std::pair<int, int>>& edges,
+                                     int ncolors, std::vector<int>& colour) {
+    std::vector<std::vector<int>> at_l(n_left, std::vector<int>(ncolors, -1)), at_r(n_right, std::vector<int>(ncolors, -1));
+    colour.assign(edges.size(), -1);
+    for (size_t e = 0; e < edges.size(); ++e) {
+        const int u = edges[e].first, v = edges[e].second;
+        int a = 0, b = 0;
+        while (at_l[u][a] != -1) ++a;
+        while (at_r[v][b] != -1) ++b;
+        if (a != b) {
+            // colour a is taken at v: flip the a/b alternating path that starts at v
+            std::vector<int> path;
+            int node = v, want = a;
+            bool right = true;
+            for (;;) {
+                const int f = right ? at_r[node][want] : at_l[node][want];
+                if (f == -1) break;
+                path.push_back(f);
+                node = right ? edges[f].first : edges[f].second;
+                right = !right;
+                want = (want == a) ? b : a;
+            }
+            for (int f : path) { at_l[edges[f].first][colour[f]] = -1; at_r[edges[f].second][colour[f]] = -1; }
+            for (int f : path) {
+                colour[f] = (colour[f] == a) ? b : a;
+                at_l[edges[f].first][colour[f]] = f; at_r[edges[f].second][colour[f]] = f;
+            }
+        }
+        colour[e] = a;
+        at_l[u][a] = (int)e; at_r[v][a] = (int)e;
+    }
+}
+
 // Execution plan for the kernel, derived from the CSR graph.
 inline int build_ldpc_plan(const LdpcConst& L, LdpcPlan& P) {
     P = LdpcPlan{};
     P.k = L.k; P.m = L.m; P.n = L.n; P.edges = L.edges; P.max_iterations = L.max_iterations;
     P.decoded_bytes = L.decoded_bytes;
-    if (L.m > 512) return ULTRA_HIP_ERR_UNSUPPORTED;
-    std::vector<int> edge_row(L.edges), edge_pos(L.edges);
+    if (L.m > kLdpcPlanMaxRows) return ULTRA_HIP_ERR_UNSUPPORTED;
+    bool rows_full = true;
     for (int i = 0; i < L.m; ++i) {
         const int deg = L.row_ptr[i + 1] - L.row_ptr[i];
-        if (deg < 2 || deg > 8) return ULTRA_HIP_ERR_UNSUPPORTED;          // >= 1 info bit + the parity bit
+        if (deg < 2 || deg > 7) return ULTRA_HIP_ERR_UNSUPPORTED;          // 1..6 info bits + the parity bit
         if (L.col[L.row_ptr[i + 1] - 1] != L.k + i) return ULTRA_HIP_ERR_UNSUPPORTED;   // identity part last
         P.row_deg[i] = (uint8_t)deg;
-        for (int e = L.row_ptr[i]; e < L.row_ptr[i + 1]; ++e) { edge_row[e] = i; edge_pos[e] = e - L.row_ptr[i]; }
-    }
-    int dmax = 0, na = 0;
-    for (int j = 0; j < L.k; ++j) {
-        const int deg = L.var_ptr[j + 1] - L.var_ptr[j];
-        if (deg == 0) continue;
-        if (deg > kLdpcPlanDmax || na >= kLdpcPlanMaxActive) return ULTRA_HIP_ERR_UNSUPPORTED;
-        P.act_var[na] = (uint16_t)j;
-        P.act_deg[na] = (uint8_t)deg;
-        for (int q = 0; q < deg; ++q) {
-            const int e = L.var_edge[L.var_ptr[j] + q];                     // ascending check order
-            P.act_slot[na * kLdpcPlanDmax + q] = (uint16_t)(8 * edge_row[e] + edge_pos[e]);
-        }
-        dmax = std::max(dmax, deg);
-        ++na;
+        rows_full = rows_full && deg == 7;
+        for (int t = 0; t < 6; ++t) { P.row_addr[6 * i + t] = 0xFFFF; P.row_col[6 * i + t] = 0xFFFF; }
     }
     for (int j = L.k; j < L.n; ++j)
         if (L.var_ptr[j + 1] - L.var_ptr[j] != 1) return ULTRA_HIP_ERR_UNSUPPORTED;
+    int dmax = 0;
+    for (int j = 0; j < L.k; ++j) dmax = std::max(dmax, (int)(L.var_ptr[j + 1] - L.var_ptr[j]));
+    if (dmax > kLdpcPlanDmax) return ULTRA_HIP_ERR_UNSUPPORTED;
+
+    // active variables, full-degree ones first
+    std::vector<int> act_of(L.k, -1);
+    int na = 0, n_full = 0;
+    for (int pass = 0; pass < 2; ++pass)
+        for (int j = 0; j < L.k; ++j) {
+            const int deg = L.var_ptr[j + 1] - L.var_ptr[j];
+            if (deg == 0 || (pass == 0) != (deg == dmax)) continue;
+            if (na >= kLdpcPlanMaxActive) return ULTRA_HIP_ERR_UNSUPPORTED;
+            act_of[j] = na; P.act_var[na] = (uint16_t)j; P.act_deg[na] = (uint8_t)deg;
+            ++na;
+            if (pass == 0) ++n_full;
+        }
+
+    // syndrome-filter masks
+    std::mt19937 mrng(0xF117E5u);
+    for (int i = 0; i < L.m; ++i) P.row_mask[i] = (uint32_t)mrng();
+
+    // information edges with the wave instruction (group) that touches them in each step
+    struct Edge { int row, t, act, q; };
+    std::vector<Edge> info;
+    std::vector<std::pair<int, int>> groups;
+    for (int j = 0; j < L.k; ++j) {
+        const int a = act_of[j];
+        for (int q = 0; q < L.var_ptr[j + 1] - L.var_ptr[j]; ++q) {
+            const int e = L.var_edge[L.var_ptr[j] + q];                     // ascending check order
+            int row = 0;
+            while (!(L.row_ptr[row] <= e && e < L.row_ptr[row + 1])) ++row;
+            const int t = e - L.row_ptr[row];
+            info.push_back({row, t, a, q});
+            const int cgroup = ((row / 64) * 6 + t) * 2 + ((row % 64) / 32);         // check-step half-wave
+            const int vgroup = ((a / 64) * kLdpcPlanDmax + q) * 2 + ((a % 64) / 32);  // variable-step half-wave
+            groups.push_back({cgroup, vgroup});
+            P.row_col[6 * row + t] = (uint16_t)j;
+            P.act_mask[a] ^= P.row_mask[row];
+        }
+    }
+    const int n_cg = ((L.m + 63) / 64) * 6 * 2, n_vg = ((na + 63) / 64) * kLdpcPlanDmax * 2;
+    std::vector<int> colour;
+    bipartite_edge_colouring(n_cg, n_vg, groups, 32, colour);
+    int per_colour[32] = {0};
+    int words = 0;
+    for (size_t e = 0; e < info.size(); ++e) {
+        const int addr = 32 * per_colour[colour[e]]++ + colour[e];          // bank = colour
+        words = std::max(words, addr + 1);
+        P.row_addr[6 * info[e].row + info[e].t] = (uint16_t)addr;
+        P.act_addr[info[e].act * kLdpcPlanDmax + info[e].q] = (uint16_t)addr;
+    }
+    P.msg_words = (words + 31) & ~31;
     P.n_active = na; P.dmax = dmax;
     P.row_rounds = (L.m + 63) / 64;
     P.var_rounds = (na + 63) / 64;
+    P.var_rounds_full = n_full / 64;
+    P.rows_full = rows_full ? 1 : 0;
     return ULTRA_HIP_OK;
 }
 

@@ -11,27 +11,28 @@
 //
 // Value-identical reformulations (every float operation the reference performs is performed
 // here on the same operands in the same order):
-//   * check step: the brute-force "all others" minimum is min1 unless edge e holds the minimum,
-//     then min2; the sign is the row's sign parity with edge e's own sign removed (`v < 0`, so
-//     -0.0 counts as positive as in the reference); one multiply by 0.75f.
-//   * H = [H_data | I]: parity variable k+i has exactly one edge, the last one of row i.  Its
-//     total (llr + c2v), its new v2c and its hard bit are formed by the lane that owns row i,
-//     straight from registers.
+//   * check step: "min over all others" = min(prefix min, suffix min) of |v| (min is exact and
+//     order-free; fminf ignores NaN exactly as the reference's `abs < min` update does); the sign is
+//     the row's sign parity with edge e's own sign removed (`v < 0`: -0.0 and NaN count as
+//     positive, as in the reference), applied to min*0.75f by flipping the sign bit.
+//   * H = [H_data | I]: parity bit k+i has exactly one edge, the last one of row i.  Its message,
+//     total and hard bit never leave the registers of the lane that owns row i.
 //   * variables without any check (R3/4: info bits 325..485, R5/6: 217..539) keep
 //     total = llr_in forever; they are never touched after the load.
-//   * the parity test of iteration it-1 runs at the top of iteration it, from one hard-bit
-//     byte per edge that the variable step left next to the messages.
+//   * stopping test: the exact test "every row xors to 0" is preceded by a 32-bit linear filter
+//     F = xor_i (syndrome_i ? mask_i : 0), evaluated from the variables' side with wave shuffles
+//     (F = xor_j (hard_j ? xor_{i in N(j)} mask_i : 0)).  F != 0 proves the syndrome is non-zero;
+//     only when F == 0 (a converged codeword, or a 2^-32 coincidence) is the exact row-by-row
+//     test run.  The decision is therefore exactly the reference's.
 //
-// Layout in LDS per codeword: rows padded to 8 slots (max row degree is 7):
-//   msg[8*row + pos]  f32   v2c before the check step, c2v after it; pad slots hold +FLT_MAX,
-//                           which is neutral for the min (`a < FLT_MAX` false) and the sign
-//   hb [8*row + pos]  u8    hard bit of the variable on that edge (info edges only, else 0)
-//   hard[648]         u8    hard decision per variable (for the output bytes)
-// so a row is two ds_read_b128 + one ds_read_b64.  The Tanner graph lives in REGISTERS: each lane
-// keeps the degrees of the rows it owns and, for the variables it owns, their slot lists in
-// ascending check order (the order llr_total accumulates in), loaded once per workgroup;
-// workgroups are persistent and pull codewords from an atomic counter, because iteration
-// counts range from 0 to 50 per codeword.
+// LDS: one f32 per information edge.  The word address of every edge is chosen on the host by a
+// proper 32-colouring of the bipartite "instruction" graph (check-step half-waves x
+// variable-step half-waves; colour = LDS bank), so every ds_read/ds_write of both steps is
+// bank-conflict-free by construction (rocprof: 68 % of LDS cycles were conflicts before).  The
+// Tanner graph itself lives in REGISTERS (per lane: addresses of the 6 edges of each row it owns
+// and of the edges of each variable it owns, in ascending check order), loaded once per
+// workgroup; workgroups are persistent and pull codewords from an atomic counter because
+// iteration counts range from 0 to 50 per codeword.
 #ifndef ULTRA_LDPC_KERNEL_H
 #define ULTRA_LDPC_KERNEL_H
 
@@ -48,12 +49,20 @@ constexpr float kFltMax = 3.402823466e+38f;
 // included (std::min(50, NaN) = 50 because `NaN < 50` is false; fminf(50, NaN) = 50)
 __device__ __forceinline__ float clamp50(float v) { return fmaxf(-50.0f, fminf(50.0f, v)); }
 
-__host__ __device__ inline size_t ldpc_lds_bytes(int m) {
-    return (size_t)m * 8 * sizeof(float) + (size_t)m * 8 + 656 + 648 * sizeof(float);
+__host__ __device__ inline size_t ldpc_lds_bytes(int msg_words) {
+    return (size_t)msg_words * sizeof(float) + 656 + 648 * sizeof(float);
 }
 
-// RR = ceil(m / 64) row rounds, VR = ceil(n_active / 64) variable rounds, DMAX = max variable degree
-template <int RR, int VR, int DMAX, bool WANT_TOTAL>
+__device__ __forceinline__ unsigned wave_xor(unsigned v) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v ^= (unsigned)__shfl_xor((int)v, off, 64);
+    return v;
+}
+
+// RR = ceil(m / 64) row rounds, VR = ceil(n_active / 64) variable rounds, DMAX = max variable degree,
+// ROWS_FULL = every row has 6 information edges (R3/4, R5/6).  The first P.var_rounds_full
+// variable rounds hold only variables of degree DMAX in all 64 lanes (no predicates).
+template <int RR, int VR, int DMAX, bool ROWS_FULL, bool WANT_TOTAL>
 __global__ __launch_bounds__(kLdpcThreads) void ldpc_decode_kernel(
     const LdpcPlan* __restrict__ Pp, const float* __restrict__ llr, size_t llr_stride, int n_cw,
     uint8_t* __restrict__ bytes, int32_t* __restrict__ iters, uint8_t* __restrict__ okv,
@@ -62,28 +71,37 @@ __global__ __launch_bounds__(kLdpcThreads) void ldpc_decode_kernel(
     const LdpcPlan& P = *Pp;
     const int lane = threadIdx.x;
     const int m = P.m, k = P.k, n = P.n;
-    float* msg = reinterpret_cast<float*>(lds_raw);                      // [m][8]
-    uint8_t* hb = reinterpret_cast<uint8_t*>(msg + (size_t)m * 8);       // [m][8]
-    uint8_t* hard = hb + (size_t)m * 8;                                  // [648] (+8 pad)
+    float* msg = reinterpret_cast<float*>(lds_raw);                      // [msg_words]
+    uint8_t* hard = reinterpret_cast<uint8_t*>(msg + P.msg_words);       // [648] (+8 pad)
     float* llr_s = reinterpret_cast<float*>(hard + 656);                 // [648] staging of the input
 
     // ---- per-lane slice of the Tanner graph, kept in registers for the whole launch ----
-    int row_deg[RR];
+    bool row_ok[RR];                // row exists
+    int raddr[RR][6];               // LDS word address of information edge t of the row, -1 if none
+    unsigned rmask[RR];
 #pragma unroll
-    for (int r = 0; r < RR; ++r) { const int row = r * 64 + lane; row_deg[r] = (row < m) ? P.row_deg[row] : 0; }
-    int var_j[VR], var_deg[VR];
-    int slot[VR][DMAX];          // slot index (8*row + pos) of each edge of the variable, ascending check order
+    for (int r = 0; r < RR; ++r) {
+        const int row = r * 64 + lane;
+        row_ok[r] = row < m;
+        rmask[r] = row_ok[r] ? P.row_mask[row] : 0u;
+#pragma unroll
+        for (int t = 0; t < 6; ++t) {
+            const int a = row_ok[r] ? (int)P.row_addr[row * 6 + t] : 0xFFFF;
+            raddr[r][t] = (a == 0xFFFF) ? -1 : a;
+        }
+    }
+    int var_j[VR], var_deg[VR], vaddr[VR][DMAX];
+    unsigned vmask[VR];
 #pragma unroll
     for (int r = 0; r < VR; ++r) {
         const int a = r * 64 + lane;
         const bool on = a < P.n_active;
         var_j[r] = on ? P.act_var[a] : 0;
         var_deg[r] = on ? P.act_deg[a] : 0;
+        vmask[r] = on ? P.act_mask[a] : 0u;
 #pragma unroll
-        for (int t = 0; t < DMAX; ++t) slot[r][t] = on ? P.act_slot[a * kLdpcPlanDmax + t] : 0;
+        for (int t = 0; t < DMAX; ++t) vaddr[r][t] = on ? P.act_addr[a * kLdpcPlanDmax + t] : 0;
     }
-    for (int i = lane; i < m * 2; i += kLdpcThreads) reinterpret_cast<unsigned int*>(hb)[i] = 0u;   // pad / parity slots stay 0
-    __syncthreads();
 
     for (;;) {
         int cw = 0;
@@ -100,126 +118,140 @@ __global__ __launch_bounds__(kLdpcThreads) void ldpc_decode_kernel(
             if (WANT_TOTAL) llr_total[(size_t)cw * kLdpcN + j] = v;
         }
         __syncthreads();
-        float llr_v[VR], llr_p[RR];
-        int hpar[RR];
+        float llr_v[VR], llr_p[RR], vpar[RR];
+        int hpar[RR], hv[VR];
 #pragma unroll
         for (int r = 0; r < VR; ++r) {
             llr_v[r] = llr_s[var_j[r]];
+            hv[r] = 0;
 #pragma unroll
             for (int t = 0; t < DMAX; ++t)
-                if (t < var_deg[r]) msg[slot[r][t]] = llr_v[r];               // v2c = llr_in[col]
+                if (t < var_deg[r]) msg[vaddr[r][t]] = llr_v[r];              // v2c = llr_in[col]
         }
 #pragma unroll
         for (int r = 0; r < RR; ++r) {
-            const int row = r * 64 + lane;
+            llr_p[r] = row_ok[r] ? llr_s[k + r * 64 + lane] : 0.0f;
+            vpar[r] = llr_p[r];                                                // v2c of the parity bit
             hpar[r] = 0;
-            llr_p[r] = 0.0f;
-            if (row < m) {
-                llr_p[r] = llr_s[k + row];
-#pragma unroll
-                for (int t = 0; t < 8; ++t) {
-                    if (t == row_deg[r] - 1) msg[row * 8 + t] = llr_p[r];
-                    else if (t >= row_deg[r]) msg[row * 8 + t] = kFltMax;
-                }
-            }
         }
         __syncthreads();
 
         int it = 0, ok = 0;
+        unsigned F = 1u;                                                       // syndrome filter of iteration it-1
         for (;;) {
-            if (it > 0) {
-                // ---- parity of the totals left by iteration it-1 (checkParity :139-151) ----
+            if (it > 0 && F == 0u) {
+                // ---- exact parity test (checkParity :139-151); reached once per converged codeword ----
+#pragma unroll
+                for (int r = 0; r < VR; ++r)
+                    if (var_deg[r] > 0) hard[var_j[r]] = (uint8_t)hv[r];
+                __syncthreads();
                 int bad = 0;
 #pragma unroll
                 for (int r = 0; r < RR; ++r) {
-                    const int row = r * 64 + lane;
-                    if (row < m) {
-                        const uint2 b = *reinterpret_cast<const uint2*>(hb + row * 8);
-                        unsigned x = b.x ^ b.y;
-                        x ^= x >> 16;
-                        x ^= x >> 8;
-                        bad |= (int)((x & 1u) ^ (unsigned)hpar[r]);
+                    if (row_ok[r]) {
+                        const int row = r * 64 + lane;
+                        int s = hpar[r];
+                        for (int t = 0; t < 6; ++t) {
+                            const unsigned c = P.row_col[row * 6 + t];
+                            if (c != 0xFFFFu) s ^= hard[c];
+                        }
+                        bad |= s;
                     }
                 }
                 if (__ballot(bad != 0) == 0ull) { ok = 1; --it; break; }
             }
             if (it >= P.max_iterations) break;
 
-            // ---- check step + the row's own parity variable: one lane per row ----
+            // ---- check step + the row's own parity bit: one lane per row ----
 #pragma unroll
             for (int r = 0; r < RR; ++r) {
-                const int row = r * 64 + lane;
-                if (row < m) {
-                    float4* rowp = reinterpret_cast<float4*>(msg + row * 8);
-                    const float4 lo = rowp[0], hi = rowp[1];
-                    float v[8] = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
-                    // min over "all others": prefix/suffix minima of |v| (min is exact and order-free;
-                    // the reference's `abs < min` update ignores NaN exactly like fminf does)
-                    float a[8], pre[8], suf[8];
-                    unsigned sg[8], par = 0u;
+                if (row_ok[r]) {
+                    float v[7];
 #pragma unroll
-                    for (int t = 0; t < 8; ++t) {
+                    for (int t = 0; t < 6; ++t) {
+                        if (ROWS_FULL) v[t] = msg[raddr[r][t]];
+                        else v[t] = (raddr[r][t] >= 0) ? msg[raddr[r][t]] : kFltMax;   // missing edge: neutral
+                    }
+                    v[6] = vpar[r];
+                    float a[7], pre[7], suf[7];
+                    unsigned sg[7], par = 0u;
+#pragma unroll
+                    for (int t = 0; t < 7; ++t) {
                         a[t] = fabsf(v[t]);
-                        sg[t] = (v[t] < 0) ? 0x80000000u : 0u;     // `msg < 0`: -0.0 and NaN count as positive
+                        sg[t] = (v[t] < 0) ? 0x80000000u : 0u;
                         par ^= sg[t];
                     }
                     pre[0] = kFltMax;
 #pragma unroll
-                    for (int t = 1; t < 8; ++t) pre[t] = fminf(pre[t - 1], a[t - 1]);
-                    suf[7] = kFltMax;
+                    for (int t = 1; t < 7; ++t) pre[t] = fminf(pre[t - 1], a[t - 1]);
+                    suf[6] = kFltMax;
 #pragma unroll
-                    for (int t = 6; t >= 0; --t) suf[t] = fminf(suf[t + 1], a[t + 1]);
-                    const int d = row_deg[r];
-                    float c_last = 0.0f;
+                    for (int t = 5; t >= 0; --t) suf[t] = fminf(suf[t + 1], a[t + 1]);
 #pragma unroll
-                    for (int t = 0; t < 8; ++t) {
+                    for (int t = 0; t < 6; ++t) {
                         const float mag = fminf(pre[t], suf[t]) * 0.75f;
                         const float c = __uint_as_float(__float_as_uint(mag) ^ (par ^ sg[t]));   // sign * min * 0.75f
-                        if (t == d - 1) c_last = c;
-                        v[t] = (t < d - 1) ? c : kFltMax;
+                        if (ROWS_FULL) msg[raddr[r][t]] = c;
+                        else if (raddr[r][t] >= 0) msg[raddr[r][t]] = c;
                     }
-                    const float total_p = llr_p[r] + c_last;              // parity variable k+row
+                    const float mag6 = fminf(pre[6], suf[6]) * 0.75f;
+                    const float c_last = __uint_as_float(__float_as_uint(mag6) ^ (par ^ sg[6]));
+                    const float total_p = llr_p[r] + c_last;               // parity bit k+row
                     hpar[r] = (total_p < 0) ? 1 : 0;
-                    const float v2c_p = clamp50(total_p - c_last);
-#pragma unroll
-                    for (int t = 0; t < 8; ++t)
-                        if (t == d - 1) v[t] = v2c_p;
-                    rowp[0] = make_float4(v[0], v[1], v[2], v[3]);
-                    rowp[1] = make_float4(v[4], v[5], v[6], v[7]);
-                    if (WANT_TOTAL) llr_total[(size_t)cw * kLdpcN + k + row] = total_p;
+                    vpar[r] = clamp50(total_p - c_last);
+                    if (WANT_TOTAL) llr_total[(size_t)cw * kLdpcN + k + r * 64 + lane] = total_p;
                 }
             }
             __syncthreads();
             // ---- totals + variable step for the information bits that have checks ----
+            unsigned f = 0u;
 #pragma unroll
             for (int r = 0; r < VR; ++r) {
-                const int d = var_deg[r];
-                if (d > 0) {
+                if (r < P.var_rounds_full) {                               // wave-uniform: all 64 lanes, degree DMAX
                     float c[DMAX];
 #pragma unroll
-                    for (int t = 0; t < DMAX; ++t) c[t] = (t < d) ? msg[slot[r][t]] : 0.0f;
+                    for (int t = 0; t < DMAX; ++t) c[t] = msg[vaddr[r][t]];
                     float tot = llr_v[r];
 #pragma unroll
-                    for (int t = 0; t < DMAX; ++t)
-                        if (t < d) tot += c[t];                            // ascending check order
-                    const uint8_t hbit = (tot < 0) ? 1 : 0;
-                    hard[var_j[r]] = hbit;
+                    for (int t = 0; t < DMAX; ++t) tot += c[t];             // ascending check order
+                    hv[r] = (tot < 0) ? 1 : 0;
 #pragma unroll
-                    for (int t = 0; t < DMAX; ++t) {
-                        if (t < d) {
-                            msg[slot[r][t]] = clamp50(tot - c[t]);
-                            hb[slot[r][t]] = hbit;
-                        }
-                    }
+                    for (int t = 0; t < DMAX; ++t) msg[vaddr[r][t]] = clamp50(tot - c[t]);
                     if (WANT_TOTAL) llr_total[(size_t)cw * kLdpcN + var_j[r]] = tot;
+                } else {
+                    const int d = var_deg[r];
+                    if (d > 0) {
+                        float c[DMAX];
+#pragma unroll
+                        for (int t = 0; t < DMAX; ++t) c[t] = (t < d) ? msg[vaddr[r][t]] : 0.0f;
+                        float tot = llr_v[r];
+#pragma unroll
+                        for (int t = 0; t < DMAX; ++t)
+                            if (t < d) tot += c[t];                        // ascending check order
+                        hv[r] = (tot < 0) ? 1 : 0;
+#pragma unroll
+                        for (int t = 0; t < DMAX; ++t)
+                            if (t < d) msg[vaddr[r][t]] = clamp50(tot - c[t]);
+                        if (WANT_TOTAL) llr_total[(size_t)cw * kLdpcN + var_j[r]] = tot;
+                    }
                 }
+                f ^= hv[r] ? vmask[r] : 0u;
             }
+#pragma unroll
+            for (int r = 0; r < RR; ++r) f ^= hpar[r] ? rmask[r] : 0u;
+            F = wave_xor(f);
             __syncthreads();
             ++it;
         }
         const int iters_out = ok ? it : P.max_iterations;
 
         // ---- pack the k info bits MSB-first (ldpc_decoder.cpp:238-258) ----
+        if (!ok && P.max_iterations > 0) {                                 // on success `hard` was just refreshed
+#pragma unroll
+            for (int r = 0; r < VR; ++r)
+                if (var_deg[r] > 0) hard[var_j[r]] = (uint8_t)hv[r];
+            __syncthreads();
+        }
         uint8_t* ob = bytes + (size_t)cw * P.decoded_bytes;
         for (int b = lane; b < P.decoded_bytes; b += kLdpcThreads) {
             unsigned v = 0;

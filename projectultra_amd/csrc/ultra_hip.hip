@@ -90,28 +90,29 @@ int launch_ldpc(ultra_hip_ctx* ctx, const float* d_llr, size_t llr_stride, size_
     // persistent workgroups (one wavefront each) pull codewords from an atomic counter; every
     // launch uses its own counter word, zeroed on the stream just before the launch
     const LdpcPlan& P = ctx->h_plan;
-    const size_t lds = dev::ldpc_lds_bytes(P.m);
+    const size_t lds = dev::ldpc_lds_bytes(P.msg_words);
     const size_t per_cu = std::max<size_t>(1, std::min<size_t>(16, (size_t)(160 * 1024) / lds));
     const unsigned grid = (unsigned)std::min(n_cw, (size_t)ctx->cu_count * per_cu);
     unsigned int* counter = ctx->d_work + (ctx->work_slot++ & 63);
     UH_HIP(hipMemsetAsync(counter, 0, sizeof(unsigned int), ctx->stream));
-#define UH_LDPC_LAUNCH(RR, VR, DM)                                                                              \
+#define UH_LDPC_LAUNCH(RR, VR, DM, RF)                                                                              \
     do {                                                                                                        \
         if (d_llr_total)                                                                                        \
-            hipLaunchKernelGGL((dev::ldpc_decode_kernel<RR, VR, DM, true>), dim3(grid), dim3(dev::kLdpcThreads), \
-                               lds, ctx->stream, ctx->d_plan, d_llr, llr_stride, (int)n_cw, d_bytes, d_iters,    \
-                               d_ok, d_llr_total, counter);                                                      \
+            hipLaunchKernelGGL((dev::ldpc_decode_kernel<RR, VR, DM, RF, true>), dim3(grid),                      \
+                               dim3(dev::kLdpcThreads), lds, ctx->stream, ctx->d_plan, d_llr, llr_stride,        \
+                               (int)n_cw, d_bytes, d_iters, d_ok, d_llr_total, counter);                         \
         else                                                                                                    \
-            hipLaunchKernelGGL((dev::ldpc_decode_kernel<RR, VR, DM, false>), dim3(grid), dim3(dev::kLdpcThreads),\
-                               lds, ctx->stream, ctx->d_plan, d_llr, llr_stride, (int)n_cw, d_bytes, d_iters,    \
-                               d_ok, d_llr_total, counter);                                                      \
+            hipLaunchKernelGGL((dev::ldpc_decode_kernel<RR, VR, DM, RF, false>), dim3(grid),                     \
+                               dim3(dev::kLdpcThreads), lds, ctx->stream, ctx->d_plan, d_llr, llr_stride,        \
+                               (int)n_cw, d_bytes, d_iters, d_ok, d_llr_total, counter);                         \
     } while (0)
     auto fits = [&](int rr, int vr, int dm) { return P.row_rounds <= rr && P.var_rounds <= vr && P.dmax <= dm; };
-    if (fits(2, 4, 4)) UH_LDPC_LAUNCH(2, 4, 4);            // R5/6
-    else if (fits(3, 6, 4)) UH_LDPC_LAUNCH(3, 6, 4);       // R3/4
-    else if (fits(4, 7, 4)) UH_LDPC_LAUNCH(4, 7, 4);       // R2/3
-    else if (fits(6, 6, 6)) UH_LDPC_LAUNCH(6, 6, 6);       // R1/2, R1/3
-    else if (fits(8, 3, 14)) UH_LDPC_LAUNCH(8, 3, 14);     // R1/4
+    const bool rf = P.rows_full != 0;
+    if (rf && fits(2, 4, 3)) UH_LDPC_LAUNCH(2, 4, 3, true);            // R5/6
+    else if (rf && fits(3, 6, 3)) UH_LDPC_LAUNCH(3, 6, 3, true);       // R3/4
+    else if (fits(4, 7, 3)) UH_LDPC_LAUNCH(4, 7, 3, false);            // R2/3
+    else if (fits(6, 6, 6)) UH_LDPC_LAUNCH(6, 6, 6, false);            // R1/2, R1/3
+    else if (fits(8, 3, 14)) UH_LDPC_LAUNCH(8, 3, 14, false);          // R1/4
     else return ULTRA_HIP_ERR_UNSUPPORTED;
 #undef UH_LDPC_LAUNCH
     UH_HIP(hipGetLastError());

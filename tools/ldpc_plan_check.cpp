@@ -1,0 +1,30 @@
+// tools/ldpc_plan_check.cpp — host check of the LDPC execution plan (csrc/host_tables.h):
+// LDS addresses unique, and every half-wave instruction of the check step and of the variable
+// step touches 32 distinct banks (the edge colouring is proper).
+//   g++ -std=c++17 -O1 -Iprojectultra_amd/csrc tools/ldpc_plan_check.cpp -o /tmp/lpc && /tmp/lpc
+#include "host_tables.h"
+#include <cstdio>
+#include <set>
+using namespace ultra_hip;
+int main() {
+    int total_bad = 0;
+    for (uint32_t rate = 0; rate < 6; ++rate) {
+        LdpcConst L; build_ldpc(rate, 50, L);
+        LdpcPlan P; int rc = build_ldpc_plan(L, P);
+        std::set<int> used; int bad = 0;
+        for (int i = 0; i < L.m; i++) for (int t = 0; t < 6; t++) { int a = P.row_addr[6 * i + t]; if (a != 0xFFFF && !used.insert(a).second) bad++; }
+        for (int r = 0; r < P.row_rounds; r++) for (int t = 0; t < 6; t++) for (int h = 0; h < 2; h++) {
+            std::set<int> banks;
+            for (int l = 0; l < 32; l++) { int row = r * 64 + h * 32 + l; if (row >= L.m) continue; int a = P.row_addr[6 * row + t]; if (a == 0xFFFF) continue; if (!banks.insert(a % 32).second) bad++; }
+        }
+        for (int r = 0; r < P.var_rounds; r++) for (int q = 0; q < P.dmax; q++) for (int h = 0; h < 2; h++) {
+            std::set<int> banks;
+            for (int l = 0; l < 32; l++) { int a = r * 64 + h * 32 + l; if (a >= P.n_active || q >= P.act_deg[a]) continue; int ad = P.act_addr[a * kLdpcPlanDmax + q]; if (!banks.insert(ad % 32).second) bad++; }
+        }
+        int info_edges = L.edges - L.m;
+        printf("rate %u rc %d info_edges %d unique_addr %zu msg_words %d row_rounds %d var_rounds %d (full %d) rows_full %d dmax %d conflicts %d\n",
+               rate, rc, info_edges, used.size(), P.msg_words, P.row_rounds, P.var_rounds, P.var_rounds_full, P.rows_full, P.dmax, bad);
+        if (rc != 0 || bad != 0 || (int)used.size() != info_edges) total_bad++;
+    }
+    return total_bad ? 1 : 0;
+}
