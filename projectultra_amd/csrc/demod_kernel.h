@@ -149,10 +149,24 @@ template <int A> __device__ __forceinline__ constexpr int bitrev_small(int q) {
     } while (0)
 
 // ---------------------------------------------------------------------------
-// mix one symbol to baseband (with CFO rotation), FFT it, leave the used bins in sh.Fq
+// Asynchronous HBM -> LDS copy of the FFT window of one symbol (global_load_lds: no VGPRs, the
+// wave keeps computing).  The staging area aliases the FFT exchange buffer X, which is idle
+// between the last FFT stage of one symbol and the first LDS transpose of the next, so the HBM
+// latency of symbol s+1 hides behind the tracking / demapping of symbol s.
+template <int LOG2N>
+__device__ __forceinline__ void prefetch_symbol(DemodShared<LOG2N>& sh, const DemodConst& D,
+                                                const float* __restrict__ audio_sym) {
+    constexpr int P = (1 << LOG2N) / kWave;
+    float* stage = reinterpret_cast<float*>(sh.X);
+#pragma unroll
+    for (int q = 0; q < P; ++q)
+        __builtin_amdgcn_global_load_lds(audio_sym + D.cp + 64 * q + (int)threadIdx.x, stage + 64 * q, 4, 0, 0);
+}
+
+// mix one symbol to baseband (with CFO rotation), FFT it, leave the used bins in sh.Fq.
+// The symbol's FFT window must have been requested with prefetch_symbol().
 template <int LOG2N>
 __device__ __forceinline__ void symbol_to_freq(DemodShared<LOG2N>& sh, const DemodConst& D, Track& tr,
-                                               const float* __restrict__ audio_sym,
                                                const c32* __restrict__ nco_sym,
                                                const c32* __restrict__ twiddle) {
     constexpr int N = 1 << LOG2N, P = N / kWave, A = DemodShared<LOG2N>::A;
@@ -160,27 +174,25 @@ __device__ __forceinline__ void symbol_to_freq(DemodShared<LOG2N>& sh, const Dem
     const int rl = (int)(__brev((unsigned)lane) >> 26);      // bitrev6(lane)
     const bool cfo_on = fabsf(tr.freq_offset_hz) > 0.01f;
     c32 v[P];
+    const float* stage = reinterpret_cast<const float*>(sh.X);
+    c32 os[P];
+#pragma unroll
+    for (int qp = 0; qp < P; ++qp) os[qp] = nco_sym[D.cp + rl + 64 * qp];      // L2-resident table
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                            // staged audio has landed
+    __syncthreads();
+    float xs[P];
+#pragma unroll
+    for (int qp = 0; qp < P; ++qp) xs[qp] = stage[64 * qp + rl];
+    __syncthreads();                                                            // X may be overwritten from here on
 
     // ---- toBaseband for the samples this lane feeds into the first butterflies ----
     // bit-reversed position P*lane + q holds time sample j = bitrev_A(q)*64 + bitrev6(lane)
     if (!cfo_on) {
 #pragma unroll
-        for (int qp = 0; qp < P; ++qp) {
-            const int i = D.cp + rl + 64 * qp;
-            const float x = audio_sym[i];
-            const c32 osc = nco_sym[i];
-            v[bitrev_small<A>(qp)] = mk(osc.re * x, (-osc.im) * x);      // samples[i] * conj(osc)
-        }
+        for (int qp = 0; qp < P; ++qp)
+            v[bitrev_small<A>(qp)] = mk(os[qp].re * xs[qp], (-os[qp].im) * xs[qp]);   // samples[i] * conj(osc)
     } else {
         const float inc = (float)(((-kTwoPi) * (double)tr.freq_offset_hz) / (double)D.sample_rate);
-        float xs[P];
-        c32 os[P];
-#pragma unroll
-        for (int qp = 0; qp < P; ++qp) {                    // issue the HBM loads before the table walk
-            const int i = D.cp + rl + 64 * qp;
-            xs[qp] = audio_sym[i];
-            os[qp] = nco_sym[i];
-        }
         int done = 0;
         float pcur = tr.cfo_phase;
         while (done < D.sym_len) {                           // one round unless a table overflows
@@ -647,6 +659,7 @@ __global__ __launch_bounds__(kWave, 4) void demod_frames_kernel(
         lc.zc = D.sync_seq[lane % D.n_carriers];
     }
 
+    if ((int)blockIdx.x < n_frames) prefetch_symbol<LOG2N>(sh, D, audio + (size_t)blockIdx.x * frame_stride);
     for (int frame = blockIdx.x; frame < n_frames; frame += gridDim.x) {
         // fresh demodulator (demodulator.cpp:26-43 + SYNCED transition :533-591, or the reset
         // block of processPresynced :868-905)
@@ -663,14 +676,24 @@ __global__ __launch_bounds__(kWave, 4) void demod_frames_kernel(
 
         const float* a = audio + (size_t)frame * frame_stride;
         float* l = llr + (size_t)frame * llr_stride;
+        const int n_sym = D.n_train + D.n_data_sym;
+        const int next_frame = frame + (int)gridDim.x;
+        // software pipeline: the FFT window of the next symbol (of this frame, or the first one of
+        // the next frame this wave will process) is in flight while the current one is tracked
+        auto prefetch_after = [&](int s_done) {
+            if (s_done + 1 < n_sym) prefetch_symbol<LOG2N>(sh, D, a + (size_t)(s_done + 1) * D.sym_len);
+            else if (next_frame < n_frames) prefetch_symbol<LOG2N>(sh, D, audio + (size_t)next_frame * frame_stride);
+        };
         int s = 0;
         for (; s < D.n_train; ++s) {
-            symbol_to_freq<LOG2N>(sh, D, tr, a + (size_t)s * D.sym_len, nco + (size_t)s * D.sym_len, twiddle);
+            symbol_to_freq<LOG2N>(sh, D, tr, nco + (size_t)s * D.sym_len, twiddle);
+            prefetch_after(s);
             lts_symbol<LOG2N>(sh, D, lc, s, D.n_train, lts_acc);
         }
         if (D.n_train > 0) lts_finish<LOG2N>(sh, D, lc, tr, D.n_train, lts_acc);
         for (int ds = 0; ds < D.n_data_sym; ++ds, ++s) {
-            symbol_to_freq<LOG2N>(sh, D, tr, a + (size_t)s * D.sym_len, nco + (size_t)s * D.sym_len, twiddle);
+            symbol_to_freq<LOG2N>(sh, D, tr, nco + (size_t)s * D.sym_len, twiddle);
+            prefetch_after(s);
             if (!D.presynced || D.n_pilot != 0) update_channel_estimate<LOG2N>(sh, D, lc, tr, prev);
             equalize_demap<LOG2N>(sh, D, lc, tr, dprev, l + (size_t)ds * D.llrs_per_symbol);
         }
