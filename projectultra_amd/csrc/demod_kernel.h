@@ -65,9 +65,20 @@ __device__ __forceinline__ c32 cdivf(c32 a, float s) { return mk(a.re / s, a.im 
 __device__ __forceinline__ float cnorm(c32 a) { return a.re * a.re + a.im * a.im; }
 __device__ __forceinline__ float cabs_(c32 a) { return um::hypotf_(a.re, a.im); }
 __device__ __forceinline__ float carg_(c32 a) { return um::atan2f_(a.im, a.re); }
-__device__ __forceinline__ c32 cexpj(float t) { return mk(um::cosf_(t), um::sinf_(t)); }
+__device__ __forceinline__ c32 cexpj(float t) { float sn, cs; um::sincosf_(t, &sn, &cs); return mk(cs, sn); }
 __device__ __forceinline__ float fmin_std(float a, float b) { return (b < a) ? b : a; }  // std::min(a, b)
 __device__ __forceinline__ float fmax_std(float a, float b) { return (a < b) ? b : a; }  // std::max(a, b)
+
+// A workgroup is ONE wavefront: lanes exchange data through LDS in program order (the LDS
+// pipeline executes a wave's instructions in order), so the only thing needed between a store
+// and a dependent load by another lane is that the COMPILER keeps the order.  Unlike
+// __syncthreads() this emits no s_barrier and — important for the asynchronous HBM->LDS
+// prefetch — no s_waitcnt vmcnt(0).
+__device__ __forceinline__ void wave_sync() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
 
 constexpr double kPi = 3.14159265358979323846;
 constexpr double kTwoPi = 2.0 * kPi;
@@ -131,6 +142,7 @@ struct DemodShared {
     static constexpr int A = (P == 16) ? 4 : 3;             // log2(P)
     c32 X[N + N / P];                                       // FFT exchange buffer, 1 pad per P entries
     c32 Fq[128];                                            // used output bins: [0,64) and [N-64,N)
+    c32 tw4[128];                                           // twiddle[i * N/256]: the entries stages A..2A-1 use
     c32 H[kMaxCarriers];                                    // channel_estimate by slot
     um::PhaseSeg seg[kPhaseCap];
 };
@@ -175,23 +187,19 @@ __device__ __forceinline__ void symbol_to_freq(DemodShared<LOG2N>& sh, const Dem
     const bool cfo_on = fabsf(tr.freq_offset_hz) > 0.01f;
     c32 v[P];
     const float* stage = reinterpret_cast<const float*>(sh.X);
-    c32 os[P];
-#pragma unroll
-    for (int qp = 0; qp < P; ++qp) os[qp] = nco_sym[D.cp + rl + 64 * qp];      // L2-resident table
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                            // staged audio has landed
-    __syncthreads();
+    wave_sync();
     float xs[P];
 #pragma unroll
     for (int qp = 0; qp < P; ++qp) xs[qp] = stage[64 * qp + rl];
-    __syncthreads();                                                            // X may be overwritten from here on
+    wave_sync();                                                                // X may be overwritten from here on
 
-    // ---- toBaseband for the samples this lane feeds into the first butterflies ----
-    // bit-reversed position P*lane + q holds time sample j = bitrev_A(q)*64 + bitrev6(lane)
-    if (!cfo_on) {
-#pragma unroll
-        for (int qp = 0; qp < P; ++qp)
-            v[bitrev_small<A>(qp)] = mk(os[qp].re * xs[qp], (-os[qp].im) * xs[qp]);   // samples[i] * conj(osc)
-    } else {
+    // ---- CFO rotation factors (toBaseband: phase recurrence + cos/sin per sample) ----
+    // Computed BEFORE the oscillator values are loaded and parked in LDS (the idle exchange
+    // buffer), so that the double-precision sincos work never coexists with the 48 registers of
+    // the mixing stage: this kernel is register-limited.
+    c32* rot = sh.X;                                       // rot[P*lane + qp] (+pad)
+    if (cfo_on) {
         const float inc = (float)(((-kTwoPi) * (double)tr.freq_offset_hz) / (double)D.sample_rate);
         int done = 0;
         float pcur = tr.cfo_phase;
@@ -200,24 +208,38 @@ __device__ __forceinline__ void symbol_to_freq(DemodShared<LOG2N>& sh, const Dem
             float pnext;
             const int ns = um::phase_table_build(pcur, inc, D.sym_len - done, sh.seg, kPhaseCap, &covered, &pnext,
                                                  lane == 0);
-            __syncthreads();
-            int s = 0;
-#pragma unroll
+            wave_sync();
+            int sg = 0;
+#pragma unroll 4
             for (int qp = 0; qp < P; ++qp) {
                 const int i = D.cp + rl + 64 * qp - done;   // position inside this round
                 if (i >= 0 && i < covered) {
-                    while (s + 1 < ns && sh.seg[s + 1].start <= i) ++s;
-                    const float ph = um::phase_table_eval(sh.seg[s], i);
-                    const c32 mixed = mk(os[qp].re * xs[qp], (-os[qp].im) * xs[qp]);
-                    v[bitrev_small<A>(qp)] = cmul(mixed, mk(um::cosf_(ph), um::sinf_(ph)));
+                    while (sg + 1 < ns && sh.seg[sg + 1].start <= i) ++sg;
+                    const int xi = P * lane + qp;
+                    rot[xi + (xi >> A)] = cexpj(um::phase_table_eval(sh.seg[sg], i));
                 }
             }
-            __syncthreads();
+            wave_sync();
             done += covered;
             pcur = pnext;
         }
         tr.cfo_phase = pcur;
     }
+    // ---- mix: samples[i] * conj(osc) (* rotation), in two halves to bound live registers ----
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+        c32 os[P / 2];
+#pragma unroll
+        for (int q2 = 0; q2 < P / 2; ++q2) os[q2] = nco_sym[D.cp + rl + 64 * (h * (P / 2) + q2)];   // L2-resident table
+#pragma unroll
+        for (int q2 = 0; q2 < P / 2; ++q2) {
+            const int qp = h * (P / 2) + q2;
+            c32 mixed = mk(os[q2].re * xs[qp], (-os[q2].im) * xs[qp]);
+            if (cfo_on) { const int xi = P * lane + qp; mixed = cmul(mixed, rot[xi + (xi >> A)]); }
+            v[bitrev_small<A>(qp)] = mixed;
+        }
+    }
+    if (cfo_on) wave_sync();
 
     // ---- group A: stages 0..A-1 on the lane's P consecutive (bit-reversed) positions ----
 #pragma unroll
@@ -232,7 +254,7 @@ __device__ __forceinline__ void symbol_to_freq(DemodShared<LOG2N>& sh, const Dem
     }
 #pragma unroll
     for (int q = 0; q < P; ++q) { const int i = P * lane + q; sh.X[i + (i >> A)] = v[q]; }
-    __syncthreads();
+    wave_sync();
 
     // ---- group B: stages A..2A-1, lane (blk, r) holds X[blk*P*P + r + P*j] ----
     {
@@ -246,14 +268,15 @@ __device__ __forceinline__ void symbol_to_freq(DemodShared<LOG2N>& sh, const Dem
             for (int j = 0; j < P; ++j) {
                 if (j & hj) continue;
                 const int k = r + P * (j & (hj - 1));
-                const c32 w = twiddle[k << (LOG2N - 1 - s)];
+                // tw4[i] = twiddle[i * N/256]; the indices of these stages are multiples of N/256
+                const c32 w = sh.tw4[(k << (LOG2N - 1 - s)) >> (LOG2N - 8)];
                 UH_BUTTERFLY(v[j], v[j + hj], w);
             }
         }
 #pragma unroll
         for (int j = 0; j < P; ++j) { const int i = blk * P * P + r + P * j; sh.X[i + (i >> A)] = v[j]; }
     }
-    __syncthreads();
+    wave_sync();
 
     // ---- group C: stages 2A..LOG2N-1, lane holds X[lane + 64*t]; only outputs t = 0 and
     //      t = P-1 (bins `lane` and N-64+lane) are used, the rest is dead code ----
@@ -274,7 +297,7 @@ __device__ __forceinline__ void symbol_to_freq(DemodShared<LOG2N>& sh, const Dem
         sh.Fq[lane] = v[0];
         sh.Fq[64 + lane] = v[P - 1];
     }
-    __syncthreads();
+    wave_sync();
 }
 
 // interpolateChannel (channel_equalizer.cpp:601-631): one lane per table entry
@@ -350,7 +373,7 @@ __device__ __forceinline__ void update_channel_estimate(DemodShared<LOG2N>& sh, 
         if (valid > 0) {
             const c32 avg = cdivf(sum, (float)valid);
             const float apd = um::atan2f_(avg.im, avg.re);
-            tr.ppc = mk(um::cosf_(-apd), um::sinf_(-apd));
+            tr.ppc = cexpj(-apd);
             const float residual = (float)((double)apd / D.two_pi_symbol_duration);
             const float total = tr.freq_offset_hz + residual;
             float a = 0.3f;
@@ -400,9 +423,9 @@ __device__ __forceinline__ void update_channel_estimate(DemodShared<LOG2N>& sh, 
         const float tp = timing_phase_of(lc.pilot_k, tr.timing, D.fft);
         sh.H[lc.pilot_slot] = cmul(sh.H[lc.pilot_slot], cexpj(-tp));
     }
-    __syncthreads();
+    wave_sync();
     interpolate_channel(sh, D, lc);
-    __syncthreads();
+    wave_sync();
     if (fix && lane < D.n_carriers) {       // pilots then data carriers: every used slot exactly once
         const float tp = timing_phase_of(lc.slot_k, tr.timing, D.fft);
         sh.H[lane] = cmul(sh.H[lane], cexpj(tp));
@@ -416,7 +439,7 @@ __device__ __forceinline__ void update_channel_estimate(DemodShared<LOG2N>& sh, 
         tr.snr_linear = 0.3f * inst_snr + (1.0f - 0.3f) * tr.snr_linear;
     }
     tr.snr_symbol_count++;
-    __syncthreads();
+    wave_sync();
 }
 
 // one carrier's LLRs (soft_demap.hpp), stored to out[0..bits)
@@ -590,7 +613,7 @@ __device__ __forceinline__ void equalize_demap(DemodShared<LOG2N>& sh, const Dem
         }
     }
     if (D.differential) tr.has_dprev = 1;
-    __syncthreads();
+    wave_sync();
 }
 
 // estimateChannelFromLTS (channel_equalizer.cpp:77-328), one training symbol
@@ -607,7 +630,7 @@ __device__ __forceinline__ void lts_symbol(DemodShared<LOG2N>& sh, const DemodCo
         if (sym == 0) lts_acc = mk(0.0f, 0.0f);
         if (cabs_(lc.pilot_seq) > 0.01f) lts_acc = cadd(lts_acc, cdiv(sh.Fq[lc.pilot_fq], lc.pilot_seq));
     }
-    __syncthreads();
+    wave_sync();
 }
 
 template <int LOG2N>
@@ -616,7 +639,7 @@ __device__ __forceinline__ void lts_finish(DemodShared<LOG2N>& sh, const DemodCo
     const int lane = threadIdx.x;
     const float inv_count = 1.0f / (float)n_train;
     if (lane < D.n_pilot) sh.H[lc.pilot_slot] = cscale(lts_acc, inv_count);
-    __syncthreads();
+    wave_sync();
     float mag = 0.0f;
     if (lane < D.n_data) mag = cabs_(sh.H[lc.data_slot]);
     const float h_mag_avg = ordered_sum(mag, D.n_data) / (float)D.n_data;
@@ -625,7 +648,7 @@ __device__ __forceinline__ void lts_finish(DemodShared<LOG2N>& sh, const DemodCo
         tr.snr_linear = fmax_std(0.1f, fmin_std(10000.0f, s));
     }
     tr.snr_symbol_count = n_train;
-    __syncthreads();
+    wave_sync();
 }
 
 // ---------------------------------------------------------------------------
@@ -659,6 +682,9 @@ __global__ __launch_bounds__(kWave, 4) void demod_frames_kernel(
         lc.zc = D.sync_seq[lane % D.n_carriers];
     }
 
+    sh.tw4[lane] = twiddle[lane << (LOG2N - 8)];
+    sh.tw4[64 + lane] = twiddle[(64 + lane) << (LOG2N - 8)];
+    wave_sync();
     if ((int)blockIdx.x < n_frames) prefetch_symbol<LOG2N>(sh, D, audio + (size_t)blockIdx.x * frame_stride);
     for (int frame = blockIdx.x; frame < n_frames; frame += gridDim.x) {
         // fresh demodulator (demodulator.cpp:26-43 + SYNCED transition :533-591, or the reset
@@ -672,7 +698,7 @@ __global__ __launch_bounds__(kWave, 4) void demod_frames_kernel(
         tr.cpc_init = 0; tr.snr_symbol_count = 0; tr.symbols_since_sync = 0; tr.has_prev = 0; tr.has_dprev = 0;
         c32 prev = mk(0.0f, 0.0f), dprev = mk(1.0f, 0.0f), lts_acc = mk(0.0f, 0.0f);
         sh.H[lane] = mk(1.0f, 0.0f);
-        __syncthreads();
+        wave_sync();
 
         const float* a = audio + (size_t)frame * frame_stride;
         float* l = llr + (size_t)frame * llr_stride;
@@ -708,7 +734,7 @@ __global__ __launch_bounds__(kWave, 4) void demod_frames_kernel(
             st[ULTRA_HIP_STATE_SYMBOLS] = (float)tr.snr_symbol_count;
             st[ULTRA_HIP_STATE_RESERVED] = 0.0f;
         }
-        __syncthreads();
+        wave_sync();
     }
 }
 

@@ -84,9 +84,17 @@ UM_FN int phase_table_build(float p0, float inc, int n, PhaseSeg* seg, int cap, 
                         const float bottom = as_f32((up & 0x7f800000u) + 1u);   // 2^e + ulp
                         room = (double)ap - (double)bottom;
                     }
+                    // floor(room / |d|): room and |d| are integers (< 2^24) times the binade's ulp.  A float
+                    // quotient is within one of the true floor; the products t*|d| are exact in double
+                    // (< 2^48), so two comparisons make it exact without a double-precision divide.
                     const double ad = (d1 < 0.0f) ? -(double)d1 : (double)d1;
-                    double t = room / ad;              // exact floor: both are integers < 2^24 times u
-                    if (t < 0.0) t = 0.0;
+                    double t = 0.0;
+                    if (room > 0.0) {
+                        t = (double)(float)((float)room / (float)ad);
+                        t = (double)(long long)t;                       // trunc (t >= 0)
+                        if (t * ad > room) t -= 1.0;
+                        else if ((t + 1.0) * ad <= room) t += 1.0;
+                    }
                     const double lim = (double)(n - i - 1);
                     if (t > lim) t = lim;
                     len = (int)t + 1;                  // positions t = 0 .. floor(room/ad)

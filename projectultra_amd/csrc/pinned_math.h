@@ -149,14 +149,55 @@ UM_FN float cosf_(float y) {
     return y - y;
 }
 
-// glibc sincosf: same reduction and polynomials as sinf/cosf (s_sincosf.c);
-// cexpf(0 + i*t) = (cos t, sin t) through it (s_cexp_template.c).
-UM_FN void sincosf_(float y, float* sp, float* cp) { *sp = sinf_(y); *cp = cosf_(y); }
+// glibc sincosf (s_sincosf.c, sincosf_poly): ONE reduction, the sine polynomial of (x*s, x2) and
+// the cosine polynomial of x2 (which does not depend on the sign s), swapped when the quadrant is
+// odd.  Bit-identical to (sinf_(y), cosf_(y)) — the separate functions evaluate exactly these two
+// polynomials, one each — but branch-free and half the work; cexpf(0 + i*t) = (cos t, sin t)
+// goes through it (s_cexp_template.c).
+UM_FN void sincosf_(float y, float* sp, float* cp) {
+    const SinCosTab t0 = UM_TAB0, t1 = UM_TAB1;
+    double x = y, s = 1.0;
+    int n = 0;
+    bool second = false;
+    const uint32_t top = abstop12(y);
+    if (top < 0x3f4) {                       // |y| < pi/4
+        if (top < 0x398) { *sp = y; *cp = 1.0f; return; }   // |y| < 2^-12
+    } else if (top < 0x42f) {                // |y| < 120
+        x = reduce_fast(x, &n);
+        s = quadrant_sign(n);
+        second = (n & 2) != 0;
+    } else if (top < 0x7f8) {
+        const uint32_t xi = as_u32(y);
+        const int sign = (int)(xi >> 31);
+        x = reduce_large(xi, &n);
+        s = quadrant_sign(n + sign);         // sign and table include the input's sign,
+        second = ((n + sign) & 2) != 0;      // the sin/cos swap below uses n alone (s_sincosf.c)
+    } else {
+        *sp = y - y; *cp = y - y; return;    // inf/NaN -> NaN
+    }
+    const SinCosTab& p = second ? t1 : t0;
+    const double x2 = x * x, xs = x * s;
+    // sine polynomial (sinf_poly, n even)
+    const double x3 = xs * x2;
+    const double s1 = fma(x2, p.s3, p.s2);
+    const double x7 = x3 * x2;
+    const double sa = fma(x3, p.s1, xs);
+    const float sine = (float)fma(x7, s1, sa);
+    // cosine polynomial (sinf_poly, n odd)
+    const double x4 = x2 * x2;
+    const double c2 = fma(x2, p.c4, p.c3);
+    const double c1 = fma(x2, p.c1, p.c0);
+    const double x6 = x4 * x2;
+    const double ca = fma(x4, p.c2, c1);
+    const float cosine = (float)fma(x6, c2, ca);
+    if (n & 1) { *sp = cosine; *cp = sine; } else { *sp = sine; *cp = cosine; }
+}
 
 // fdlibm atanf (s_atanf.c)
 UM_FN float atanf_(float x) {
-    const float atanhi[4] = {as_f32(0x3eed6338), as_f32(0x3f490fda), as_f32(0x3f7b985e), as_f32(0x3fc90fda)};
-    const float atanlo[4] = {as_f32(0x31ac3769), as_f32(0x33222168), as_f32(0x33140fb4), as_f32(0x33a22168)};
+    // atanhi / atanlo as selects (a dynamically indexed local array would live in memory on the GPU)
+    const float hi0 = as_f32(0x3eed6338), hi1 = as_f32(0x3f490fda), hi2 = as_f32(0x3f7b985e), hi3 = as_f32(0x3fc90fda);
+    const float lo0 = as_f32(0x31ac3769), lo1 = as_f32(0x33222168), lo2 = as_f32(0x33140fb4), lo3 = as_f32(0x33a22168);
     const float aT0 = as_f32(0x3eaaaaab), aT1 = as_f32(0xbe4ccccd), aT2 = as_f32(0x3e124925),
                 aT3 = as_f32(0xbde38e38), aT4 = as_f32(0x3dba2e6e), aT5 = as_f32(0xbd9d8795),
                 aT6 = as_f32(0x3d886b35), aT7 = as_f32(0xbd6ef16b), aT8 = as_f32(0x3d4bda59),
@@ -166,8 +207,8 @@ UM_FN float atanf_(float x) {
     int id;
     if (ix >= 0x4c000000) {  // |x| >= 2^25
         if (ix > 0x7f800000) return x + x;
-        if (hx > 0) return atanhi[3] + atanlo[3];
-        return -atanhi[3] - atanlo[3];
+        if (hx > 0) return hi3 + lo3;
+        return -hi3 - lo3;
     }
     if (ix < 0x3ee00000) {       // |x| < 0.4375
         if (ix < 0x31000000) return x;  // |x| < 2^-29 (huge + x > one always holds)
@@ -187,7 +228,9 @@ UM_FN float atanf_(float x) {
     float s1 = z * (aT0 + w * (aT2 + w * (aT4 + w * (aT6 + w * (aT8 + w * aT10)))));
     float s2 = w * (aT1 + w * (aT3 + w * (aT5 + w * (aT7 + w * aT9))));
     if (id < 0) return x - x * (s1 + s2);
-    z = atanhi[id] - ((x * (s1 + s2) - atanlo[id]) - x);
+    const float ahi = (id == 0) ? hi0 : (id == 1) ? hi1 : (id == 2) ? hi2 : hi3;
+    const float alo = (id == 0) ? lo0 : (id == 1) ? lo1 : (id == 2) ? lo2 : lo3;
+    z = ahi - ((x * (s1 + s2) - alo) - x);
     return (hx < 0) ? -z : z;
 }
 

@@ -38,7 +38,8 @@ int main(int argc, char** argv) {
             float s, c; sincosf(x, &s, &c);
             lc[0]++; if (!same(um::sinf_(x), sinf(x))) { if (lb[0]++ < 3) fprintf(stderr, "sinf %08x\n", (unsigned)u); }
             lc[1]++; if (!same(um::cosf_(x), cosf(x))) { if (lb[1]++ < 3) fprintf(stderr, "cosf %08x\n", (unsigned)u); }
-            lc[2]++; if (!same(um::sinf_(x), s) || !same(um::cosf_(x), c)) lb[2]++;
+            float ms, mc; um::sincosf_(x, &ms, &mc);
+            lc[2]++; if (!same(ms, s) || !same(mc, c)) { if (lb[2]++ < 3) fprintf(stderr, "sincosf %08x\n", (unsigned)u); }
             lc[3]++; if (!same(um::atanf_(x), atanf(x))) { if (lb[3]++ < 3) fprintf(stderr, "atanf %08x\n", (unsigned)u); }
         }
         uint64_t seed = 0x1234 + t;
