@@ -1,4 +1,4 @@
-// demod_kernel.h — batched OFDM demodulation for gfx950: ONE WAVEFRONT PER FRAME.
+// demod_kernel.h — batched OFDM demodulation for gfx950: ONE WAVEFRONT PER FRAME, two kernels per symbol.
 //
 // Restates, with the reference's exact float/double operation order, the
 // per-symbol chain of OFDMDemodulator (SYNCED loop src/ofdm/demodulator.cpp:
@@ -12,9 +12,14 @@
 //   demodulateSymbol      src/ofdm/demodulator.cpp:199-435 + src/ofdm/soft_demap.hpp
 //
 // Mapping (MI355X, wave64): frames are independent, symbols inside a frame are
-// sequential (CFO / channel / noise tracking feed forward).  One 64-lane wavefront
-// owns one frame; a CU keeps ~15 frames in flight (LDS-bound, ~10 KB each), so the
-// short serial stretches of one frame hide behind the butterflies of the others.
+// sequential (CFO / channel / noise tracking feed forward).  Each symbol is processed by
+// two launches over the whole batch, one 64-lane wavefront per frame in both:
+//   mix_fft_kernel   audio -> the 59/30 used FFT bins (streaming, no per-frame state in registers:
+//                    high occupancy, the FFT and the double-precision sincos hide each other's latency)
+//   track_kernel     pilots -> tracker update -> equalise -> LLRs (tiny, state record in HBM)
+// The per-frame tracker state (channel estimate, previous pilots, scalars: < 1 KB) lives in a
+// workspace record between the two; splitting the monolithic per-frame kernel this way removed
+// its register spills and nearly doubled the resident waves per CU.
 //   * mixing: every lane loads the 8/16 time samples it needs for the first FFT
 //     stages straight from HBM (the wave reads 64 consecutive floats per load; the
 //     cyclic prefix and guard are never fetched), multiplies by the NCO table and
@@ -136,16 +141,28 @@ struct LaneConst {
 };
 
 template <int LOG2N>
-struct DemodShared {
+struct FftShared {                                          // mix_fft_kernel
     static constexpr int N = 1 << LOG2N;
     static constexpr int P = N / kWave;                     // points per lane: 8 / 16
     static constexpr int A = (P == 16) ? 4 : 3;             // log2(P)
     c32 X[N + N / P];                                       // FFT exchange buffer, 1 pad per P entries
-    c32 Fq[128];                                            // used output bins: [0,64) and [N-64,N)
     c32 tw4[128];                                           // twiddle[i * N/256]: the entries stages A..2A-1 use
-    c32 H[kMaxCarriers];                                    // channel_estimate by slot
     um::PhaseSeg seg[kPhaseCap];
 };
+struct TrackShared {                                        // track_kernel
+    c32 H[kMaxCarriers];                                    // channel_estimate by slot
+};
+
+// Per-frame record between the kernels (floats).  Arrays are c32 indexed by lane.
+constexpr int kStScal = 0;          // 16 scalars, see st_* below
+constexpr int kStH = 16;            // c32 H[64]
+constexpr int kStPrev = 16 + 128;   // c32 prev_pilot_phases[64]
+constexpr int kStDprev = 16 + 256;  // c32 dbpsk_prev_equalized[64]
+constexpr int kStLts = 16 + 384;    // c32 h_sum_pilot[64] (presynced)
+constexpr int kStFloats = 16 + 512;
+enum { st_cfo = 0, st_cfo_filt, st_cfo_phase, st_noise, st_snr, st_timing, st_ppc_re, st_ppc_im, st_cpc_re, st_cpc_im,
+       st_flags, st_count, st_since };
+constexpr int kFqFloats = 256;      // c32 Fq[128] per frame: bins [0,64) and [N-64,N)
 
 template <int A> __device__ __forceinline__ constexpr int bitrev_small(int q) {
     int r = 0;
@@ -166,7 +183,7 @@ template <int A> __device__ __forceinline__ constexpr int bitrev_small(int q) {
 // between the last FFT stage of one symbol and the first LDS transpose of the next, so the HBM
 // latency of symbol s+1 hides behind the tracking / demapping of symbol s.
 template <int LOG2N>
-__device__ __forceinline__ void prefetch_symbol(DemodShared<LOG2N>& sh, const DemodConst& D,
+__device__ __forceinline__ void prefetch_symbol(FftShared<LOG2N>& sh, const DemodConst& D,
                                                 const float* __restrict__ audio_sym) {
     constexpr int P = (1 << LOG2N) / kWave;
     float* stage = reinterpret_cast<float*>(sh.X);
@@ -178,13 +195,13 @@ __device__ __forceinline__ void prefetch_symbol(DemodShared<LOG2N>& sh, const De
 // mix one symbol to baseband (with CFO rotation), FFT it, leave the used bins in sh.Fq.
 // The symbol's FFT window must have been requested with prefetch_symbol().
 template <int LOG2N>
-__device__ __forceinline__ void symbol_to_freq(DemodShared<LOG2N>& sh, const DemodConst& D, Track& tr,
-                                               const c32* __restrict__ nco_sym,
-                                               const c32* __restrict__ twiddle) {
-    constexpr int N = 1 << LOG2N, P = N / kWave, A = DemodShared<LOG2N>::A;
+__device__ __forceinline__ void symbol_to_freq(FftShared<LOG2N>& sh, const DemodConst& D, float freq_offset_hz,
+                                               float& cfo_phase, const c32* __restrict__ nco_sym,
+                                               const c32* __restrict__ twiddle, c32* __restrict__ fq_out) {
+    constexpr int N = 1 << LOG2N, P = N / kWave, A = FftShared<LOG2N>::A;
     const int lane = threadIdx.x;
     const int rl = (int)(__brev((unsigned)lane) >> 26);      // bitrev6(lane)
-    const bool cfo_on = fabsf(tr.freq_offset_hz) > 0.01f;
+    const bool cfo_on = fabsf(freq_offset_hz) > 0.01f;
     c32 v[P];
     const float* stage = reinterpret_cast<const float*>(sh.X);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                            // staged audio has landed
@@ -200,9 +217,9 @@ __device__ __forceinline__ void symbol_to_freq(DemodShared<LOG2N>& sh, const Dem
     // the mixing stage: this kernel is register-limited.
     c32* rot = sh.X;                                       // rot[P*lane + qp] (+pad)
     if (cfo_on) {
-        const float inc = (float)(((-kTwoPi) * (double)tr.freq_offset_hz) / (double)D.sample_rate);
+        const float inc = (float)(((-kTwoPi) * (double)freq_offset_hz) / (double)D.sample_rate);
         int done = 0;
-        float pcur = tr.cfo_phase;
+        float pcur = cfo_phase;
         while (done < D.sym_len) {                           // one round unless a table overflows
             int covered;
             float pnext;
@@ -223,7 +240,7 @@ __device__ __forceinline__ void symbol_to_freq(DemodShared<LOG2N>& sh, const Dem
             done += covered;
             pcur = pnext;
         }
-        tr.cfo_phase = pcur;
+        cfo_phase = pcur;
     }
     // ---- mix: samples[i] * conj(osc) (* rotation), in two halves to bound live registers ----
 #pragma unroll
@@ -294,15 +311,14 @@ __device__ __forceinline__ void symbol_to_freq(DemodShared<LOG2N>& sh, const Dem
                 UH_BUTTERFLY(v[t], v[t + ht], w);
             }
         }
-        sh.Fq[lane] = v[0];
-        sh.Fq[64 + lane] = v[P - 1];
+        fq_out[lane] = v[0];
+        fq_out[64 + lane] = v[P - 1];
     }
     wave_sync();
 }
 
 // interpolateChannel (channel_equalizer.cpp:601-631): one lane per table entry
-template <int LOG2N>
-__device__ __forceinline__ void interpolate_channel(DemodShared<LOG2N>& sh, const DemodConst& D, const LaneConst& lc) {
+__device__ __forceinline__ void interpolate_channel(TrackShared& sh, const DemodConst& D, const LaneConst& lc) {
     if ((int)threadIdx.x < D.n_interp) {
         const int lo = lc.i_lo, hi = lc.i_hi, dst = lc.i_dst;
         if (lo >= 0 && hi >= 0) {
@@ -320,16 +336,15 @@ __device__ __forceinline__ void interpolate_channel(DemodShared<LOG2N>& sh, cons
 }
 
 // updateChannelEstimate (channel_equalizer.cpp:330-595); prev = prev_pilot_phases[lane]
-template <int LOG2N>
-__device__ __forceinline__ void update_channel_estimate(DemodShared<LOG2N>& sh, const DemodConst& D,
-                                                        const LaneConst& lc, Track& tr, c32& prev) {
+__device__ __forceinline__ void update_channel_estimate(TrackShared& sh, const DemodConst& D, const LaneConst& lc,
+                                                        Track& tr, c32& prev, const c32* __restrict__ fq) {
     const int lane = threadIdx.x;
     const int np = D.n_pilot;
     const bool is_pilot = lane < np;
     const float alpha = (tr.snr_symbol_count == 0) ? 1.0f : 0.9f;
 
     c32 h = mk(0.0f, 0.0f);
-    if (is_pilot) h = cdiv(sh.Fq[lc.pilot_fq], lc.pilot_seq);
+    if (is_pilot) h = cdiv(fq[lc.pilot_fq], lc.pilot_seq);
     c32 h_sum = ordered_csum(h, np);
     if (!tr.cpc_init && np != 0) {                              // carrier phase recovery (:348-357)
         const c32 h_avg = cdivf(h_sum, (float)np);
@@ -543,9 +558,8 @@ __device__ __forceinline__ void demap_carrier(int modulation, c32 sym, c32 prev,
 
 // equalize (channel_equalizer.cpp:728-840, adaptive_eq off) + demodulateSymbol
 // (demodulator.cpp:199-435) for one symbol; dprev = dbpsk_prev_equalized[lane]
-template <int LOG2N>
-__device__ __forceinline__ void equalize_demap(DemodShared<LOG2N>& sh, const DemodConst& D, const LaneConst& lc,
-                                               Track& tr, c32& dprev, float* __restrict__ llr_sym) {
+__device__ __forceinline__ void equalize_demap(TrackShared& sh, const DemodConst& D, const LaneConst& lc, Track& tr,
+                                               c32& dprev, const c32* __restrict__ fq, float* __restrict__ llr_sym) {
     const int lane = threadIdx.x;
     const int nd = D.n_data;
     const bool is_data = lane < nd;
@@ -553,7 +567,7 @@ __device__ __forceinline__ void equalize_demap(DemodShared<LOG2N>& sh, const Dem
     float nv = 100.0f;
     if (D.differential) {
         if (is_data) {
-            const c32 received = sh.Fq[lc.data_fq], h = sh.H[lc.data_slot];
+            const c32 received = fq[lc.data_fq], h = sh.H[lc.data_slot];
             const float h_power = cnorm(h);
             const c32 tc = cexpj(timing_phase_of(lc.data_k, tr.timing, D.fft));
             if (h_power > 1e-6f) {
@@ -569,7 +583,7 @@ __device__ __forceinline__ void equalize_demap(DemodShared<LOG2N>& sh, const Dem
     } else {
         float h_power = 0.0f;
         if (is_data) {
-            const c32 received = sh.Fq[lc.data_fq], h = sh.H[lc.data_slot];
+            const c32 received = fq[lc.data_fq], h = sh.H[lc.data_slot];
             h_power = cnorm(h);
             const float mmse_denom = h_power + tr.noise_variance;
             if (mmse_denom < 1e-10f) {
@@ -617,25 +631,23 @@ __device__ __forceinline__ void equalize_demap(DemodShared<LOG2N>& sh, const Dem
 }
 
 // estimateChannelFromLTS (channel_equalizer.cpp:77-328), one training symbol
-template <int LOG2N>
-__device__ __forceinline__ void lts_symbol(DemodShared<LOG2N>& sh, const DemodConst& D, const LaneConst& lc,
-                                           int sym, int n_train, c32& lts_acc) {
+__device__ __forceinline__ void lts_symbol(TrackShared& sh, const DemodConst& D, const LaneConst& lc, int sym,
+                                           int n_train, c32& lts_acc, const c32* __restrict__ fq) {
     const int lane = threadIdx.x;
     if (lane < D.n_data && sym == n_train - 1) {
         c32 h = mk(0.0f, 0.0f);
-        if (cabs_(lc.zc) > 0.01f) h = cdiv(sh.Fq[lc.data_fq], lc.zc);
+        if (cabs_(lc.zc) > 0.01f) h = cdiv(fq[lc.data_fq], lc.zc);
         sh.H[lc.data_slot] = h;                                   // last training symbol's estimate
     }
     if (lane < D.n_pilot) {
         if (sym == 0) lts_acc = mk(0.0f, 0.0f);
-        if (cabs_(lc.pilot_seq) > 0.01f) lts_acc = cadd(lts_acc, cdiv(sh.Fq[lc.pilot_fq], lc.pilot_seq));
+        if (cabs_(lc.pilot_seq) > 0.01f) lts_acc = cadd(lts_acc, cdiv(fq[lc.pilot_fq], lc.pilot_seq));
     }
     wave_sync();
 }
 
-template <int LOG2N>
-__device__ __forceinline__ void lts_finish(DemodShared<LOG2N>& sh, const DemodConst& D, const LaneConst& lc,
-                                           Track& tr, int n_train, c32 lts_acc) {
+__device__ __forceinline__ void lts_finish(TrackShared& sh, const DemodConst& D, const LaneConst& lc, Track& tr,
+                                           int n_train, c32 lts_acc) {
     const int lane = threadIdx.x;
     const float inv_count = 1.0f / (float)n_train;
     if (lane < D.n_pilot) sh.H[lc.pilot_slot] = cscale(lts_acc, inv_count);
@@ -652,22 +664,66 @@ __device__ __forceinline__ void lts_finish(DemodShared<LOG2N>& sh, const DemodCo
 }
 
 // ---------------------------------------------------------------------------
-// Kernel: one 64-lane workgroup per frame (grid-stride over frames).
-//   audio     [n_frames] rows of frame_stride floats
-//   cfo_hz    [n_frames] or nullptr, cfo_phase [n_frames] or nullptr
-//   llr       [n_frames][llr_stride] (llr_stride >= llrs_per_frame)
-//   state     [n_frames][ULTRA_HIP_STATE_FLOATS] or nullptr
+// Kernels.  All three use one 64-lane workgroup per frame with a grid-stride loop over frames.
+//   state   [n_frames][kStFloats] f32 workspace records
+//   fq      [n_frames][128] c32 workspace: the used FFT bins of the symbol in flight
+
+// Fresh demodulator per frame (demodulator.cpp:26-43 + SYNCED transition :533-591, or the reset
+// block of processPresynced :868-905).
+__global__ __launch_bounds__(kWave) void init_state_kernel(const float* __restrict__ cfo_hz,
+                                                           const float* __restrict__ cfo_phase, int n_frames,
+                                                           float* __restrict__ state) {
+    const int lane = threadIdx.x;
+    for (int frame = blockIdx.x; frame < n_frames; frame += gridDim.x) {
+        float* st = state + (size_t)frame * kStFloats;
+        reinterpret_cast<c32*>(st + kStH)[lane] = mk(1.0f, 0.0f);
+        if (lane < 16) {
+            float v = 0.0f;
+            const float cfo = cfo_hz ? cfo_hz[frame] : 0.0f;
+            if (lane == st_cfo || lane == st_cfo_filt) v = cfo;
+            else if (lane == st_cfo_phase) v = cfo_phase ? cfo_phase[frame] : 0.0f;
+            else if (lane == st_noise) v = 0.1f;
+            else if (lane == st_snr) v = 1.0f;
+            else if (lane == st_ppc_re || lane == st_cpc_re) v = 1.0f;
+            st[lane] = v;
+        }
+    }
+}
+
+// toBaseband + extractSymbol/FFT of symbol `sym` of every frame.
 template <int LOG2N>
-__global__ __launch_bounds__(kWave, 4) void demod_frames_kernel(
+__global__ __launch_bounds__(kWave, 5) void mix_fft_kernel(
     const DemodConst* __restrict__ Dp, const c32* __restrict__ nco, const c32* __restrict__ twiddle,
-    const float* __restrict__ audio, size_t frame_stride, const float* __restrict__ cfo_hz,
-    const float* __restrict__ cfo_phase, int n_frames, float* __restrict__ llr, size_t llr_stride,
-    float* __restrict__ state) {
-    __shared__ DemodShared<LOG2N> sh;
+    const float* __restrict__ audio, size_t frame_stride, int n_frames, int sym, float* __restrict__ state,
+    c32* __restrict__ fq) {
+    __shared__ FftShared<LOG2N> sh;
     const DemodConst& D = *Dp;
     const int lane = threadIdx.x;
-    constexpr int N = 1 << LOG2N;
+    sh.tw4[lane] = twiddle[lane << (LOG2N - 8)];
+    sh.tw4[64 + lane] = twiddle[(64 + lane) << (LOG2N - 8)];
+    wave_sync();
+    const size_t sym_off = (size_t)sym * D.sym_len;
+    if ((int)blockIdx.x < n_frames) prefetch_symbol<LOG2N>(sh, D, audio + (size_t)blockIdx.x * frame_stride + sym_off);
+    for (int frame = blockIdx.x; frame < n_frames; frame += gridDim.x) {
+        float* st = state + (size_t)frame * kStFloats;
+        const float cfo = st[st_cfo];
+        float phase = st[st_cfo_phase];
+        symbol_to_freq<LOG2N>(sh, D, cfo, phase, nco + sym_off, twiddle, fq + (size_t)frame * 128);
+        if (lane == 0) st[st_cfo_phase] = phase;
+        const int next = frame + (int)gridDim.x;
+        if (next < n_frames) prefetch_symbol<LOG2N>(sh, D, audio + (size_t)next * frame_stride + sym_off);
+    }
+}
 
+// mode 0: data symbol (updateChannelEstimate + equalize + demodulateSymbol)
+// mode 1: training symbol `sym` of n_train (estimateChannelFromLTS), finishing on the last one
+__global__ __launch_bounds__(kWave) void track_kernel(
+    const DemodConst* __restrict__ Dp, int n_frames, int mode, int sym, int data_sym, float* __restrict__ state,
+    const c32* __restrict__ fq_all, float* __restrict__ llr, size_t llr_stride, float* __restrict__ state_out) {
+    __shared__ TrackShared sh;
+    const DemodConst& D = *Dp;
+    const int lane = threadIdx.x;
+    const int N = D.fft;
     LaneConst lc;
     {
         auto fq_of = [&](int bin) { return (bin < 64) ? bin : 64 + (bin - (N - 64)); };
@@ -681,58 +737,51 @@ __global__ __launch_bounds__(kWave, 4) void demod_frames_kernel(
         lc.slot_k = D.k_of[(lane < D.n_carriers) ? lane : 0];
         lc.zc = D.sync_seq[lane % D.n_carriers];
     }
-
-    sh.tw4[lane] = twiddle[lane << (LOG2N - 8)];
-    sh.tw4[64 + lane] = twiddle[(64 + lane) << (LOG2N - 8)];
-    wave_sync();
-    if ((int)blockIdx.x < n_frames) prefetch_symbol<LOG2N>(sh, D, audio + (size_t)blockIdx.x * frame_stride);
     for (int frame = blockIdx.x; frame < n_frames; frame += gridDim.x) {
-        // fresh demodulator (demodulator.cpp:26-43 + SYNCED transition :533-591, or the reset
-        // block of processPresynced :868-905)
+        float* st = state + (size_t)frame * kStFloats;
+        const c32* fq = fq_all + (size_t)frame * 128;
         Track tr;
-        tr.freq_offset_hz = cfo_hz ? cfo_hz[frame] : 0.0f;
-        tr.freq_offset_filtered = tr.freq_offset_hz;
-        tr.cfo_phase = cfo_phase ? cfo_phase[frame] : 0.0f;
-        tr.noise_variance = 0.1f; tr.snr_linear = 1.0f; tr.timing = 0.0f;
-        tr.ppc = mk(1.0f, 0.0f); tr.cpc = mk(1.0f, 0.0f);
-        tr.cpc_init = 0; tr.snr_symbol_count = 0; tr.symbols_since_sync = 0; tr.has_prev = 0; tr.has_dprev = 0;
-        c32 prev = mk(0.0f, 0.0f), dprev = mk(1.0f, 0.0f), lts_acc = mk(0.0f, 0.0f);
-        sh.H[lane] = mk(1.0f, 0.0f);
+        tr.freq_offset_hz = st[st_cfo]; tr.freq_offset_filtered = st[st_cfo_filt]; tr.cfo_phase = st[st_cfo_phase];
+        tr.noise_variance = st[st_noise]; tr.snr_linear = st[st_snr]; tr.timing = st[st_timing];
+        tr.ppc = mk(st[st_ppc_re], st[st_ppc_im]); tr.cpc = mk(st[st_cpc_re], st[st_cpc_im]);
+        const int flags = (int)st[st_flags];
+        tr.cpc_init = flags & 1; tr.has_prev = (flags >> 1) & 1; tr.has_dprev = (flags >> 2) & 1;
+        tr.snr_symbol_count = (int)st[st_count]; tr.symbols_since_sync = (int)st[st_since];
+        sh.H[lane] = reinterpret_cast<const c32*>(st + kStH)[lane];
+        c32 prev = (lane < D.n_pilot) ? reinterpret_cast<const c32*>(st + kStPrev)[lane] : mk(0.0f, 0.0f);
+        c32 dprev = D.differential ? reinterpret_cast<const c32*>(st + kStDprev)[lane] : mk(1.0f, 0.0f);
         wave_sync();
-
-        const float* a = audio + (size_t)frame * frame_stride;
-        float* l = llr + (size_t)frame * llr_stride;
-        const int n_sym = D.n_train + D.n_data_sym;
-        const int next_frame = frame + (int)gridDim.x;
-        // software pipeline: the FFT window of the next symbol (of this frame, or the first one of
-        // the next frame this wave will process) is in flight while the current one is tracked
-        auto prefetch_after = [&](int s_done) {
-            if (s_done + 1 < n_sym) prefetch_symbol<LOG2N>(sh, D, a + (size_t)(s_done + 1) * D.sym_len);
-            else if (next_frame < n_frames) prefetch_symbol<LOG2N>(sh, D, audio + (size_t)next_frame * frame_stride);
-        };
-        int s = 0;
-        for (; s < D.n_train; ++s) {
-            symbol_to_freq<LOG2N>(sh, D, tr, nco + (size_t)s * D.sym_len, twiddle);
-            prefetch_after(s);
-            lts_symbol<LOG2N>(sh, D, lc, s, D.n_train, lts_acc);
+        if (mode == 1) {
+            c32 lts_acc = (sym > 0 && lane < D.n_pilot) ? reinterpret_cast<const c32*>(st + kStLts)[lane] : mk(0.0f, 0.0f);
+            lts_symbol(sh, D, lc, sym, D.n_train, lts_acc, fq);
+            if (sym == D.n_train - 1) lts_finish(sh, D, lc, tr, D.n_train, lts_acc);
+            else if (lane < D.n_pilot) reinterpret_cast<c32*>(st + kStLts)[lane] = lts_acc;
+        } else {
+            if (!D.presynced || D.n_pilot != 0) update_channel_estimate(sh, D, lc, tr, prev, fq);
+            equalize_demap(sh, D, lc, tr, dprev, fq, llr + (size_t)frame * llr_stride + (size_t)data_sym * D.llrs_per_symbol);
         }
-        if (D.n_train > 0) lts_finish<LOG2N>(sh, D, lc, tr, D.n_train, lts_acc);
-        for (int ds = 0; ds < D.n_data_sym; ++ds, ++s) {
-            symbol_to_freq<LOG2N>(sh, D, tr, nco + (size_t)s * D.sym_len, twiddle);
-            prefetch_after(s);
-            if (!D.presynced || D.n_pilot != 0) update_channel_estimate<LOG2N>(sh, D, lc, tr, prev);
-            equalize_demap<LOG2N>(sh, D, lc, tr, dprev, l + (size_t)ds * D.llrs_per_symbol);
-        }
-        if (state && lane == 0) {
-            float* st = state + (size_t)frame * ULTRA_HIP_STATE_FLOATS;
-            st[ULTRA_HIP_STATE_FREQ_OFFSET_HZ] = tr.freq_offset_hz;
-            st[ULTRA_HIP_STATE_NOISE_VARIANCE] = tr.noise_variance;
-            st[ULTRA_HIP_STATE_SNR_LINEAR] = tr.snr_linear;
-            st[ULTRA_HIP_STATE_TIMING_OFFSET] = tr.timing;
-            st[ULTRA_HIP_STATE_CFO_PHASE] = tr.cfo_phase;
-            st[ULTRA_HIP_STATE_MIXER_PHASE] = D.mixer_phase_end;
-            st[ULTRA_HIP_STATE_SYMBOLS] = (float)tr.snr_symbol_count;
-            st[ULTRA_HIP_STATE_RESERVED] = 0.0f;
+        wave_sync();
+        // write the record back
+        reinterpret_cast<c32*>(st + kStH)[lane] = sh.H[lane];
+        if (lane < D.n_pilot) reinterpret_cast<c32*>(st + kStPrev)[lane] = prev;
+        if (D.differential) reinterpret_cast<c32*>(st + kStDprev)[lane] = dprev;
+        if (lane == 0) {
+            st[st_cfo] = tr.freq_offset_hz; st[st_cfo_filt] = tr.freq_offset_filtered;
+            st[st_noise] = tr.noise_variance; st[st_snr] = tr.snr_linear; st[st_timing] = tr.timing;
+            st[st_ppc_re] = tr.ppc.re; st[st_ppc_im] = tr.ppc.im; st[st_cpc_re] = tr.cpc.re; st[st_cpc_im] = tr.cpc.im;
+            st[st_flags] = (float)(tr.cpc_init | (tr.has_prev << 1) | (tr.has_dprev << 2));
+            st[st_count] = (float)tr.snr_symbol_count; st[st_since] = (float)tr.symbols_since_sync;
+            if (state_out) {
+                float* so = state_out + (size_t)frame * ULTRA_HIP_STATE_FLOATS;
+                so[ULTRA_HIP_STATE_FREQ_OFFSET_HZ] = tr.freq_offset_hz;
+                so[ULTRA_HIP_STATE_NOISE_VARIANCE] = tr.noise_variance;
+                so[ULTRA_HIP_STATE_SNR_LINEAR] = tr.snr_linear;
+                so[ULTRA_HIP_STATE_TIMING_OFFSET] = tr.timing;
+                so[ULTRA_HIP_STATE_CFO_PHASE] = tr.cfo_phase;
+                so[ULTRA_HIP_STATE_MIXER_PHASE] = D.mixer_phase_end;
+                so[ULTRA_HIP_STATE_SYMBOLS] = (float)tr.snr_symbol_count;
+                so[ULTRA_HIP_STATE_RESERVED] = 0.0f;
+            }
         }
         wave_sync();
     }

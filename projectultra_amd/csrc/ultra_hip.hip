@@ -37,6 +37,10 @@ struct ultra_hip_ctx {
     // workspace for the fused call when the caller does not want LLRs
     float* d_ws_llr = nullptr;
     size_t ws_llr_frames = 0;
+    // demodulator workspace: per-frame tracker records + the used FFT bins of the symbol in flight
+    float* d_ws_state = nullptr;
+    c32* d_ws_fq = nullptr;
+    size_t ws_demod_frames = 0;
     hipEvent_t ev_begin = nullptr, ev_end = nullptr;
     int cu_count = 256;
 };
@@ -66,20 +70,39 @@ struct DeviceGuard {
 int launch_demod(ultra_hip_ctx* ctx, const float* d_audio, size_t frame_stride, const float* d_cfo_hz,
                  const float* d_cfo_phase, size_t n_frames, float* d_llr, size_t llr_stride, float* d_state) {
     if (n_frames == 0) return ULTRA_HIP_OK;
-    // one wavefront per frame; the grid is capped (several resident waves per CU, grid-stride over
-    // frames) so a huge batch stays one launch and per-workgroup constants are loaded once
-    const size_t max_blocks = (size_t)ctx->cu_count * 32;
-    const unsigned grid = (unsigned)std::min(n_frames, max_blocks);
-    if (ctx->h_demod.log2_fft == 10)
-        hipLaunchKernelGGL(dev::demod_frames_kernel<10>, dim3(grid), dim3(dev::kWave), 0, ctx->stream,
-                           ctx->d_demod, ctx->d_nco, ctx->d_twiddle, d_audio, frame_stride, d_cfo_hz, d_cfo_phase,
-                           (int)n_frames, d_llr, llr_stride, d_state);
-    else if (ctx->h_demod.log2_fft == 9)
-        hipLaunchKernelGGL(dev::demod_frames_kernel<9>, dim3(grid), dim3(dev::kWave), 0, ctx->stream,
-                           ctx->d_demod, ctx->d_nco, ctx->d_twiddle, d_audio, frame_stride, d_cfo_hz, d_cfo_phase,
-                           (int)n_frames, d_llr, llr_stride, d_state);
-    else
-        return ULTRA_HIP_ERR_UNSUPPORTED;
+    if (ctx->ws_demod_frames < n_frames) {
+        UH_HIP(hipStreamSynchronize(ctx->stream));
+        if (ctx->d_ws_state) { (void)hipFree(ctx->d_ws_state); ctx->d_ws_state = nullptr; }
+        if (ctx->d_ws_fq) { (void)hipFree(ctx->d_ws_fq); ctx->d_ws_fq = nullptr; }
+        ctx->ws_demod_frames = 0;
+        UH_HIP(hipMalloc(&ctx->d_ws_state, n_frames * (size_t)dev::kStFloats * sizeof(float)));
+        UH_HIP(hipMalloc(&ctx->d_ws_fq, n_frames * (size_t)128 * sizeof(c32)));
+        ctx->ws_demod_frames = n_frames;
+    }
+    // one wavefront per frame in every kernel; grids are capped (grid-stride over frames) so a huge
+    // batch stays one launch per stage and per-workgroup constants are loaded once
+    const DemodConst& D = ctx->h_demod;
+    const unsigned grid_fft = (unsigned)std::min(n_frames, (size_t)ctx->cu_count * 40);
+    const unsigned grid_trk = (unsigned)std::min(n_frames, (size_t)ctx->cu_count * 32);
+    hipStream_t st = ctx->stream;
+    hipLaunchKernelGGL(dev::init_state_kernel, dim3(grid_trk), dim3(dev::kWave), 0, st, d_cfo_hz, d_cfo_phase,
+                       (int)n_frames, ctx->d_ws_state);
+    const int n_sym = D.n_train + D.n_data_sym;
+    for (int s = 0; s < n_sym; ++s) {
+        if (D.log2_fft == 10)
+            hipLaunchKernelGGL(dev::mix_fft_kernel<10>, dim3(grid_fft), dim3(dev::kWave), 0, st, ctx->d_demod, ctx->d_nco,
+                               ctx->d_twiddle, d_audio, frame_stride, (int)n_frames, s, ctx->d_ws_state, ctx->d_ws_fq);
+        else if (D.log2_fft == 9)
+            hipLaunchKernelGGL(dev::mix_fft_kernel<9>, dim3(grid_fft), dim3(dev::kWave), 0, st, ctx->d_demod, ctx->d_nco,
+                               ctx->d_twiddle, d_audio, frame_stride, (int)n_frames, s, ctx->d_ws_state, ctx->d_ws_fq);
+        else
+            return ULTRA_HIP_ERR_UNSUPPORTED;
+        const bool training = s < D.n_train;
+        const bool last = (s == n_sym - 1);
+        hipLaunchKernelGGL(dev::track_kernel, dim3(grid_trk), dim3(dev::kWave), 0, st, ctx->d_demod, (int)n_frames,
+                           training ? 1 : 0, s, training ? 0 : s - D.n_train, ctx->d_ws_state, ctx->d_ws_fq, d_llr,
+                           llr_stride, last ? d_state : nullptr);
+    }
     UH_HIP(hipGetLastError());
     return ULTRA_HIP_OK;
 }
@@ -211,6 +234,8 @@ void ultra_hip_destroy(ultra_hip_ctx* ctx) {
     if (ctx->d_nco) (void)hipFree(ctx->d_nco);
     if (ctx->d_twiddle) (void)hipFree(ctx->d_twiddle);
     if (ctx->d_ws_llr) (void)hipFree(ctx->d_ws_llr);
+    if (ctx->d_ws_state) (void)hipFree(ctx->d_ws_state);
+    if (ctx->d_ws_fq) (void)hipFree(ctx->d_ws_fq);
     if (ctx->ev_begin) (void)hipEventDestroy(ctx->ev_begin);
     if (ctx->ev_end) (void)hipEventDestroy(ctx->ev_end);
     delete ctx;
