@@ -65,6 +65,14 @@ __device__ __forceinline__ c32 cdiv(c32 x, c32 y) {
     double yi = ((b * c) - (a * d)) / denom;
     return mk((float)xr, (float)yi);
 }
+// Division by a BPSK pilot (+-1, +0): the double formula has denom == 1.0 and exact products, so
+// x = a*c + b*d and y = b*c - a*d evaluated in float (products exact, one exact sum each, same
+// signed-zero behaviour) give the very same bits without a double-precision divide.
+__device__ __forceinline__ c32 cdiv_pilot(c32 x, c32 y) {
+    if (y.im == 0.0f && !(__float_as_uint(y.im) >> 31) && fabsf(y.re) == 1.0f)
+        return mk(x.re * y.re + x.im * y.im, x.im * y.re - x.re * y.im);
+    return cdiv(x, y);
+}
 __device__ __forceinline__ c32 cscale(c32 a, float s) { return mk(a.re * s, a.im * s); }
 __device__ __forceinline__ c32 cdivf(c32 a, float s) { return mk(a.re / s, a.im / s); }
 __device__ __forceinline__ float cnorm(c32 a) { return a.re * a.re + a.im * a.im; }
@@ -344,7 +352,7 @@ __device__ __forceinline__ void update_channel_estimate(TrackShared& sh, const D
     const float alpha = (tr.snr_symbol_count == 0) ? 1.0f : 0.9f;
 
     c32 h = mk(0.0f, 0.0f);
-    if (is_pilot) h = cdiv(fq[lc.pilot_fq], lc.pilot_seq);
+    if (is_pilot) h = cdiv_pilot(fq[lc.pilot_fq], lc.pilot_seq);
     c32 h_sum = ordered_csum(h, np);
     if (!tr.cpc_init && np != 0) {                              // carrier phase recovery (:348-357)
         const c32 h_avg = cdivf(h_sum, (float)np);
@@ -373,20 +381,39 @@ __device__ __forceinline__ void update_channel_estimate(TrackShared& sh, const D
         const c32 h_old = sh.H[lc.pilot_slot];
         sh.H[lc.pilot_slot] = cadd(cscale(h, alpha), cscale(h_old, 1.0f - alpha));
     }
-    const unsigned long long m_noise = __ballot(f_noise), m_cfo = __ballot(f_cfo), m_tim = __ballot(f_tim);
-
-    const float signal_power = ordered_sum(n2, np) / (float)np;     // NaN when np == 0 (reference quirk)
-    int noise_count;
-    float noise_power_sum = ordered_sum_masked(nd, np, m_noise, &noise_count);
+    // All serial sums of the reference over the pilots (:385-412, :420-440, :473-490) in ONE pass:
+    // every lane walks i = 0..np-1 in order and accumulates lane i's terms, so all lanes hold the
+    // reference's running sums.  A term the reference skips is replaced by -0.0f, the exact neutral
+    // element of float addition (x + -0.0f == x bit for bit, also for x = +-0), which keeps the loop
+    // branch-free and lets the eight independent chains overlap.
+    const int noise_hits = __popcll(__ballot(f_noise)), cfo_hits = __popcll(__ballot(f_cfo)),
+              tim_hits = __popcll(__ballot(f_tim));
+    const float kf = (float)lc.pilot_k;
+    const float t_nd = f_noise ? nd : -0.0f;
+    const float t_ur = f_cfo ? unit.re : -0.0f, t_ui = f_cfo ? unit.im : -0.0f;
+    const float t_k = f_tim ? kf : -0.0f, t_k2 = f_tim ? (float)(lc.pilot_k * lc.pilot_k) : -0.0f;
+    const float t_ph = f_tim ? ph : -0.0f, t_kph = f_tim ? kf * ph : -0.0f;
+    float s_sig = 0.0f, s_nd = 0.0f, s_ur = 0.0f, s_ui = 0.0f, sum_k = 0.0f, sum_k2 = 0.0f, sum_phase = 0.0f,
+          sum_k_phase = 0.0f;
+    for (int i = 0; i < np; ++i) {
+        s_sig += lane_f(n2, i);
+        s_nd += lane_f(t_nd, i);
+        s_ur += lane_f(t_ur, i);
+        s_ui += lane_f(t_ui, i);
+        sum_k += lane_f(t_k, i);
+        sum_k2 += lane_f(t_k2, i);
+        sum_phase += lane_f(t_ph, i);
+        sum_k_phase += lane_f(t_kph, i);
+    }
+    const float signal_power = s_sig / (float)np;                   // NaN when np == 0 (reference quirk)
+    int noise_count = noise_hits;
+    float noise_power_sum = s_nd;
     if (noise_count == 0) { noise_power_sum = signal_power / 31.6f; noise_count = 1; }
 
     if (tr.has_prev && np != 0) {                               // CFO from pilot phase differences
-        c32 sum = mk(0.0f, 0.0f);
-        int valid = 0;
-        for (int i = 0; i < np; ++i)
-            if ((m_cfo >> i) & 1ull) { sum = cadd(sum, mk(lane_f(unit.re, i), lane_f(unit.im, i))); ++valid; }
+        const int valid = cfo_hits;
         if (valid > 0) {
-            const c32 avg = cdivf(sum, (float)valid);
+            const c32 avg = cdivf(mk(s_ur, s_ui), (float)valid);
             const float apd = um::atan2f_(avg.im, avg.re);
             tr.ppc = cexpj(-apd);
             const float residual = (float)((double)apd / D.two_pi_symbol_duration);
@@ -406,18 +433,7 @@ __device__ __forceinline__ void update_channel_estimate(TrackShared& sh, const D
     }
 
     if (tr.snr_symbol_count >= 3) {                             // timing from the pilot phase slope
-        float sum_k = 0, sum_k2 = 0, sum_phase = 0, sum_k_phase = 0;
-        int tv = 0;
-        for (int i = 0; i < np; ++i) {
-            if (!((m_tim >> i) & 1ull)) continue;
-            const int k = __builtin_amdgcn_readlane(lc.pilot_k, i);
-            const float phase = lane_f(ph, i);
-            sum_k += (float)k;
-            sum_k2 += (float)(k * k);
-            sum_phase += phase;
-            sum_k_phase += (float)k * phase;
-            tv++;
-        }
+        const int tv = tim_hits;
         if (tv >= 3) {
             const float n = (float)tv;
             const float denom = n * sum_k2 - sum_k * sum_k;
@@ -458,8 +474,9 @@ __device__ __forceinline__ void update_channel_estimate(TrackShared& sh, const D
 }
 
 // one carrier's LLRs (soft_demap.hpp), stored to out[0..bits)
-__device__ __forceinline__ void demap_carrier(int modulation, c32 sym, c32 prev, float nv, float* __restrict__ out) {
-    switch (modulation) {
+template <int MOD>
+__device__ __forceinline__ void demap_carrier(c32 sym, c32 prev, float nv, float* __restrict__ out) {
+    switch (MOD) {
         case ULTRA_MOD_DBPSK: {
             const c32 diff = cmul(sym, cconj(prev));
             const float pd = um::atan2f_(diff.im, diff.re);
@@ -558,14 +575,19 @@ __device__ __forceinline__ void demap_carrier(int modulation, c32 sym, c32 prev,
 
 // equalize (channel_equalizer.cpp:728-840, adaptive_eq off) + demodulateSymbol
 // (demodulator.cpp:199-435) for one symbol; dprev = dbpsk_prev_equalized[lane]
+template <int MOD>
 __device__ __forceinline__ void equalize_demap(TrackShared& sh, const DemodConst& D, const LaneConst& lc, Track& tr,
                                                c32& dprev, const c32* __restrict__ fq, float* __restrict__ llr_sym) {
+    constexpr bool kDiff = (MOD == ULTRA_MOD_DBPSK || MOD == ULTRA_MOD_DQPSK || MOD == ULTRA_MOD_D8PSK);
+    constexpr int kBits = (MOD == ULTRA_MOD_DBPSK || MOD == ULTRA_MOD_BPSK) ? 1 : (MOD == ULTRA_MOD_DQPSK || MOD == ULTRA_MOD_QPSK) ? 2
+                        : (MOD == ULTRA_MOD_D8PSK) ? 3 : (MOD == ULTRA_MOD_QAM16) ? 4 : (MOD == ULTRA_MOD_QAM32) ? 5
+                        : (MOD == ULTRA_MOD_QAM64) ? 6 : 8;
     const int lane = threadIdx.x;
     const int nd = D.n_data;
     const bool is_data = lane < nd;
     c32 eq = mk(0.0f, 0.0f);
     float nv = 100.0f;
-    if (D.differential) {
+    if (kDiff) {
         if (is_data) {
             const c32 received = fq[lc.data_fq], h = sh.H[lc.data_slot];
             const float h_power = cnorm(h);
@@ -600,12 +622,12 @@ __device__ __forceinline__ void equalize_demap(TrackShared& sh, const DemodConst
         if (is_data && h_power < 0.1f * avg) nv = 100.0f;
     }
 
-    if (D.differential && !tr.has_dprev) dprev = mk(1.0f, 0.0f);   // (1,0) reference on every path
+    if (kDiff && !tr.has_dprev) dprev = mk(1.0f, 0.0f);   // (1,0) reference on every path
     if (is_data) {
-        demap_carrier(D.modulation, eq, dprev, nv * D.ce_margin, llr_sym + lane * D.bits);
-        if (D.differential) dprev = eq;
+        demap_carrier<MOD>(eq, dprev, nv * D.ce_margin, llr_sym + lane * kBits);
+        if (kDiff) dprev = eq;
     }
-    if ((D.modulation == ULTRA_MOD_DQPSK || D.modulation == ULTRA_MOD_D8PSK) && tr.snr_symbol_count >= 1) {
+    if ((MOD == ULTRA_MOD_DQPSK || MOD == ULTRA_MOD_D8PSK) && tr.snr_symbol_count >= 1) {
         // Decision-directed block (demodulator.cpp:362-434).  dbpsk_prev_equalized[i] was just
         // overwritten with equalized[i], so diff = eq * conj(eq) has phase +0 exactly: quadrant 0,
         // phase_error 0, phase_correction = (cos(-0), sin(-0)) = (1, -0); phase_error_sum =
@@ -626,7 +648,7 @@ __device__ __forceinline__ void equalize_demap(TrackShared& sh, const DemodConst
             tr.ppc = p;
         }
     }
-    if (D.differential) tr.has_dprev = 1;
+    if (kDiff) tr.has_dprev = 1;
     wave_sync();
 }
 
@@ -641,7 +663,7 @@ __device__ __forceinline__ void lts_symbol(TrackShared& sh, const DemodConst& D,
     }
     if (lane < D.n_pilot) {
         if (sym == 0) lts_acc = mk(0.0f, 0.0f);
-        if (cabs_(lc.pilot_seq) > 0.01f) lts_acc = cadd(lts_acc, cdiv(fq[lc.pilot_fq], lc.pilot_seq));
+        if (cabs_(lc.pilot_seq) > 0.01f) lts_acc = cadd(lts_acc, cdiv_pilot(fq[lc.pilot_fq], lc.pilot_seq));
     }
     wave_sync();
 }
@@ -717,7 +739,8 @@ __global__ __launch_bounds__(kWave, 5) void mix_fft_kernel(
 
 // mode 0: data symbol (updateChannelEstimate + equalize + demodulateSymbol)
 // mode 1: training symbol `sym` of n_train (estimateChannelFromLTS), finishing on the last one
-__global__ __launch_bounds__(kWave) void track_kernel(
+template <int MOD>
+__global__ __launch_bounds__(kWave, 4) void track_kernel(
     const DemodConst* __restrict__ Dp, int n_frames, int mode, int sym, int data_sym, float* __restrict__ state,
     const c32* __restrict__ fq_all, float* __restrict__ llr, size_t llr_stride, float* __restrict__ state_out) {
     __shared__ TrackShared sh;
@@ -758,7 +781,7 @@ __global__ __launch_bounds__(kWave) void track_kernel(
             else if (lane < D.n_pilot) reinterpret_cast<c32*>(st + kStLts)[lane] = lts_acc;
         } else {
             if (!D.presynced || D.n_pilot != 0) update_channel_estimate(sh, D, lc, tr, prev, fq);
-            equalize_demap(sh, D, lc, tr, dprev, fq, llr + (size_t)frame * llr_stride + (size_t)data_sym * D.llrs_per_symbol);
+            equalize_demap<MOD>(sh, D, lc, tr, dprev, fq, llr + (size_t)frame * llr_stride + (size_t)data_sym * D.llrs_per_symbol);
         }
         wave_sync();
         // write the record back

@@ -99,9 +99,23 @@ int launch_demod(ultra_hip_ctx* ctx, const float* d_audio, size_t frame_stride, 
             return ULTRA_HIP_ERR_UNSUPPORTED;
         const bool training = s < D.n_train;
         const bool last = (s == n_sym - 1);
-        hipLaunchKernelGGL(dev::track_kernel, dim3(grid_trk), dim3(dev::kWave), 0, st, ctx->d_demod, (int)n_frames,
-                           training ? 1 : 0, s, training ? 0 : s - D.n_train, ctx->d_ws_state, ctx->d_ws_fq, d_llr,
-                           llr_stride, last ? d_state : nullptr);
+#define UH_TRACK(MOD)                                                                                            \
+    hipLaunchKernelGGL(dev::track_kernel<MOD>, dim3(grid_trk), dim3(dev::kWave), 0, st, ctx->d_demod, (int)n_frames,  \
+                       training ? 1 : 0, s, training ? 0 : s - D.n_train, ctx->d_ws_state, ctx->d_ws_fq, d_llr,       \
+                       llr_stride, last ? d_state : nullptr)
+        switch (D.modulation) {
+            case ULTRA_MOD_DBPSK: UH_TRACK(ULTRA_MOD_DBPSK); break;
+            case ULTRA_MOD_BPSK: UH_TRACK(ULTRA_MOD_BPSK); break;
+            case ULTRA_MOD_DQPSK: UH_TRACK(ULTRA_MOD_DQPSK); break;
+            case ULTRA_MOD_QPSK: UH_TRACK(ULTRA_MOD_QPSK); break;
+            case ULTRA_MOD_D8PSK: UH_TRACK(ULTRA_MOD_D8PSK); break;
+            case ULTRA_MOD_QAM16: UH_TRACK(ULTRA_MOD_QAM16); break;
+            case ULTRA_MOD_QAM32: UH_TRACK(ULTRA_MOD_QAM32); break;
+            case ULTRA_MOD_QAM64: UH_TRACK(ULTRA_MOD_QAM64); break;
+            case ULTRA_MOD_QAM256: UH_TRACK(ULTRA_MOD_QAM256); break;
+            default: return ULTRA_HIP_ERR_UNSUPPORTED;
+        }
+#undef UH_TRACK
     }
     UH_HIP(hipGetLastError());
     return ULTRA_HIP_OK;
