@@ -714,7 +714,7 @@ __global__ __launch_bounds__(kWave) void init_state_kernel(const float* __restri
 
 // toBaseband + extractSymbol/FFT of symbol `sym` of every frame.
 template <int LOG2N>
-__global__ __launch_bounds__(kWave, 5) void mix_fft_kernel(
+__global__ __launch_bounds__(kWave, 3) void mix_fft_kernel(
     const DemodConst* __restrict__ Dp, const c32* __restrict__ nco, const c32* __restrict__ twiddle,
     const float* __restrict__ audio, size_t frame_stride, int n_frames, int sym, float* __restrict__ state,
     c32* __restrict__ fq) {

@@ -63,7 +63,7 @@ __device__ __forceinline__ unsigned wave_xor(unsigned v) {
 // ROWS_FULL = every row has 6 information edges (R3/4, R5/6).  The first P.var_rounds_full
 // variable rounds hold only variables of degree DMAX in all 64 lanes (no predicates).
 template <int RR, int VR, int DMAX, bool ROWS_FULL, bool WANT_TOTAL>
-__global__ __launch_bounds__(kLdpcThreads) void ldpc_decode_kernel(
+__global__ __launch_bounds__(kLdpcThreads, 5) void ldpc_decode_kernel(
     const LdpcPlan* __restrict__ Pp, const float* __restrict__ llr, size_t llr_stride, int n_cw,
     uint8_t* __restrict__ bytes, int32_t* __restrict__ iters, uint8_t* __restrict__ okv,
     float* __restrict__ llr_total, unsigned int* __restrict__ work_counter) {

@@ -128,7 +128,7 @@ int launch_ldpc(ultra_hip_ctx* ctx, const float* d_llr, size_t llr_stride, size_
     // launch uses its own counter word, zeroed on the stream just before the launch
     const LdpcPlan& P = ctx->h_plan;
     const size_t lds = dev::ldpc_lds_bytes(P.msg_words);
-    const size_t per_cu = std::max<size_t>(1, std::min<size_t>(16, (size_t)(160 * 1024) / lds));
+    const size_t per_cu = std::max<size_t>(1, std::min<size_t>(20, (size_t)(160 * 1024) / lds));
     const unsigned grid = (unsigned)std::min(n_cw, (size_t)ctx->cu_count * per_cu);
     unsigned int* counter = ctx->d_work + (ctx->work_slot++ & 63);
     UH_HIP(hipMemsetAsync(counter, 0, sizeof(unsigned int), ctx->stream));
