@@ -154,7 +154,12 @@ struct FftShared {                                          // mix_fft_kernel
     static constexpr int P = N / kWave;                     // points per lane: 8 / 16
     static constexpr int A = (P == 16) ? 4 : 3;             // log2(P)
     c32 X[N + N / P];                                       // FFT exchange buffer, 1 pad per P entries
-    c32 tw4[128];                                           // twiddle[i * N/256]: the entries stages A..2A-1 use
+    // Twiddles of stages A..2A-1, one contiguous run per stage: stage s uses k = 0 .. P*2^(s-A)-1
+    // (w = twiddle[k << (LOG2N-1-s)]), stored at twB[P*(2^(s-A)-1) + k].  Lanes of a 32-lane group
+    // then read consecutive slots (or the same one): no bank conflicts, unlike a strided view of
+    // the global table (8-way at stage A).
+    static constexpr int kTwB = P * ((1 << A) - 1);
+    c32 twB[kTwB];
     um::PhaseSeg seg[kPhaseCap];
 };
 struct TrackShared {                                        // track_kernel
@@ -293,8 +298,7 @@ __device__ __forceinline__ void symbol_to_freq(FftShared<LOG2N>& sh, const Demod
             for (int j = 0; j < P; ++j) {
                 if (j & hj) continue;
                 const int k = r + P * (j & (hj - 1));
-                // tw4[i] = twiddle[i * N/256]; the indices of these stages are multiples of N/256
-                const c32 w = sh.tw4[(k << (LOG2N - 1 - s)) >> (LOG2N - 8)];
+                const c32 w = sh.twB[P * (hj - 1) + k];
                 UH_BUTTERFLY(v[j], v[j + hj], w);
             }
         }
@@ -721,8 +725,14 @@ __global__ __launch_bounds__(kWave, 3) void mix_fft_kernel(
     __shared__ FftShared<LOG2N> sh;
     const DemodConst& D = *Dp;
     const int lane = threadIdx.x;
-    sh.tw4[lane] = twiddle[lane << (LOG2N - 8)];
-    sh.tw4[64 + lane] = twiddle[(64 + lane) << (LOG2N - 8)];
+    {
+        constexpr int P = FftShared<LOG2N>::P, A = FftShared<LOG2N>::A;
+        for (int idx = lane; idx < FftShared<LOG2N>::kTwB; idx += kWave) {
+            const int sA = 31 - __clz(idx / P + 1);          // stage - A: runs start at P*(2^sA - 1)
+            const int k = idx - P * ((1 << sA) - 1);
+            sh.twB[idx] = twiddle[k << (LOG2N - 1 - (A + sA))];
+        }
+    }
     wave_sync();
     const size_t sym_off = (size_t)sym * D.sym_len;
     if ((int)blockIdx.x < n_frames) prefetch_symbol<LOG2N>(sh, D, audio + (size_t)blockIdx.x * frame_stride + sym_off);

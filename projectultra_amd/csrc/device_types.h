@@ -12,7 +12,7 @@ constexpr int kLdpcN = 648;        // LDPC block length (src/fec/ldpc_decoder.cp
 constexpr int kLdpcMaxEdges = 2560;  // R1/4 has 2437 edges
 constexpr int kLdpcMaxChecks = 486;
 
-struct c32 { float re, im; };
+struct alignas(8) c32 { float re, im; };   // 8-byte aligned: one ds_read_b64 / global_load_dwordx2 per value
 
 // Per-configuration demodulator constants.  One copy in HBM per context; every
 // field is read with wave-uniform addresses (scalar loads) except the tables
