@@ -11,10 +11,16 @@
 //
 // Value-identical reformulations (every float operation the reference performs is performed
 // here on the same operands in the same order):
-//   * check step: "min over all others" = min(prefix min, suffix min) of |v| (min is exact and
-//     order-free; fminf ignores NaN exactly as the reference's `abs < min` update does); the sign is
-//     the row's sign parity with edge e's own sign removed (`v < 0`: -0.0 and NaN count as
-//     positive, as in the reference), applied to min*0.75f by flipping the sign bit.
+//   * check step: "min over all others" of |v| as unsigned-integer minima of the |v| bit patterns
+//     (order-isomorphic for non-NaN values; NaN/inf patterns exceed FLT_MAX's and lose against the
+//     FLT_MAX seed exactly as in the reference's `abs < min` update); the sign is the row's sign
+//     parity with edge e's own sign removed (`v < 0`: -0.0 and NaN count as positive, as in the
+//     reference), applied to min*0.75f by selecting mag or -mag.
+//   * var step: clamp(x, -50, 50) = std::max(-50.0f, std::min(50.0f, x)) keeps the sign of x (NaN
+//     becomes +50, and `NaN < 0` is false) and turns |x| into min(|x|, 50).  The only reader of a
+//     v2c message is the check step, which uses its sign and the minimum of the other edges'
+//     magnitudes; so messages are stored unclamped and the minimum is capped at 50 instead (at
+//     FLT_MAX in iteration 0, whose messages are the unclamped channel values).
 //   * H = [H_data | I]: parity bit k+i has exactly one edge, the last one of row i.  Its message,
 //     total and hard bit never leave the registers of the lane that owns row i.
 //   * variables without any check (R3/4: info bits 325..485, R5/6: 217..539) keep
@@ -45,18 +51,26 @@ namespace dev {
 constexpr int kLdpcThreads = 64;
 constexpr float kFltMax = 3.402823466e+38f;
 
-// std::max(-50.0f, std::min(50.0f, v)): fminf/fmaxf give the same value for every input, NaN
-// included (std::min(50, NaN) = 50 because `NaN < 50` is false; fminf(50, NaN) = 50)
-__device__ __forceinline__ float clamp50(float v) { return fmaxf(-50.0f, fminf(50.0f, v)); }
+__device__ __forceinline__ unsigned umin2(unsigned x, unsigned y) { return x < y ? x : y; }
+__device__ __forceinline__ unsigned umin3(unsigned x, unsigned y, unsigned z) {
+    unsigned r;
+    asm("v_min3_u32 %0, %1, %2, %3" : "=v"(r) : "v"(x), "v"(y), "v"(z));
+    return r;
+}
 
 __host__ __device__ inline size_t ldpc_lds_bytes(int msg_words) {
     return (size_t)msg_words * sizeof(float) + 656 + 648 * sizeof(float);
 }
 
+// xor over the 64 lanes (all active), result wave-uniform.  DPP cross-lane operands inside the
+// 16-lane rows (no LDS round trips, unlike ds_bpermute shuffles), then four readlanes.
 __device__ __forceinline__ unsigned wave_xor(unsigned v) {
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) v ^= (unsigned)__shfl_xor((int)v, off, 64);
-    return v;
+    v ^= (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0xB1, 0xF, 0xF, true);    // quad_perm [1,0,3,2]
+    v ^= (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x4E, 0xF, 0xF, true);    // quad_perm [2,3,0,1]
+    v ^= (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x141, 0xF, 0xF, true);   // row_half_mirror
+    v ^= (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x140, 0xF, 0xF, true);   // row_mirror
+    return (unsigned)__builtin_amdgcn_readlane((int)v, 0) ^ (unsigned)__builtin_amdgcn_readlane((int)v, 16) ^
+           (unsigned)__builtin_amdgcn_readlane((int)v, 32) ^ (unsigned)__builtin_amdgcn_readlane((int)v, 48);
 }
 
 // RR = ceil(m / 64) row rounds, VR = ceil(n_active / 64) variable rounds, DMAX = max variable degree,
@@ -119,11 +133,11 @@ __global__ __launch_bounds__(kLdpcThreads, 5) void ldpc_decode_kernel(
         }
         __syncthreads();
         float llr_v[VR], llr_p[RR], vpar[RR];
-        int hpar[RR], hv[VR];
+        bool hpar[RR], hv[VR];                                             // hard decisions as lane masks
 #pragma unroll
         for (int r = 0; r < VR; ++r) {
             llr_v[r] = llr_s[var_j[r]];
-            hv[r] = 0;
+            hv[r] = false;
 #pragma unroll
             for (int t = 0; t < DMAX; ++t)
                 if (t < var_deg[r]) msg[vaddr[r][t]] = llr_v[r];              // v2c = llr_in[col]
@@ -132,7 +146,7 @@ __global__ __launch_bounds__(kLdpcThreads, 5) void ldpc_decode_kernel(
         for (int r = 0; r < RR; ++r) {
             llr_p[r] = row_ok[r] ? llr_s[k + r * 64 + lane] : 0.0f;
             vpar[r] = llr_p[r];                                                // v2c of the parity bit
-            hpar[r] = 0;
+            hpar[r] = false;
         }
         __syncthreads();
 
@@ -143,14 +157,14 @@ __global__ __launch_bounds__(kLdpcThreads, 5) void ldpc_decode_kernel(
                 // ---- exact parity test (checkParity :139-151); reached once per converged codeword ----
 #pragma unroll
                 for (int r = 0; r < VR; ++r)
-                    if (var_deg[r] > 0) hard[var_j[r]] = (uint8_t)hv[r];
+                    if (var_deg[r] > 0) hard[var_j[r]] = hv[r] ? 1 : 0;
                 __syncthreads();
                 int bad = 0;
 #pragma unroll
                 for (int r = 0; r < RR; ++r) {
                     if (row_ok[r]) {
                         const int row = r * 64 + lane;
-                        int s = hpar[r];
+                        int s = hpar[r] ? 1 : 0;
                         for (int t = 0; t < 6; ++t) {
                             const unsigned c = P.row_col[row * 6 + t];
                             if (c != 0xFFFFu) s ^= hard[c];
@@ -163,6 +177,14 @@ __global__ __launch_bounds__(kLdpcThreads, 5) void ldpc_decode_kernel(
             if (it >= P.max_iterations) break;
 
             // ---- check step + the row's own parity bit: one lane per row ----
+            // The reference clamps every variable-to-check message to +-50 when it is produced
+            // (:216-224), except the initial ones (= llr_in).  The clamp keeps the sign (NaN -> +50,
+            // and `NaN < 0` is false) and turns |v| into min(|v|, 50), so "min over the other edges of
+            // the clamped magnitudes" = min(min over the other edges of the raw magnitudes, 50): the
+            // messages are stored unclamped and the two seeds of the minimum chains carry the cap
+            // (FLT_MAX in iteration 0, whose inputs are the unclamped channel values).
+            unsigned f = 0u;                                               // this lane's share of the syndrome filter
+            const unsigned cap = (it == 0) ? 0x7f7fffffu : 0x42480000u;    // FLT_MAX : 50.0f
 #pragma unroll
             for (int r = 0; r < RR; ++r) {
                 if (row_ok[r]) {
@@ -173,38 +195,52 @@ __global__ __launch_bounds__(kLdpcThreads, 5) void ldpc_decode_kernel(
                         else v[t] = (raddr[r][t] >= 0) ? msg[raddr[r][t]] : kFltMax;   // missing edge: neutral
                     }
                     v[6] = vpar[r];
-                    float a[7], pre[7], suf[7];
-                    unsigned sg[7], par = 0u;
+                    // Signs as lane masks (SGPR pairs): the row parity and each edge's "all others"
+                    // sign are scalar xors; the sign is applied with one select between mag and -mag.
+                    // Magnitudes as unsigned integers (|x| bit patterns order like the values; NaN and
+                    // inf patterns exceed FLT_MAX's, so capping at FLT_MAX ignores them exactly as the
+                    // reference's `abs < min` update starting from FLT_MAX does).  Leave-one-out minima
+                    // of 7 values in 12 min/min3 operations.
+                    unsigned a[7];
+                    bool ng[7], par = false;
 #pragma unroll
                     for (int t = 0; t < 7; ++t) {
-                        a[t] = fabsf(v[t]);
-                        sg[t] = (v[t] < 0) ? 0x80000000u : 0u;
-                        par ^= sg[t];
+                        a[t] = __float_as_uint(v[t]) & 0x7fffffffu;
+                        ng[t] = v[t] < 0;
+                        par ^= ng[t];
                     }
-                    pre[0] = kFltMax;
-#pragma unroll
-                    for (int t = 1; t < 7; ++t) pre[t] = fminf(pre[t - 1], a[t - 1]);
-                    suf[6] = kFltMax;
-#pragma unroll
-                    for (int t = 5; t >= 0; --t) suf[t] = fminf(suf[t + 1], a[t + 1]);
+                    const unsigned L2 = umin3(a[0], a[1], cap);             // min of edges 0..1
+                    const unsigned L4 = umin3(L2, a[2], a[3]);              // 0..3
+                    const unsigned L6 = umin3(L4, a[4], a[5]);              // 0..5
+                    const unsigned R4 = umin3(a[5], a[6], cap);             // 5..6
+                    const unsigned R3 = umin2(R4, a[4]);                    // 4..6
+                    const unsigned R2 = umin3(R4, a[4], a[3]);              // 3..6
+                    unsigned mn[7];
+                    mn[0] = umin3(R2, a[2], a[1]);
+                    mn[1] = umin3(a[0], R2, a[2]);
+                    mn[2] = umin2(L2, R2);
+                    mn[3] = umin3(L2, a[2], R3);
+                    mn[4] = umin2(L4, R4);
+                    mn[5] = umin3(L4, a[4], a[6]);
+                    mn[6] = L6;
 #pragma unroll
                     for (int t = 0; t < 6; ++t) {
-                        const float mag = fminf(pre[t], suf[t]) * 0.75f;
-                        const float c = __uint_as_float(__float_as_uint(mag) ^ (par ^ sg[t]));   // sign * min * 0.75f
+                        const float mag = __uint_as_float(mn[t]) * 0.75f;
+                        const float c = (par != ng[t]) ? -mag : mag;           // sign * min * 0.75f
                         if (ROWS_FULL) msg[raddr[r][t]] = c;
                         else if (raddr[r][t] >= 0) msg[raddr[r][t]] = c;
                     }
-                    const float mag6 = fminf(pre[6], suf[6]) * 0.75f;
-                    const float c_last = __uint_as_float(__float_as_uint(mag6) ^ (par ^ sg[6]));
+                    const float mag6 = __uint_as_float(mn[6]) * 0.75f;
+                    const float c_last = (par != ng[6]) ? -mag6 : mag6;
                     const float total_p = llr_p[r] + c_last;               // parity bit k+row
-                    hpar[r] = (total_p < 0) ? 1 : 0;
-                    vpar[r] = clamp50(total_p - c_last);
+                    hpar[r] = total_p < 0;
+                    f ^= hpar[r] ? rmask[r] : 0u;
+                    vpar[r] = total_p - c_last;                            // clamp deferred, see `cap`
                     if (WANT_TOTAL) llr_total[(size_t)cw * kLdpcN + k + r * 64 + lane] = total_p;
                 }
             }
             __syncthreads();
             // ---- totals + variable step for the information bits that have checks ----
-            unsigned f = 0u;
 #pragma unroll
             for (int r = 0; r < VR; ++r) {
                 if (r < P.var_rounds_full) {                               // wave-uniform: all 64 lanes, degree DMAX
@@ -214,9 +250,10 @@ __global__ __launch_bounds__(kLdpcThreads, 5) void ldpc_decode_kernel(
                     float tot = llr_v[r];
 #pragma unroll
                     for (int t = 0; t < DMAX; ++t) tot += c[t];             // ascending check order
-                    hv[r] = (tot < 0) ? 1 : 0;
+                    hv[r] = tot < 0;
+                    f ^= hv[r] ? vmask[r] : 0u;
 #pragma unroll
-                    for (int t = 0; t < DMAX; ++t) msg[vaddr[r][t]] = clamp50(tot - c[t]);
+                    for (int t = 0; t < DMAX; ++t) msg[vaddr[r][t]] = tot - c[t];   // clamp deferred to the reader
                     if (WANT_TOTAL) llr_total[(size_t)cw * kLdpcN + var_j[r]] = tot;
                 } else {
                     const int d = var_deg[r];
@@ -228,17 +265,15 @@ __global__ __launch_bounds__(kLdpcThreads, 5) void ldpc_decode_kernel(
 #pragma unroll
                         for (int t = 0; t < DMAX; ++t)
                             if (t < d) tot += c[t];                        // ascending check order
-                        hv[r] = (tot < 0) ? 1 : 0;
+                        hv[r] = tot < 0;
+                        f ^= hv[r] ? vmask[r] : 0u;
 #pragma unroll
                         for (int t = 0; t < DMAX; ++t)
-                            if (t < d) msg[vaddr[r][t]] = clamp50(tot - c[t]);
+                            if (t < d) msg[vaddr[r][t]] = tot - c[t];
                         if (WANT_TOTAL) llr_total[(size_t)cw * kLdpcN + var_j[r]] = tot;
                     }
                 }
-                f ^= hv[r] ? vmask[r] : 0u;
             }
-#pragma unroll
-            for (int r = 0; r < RR; ++r) f ^= hpar[r] ? rmask[r] : 0u;
             F = wave_xor(f);
             __syncthreads();
             ++it;
@@ -249,7 +284,7 @@ __global__ __launch_bounds__(kLdpcThreads, 5) void ldpc_decode_kernel(
         if (!ok && P.max_iterations > 0) {                                 // on success `hard` was just refreshed
 #pragma unroll
             for (int r = 0; r < VR; ++r)
-                if (var_deg[r] > 0) hard[var_j[r]] = (uint8_t)hv[r];
+                if (var_deg[r] > 0) hard[var_j[r]] = hv[r] ? 1 : 0;
             __syncthreads();
         }
         uint8_t* ob = bytes + (size_t)cw * P.decoded_bytes;
