@@ -49,3 +49,20 @@ def noisy_codewords(oracle, rate, n, sigmas, seed):
         y = (1 - 2 * bits) + rng.normal(0, s, 648)
         llr[i] = (2 * y / (s * s)).astype(np.float32)
     return llr, payloads
+
+
+def nonfinite_cases(rng, oracle, rate, n=12):
+    """Noisy codewords with NaN / +-inf / huge / -0.0 values sprinkled in (the decoder's `<` tests and
+    std::min/std::max clamps decide what those do: ldpc_decoder.cpp:181-224)."""
+    k = INFO_BITS[rate]
+    out = []
+    for i in range(n):
+        enc = oracle.ldpc_encode(rate, bytes(rng.integers(0, 256, k // 8, dtype=np.uint8)))
+        bits = np.unpackbits(np.frombuffer(enc, np.uint8))[:648].astype(np.float32)
+        llr = ((2 * (1 - 2 * bits) + rng.normal(0, 1.6, 648)) / 0.8).astype(np.float32)
+        idx = rng.choice(648, 24, replace=False)
+        vals = [np.nan, np.inf, -np.inf, 3e38, -3e38, -0.0, 75.0, -75.0]
+        for j, ix in enumerate(idx[: 3 * (i % 8) + 1]):
+            llr[ix] = vals[(i + j) % len(vals)]
+        out.append(llr)
+    return np.stack(out)

@@ -5,7 +5,7 @@ fixtures in tests/golden/ldpc.npz come straight from the compiled reference."""
 import numpy as np
 import pytest
 
-from _util import INFO_BITS, beq, noisy_codewords
+from _util import INFO_BITS, beq, noisy_codewords, nonfinite_cases
 from conftest import GOLDEN
 
 pytestmark = pytest.mark.gpu
@@ -97,6 +97,23 @@ def test_edge_llrs(oracle):
     assert beq(r["llr_total"], ototal)
     one = d.decode_batch(cases[5:6])
     assert np.array_equal(one["bytes"], ob[5:6])
+
+
+@pytest.mark.parametrize("rate", range(6))
+def test_nonfinite_llrs(oracle, rate):
+    """NaN, +-inf, +-3e38, -0.0 and |LLR| > 50 sprinkled into noisy codewords: the kernel defers the
+    +-50 clamp to the reader and takes minima on bit patterns, which must not change any decision
+    (the oracle is checked against the compiled reference on the same generator in
+    test_oracle_vs_ref.py::test_fec_nonfinite_inputs)."""
+    cases = nonfinite_cases(np.random.default_rng(77 + rate), oracle, rate, n=32)
+    d = _decoder(rate)
+    r = d.decode_batch(cases, want_total=True)
+    ob, oi, ook, ototal = oracle.ldpc_decode_batch(rate, cases, want_total=True)
+    assert np.array_equal(r["iters"], oi) and np.array_equal(r["ok"], ook) and np.array_equal(r["bytes"], ob)
+    got = np.asarray(r["llr_total"])
+    both_nan = np.isnan(got) & np.isnan(ototal)          # a fresh NaN's sign bit differs between x86 and gfx950
+    assert np.array_equal(np.isnan(got), np.isnan(ototal))
+    assert beq(np.where(both_nan, np.float32(0), got), np.where(both_nan, np.float32(0), ototal))
 
 
 def test_full_size_round_trip_property(oracle):

@@ -3,7 +3,7 @@ box that received the prebuilt .so).  Everything is compared BITWISE, stage by s
 import numpy as np
 import pytest
 
-from _util import beq
+from _util import beq, nonfinite_cases
 from oracle.bindings import INFO_BITS, geometry, make_config
 
 
@@ -21,6 +21,13 @@ def test_fec(oracle, ref):
         for n in (100, 649, 2000):
             llr = rng.normal(0, 3, n).astype(np.float32)
             assert oracle.ldpc_decode_soft(rate, llr, 6) == ref.ldpc_decode_soft(rate, llr, 6)
+
+
+def test_fec_nonfinite_inputs(oracle, ref):
+    rng = np.random.default_rng(77)
+    for rate in range(6):
+        for llr in nonfinite_cases(rng, oracle, rate):
+            assert oracle.ldpc_decode_soft(rate, llr) == ref.ldpc_decode_soft(rate, llr)
 
 
 def test_interleavers(oracle, ref):
