@@ -108,25 +108,35 @@ __device__ __forceinline__ float timing_phase_of(int k, float timing, int fft) {
 }
 
 // ---- in-order reductions across lanes: every lane ends with the same sum ----
+// The reference accumulates serially (s = 0; s += x[0]; s += x[1]; ...), and float addition is not
+// associative, so the order is kept.  Terms go through LDS: every lane reads them back with
+// wave-uniform (broadcast) addresses and runs the serial chain itself — one v_add per term instead
+// of a v_readlane + v_add pair, and chains of different sums run in different lanes (see
+// update_channel_estimate).
 __device__ __forceinline__ float lane_f(float v, int i) {
     return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), i));
 }
-__device__ __forceinline__ float ordered_sum(float v, int n) {
+// buf: 64 floats of LDS, 16-byte aligned
+__device__ __forceinline__ float ordered_sum(float* buf, float v, int n) {
+    buf[threadIdx.x] = v;
+    wave_sync();
     float s = 0.0f;
-    for (int i = 0; i < n; ++i) s += lane_f(v, i);
+    int i = 0;
+    for (; i + 4 <= n; i += 4) {
+        const float4 q = *reinterpret_cast<const float4*>(buf + i);
+        s += q.x; s += q.y; s += q.z; s += q.w;
+    }
+    for (; i < n; ++i) s += buf[i];
+    wave_sync();
     return s;
 }
-__device__ __forceinline__ float ordered_sum_masked(float v, int n, unsigned long long mask, int* count) {
-    float s = 0.0f;
-    int c = 0;
-    for (int i = 0; i < n; ++i)
-        if ((mask >> i) & 1ull) { s += lane_f(v, i); ++c; }
-    *count = c;
-    return s;
-}
-__device__ __forceinline__ c32 ordered_csum(c32 v, int n) {
+// buf: 64 c32 of LDS
+__device__ __forceinline__ c32 ordered_csum(c32* buf, c32 v, int n) {
+    buf[threadIdx.x] = v;
+    wave_sync();
     c32 s = mk(0.0f, 0.0f);
-    for (int i = 0; i < n; ++i) s = cadd(s, mk(lane_f(v.re, i), lane_f(v.im, i)));
+    for (int i = 0; i < n; ++i) s = cadd(s, buf[i]);
+    wave_sync();
     return s;
 }
 
@@ -164,6 +174,11 @@ struct FftShared {                                          // mix_fft_kernel
 };
 struct TrackShared {                                        // track_kernel
     c32 H[kMaxCarriers];                                    // channel_estimate by slot
+    union {
+        float terms[kMaxCarriers][8];                       // per-pilot terms of the eight serial sums
+        c32 cbuf[kMaxCarriers];                             // staging of ordered_csum
+        float fbuf[kMaxCarriers];                           // staging of ordered_sum
+    } __attribute__((aligned(16)));
 };
 
 // Per-frame record between the kernels (floats).  Arrays are c32 indexed by lane.
@@ -357,8 +372,8 @@ __device__ __forceinline__ void update_channel_estimate(TrackShared& sh, const D
 
     c32 h = mk(0.0f, 0.0f);
     if (is_pilot) h = cdiv_pilot(fq[lc.pilot_fq], lc.pilot_seq);
-    c32 h_sum = ordered_csum(h, np);
     if (!tr.cpc_init && np != 0) {                              // carrier phase recovery (:348-357)
+        const c32 h_sum = ordered_csum(sh.cbuf, h, np);         // the reference sums on every symbol, uses it here only
         const c32 h_avg = cdivf(h_sum, (float)np);
         const float avg_mag = cabs_(h_avg);
         if (avg_mag > 0.01f) { tr.cpc = cdivf(cconj(h_avg), avg_mag); tr.cpc_init = 1; }
@@ -385,30 +400,38 @@ __device__ __forceinline__ void update_channel_estimate(TrackShared& sh, const D
         const c32 h_old = sh.H[lc.pilot_slot];
         sh.H[lc.pilot_slot] = cadd(cscale(h, alpha), cscale(h_old, 1.0f - alpha));
     }
-    // All serial sums of the reference over the pilots (:385-412, :420-440, :473-490) in ONE pass:
-    // every lane walks i = 0..np-1 in order and accumulates lane i's terms, so all lanes hold the
-    // reference's running sums.  A term the reference skips is replaced by -0.0f, the exact neutral
-    // element of float addition (x + -0.0f == x bit for bit, also for x = +-0), which keeps the loop
-    // branch-free and lets the eight independent chains overlap.
+    // All eight serial sums of the reference over the pilots (:385-412, :420-440, :473-490) at once:
+    // pilot i stores its eight terms as row i of sh.terms; lane s (mod 8) then walks column s in
+    // pilot order, so the eight chains run in eight lanes side by side (np v_adds in total instead
+    // of 8*np readlane+add pairs).  A term the reference skips is replaced by -0.0f, the exact
+    // neutral element of float addition (x + -0.0f == x bit for bit, also for x = +-0), which keeps
+    // the walk branch-free.
     const int noise_hits = __popcll(__ballot(f_noise)), cfo_hits = __popcll(__ballot(f_cfo)),
               tim_hits = __popcll(__ballot(f_tim));
-    const float kf = (float)lc.pilot_k;
-    const float t_nd = f_noise ? nd : -0.0f;
-    const float t_ur = f_cfo ? unit.re : -0.0f, t_ui = f_cfo ? unit.im : -0.0f;
-    const float t_k = f_tim ? kf : -0.0f, t_k2 = f_tim ? (float)(lc.pilot_k * lc.pilot_k) : -0.0f;
-    const float t_ph = f_tim ? ph : -0.0f, t_kph = f_tim ? kf * ph : -0.0f;
-    float s_sig = 0.0f, s_nd = 0.0f, s_ur = 0.0f, s_ui = 0.0f, sum_k = 0.0f, sum_k2 = 0.0f, sum_phase = 0.0f,
-          sum_k_phase = 0.0f;
-    for (int i = 0; i < np; ++i) {
-        s_sig += lane_f(n2, i);
-        s_nd += lane_f(t_nd, i);
-        s_ur += lane_f(t_ur, i);
-        s_ui += lane_f(t_ui, i);
-        sum_k += lane_f(t_k, i);
-        sum_k2 += lane_f(t_k2, i);
-        sum_phase += lane_f(t_ph, i);
-        sum_k_phase += lane_f(t_kph, i);
+    if (is_pilot) {
+        const float kf = (float)lc.pilot_k;
+        float4 ta, tb;
+        ta.x = n2;
+        ta.y = f_noise ? nd : -0.0f;
+        ta.z = f_cfo ? unit.re : -0.0f;
+        ta.w = f_cfo ? unit.im : -0.0f;
+        tb.x = f_tim ? kf : -0.0f;
+        tb.y = f_tim ? (float)(lc.pilot_k * lc.pilot_k) : -0.0f;
+        tb.z = f_tim ? ph : -0.0f;
+        tb.w = f_tim ? kf * ph : -0.0f;
+        *reinterpret_cast<float4*>(&sh.terms[lane][0]) = ta;
+        *reinterpret_cast<float4*>(&sh.terms[lane][4]) = tb;
     }
+    wave_sync();
+    float acc = 0.0f;
+    {
+        const int col = lane & 7;
+        for (int i = 0; i < np; ++i) acc += sh.terms[i][col];
+    }
+    const float s_sig = lane_f(acc, 0), s_nd = lane_f(acc, 1), s_ur = lane_f(acc, 2), s_ui = lane_f(acc, 3),
+                sum_k = lane_f(acc, 4), sum_k2 = lane_f(acc, 5), sum_phase = lane_f(acc, 6),
+                sum_k_phase = lane_f(acc, 7);
+    wave_sync();
     const float signal_power = s_sig / (float)np;                   // NaN when np == 0 (reference quirk)
     int noise_count = noise_hits;
     float noise_power_sum = s_nd;
@@ -621,7 +644,7 @@ __device__ __forceinline__ void equalize_demap(TrackShared& sh, const DemodConst
                 nv = fmax_std(1e-6f, fmin_std(100.0f, nv));
             }
         }
-        float avg = ordered_sum(h_power, nd);                   // deep-fade soft erasure (:822-837)
+        float avg = ordered_sum(sh.fbuf, h_power, nd);          // deep-fade soft erasure (:822-837)
         avg /= (float)nd;
         if (is_data && h_power < 0.1f * avg) nv = 100.0f;
     }
@@ -680,7 +703,7 @@ __device__ __forceinline__ void lts_finish(TrackShared& sh, const DemodConst& D,
     wave_sync();
     float mag = 0.0f;
     if (lane < D.n_data) mag = cabs_(sh.H[lc.data_slot]);
-    const float h_mag_avg = ordered_sum(mag, D.n_data) / (float)D.n_data;
+    const float h_mag_avg = ordered_sum(sh.fbuf, mag, D.n_data) / (float)D.n_data;
     if (h_mag_avg > 1e-6f && tr.noise_variance > 1e-10f) {
         const float s = (h_mag_avg * h_mag_avg) / tr.noise_variance;
         tr.snr_linear = fmax_std(0.1f, fmin_std(10000.0f, s));
