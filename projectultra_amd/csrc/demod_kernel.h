@@ -102,9 +102,12 @@ __device__ __forceinline__ float clip_llr(float llr) {  // soft_demap.hpp:22-29
     return c;
 }
 
-// float timing_phase = 2.0f * M_PI * k * timing_offset_samples / config.fft_size  (double expr)
-__device__ __forceinline__ float timing_phase_of(int k, float timing, int fft) {
-    return (float)(((kTwoPi * (double)k) * (double)timing) / (double)fft);
+// float timing_phase = 2.0f * M_PI * k * timing_offset_samples / config.fft_size  (double expr).
+// fft_size is a power of two: dividing the double by it is an exact exponent shift (v_ldexp_f64;
+// the quotient of two float-derived factors is far from the subnormal range), not a 30-instruction
+// double-precision division.
+__device__ __forceinline__ float timing_phase_of(int k, float timing, int log2_fft) {
+    return (float)ldexp((kTwoPi * (double)k) * (double)timing, -log2_fft);
 }
 
 // ---- in-order reductions across lanes: every lane ends with the same sum ----
@@ -478,14 +481,14 @@ __device__ __forceinline__ void update_channel_estimate(TrackShared& sh, const D
     // coherent timing fix around the interpolation (:514-567)
     const bool fix = !D.differential && fabsf(tr.timing) > 0.1f;
     if (fix && is_pilot) {
-        const float tp = timing_phase_of(lc.pilot_k, tr.timing, D.fft);
+        const float tp = timing_phase_of(lc.pilot_k, tr.timing, D.log2_fft);
         sh.H[lc.pilot_slot] = cmul(sh.H[lc.pilot_slot], cexpj(-tp));
     }
     wave_sync();
     interpolate_channel(sh, D, lc);
     wave_sync();
     if (fix && lane < D.n_carriers) {       // pilots then data carriers: every used slot exactly once
-        const float tp = timing_phase_of(lc.slot_k, tr.timing, D.fft);
+        const float tp = timing_phase_of(lc.slot_k, tr.timing, D.log2_fft);
         sh.H[lane] = cmul(sh.H[lane], cexpj(tp));
     }
     if (noise_count > 1 && noise_power_sum > 0.0f) {            // (:583-592)
@@ -618,7 +621,7 @@ __device__ __forceinline__ void equalize_demap(TrackShared& sh, const DemodConst
         if (is_data) {
             const c32 received = fq[lc.data_fq], h = sh.H[lc.data_slot];
             const float h_power = cnorm(h);
-            const c32 tc = cexpj(timing_phase_of(lc.data_k, tr.timing, D.fft));
+            const c32 tc = cexpj(timing_phase_of(lc.data_k, tr.timing, D.log2_fft));
             if (h_power > 1e-6f) {
                 const c32 t = cdivf(cmul(received, cconj(h)), h_power);
                 eq = cmul(cmul(t, tr.ppc), tc);

@@ -202,36 +202,32 @@ UM_FN float atanf_(float x) {
                 aT3 = as_f32(0xbde38e38), aT4 = as_f32(0x3dba2e6e), aT5 = as_f32(0xbd9d8795),
                 aT6 = as_f32(0x3d886b35), aT7 = as_f32(0xbd6ef16b), aT8 = as_f32(0x3d4bda59),
                 aT9 = as_f32(0xbd15a221), aT10 = as_f32(0x3c8569d7);
-    int32_t hx = (int32_t)as_u32(x);
-    int32_t ix = hx & 0x7fffffff;
-    int id;
-    if (ix >= 0x4c000000) {  // |x| >= 2^25
-        if (ix > 0x7f800000) return x + x;
-        if (hx > 0) return hi3 + lo3;
-        return -hi3 - lo3;
-    }
-    if (ix < 0x3ee00000) {       // |x| < 0.4375
-        if (ix < 0x31000000) return x;  // |x| < 2^-29 (huge + x > one always holds)
-        id = -1;
-    } else {
-        x = fabsf(x);
-        if (ix < 0x3f980000) {
-            if (ix < 0x3f300000) { id = 0; x = (2.0f * x - 1.0f) / (2.0f + x); }
-            else { id = 1; x = (x - 1.0f) / (x + 1.0f); }
-        } else {
-            if (ix < 0x401c0000) { id = 2; x = (x - 1.5f) / (1.0f + 1.5f * x); }
-            else { id = 3; x = -1.0f / x; }
-        }
-    }
-    float z = x * x;
-    float w = z * z;
-    float s1 = z * (aT0 + w * (aT2 + w * (aT4 + w * (aT6 + w * (aT8 + w * aT10)))));
-    float s2 = w * (aT1 + w * (aT3 + w * (aT5 + w * (aT7 + w * aT9))));
-    if (id < 0) return x - x * (s1 + s2);
-    const float ahi = (id == 0) ? hi0 : (id == 1) ? hi1 : (id == 2) ? hi2 : hi3;
-    const float alo = (id == 0) ? lo0 : (id == 1) ? lo1 : (id == 2) ? lo2 : lo3;
-    z = ahi - ((x * (s1 + s2) - alo) - x);
-    return (hx < 0) ? -z : z;
+    // Same operations on the same operands as s_atanf.c, written without divergent branches: the four
+    // argument reductions are four (numerator, denominator) pairs and ONE correctly rounded division
+    // (|x| < 0.4375 divides x by 1.0f, which is exact), the range cases are selects.  A wavefront
+    // whose lanes fall into different ranges then runs one division instead of up to four.
+    const int32_t hx = (int32_t)as_u32(x);
+    const int32_t ix = hx & 0x7fffffff;
+    const float ax = as_f32((uint32_t)ix);
+    const bool r_small = ix < 0x3ee00000;                  // |x| < 0.4375        id = -1
+    const bool r0 = ix < 0x3f300000;                       // |x| < 11/16         id = 0
+    const bool r1 = ix < 0x3f980000;                       // |x| < 19/16         id = 1
+    const bool r2 = ix < 0x401c0000;                       // |x| < 39/16         id = 2, else id = 3
+    const float num = r_small ? x : r0 ? (2.0f * ax - 1.0f) : r1 ? (ax - 1.0f) : r2 ? (ax - 1.5f) : -1.0f;
+    const float den = r_small ? 1.0f : r0 ? (2.0f + ax) : r1 ? (ax + 1.0f) : r2 ? (1.0f + 1.5f * ax) : ax;
+    const float xr = num / den;
+    const float z = xr * xr;
+    const float w = z * z;
+    const float s1 = z * (aT0 + w * (aT2 + w * (aT4 + w * (aT6 + w * (aT8 + w * aT10)))));
+    const float s2 = w * (aT1 + w * (aT3 + w * (aT5 + w * (aT7 + w * aT9))));
+    const float ahi = r0 ? hi0 : r1 ? hi1 : r2 ? hi2 : hi3;
+    const float alo = r0 ? lo0 : r1 ? lo1 : r2 ? lo2 : lo3;
+    const float zb = ahi - ((xr * (s1 + s2) - alo) - xr);
+    float r = r_small ? (xr - xr * (s1 + s2)) : ((hx < 0) ? -zb : zb);
+    if (ix < 0x31000000) r = x;                            // |x| < 2^-29 (huge + x > one always holds)
+    if (ix >= 0x4c000000)                                  // |x| >= 2^25, inf, NaN
+        r = (ix > 0x7f800000) ? (x + x) : ((hx > 0) ? (hi3 + lo3) : (-hi3 - lo3));
+    return r;
 }
 
 // fdlibm __ieee754_atan2f (e_atan2f.c); the errno wrapper adds nothing numerically.
