@@ -174,6 +174,7 @@ struct FftShared {                                          // mix_fft_kernel
     static constexpr int kTwB = P * ((1 << A) - 1);
     c32 twB[kTwB];
     um::PhaseSeg seg[kPhaseCap];
+    int seg_start[kPhaseCap + 4] __attribute__((aligned(16)));   // segment starts, INT_MAX beyond the last one
 };
 struct TrackShared {                                        // track_kernel
     c32 H[kMaxCarriers];                                    // channel_estimate by slot
@@ -243,12 +244,19 @@ __device__ __forceinline__ void symbol_to_freq(FftShared<LOG2N>& sh, const Demod
     wave_sync();                                                                // X may be overwritten from here on
 
     // ---- CFO rotation factors (toBaseband: phase recurrence + cos/sin per sample) ----
-    // Computed BEFORE the oscillator values are loaded and parked in LDS (the idle exchange
-    // buffer), so that the double-precision sincos work never coexists with the 48 registers of
-    // the mixing stage: this kernel is register-limited.
-    c32* rot = sh.X;                                       // rot[P*lane + qp] (+pad)
+    // Lane l produces the factors of the P CONSECUTIVE window positions P*l .. P*l+P-1 (they
+    // almost always lie in one segment of the phase table: one lookup, then straight-line code)
+    // and parks them in the idle exchange buffer; the mixing stage below picks up the positions
+    // rl + 64*q it needs.  The P phases are computed first and the P sincos evaluations follow as
+    // one branch-free block, so their dependent double-precision chains overlap.
+    c32* rot = sh.X;                                       // rot[w + (w >> A)], w = window position
     if (cfo_on) {
         const float inc = (float)(((-kTwoPi) * (double)freq_offset_hz) / (double)D.sample_rate);
+        // every phase of the symbol stays below 120 in magnitude (domain of the branch-free sincos)
+        const bool bounded = fabsf(cfo_phase) <= 4.0f && fabsf(inc) <= 1.0f;
+        float ph[P];
+#pragma unroll
+        for (int j = 0; j < P; ++j) ph[j] = 0.0f;
         int done = 0;
         float pcur = cfo_phase;
         while (done < D.sym_len) {                           // one round unless a table overflows
@@ -257,14 +265,32 @@ __device__ __forceinline__ void symbol_to_freq(FftShared<LOG2N>& sh, const Demod
             const int ns = um::phase_table_build(pcur, inc, D.sym_len - done, sh.seg, kPhaseCap, &covered, &pnext,
                                                  lane == 0);
             wave_sync();
-            int sg = 0;
-#pragma unroll 4
-            for (int qp = 0; qp < P; ++qp) {
-                const int i = D.cp + rl + 64 * qp - done;   // position inside this round
-                if (i >= 0 && i < covered) {
-                    while (sg + 1 < ns && sh.seg[sg + 1].start <= i) ++sg;
-                    const int xi = P * lane + qp;
-                    rot[xi + (xi >> A)] = cexpj(um::phase_table_eval(sh.seg[sg], i));
+            if (lane < kPhaseCap + 4) sh.seg_start[lane] = (lane < ns) ? sh.seg[lane].start : 0x7fffffff;
+            wave_sync();
+            const int i0 = D.cp + P * lane - done;          // this lane's first position inside this round
+            if (i0 + P > 0 && i0 < covered) {
+                const int ifirst = (i0 > 0) ? i0 : 0;
+                int cnt = 0;                                 // segments starting at or before ifirst
+                for (int s0 = 0; s0 < ns; s0 += 4) {
+                    const int4 st = *reinterpret_cast<const int4*>(&sh.seg_start[s0]);
+                    cnt += (st.x <= ifirst) + (st.y <= ifirst) + (st.z <= ifirst) + (st.w <= ifirst);
+                }
+                int sg = cnt - 1;
+                um::PhaseSeg cur = sh.seg[sg];
+                int nstart = sh.seg_start[sg + 1];
+                const int ilast = i0 + P - 1;
+                if (i0 >= 0 && ilast < covered && ilast < nstart) {          // the usual case: one segment
+#pragma unroll
+                    for (int j = 0; j < P; ++j) ph[j] = um::phase_table_eval(cur, i0 + j);
+                } else {
+#pragma unroll
+                    for (int j = 0; j < P; ++j) {
+                        const int i = i0 + j;
+                        if (i >= 0 && i < covered) {
+                            while (i >= nstart) { ++sg; cur = sh.seg[sg]; nstart = sh.seg_start[sg + 1]; }
+                            ph[j] = um::phase_table_eval(cur, i);
+                        }
+                    }
                 }
             }
             wave_sync();
@@ -272,6 +298,19 @@ __device__ __forceinline__ void symbol_to_freq(FftShared<LOG2N>& sh, const Demod
             pcur = pnext;
         }
         cfo_phase = pcur;
+        if (bounded) {
+#pragma unroll
+            for (int j = 0; j < P; ++j) {
+                float sn, cs;
+                um::sincosf_bounded_(ph[j], &sn, &cs);
+                const int w = P * lane + j;
+                rot[w + (w >> A)] = mk(cs, sn);
+            }
+        } else {
+#pragma unroll 2
+            for (int j = 0; j < P; ++j) { const int w = P * lane + j; rot[w + (w >> A)] = cexpj(ph[j]); }
+        }
+        wave_sync();
     }
     // ---- mix: samples[i] * conj(osc) (* rotation), in two halves to bound live registers ----
 #pragma unroll
@@ -283,7 +322,7 @@ __device__ __forceinline__ void symbol_to_freq(FftShared<LOG2N>& sh, const Demod
         for (int q2 = 0; q2 < P / 2; ++q2) {
             const int qp = h * (P / 2) + q2;
             c32 mixed = mk(os[q2].re * xs[qp], (-os[q2].im) * xs[qp]);
-            if (cfo_on) { const int xi = P * lane + qp; mixed = cmul(mixed, rot[xi + (xi >> A)]); }
+            if (cfo_on) { const int w = rl + 64 * qp; mixed = cmul(mixed, rot[w + (w >> A)]); }
             v[bitrev_small<A>(qp)] = mixed;
         }
     }

@@ -16,8 +16,8 @@
 // piecewise affine: phase[i0 + t] = base + t*step, exactly, for all t that keep
 // the value in the binade and inside (-pi, pi].  build() walks the (few) segments
 // with real float steps at every boundary — binade changes, zero crossing, +-pi
-// wraps — and lookups evaluate  (float)((double)base + (double)t * (double)step),
-// which is exact because the result is representable.
+// wraps — and lookups evaluate  base + (float)t * step  in single precision, which
+// is exact because the product and the sum are representable (they lie on the grid).
 //
 // Checked against the serial recurrence position by position on the host
 // (tools/phase_table_check.cpp: random starts/increments, ties, zero crossings,
@@ -35,11 +35,13 @@ struct PhaseSeg { int start; float base; float step; };
 constexpr double kPiD = 3.14159265358979323846;
 constexpr double kTwoPiD = 2.0 * 3.14159265358979323846;
 
-// one step of the reference recurrence
+// one step of the reference recurrence.  The reference compares in double against M_PI; pi is not
+// a float, so for a float p: (double)p > M_PI  <=>  p > kPiMax (the largest float below pi).
 UM_FN float phase_step(float p, float inc) {
+    const float pi_max = as_f32(0x40490FDAu);
     p += inc;
-    if ((double)p > kPiD) p = (float)((double)p - kTwoPiD);
-    else if ((double)p < -kPiD) p = (float)((double)p + kTwoPiD);
+    if (p > pi_max) p = (float)((double)p - kTwoPiD);
+    else if (p < -pi_max) p = (float)((double)p + kTwoPiD);
     return p;
 }
 
@@ -49,10 +51,36 @@ UM_FN bool same_binade(float a, float b) {
     return ((ua ^ ub) < 0x00800000u) && ea != 0 && ea != 0xff;
 }
 
+// v >= 0, a multiple of the grid 2^(E-150) of the binade with biased exponent E (E >= 1), and
+// smaller than 2^24 grid units: the multiple, by integer manipulation of the bits (no dependence
+// on the denormal mode of the float pipeline).
+UM_FN uint32_t grid_units(float v, uint32_t E) {
+    const uint32_t b = as_u32(v);
+    uint32_t e = b >> 23, m = b & 0x007fffffu;
+    if (e != 0) m |= 0x00800000u; else e = 1;
+    const uint32_t sh = E - e;
+    return (sh < 32u) ? (m >> sh) : 0u;
+}
+
+// float approximation of 1/q for the quotient estimate (any error is removed by the integer fix-up)
+UM_FN float approx_rcp(float q) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    return __builtin_amdgcn_rcpf(q);
+#else
+    return 1.0f / q;
+#endif
+}
+
 // Build segments for positions [0, n) starting from phase p0 (= phase[0]).
 // Writes at most `cap` segments (only when `write`: on the GPU every lane walks the same
 // uniform control flow and lane 0 stores); returns their count, the number of positions they
 // cover in *covered (== n unless cap was hit) and phase[*covered] in *p_next.
+//
+// This is a serial chain (every segment starts where the previous one ends) that a whole
+// wavefront waits for, so it is written for latency: single-precision and integer operations
+// only — every product and sum below is exact because its result lies on the binade's grid —
+// and the segment length floor(room/|d|) comes from an approximate reciprocal plus an exact
+// integer remainder fix-up instead of a correctly rounded division.
 UM_FN int phase_table_build(float p0, float inc, int n, PhaseSeg* seg, int cap, int* covered, float* p_next,
                              bool write = true) {
     const float pi_max = as_f32(0x40490FDAu);   // largest float <= pi: no wrap while |phase| <= pi_max
@@ -73,31 +101,31 @@ UM_FN int phase_table_build(float p0, float inc, int n, PhaseSeg* seg, int cap, 
                     const uint32_t up = as_u32(p);
                     const float ap = as_f32(up & 0x7fffffffu);                 // |p|
                     const bool growing = ((up >> 31) != 0) == (d1 < 0.0f);     // |phase| increases
-                    double room;
+                    float room;                                                // exact differences inside one binade
                     if (growing) {
                         float top = as_f32((up & 0x7fffffffu) | 0x007fffffu);  // largest value of the binade
                         if (top > pi_max) top = pi_max;
-                        room = (double)top - (double)ap;
+                        room = top - ap;
                     } else {
                         // stay strictly above 2^e: a sum that lands just below the binade is rounded
                         // on the finer grid of the binade underneath, so exactly 2^e is not safe
                         const float bottom = as_f32((up & 0x7f800000u) + 1u);   // 2^e + ulp
-                        room = (double)ap - (double)bottom;
+                        room = ap - bottom;
                     }
-                    // floor(room / |d|): room and |d| are integers (< 2^24) times the binade's ulp.  A float
-                    // quotient is within one of the true floor; the products t*|d| are exact in double
-                    // (< 2^48), so two comparisons make it exact without a double-precision divide.
-                    const double ad = (d1 < 0.0f) ? -(double)d1 : (double)d1;
-                    double t = 0.0;
-                    if (room > 0.0) {
-                        t = (double)(float)((float)room / (float)ad);
-                        t = (double)(long long)t;                       // trunc (t >= 0)
-                        if (t * ad > room) t -= 1.0;
-                        else if ((t + 1.0) * ad <= room) t += 1.0;
+                    // t = floor(room / |d|), both integers (< 2^24) times the binade's ulp
+                    int t = 0;
+                    if (room > 0.0f) {
+                        const uint32_t E = (up >> 23) & 0xffu;
+                        const int R = (int)grid_units(room, E);
+                        const int Q = (int)grid_units(fabsf(d1), E);           // >= 1
+                        t = (int)((float)R * approx_rcp((float)Q));             // within a few units of the floor
+                        int r = R - t * Q;                                      // |t*Q| < 2^26: no overflow
+                        while (r < 0) { --t; r += Q; }
+                        while (r >= Q) { ++t; r -= Q; }
                     }
-                    const double lim = (double)(n - i - 1);
+                    const int lim = n - i - 1;
                     if (t > lim) t = lim;
-                    len = (int)t + 1;                  // positions t = 0 .. floor(room/ad)
+                    len = t + 1;                       // positions t = 0 .. floor(room/|d|)
                 }
             }
         }
@@ -106,7 +134,7 @@ UM_FN int phase_table_build(float p0, float inc, int n, PhaseSeg* seg, int cap, 
         if (len == 1) {
             p = p1;
         } else {
-            const float last = (float)((double)p + (double)(len - 1) * (double)d);
+            const float last = p + (float)(len - 1) * d;    // exact: (len-1)*|d| <= room, result on the binade's grid
             p = phase_step(last, inc);
         }
         i += len;
@@ -116,9 +144,9 @@ UM_FN int phase_table_build(float p0, float inc, int n, PhaseSeg* seg, int cap, 
     return ns;
 }
 
-// phase at position i (seg = the segment with start <= i < next start)
+// phase at position i (seg = the segment with start <= i < next start); both operations are exact
 UM_FN float phase_table_eval(const PhaseSeg& s, int i) {
-    return (float)((double)s.base + (double)(i - s.start) * (double)s.step);
+    return s.base + (float)(i - s.start) * s.step;
 }
 
 }  // namespace um

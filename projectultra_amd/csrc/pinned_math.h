@@ -193,6 +193,39 @@ UM_FN void sincosf_(float y, float* sp, float* cp) {
     if (n & 1) { *sp = cosine; *cp = sine; } else { *sp = sine; *cp = cosine; }
 }
 
+// sincosf_ restricted to |y| < 120 (abstop12(y) < 0x42f), without branches.  Same values:
+//   * |y| < pi/4: glibc skips the reduction; reduce_fast yields n = 0 and fma(-0.0, hpi, x) = x,
+//     so the shared path computes exactly what the short path does;
+//   * table 1 is table 0 with the cosine coefficients negated (sine coefficients equal), and every
+//     operation of the cosine polynomial is odd in its coefficients, so "table 1" = negate the
+//     cosine of table 0; multiplying x by the quadrant sign +-1.0 = flipping its sign bit;
+//   * |y| < 2^-12 returns (y, 1.0f) as glibc does (the polynomial would round to the same cosine,
+//     but not to the same sine for y = -0.0).
+// Checked against libm over every float of the range (tools/pinned_math_check.cpp).
+UM_FN void sincosf_bounded_(float y, float* sp, float* cp) {
+    const SinCosTab p = UM_TAB0;
+    int n;
+    const double x = reduce_fast((double)y, &n);
+    const double xs = ((n + 1) & 2) ? -x : x;
+    const double x2 = x * x;
+    const double x3 = xs * x2;
+    const double s1 = fma(x2, p.s3, p.s2);
+    const double x7 = x3 * x2;
+    const double sa = fma(x3, p.s1, xs);
+    float sine = (float)fma(x7, s1, sa);
+    const double x4 = x2 * x2;
+    const double c2 = fma(x2, p.c4, p.c3);
+    const double c1 = fma(x2, p.c1, p.c0);
+    const double x6 = x4 * x2;
+    const double ca = fma(x4, p.c2, c1);
+    float cosine = (float)fma(x6, c2, ca);
+    if (n & 2) cosine = -cosine;
+    if (n & 1) { const float t = sine; sine = cosine; cosine = t; }
+    if (abstop12(y) < 0x398) { sine = y; cosine = 1.0f; }
+    *sp = sine;
+    *cp = cosine;
+}
+
 // fdlibm atanf (s_atanf.c)
 UM_FN float atanf_(float x) {
     // atanhi / atanlo as selects (a dynamically indexed local array would live in memory on the GPU)

@@ -28,11 +28,11 @@ int main(int argc, char** argv) {
     const unsigned T = std::max(1u, std::thread::hardware_concurrency());
     const uint64_t stride = full ? 1 : 1021;            // prime stride for the quick subset
     const uint64_t pairs = full ? (1ull << 31) : (1ull << 24);
-    std::atomic<uint64_t> bad[6]; for (auto& b : bad) b = 0;
-    std::atomic<uint64_t> cnt[6]; for (auto& c : cnt) c = 0;
+    std::atomic<uint64_t> bad[7]; for (auto& b : bad) b = 0;
+    std::atomic<uint64_t> cnt[7]; for (auto& c : cnt) c = 0;
     std::vector<std::thread> th;
     for (unsigned t = 0; t < T; ++t) th.emplace_back([&, t] {
-        uint64_t lb[6] = {0}, lc[6] = {0};
+        uint64_t lb[7] = {0}, lc[7] = {0};
         for (uint64_t u = t * stride; u < (1ull << 32); u += (uint64_t)T * stride) {
             float x = um::as_f32((uint32_t)u);
             float s, c; sincosf(x, &s, &c);
@@ -40,6 +40,10 @@ int main(int argc, char** argv) {
             lc[1]++; if (!same(um::cosf_(x), cosf(x))) { if (lb[1]++ < 3) fprintf(stderr, "cosf %08x\n", (unsigned)u); }
             float ms, mc; um::sincosf_(x, &ms, &mc);
             lc[2]++; if (!same(ms, s) || !same(mc, c)) { if (lb[2]++ < 3) fprintf(stderr, "sincosf %08x\n", (unsigned)u); }
+            if (um::abstop12(x) < 0x42f) {            // the branch-free variant's domain: |x| < 120
+                float bs, bc; um::sincosf_bounded_(x, &bs, &bc);
+                lc[6]++; if (!same(bs, s) || !same(bc, c)) { if (lb[6]++ < 3) fprintf(stderr, "sincosf_bounded %08x\n", (unsigned)u); }
+            }
             lc[3]++; if (!same(um::atanf_(x), atanf(x))) { if (lb[3]++ < 3) fprintf(stderr, "atanf %08x\n", (unsigned)u); }
         }
         uint64_t seed = 0x1234 + t;
@@ -64,12 +68,12 @@ int main(int argc, char** argv) {
                 lc[5]++; if (!same(um::hypotf_(y, x), hypotf(y, x))) lb[5]++;
             }
         }
-        for (int k = 0; k < 6; ++k) { bad[k] += lb[k]; cnt[k] += lc[k]; }
+        for (int k = 0; k < 7; ++k) { bad[k] += lb[k]; cnt[k] += lc[k]; }
     });
     for (auto& x : th) x.join();
-    const char* names[6] = {"sinf", "cosf", "sincosf", "atanf", "atan2f", "hypotf"};
+    const char* names[7] = {"sinf", "cosf", "sincosf", "atanf", "atan2f", "hypotf", "sincosf_bounded"};
     int rc = 0;
-    for (int k = 0; k < 6; ++k) {
+    for (int k = 0; k < 7; ++k) {
         printf("%s checked=%llu mismatches=%llu\n", names[k], (unsigned long long)cnt[k].load(), (unsigned long long)bad[k].load());
         if (bad[k].load()) rc = 1;
     }
