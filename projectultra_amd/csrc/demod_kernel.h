@@ -262,19 +262,24 @@ __device__ __forceinline__ void symbol_to_freq(FftShared<LOG2N>& sh, const Demod
         while (done < D.sym_len) {                           // one round unless a table overflows
             int covered;
             float pnext;
-            const int ns = um::phase_table_build(pcur, inc, D.sym_len - done, sh.seg, kPhaseCap, &covered, &pnext,
-                                                 lane == 0);
-            wave_sync();
-            if (lane < kPhaseCap + 4) sh.seg_start[lane] = (lane < ns) ? sh.seg[lane].start : 0x7fffffff;
+            // every lane walks the same (wave-uniform) chain; lane k keeps segment k in registers
+            int my_start = 0x7fffffff;
+            float my_base = 0.0f, my_step = 0.0f;
+            const int ns = um::phase_table_walk(pcur, inc, D.sym_len - done, kPhaseCap, &covered, &pnext,
+                                                [&](int k, int start, float base, float step) {
+                                                    const bool mine = (lane == k);
+                                                    my_start = mine ? start : my_start;
+                                                    my_base = mine ? base : my_base;
+                                                    my_step = mine ? step : my_step;
+                                                });
+            if (lane < kPhaseCap) { sh.seg[lane].start = my_start; sh.seg[lane].base = my_base; sh.seg[lane].step = my_step; }
+            if (lane < kPhaseCap + 4) sh.seg_start[lane] = my_start;         // INT_MAX beyond the last segment
             wave_sync();
             const int i0 = D.cp + P * lane - done;          // this lane's first position inside this round
             if (i0 + P > 0 && i0 < covered) {
                 const int ifirst = (i0 > 0) ? i0 : 0;
-                int cnt = 0;                                 // segments starting at or before ifirst
-                for (int s0 = 0; s0 < ns; s0 += 4) {
-                    const int4 st = *reinterpret_cast<const int4*>(&sh.seg_start[s0]);
-                    cnt += (st.x <= ifirst) + (st.y <= ifirst) + (st.z <= ifirst) + (st.w <= ifirst);
-                }
+                int cnt = 1;                                 // segments starting at or before ifirst (segment 0 starts at 0)
+                for (int k = 1; k < ns; ++k) cnt += (__builtin_amdgcn_readlane(my_start, k) <= ifirst) ? 1 : 0;
                 int sg = cnt - 1;
                 um::PhaseSeg cur = sh.seg[sg];
                 int nstart = sh.seg_start[sg + 1];

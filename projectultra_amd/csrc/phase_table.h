@@ -36,24 +36,18 @@ constexpr double kPiD = 3.14159265358979323846;
 constexpr double kTwoPiD = 2.0 * 3.14159265358979323846;
 
 // one step of the reference recurrence.  The reference compares in double against M_PI; pi is not
-// a float, so for a float p: (double)p > M_PI  <=>  p > kPiMax (the largest float below pi).
+// a float, so for a float s: (double)s > M_PI  <=>  s > pi_max (the largest float below pi), and
+// s + 2*pi == s - (-2*pi): one rarely taken branch covers both wraps.
 UM_FN float phase_step(float p, float inc) {
     const float pi_max = as_f32(0x40490FDAu);
-    p += inc;
-    if (p > pi_max) p = (float)((double)p - kTwoPiD);
-    else if (p < -pi_max) p = (float)((double)p + kTwoPiD);
-    return p;
-}
-
-UM_FN bool same_binade(float a, float b) {
-    const uint32_t ua = as_u32(a), ub = as_u32(b);
-    const uint32_t ea = (ua >> 23) & 0xff;
-    return ((ua ^ ub) < 0x00800000u) && ea != 0 && ea != 0xff;
+    float s = p + inc;
+    if (fabsf(s) > pi_max) s = (float)((double)s - ((s < 0.0f) ? -kTwoPiD : kTwoPiD));
+    return s;
 }
 
 // v >= 0, a multiple of the grid 2^(E-150) of the binade with biased exponent E (E >= 1), and
 // smaller than 2^24 grid units: the multiple, by integer manipulation of the bits (no dependence
-// on the denormal mode of the float pipeline).
+// on the denormal mode of the float pipeline).  Anything else yields some harmless integer.
 UM_FN uint32_t grid_units(float v, uint32_t E) {
     const uint32_t b = as_u32(v);
     uint32_t e = b >> 23, m = b & 0x007fffffu;
@@ -71,77 +65,72 @@ UM_FN float approx_rcp(float q) {
 #endif
 }
 
-// Build segments for positions [0, n) starting from phase p0 (= phase[0]).
-// Writes at most `cap` segments (only when `write`: on the GPU every lane walks the same
-// uniform control flow and lane 0 stores); returns their count, the number of positions they
-// cover in *covered (== n unless cap was hit) and phase[*covered] in *p_next.
+// Walk the segments of positions [0, n) starting from phase p0 (= phase[0]); emit(k, start, base,
+// step) receives segment k.  At most `cap` segments; returns their count, the number of positions
+// they cover in *covered (== n unless cap was hit) and phase[*covered] in *p_next.
 //
 // This is a serial chain (every segment starts where the previous one ends) that a whole
 // wavefront waits for, so it is written for latency: single-precision and integer operations
-// only — every product and sum below is exact because its result lies on the binade's grid —
-// and the segment length floor(room/|d|) comes from an approximate reciprocal plus an exact
-// integer remainder fix-up instead of a correctly rounded division.
-UM_FN int phase_table_build(float p0, float inc, int n, PhaseSeg* seg, int cap, int* covered, float* p_next,
-                             bool write = true) {
+// only — every product and sum below is exact because its result lies on the binade's grid —,
+// selects instead of branches (the only branches left are the rare +-pi wraps), and the segment
+// length floor(room/|d|) from an approximate reciprocal plus an exact integer remainder fix-up
+// instead of a correctly rounded division.
+template <class Emit>
+UM_FN int phase_table_walk(float p0, float inc, int n, int cap, int* covered, float* p_next, Emit emit) {
     const float pi_max = as_f32(0x40490FDAu);   // largest float <= pi: no wrap while |phase| <= pi_max
     int i = 0, ns = 0;
     float p = p0;
     while (i < n && ns < cap) {
         const float p1 = phase_step(p, inc);
         const float p2 = phase_step(p1, inc);
-        int len = 1;
-        float d = 0.0f;
-        if (same_binade(p, p1) && same_binade(p1, p2)) {
-            const float d1 = p1 - p, d2 = p2 - p1;     // exact: same exponent
-            if (d1 == d2) {
-                d = d1;
-                if (d1 == 0.0f) {
-                    len = n - i;                        // increment absorbed: constant from here on
-                } else {
-                    const uint32_t up = as_u32(p);
-                    const float ap = as_f32(up & 0x7fffffffu);                 // |p|
-                    const bool growing = ((up >> 31) != 0) == (d1 < 0.0f);     // |phase| increases
-                    float room;                                                // exact differences inside one binade
-                    if (growing) {
-                        float top = as_f32((up & 0x7fffffffu) | 0x007fffffu);  // largest value of the binade
-                        if (top > pi_max) top = pi_max;
-                        room = top - ap;
-                    } else {
-                        // stay strictly above 2^e: a sum that lands just below the binade is rounded
-                        // on the finer grid of the binade underneath, so exactly 2^e is not safe
-                        const float bottom = as_f32((up & 0x7f800000u) + 1u);   // 2^e + ulp
-                        room = ap - bottom;
-                    }
-                    // t = floor(room / |d|), both integers (< 2^24) times the binade's ulp
-                    int t = 0;
-                    if (room > 0.0f) {
-                        const uint32_t E = (up >> 23) & 0xffu;
-                        const int R = (int)grid_units(room, E);
-                        const int Q = (int)grid_units(fabsf(d1), E);           // >= 1
-                        t = (int)((float)R * approx_rcp((float)Q));             // within a few units of the floor
-                        int r = R - t * Q;                                      // |t*Q| < 2^26: no overflow
-                        while (r < 0) { --t; r += Q; }
-                        while (r >= Q) { ++t; r -= Q; }
-                    }
-                    const int lim = n - i - 1;
-                    if (t > lim) t = lim;
-                    len = t + 1;                       // positions t = 0 .. floor(room/|d|)
-                }
-            }
-        }
-        if (write) { seg[ns].start = i; seg[ns].base = p; seg[ns].step = d; }   // one lane stores on the GPU
+        const float d1 = p1 - p, d2 = p2 - p1;         // exact when the three share a binade
+        const uint32_t up = as_u32(p), u1 = as_u32(p1), u2 = as_u32(p2);
+        const uint32_t E = (up >> 23) & 0xffu;
+        // p, p1, p2 in one binade (same sign and exponent, normal) and equally spaced: from here the
+        // recurrence is the arithmetic progression p + t*d1 for as long as it stays in the binade
+        const bool reg = ((up ^ u1) < 0x00800000u) & ((u1 ^ u2) < 0x00800000u) & (E != 0u) & (E != 0xffu) & (d1 == d2);
+        const float ap = as_f32(up & 0x7fffffffu);                          // |p|
+        const bool growing = ((up >> 31) != 0) == (d1 < 0.0f);              // |phase| increases
+        float top = as_f32((up & 0x7fffffffu) | 0x007fffffu);               // largest value of the binade
+        top = (top > pi_max) ? pi_max : top;
+        // shrinking: stay strictly above 2^e — a sum that lands just below the binade is rounded on
+        // the finer grid of the binade underneath, so exactly 2^e is not safe
+        const float bottom = as_f32((up & 0x7f800000u) + 1u);               // 2^e + ulp
+        float room = growing ? (top - ap) : (ap - bottom);                  // exact differences inside one binade
+        room = (reg && room > 0.0f) ? room : 0.0f;
+        // t = floor(room / |d1|), both integers (< 2^24) times the binade's ulp
+        const int R = (int)grid_units(room, E);
+        int Q = (int)grid_units(as_f32(as_u32(d1) & 0x7fffffffu), E);
+        Q = (Q > 0) ? Q : 1;                                                // d1 == 0 or irregular: unused
+        const float rq = approx_rcp((float)Q);
+        int t = (int)((float)R * rq);                                       // within a few units of the floor
+        int r = R - t * Q;                                                  // |t*Q| < 2^26: no overflow
+        const int c = (int)((float)r * rq);                                 // |r| is a few Q at most
+        t += c;
+        r -= c * Q;                                                         // now within one Q of [0, Q)
+        if (r < 0) { --t; r += Q; }
+        if (r >= Q) { ++t; r -= Q; }
+        const int lim = n - i - 1;
+        t = (t > lim) ? lim : t;
+        int len = (d1 == 0.0f) ? (n - i) : (t + 1);                        // increment absorbed: constant from here on
+        len = reg ? len : 1;
+        const float d = reg ? d1 : 0.0f;
+        emit(ns, i, p, d);
         ++ns;
-        if (len == 1) {
-            p = p1;
-        } else {
-            const float last = p + (float)(len - 1) * d;    // exact: (len-1)*|d| <= room, result on the binade's grid
-            p = phase_step(last, inc);
-        }
+        // exact: (len-1)*|d| <= room and the sum lies on the binade's grid; len == 1 gives p1 again
+        p = phase_step(p + (float)(len - 1) * d, inc);
         i += len;
     }
     *covered = i;
     *p_next = p;
     return ns;
+}
+
+// Array form: seg[k] = {start, base, step}.
+UM_FN int phase_table_build(float p0, float inc, int n, PhaseSeg* seg, int cap, int* covered, float* p_next) {
+    return phase_table_walk(p0, inc, n, cap, covered, p_next, [seg](int k, int start, float base, float step) {
+        seg[k].start = start; seg[k].base = base; seg[k].step = step;
+    });
 }
 
 // phase at position i (seg = the segment with start <= i < next start); both operations are exact

@@ -14,10 +14,33 @@ def test_quick_subset_matches_libm(tmp_path):
     out = subprocess.run([str(exe), "quick"], capture_output=True, text=True, timeout=300)
     assert out.returncode == 0, out.stdout + out.stderr
     lines = dict(l.split()[0:1] + [l] for l in out.stdout.splitlines())
-    for fn in ("sinf", "cosf", "sincosf", "atanf", "atan2f", "hypotf"):
+    for fn in ("sinf", "cosf", "sincosf", "sincosf_bounded", "atanf", "atan2f", "hypotf"):
         assert "mismatches=0" in lines[fn], lines[fn]
 
 
 def test_exhaustive_record_is_clean():
     txt = (ROOT / "profiles" / "r01_pinned_math_exhaustive.txt").read_text()
-    assert txt.count("mismatches=0") == 6 and "checked=4294967296" in txt
+    assert txt.count("mismatches=0") == 7 and "checked=4294967296" in txt and "mismatches=0" in txt.splitlines()[-1]
+
+
+def test_phase_table_equals_serial_recurrence(tmp_path):
+    """phase_table.h (closed-form jumps of the float CFO phase recurrence of toBaseband,
+    channel_equalizer.cpp:43-50) against the serial recurrence, position by position: random starts and
+    increments, ties, +-pi wraps, zero crossings, denormals, small table capacities."""
+    exe = tmp_path / "ptc"
+    subprocess.check_call(["g++", "-O2", "-std=c++17", "-ffp-contract=off", "-pthread",
+                           str(ROOT / "tools" / "phase_table_check.cpp"), "-o", str(exe)])
+    out = subprocess.run([str(exe), "400000"], capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stdout + out.stderr
+    assert "mismatches=0" in out.stdout.splitlines()[0], out.stdout
+
+
+def test_ldpc_plan_is_conflict_free(tmp_path):
+    """The host-side LDPC execution plan (csrc/host_tables.h): every information edge has its own LDS
+    word and every half-wave access of both decoder steps touches 32 distinct banks, for all six rates."""
+    exe = tmp_path / "lpc"
+    subprocess.check_call(["g++", "-O1", "-std=c++17", "-I" + str(ROOT / "projectultra_amd" / "csrc"),
+                           str(ROOT / "tools" / "ldpc_plan_check.cpp"), "-o", str(exe)])
+    out = subprocess.run([str(exe)], capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stdout + out.stderr
+    assert out.stdout.count("conflicts 0") == 6, out.stdout
