@@ -49,6 +49,9 @@ namespace ultra_hip {
 namespace dev {
 
 constexpr int kLdpcThreads = 64;
+constexpr int kLdpcQueues = 8;        // work queues per launch
+constexpr int kLdpcQueueStride = 32;  // unsigned ints between their counters (128 B)
+constexpr int kLdpcQueueWords = kLdpcQueues * kLdpcQueueStride;
 constexpr float kFltMax = 3.402823466e+38f;
 
 __device__ __forceinline__ unsigned umin2(unsigned x, unsigned y) { return x < y ? x : y; }
@@ -76,8 +79,9 @@ __device__ __forceinline__ unsigned wave_xor(unsigned v) {
 // RR = ceil(m / 64) row rounds, VR = ceil(n_active / 64) variable rounds, DMAX = max variable degree,
 // ROWS_FULL = every row has 6 information edges (R3/4, R5/6).  The first P.var_rounds_full
 // variable rounds hold only variables of degree DMAX in all 64 lanes (no predicates).
-template <int RR, int VR, int DMAX, bool ROWS_FULL, bool WANT_TOTAL>
-__global__ __launch_bounds__(kLdpcThreads, 5) void ldpc_decode_kernel(
+// WAVES = resident wavefronts per SIMD the register budget is sized for (5 -> 96 VGPRs, 4 -> 128, 3 -> 168).
+template <int RR, int VR, int DMAX, bool ROWS_FULL, bool WANT_TOTAL, int WAVES>
+__global__ __launch_bounds__(kLdpcThreads, WAVES) void ldpc_decode_kernel(
     const LdpcPlan* __restrict__ Pp, const float* __restrict__ llr, size_t llr_stride, int n_cw,
     uint8_t* __restrict__ bytes, int32_t* __restrict__ iters, uint8_t* __restrict__ okv,
     float* __restrict__ llr_total, unsigned int* __restrict__ work_counter) {
@@ -117,11 +121,22 @@ __global__ __launch_bounds__(kLdpcThreads, 5) void ldpc_decode_kernel(
         for (int t = 0; t < DMAX; ++t) vaddr[r][t] = on ? P.act_addr[a * kLdpcPlanDmax + t] : 0;
     }
 
+    // Work queue: kLdpcQueues interleaved queues (queue q serves codewords q, q + Q, q + 2Q, ...), each
+    // with its own counter in its own cache line.  A single counter serialises in L2 at ~11.6 ns per
+    // atomic — 3.05 ms per 2^18 codewords, as long as the decoding itself (measured: a batch that
+    // converges at iteration 0 took as long as one at 20 iterations).  A wavefront starts on queue
+    // blockIdx % Q and moves on to the next one when its queue runs dry.  (Claiming several
+    // consecutive codewords per atomic was measured slower: 3.44 -> 3.59 ms at 4 per claim.)
+    int queue = (int)(blockIdx.x % kLdpcQueues), dry = 0;
     for (;;) {
-        int cw = 0;
-        if (lane == 0) cw = (int)atomicAdd(work_counter, 1u);
-        cw = __builtin_amdgcn_readfirstlane(cw);
-        if (cw >= n_cw) break;
+        int ticket = 0;
+        if (lane == 0) ticket = (int)atomicAdd(work_counter + queue * kLdpcQueueStride, 1u);
+        const int cw = __builtin_amdgcn_readfirstlane(ticket) * kLdpcQueues + queue;
+        if (cw >= n_cw) {
+            if (++dry == kLdpcQueues) break;
+            queue = (queue + 1) % kLdpcQueues;
+            continue;
+        }
         const float* in = llr + (size_t)cw * llr_stride;
 
         // ---- load: 648 LLRs once (coalesced), hard decisions of the raw channel values ----

@@ -131,28 +131,32 @@ int launch_ldpc(ultra_hip_ctx* ctx, const float* d_llr, size_t llr_stride, size_
     // launch uses its own counter word, zeroed on the stream just before the launch
     const LdpcPlan& P = ctx->h_plan;
     const size_t lds = dev::ldpc_lds_bytes(P.msg_words);
-    const size_t per_cu = std::max<size_t>(1, std::min<size_t>(20, (size_t)(160 * 1024) / lds));
-    const unsigned grid = (unsigned)std::min(n_cw, (size_t)ctx->cu_count * per_cu);
-    unsigned int* counter = ctx->d_work + (ctx->work_slot++ & 63);
-    UH_HIP(hipMemsetAsync(counter, 0, sizeof(unsigned int), ctx->stream));
-#define UH_LDPC_LAUNCH(RR, VR, DM, RF)                                                                              \
+    unsigned int* counter = ctx->d_work + (size_t)(ctx->work_slot++ & 15) * dev::kLdpcQueueWords;
+    UH_HIP(hipMemsetAsync(counter, 0, dev::kLdpcQueueWords * sizeof(unsigned int), ctx->stream));
+    // WV = wavefronts per SIMD the instance's registers are budgeted for; the grid is one resident set
+    // (bounded by LDS: one codeword's messages + staging per workgroup)
+#define UH_LDPC_LAUNCH(RR, VR, DM, RF, WV)                                                                          \
     do {                                                                                                        \
+        const size_t per_cu = std::max<size_t>(1, std::min<size_t>(4 * (WV), (size_t)(160 * 1024) / lds));      \
+        const unsigned grid = (unsigned)std::min(n_cw, (size_t)ctx->cu_count * per_cu);                         \
         if (d_llr_total)                                                                                        \
-            hipLaunchKernelGGL((dev::ldpc_decode_kernel<RR, VR, DM, RF, true>), dim3(grid),                      \
+            hipLaunchKernelGGL((dev::ldpc_decode_kernel<RR, VR, DM, RF, true, WV>), dim3(grid),                  \
                                dim3(dev::kLdpcThreads), lds, ctx->stream, ctx->d_plan, d_llr, llr_stride,        \
                                (int)n_cw, d_bytes, d_iters, d_ok, d_llr_total, counter);                         \
         else                                                                                                    \
-            hipLaunchKernelGGL((dev::ldpc_decode_kernel<RR, VR, DM, RF, false>), dim3(grid),                     \
+            hipLaunchKernelGGL((dev::ldpc_decode_kernel<RR, VR, DM, RF, false, WV>), dim3(grid),                 \
                                dim3(dev::kLdpcThreads), lds, ctx->stream, ctx->d_plan, d_llr, llr_stride,        \
                                (int)n_cw, d_bytes, d_iters, d_ok, d_llr_total, counter);                         \
     } while (0)
+    // Register budgets measured with tools/ldpc_bench.py (2^17 codewords, ~50 iterations): the wider
+    // instances spill at 96 VGPRs (R1/2: 38.1 -> 10.5 ms at 4 waves per SIMD; R1/4: 68.2 -> 14.3 ms at 3)
     auto fits = [&](int rr, int vr, int dm) { return P.row_rounds <= rr && P.var_rounds <= vr && P.dmax <= dm; };
     const bool rf = P.rows_full != 0;
-    if (rf && fits(2, 4, 3)) UH_LDPC_LAUNCH(2, 4, 3, true);            // R5/6
-    else if (rf && fits(3, 6, 3)) UH_LDPC_LAUNCH(3, 6, 3, true);       // R3/4
-    else if (fits(4, 7, 3)) UH_LDPC_LAUNCH(4, 7, 3, false);            // R2/3
-    else if (fits(6, 6, 6)) UH_LDPC_LAUNCH(6, 6, 6, false);            // R1/2, R1/3
-    else if (fits(8, 3, 14)) UH_LDPC_LAUNCH(8, 3, 14, false);          // R1/4
+    if (rf && fits(2, 4, 3)) UH_LDPC_LAUNCH(2, 4, 3, true, 5);          // R5/6
+    else if (rf && fits(3, 6, 3)) UH_LDPC_LAUNCH(3, 6, 3, true, 5);     // R3/4
+    else if (fits(4, 7, 3)) UH_LDPC_LAUNCH(4, 7, 3, false, 4);          // R2/3
+    else if (fits(6, 6, 6)) UH_LDPC_LAUNCH(6, 6, 6, false, 4);          // R1/2, R1/3
+    else if (fits(8, 3, 14)) UH_LDPC_LAUNCH(8, 3, 14, false, 3);        // R1/4
     else return ULTRA_HIP_ERR_UNSUPPORTED;
 #undef UH_LDPC_LAUNCH
     UH_HIP(hipGetLastError());
@@ -228,7 +232,7 @@ int ultra_hip_create(const ultra_hip_config* cfg, int device, void* stream, ultr
     auto fail = [&](int code) { ultra_hip_destroy(ctx); return code; };
     if (hipMalloc(&ctx->d_demod, sizeof(DemodConst)) != hipSuccess) return fail(ULTRA_HIP_ERR_OOM);
     if (hipMalloc(&ctx->d_plan, sizeof(LdpcPlan)) != hipSuccess) return fail(ULTRA_HIP_ERR_OOM);
-    if (hipMalloc(&ctx->d_work, 64 * sizeof(unsigned int)) != hipSuccess) return fail(ULTRA_HIP_ERR_OOM);
+    if (hipMalloc(&ctx->d_work, 16 * dev::kLdpcQueueWords * sizeof(unsigned int)) != hipSuccess) return fail(ULTRA_HIP_ERR_OOM);
     if (hipMalloc(&ctx->d_nco, nco.size() * sizeof(c32)) != hipSuccess) return fail(ULTRA_HIP_ERR_OOM);
     if (hipMalloc(&ctx->d_twiddle, tw.size() * sizeof(c32)) != hipSuccess) return fail(ULTRA_HIP_ERR_OOM);
     if (hipMemcpy(ctx->d_demod, &ctx->h_demod, sizeof(DemodConst), hipMemcpyHostToDevice) != hipSuccess ||
