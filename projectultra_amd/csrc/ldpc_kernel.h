@@ -127,22 +127,33 @@ __global__ __launch_bounds__(kLdpcThreads, WAVES) void ldpc_decode_kernel(
     // converges at iteration 0 took as long as one at 20 iterations).  A wavefront starts on queue
     // blockIdx % Q and moves on to the next one when its queue runs dry.  (Claiming several
     // consecutive codewords per atomic was measured slower: 3.44 -> 3.59 ms at 4 per claim.)
+    // The next codeword is claimed and its LLRs are fetched (asynchronously, straight into the LDS
+    // staging area, which is idle once the messages are initialised) while the current one is being
+    // decoded, so neither the atomic's round trip nor the HBM latency is paid per codeword.
     int queue = (int)(blockIdx.x % kLdpcQueues), dry = 0;
-    for (;;) {
-        int ticket = 0;
-        if (lane == 0) ticket = (int)atomicAdd(work_counter + queue * kLdpcQueueStride, 1u);
-        const int cw = __builtin_amdgcn_readfirstlane(ticket) * kLdpcQueues + queue;
-        if (cw >= n_cw) {
-            if (++dry == kLdpcQueues) break;
+    auto claim = [&]() -> int {                           // next codeword of this wavefront, -1 when all queues are dry
+        for (;;) {
+            int ticket = 0;
+            if (lane == 0) ticket = (int)atomicAdd(work_counter + queue * kLdpcQueueStride, 1u);
+            const int c = __builtin_amdgcn_readfirstlane(ticket) * kLdpcQueues + queue;
+            if (c < n_cw) return c;
+            if (++dry == kLdpcQueues) return -1;
             queue = (queue + 1) % kLdpcQueues;
-            continue;
         }
-        const float* in = llr + (size_t)cw * llr_stride;
-
-        // ---- load: 648 LLRs once (coalesced), hard decisions of the raw channel values ----
+    };
+    auto fetch = [&](int c) {                             // 648 floats -> llr_s, 64 per instruction
+        const float* src = llr + (size_t)c * llr_stride;
+        for (int j0 = 0; j0 < n; j0 += kLdpcThreads)
+            if (j0 + lane < n) __builtin_amdgcn_global_load_lds(src + j0 + lane, llr_s + j0, 4, 0, 0);
+    };
+    int cw = claim();
+    if (cw >= 0) fetch(cw);
+    while (cw >= 0) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // staged LLRs have landed
+        __syncthreads();
+        // ---- hard decisions of the raw channel values (decided bits of unchecked variables) ----
         for (int j = lane; j < n; j += kLdpcThreads) {
-            const float v = in[j];
-            llr_s[j] = v;
+            const float v = llr_s[j];
             hard[j] = (v < 0) ? 1 : 0;
             if (WANT_TOTAL) llr_total[(size_t)cw * kLdpcN + j] = v;
         }
@@ -164,6 +175,8 @@ __global__ __launch_bounds__(kLdpcThreads, WAVES) void ldpc_decode_kernel(
             hpar[r] = false;
         }
         __syncthreads();
+        const int cw_next = claim();                       // llr_s is free from here on
+        if (cw_next >= 0) fetch(cw_next);
 
         int it = 0, ok = 0;
         unsigned F = 1u;                                                       // syndrome filter of iteration it-1
@@ -313,7 +326,7 @@ __global__ __launch_bounds__(kLdpcThreads, WAVES) void ldpc_decode_kernel(
             ob[b] = (uint8_t)v;
         }
         if (lane == 0) { iters[cw] = iters_out; okv[cw] = (uint8_t)ok; }
-        __syncthreads();
+        cw = cw_next;
     }
 }
 
