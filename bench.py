@@ -121,63 +121,69 @@ def main():
         step()
     barrier()
     elapsed = time.perf_counter() - t0
+    # The same K steps once more (all ranks: the step holds the collective) with, on rank 0, every
+    # kernel launch bracketed by HIP events on the launch stream (ultra_hip_profile_enable): per-kernel
+    # durations for the roofline object.  Kept out of the timed region because the ~22 event records
+    # per step cost ~1.7 % of a step.
+    prof = None
+    if rank == 0:
+        ctx.profile_read()
+        ctx.profile_enable(True)
+    for _ in range(args.steps):
+        step()
+    barrier()
+    if rank == 0:
+        ctx.profile_enable(False)
+        prof = ctx.profile_read()
     t_max = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
     if world > 1:
         dist.all_reduce(t_max, op=dist.ReduceOp.MAX)
     elapsed = float(t_max.item())
     stats = counters_dict(counters.cpu())
 
-    # ---- per-stage time with HIP events on the launch stream (rank 0) --------------------------
-    # demod stage = init_state + 4 x (mix_fft_kernel + track_kernel) launches; LDPC = one launch
-    roofline, kernels = None, {}
+    # ---- roofline of the dominant kernel (largest share of the step), rank 0 ------------------
+    # Algorithmic bytes per launch = SURVEY.md 8(d)'s per-frame figure (20,581 B = 4 x 4480 audio + 4
+    # + 4 x 648 LLR + 61 + 4) apportioned to the launch that moves them, x the frames of one launch:
+    #   mix_fft_kernel  one OFDM symbol of audio in            4480 B/frame/launch
+    #   track_kernel    that symbol's share of the 648 LLRs     648 B/frame/launch
+    #   ldpc_decode     648 LLRs in, 61 bytes + iters + ok out 2658 B/frame/launch
+    roofline = None
     if rank == 0:
-        reps_k = max(3, min(args.steps, 10))
-        llr = torch.empty((n_frames, geo.llrs_per_frame), dtype=torch.float32, device="cuda")
-        ctx.demod(d_audio)                                   # warm
-        torch.cuda.synchronize()
-        ctx.timer_begin()
-        for _ in range(reps_k):
-            rc = ctx.lib.ultra_hip_demod_batch(ctx._ctx, d_audio.data_ptr(), d_audio.stride(0), None, None,
-                                               n_frames, llr.data_ptr(), None)
-            assert rc == 0
-        ms_demod = ctx.timer_end() / reps_k
-        llr648 = llr[:, :648].contiguous()
-        ctx.ldpc_decode(llr648)
-        torch.cuda.synchronize()
-        ctx.timer_begin()
-        for _ in range(reps_k):
-            ctx.ldpc_decode(llr648)
-        ms_ldpc = ctx.timer_end() / reps_k
-        del llr, llr648
-        kernels = {
-            "demod_stage(init+4x(mix_fft_kernel+track_kernel))": {
-                "ms": ms_demod, "algorithmic_bytes": n_frames * BYTES_PER_FRAME_DEMOD,
-                "GBps": n_frames * BYTES_PER_FRAME_DEMOD / (ms_demod * 1e-3) / 1e9},
-            "ldpc_decode_kernel": {"ms": ms_ldpc, "algorithmic_bytes": n_frames * BYTES_PER_CW_LDPC,
-                                   "GBps": n_frames * BYTES_PER_CW_LDPC / (ms_ldpc * 1e-3) / 1e9},
-        }
-        # the single longest launch of a step is the LDPC kernel (the demod stage is 9 shorter launches)
-        dom = "ldpc_decode_kernel"
-        traffic = None
+        per_launch = {"mix_fft_kernel": geo.symbol_samples * 4, "track_kernel": 648,
+                      "ldpc_decode_kernel": BYTES_PER_CW_LDPC}
+        traffic_all = {}
         tf = ROOT / "profiles" / "traffic.json"              # PMC-derived HBM bytes per launch, if collected
         if tf.exists():
             try:
                 t = json.loads(tf.read_text())
-                if t.get("n_frames") == n_frames and dom in t.get("kernels", {}):
-                    traffic = t["kernels"][dom]["hbm_bytes_per_launch"]
+                if t.get("n_frames") == n_frames:
+                    traffic_all = {k: v["hbm_bytes_per_launch"] for k, v in t.get("kernels", {}).items()}
             except Exception:
-                traffic = None
-        ach = kernels[dom]["GBps"]
-        roofline = {"bound": "hbm", "kernel": dom, "achieved": ach, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-                    "frac": ach / HBM_PEAK_GBPS, "traffic": traffic,
-                    "launch_ms": kernels[dom]["ms"], "algorithmic_bytes_per_launch": kernels[dom]["algorithmic_bytes"],
-                    "stages": kernels,
+                traffic_all = {}
+        kernels = {}
+        for name, (ms_total, launches) in prof.items():
+            if launches == 0 or name not in per_launch:
+                continue
+            avg = ms_total / launches
+            alg = n_frames * per_launch[name]
+            kernels[name] = {"avg_launch_ms": avg, "launches_per_step": launches / args.steps,
+                             "ms_per_step": ms_total / args.steps, "algorithmic_bytes_per_launch": alg,
+                             "GBps": alg / (avg * 1e-3) / 1e9, "frac": alg / (avg * 1e-3) / 1e9 / HBM_PEAK_GBPS,
+                             "traffic": traffic_all.get(name)}
+        dom = max(kernels, key=lambda k: kernels[k]["ms_per_step"])
+        roofline = {"bound": "hbm", "kernel": dom, "achieved": kernels[dom]["GBps"], "peak": HBM_PEAK_GBPS,
+                    "unit": "GB/s", "frac": kernels[dom]["frac"], "traffic": kernels[dom]["traffic"],
+                    "launch_ms": kernels[dom]["avg_launch_ms"],
+                    "algorithmic_bytes_per_launch": kernels[dom]["algorithmic_bytes_per_launch"],
+                    "kernels": kernels,
                     "path_GBps": n_frames * BYTES_PER_FRAME_FUSED * args.steps / elapsed / 1e9,
-                    "note": "path_GBps = frames/s x 20,581 B (SURVEY 8d) for one GPU. At this operating point the "
-                            "reference decodes only ~11 % of the frames (R3/4 leaves 161 info bits unchecked, the "
-                            "static two-tap channel nulls 1 kHz), so most codewords run all 50 BP iterations and the "
-                            "LDPC kernel is LDS/VALU-bound (LDS pipe ~55 % busy, conflict-free), not HBM-bound; the "
-                            "demod stage moves 20,740 B/frame"}
+                    "note": "achieved = algorithmic bytes per launch / mean launch duration (HIP events around every "
+                            "launch of a repeat of the timed steps). The path is not HBM-bound at this operating point: mix_fft is "
+                            "latency/VALU-bound (double-precision sincos of the CFO rotation, 1024-point FFT through "
+                            "LDS), and the reference decodes only ~11 % of these frames (R3/4 leaves 161 info bits "
+                            "unchecked, the two-tap channel nulls 1 kHz), so most codewords run all 50 BP iterations "
+                            "and ldpc_decode_kernel is LDS-bound (~216 LDS cycles per codeword-iteration, "
+                            "conflict-free). path_GBps = frames/s x 20,581 B (SURVEY 8d) for one GPU"}
 
     # ---- CPU baseline: the oracle on the host cores, bounded sample (rank 0, N=1 only) ----------
     cpu = None

@@ -247,6 +247,21 @@ int ultra_hip_synchronize(ultra_hip_ctx* ctx);
 int ultra_hip_timer_begin(ultra_hip_ctx* ctx);
 int ultra_hip_timer_end(ultra_hip_ctx* ctx, float* ms);
 
+/* Per-kernel timing (diagnostics; bench.py's roofline object uses it): while enabled, every kernel
+ * launch of this context is bracketed by a pair of HIP events on the context's stream.  read()
+ * waits for the recorded launches, adds their elapsed milliseconds and launch counts per kernel
+ * class into ms[] / launches[] (ULTRA_HIP_K_N entries each, overwritten) and forgets them. */
+enum ultra_hip_kernel_class {
+    ULTRA_HIP_K_INIT_STATE = 0, /* init_state_kernel */
+    ULTRA_HIP_K_MIX_FFT = 1,    /* mix_fft_kernel: toBaseband + FFT, one launch per OFDM symbol */
+    ULTRA_HIP_K_TRACK = 2,      /* track_kernel: channel tracking + equalize + demap, one per symbol */
+    ULTRA_HIP_K_LDPC = 3,       /* ldpc_decode_kernel */
+    ULTRA_HIP_K_COUNT = 4,      /* count_errors_kernel */
+    ULTRA_HIP_K_N = 5
+};
+int ultra_hip_profile_enable(ultra_hip_ctx* ctx, int enable);
+int ultra_hip_profile_read(ultra_hip_ctx* ctx, float* ms, uint32_t* launches);
+
 /* Convenience for hosts without their own device allocator (the C++ adapter
  * and the ctypes tests): hipMalloc/hipFree/hipMemcpy on the context's device. */
 int ultra_hip_malloc(ultra_hip_ctx* ctx, size_t bytes, void** d_ptr);

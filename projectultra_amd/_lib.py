@@ -67,6 +67,8 @@ PROTOTYPES = {
     "ultra_hip_synchronize": (_i, [_vp]),
     "ultra_hip_timer_begin": (_i, [_vp]),
     "ultra_hip_timer_end": (_i, [_vp, C.POINTER(C.c_float)]),
+    "ultra_hip_profile_enable": (_i, [_vp, _i]),
+    "ultra_hip_profile_read": (_i, [_vp, C.POINTER(C.c_float), C.POINTER(C.c_uint32)]),
     "ultra_hip_malloc": (_i, [_vp, _sz, C.POINTER(_vp)]),
     "ultra_hip_free": (_i, [_vp, _vp]),
     "ultra_hip_memcpy_h2d": (_i, [_vp, _vp, _vp, _sz]),

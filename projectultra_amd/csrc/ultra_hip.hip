@@ -43,6 +43,11 @@ struct ultra_hip_ctx {
     size_t ws_demod_frames = 0;
     hipEvent_t ev_begin = nullptr, ev_end = nullptr;
     int cu_count = 256;
+    // per-kernel profiling (ultra_hip_profile_*): recorded (class, start, stop) triples + spare events
+    bool profiling = false;
+    struct Span { int kind; hipEvent_t e0, e1; };
+    std::vector<Span> spans;
+    std::vector<hipEvent_t> spare_events;
 };
 
 namespace {
@@ -56,6 +61,29 @@ namespace {
             return (e_ == hipErrorOutOfMemory) ? ULTRA_HIP_ERR_OOM : ULTRA_HIP_ERR_HIP;        \
         }                                                                                     \
     } while (0)
+
+// brackets one kernel launch with events when the context is profiling
+struct LaunchSpan {
+    ultra_hip_ctx* ctx;
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    int kind;
+    static hipEvent_t take(ultra_hip_ctx* c) {
+        hipEvent_t e = nullptr;
+        if (!c->spare_events.empty()) { e = c->spare_events.back(); c->spare_events.pop_back(); }
+        else if (hipEventCreate(&e) != hipSuccess) e = nullptr;
+        return e;
+    }
+    LaunchSpan(ultra_hip_ctx* c, int k) : ctx(c), kind(k) {
+        if (!ctx->profiling) return;
+        e0 = take(ctx); e1 = take(ctx);
+        if (e0) (void)hipEventRecord(e0, ctx->stream);
+    }
+    ~LaunchSpan() {
+        if (!ctx->profiling || !e0 || !e1) return;
+        (void)hipEventRecord(e1, ctx->stream);
+        ctx->spans.push_back({kind, e0, e1});
+    }
+};
 
 struct DeviceGuard {
     int prev = -1;
@@ -88,24 +116,32 @@ int launch_demod(ultra_hip_ctx* ctx, const float* d_audio, size_t frame_stride, 
     const unsigned grid_fft = (unsigned)std::min(n_frames, (size_t)ctx->cu_count * 384);
     const unsigned grid_trk = (unsigned)std::min(n_frames, (size_t)ctx->cu_count * 128);
     hipStream_t st = ctx->stream;
-    hipLaunchKernelGGL(dev::init_state_kernel, dim3(grid_trk), dim3(dev::kWave), 0, st, d_cfo_hz, d_cfo_phase,
-                       (int)n_frames, ctx->d_ws_state);
+    {
+        LaunchSpan span(ctx, ULTRA_HIP_K_INIT_STATE);
+        hipLaunchKernelGGL(dev::init_state_kernel, dim3(grid_trk), dim3(dev::kWave), 0, st, d_cfo_hz, d_cfo_phase,
+                           (int)n_frames, ctx->d_ws_state);
+    }
     const int n_sym = D.n_train + D.n_data_sym;
     for (int s = 0; s < n_sym; ++s) {
-        if (D.log2_fft == 10)
-            hipLaunchKernelGGL(dev::mix_fft_kernel<10>, dim3(grid_fft), dim3(dev::kWave), 0, st, ctx->d_demod, ctx->d_nco,
-                               ctx->d_twiddle, d_audio, frame_stride, (int)n_frames, s, ctx->d_ws_state, ctx->d_ws_fq);
-        else if (D.log2_fft == 9)
-            hipLaunchKernelGGL(dev::mix_fft_kernel<9>, dim3(grid_fft), dim3(dev::kWave), 0, st, ctx->d_demod, ctx->d_nco,
-                               ctx->d_twiddle, d_audio, frame_stride, (int)n_frames, s, ctx->d_ws_state, ctx->d_ws_fq);
-        else
-            return ULTRA_HIP_ERR_UNSUPPORTED;
+        if (D.log2_fft != 10 && D.log2_fft != 9) return ULTRA_HIP_ERR_UNSUPPORTED;
+        {
+            LaunchSpan span(ctx, ULTRA_HIP_K_MIX_FFT);
+            if (D.log2_fft == 10)
+                hipLaunchKernelGGL(dev::mix_fft_kernel<10>, dim3(grid_fft), dim3(dev::kWave), 0, st, ctx->d_demod,
+                                   ctx->d_nco, ctx->d_twiddle, d_audio, frame_stride, (int)n_frames, s, ctx->d_ws_state,
+                                   ctx->d_ws_fq);
+            else
+                hipLaunchKernelGGL(dev::mix_fft_kernel<9>, dim3(grid_fft), dim3(dev::kWave), 0, st, ctx->d_demod,
+                                   ctx->d_nco, ctx->d_twiddle, d_audio, frame_stride, (int)n_frames, s, ctx->d_ws_state,
+                                   ctx->d_ws_fq);
+        }
         const bool training = s < D.n_train;
         const bool last = (s == n_sym - 1);
 #define UH_TRACK(MOD)                                                                                            \
     hipLaunchKernelGGL(dev::track_kernel<MOD>, dim3(grid_trk), dim3(dev::kWave), 0, st, ctx->d_demod, (int)n_frames,  \
                        training ? 1 : 0, s, training ? 0 : s - D.n_train, ctx->d_ws_state, ctx->d_ws_fq, d_llr,       \
                        llr_stride, last ? d_state : nullptr)
+        LaunchSpan span(ctx, ULTRA_HIP_K_TRACK);
         switch (D.modulation) {
             case ULTRA_MOD_DBPSK: UH_TRACK(ULTRA_MOD_DBPSK); break;
             case ULTRA_MOD_BPSK: UH_TRACK(ULTRA_MOD_BPSK); break;
@@ -137,6 +173,7 @@ int launch_ldpc(ultra_hip_ctx* ctx, const float* d_llr, size_t llr_stride, size_
     // (bounded by LDS: one codeword's messages + staging per workgroup)
 #define UH_LDPC_LAUNCH(RR, VR, DM, RF, WV)                                                                          \
     do {                                                                                                        \
+        LaunchSpan span(ctx, ULTRA_HIP_K_LDPC);                                                                 \
         const size_t per_cu = std::max<size_t>(1, std::min<size_t>(4 * (WV), (size_t)(160 * 1024) / lds));      \
         const unsigned grid = (unsigned)std::min(n_cw, (size_t)ctx->cu_count * per_cu);                         \
         if (d_llr_total)                                                                                        \
@@ -252,6 +289,8 @@ void ultra_hip_destroy(ultra_hip_ctx* ctx) {
     if (ctx->d_demod) (void)hipFree(ctx->d_demod);
     if (ctx->d_plan) (void)hipFree(ctx->d_plan);
     if (ctx->d_work) (void)hipFree(ctx->d_work);
+    for (auto& sp : ctx->spans) { (void)hipEventDestroy(sp.e0); (void)hipEventDestroy(sp.e1); }
+    for (auto e : ctx->spare_events) (void)hipEventDestroy(e);
     if (ctx->d_nco) (void)hipFree(ctx->d_nco);
     if (ctx->d_twiddle) (void)hipFree(ctx->d_twiddle);
     if (ctx->d_ws_llr) (void)hipFree(ctx->d_ws_llr);
@@ -332,10 +371,33 @@ int ultra_hip_count_errors(ultra_hip_ctx* ctx, const uint8_t* d_bytes, const int
         return ULTRA_HIP_ERR_INVALID_ARG;
     DeviceGuard guard(ctx->device);
     const unsigned grid = (unsigned)std::min<size_t>((n_frames + 255) / 256, (size_t)ctx->cu_count * 8);
+    LaunchSpan span(ctx, ULTRA_HIP_K_COUNT);
     hipLaunchKernelGGL(dev::count_errors_kernel, dim3(grid), dim3(256), 0, ctx->stream, d_bytes,
                        (size_t)ctx->geo.decoded_bytes, d_iters, d_ok, d_payload, (int)payload_bytes, (int)n_frames,
                        reinterpret_cast<unsigned long long*>(d_counters));
     UH_HIP(hipGetLastError());
+    return ULTRA_HIP_OK;
+}
+
+int ultra_hip_profile_enable(ultra_hip_ctx* ctx, int enable) {
+    if (!ctx) return ULTRA_HIP_ERR_INVALID_ARG;
+    ctx->profiling = enable != 0;
+    return ULTRA_HIP_OK;
+}
+
+int ultra_hip_profile_read(ultra_hip_ctx* ctx, float* ms, uint32_t* launches) {
+    if (!ctx || !ms || !launches) return ULTRA_HIP_ERR_INVALID_ARG;
+    DeviceGuard guard(ctx->device);
+    for (int k = 0; k < ULTRA_HIP_K_N; ++k) { ms[k] = 0.0f; launches[k] = 0; }
+    for (const auto& sp : ctx->spans) {
+        float t = 0.0f;
+        UH_HIP(hipEventSynchronize(sp.e1));
+        UH_HIP(hipEventElapsedTime(&t, sp.e0, sp.e1));
+        if (sp.kind >= 0 && sp.kind < ULTRA_HIP_K_N) { ms[sp.kind] += t; launches[sp.kind]++; }
+        ctx->spare_events.push_back(sp.e0);
+        ctx->spare_events.push_back(sp.e1);
+    }
+    ctx->spans.clear();
     return ULTRA_HIP_OK;
 }
 

@@ -183,6 +183,19 @@ class ReceiveContext:
             out["llr"] = llr
         return out
 
+    KERNEL_CLASSES = ("init_state_kernel", "mix_fft_kernel", "track_kernel", "ldpc_decode_kernel", "count_errors_kernel")
+
+    def profile_enable(self, on: bool = True):
+        """Bracket every kernel launch of this context with HIP events (ultra_hip_profile_enable)."""
+        check(self.lib.ultra_hip_profile_enable(self._ctx, 1 if on else 0), "ultra_hip_profile_enable")
+
+    def profile_read(self):
+        """{kernel class: (total ms, launches)} of the launches recorded since the last read."""
+        ms = (C.c_float * len(self.KERNEL_CLASSES))()
+        cnt = (C.c_uint32 * len(self.KERNEL_CLASSES))()
+        check(self.lib.ultra_hip_profile_read(self._ctx, ms, cnt), "ultra_hip_profile_read")
+        return {k: (float(ms[i]), int(cnt[i])) for i, k in enumerate(self.KERNEL_CLASSES)}
+
     def count_errors(self, result, payload, counters=None):
         """Accumulate the Monte-Carlo counters (device int64[8]) for a decoded batch."""
         torch = _torch()
