@@ -33,7 +33,7 @@
 extern "C" {
 #endif
 
-#define ULTRA_HIP_ABI_VERSION 1
+#define ULTRA_HIP_ABI_VERSION 2
 
 /* ultra::Modulation (include/ultra/types.hpp:27-39) — same numeric values. */
 enum ultra_hip_modulation {
@@ -246,6 +246,18 @@ int ultra_hip_synchronize(ultra_hip_ctx* ctx);
  * and returns the elapsed milliseconds in *ms. */
 int ultra_hip_timer_begin(ultra_hip_ctx* ctx);
 int ultra_hip_timer_end(ultra_hip_ctx* ctx, float* ms);
+
+/* Channel deinterleaver of the production receive path, fused into the decoder's LLR load.
+ * Replaces RxPipeline::setInterleaverConfig(bits_per_symbol) + deinterleaveCodewords
+ * (src/gui/modem/rx_pipeline.cpp:24-31,475-491): every 648-LLR codeword handed to
+ * ultra_hip_ldpc_decode_batch / ultra_hip_demod_decode_batch is first passed through
+ * ChannelInterleaver(bits_per_symbol, 648)::deinterleave (src/fec/ldpc_decoder.cpp:575-617),
+ * out[j] = in[(j * step) % 648].  bits_per_symbol = 0 switches it off (the default; the
+ * Monte-Carlo harnesses of SURVEY.md 3.1 do not interleave).  The LLRs returned by
+ * ultra_hip_demod_batch / the llr output of the fused call stay in channel order.
+ * The legacy Modem's Interleaver(32,32) (src/modem/modem.cpp:116,161) reads past the 648 soft
+ * bits it is given and is not reproduced. */
+int ultra_hip_set_deinterleave(ultra_hip_ctx* ctx, uint32_t bits_per_symbol);
 
 /* Per-kernel timing (diagnostics; bench.py's roofline object uses it): while enabled, every kernel
  * launch of this context is bracketed by a pair of HIP events on the context's stream.  read()

@@ -137,6 +137,13 @@ public:
         for (size_t i = 0; i < bits.size(); ++i) if (bits[i]) out[i / 8] |= uint8_t(1u << (7 - i % 8));
         return out;
     }
+    // RxPipeline::setInterleaverConfig + deinterleaveCodewords (src/gui/modem/rx_pipeline.cpp:24-31,475-491):
+    // every codeword goes through ChannelInterleaver(bits_per_symbol, 648)::deinterleave before it is
+    // decoded — on the GPU, fused into the decoder's LLR load.  0 switches it off.
+    void setDeinterleave(size_t bits_per_symbol) {
+        deinterleave_ = (uint32_t)bits_per_symbol;
+        detail::check(ultra_hip_set_deinterleave(ctx_.p, deinterleave_), "ultra_hip_set_deinterleave");
+    }
     Bytes decode(std::span<const uint8_t> coded) {                     // ldpc_decoder.cpp:267-281
         std::vector<float> llrs; llrs.reserve(coded.size() * 8);
         for (uint8_t byte : coded) for (int b = 7; b >= 0; --b) llrs.push_back(((byte >> b) & 1) ? -6.0f : 6.0f);
@@ -165,8 +172,10 @@ private:
     void rebuild() {
         ModemConfig c; c.code_rate = rate_;
         ctx_ = detail::Ctx(to_c_config(c, ULTRA_ENTRY_SYNCED, 44, 0, static_cast<uint32_t>(max_iter_)), device_);
+        if (deinterleave_) detail::check(ultra_hip_set_deinterleave(ctx_.p, deinterleave_), "ultra_hip_set_deinterleave");
     }
     CodeRate rate_; int device_; int max_iter_ = 50; bool last_success_ = false; int last_iters_ = 0;
+    uint32_t deinterleave_ = 0;
     detail::Ctx ctx_;
 };
 

@@ -11,7 +11,7 @@ from ._lib import UltraHipError, build
 
 __all__ = ["CodeRate", "CyclicPrefixMode", "Entry", "LDPC_BLOCK_SIZE", "ModemConfig", "Modulation", "presets",
            "getBitsPerSymbol", "getCodeRateValue", "info_bits", "is_differential", "UltraHipError", "build",
-           "ReceiveContext", "LDPCDecoder", "OFDMDemodulator", "HipOfdmWaveform", "SyncResult"]
+           "ReceiveContext", "LDPCDecoder", "ChannelInterleaver", "OFDMDemodulator", "HipOfdmWaveform", "SyncResult"]
 
 
 def __getattr__(name):
@@ -20,9 +20,9 @@ def __getattr__(name):
     if name == "ReceiveContext":
         from .engine import ReceiveContext
         return ReceiveContext
-    if name == "LDPCDecoder":
-        from .fec import LDPCDecoder
-        return LDPCDecoder
+    if name in ("LDPCDecoder", "ChannelInterleaver"):
+        from . import fec
+        return getattr(fec, name)
     if name == "OFDMDemodulator":
         from .ofdm import OFDMDemodulator
         return OFDMDemodulator

@@ -14,7 +14,7 @@ PKG_DIR = Path(__file__).resolve().parent
 LIB_PATH = PKG_DIR / "libultra_hip.so"
 CSRC_DIR = PKG_DIR / "csrc"
 
-ULTRA_HIP_ABI_VERSION = 1
+ULTRA_HIP_ABI_VERSION = 2
 STATE_FLOATS = 8
 
 
@@ -67,6 +67,7 @@ PROTOTYPES = {
     "ultra_hip_synchronize": (_i, [_vp]),
     "ultra_hip_timer_begin": (_i, [_vp]),
     "ultra_hip_timer_end": (_i, [_vp, C.POINTER(C.c_float)]),
+    "ultra_hip_set_deinterleave": (_i, [_vp, C.c_uint32]),
     "ultra_hip_profile_enable": (_i, [_vp, _i]),
     "ultra_hip_profile_read": (_i, [_vp, C.POINTER(C.c_float), C.POINTER(C.c_uint32)]),
     "ultra_hip_malloc": (_i, [_vp, _sz, C.POINTER(_vp)]),

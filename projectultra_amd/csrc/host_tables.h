@@ -197,6 +197,19 @@ inline void bipartite_edge_colouring(int n_left, int n_right, const std::vector<
 }
 
 // Execution plan for the kernel, derived from the CSR graph.
+// ChannelInterleaver (src/fec/ldpc_decoder.cpp:547-596): permutation[i] = (i * step) % total with the
+// step chosen by findCoprimeStep(bits_per_symbol, total) (:549-573); deinterleave writes
+// out[inverse_permutation[i]] = in[i], i.e. out[j] = in[(j * step) % total].
+inline uint32_t channel_interleaver_step(uint32_t bits_per_symbol, uint32_t total) {
+    auto gcd = [](size_t a, size_t b) { while (b != 0) { const size_t t = b; b = a % b; a = t; } return a; };
+    const size_t n = bits_per_symbol, tot = total;
+    size_t target = n * 3;
+    if (target >= tot) target = tot / 2;
+    for (size_t step = target; step < tot; ++step) if (gcd(step, tot) == 1) return (uint32_t)step;
+    for (size_t step = n + 1; step < tot; ++step) if (gcd(step, tot) == 1) return (uint32_t)step;
+    return (uint32_t)(n + 1);
+}
+
 inline int build_ldpc_plan(const LdpcConst& L, LdpcPlan& P) {
     P = LdpcPlan{};
     P.k = L.k; P.m = L.m; P.n = L.n; P.edges = L.edges; P.max_iterations = L.max_iterations;

@@ -44,6 +44,7 @@ struct ultra_hip_ctx {
     hipEvent_t ev_begin = nullptr, ev_end = nullptr;
     int cu_count = 256;
     // per-kernel profiling (ultra_hip_profile_*): recorded (class, start, stop) triples + spare events
+    uint32_t deint_step = 1;             // ChannelInterleaver step fused into the LDPC LLR load (1 = off)
     bool profiling = false;
     struct Span { int kind; hipEvent_t e0, e1; };
     std::vector<Span> spans;
@@ -179,11 +180,11 @@ int launch_ldpc(ultra_hip_ctx* ctx, const float* d_llr, size_t llr_stride, size_
         if (d_llr_total)                                                                                        \
             hipLaunchKernelGGL((dev::ldpc_decode_kernel<RR, VR, DM, RF, true, WV>), dim3(grid),                  \
                                dim3(dev::kLdpcThreads), lds, ctx->stream, ctx->d_plan, d_llr, llr_stride,        \
-                               (int)n_cw, d_bytes, d_iters, d_ok, d_llr_total, counter);                         \
+                               (int)n_cw, d_bytes, d_iters, d_ok, d_llr_total, counter, (int)ctx->deint_step);                         \
         else                                                                                                    \
             hipLaunchKernelGGL((dev::ldpc_decode_kernel<RR, VR, DM, RF, false, WV>), dim3(grid),                 \
                                dim3(dev::kLdpcThreads), lds, ctx->stream, ctx->d_plan, d_llr, llr_stride,        \
-                               (int)n_cw, d_bytes, d_iters, d_ok, d_llr_total, counter);                         \
+                               (int)n_cw, d_bytes, d_iters, d_ok, d_llr_total, counter, (int)ctx->deint_step);                         \
     } while (0)
     // Register budgets measured with tools/ldpc_bench.py (2^17 codewords, ~50 iterations): the wider
     // instances spill at 96 VGPRs (R1/2: 38.1 -> 10.5 ms at 4 waves per SIMD; R1/4: 68.2 -> 14.3 ms at 3)
@@ -376,6 +377,13 @@ int ultra_hip_count_errors(ultra_hip_ctx* ctx, const uint8_t* d_bytes, const int
                        (size_t)ctx->geo.decoded_bytes, d_iters, d_ok, d_payload, (int)payload_bytes, (int)n_frames,
                        reinterpret_cast<unsigned long long*>(d_counters));
     UH_HIP(hipGetLastError());
+    return ULTRA_HIP_OK;
+}
+
+int ultra_hip_set_deinterleave(ultra_hip_ctx* ctx, uint32_t bits_per_symbol) {
+    if (!ctx) return ULTRA_HIP_ERR_INVALID_ARG;
+    if (bits_per_symbol >= (uint32_t)kLdpcN) return ULTRA_HIP_ERR_INVALID_ARG;
+    ctx->deint_step = bits_per_symbol ? channel_interleaver_step(bits_per_symbol, (uint32_t)kLdpcN) : 1u;
     return ULTRA_HIP_OK;
 }
 

@@ -183,6 +183,12 @@ class ReceiveContext:
             out["llr"] = llr
         return out
 
+    def set_deinterleave(self, bits_per_symbol: int):
+        """RxPipeline::setInterleaverConfig + deinterleaveCodewords (rx_pipeline.cpp:24-31,475-491): every
+        codeword is passed through ChannelInterleaver(bits_per_symbol, 648)::deinterleave before it is
+        decoded, fused into the decoder's LLR load.  0 switches it off."""
+        check(self.lib.ultra_hip_set_deinterleave(self._ctx, int(bits_per_symbol)), "ultra_hip_set_deinterleave")
+
     KERNEL_CLASSES = ("init_state_kernel", "mix_fft_kernel", "track_kernel", "ldpc_decode_kernel", "count_errors_kernel")
 
     def profile_enable(self, on: bool = True):

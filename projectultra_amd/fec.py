@@ -73,13 +73,67 @@ class LDPCDecoder:
             r = {k: v.cpu().numpy() for k, v in r.items()}
         return r
 
+    def setDeinterleave(self, bits_per_symbol: int) -> None:
+        """Fuse RxPipeline's per-codeword ChannelInterleaver(bits_per_symbol, 648)::deinterleave
+        (rx_pipeline.cpp:24-31,475-491) into the decoder's LLR load; 0 switches it off."""
+        self._deinterleave = int(bits_per_symbol)
+        self._ctx.set_deinterleave(self._deinterleave)
+
     # ---------------------------------------------------------------------
     def _rebuild(self):
         if self._ctx is not None:
             self._ctx.close()
         cfg = ModemConfig(code_rate=self._rate)
         self._ctx = ReceiveContext(cfg, max_iterations=self._max_iterations, device=self._device)
+        if getattr(self, "_deinterleave", 0):
+            self._ctx.set_deinterleave(self._deinterleave)
 
     @property
     def context(self) -> ReceiveContext:
         return self._ctx
+
+
+class ChannelInterleaver:
+    """Host mirror of ultra::ChannelInterleaver (include/ultra/fec.hpp:120-142,
+    src/fec/ldpc_decoder.cpp:547-680): permutation[i] = (i * step) % total_bits with the coprime step of
+    findCoprimeStep.  The receive side of it runs on the GPU (ReceiveContext.set_deinterleave); this
+    class serves transmit-side stimulus and the tests."""
+
+    def __init__(self, bits_per_symbol: int, total_bits: int = LDPC_BLOCK_SIZE):
+        self.bits_per_symbol, self.total_bits = int(bits_per_symbol), int(total_bits)
+        self.step = self._find_coprime_step(self.bits_per_symbol, self.total_bits)
+        self.symbol_separation = max(1, self.step // self.bits_per_symbol)
+        self.permutation = (np.arange(self.total_bits, dtype=np.int64) * self.step) % self.total_bits
+        self.inverse_permutation = np.empty_like(self.permutation)
+        self.inverse_permutation[self.permutation] = np.arange(self.total_bits)
+
+    @staticmethod
+    def _find_coprime_step(n: int, total: int) -> int:      # ldpc_decoder.cpp:549-573
+        from math import gcd
+        target = n * 3
+        if target >= total:
+            target = total // 2
+        for step in range(target, total):
+            if gcd(step, total) == 1:
+                return step
+        for step in range(n + 1, total):
+            if gcd(step, total) == 1:
+                return step
+        return n + 1
+
+    def getSymbolSeparation(self) -> int:
+        return self.symbol_separation
+
+    def interleave(self, soft_bits) -> np.ndarray:           # :598-607  output[permutation[i]] = in[i]
+        x = np.ascontiguousarray(soft_bits, dtype=np.float32).reshape(-1)
+        n = min(x.size, self.total_bits)
+        out = np.zeros(self.total_bits, np.float32)
+        out[self.permutation[:n]] = x[:n]
+        return out
+
+    def deinterleave(self, soft_bits) -> np.ndarray:         # :609-617  output[inverse_permutation[i]] = in[i]
+        x = np.ascontiguousarray(soft_bits, dtype=np.float32).reshape(-1)
+        n = min(x.size, self.total_bits)
+        out = np.zeros(self.total_bits, np.float32)
+        out[self.inverse_permutation[:n]] = x[:n]
+        return out

@@ -45,6 +45,31 @@ def test_golden_reference_frames(name):
         _check_llr(r["llr"].cpu().numpy(), g[f"{name}__llr"], name + " fused")
 
 
+@pytest.mark.parametrize("name", ["cfg3_qam16_r34", "cfg2_dqpsk_r12"])
+def test_fused_path_with_channel_deinterleaver(oracle, name):
+    """RxPipeline order of operations (rx_pipeline.cpp:221-230): soft bits -> per-codeword
+    ChannelInterleaver::deinterleave -> decodeSoft.  The fused GPU call with ultra_hip_set_deinterleave must
+    equal: reference LLRs (fixture) -> deinterleave on the host -> oracle decode; the LLRs it hands back stay
+    in channel order."""
+    from projectultra_amd import ChannelInterleaver
+    g = np.load(GOLDEN / "demod.npz")
+    cfg = cfg_from_array(g[f"{name}__cfg"])
+    ctx = context_for(cfg)
+    bps = ctx.geometry.llrs_per_symbol
+    il = ChannelInterleaver(bps)
+    ctx.set_deinterleave(bps)
+    try:
+        r = ctx.demod_decode(g[f"{name}__audio"], cfo_hz=g[f"{name}__cfo"], want_llr=True)
+        ctx.synchronize()
+    finally:
+        ctx.set_deinterleave(0)
+    _check_llr(r["llr"].cpu().numpy(), g[f"{name}__llr"], name + " fused, channel order")
+    deint = np.stack([il.deinterleave(row[:648]) for row in g[f"{name}__llr"]])
+    ob, oi, ook = oracle.ldpc_decode_batch(int(cfg.code_rate), deint)
+    assert np.array_equal(r["bytes"].cpu().numpy(), ob)
+    assert np.array_equal(r["iters"].cpu().numpy(), oi) and np.array_equal(r["ok"].cpu().numpy(), ook)
+
+
 @pytest.mark.parametrize("name", ["ps_dqpsk", "ps_qam16", "ps_d8psk", "ps_qpsk"])
 def test_golden_presynced_frames(name):
     g = np.load(GOLDEN / "presynced.npz")

@@ -116,6 +116,34 @@ def test_nonfinite_llrs(oracle, rate):
     assert beq(np.where(both_nan, np.float32(0), got), np.where(both_nan, np.float32(0), ototal))
 
 
+@pytest.mark.parametrize("bps", [60, 116, 176])
+@pytest.mark.parametrize("rate", [2, 4])
+def test_fused_channel_deinterleaver(oracle, rate, bps):
+    """SURVEY 8 row f3: ChannelInterleaver(bits_per_symbol, 648)::deinterleave per codeword
+    (rx_pipeline.cpp:475-491) fused into the decoder's LLR load == oracle decode of the deinterleaved LLRs.
+    The transmit side interleaves, so these codewords decode; plus pure-noise rows."""
+    from projectultra_amd import ChannelInterleaver
+    llr, _ = noisy_codewords(oracle, rate, 96, [0.45, 0.6] if rate == 2 else [0.3, 0.4], seed=40 + bps)
+    il = ChannelInterleaver(bps)
+    perm, inv = oracle.channel_interleaver_perm(bps)
+    assert np.array_equal(il.permutation, perm) and np.array_equal(il.inverse_permutation, inv)
+    tx = np.stack([il.interleave(r) for r in llr])               # what the channel carries
+    tx[::7] = np.random.default_rng(bps).normal(0, 3, (tx[::7].shape[0], 648)).astype(np.float32)
+    want_in = np.stack([il.deinterleave(r) for r in tx])
+    assert beq(want_in[1], llr[1])
+    d = _decoder(rate)
+    d.setDeinterleave(bps)
+    r = d.decode_batch(tx, want_total=True)
+    ob, oi, ook, ototal = oracle.ldpc_decode_batch(rate, want_in, want_total=True)
+    assert np.array_equal(r["iters"], oi) and np.array_equal(r["ok"], ook) and np.array_equal(r["bytes"], ob)
+    assert beq(r["llr_total"], ototal)
+    assert ook.mean() > 0.5
+    d.setDeinterleave(0)                                           # off again: channel order decodes differently
+    r0 = d.decode_batch(tx)
+    ob0, oi0, ook0 = oracle.ldpc_decode_batch(rate, tx)
+    assert np.array_equal(r0["bytes"], ob0) and np.array_equal(r0["iters"], oi0)
+
+
 def test_full_size_round_trip_property(oracle):
     """BASELINE cfg4 shape at 2^18 codewords: encode -> BPSK/AWGN -> decode; every frame the decoder
     declares OK must equal its payload or be counted as undetected; high-SNR frames all decode."""

@@ -96,3 +96,18 @@ def test_counter_allreduce_across_ranks_gloo(tmp_path, world):
     r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=240)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
     assert r.stdout.count("ok") == world
+
+
+def test_channel_interleaver_mirror_matches_oracle(oracle):
+    """projectultra_amd.ChannelInterleaver (host mirror of src/fec/ldpc_decoder.cpp:547-617) against the
+    oracle's restatement, which tests/test_oracle_vs_ref.py pins to the compiled reference."""
+    from projectultra_amd.fec import ChannelInterleaver
+    x = np.random.default_rng(3).normal(size=648).astype(np.float32)
+    for bps in (30, 60, 116, 176, 236, 300, 472):
+        il = ChannelInterleaver(bps)
+        perm, inv = oracle.channel_interleaver_perm(bps)
+        assert np.array_equal(il.permutation, perm) and np.array_equal(il.inverse_permutation, inv)
+        assert np.array_equal(il.deinterleave(il.interleave(x)), x)
+        short = il.deinterleave(x[:100])
+        want = np.zeros(648, np.float32); want[inv[:100]] = x[:100]
+        assert np.array_equal(short, want)
