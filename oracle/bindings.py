@@ -101,6 +101,36 @@ class _Base:
     def _fn(self, name):
         return getattr(self.lib, self.prefix + name)
 
+    # ------------------------------------------------------- acquisition
+    def acquire(self, cfg, audio, chunk=960):
+        """SEARCHING state fed in chunk-sample calls -> dict(found, fed_at_sync, sync_offset, coarse_cfo,
+        refined_lts, data_start, noise_floor)."""
+        audio = _f32(audio)
+        u = [C.c_uint32(0) for _ in range(5)]
+        cfo, nf = C.c_float(0), C.c_float(0)
+        name = "acquire" if self.prefix == "uo_" else "demod_acquire"
+        rc = self._fn(name)(C.byref(cfg), _ptr(audio), C.c_uint32(audio.size), C.c_uint32(chunk), C.byref(u[0]),
+                            C.byref(u[1]), C.byref(u[2]), C.byref(cfo), C.byref(u[3]), C.byref(u[4]), C.byref(nf))
+        assert rc == 0, rc
+        return dict(found=u[0].value, fed_at_sync=u[1].value, sync_offset=u[2].value, coarse_cfo=cfo.value,
+                    refined_lts=u[3].value, data_start=u[4].value, noise_floor=nf.value)
+
+    def sc_metric(self, cfg, audio, offset, noise_floor=0.0):
+        """One Schmidl-Cox metric + energy gate -> (corr, P.re, P.im, energy, noise_floor_after, has_energy)."""
+        audio = _f32(audio)
+        f = [C.c_float(0) for _ in range(4)]
+        nf = C.c_float(noise_floor); he = C.c_uint32(0)
+        rc = self._fn("sc_metric")(C.byref(cfg), _ptr(audio), C.c_uint32(audio.size), C.c_uint32(offset), C.byref(f[0]),
+                                   C.byref(f[1]), C.byref(f[2]), C.byref(f[3]), C.byref(nf), C.byref(he))
+        assert rc == 0
+        return np.array([x.value for x in f] + [nf.value], np.float32), he.value
+
+    def lts_templates(self, cfg):
+        I = np.zeros(2048, np.float32); Q = np.zeros(2048, np.float32)
+        m = self._fn("lts_templates")(C.byref(cfg), _ptr(I), _ptr(Q), C.c_uint32(2048))
+        assert m > 0
+        return I[:m].copy(), Q[:m].copy()
+
     # -------------------------------------------------------------- FEC
     def ldpc_encode(self, rate, data: bytes) -> bytes:
         out = (C.c_uint8 * 4096)()

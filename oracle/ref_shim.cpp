@@ -285,6 +285,68 @@ int ref_demod_process_coarse(const ultra_hip_config* c, const float* audio, uint
     return (int)sb.size();
 }
 
+// Acquisition (scope row f1): OFDMDemodulator::process in the SEARCHING state, fed in `chunk`-sample
+// calls (src/ofdm/demodulator.cpp:461-600).  Reports, per stream: whether sync was declared, after how
+// many fed samples, the Schmidl-Cox offset (last_sync_offset), the coarse CFO and the refined LTS start
+// it was declared with, and data_start = refined_lts + 2 preamble symbols (= what process() consumes,
+// :572).  The last three are re-derived on a probe demodulator holding the same buffer, calling the
+// reference's own Impl::estimateCoarseCFO / refineLTSTiming; valid while no trimming happened, i.e. for
+// streams shorter than 2*OVERLAP_SAMPLES = 40000 samples (returns -2 otherwise).
+int ref_demod_acquire(const ultra_hip_config* c, const float* audio, uint32_t n, uint32_t chunk,
+                      uint32_t* found, uint32_t* fed_at_sync, uint32_t* sync_offset, float* coarse_cfo,
+                      uint32_t* refined_lts, uint32_t* data_start, float* noise_floor) {
+    if (n >= 40000) return -2;
+    StderrMute mute;
+    ModemConfig cfg = to_cfg(c);
+    OFDMDemodulator demod(cfg);
+    *found = 0; *fed_at_sync = 0; *sync_offset = 0; *coarse_cfo = 0; *refined_lts = 0; *data_start = 0;
+    for (uint32_t i = 0; i < n; i += chunk) {
+        uint32_t len = std::min(chunk, n - i);
+        demod.process(SampleSpan(audio + i, len));
+        if (demod.isSynced()) { *found = 1; *fed_at_sync = i + len; break; }
+    }
+    *noise_floor = demod.impl_->noise_floor_energy;
+    if (*found) {
+        *sync_offset = (uint32_t)demod.getLastSyncOffset();
+        OFDMDemodulator probe(cfg);
+        probe.impl_->rx_buffer.assign(audio, audio + *fed_at_sync);
+        *coarse_cfo = probe.impl_->estimateCoarseCFO(*sync_offset);
+        size_t r = probe.impl_->refineLTSTiming(*sync_offset);
+        *refined_lts = (uint32_t)r;
+        *data_start = (uint32_t)(r + 2 * (cfg.fft_size + cfg.getCyclicPrefix()));
+    }
+    return 0;
+}
+
+// One Schmidl-Cox metric (Impl::measureSchmidlCoxCorrelation, ofdm_sync.cpp:120-163) and the energy
+// gate (Impl::hasMinimumEnergy, :20-50, stateful: noise_floor in/out) at `offset` of a buffer.
+int ref_sc_metric(const ultra_hip_config* c, const float* audio, uint32_t n, uint32_t offset,
+                  float* corr, float* p_re, float* p_im, float* energy, float* noise_floor_io, uint32_t* has_energy) {
+    StderrMute mute;
+    ModemConfig cfg = to_cfg(c);
+    OFDMDemodulator probe(cfg);
+    probe.impl_->rx_buffer.assign(audio, audio + n);
+    Complex P(0, 0); float e = 0;
+    *corr = probe.impl_->measureSchmidlCoxCorrelation(offset, &P, &e);
+    *p_re = P.real(); *p_im = P.imag(); *energy = e;
+    probe.impl_->noise_floor_energy = *noise_floor_io;
+    size_t win = 2 * (cfg.fft_size + cfg.getCyclicPrefix());
+    *has_energy = probe.impl_->hasMinimumEnergy(offset, win) ? 1 : 0;
+    *noise_floor_io = probe.impl_->noise_floor_energy;
+    return 0;
+}
+
+// LTS passband templates of the constructor (demodulator.cpp:100-133)
+int ref_lts_templates(const ultra_hip_config* c, float* I, float* Q, uint32_t cap) {
+    StderrMute mute;
+    OFDMDemodulator probe(to_cfg(c));
+    uint32_t m = (uint32_t)probe.impl_->lts_passband_I.size();
+    if (m > cap) return -1;
+    std::memcpy(I, probe.impl_->lts_passband_I.data(), m * sizeof(float));
+    std::memcpy(Q, probe.impl_->lts_passband_Q.data(), m * sizeof(float));
+    return (int)m;
+}
+
 // Per-symbol stage dump layout (floats), see ref_demod_synced:
 //   bb      [symbol_samples][2]
 //   freq    [fft][2]

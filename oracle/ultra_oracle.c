@@ -1349,6 +1349,229 @@ int uo_demod_decode_batch(const ultra_hip_config* c, const float* audio, size_t 
 }
 
 /* ====================================================================== */
+/* Acquisition: SEARCHING state of OFDMDemodulator::process (scope row f1) */
+/* src/ofdm/demodulator.cpp:461-600, src/ofdm/ofdm_sync.cpp:20-261,386-461 */
+/* ====================================================================== */
+#define ACQ_MIN_SEARCH_SAMPLES 4000u      /* demodulator_constants.hpp:41-53 */
+#define ACQ_MAX_BUFFER_SAMPLES 240000u
+#define ACQ_OVERLAP_SAMPLES 20000u
+#define ACQ_SEARCH_STEP 8u
+#define ACQ_PLATEAU_WINDOW 300u
+#define ACQ_MIN_PLATEAU 15u
+#define ACQ_LTS_MAX (MAX_FFT + 256)
+
+typedef struct acq {
+    demod d;
+    float sync_threshold;          /* ModemConfig::sync_threshold = 0.80f (types.hpp:188) */
+    float noise_floor_energy;      /* demodulator_impl.hpp:62 */
+    size_t lts_len;
+    float lts_I[ACQ_LTS_MAX], lts_Q[ACQ_LTS_MAX];
+    cf work[MAX_FFT];
+    float dc_removed[MAX_FFT];
+} acq;
+
+/* LTS passband templates of the constructor, src/ofdm/demodulator.cpp:100-133 */
+static int acq_init(acq* a, const ultra_hip_config* c) {
+    if (demod_init(&a->d, c) != 0) return -1;
+    a->sync_threshold = 0.80f;
+    a->noise_floor_energy = 0.0f;
+    const uint32_t N = c->fft_size, cp = a->d.cp;
+    if (cp + N > ACQ_LTS_MAX) return -1;
+    cf lts[MAX_FFT];
+    for (uint32_t i = 0; i < N; ++i) lts[i] = c_make(0, 0);
+    for (int i = 0; i < a->d.cr.n_data; ++i) lts[a->d.cr.data_idx[i]] = a->d.cr.sync_seq[i % a->d.cr.n_sync];
+    for (int i = 0; i < a->d.cr.n_pilot; ++i) lts[a->d.cr.pilot_idx[i]] = a->d.cr.pilot_seq[i];
+    fft_exec(&a->d.fft, lts, 1);
+    nco o; nco_init(&o, (float)c->center_freq, (float)c->sample_rate);
+    a->lts_len = cp + N;
+    for (uint32_t i = 0; i < cp + N; ++i) {
+        cf base = (i < cp) ? lts[N - cp + i] : lts[i - cp];
+        cf mixed = c_mul(base, nco_next(&o));
+        a->lts_I[i] = mixed.re;
+        a->lts_Q[i] = mixed.im;
+    }
+    return 0;
+}
+
+/* Impl::hasMinimumEnergy, ofdm_sync.cpp:20-50 (stateful: noise floor) */
+static int acq_has_energy(acq* a, const float* buf, size_t size, size_t offset, size_t window_len) {
+    if (offset + window_len > size) return 0;
+    float sum_sq = 0; size_t count = 0;
+    for (size_t i = 0; i < window_len; i += 16) { float s = buf[offset + i]; sum_sq += s * s; ++count; }
+    float energy = sum_sq / (float)count;
+    if (a->noise_floor_energy < 1e-20f) a->noise_floor_energy = energy * 0.1f;
+    if (energy < a->noise_floor_energy) a->noise_floor_energy = energy;
+    else if (energy < a->noise_floor_energy * 3.0f)
+        a->noise_floor_energy = (1.0f - 0.01f) * a->noise_floor_energy + 0.01f * energy;
+    float threshold = a->noise_floor_energy * 4.0f;
+    return energy >= threshold;
+}
+
+/* Impl::toAnalytic, ofdm_sync.cpp:56-84, for len == fft_size (a power of two: no padding) */
+static void acq_analytic(acq* a, const float* samples, cf* out) {
+    const uint32_t N = a->d.cfg.fft_size;
+    for (uint32_t i = 0; i < N; ++i) out[i] = c_make(samples[i], 0);
+    fft_exec(&a->d.fft, out, 0);
+    for (uint32_t i = 1; i < N / 2; ++i) out[i] = c_scale(out[i], 2.0f);
+    for (uint32_t i = N / 2 + 1; i < N; ++i) out[i] = c_make(0, 0);
+    fft_exec(&a->d.fft, out, 1);
+}
+
+/* Impl::measureSchmidlCoxCorrelation, ofdm_sync.cpp:120-163 */
+static float acq_sc(acq* a, const float* buf, size_t size, size_t offset, cf* out_P, float* out_energy) {
+    const size_t cp = a->d.cp, N = a->d.cfg.fft_size, half = N / 2;
+    if (offset + cp + N > size) { if (out_energy) *out_energy = 0.0f; return 0.0f; }
+    const size_t ds = offset + cp;
+    float dc_sum = 0.0f;
+    for (size_t i = 0; i < N; ++i) dc_sum += buf[ds + i];
+    float dc_offset = dc_sum / (float)N;
+    for (size_t i = 0; i < N; ++i) a->dc_removed[i] = buf[ds + i] - dc_offset;
+    acq_analytic(a, a->dc_removed, a->work);
+    cf P = c_make(0, 0); float R1 = 0, R2 = 0;
+    for (size_t i = 0; i < half; ++i) {
+        P = c_add(P, c_mul(c_conj(a->work[i]), a->work[i + half]));
+        R1 += c_norm(a->work[i]);
+        R2 += c_norm(a->work[i + half]);
+    }
+    if (out_P) *out_P = P;
+    if (out_energy) *out_energy = R2;
+    float normalization = sqrtf(R1 * R2);
+    if (normalization < 1e-10f) return 0.0f;
+    return c_abs(P) / normalization;
+}
+
+/* Impl::estimateCoarseCFO, ofdm_sync.cpp:230-261 */
+static float acq_coarse_cfo(acq* a, const float* buf, size_t size, size_t sync_offset) {
+    const size_t cp = a->d.cp, N = a->d.cfg.fft_size, half = N / 2;
+    const size_t ds = sync_offset + cp;
+    if (ds + N > size) return 0.0f;
+    acq_analytic(a, buf + ds, a->work);
+    cf P = c_make(0, 0);
+    for (size_t i = 0; i < half; ++i) P = c_add(P, c_mul(c_conj(a->work[i]), a->work[i + half]));
+    float phase = atan2f(P.im, P.re);
+    /* float cfo_hz = phase * config.sample_rate / (M_PI * fft_len);  float*uint32 -> float, / double */
+    float cfo_hz = (float)((double)(phase * (float)a->d.cfg.sample_rate) / (M_PI * (double)N));
+    /* float max_cfo = config.sample_rate / fft_len;  integer division */
+    float max_cfo = (float)((size_t)a->d.cfg.sample_rate / N);
+    return f_max(-max_cfo, f_min(max_cfo, cfo_hz));
+}
+
+/* Impl::refineLTSTiming, ofdm_sync.cpp:386-461; SIZE_MAX = failure */
+static size_t acq_refine_lts(acq* a, const float* buf, size_t size, size_t coarse_sts_start) {
+    const size_t psl = a->d.cfg.fft_size + a->d.cp;
+    const size_t coarse_lts_start = coarse_sts_start + 4 * psl;
+    const int SEARCH_BACK = (int)(3 * psl), SEARCH_FWD = (int)(psl / 2);
+    if (coarse_lts_start < (size_t)SEARCH_BACK || coarse_lts_start + (size_t)SEARCH_FWD + a->lts_len > size)
+        return coarse_lts_start;
+    float best_corr = 0.0f; size_t best_offset = coarse_lts_start;
+    float energy_ref = 0.0f;
+    for (size_t i = 0; i < a->lts_len; ++i) {
+        energy_ref += a->lts_I[i] * a->lts_I[i];
+        energy_ref += a->lts_Q[i] * a->lts_Q[i];
+    }
+    energy_ref *= 0.5f;
+    for (int delta = -SEARCH_BACK; delta <= SEARCH_FWD; ++delta) {
+        size_t offset = coarse_lts_start + (size_t)(long)delta;
+        float corr_I = 0, corr_Q = 0, energy_rx = 0;
+        for (size_t i = 0; i < a->lts_len; ++i) {
+            float rx = buf[offset + i];
+            corr_I += rx * a->lts_I[i];
+            corr_Q += rx * a->lts_Q[i];
+            energy_rx += rx * rx;
+        }
+        float corr_mag = sqrtf(corr_I * corr_I + corr_Q * corr_Q);
+        float norm = sqrtf(energy_rx * energy_ref);
+        float corr = (norm > 1e-6f) ? corr_mag / norm : 0.0f;
+        if (corr > best_corr) { best_corr = corr; best_offset = offset; }
+    }
+    float thr = (a->d.cfg.fft_size >= 1024) ? 0.05f : 0.35f;
+    if (best_corr < thr) return (size_t)-1;
+    return best_offset;
+}
+
+/* One stream fed in `chunk`-sample calls until sync is declared.  data_start is absolute in the
+ * stream (process() erases the buffer up to it: demodulator.cpp:572-575). */
+int uo_acquire(const ultra_hip_config* c, const float* audio, uint32_t n, uint32_t chunk,
+               uint32_t* found, uint32_t* fed_at_sync, uint32_t* sync_offset, float* coarse_cfo,
+               uint32_t* refined_lts, uint32_t* data_start, float* noise_floor) {
+    acq* a = (acq*)malloc(sizeof(acq));
+    if (!a) return -1;
+    if (chunk == 0 || acq_init(a, c) != 0) { free(a); return -1; }
+    *found = 0; *fed_at_sync = 0; *sync_offset = 0; *coarse_cfo = 0; *refined_lts = 0; *data_start = 0;
+    const size_t psl = c->fft_size + a->d.cp, preamble_total = psl * 6, corr_win = psl * 2;
+    size_t base = 0, fed = 0;
+    while (fed < n && !*found) {
+        fed += (n - fed < chunk) ? (n - fed) : chunk;
+        size_t size = fed - base;
+        if (size < ACQ_MIN_SEARCH_SAMPLES) continue;
+        if (size > ACQ_MAX_BUFFER_SAMPLES) { base = fed - ACQ_OVERLAP_SAMPLES; size = ACQ_OVERLAP_SAMPLES; }
+        const float* buf = audio + base;
+        int found_sync = 0; size_t so = 0;
+        size_t search_end = (size > preamble_total + corr_win) ? size - preamble_total - corr_win : 0;
+        for (size_t i = 0; i < search_end; i += ACQ_SEARCH_STEP) {
+            if (!acq_has_energy(a, buf, size, i, corr_win)) { i += corr_win / 2 - ACQ_SEARCH_STEP; continue; }
+            float corr = acq_sc(a, buf, size, i, NULL, NULL);
+            if (corr > a->sync_threshold) {
+                size_t plateau = 0, peak_pos = i; float peak = corr;
+                for (size_t j = 0; j <= ACQ_PLATEAU_WINDOW && i + j + preamble_total < size; j += 8) {
+                    float rc = acq_sc(a, buf, size, i + j, NULL, NULL);
+                    if (rc >= 0.90f) plateau++;
+                    if (rc > peak) { peak = rc; peak_pos = i + j; }
+                }
+                if (plateau >= ACQ_MIN_PLATEAU) { found_sync = 1; so = peak_pos; break; }
+            }
+        }
+        if (found_sync) {
+            float cfo = acq_coarse_cfo(a, buf, size, so);
+            size_t refined = acq_refine_lts(a, buf, size, so);
+            if (refined == (size_t)-1) {
+                if (size > ACQ_OVERLAP_SAMPLES * 2) {
+                    size_t trim = so + psl;
+                    if (trim > size - ACQ_OVERLAP_SAMPLES) trim = size - ACQ_OVERLAP_SAMPLES;
+                    base += trim;
+                }
+            } else {
+                *found = 1; *fed_at_sync = (uint32_t)fed; *sync_offset = (uint32_t)so; *coarse_cfo = cfo;
+                *refined_lts = (uint32_t)refined;
+                *data_start = (uint32_t)(base + refined + 2 * psl);
+            }
+        } else if (size > ACQ_OVERLAP_SAMPLES * 2) {
+            base += size - ACQ_OVERLAP_SAMPLES;
+        }
+    }
+    *noise_floor = a->noise_floor_energy;
+    demod_free(&a->d);
+    free(a);
+    return 0;
+}
+
+/* Stage probes for the tests (same outputs as ref_sc_metric / ref_lts_templates in oracle/ref_shim.cpp) */
+int uo_sc_metric(const ultra_hip_config* c, const float* audio, uint32_t n, uint32_t offset,
+                 float* corr, float* p_re, float* p_im, float* energy, float* noise_floor_io, uint32_t* has_energy) {
+    acq* a = (acq*)malloc(sizeof(acq));
+    if (!a) return -1;
+    if (acq_init(a, c) != 0) { free(a); return -1; }
+    cf P = c_make(0, 0); float e = 0;
+    *corr = acq_sc(a, audio, n, offset, &P, &e);
+    *p_re = P.re; *p_im = P.im; *energy = e;
+    a->noise_floor_energy = *noise_floor_io;
+    *has_energy = (uint32_t)acq_has_energy(a, audio, n, offset, 2 * (size_t)(c->fft_size + a->d.cp));
+    *noise_floor_io = a->noise_floor_energy;
+    demod_free(&a->d); free(a);
+    return 0;
+}
+int uo_lts_templates(const ultra_hip_config* c, float* I, float* Q, uint32_t cap) {
+    acq* a = (acq*)malloc(sizeof(acq));
+    if (!a) return -1;
+    if (acq_init(a, c) != 0) { free(a); return -1; }
+    int m = (int)a->lts_len;
+    if ((uint32_t)m > cap) { demod_free(&a->d); free(a); return -1; }
+    memcpy(I, a->lts_I, sizeof(float) * m); memcpy(Q, a->lts_Q, sizeof(float) * m);
+    demod_free(&a->d); free(a);
+    return m;
+}
+
+/* ====================================================================== */
 /* Modulator (stimulus), src/ofdm/modulator.cpp                            */
 /* ====================================================================== */
 typedef struct modulator {

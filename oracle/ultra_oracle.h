@@ -53,6 +53,15 @@ int uo_fft_forward(uint32_t n, const float* in_ri, float* out_ri);
 int uo_fft_inverse(uint32_t n, const float* in_ri, float* out_ri);
 int uo_nco(float freq, float fs, uint32_t n, float* out_ri);
 
+/* ---- acquisition (scope row f1): SEARCHING state of OFDMDemodulator::process fed in chunk-sample
+ * calls; same outputs as ref_demod_acquire / ref_sc_metric / ref_lts_templates (oracle/ref_shim.cpp) */
+int uo_acquire(const ultra_hip_config* c, const float* audio, uint32_t n, uint32_t chunk,
+               uint32_t* found, uint32_t* fed_at_sync, uint32_t* sync_offset, float* coarse_cfo,
+               uint32_t* refined_lts, uint32_t* data_start, float* noise_floor);
+int uo_sc_metric(const ultra_hip_config* c, const float* audio, uint32_t n, uint32_t offset,
+                 float* corr, float* p_re, float* p_im, float* energy, float* noise_floor_io, uint32_t* has_energy);
+int uo_lts_templates(const ultra_hip_config* c, float* I, float* Q, uint32_t cap);
+
 /* ---- demodulator ------------------------------------------------------- */
 int uo_demod_tables(const ultra_hip_config* c, int32_t* data_idx, int32_t* pilot_idx,
                     float* pilot_seq_ri, int32_t* interp_i, float* interp_alpha,

@@ -127,3 +127,58 @@ def test_complex_division_is_the_double_formula():
         p = os.path.join(td, "d.cpp"); open(p, "w").write(src)
         subprocess.check_call(["g++", "-O2", "-std=c++17", p, "-o", os.path.join(td, "d")])
         assert subprocess.check_output([os.path.join(td, "d")]).strip() == b"0"
+
+
+ACQ_MODES = [(1024, "QAM16", "R3_4", {}), (512, "DQPSK", "R1_2", {})]
+
+
+def _streams(ref, cfg, rng, n=6):
+    """Whole frames as the harnesses build them (silence + preamble + data, AWGN), plus variations of
+    the leading silence and of the level."""
+    out = []
+    for t in range(n):
+        payload = bytes(rng.integers(0, 256, INFO_BITS[cfg.code_rate] // 8, dtype=np.uint8))
+        a, pre = ref.harness_awgn(cfg, payload, [30.0, 22.0, 12.0][t % 3], 777 + t)   # the search fails at 12 dB
+        if t % 2:
+            lead = rng.normal(0, 1e-3, int(rng.integers(200, 3000))).astype(np.float32)
+            a = np.concatenate([lead, a * np.float32(0.3 + 0.2 * t)])
+            pre += lead.size
+        out.append((a.astype(np.float32), pre))
+    return out
+
+
+@pytest.mark.parametrize("fft,mod,rate,kw", ACQ_MODES)
+def test_acquisition_stages(oracle, ref, fft, mod, rate, kw):
+    """Scope row f1, stage by stage: LTS templates, Schmidl-Cox metric + energy gate at many offsets."""
+    cfg = make_config(fft, mod, rate, **kw)
+    for x, y in zip(oracle.lts_templates(cfg), ref.lts_templates(cfg)):
+        assert beq(x, y)
+    rng = np.random.default_rng(5)
+    for a, pre in _streams(ref, cfg, rng, 3):
+        nf = 0.0
+        for off in list(range(0, 2400, 152)) + [pre - 7 * (fft + 96) + d for d in (0, 8, 40, 300)]:
+            if off < 0:
+                continue
+            mo, ho = oracle.sc_metric(cfg, a, off, nf)
+            mr, hr = ref.sc_metric(cfg, a, off, nf)
+            assert beq(mo, mr) and ho == hr, (off, mo, mr)
+            nf = float(mr[4])
+
+
+@pytest.mark.parametrize("fft,mod,rate,kw", ACQ_MODES)
+def test_acquisition_whole_streams(oracle, ref, fft, mod, rate, kw):
+    """The chunk-fed search as a whole: sync declared at the same call, same Schmidl-Cox offset, same
+    coarse CFO (bitwise), same refined LTS start / data start, same noise floor; different chunkings."""
+    cfg = make_config(fft, mod, rate, **kw)
+    rng = np.random.default_rng(6)
+    hits = 0
+    for a, pre in _streams(ref, cfg, rng, 6):
+        for chunk in (960, 4800, 441):
+            o = oracle.acquire(cfg, a, chunk)
+            r = ref.acquire(cfg, a, chunk)
+            for k in ("found", "fed_at_sync", "sync_offset", "refined_lts", "data_start"):
+                assert o[k] == r[k], (k, chunk, o, r)
+            assert np.float32(o["coarse_cfo"]).tobytes() == np.float32(r["coarse_cfo"]).tobytes(), (o, r)
+            assert np.float32(o["noise_floor"]).tobytes() == np.float32(r["noise_floor"]).tobytes(), (o, r)
+            hits += o["found"]
+    assert hits >= 6
