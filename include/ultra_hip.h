@@ -247,6 +247,24 @@ int ultra_hip_synchronize(ultra_hip_ctx* ctx);
 int ultra_hip_timer_begin(ultra_hip_ctx* ctx);
 int ultra_hip_timer_end(ultra_hip_ctx* ctx, float* ms);
 
+/* Preamble acquisition: the SEARCHING state of OFDMDemodulator::process
+ * (src/ofdm/demodulator.cpp:461-600: Schmidl-Cox search with energy gate and plateau test, coarse CFO,
+ * LTS matched-filter refinement; src/ofdm/ofdm_sync.cpp:20-261,386-461) for a batch of independent
+ * streams.  Stream s = d_audio[s * stream_stride .. + n_samples) is received by a fresh demodulator
+ * that is fed `chunk` samples per process() call (the harnesses use 960: the search result depends on
+ * the chunking, docs and SURVEY quirk 7), until sync is declared or the stream ends.
+ *   d_found[s]       1 when sync was declared
+ *   d_data_start[s]  absolute sample index of the first data symbol (what process() erases the buffer
+ *                    up to: demodulator.cpp:572-575)
+ *   d_cfo_hz[s]      Impl::estimateCoarseCFO at the Schmidl-Cox offset
+ *   d_sync_offset[s] (nullable) OFDMDemodulator::getLastSyncOffset()
+ *   d_fed_at_sync[s] (nullable) samples fed when sync was declared
+ * (d_data_start, d_cfo_hz) is the SYNCED entry of ultra_hip_demod_batch.  Uses
+ * ModemConfig::sync_threshold's default 0.80. */
+int ultra_hip_acquire_batch(ultra_hip_ctx* ctx, const float* d_audio, size_t stream_stride, uint32_t n_samples,
+                            uint32_t chunk, size_t n_streams, uint32_t* d_found, uint32_t* d_data_start,
+                            float* d_cfo_hz, uint32_t* d_sync_offset, uint32_t* d_fed_at_sync);
+
 /* Channel deinterleaver of the production receive path, fused into the decoder's LLR load.
  * Replaces RxPipeline::setInterleaverConfig(bits_per_symbol) + deinterleaveCodewords
  * (src/gui/modem/rx_pipeline.cpp:24-31,475-491): every 648-LLR codeword handed to
@@ -269,7 +287,8 @@ enum ultra_hip_kernel_class {
     ULTRA_HIP_K_TRACK = 2,      /* track_kernel: channel tracking + equalize + demap, one per symbol */
     ULTRA_HIP_K_LDPC = 3,       /* ldpc_decode_kernel */
     ULTRA_HIP_K_COUNT = 4,      /* count_errors_kernel */
-    ULTRA_HIP_K_N = 5
+    ULTRA_HIP_K_ACQUIRE = 5,    /* acquire_kernel */
+    ULTRA_HIP_K_N = 6
 };
 int ultra_hip_profile_enable(ultra_hip_ctx* ctx, int enable);
 int ultra_hip_profile_read(ultra_hip_ctx* ctx, float* ms, uint32_t* launches);

@@ -385,5 +385,59 @@ inline int build_demod(const ultra_hip_config& c, DemodConst& D, std::vector<c32
     return ULTRA_HIP_OK;
 }
 
+// LTS passband templates of the demodulator constructor (src/ofdm/demodulator.cpp:100-133): the LTS
+// symbol (Zadoff-Chu on the data carriers, BPSK pilots) through the reference's inverse radix-2 FFT
+// (src/dsp/fft.cpp:89-121), cyclic prefix prepended, multiplied by a fresh NCO (= the first entries of
+// the frame's oscillator table), real and imaginary parts kept.  energy_ref is the serial float sum
+// refineLTSTiming recomputes on every call (src/ofdm/ofdm_sync.cpp:405-411).
+inline void build_lts_templates(const ultra_hip_config& c, const DemodConst& D, const std::vector<c32>& nco,
+                                const std::vector<c32>& twiddle, std::vector<float>& lts_I,
+                                std::vector<float>& lts_Q, float& energy_ref) {
+    const size_t N = c.fft_size, cp = (size_t)D.cp;
+    auto cmulh = [](c32 x, c32 y) {
+        const float ac = x.re * y.re, bd = x.im * y.im, ad = x.re * y.im, bc = x.im * y.re;
+        return c32{ac - bd, ad + bc};
+    };
+    std::vector<c32> d(N, c32{0.0f, 0.0f});
+    for (int i = 0; i < D.n_data; ++i) d[(size_t)D.bin[D.data_slot[i]]] = D.sync_seq[(size_t)i % c.num_carriers];
+    for (int i = 0; i < D.n_pilot; ++i) d[(size_t)D.bin[D.pilot_slot[i]]] = D.pilot_seq[i];
+    // fft_impl(inverse = true)
+    size_t j = 0;
+    for (size_t i = 0; i + 1 < N; ++i) {
+        if (i < j) std::swap(d[i], d[j]);
+        size_t k = N / 2;
+        while (k <= j) { j -= k; k /= 2; }
+        j += k;
+    }
+    for (size_t len = 2; len <= N; len *= 2) {
+        const size_t half = len / 2, step = N / len;
+        for (size_t i = 0; i < N; i += len)
+            for (size_t k = 0; k < half; ++k) {
+                c32 w = twiddle[k * step];
+                w.im = -w.im;
+                const c32 t = cmulh(w, d[i + k + half]);
+                const c32 a = d[i + k];
+                d[i + k + half] = c32{a.re - t.re, a.im - t.im};
+                d[i + k] = c32{a.re + t.re, a.im + t.im};
+            }
+    }
+    const float scale = 1.0f / (float)N;
+    for (auto& v : d) v = c32{v.re * scale, v.im * scale};
+    lts_I.resize(cp + N);
+    lts_Q.resize(cp + N);
+    for (size_t i = 0; i < cp + N; ++i) {
+        const c32 base = (i < cp) ? d[N - cp + i] : d[i - cp];
+        const c32 mixed = cmulh(base, nco[i]);
+        lts_I[i] = mixed.re;
+        lts_Q[i] = mixed.im;
+    }
+    energy_ref = 0.0f;
+    for (size_t i = 0; i < cp + N; ++i) {
+        energy_ref += lts_I[i] * lts_I[i];
+        energy_ref += lts_Q[i] * lts_Q[i];
+    }
+    energy_ref *= 0.5f;
+}
+
 }  // namespace ultra_hip
 #endif

@@ -17,6 +17,7 @@
 #include "host_tables.h"
 #include "demod_kernel.h"
 #include "ldpc_kernel.h"
+#include "acquire_kernel.h"
 
 using namespace ultra_hip;
 
@@ -34,6 +35,9 @@ struct ultra_hip_ctx {
     int work_slot = 0;
     c32* d_nco = nullptr;
     c32* d_twiddle = nullptr;
+    float* d_lts = nullptr;              // LTS passband templates I then Q (acquisition)
+    uint32_t lts_len = 0;
+    float lts_energy_ref = 0.0f;
     // workspace for the fused call when the caller does not want LLRs
     float* d_ws_llr = nullptr;
     size_t ws_llr_frames = 0;
@@ -278,6 +282,15 @@ int ultra_hip_create(const ultra_hip_config* cfg, int device, void* stream, ultr
         hipMemcpy(ctx->d_nco, nco.data(), nco.size() * sizeof(c32), hipMemcpyHostToDevice) != hipSuccess ||
         hipMemcpy(ctx->d_twiddle, tw.data(), tw.size() * sizeof(c32), hipMemcpyHostToDevice) != hipSuccess)
         return fail(ULTRA_HIP_ERR_HIP);
+    {
+        std::vector<float> li, lq;
+        build_lts_templates(*cfg, ctx->h_demod, nco, tw, li, lq, ctx->lts_energy_ref);
+        ctx->lts_len = (uint32_t)li.size();
+        if (hipMalloc(&ctx->d_lts, 2 * li.size() * sizeof(float)) != hipSuccess) return fail(ULTRA_HIP_ERR_OOM);
+        if (hipMemcpy(ctx->d_lts, li.data(), li.size() * sizeof(float), hipMemcpyHostToDevice) != hipSuccess ||
+            hipMemcpy(ctx->d_lts + li.size(), lq.data(), lq.size() * sizeof(float), hipMemcpyHostToDevice) != hipSuccess)
+            return fail(ULTRA_HIP_ERR_HIP);
+    }
     if (hipEventCreate(&ctx->ev_begin) != hipSuccess || hipEventCreate(&ctx->ev_end) != hipSuccess)
         return fail(ULTRA_HIP_ERR_HIP);
     *out = ctx;
@@ -294,6 +307,7 @@ void ultra_hip_destroy(ultra_hip_ctx* ctx) {
     for (auto e : ctx->spare_events) (void)hipEventDestroy(e);
     if (ctx->d_nco) (void)hipFree(ctx->d_nco);
     if (ctx->d_twiddle) (void)hipFree(ctx->d_twiddle);
+    if (ctx->d_lts) (void)hipFree(ctx->d_lts);
     if (ctx->d_ws_llr) (void)hipFree(ctx->d_ws_llr);
     if (ctx->d_ws_state) (void)hipFree(ctx->d_ws_state);
     if (ctx->d_ws_fq) (void)hipFree(ctx->d_ws_fq);
@@ -360,6 +374,36 @@ int ultra_hip_demod_decode_batch(ultra_hip_ctx* ctx, const float* d_audio, size_
                           ctx->geo.llrs_per_frame, nullptr);
     if (rc != ULTRA_HIP_OK) return rc;
     return launch_ldpc(ctx, llr, ctx->geo.llrs_per_frame, n_frames, d_bytes, d_iters, d_ok, nullptr);
+}
+
+int ultra_hip_acquire_batch(ultra_hip_ctx* ctx, const float* d_audio, size_t stream_stride, uint32_t n_samples,
+                            uint32_t chunk, size_t n_streams, uint32_t* d_found, uint32_t* d_data_start,
+                            float* d_cfo_hz, uint32_t* d_sync_offset, uint32_t* d_fed_at_sync) {
+    if (!ctx) return ULTRA_HIP_ERR_INVALID_ARG;
+    if (n_streams == 0) return ULTRA_HIP_OK;
+    if (!d_audio || !d_found || !d_data_start || !d_cfo_hz || chunk == 0 || stream_stride < n_samples ||
+        n_streams > 0x7fffffffull || n_samples > 0x3fffffffu)
+        return ULTRA_HIP_ERR_INVALID_ARG;
+    DeviceGuard guard(ctx->device);
+    const unsigned grid = (unsigned)std::min(n_streams, (size_t)ctx->cu_count * 64);
+    LaunchSpan span(ctx, ULTRA_HIP_K_ACQUIRE);
+    const float* lts_I = ctx->d_lts;
+    const float* lts_Q = ctx->d_lts + ctx->lts_len;
+    const float sync_threshold = 0.80f;          // ModemConfig::sync_threshold default (types.hpp:188)
+    if (ctx->h_demod.log2_fft == 10)
+        hipLaunchKernelGGL(dev::acquire_kernel<10>, dim3(grid), dim3(dev::kWave), 0, ctx->stream, ctx->d_demod,
+                           ctx->d_twiddle, lts_I, lts_Q, ctx->lts_energy_ref, sync_threshold, d_audio, stream_stride,
+                           n_samples, chunk, (int)n_streams, d_found, d_data_start, d_cfo_hz, d_sync_offset,
+                           d_fed_at_sync);
+    else if (ctx->h_demod.log2_fft == 9)
+        hipLaunchKernelGGL(dev::acquire_kernel<9>, dim3(grid), dim3(dev::kWave), 0, ctx->stream, ctx->d_demod,
+                           ctx->d_twiddle, lts_I, lts_Q, ctx->lts_energy_ref, sync_threshold, d_audio, stream_stride,
+                           n_samples, chunk, (int)n_streams, d_found, d_data_start, d_cfo_hz, d_sync_offset,
+                           d_fed_at_sync);
+    else
+        return ULTRA_HIP_ERR_UNSUPPORTED;
+    UH_HIP(hipGetLastError());
+    return ULTRA_HIP_OK;
 }
 
 int ultra_hip_count_errors(ultra_hip_ctx* ctx, const uint8_t* d_bytes, const int32_t* d_iters, const uint8_t* d_ok,

@@ -183,13 +183,34 @@ class ReceiveContext:
             out["llr"] = llr
         return out
 
+    def acquire(self, audio, chunk: int = 960):
+        """Preamble acquisition of a batch of streams [n][n_samples] (OFDMDemodulator::process in the
+        SEARCHING state, each stream fed `chunk` samples per call: demodulator.cpp:461-600).
+        Returns device tensors dict(found, data_start, cfo_hz, sync_offset, fed_at_sync)."""
+        torch = _torch()
+        audio = self._dev(audio, torch.float32, "audio")
+        if audio.dim() != 2:
+            raise ValueError("audio must be [n_streams][n_samples]")
+        n, ns = audio.shape
+        out = dict(found=torch.zeros(n, dtype=torch.int32, device=self.device),
+                   data_start=torch.zeros(n, dtype=torch.int32, device=self.device),
+                   cfo_hz=torch.zeros(n, dtype=torch.float32, device=self.device),
+                   sync_offset=torch.zeros(n, dtype=torch.int32, device=self.device),
+                   fed_at_sync=torch.zeros(n, dtype=torch.int32, device=self.device))
+        check(self.lib.ultra_hip_acquire_batch(self._ctx, audio.data_ptr(), audio.stride(0), ns, int(chunk), n,
+                                               out["found"].data_ptr(), out["data_start"].data_ptr(),
+                                               out["cfo_hz"].data_ptr(), out["sync_offset"].data_ptr(),
+                                               out["fed_at_sync"].data_ptr()), "ultra_hip_acquire_batch")
+        return out
+
     def set_deinterleave(self, bits_per_symbol: int):
         """RxPipeline::setInterleaverConfig + deinterleaveCodewords (rx_pipeline.cpp:24-31,475-491): every
         codeword is passed through ChannelInterleaver(bits_per_symbol, 648)::deinterleave before it is
         decoded, fused into the decoder's LLR load.  0 switches it off."""
         check(self.lib.ultra_hip_set_deinterleave(self._ctx, int(bits_per_symbol)), "ultra_hip_set_deinterleave")
 
-    KERNEL_CLASSES = ("init_state_kernel", "mix_fft_kernel", "track_kernel", "ldpc_decode_kernel", "count_errors_kernel")
+    KERNEL_CLASSES = ("init_state_kernel", "mix_fft_kernel", "track_kernel", "ldpc_decode_kernel", "count_errors_kernel",
+                      "acquire_kernel")
 
     def profile_enable(self, on: bool = True):
         """Bracket every kernel launch of this context with HIP events (ultra_hip_profile_enable)."""

@@ -190,3 +190,57 @@ def test_device_math_matches_host_libm():
         f = getattr(libm, name)
         want = np.array([f(x) if fn < 3 else f(x, y) for x, y in zip(a.tolist(), b.tolist())], np.float32)
         assert beq(got, want), (name, np.flatnonzero(got.view(np.uint32) != want.view(np.uint32))[:5])
+
+
+@pytest.mark.parametrize("fft,mod,rate", [(1024, "QAM16", "R3_4"), (512, "DQPSK", "R1_2")])
+def test_acquisition_matches_oracle(oracle, fft, mod, rate):
+    """Scope row f1: the chunk-fed Schmidl-Cox search + coarse CFO + LTS refinement on the GPU equals the
+    oracle (which tests/test_oracle_vs_ref.py pins to the compiled reference, stage by stage and whole):
+    found / data start / Schmidl-Cox offset / samples fed exactly, coarse CFO bitwise.  Streams: whole
+    frames at several SNRs (the search fails at low SNR), shifted starts and levels, pure noise, silence;
+    two chunkings.  Then the acquired (data_start, cfo) feeds the SYNCED entry: LLRs equal the oracle's."""
+    cfg = make_config(fft, mod, rate)
+    g = geometry(cfg)
+    rng = np.random.default_rng(11)
+    n_samples = g.frame_samples + 7 * (fft + g.cp_len) + 3200
+    streams = []
+    for t in range(10):
+        payload = bytes(rng.integers(0, 256, INFO_BITS[cfg.code_rate] // 8, dtype=np.uint8))
+        a, _ = oracle.modulate_frame(cfg, oracle.ldpc_encode(int(cfg.code_rate), payload))   # preamble + data
+        a = a * np.float32(0.5 / np.abs(a).max())
+        snr_db = [30.0, 26.0, 20.0, 12.0][t % 4]
+        sigma = np.sqrt(np.mean(a.astype(np.float64) ** 2) / 10 ** (snr_db / 10))
+        a = (a + rng.normal(0, sigma, a.size)).astype(np.float32)
+        lead = rng.normal(0, 2e-4, int(rng.integers(0, 2800))).astype(np.float32)
+        x = np.concatenate([lead, a * np.float32(0.4 + 0.15 * (t % 5))])
+        x = np.concatenate([x, rng.normal(0, 2e-4, max(0, n_samples - x.size)).astype(np.float32)])[:n_samples]
+        streams.append(x)
+    streams.append(rng.normal(0, 0.05, n_samples).astype(np.float32))     # noise only
+    streams.append(np.zeros(n_samples, np.float32))                       # silence
+    audio = np.stack(streams)
+    ctx = context_for(cfg)
+    hits = 0
+    for chunk in (960, 3000):
+        r = ctx.acquire(audio, chunk)
+        ctx.synchronize()
+        r = {k: v.cpu().numpy() for k, v in r.items()}
+        for i, x in enumerate(streams):
+            o = oracle.acquire(cfg, x, chunk)
+            assert r["found"][i] == o["found"], (i, chunk, o)
+            if o["found"]:
+                hits += 1
+                assert r["data_start"][i] == o["data_start"] and r["sync_offset"][i] == o["sync_offset"], (i, chunk, o)
+                assert r["fed_at_sync"][i] == o["fed_at_sync"], (i, chunk, o)
+                assert np.float32(r["cfo_hz"][i]).tobytes() == np.float32(o["coarse_cfo"]).tobytes(), (i, chunk, o)
+    assert hits >= 6
+    # acquired entry -> SYNCED demodulation, against the oracle on the same (data_start, cfo)
+    r = ctx.acquire(audio, 960)
+    ctx.synchronize()
+    found = r["found"].cpu().numpy().astype(bool)
+    ds, cfo = r["data_start"].cpu().numpy(), r["cfo_hz"].cpu().numpy()
+    ok = found & (ds + g.frame_samples <= n_samples)
+    frames = np.stack([audio[i, ds[i]: ds[i] + g.frame_samples] for i in np.flatnonzero(ok)])
+    llr = ctx.demod(frames, cfo_hz=cfo[ok])
+    ctx.synchronize()
+    want = np.stack([oracle.demod_synced(cfg, f, c)[0] for f, c in zip(frames, cfo[ok])])
+    _check_llr(llr.cpu().numpy(), want, "acquired entry")
