@@ -265,6 +265,20 @@ int ultra_hip_acquire_batch(ultra_hip_ctx* ctx, const float* d_audio, size_t str
                             uint32_t chunk, size_t n_streams, uint32_t* d_found, uint32_t* d_data_start,
                             float* d_cfo_hz, uint32_t* d_sync_offset, uint32_t* d_fed_at_sync);
 
+/* End to end from raw audio: ultra_hip_acquire_batch, then the SYNCED demodulation of each stream from
+ * its own data start with its own coarse CFO, then the LDPC decode of the first 648 soft bits — what
+ * one OFDMDemodulator::process loop + getSoftBits + LDPCDecoder::decodeSoft does per trial in the
+ * harnesses (tools/test_nvis_mode.cpp:88-113), for n_streams independent trials.
+ *   d_entry[s]   (nullable) first data sample, 0xffffffff when the stream yields no frame: no sync, or
+ *                fewer than frame_samples after the data start (the reference would still be waiting)
+ *   d_cfo_hz[s]  (nullable) coarse CFO
+ *   d_llr        (nullable) [n_streams][llrs_per_frame]; rows of streams without a frame are unspecified
+ *   d_bytes / d_iters / d_ok  as ultra_hip_demod_decode_batch; all zero for streams without a frame
+ * Requires n_samples >= frame_samples and the SYNCED entry. */
+int ultra_hip_receive_batch(ultra_hip_ctx* ctx, const float* d_audio, size_t stream_stride, uint32_t n_samples,
+                            uint32_t chunk, size_t n_streams, float* d_llr, uint8_t* d_bytes, int32_t* d_iters,
+                            uint8_t* d_ok, uint32_t* d_entry, float* d_cfo_hz);
+
 /* Channel deinterleaver of the production receive path, fused into the decoder's LLR load.
  * Replaces RxPipeline::setInterleaverConfig(bits_per_symbol) + deinterleaveCodewords
  * (src/gui/modem/rx_pipeline.cpp:24-31,475-491): every 648-LLR codeword handed to

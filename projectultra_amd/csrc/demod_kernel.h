@@ -790,8 +790,8 @@ __global__ __launch_bounds__(kWave) void init_state_kernel(const float* __restri
 template <int LOG2N>
 __global__ __launch_bounds__(kWave, 3) void mix_fft_kernel(
     const DemodConst* __restrict__ Dp, const c32* __restrict__ nco, const c32* __restrict__ twiddle,
-    const float* __restrict__ audio, size_t frame_stride, int n_frames, int sym, float* __restrict__ state,
-    c32* __restrict__ fq) {
+    const float* __restrict__ audio, size_t frame_stride, const unsigned* __restrict__ frame_offset, int n_frames,
+    int sym, float* __restrict__ state, c32* __restrict__ fq) {
     __shared__ FftShared<LOG2N> sh;
     const DemodConst& D = *Dp;
     const int lane = threadIdx.x;
@@ -805,7 +805,9 @@ __global__ __launch_bounds__(kWave, 3) void mix_fft_kernel(
     }
     wave_sync();
     const size_t sym_off = (size_t)sym * D.sym_len;
-    if ((int)blockIdx.x < n_frames) prefetch_symbol<LOG2N>(sh, D, audio + (size_t)blockIdx.x * frame_stride + sym_off);
+    // frame f starts at audio + f * frame_stride (+ frame_offset[f]: per-stream data start from the acquisition)
+    auto frame_base = [&](int f) { return audio + (size_t)f * frame_stride + (frame_offset ? frame_offset[f] : 0u) + sym_off; };
+    if ((int)blockIdx.x < n_frames) prefetch_symbol<LOG2N>(sh, D, frame_base((int)blockIdx.x));
     for (int frame = blockIdx.x; frame < n_frames; frame += gridDim.x) {
         float* st = state + (size_t)frame * kStFloats;
         const float cfo = st[st_cfo];
@@ -813,7 +815,7 @@ __global__ __launch_bounds__(kWave, 3) void mix_fft_kernel(
         symbol_to_freq<LOG2N>(sh, D, cfo, phase, nco + sym_off, twiddle, fq + (size_t)frame * 128);
         if (lane == 0) st[st_cfo_phase] = phase;
         const int next = frame + (int)gridDim.x;
-        if (next < n_frames) prefetch_symbol<LOG2N>(sh, D, audio + (size_t)next * frame_stride + sym_off);
+        if (next < n_frames) prefetch_symbol<LOG2N>(sh, D, frame_base(next));
     }
 }
 

@@ -335,6 +335,32 @@ __global__ __launch_bounds__(kLdpcThreads, WAVES) void ldpc_decode_kernel(
     }
 }
 
+// Streams without a usable frame (no sync, or the frame runs past the end of the stream): the reference
+// produces no soft bits for them, so their decode results are cleared (ok = 0, iters = 0, bytes = 0).
+// entry[f] = first data sample, or 0xffffffff when unusable.
+__global__ __launch_bounds__(256) void clear_unusable_kernel(const unsigned* __restrict__ entry, int n_frames,
+                                                             uint8_t* __restrict__ bytes, int bytes_stride,
+                                                             int32_t* __restrict__ iters, uint8_t* __restrict__ okv) {
+    const int f = blockIdx.x * blockDim.x + threadIdx.x;
+    if (f >= n_frames || entry[f] != 0xffffffffu) return;
+    for (int b = 0; b < bytes_stride; ++b) bytes[(size_t)f * bytes_stride + b] = 0;
+    iters[f] = 0;
+    okv[f] = 0;
+}
+
+// entry[f] = found[f] && data_start[f] + frame_samples <= n_samples ? data_start[f] : 0xffffffff;
+// offset[f] = the same with 0 for unusable streams (their frame is demodulated from sample 0 and discarded)
+__global__ __launch_bounds__(256) void frame_entry_kernel(const unsigned* __restrict__ found,
+                                                          const unsigned* __restrict__ data_start, unsigned frame_samples,
+                                                          unsigned n_samples, int n_frames, unsigned* __restrict__ entry,
+                                                          unsigned* __restrict__ offset) {
+    const int f = blockIdx.x * blockDim.x + threadIdx.x;
+    if (f >= n_frames) return;
+    const bool ok = found[f] != 0 && data_start[f] + frame_samples <= n_samples;
+    entry[f] = ok ? data_start[f] : 0xffffffffu;
+    offset[f] = ok ? data_start[f] : 0u;
+}
+
 // Monte-Carlo counters: frame OK iff ok && payload bytes equal
 // (tools/test_nvis_mode.cpp:104-113).  One lane per frame, wave + block
 // reduction, one set of atomics per block.

@@ -36,6 +36,8 @@ struct ultra_hip_ctx {
     c32* d_nco = nullptr;
     c32* d_twiddle = nullptr;
     float* d_lts = nullptr;              // LTS passband templates I then Q (acquisition)
+    unsigned* d_ws_acq = nullptr;        // receive_batch workspace: found, data_start, entry, offset [n] + cfo [n]
+    size_t ws_acq_frames = 0;
     uint32_t lts_len = 0;
     float lts_energy_ref = 0.0f;
     // workspace for the fused call when the caller does not want LLRs
@@ -101,7 +103,8 @@ struct DeviceGuard {
 };
 
 int launch_demod(ultra_hip_ctx* ctx, const float* d_audio, size_t frame_stride, const float* d_cfo_hz,
-                 const float* d_cfo_phase, size_t n_frames, float* d_llr, size_t llr_stride, float* d_state) {
+                 const float* d_cfo_phase, size_t n_frames, float* d_llr, size_t llr_stride, float* d_state,
+                 const unsigned* d_frame_offset = nullptr) {
     if (n_frames == 0) return ULTRA_HIP_OK;
     const DemodConst& D = ctx->h_demod;
     if (ctx->ws_demod_frames < n_frames) {
@@ -133,12 +136,12 @@ int launch_demod(ultra_hip_ctx* ctx, const float* d_audio, size_t frame_stride, 
             LaunchSpan span(ctx, ULTRA_HIP_K_MIX_FFT);
             if (D.log2_fft == 10)
                 hipLaunchKernelGGL(dev::mix_fft_kernel<10>, dim3(grid_fft), dim3(dev::kWave), 0, st, ctx->d_demod,
-                                   ctx->d_nco, ctx->d_twiddle, d_audio, frame_stride, (int)n_frames, s, ctx->d_ws_state,
-                                   ctx->d_ws_fq);
+                                   ctx->d_nco, ctx->d_twiddle, d_audio, frame_stride, d_frame_offset, (int)n_frames, s,
+                                   ctx->d_ws_state, ctx->d_ws_fq);
             else
                 hipLaunchKernelGGL(dev::mix_fft_kernel<9>, dim3(grid_fft), dim3(dev::kWave), 0, st, ctx->d_demod,
-                                   ctx->d_nco, ctx->d_twiddle, d_audio, frame_stride, (int)n_frames, s, ctx->d_ws_state,
-                                   ctx->d_ws_fq);
+                                   ctx->d_nco, ctx->d_twiddle, d_audio, frame_stride, d_frame_offset, (int)n_frames, s,
+                                   ctx->d_ws_state, ctx->d_ws_fq);
         }
         const bool training = s < D.n_train;
         const bool last = (s == n_sym - 1);
@@ -308,6 +311,7 @@ void ultra_hip_destroy(ultra_hip_ctx* ctx) {
     if (ctx->d_nco) (void)hipFree(ctx->d_nco);
     if (ctx->d_twiddle) (void)hipFree(ctx->d_twiddle);
     if (ctx->d_lts) (void)hipFree(ctx->d_lts);
+    if (ctx->d_ws_acq) (void)hipFree(ctx->d_ws_acq);
     if (ctx->d_ws_llr) (void)hipFree(ctx->d_ws_llr);
     if (ctx->d_ws_state) (void)hipFree(ctx->d_ws_state);
     if (ctx->d_ws_fq) (void)hipFree(ctx->d_ws_fq);
@@ -402,6 +406,51 @@ int ultra_hip_acquire_batch(ultra_hip_ctx* ctx, const float* d_audio, size_t str
                            d_fed_at_sync);
     else
         return ULTRA_HIP_ERR_UNSUPPORTED;
+    UH_HIP(hipGetLastError());
+    return ULTRA_HIP_OK;
+}
+
+int ultra_hip_receive_batch(ultra_hip_ctx* ctx, const float* d_audio, size_t stream_stride, uint32_t n_samples,
+                            uint32_t chunk, size_t n_streams, float* d_llr, uint8_t* d_bytes, int32_t* d_iters,
+                            uint8_t* d_ok, uint32_t* d_entry, float* d_cfo_hz) {
+    if (!ctx) return ULTRA_HIP_ERR_INVALID_ARG;
+    if (n_streams == 0) return ULTRA_HIP_OK;
+    if (!d_audio || !d_bytes || !d_iters || !d_ok || n_samples < ctx->geo.frame_samples)
+        return ULTRA_HIP_ERR_INVALID_ARG;
+    if (ctx->cfg.entry != ULTRA_ENTRY_SYNCED || ctx->geo.llrs_per_frame < (uint32_t)kLdpcN) return ULTRA_HIP_ERR_UNSUPPORTED;
+    DeviceGuard guard(ctx->device);
+    if (ctx->ws_acq_frames < n_streams) {
+        if (ctx->d_ws_acq) { UH_HIP(hipStreamSynchronize(ctx->stream)); (void)hipFree(ctx->d_ws_acq); ctx->d_ws_acq = nullptr; }
+        ctx->ws_acq_frames = 0;
+        UH_HIP(hipMalloc(&ctx->d_ws_acq, n_streams * 5 * sizeof(unsigned)));
+        ctx->ws_acq_frames = n_streams;
+    }
+    unsigned* found = ctx->d_ws_acq;
+    unsigned* data_start = found + n_streams;
+    unsigned* entry = d_entry ? d_entry : data_start + n_streams;
+    unsigned* offset = data_start + 2 * n_streams;
+    float* cfo = d_cfo_hz ? d_cfo_hz : reinterpret_cast<float*>(data_start + 3 * n_streams);
+    int rc = ultra_hip_acquire_batch(ctx, d_audio, stream_stride, n_samples, chunk, n_streams, found, data_start, cfo,
+                                     nullptr, nullptr);
+    if (rc != ULTRA_HIP_OK) return rc;
+    const unsigned blocks = (unsigned)((n_streams + 255) / 256);
+    hipLaunchKernelGGL(dev::frame_entry_kernel, dim3(blocks), dim3(256), 0, ctx->stream, found, data_start,
+                       ctx->geo.frame_samples, n_samples, (int)n_streams, entry, offset);
+    float* llr = d_llr;
+    if (!llr) {
+        if (ctx->ws_llr_frames < n_streams) {
+            if (ctx->d_ws_llr) { UH_HIP(hipStreamSynchronize(ctx->stream)); (void)hipFree(ctx->d_ws_llr); ctx->d_ws_llr = nullptr; }
+            UH_HIP(hipMalloc(&ctx->d_ws_llr, n_streams * (size_t)ctx->geo.llrs_per_frame * sizeof(float)));
+            ctx->ws_llr_frames = n_streams;
+        }
+        llr = ctx->d_ws_llr;
+    }
+    rc = launch_demod(ctx, d_audio, stream_stride, cfo, nullptr, n_streams, llr, ctx->geo.llrs_per_frame, nullptr, offset);
+    if (rc != ULTRA_HIP_OK) return rc;
+    rc = launch_ldpc(ctx, llr, ctx->geo.llrs_per_frame, n_streams, d_bytes, d_iters, d_ok, nullptr);
+    if (rc != ULTRA_HIP_OK) return rc;
+    hipLaunchKernelGGL(dev::clear_unusable_kernel, dim3(blocks), dim3(256), 0, ctx->stream, entry, (int)n_streams,
+                       d_bytes, (int)ctx->geo.decoded_bytes, d_iters, d_ok);
     UH_HIP(hipGetLastError());
     return ULTRA_HIP_OK;
 }

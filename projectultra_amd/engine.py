@@ -203,6 +203,30 @@ class ReceiveContext:
                                                out["fed_at_sync"].data_ptr()), "ultra_hip_acquire_batch")
         return out
 
+    def receive(self, audio, chunk: int = 960, want_llr: bool = False):
+        """Raw audio streams [n][n_samples] -> acquisition -> SYNCED demodulation from each stream's own data
+        start and coarse CFO -> LDPC decode (ultra_hip_receive_batch).  Returns device tensors
+        dict(bytes, iters, ok, entry, cfo_hz[, llr]); entry == -1 (0xffffffff) marks streams without a frame."""
+        torch = _torch()
+        audio = self._dev(audio, torch.float32, "audio")
+        if audio.dim() != 2:
+            raise ValueError("audio must be [n_streams][n_samples]")
+        n, ns = audio.shape
+        g = self.geometry
+        out = dict(bytes=torch.empty((n, g.decoded_bytes), dtype=torch.uint8, device=self.device),
+                   iters=torch.empty(n, dtype=torch.int32, device=self.device),
+                   ok=torch.empty(n, dtype=torch.uint8, device=self.device),
+                   entry=torch.empty(n, dtype=torch.int32, device=self.device),
+                   cfo_hz=torch.empty(n, dtype=torch.float32, device=self.device))
+        llr = torch.empty((n, g.llrs_per_frame), dtype=torch.float32, device=self.device) if want_llr else None
+        check(self.lib.ultra_hip_receive_batch(self._ctx, audio.data_ptr(), audio.stride(0), ns, int(chunk), n,
+                                               llr.data_ptr() if want_llr else None, out["bytes"].data_ptr(),
+                                               out["iters"].data_ptr(), out["ok"].data_ptr(), out["entry"].data_ptr(),
+                                               out["cfo_hz"].data_ptr()), "ultra_hip_receive_batch")
+        if want_llr:
+            out["llr"] = llr
+        return out
+
     def set_deinterleave(self, bits_per_symbol: int):
         """RxPipeline::setInterleaverConfig + deinterleaveCodewords (rx_pipeline.cpp:24-31,475-491): every
         codeword is passed through ChannelInterleaver(bits_per_symbol, 648)::deinterleave before it is
