@@ -38,23 +38,30 @@ constexpr unsigned kAcqMinSearch = 4000u, kAcqMaxBuffer = 240000u, kAcqOverlap =
 template <int LOG2N>
 struct AcqShared {
     static constexpr int N = 1 << LOG2N;
-    c32 X[N];                     // FFT work buffer (in place)
-    c32 tw[N / 2];                // twiddle table
     union {
-        float samp[N];            // window samples (dc sum)
-        float terms[N / 2][4];    // per-index terms of the four correlation sums
+        c32 X[N];                 // FFT work buffer (in place)
+        float samp[N];            // window samples for the dc sum (before the FFT input is written)
+        float terms[N / 2][4];    // per-index terms of the four correlation sums (after the analytic signal is read)
     };
+    c32 tw[N / 2];                // twiddle table
 };
 
-// s = 0; s += a[0]; s += a[1]; ... in order, every lane (broadcast reads); n multiple of 4
+// s = 0; s += a[0]; s += a[1]; ... in order, every lane (broadcast reads); n a multiple of 16.
+// The next 16 terms are requested before the current 16 are added, so the serial chain of adds
+// (the floor: one add per term) runs without waiting for LDS.
 __device__ __forceinline__ float acq_ordered_sum(const float* a, int n) {
     float s = 0.0f;
+    float4 cur[4], nxt[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) cur[u] = *reinterpret_cast<const float4*>(a + 4 * u);
     for (int i = 0; i < n; i += 16) {
-        float4 q[4];
+        const int j = (i + 16 < n) ? i + 16 : i;            // last round re-reads its own block (unused)
 #pragma unroll
-        for (int u = 0; u < 4; ++u) q[u] = (i + 4 * u < n) ? *reinterpret_cast<const float4*>(a + i + 4 * u) : make_float4(-0.0f, -0.0f, -0.0f, -0.0f);
+        for (int u = 0; u < 4; ++u) nxt[u] = *reinterpret_cast<const float4*>(a + j + 4 * u);
 #pragma unroll
-        for (int u = 0; u < 4; ++u) { s += q[u].x; s += q[u].y; s += q[u].z; s += q[u].w; }   // -0.0f pads are exact no-ops
+        for (int u = 0; u < 4; ++u) { s += cur[u].x; s += cur[u].y; s += cur[u].z; s += cur[u].w; }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) cur[u] = nxt[u];
     }
     return s;
 }
@@ -121,27 +128,37 @@ __device__ __forceinline__ void acq_analytic(AcqShared<LOG2N>& sh, const float* 
     acq_fft_stages<LOG2N, true>(sh);
 }
 
-// P = sum conj(a[i]) a[i+half], R1 = sum |a[i]|^2, R2 = sum |a[i+half]|^2 in index order
+// P = sum conj(a[i]) a[i+half], R1 = sum |a[i]|^2, R2 = sum |a[i+half]|^2 in index order.
+// The terms overwrite the analytic signal (same LDS): all of it is read into registers first.
 template <int LOG2N>
 __device__ __forceinline__ void acq_half_sums(AcqShared<LOG2N>& sh, c32* P, float* R1, float* R2) {
     constexpr int N = 1 << LOG2N, H = N / 2;
     const int lane = threadIdx.x;
+    float4 t4[H / 64];
 #pragma unroll
     for (int q = 0; q < H / 64; ++q) {
         const int i = lane + 64 * q;
         const c32 x = sh.X[i], y = sh.X[i + H];
         const c32 t = cmul(cconj(x), y);
-        *reinterpret_cast<float4*>(&sh.terms[i][0]) = make_float4(t.re, t.im, cnorm(x), cnorm(y));
+        t4[q] = make_float4(t.re, t.im, cnorm(x), cnorm(y));
     }
+    wave_sync();
+#pragma unroll
+    for (int q = 0; q < H / 64; ++q) *reinterpret_cast<float4*>(&sh.terms[lane + 64 * q][0]) = t4[q];
     wave_sync();
     const int col = lane & 3;                       // four chains in four lanes
     float acc = 0.0f;
+    float cur[8], nxt[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) cur[u] = sh.terms[u][col];
     for (int i = 0; i < H; i += 8) {
-        float t[8];
+        const int j = (i + 8 < H) ? i + 8 : i;
 #pragma unroll
-        for (int u = 0; u < 8; ++u) t[u] = sh.terms[i + u][col];
+        for (int u = 0; u < 8; ++u) nxt[u] = sh.terms[j + u][col];
 #pragma unroll
-        for (int u = 0; u < 8; ++u) acc += t[u];
+        for (int u = 0; u < 8; ++u) acc += cur[u];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) cur[u] = nxt[u];
     }
     *P = mk(lane_f(acc, 0), lane_f(acc, 1));
     *R1 = lane_f(acc, 2);
@@ -264,7 +281,7 @@ __device__ __forceinline__ unsigned acq_refine_lts(const DemodConst& D, const fl
 }
 
 template <int LOG2N>
-__global__ __launch_bounds__(kWave, 2) void acquire_kernel(
+__global__ __launch_bounds__(kWave, 3) void acquire_kernel(
     const DemodConst* __restrict__ Dp, const c32* __restrict__ twiddle, const float* __restrict__ lts_I,
     const float* __restrict__ lts_Q, float energy_ref, float sync_threshold, const float* __restrict__ audio,
     size_t stream_stride, unsigned n_samples, unsigned chunk, int n_streams, unsigned* __restrict__ found_out,
