@@ -38,12 +38,25 @@ constexpr unsigned kAcqMinSearch = 4000u, kAcqMaxBuffer = 240000u, kAcqOverlap =
 template <int LOG2N>
 struct AcqShared {
     static constexpr int N = 1 << LOG2N;
+    static constexpr int P = N / kWave;                     // points per lane: 8 / 16
+    static constexpr int A = (P == 16) ? 4 : 3;             // log2(P)
+    static constexpr int kTwB = P * ((1 << A) - 1);
+    // audio window of the LTS matched filter: 3 symbols back, half a symbol forward, one template
+    // long (4.5 preamble symbols, cyclic prefix <= N/8).  It overlays everything else (the matched
+    // filter runs once per stream, after the search); the twiddle tables are reloaded afterwards.
+    static constexpr int kLtsWin = (N + N / 8) * 9 / 2;
     union {
-        c32 X[N];                 // FFT work buffer (in place)
-        float samp[N];            // window samples for the dc sum (before the FFT input is written)
-        float terms[N / 2][4];    // per-index terms of the four correlation sums (after the analytic signal is read)
+        struct {
+            union {
+                c32 X[N + N / P];         // FFT exchange buffer, 1 pad per P entries
+                float samp[N];            // window samples for the dc sum (before the FFT input is taken)
+                float terms[N / 2][4];    // per-index terms of the four correlation sums (analytic signal in registers)
+            };
+            c32 twB[kTwB];                // twiddles of stages A..2A-1, one contiguous run per stage (as in mix_fft_kernel)
+            c32 tw[N / 2];                // full twiddle table (stages 0..A-1 uniform reads, stages 2A.. per lane)
+        };
+        float lts_win[kLtsWin];
     };
-    c32 tw[N / 2];                // twiddle table
 };
 
 // s = 0; s += a[0]; s += a[1]; ... in order, every lane (broadcast reads); n a multiple of 16.
@@ -51,6 +64,7 @@ struct AcqShared {
 // (the floor: one add per term) runs without waiting for LDS.
 __device__ __forceinline__ float acq_ordered_sum(const float* a, int n) {
     float s = 0.0f;
+    if (threadIdx.x == 0) {                                  // one lane walks: a masked ds_read_b128 costs one LDS cycle, not four
     float4 cur[4], nxt[4];
 #pragma unroll
     for (int u = 0; u < 4; ++u) cur[u] = *reinterpret_cast<const float4*>(a + 4 * u);
@@ -63,104 +77,134 @@ __device__ __forceinline__ float acq_ordered_sum(const float* a, int n) {
 #pragma unroll
         for (int u = 0; u < 4; ++u) cur[u] = nxt[u];
     }
-    return s;
+    }
+    return lane_f(s, 0);
 }
 
-// In-place radix-2 DIT on bit-reversed input (FFT::fft_impl after its permutation), INVERSE: conj
-// twiddles and 1/N scaling.  Lane handles butterflies b = lane + 64 q of every stage.
+// Radix-2 DIT exactly as FFT::fft_impl (src/dsp/fft.cpp:89-121), register-resident like the FFT of
+// mix_fft_kernel: in: v[q] = element P*lane + q of the bit-reversed input; three groups of stages on
+// P register-resident points with two LDS transposes in between; out: v[t] = X[lane + 64*t].
+// INVERSE: conjugated twiddles and the 1/N scaling.
 template <int LOG2N, bool INVERSE>
-__device__ __forceinline__ void acq_fft_stages(AcqShared<LOG2N>& sh) {
-    constexpr int N = 1 << LOG2N;
+__device__ __forceinline__ void acq_fft(AcqShared<LOG2N>& sh, c32 (&v)[AcqShared<LOG2N>::P]) {
+    using S = AcqShared<LOG2N>;
+    constexpr int N = S::N, P = S::P, A = S::A;
     const int lane = threadIdx.x;
-    for (int s = 0; s < LOG2N; ++s) {
+    auto tw = [](c32 w) { return INVERSE ? cconj(w) : w; };
+#pragma unroll
+    for (int s = 0; s < A; ++s) {                            // stages 0..A-1, wave-uniform twiddles
         const int half = 1 << s;
 #pragma unroll
-        for (int q = 0; q < N / 128; ++q) {
-            const int b = lane + 64 * q;
-            const int k = b & (half - 1);
-            const int i0 = ((b >> s) << (s + 1)) + k, i1 = i0 + half;
-            c32 w = sh.tw[k << (LOG2N - 1 - s)];
-            if (INVERSE) w = cconj(w);
-            const c32 a = sh.X[i0], t = cmul(w, sh.X[i1]);
-            sh.X[i1] = csub(a, t);
-            sh.X[i0] = cadd(a, t);
+        for (int q = 0; q < P; ++q) {
+            if (q & half) continue;
+            const c32 w = tw(sh.tw[(q & (half - 1)) << (LOG2N - 1 - s)]);
+            UH_BUTTERFLY(v[q], v[q + half], w);
         }
-        wave_sync();
+    }
+#pragma unroll
+    for (int q = 0; q < P; ++q) { const int i = P * lane + q; sh.X[i + (i >> A)] = v[q]; }
+    wave_sync();
+    {
+        const int blk = lane / P, r = lane % P;              // stages A..2A-1 on X[blk*P*P + r + P*j]
+#pragma unroll
+        for (int j = 0; j < P; ++j) { const int i = blk * P * P + r + P * j; v[j] = sh.X[i + (i >> A)]; }
+#pragma unroll
+        for (int s = A; s < 2 * A; ++s) {
+            const int hj = 1 << (s - A);
+#pragma unroll
+            for (int j = 0; j < P; ++j) {
+                if (j & hj) continue;
+                const int k = r + P * (j & (hj - 1));
+                const c32 w = tw(sh.twB[P * (hj - 1) + k]);
+                UH_BUTTERFLY(v[j], v[j + hj], w);
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < P; ++j) { const int i = blk * P * P + r + P * j; sh.X[i + (i >> A)] = v[j]; }
+    }
+    wave_sync();
+#pragma unroll
+    for (int t = 0; t < P; ++t) { const int i = lane + 64 * t; v[t] = sh.X[i + (i >> A)]; }
+#pragma unroll
+    for (int s = 2 * A; s < LOG2N; ++s) {                    // stages 2A..LOG2N-1 on X[lane + 64*t]
+        const int ht = 1 << (s - 6);
+#pragma unroll
+        for (int t = 0; t < P; ++t) {
+            if (t & ht) continue;
+            const int k = lane + 64 * (t & (ht - 1));
+            const c32 w = tw(sh.tw[k << (LOG2N - 1 - s)]);
+            UH_BUTTERFLY(v[t], v[t + ht], w);
+        }
     }
     if (INVERSE) {
         const float scale = 1.0f / (float)N;
 #pragma unroll
-        for (int q = 0; q < N / 64; ++q) { const int i = lane + 64 * q; sh.X[i] = cscale(sh.X[i], scale); }
-        wave_sync();
+        for (int t = 0; t < P; ++t) v[t] = cscale(v[t], scale);
     }
+    wave_sync();                                             // X is free again
 }
 
-// Impl::toAnalytic for len == fft_size: samples (minus dc) -> analytic signal in sh.X (natural order)
+// Impl::toAnalytic for len == fft_size.  in: xs[qp] = sample rl + 64*qp of the window (rl =
+// bitrev6(lane)), dc subtracted here; out: v[t] = analytic[lane + 64*t].
 template <int LOG2N>
-__device__ __forceinline__ void acq_analytic(AcqShared<LOG2N>& sh, const float* __restrict__ win, float dc) {
-    constexpr int N = 1 << LOG2N;
+__device__ __forceinline__ void acq_analytic(AcqShared<LOG2N>& sh, const float (&xs)[AcqShared<LOG2N>::P], float dc,
+                                             c32 (&v)[AcqShared<LOG2N>::P]) {
+    using S = AcqShared<LOG2N>;
+    constexpr int N = S::N, P = S::P, A = S::A;
     const int lane = threadIdx.x;
+    const int rl = (int)(__brev((unsigned)lane) >> 26);
 #pragma unroll
-    for (int q = 0; q < N / 64; ++q) {
-        const int i = lane + 64 * q;
-        const int r = (int)(__brev((unsigned)i) >> (32 - LOG2N));
-        sh.X[r] = mk(win[i] - dc, 0.0f);
-    }
-    wave_sync();
-    acq_fft_stages<LOG2N, false>(sh);
-    // freq[1..N/2) *= 2, freq(N/2..N) = 0, then the inverse transform's bit reversal
-    c32 v[N / 64];
+    for (int qp = 0; qp < P; ++qp) v[bitrev_small<A>(qp)] = mk(xs[qp] - dc, 0.0f);
+    acq_fft<LOG2N, false>(sh, v);
+    // freq[1..N/2) *= 2, freq(N/2..N) = 0; then the inverse transform's bit reversal: its input element
+    // P*lane + q is freq[bitrev(P*lane + q)] = freq[64*bitrev_A(q) + rl], i.e. register bitrev_A(q) of lane rl
 #pragma unroll
-    for (int q = 0; q < N / 64; ++q) {
-        const int i = lane + 64 * q;
-        c32 f = sh.X[i];
+    for (int t = 0; t < P; ++t) {
+        const int i = lane + 64 * t;
+        c32 f = v[t];
         if (i >= 1 && i < N / 2) f = cscale(f, 2.0f);
         if (i > N / 2) f = mk(0.0f, 0.0f);
-        v[q] = f;
+        sh.X[i + (i >> A)] = f;
     }
     wave_sync();
 #pragma unroll
-    for (int q = 0; q < N / 64; ++q) {
-        const int i = lane + 64 * q;
-        sh.X[(int)(__brev((unsigned)i) >> (32 - LOG2N))] = v[q];
-    }
+    for (int q = 0; q < P; ++q) { const int i = rl + 64 * bitrev_small<A>(q); v[q] = sh.X[i + (i >> A)]; }
     wave_sync();
-    acq_fft_stages<LOG2N, true>(sh);
+    acq_fft<LOG2N, true>(sh, v);
 }
 
-// P = sum conj(a[i]) a[i+half], R1 = sum |a[i]|^2, R2 = sum |a[i+half]|^2 in index order.
-// The terms overwrite the analytic signal (same LDS): all of it is read into registers first.
+// P = sum conj(a[i]) a[i+half], R1 = sum |a[i]|^2, R2 = sum |a[i+half]|^2 in index order; a[lane + 64 t]
+// = v[t], so a[i] and a[i + N/2] sit in the same lane (registers t and t + P/2).
 template <int LOG2N>
-__device__ __forceinline__ void acq_half_sums(AcqShared<LOG2N>& sh, c32* P, float* R1, float* R2) {
-    constexpr int N = 1 << LOG2N, H = N / 2;
+__device__ __forceinline__ void acq_half_sums(AcqShared<LOG2N>& sh, const c32 (&v)[AcqShared<LOG2N>::P], c32* Pout,
+                                              float* R1, float* R2) {
+    using S = AcqShared<LOG2N>;
+    constexpr int N = S::N, P = S::P, H = N / 2;
     const int lane = threadIdx.x;
-    float4 t4[H / 64];
 #pragma unroll
-    for (int q = 0; q < H / 64; ++q) {
-        const int i = lane + 64 * q;
-        const c32 x = sh.X[i], y = sh.X[i + H];
-        const c32 t = cmul(cconj(x), y);
-        t4[q] = make_float4(t.re, t.im, cnorm(x), cnorm(y));
+    for (int t = 0; t < P / 2; ++t) {
+        const c32 x = v[t], y = v[t + P / 2];
+        const c32 m = cmul(cconj(x), y);
+        *reinterpret_cast<float4*>(&sh.terms[lane + 64 * t][0]) = make_float4(m.re, m.im, cnorm(x), cnorm(y));
     }
     wave_sync();
-#pragma unroll
-    for (int q = 0; q < H / 64; ++q) *reinterpret_cast<float4*>(&sh.terms[lane + 64 * q][0]) = t4[q];
-    wave_sync();
-    const int col = lane & 3;                       // four chains in four lanes
+    const int col = lane & 3;                       // four chains in four lanes (the others are masked off)
     float acc = 0.0f;
-    float cur[8], nxt[8];
+    if (lane < 4) {
+        float cur[8], nxt[8];
 #pragma unroll
-    for (int u = 0; u < 8; ++u) cur[u] = sh.terms[u][col];
-    for (int i = 0; i < H; i += 8) {
-        const int j = (i + 8 < H) ? i + 8 : i;
+        for (int u = 0; u < 8; ++u) cur[u] = sh.terms[u][col];
+        for (int i = 0; i < H; i += 8) {
+            const int j = (i + 8 < H) ? i + 8 : i;
 #pragma unroll
-        for (int u = 0; u < 8; ++u) nxt[u] = sh.terms[j + u][col];
+            for (int u = 0; u < 8; ++u) nxt[u] = sh.terms[j + u][col];
 #pragma unroll
-        for (int u = 0; u < 8; ++u) acc += cur[u];
+            for (int u = 0; u < 8; ++u) acc += cur[u];
 #pragma unroll
-        for (int u = 0; u < 8; ++u) cur[u] = nxt[u];
+            for (int u = 0; u < 8; ++u) cur[u] = nxt[u];
+        }
     }
-    *P = mk(lane_f(acc, 0), lane_f(acc, 1));
+    *Pout = mk(lane_f(acc, 0), lane_f(acc, 1));
     *R1 = lane_f(acc, 2);
     *R2 = lane_f(acc, 3);
     wave_sync();
@@ -174,18 +218,22 @@ __device__ __forceinline__ float acq_sc(AcqShared<LOG2N>& sh, const float* __res
     const int lane = threadIdx.x;
     if (offset + (unsigned)cp + (unsigned)N > size) return 0.0f;
     const float* win = buf + offset + cp;
+    constexpr int P = AcqShared<LOG2N>::P;
+    const int rl = (int)(__brev((unsigned)lane) >> 26);
+    float xs[P];
 #pragma unroll
-    for (int q = 0; q < N / 64; ++q) sh.samp[lane + 64 * q] = win[lane + 64 * q];
+    for (int qp = 0; qp < P; ++qp) { xs[qp] = win[rl + 64 * qp]; sh.samp[rl + 64 * qp] = xs[qp]; }
     wave_sync();
     const float dc_sum = acq_ordered_sum(sh.samp, N);
     const float dc = dc_sum / (float)N;
     wave_sync();
-    acq_analytic<LOG2N>(sh, win, dc);
-    c32 P; float R1, R2;
-    acq_half_sums<LOG2N>(sh, &P, &R1, &R2);
+    c32 v[P];
+    acq_analytic<LOG2N>(sh, xs, dc, v);
+    c32 P_; float R1, R2;
+    acq_half_sums<LOG2N>(sh, v, &P_, &R1, &R2);
     const float normalization = sqrtf(R1 * R2);
     if (normalization < 1e-10f) return 0.0f;
-    return cabs_(P) / normalization;
+    return cabs_(P_) / normalization;
 }
 
 // Impl::hasMinimumEnergy
@@ -219,9 +267,15 @@ __device__ __forceinline__ float acq_coarse_cfo(AcqShared<LOG2N>& sh, const Demo
     constexpr int N = 1 << LOG2N;
     const unsigned ds = sync_offset + (unsigned)D.cp;
     if (ds + (unsigned)N > size) return 0.0f;
-    acq_analytic<LOG2N>(sh, buf + ds, 0.0f);          // x - 0.0f == x for every float (also -0.0f)
+    constexpr int PP = AcqShared<LOG2N>::P;
+    const int rl = (int)(__brev((unsigned)threadIdx.x) >> 26);
+    float xs[PP];
+#pragma unroll
+    for (int qp = 0; qp < PP; ++qp) xs[qp] = buf[ds + rl + 64 * qp];
+    c32 v[PP];
+    acq_analytic<LOG2N>(sh, xs, 0.0f, v);              // x - 0.0f == x for every float (also -0.0f)
     c32 P; float R1, R2;
-    acq_half_sums<LOG2N>(sh, &P, &R1, &R2);
+    acq_half_sums<LOG2N>(sh, v, &P, &R1, &R2);
     const float phase = um::atan2f_(P.im, P.re);
     // float cfo_hz = phase * config.sample_rate / (M_PI * fft_len): float * uint32 -> float, then / double
     const float cfo_hz = (float)((double)(phase * D.sample_rate) / (kPi * (double)N));
@@ -231,7 +285,7 @@ __device__ __forceinline__ float acq_coarse_cfo(AcqShared<LOG2N>& sh, const Demo
 
 // Impl::refineLTSTiming; returns 0xffffffff on failure.  Lane l evaluates offsets first + l + 64 r.
 template <int LOG2N>
-__device__ __forceinline__ unsigned acq_refine_lts(const DemodConst& D, const float* __restrict__ lts_I,
+__device__ __forceinline__ unsigned acq_refine_lts(AcqShared<LOG2N>& sh, const DemodConst& D, const float* __restrict__ lts_I,
                                                    const float* __restrict__ lts_Q, float energy_ref,
                                                    const float* __restrict__ buf, unsigned size, unsigned sts_start) {
     constexpr int N = 1 << LOG2N;
@@ -241,15 +295,21 @@ __device__ __forceinline__ unsigned acq_refine_lts(const DemodConst& D, const fl
     const unsigned coarse = sts_start + 4u * psl;
     const int back = (int)(3u * psl), fwd = (int)(psl / 2u);
     if (coarse < (unsigned)back || coarse + (unsigned)fwd + lts_len > size) return coarse;
+    // the whole search window goes to LDS once: lane l at tap i reads sample l + i of it (global loads
+    // inside the tap loop left the wave waiting on memory for most of this function)
+    const unsigned win0 = coarse - (unsigned)back, win_len = (unsigned)(back + fwd) + lts_len;
+    for (unsigned i = lane; i < win_len; i += kWave) sh.lts_win[i] = buf[win0 + i];
+    wave_sync();
     float best_corr = 0.0f;
     unsigned best_off = coarse;
     const int n_off = back + fwd + 1;
     for (int r0 = 0; r0 < n_off; r0 += 64) {
         const int idx = r0 + lane;
         const bool on = idx < n_off;
-        const unsigned offset = coarse - (unsigned)back + (unsigned)(on ? idx : 0);
+        const int rel = on ? idx : 0;
+        const unsigned offset = win0 + (unsigned)rel;
         float ci = 0.0f, cq = 0.0f, er = 0.0f;
-        const float* p = buf + offset;
+        const float* p = sh.lts_win + rel;
         for (unsigned i = 0; i < lts_len; i += 4) {
             float rx[4];
 #pragma unroll
@@ -267,6 +327,7 @@ __device__ __forceinline__ unsigned acq_refine_lts(const DemodConst& D, const fl
         const float corr = (norm > 1e-6f) ? corr_mag / norm : 0.0f;
         if (on && corr > best_corr) { best_corr = corr; best_off = offset; }
     }
+    wave_sync();
     // first occurrence of the maximum over all offsets = max corr, smallest offset among equals
     float m = best_corr;
 #pragma unroll
@@ -281,7 +342,7 @@ __device__ __forceinline__ unsigned acq_refine_lts(const DemodConst& D, const fl
 }
 
 template <int LOG2N>
-__global__ __launch_bounds__(kWave, 3) void acquire_kernel(
+__global__ __launch_bounds__(kWave, 2) void acquire_kernel(
     const DemodConst* __restrict__ Dp, const c32* __restrict__ twiddle, const float* __restrict__ lts_I,
     const float* __restrict__ lts_Q, float energy_ref, float sync_threshold, const float* __restrict__ audio,
     size_t stream_stride, unsigned n_samples, unsigned chunk, int n_streams, unsigned* __restrict__ found_out,
@@ -291,8 +352,17 @@ __global__ __launch_bounds__(kWave, 3) void acquire_kernel(
     __shared__ AcqShared<LOG2N> sh;
     const DemodConst& D = *Dp;
     const int lane = threadIdx.x;
-    for (int i = lane; i < N / 2; i += kWave) sh.tw[i] = twiddle[i];
-    wave_sync();
+    auto load_tables = [&]() {
+        constexpr int P = AcqShared<LOG2N>::P, A = AcqShared<LOG2N>::A;
+        for (int i = lane; i < N / 2; i += kWave) sh.tw[i] = twiddle[i];
+        for (int idx = lane; idx < AcqShared<LOG2N>::kTwB; idx += kWave) {
+            const int sA = 31 - __clz(idx / P + 1);          // stage - A: runs start at P*(2^sA - 1)
+            const int k = idx - P * ((1 << sA) - 1);
+            sh.twB[idx] = twiddle[k << (LOG2N - 1 - (A + sA))];
+        }
+        wave_sync();
+    };
+    load_tables();
     const unsigned psl = (unsigned)(N + D.cp), preamble_total = psl * 6u, corr_win = psl * 2u;
     for (int stream = blockIdx.x; stream < n_streams; stream += gridDim.x) {
         const float* all = audio + (size_t)stream * stream_stride;
@@ -323,7 +393,8 @@ __global__ __launch_bounds__(kWave, 3) void acquire_kernel(
             }
             if (found_sync) {
                 const float c0 = acq_coarse_cfo<LOG2N>(sh, D, buf, size, so);
-                const unsigned refined = acq_refine_lts<LOG2N>(D, lts_I, lts_Q, energy_ref, buf, size, so);
+                const unsigned refined = acq_refine_lts<LOG2N>(sh, D, lts_I, lts_Q, energy_ref, buf, size, so);
+                load_tables();                               // the matched filter's window overlaid them
                 if (refined == 0xffffffffu) {
                     if (size > kAcqOverlap * 2u) {
                         unsigned trim = so + psl;
