@@ -210,30 +210,33 @@ __device__ __forceinline__ void acq_half_sums(AcqShared<LOG2N>& sh, const c32 (&
     wave_sync();
 }
 
-// Impl::measureSchmidlCoxCorrelation (buf = rx_buffer view, size = its length)
+// The half-symbol autocorrelation of the analytic signal of the N samples at `win`: P, R1, R2.
+// remove_dc: subtract the mean first (measureSchmidlCoxCorrelation, ofdm_sync.cpp:131-140);
+// estimateCoarseCFO (:241) takes the raw samples.  ONE instance of this code serves the search, the
+// plateau scan and the CFO estimate (see the state machine in acquire_kernel): three inlined copies
+// cost 239 VGPRs.
 template <int LOG2N>
-__device__ __forceinline__ float acq_sc(AcqShared<LOG2N>& sh, const float* __restrict__ buf, unsigned size,
-                                        unsigned offset, int cp) {
+__device__ __forceinline__ void acq_window_metric(AcqShared<LOG2N>& sh, const float* __restrict__ win, bool remove_dc,
+                                                  c32* P_out, float* R1, float* R2) {
     constexpr int N = 1 << LOG2N;
-    const int lane = threadIdx.x;
-    if (offset + (unsigned)cp + (unsigned)N > size) return 0.0f;
-    const float* win = buf + offset + cp;
     constexpr int P = AcqShared<LOG2N>::P;
+    const int lane = threadIdx.x;
     const int rl = (int)(__brev((unsigned)lane) >> 26);
     float xs[P];
 #pragma unroll
-    for (int qp = 0; qp < P; ++qp) { xs[qp] = win[rl + 64 * qp]; sh.samp[rl + 64 * qp] = xs[qp]; }
-    wave_sync();
-    const float dc_sum = acq_ordered_sum(sh.samp, N);
-    const float dc = dc_sum / (float)N;
-    wave_sync();
+    for (int qp = 0; qp < P; ++qp) xs[qp] = win[rl + 64 * qp];
+    float dc = 0.0f;                                         // x - 0.0f == x for every float (also -0.0f)
+    if (remove_dc) {
+#pragma unroll
+        for (int qp = 0; qp < P; ++qp) sh.samp[rl + 64 * qp] = xs[qp];
+        wave_sync();
+        const float dc_sum = acq_ordered_sum(sh.samp, N);
+        dc = dc_sum / (float)N;
+        wave_sync();
+    }
     c32 v[P];
     acq_analytic<LOG2N>(sh, xs, dc, v);
-    c32 P_; float R1, R2;
-    acq_half_sums<LOG2N>(sh, v, &P_, &R1, &R2);
-    const float normalization = sqrtf(R1 * R2);
-    if (normalization < 1e-10f) return 0.0f;
-    return cabs_(P_) / normalization;
+    acq_half_sums<LOG2N>(sh, v, P_out, R1, R2);
 }
 
 // Impl::hasMinimumEnergy
@@ -258,29 +261,6 @@ __device__ __forceinline__ bool acq_has_energy(AcqShared<LOG2N>& sh, const float
     else if (energy < noise_floor * 3.0f) noise_floor = (1.0f - 0.01f) * noise_floor + 0.01f * energy;
     const float threshold = noise_floor * 4.0f;
     return energy >= threshold;
-}
-
-// Impl::estimateCoarseCFO
-template <int LOG2N>
-__device__ __forceinline__ float acq_coarse_cfo(AcqShared<LOG2N>& sh, const DemodConst& D, const float* __restrict__ buf,
-                                                unsigned size, unsigned sync_offset) {
-    constexpr int N = 1 << LOG2N;
-    const unsigned ds = sync_offset + (unsigned)D.cp;
-    if (ds + (unsigned)N > size) return 0.0f;
-    constexpr int PP = AcqShared<LOG2N>::P;
-    const int rl = (int)(__brev((unsigned)threadIdx.x) >> 26);
-    float xs[PP];
-#pragma unroll
-    for (int qp = 0; qp < PP; ++qp) xs[qp] = buf[ds + rl + 64 * qp];
-    c32 v[PP];
-    acq_analytic<LOG2N>(sh, xs, 0.0f, v);              // x - 0.0f == x for every float (also -0.0f)
-    c32 P; float R1, R2;
-    acq_half_sums<LOG2N>(sh, v, &P, &R1, &R2);
-    const float phase = um::atan2f_(P.im, P.re);
-    // float cfo_hz = phase * config.sample_rate / (M_PI * fft_len): float * uint32 -> float, then / double
-    const float cfo_hz = (float)((double)(phase * D.sample_rate) / (kPi * (double)N));
-    const float max_cfo = (float)((unsigned)D.sample_rate / (unsigned)N);     // integer division in the reference
-    return fmax_std(-max_cfo, fmin_std(max_cfo, cfo_hz));
 }
 
 // Impl::refineLTSTiming; returns 0xffffffff on failure.  Lane l evaluates offsets first + l + 64 r.
@@ -342,7 +322,7 @@ __device__ __forceinline__ unsigned acq_refine_lts(AcqShared<LOG2N>& sh, const D
 }
 
 template <int LOG2N>
-__global__ __launch_bounds__(kWave, 2) void acquire_kernel(
+__global__ __launch_bounds__(kWave, 3) void acquire_kernel(
     const DemodConst* __restrict__ Dp, const c32* __restrict__ twiddle, const float* __restrict__ lts_I,
     const float* __restrict__ lts_Q, float energy_ref, float sync_threshold, const float* __restrict__ audio,
     size_t stream_stride, unsigned n_samples, unsigned chunk, int n_streams, unsigned* __restrict__ found_out,
@@ -374,25 +354,64 @@ __global__ __launch_bounds__(kWave, 2) void acquire_kernel(
             if (size < kAcqMinSearch) continue;
             if (size > kAcqMaxBuffer) { base = fed - kAcqOverlap; size = kAcqOverlap; }
             const float* buf = all + base;
+            // The search (demodulator.cpp:497-531) as a state machine with ONE metric evaluation per turn:
+            //   SEARCH   candidate i passes the energy gate -> metric at i; above threshold -> PLATEAU
+            //   PLATEAU  metrics at i + j, j = 0, 8, .. <= 300 while i + j + preamble < size; then the verdict
+            //   CFO      estimateCoarseCFO's correlation at the chosen offset (no dc removal), then done
             bool found_sync = false;
             unsigned so = 0;
+            float c0 = 0.0f;
             const unsigned search_end = (size > preamble_total + corr_win) ? size - preamble_total - corr_win : 0u;
-            for (unsigned i = 0; i < search_end; i += kAcqStep) {
-                if (!acq_has_energy<LOG2N>(sh, buf, size, i, corr_win, noise_floor)) { i += corr_win / 2u - kAcqStep; continue; }
-                const float corr = acq_sc<LOG2N>(sh, buf, size, i, D.cp);
-                if (corr > sync_threshold) {
-                    unsigned plateau = 0, peak_pos = i;
-                    float peak = corr;
-                    for (unsigned j = 0; j <= kAcqPlateauWindow && i + j + preamble_total < size; j += 8u) {
-                        const float rc = acq_sc<LOG2N>(sh, buf, size, i + j, D.cp);
-                        if (rc >= 0.90f) plateau++;
-                        if (rc > peak) { peak = rc; peak_pos = i + j; }
+            enum { kSearch, kPlateau, kCfo };
+            int mode = kSearch;
+            unsigned i = 0, j = 0, plateau = 0, peak_pos = 0;
+            float peak = 0.0f;
+            for (;;) {
+                unsigned off;
+                if (mode == kSearch) {
+                    if (i >= search_end) break;
+                    if (!acq_has_energy<LOG2N>(sh, buf, size, i, corr_win, noise_floor)) { i += corr_win / 2u; continue; }
+                    off = i;
+                } else if (mode == kPlateau) {
+                    if (!(j <= kAcqPlateauWindow && i + j + preamble_total < size)) {
+                        if (plateau >= kAcqMinPlateau) { so = peak_pos; mode = kCfo; continue; }
+                        mode = kSearch; i += kAcqStep; continue;
                     }
-                    if (plateau >= kAcqMinPlateau) { found_sync = true; so = peak_pos; break; }
+                    off = i + j;
+                } else {
+                    off = so;
+                }
+                // measureSchmidlCoxCorrelation / estimateCoarseCFO: window starts cp after the offset
+                const bool in_range = off + (unsigned)D.cp + (unsigned)N <= size;
+                c32 Pm = mk(0.0f, 0.0f);
+                float R1 = 0.0f, R2 = 0.0f;
+                if (in_range) acq_window_metric<LOG2N>(sh, buf + off + D.cp, mode != kCfo, &Pm, &R1, &R2);
+                if (mode == kCfo) {
+                    if (in_range) {
+                        const float phase = um::atan2f_(Pm.im, Pm.re);
+                        // float cfo_hz = phase * config.sample_rate / (M_PI * fft_len): float * uint32 -> float, / double
+                        const float cfo_hz = (float)((double)(phase * D.sample_rate) / (kPi * (double)N));
+                        const float max_cfo = (float)((unsigned)D.sample_rate / (unsigned)N);   // integer division in the reference
+                        c0 = fmax_std(-max_cfo, fmin_std(max_cfo, cfo_hz));
+                    }
+                    found_sync = true;
+                    break;
+                }
+                float corr = 0.0f;
+                if (in_range) {
+                    const float normalization = sqrtf(R1 * R2);
+                    corr = (normalization < 1e-10f) ? 0.0f : cabs_(Pm) / normalization;
+                }
+                if (mode == kSearch) {
+                    if (corr > sync_threshold) { mode = kPlateau; j = 0; plateau = 0; peak = corr; peak_pos = i; }
+                    else i += kAcqStep;
+                } else {
+                    if (corr >= 0.90f) plateau++;
+                    if (corr > peak) { peak = corr; peak_pos = i + j; }
+                    j += 8u;
                 }
             }
             if (found_sync) {
-                const float c0 = acq_coarse_cfo<LOG2N>(sh, D, buf, size, so);
                 const unsigned refined = acq_refine_lts<LOG2N>(sh, D, lts_I, lts_Q, energy_ref, buf, size, so);
                 load_tables();                               // the matched filter's window overlaid them
                 if (refined == 0xffffffffu) {
