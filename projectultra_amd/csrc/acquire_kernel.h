@@ -41,44 +41,35 @@ struct AcqShared {
     static constexpr int P = N / kWave;                     // points per lane: 8 / 16
     static constexpr int A = (P == 16) ? 4 : 3;             // log2(P)
     static constexpr int kTwB = P * ((1 << A) - 1);
-    // audio window of the LTS matched filter: 3 symbols back, half a symbol forward, one template
-    // long (4.5 preamble symbols, cyclic prefix <= N/8).  It overlays everything else (the matched
-    // filter runs once per stream, after the search); the twiddle tables are reloaded afterwards.
-    static constexpr int kLtsWin = (N + N / 8) * 9 / 2;
+    static constexpr int kTwA = (1 << A) - 1;               // wave-uniform twiddles of stages 0..A-1, one run per stage
     union {
-        struct {
-            union {
-                c32 X[N + N / P];         // FFT exchange buffer, 1 pad per P entries
-                float samp[N];            // window samples for the dc sum (before the FFT input is taken)
-                float terms[N / 2][4];    // per-index terms of the four correlation sums (analytic signal in registers)
-            };
-            c32 twB[kTwB];                // twiddles of stages A..2A-1, one contiguous run per stage (as in mix_fft_kernel)
-            c32 tw[N / 2];                // full twiddle table (stages 0..A-1 uniform reads, stages 2A.. per lane)
-        };
-        float lts_win[kLtsWin];
+        c32 X[N + N / P];             // FFT exchange buffer, 1 pad per P entries
+        float terms[N / 2][4];        // per-index terms of the four correlation sums (analytic signal in registers)
+        float lts_win[2 * (N + N / P)];   // audio window of one matched-filter pass (same bytes as X)
     };
+    c32 twB[kTwB];                    // twiddles of stages A..2A-1, one contiguous run per stage (as in mix_fft_kernel)
+    c32 twA[kTwA + 1];
 };
 
-// s = 0; s += a[0]; s += a[1]; ... in order, every lane (broadcast reads); n a multiple of 16.
-// The next 16 terms are requested before the current 16 are added, so the serial chain of adds
-// (the floor: one add per term) runs without waiting for LDS.
-__device__ __forceinline__ float acq_ordered_sum(const float* a, int n) {
-    float s = 0.0f;
-    if (threadIdx.x == 0) {                                  // one lane walks: a masked ds_read_b128 costs one LDS cycle, not four
-    float4 cur[4], nxt[4];
+// per-lane twiddles of stages 2A..LOG2N-1 (k = lane + 64*(t & (ht-1))), loop-invariant: kept in registers
+template <int LOG2N>
+struct AcqLaneTw {
+    static constexpr int P = (1 << LOG2N) / kWave;
+    c32 w[P - 1];                     // stage s (pair distance ht = 2^(s-6) in t) uses w[(ht - 1) + (t & (ht - 1))]
+};
+
+// In-order sum across the wavefront without LDS: returns ((..((s + x[lane 0]) + x[lane 1]) + ..) + x[lane 63]).
+// 63 dependent DPP adds (wave_shr:1: lane k takes lane k-1's running value; lane 0 has no source and
+// keeps its own, s + x0): after step m lane m holds the sum of the first m + 1 terms.  A broadcast
+// walk through LDS costs the same chain of adds plus ~27 LDS cycles per 16-byte read (measured), and
+// the LDS pipe was what bounded this kernel.  "s_nop 1": the two wait states the hardware needs between a
+// VALU write and a DPP read of the same VGPR (the compiler does not see inside the asm).
+__device__ __forceinline__ float acq_chain_add(float s, float x) {
+    float y = (threadIdx.x == 0) ? s + x : x;
 #pragma unroll
-    for (int u = 0; u < 4; ++u) cur[u] = *reinterpret_cast<const float4*>(a + 4 * u);
-    for (int i = 0; i < n; i += 16) {
-        const int j = (i + 16 < n) ? i + 16 : i;            // last round re-reads its own block (unused)
-#pragma unroll
-        for (int u = 0; u < 4; ++u) nxt[u] = *reinterpret_cast<const float4*>(a + j + 4 * u);
-#pragma unroll
-        for (int u = 0; u < 4; ++u) { s += cur[u].x; s += cur[u].y; s += cur[u].z; s += cur[u].w; }
-#pragma unroll
-        for (int u = 0; u < 4; ++u) cur[u] = nxt[u];
-    }
-    }
-    return lane_f(s, 0);
+    for (int k = 1; k < kWave; ++k)
+        asm volatile("s_nop 1\n\tv_add_f32_dpp %0, %0, %1 wave_shr:1 row_mask:0xf bank_mask:0xf" : "+v"(y) : "v"(x));
+    return lane_f(y, kWave - 1);
 }
 
 // Radix-2 DIT exactly as FFT::fft_impl (src/dsp/fft.cpp:89-121), register-resident like the FFT of
@@ -86,7 +77,7 @@ __device__ __forceinline__ float acq_ordered_sum(const float* a, int n) {
 // P register-resident points with two LDS transposes in between; out: v[t] = X[lane + 64*t].
 // INVERSE: conjugated twiddles and the 1/N scaling.
 template <int LOG2N, bool INVERSE>
-__device__ __forceinline__ void acq_fft(AcqShared<LOG2N>& sh, c32 (&v)[AcqShared<LOG2N>::P]) {
+__device__ __forceinline__ void acq_fft(AcqShared<LOG2N>& sh, const AcqLaneTw<LOG2N>& ltw, c32 (&v)[AcqShared<LOG2N>::P]) {
     using S = AcqShared<LOG2N>;
     constexpr int N = S::N, P = S::P, A = S::A;
     const int lane = threadIdx.x;
@@ -97,7 +88,7 @@ __device__ __forceinline__ void acq_fft(AcqShared<LOG2N>& sh, c32 (&v)[AcqShared
 #pragma unroll
         for (int q = 0; q < P; ++q) {
             if (q & half) continue;
-            const c32 w = tw(sh.tw[(q & (half - 1)) << (LOG2N - 1 - s)]);
+            const c32 w = tw(sh.twA[(half - 1) + (q & (half - 1))]);
             UH_BUTTERFLY(v[q], v[q + half], w);
         }
     }
@@ -131,8 +122,7 @@ __device__ __forceinline__ void acq_fft(AcqShared<LOG2N>& sh, c32 (&v)[AcqShared
 #pragma unroll
         for (int t = 0; t < P; ++t) {
             if (t & ht) continue;
-            const int k = lane + 64 * (t & (ht - 1));
-            const c32 w = tw(sh.tw[k << (LOG2N - 1 - s)]);
+            const c32 w = tw(ltw.w[(ht - 1) + (t & (ht - 1))]);
             UH_BUTTERFLY(v[t], v[t + ht], w);
         }
     }
@@ -147,7 +137,8 @@ __device__ __forceinline__ void acq_fft(AcqShared<LOG2N>& sh, c32 (&v)[AcqShared
 // Impl::toAnalytic for len == fft_size.  in: xs[qp] = sample rl + 64*qp of the window (rl =
 // bitrev6(lane)), dc subtracted here; out: v[t] = analytic[lane + 64*t].
 template <int LOG2N>
-__device__ __forceinline__ void acq_analytic(AcqShared<LOG2N>& sh, const float (&xs)[AcqShared<LOG2N>::P], float dc,
+__device__ __forceinline__ void acq_analytic(AcqShared<LOG2N>& sh, const AcqLaneTw<LOG2N>& ltw,
+                                             const float (&xs)[AcqShared<LOG2N>::P], float dc,
                                              c32 (&v)[AcqShared<LOG2N>::P]) {
     using S = AcqShared<LOG2N>;
     constexpr int N = S::N, P = S::P, A = S::A;
@@ -155,7 +146,7 @@ __device__ __forceinline__ void acq_analytic(AcqShared<LOG2N>& sh, const float (
     const int rl = (int)(__brev((unsigned)lane) >> 26);
 #pragma unroll
     for (int qp = 0; qp < P; ++qp) v[bitrev_small<A>(qp)] = mk(xs[qp] - dc, 0.0f);
-    acq_fft<LOG2N, false>(sh, v);
+    acq_fft<LOG2N, false>(sh, ltw, v);
     // freq[1..N/2) *= 2, freq(N/2..N) = 0; then the inverse transform's bit reversal: its input element
     // P*lane + q is freq[bitrev(P*lane + q)] = freq[64*bitrev_A(q) + rl], i.e. register bitrev_A(q) of lane rl
 #pragma unroll
@@ -170,7 +161,7 @@ __device__ __forceinline__ void acq_analytic(AcqShared<LOG2N>& sh, const float (
 #pragma unroll
     for (int q = 0; q < P; ++q) { const int i = rl + 64 * bitrev_small<A>(q); v[q] = sh.X[i + (i >> A)]; }
     wave_sync();
-    acq_fft<LOG2N, true>(sh, v);
+    acq_fft<LOG2N, true>(sh, ltw, v);
 }
 
 // P = sum conj(a[i]) a[i+half], R1 = sum |a[i]|^2, R2 = sum |a[i+half]|^2 in index order; a[lane + 64 t]
@@ -188,9 +179,9 @@ __device__ __forceinline__ void acq_half_sums(AcqShared<LOG2N>& sh, const c32 (&
         *reinterpret_cast<float4*>(&sh.terms[lane + 64 * t][0]) = make_float4(m.re, m.im, cnorm(x), cnorm(y));
     }
     wave_sync();
-    const int col = lane & 3;                       // four chains in four lanes (the others are masked off)
+    const int col = lane & 3;                       // four chains, lane l follows chain l & 3 (broadcast reads)
     float acc = 0.0f;
-    if (lane < 4) {
+    {
         float cur[8], nxt[8];
 #pragma unroll
         for (int u = 0; u < 8; ++u) cur[u] = sh.terms[u][col];
@@ -216,8 +207,9 @@ __device__ __forceinline__ void acq_half_sums(AcqShared<LOG2N>& sh, const c32 (&
 // plateau scan and the CFO estimate (see the state machine in acquire_kernel): three inlined copies
 // cost 239 VGPRs.
 template <int LOG2N>
-__device__ __forceinline__ void acq_window_metric(AcqShared<LOG2N>& sh, const float* __restrict__ win, bool remove_dc,
-                                                  c32* P_out, float* R1, float* R2) {
+__device__ __forceinline__ void acq_window_metric(AcqShared<LOG2N>& sh, const AcqLaneTw<LOG2N>& ltw,
+                                                  const float* __restrict__ win, bool remove_dc, c32* P_out, float* R1,
+                                                  float* R2) {
     constexpr int N = 1 << LOG2N;
     constexpr int P = AcqShared<LOG2N>::P;
     const int lane = threadIdx.x;
@@ -226,16 +218,14 @@ __device__ __forceinline__ void acq_window_metric(AcqShared<LOG2N>& sh, const fl
 #pragma unroll
     for (int qp = 0; qp < P; ++qp) xs[qp] = win[rl + 64 * qp];
     float dc = 0.0f;                                         // x - 0.0f == x for every float (also -0.0f)
-    if (remove_dc) {
-#pragma unroll
-        for (int qp = 0; qp < P; ++qp) sh.samp[rl + 64 * qp] = xs[qp];
-        wave_sync();
-        const float dc_sum = acq_ordered_sum(sh.samp, N);
+    if (remove_dc) {                                         // dc_sum: samples 0..N-1 in order, 64 per chain
+        float dc_sum = 0.0f;
+#pragma unroll 4
+        for (int q = 0; q < P; ++q) dc_sum = acq_chain_add(dc_sum, win[lane + 64 * q]);
         dc = dc_sum / (float)N;
-        wave_sync();
     }
     c32 v[P];
-    acq_analytic<LOG2N>(sh, xs, dc, v);
+    acq_analytic<LOG2N>(sh, ltw, xs, dc, v);
     acq_half_sums<LOG2N>(sh, v, P_out, R1, R2);
 }
 
@@ -246,15 +236,13 @@ __device__ __forceinline__ bool acq_has_energy(AcqShared<LOG2N>& sh, const float
     if (offset + window_len > size) return false;
     const int lane = threadIdx.x;
     const int count = (int)((window_len + 15u) / 16u);          // i = 0, 16, ... < window_len
-    const int padded = (count + 15) & ~15;
-    for (int t = lane; t < padded; t += 64) {
-        float sq = -0.0f;                                           // pad: exact no-op in the sum
-        if (t < count) { const float s = buf[offset + 16u * (unsigned)t]; sq = s * s; }
-        sh.samp[t] = sq;
+    float sum_sq = 0.0f;
+    for (int t0 = 0; t0 < count; t0 += kWave) {
+        const int t = t0 + lane;
+        float sq = -0.0f;                                           // beyond the last sample: exact no-op in the sum
+        if (t < count) { const float v = buf[offset + 16u * (unsigned)t]; sq = v * v; }
+        sum_sq = acq_chain_add(sum_sq, sq);
     }
-    wave_sync();
-    const float sum_sq = acq_ordered_sum(sh.samp, padded);
-    wave_sync();
     const float energy = sum_sq / (float)count;
     if (noise_floor < 1e-20f) noise_floor = energy * 0.1f;
     if (energy < noise_floor) noise_floor = energy;
@@ -275,37 +263,45 @@ __device__ __forceinline__ unsigned acq_refine_lts(AcqShared<LOG2N>& sh, const D
     const unsigned coarse = sts_start + 4u * psl;
     const int back = (int)(3u * psl), fwd = (int)(psl / 2u);
     if (coarse < (unsigned)back || coarse + (unsigned)fwd + lts_len > size) return coarse;
-    // the whole search window goes to LDS once: lane l at tap i reads sample l + i of it (global loads
-    // inside the tap loop left the wave waiting on memory for most of this function)
-    const unsigned win0 = coarse - (unsigned)back, win_len = (unsigned)(back + fwd) + lts_len;
-    for (unsigned i = lane; i < win_len; i += kWave) sh.lts_win[i] = buf[win0 + i];
-    wave_sync();
+    // The search window goes through LDS in passes (lane l at tap i reads sample l + i of the pass's
+    // window; global loads inside the tap loop left the wave waiting on memory for most of this
+    // function).  A pass covers as many offsets as fit next to one template length.
+    const unsigned win0 = coarse - (unsigned)back;
+    const int n_off = back + fwd + 1;
+    const int cap = (int)(sizeof(sh.lts_win) / sizeof(float));
+    const int per_pass = ((cap - (int)lts_len) / 64) * 64;          // offsets per pass, whole 64-lane rounds
     float best_corr = 0.0f;
     unsigned best_off = coarse;
-    const int n_off = back + fwd + 1;
-    for (int r0 = 0; r0 < n_off; r0 += 64) {
-        const int idx = r0 + lane;
-        const bool on = idx < n_off;
-        const int rel = on ? idx : 0;
-        const unsigned offset = win0 + (unsigned)rel;
-        float ci = 0.0f, cq = 0.0f, er = 0.0f;
-        const float* p = sh.lts_win + rel;
-        for (unsigned i = 0; i < lts_len; i += 4) {
-            float rx[4];
+    for (int p0 = 0; p0 < n_off; p0 += per_pass) {
+        const int n_here = (n_off - p0 < per_pass) ? n_off - p0 : per_pass;
+        const unsigned need = (unsigned)n_here - 1u + lts_len;
+        wave_sync();
+        for (unsigned i = lane; i < need; i += kWave) sh.lts_win[i] = buf[win0 + (unsigned)p0 + i];
+        wave_sync();
+        for (int r0 = 0; r0 < n_here; r0 += 64) {
+            const int idx = r0 + lane;
+            const bool on = idx < n_here;
+            const int rel = on ? idx : 0;
+            const unsigned offset = win0 + (unsigned)(p0 + rel);
+            float ci = 0.0f, cq = 0.0f, er = 0.0f;
+            const float* p = sh.lts_win + rel;
+            for (unsigned i = 0; i < lts_len; i += 4) {
+                float rx[4];
 #pragma unroll
-            for (int u = 0; u < 4; ++u) rx[u] = p[i + u];
+                for (int u = 0; u < 4; ++u) rx[u] = p[i + u];
 #pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                const float ti = lts_I[i + u], tq = lts_Q[i + u];
-                ci += rx[u] * ti;
-                cq += rx[u] * tq;
-                er += rx[u] * rx[u];
+                for (int u = 0; u < 4; ++u) {
+                    const float ti = lts_I[i + u], tq = lts_Q[i + u];
+                    ci += rx[u] * ti;
+                    cq += rx[u] * tq;
+                    er += rx[u] * rx[u];
+                }
             }
+            const float corr_mag = sqrtf(ci * ci + cq * cq);
+            const float norm = sqrtf(er * energy_ref);
+            const float corr = (norm > 1e-6f) ? corr_mag / norm : 0.0f;
+            if (on && corr > best_corr) { best_corr = corr; best_off = offset; }   // increasing offsets within a lane
         }
-        const float corr_mag = sqrtf(ci * ci + cq * cq);
-        const float norm = sqrtf(er * energy_ref);
-        const float corr = (norm > 1e-6f) ? corr_mag / norm : 0.0f;
-        if (on && corr > best_corr) { best_corr = corr; best_off = offset; }
     }
     wave_sync();
     // first occurrence of the maximum over all offsets = max corr, smallest offset among equals
@@ -322,7 +318,7 @@ __device__ __forceinline__ unsigned acq_refine_lts(AcqShared<LOG2N>& sh, const D
 }
 
 template <int LOG2N>
-__global__ __launch_bounds__(kWave, 3) void acquire_kernel(
+__global__ __launch_bounds__(kWave, 2) void acquire_kernel(
     const DemodConst* __restrict__ Dp, const c32* __restrict__ twiddle, const float* __restrict__ lts_I,
     const float* __restrict__ lts_Q, float energy_ref, float sync_threshold, const float* __restrict__ audio,
     size_t stream_stride, unsigned n_samples, unsigned chunk, int n_streams, unsigned* __restrict__ found_out,
@@ -332,17 +328,26 @@ __global__ __launch_bounds__(kWave, 3) void acquire_kernel(
     __shared__ AcqShared<LOG2N> sh;
     const DemodConst& D = *Dp;
     const int lane = threadIdx.x;
-    auto load_tables = [&]() {
+    AcqLaneTw<LOG2N> ltw;
+    {
         constexpr int P = AcqShared<LOG2N>::P, A = AcqShared<LOG2N>::A;
-        for (int i = lane; i < N / 2; i += kWave) sh.tw[i] = twiddle[i];
+#pragma unroll
+        for (int s = 2 * A; s < LOG2N; ++s) {                // stage s: pair distance ht = 2^(s-6) in t, k = lane + 64*c, c < ht
+            const int ht = 1 << (s - 6);
+#pragma unroll
+            for (int c = 0; c < ht; ++c) ltw.w[(ht - 1) + c] = twiddle[(lane + 64 * c) << (LOG2N - 1 - s)];
+        }
         for (int idx = lane; idx < AcqShared<LOG2N>::kTwB; idx += kWave) {
             const int sA = 31 - __clz(idx / P + 1);          // stage - A: runs start at P*(2^sA - 1)
             const int k = idx - P * ((1 << sA) - 1);
             sh.twB[idx] = twiddle[k << (LOG2N - 1 - (A + sA))];
         }
+        if (lane < AcqShared<LOG2N>::kTwA) {                  // stage s < A: k < 2^s, run starts at 2^s - 1
+            const int s0 = 31 - __clz(lane + 1);
+            sh.twA[lane] = twiddle[(lane - ((1 << s0) - 1)) << (LOG2N - 1 - s0)];
+        }
         wave_sync();
-    };
-    load_tables();
+    }
     const unsigned psl = (unsigned)(N + D.cp), preamble_total = psl * 6u, corr_win = psl * 2u;
     for (int stream = blockIdx.x; stream < n_streams; stream += gridDim.x) {
         const float* all = audio + (size_t)stream * stream_stride;
@@ -385,7 +390,7 @@ __global__ __launch_bounds__(kWave, 3) void acquire_kernel(
                 const bool in_range = off + (unsigned)D.cp + (unsigned)N <= size;
                 c32 Pm = mk(0.0f, 0.0f);
                 float R1 = 0.0f, R2 = 0.0f;
-                if (in_range) acq_window_metric<LOG2N>(sh, buf + off + D.cp, mode != kCfo, &Pm, &R1, &R2);
+                if (in_range) acq_window_metric<LOG2N>(sh, ltw, buf + off + D.cp, mode != kCfo, &Pm, &R1, &R2);
                 if (mode == kCfo) {
                     if (in_range) {
                         const float phase = um::atan2f_(Pm.im, Pm.re);
@@ -413,7 +418,6 @@ __global__ __launch_bounds__(kWave, 3) void acquire_kernel(
             }
             if (found_sync) {
                 const unsigned refined = acq_refine_lts<LOG2N>(sh, D, lts_I, lts_Q, energy_ref, buf, size, so);
-                load_tables();                               // the matched filter's window overlaid them
                 if (refined == 0xffffffffu) {
                     if (size > kAcqOverlap * 2u) {
                         unsigned trim = so + psl;
