@@ -279,6 +279,23 @@ int ultra_hip_receive_batch(ultra_hip_ctx* ctx, const float* d_audio, size_t str
                             uint32_t chunk, size_t n_streams, float* d_llr, uint8_t* d_bytes, int32_t* d_iters,
                             uint8_t* d_ok, uint32_t* d_entry, float* d_cfo_hz);
 
+/* Transmit-side stimulus on the device: what one Monte-Carlo trial of the harnesses
+ * builds before the receiver runs (tools/test_nvis_mode.cpp:35-93), for frames first_frame ..
+ * first_frame + n_frames - 1: payload of floor(k/8) random bytes per codeword -> LDPCEncoder::encode
+ * (src/fec/ldpc_encoder.cpp:193-257) -> OFDMModulator::generatePreamble + modulate
+ * (src/ofdm/modulator.cpp:202-283,348-532) -> whole signal scaled to a 0.5 peak -> channel -> the
+ * frame_samples from the first data symbol on (the SYNCED entry's input).
+ *   channel_kind 0 none, 1 AWGN at snr_db, 2 Watterson two-tap (gains 0.707/0.707, delay_ms, doppler_hz,
+ *                fading restarted per frame: src/sim/hf_channel.hpp:106-168,258-275)
+ *   d_audio      [n_frames][frame_stride >= frame_samples] f32
+ *   d_payload    [n_frames][floor(k/8)] bytes of the first codeword (what ultra_hip_count_errors compares)
+ * Payload, codewords, transmitted samples and scaling are bit-identical to oracle/ultra_oracle.c's
+ * uo_make_batch for the same (seed, frame index); the channels use a per-sample counter-based
+ * generator and are statistically, not bitwise, equivalent to the serial CPU draws. */
+int ultra_hip_make_batch(ultra_hip_ctx* ctx, uint64_t seed, uint64_t first_frame, size_t n_frames, int channel_kind,
+                         float snr_db, float delay_ms, float doppler_hz, float* d_audio, size_t frame_stride,
+                         uint8_t* d_payload);
+
 /* Channel deinterleaver of the production receive path, fused into the decoder's LLR load.
  * Replaces RxPipeline::setInterleaverConfig(bits_per_symbol) + deinterleaveCodewords
  * (src/gui/modem/rx_pipeline.cpp:24-31,475-491): every 648-LLR codeword handed to

@@ -227,6 +227,21 @@ class ReceiveContext:
             out["llr"] = llr
         return out
 
+    def make_batch(self, n_frames: int, seed: int = 0x5EED, first_frame: int = 0, channel: str = "awgn",
+                   snr_db: float = 30.0, delay_ms: float = 0.5, doppler_hz: float = 0.1):
+        """Synthetic frames at the SYNCED entry, generated on the device (ultra_hip_make_batch): random
+        payload -> encode -> preamble + modulate -> 0.5 peak -> channel.  Returns (audio [n][frame_samples],
+        payload [n][k // 8]) device tensors.  Bit-identical to the oracle's uo_make_batch for channel "none"."""
+        torch = _torch()
+        g = self.geometry
+        audio = torch.empty((n_frames, g.frame_samples), dtype=torch.float32, device=self.device)
+        payload = torch.empty((n_frames, g.ldpc_k // 8), dtype=torch.uint8, device=self.device)
+        kind = dict(none=0, awgn=1, watterson=2)[channel]
+        check(self.lib.ultra_hip_make_batch(self._ctx, int(seed), int(first_frame), n_frames, kind, float(snr_db),
+                                            float(delay_ms), float(doppler_hz), audio.data_ptr(), audio.stride(0),
+                                            payload.data_ptr()), "ultra_hip_make_batch")
+        return audio, payload
+
     def set_deinterleave(self, bits_per_symbol: int):
         """RxPipeline::setInterleaverConfig + deinterleaveCodewords (rx_pipeline.cpp:24-31,475-491): every
         codeword is passed through ChannelInterleaver(bits_per_symbol, 648)::deinterleave before it is

@@ -1,0 +1,86 @@
+"""GPU stimulus generator (scope row f2, ultra_hip_make_batch) against the oracle's generator
+(oracle/ultra_oracle.c uo_make_batch: pinned modulator / encoder restatements, same counter-based
+payload stream).  Channel "none": audio and payloads BITWISE.  Channels: statistics."""
+import numpy as np
+import pytest
+
+from _util import INFO_BITS, beq, context_for, geometry, make_config
+
+pytestmark = pytest.mark.gpu
+
+MODES = [(1024, "QAM16", "R3_4", {}), (512, "DQPSK", "R1_2", {}), (512, "QPSK", "R1_2", {}), (1024, "QAM32", "R3_4", {}),
+         (1024, "D8PSK", "R3_4", dict(pilot_spacing=2)), (512, "DBPSK", "R1_4", {}), (512, "BPSK", "R1_2", {}),
+         (512, "QAM64", "R3_4", {}), (512, "QAM256", "R5_6", {}), (1024, "QAM16", "R2_3", dict(n_data_symbols=12))]
+
+
+@pytest.mark.parametrize("fft,mod,rate,kw", MODES)
+def test_clean_frames_are_bit_identical_to_the_oracle(oracle, fft, mod, rate, kw):
+    cfg = make_config(fft, mod, rate, **kw)
+    ctx = context_for(cfg)
+    n, seed, f0 = 40, 0xABCDEF, 1000
+    audio, payload = ctx.make_batch(n, seed=seed, first_frame=f0, channel="none")
+    ctx.synchronize()
+    want_a, want_p = oracle.make_batch(cfg, n, seed=seed, f0=f0, channel="none")
+    assert np.array_equal(payload.cpu().numpy(), want_p)
+    got = audio.cpu().numpy()
+    if not beq(got, want_a):
+        bad = np.argwhere(got.view(np.uint32) != want_a.view(np.uint32))
+        raise AssertionError(f"{len(bad)} samples differ, first {bad[:4].tolist()}, max abs err {np.abs(got - want_a).max():g}")
+
+
+def test_awgn_level_and_receive_statistics(oracle):
+    """AWGN: the added noise has the power the harness formula asks for; frames decode like the oracle's."""
+    cfg = make_config(1024, "QAM16", "R3_4")
+    ctx = context_for(cfg)
+    n = 2048
+    clean, payload = ctx.make_batch(n, seed=7, channel="none")
+    # the harness sets the noise from the mean power of the WHOLE signal (preamble with its leading silence
+    # included, tools/test_nvis_mode.cpp:78-86); the frame part alone is a little stronger
+    g = geometry(cfg)
+    off = []
+    for t in range(8):
+        pl = bytes(np.random.default_rng(t).integers(0, 256, 2 * (INFO_BITS[cfg.code_rate] // 8), dtype=np.uint8))
+        whole, pre = oracle.modulate_frame(cfg, oracle.ldpc_encode(int(cfg.code_rate), pl))
+        off.append(np.mean(whole[pre: pre + g.frame_samples].astype(np.float64) ** 2) / np.mean(whole.astype(np.float64) ** 2))
+    offset_db = 10 * np.log10(np.mean(off))
+    for snr_db in (30.0, 14.0):
+        noisy, _ = ctx.make_batch(n, seed=7, channel="awgn", snr_db=snr_db)
+        ctx.synchronize()
+        d = (noisy - clean).double()
+        # whole-signal power incl. preamble: estimate it from the oracle's generator on a few frames
+        ratio = (clean.double() ** 2).mean().item() / (d ** 2).mean().item()
+        assert abs(10 * np.log10(ratio) - (snr_db + offset_db)) < 0.25, (snr_db, offset_db, 10 * np.log10(ratio))
+        assert abs(d.mean().item()) < 4 * d.std().item() / np.sqrt(d.numel())
+        z = d / d.std(dim=1, keepdim=True)                    # the level is per frame (each frame's own power)
+        kurt = (z ** 4).mean().item() / (z ** 2).mean().item() ** 2
+        assert abs(kurt - 3.0) < 0.05, kurt
+    r = ctx.demod_decode(noisy)
+    c = ctx.count_errors(r, payload).cpu().numpy()
+    oa, op = oracle.make_batch(cfg, 512, seed=7, channel="awgn", snr_db=14.0)
+    ro = ctx.demod_decode(oa)
+    co = ctx.count_errors(ro, op).cpu().numpy()
+    fer_gpu, fer_cpu = c[1] / c[0], co[1] / co[0]
+    assert abs(fer_gpu - fer_cpu) < 0.08, (fer_gpu, fer_cpu)
+
+
+def test_watterson_statistics_match_the_oracle_generator(oracle):
+    """Two-tap fading channel: output power, and the error rates of the receive path, agree with frames
+    drawn by the oracle's serial generator within sampling tolerance."""
+    cfg = make_config(1024, "QAM16", "R3_4")
+    ctx = context_for(cfg)
+    n = 4096
+    audio, payload = ctx.make_batch(n, seed=99, channel="watterson", snr_db=30.0)
+    ctx.synchronize()
+    oa, op = oracle.make_batch(cfg, 1024, seed=99, channel="watterson", snr_db=30.0)
+    p_gpu = (audio.double() ** 2).mean(dim=1).cpu().numpy()
+    p_cpu = (oa.astype(np.float64) ** 2).mean(axis=1)
+    assert abs(p_gpu.mean() / p_cpu.mean() - 1.0) < 0.06, (p_gpu.mean(), p_cpu.mean())
+    assert abs(p_gpu.std() / p_cpu.std() - 1.0) < 0.25, (p_gpu.std(), p_cpu.std())
+    r = ctx.demod_decode(audio)
+    c = ctx.count_errors(r, payload).cpu().numpy()
+    ro = ctx.demod_decode(oa)
+    co = ctx.count_errors(ro, op).cpu().numpy()
+    fer_gpu, fer_cpu = c[1] / c[0], co[1] / co[0]
+    assert abs(fer_gpu - fer_cpu) < 0.06, (fer_gpu, fer_cpu)
+    it_gpu, it_cpu = c[5] / c[0], co[5] / co[0]
+    assert abs(it_gpu - it_cpu) < 3.0, (it_gpu, it_cpu)
