@@ -46,6 +46,9 @@ def parse():
     ap.add_argument("--frames", type=int, default=1 << 18, help="frames per GPU per step")
     ap.add_argument("--unique", type=int, default=8192, help="distinct synthetic frames generated on the host")
     ap.add_argument("--snr-db", type=float, default=30.0)
+    ap.add_argument("--stimulus", choices=("host", "device"), default="host",
+                    help="host: --unique frames from the oracle's TX chain, tiled in HBM; device: every frame distinct, "
+                         "generated on the GPU (ultra_hip_make_batch, scope row f2)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample", type=int, default=0, help="frames for the CPU baseline (0 = auto)")
     return ap.parse_args()
@@ -85,17 +88,26 @@ def main():
     reps = -(-n_frames // unique)
     glob_lo, _ = shard_range(n_frames * world, rank, world)    # global frame ids of this rank
 
-    # ---- synthetic stimulus (host, oracle TX chain + Watterson "good": 0.5 ms / 0.1 Hz) -------
+    # ---- synthetic stimulus: TX chain + Watterson "good" (0.5 ms / 0.1 Hz) ----------------------
     o = oracle()
-    t0 = time.time()
-    audio_u, payload_u = o.make_batch(ccfg, unique, seed=0x5EED, f0=glob_lo, channel="watterson",
-                                      snr_db=args.snr_db, delay_ms=0.5, doppler_hz=0.1)
-    t_gen = time.time() - t0
     ctx = ReceiveContext(mc)
-    d_audio_u = torch.from_numpy(audio_u).cuda()
-    d_audio = d_audio_u.repeat(reps, 1)[:n_frames].contiguous()        # [n_frames][4480] f32, resident in HBM
-    d_payload = torch.from_numpy(payload_u).cuda().repeat(reps, 1)[:n_frames].contiguous()
-    del d_audio_u
+    t0 = time.time()
+    if args.stimulus == "device":
+        # every frame of the rank distinct, generated in HBM (payload/encoder/modulator bit-identical to the
+        # oracle's generator, channel statistically equivalent: tests/test_gpu_stimulus.py)
+        d_audio, d_payload = ctx.make_batch(n_frames, seed=0x5EED, first_frame=glob_lo, channel="watterson",
+                                            snr_db=args.snr_db, delay_ms=0.5, doppler_hz=0.1)
+        torch.cuda.synchronize()
+        unique = n_frames
+        audio_u = None
+    else:
+        audio_u, payload_u = o.make_batch(ccfg, unique, seed=0x5EED, f0=glob_lo, channel="watterson",
+                                          snr_db=args.snr_db, delay_ms=0.5, doppler_hz=0.1)
+        d_audio_u = torch.from_numpy(audio_u).cuda()
+        d_audio = d_audio_u.repeat(reps, 1)[:n_frames].contiguous()        # [n_frames][4480] f32, resident in HBM
+        d_payload = torch.from_numpy(payload_u).cuda().repeat(reps, 1)[:n_frames].contiguous()
+        del d_audio_u
+    t_gen = time.time() - t0
     out = dict(bytes=torch.empty((n_frames, geo.decoded_bytes), dtype=torch.uint8, device="cuda"),
                iters=torch.empty(n_frames, dtype=torch.int32, device="cuda"),
                ok=torch.empty(n_frames, dtype=torch.uint8, device="cuda"))
@@ -192,8 +204,10 @@ def main():
         threads = min(cores, 64)
         # bounded sample: ~10-20 core-seconds of CPU work (the unique frames, tiled on the host)
         sample = args.cpu_sample or min(n_frames, 1024 * threads)
-        reps_cpu = -(-sample // unique)
-        audio_cpu = np.tile(audio_u, (reps_cpu, 1))[:sample]
+        if audio_u is None:
+            audio_cpu = d_audio[:sample].cpu().numpy()          # device stimulus: copy the sample to the host
+        else:
+            audio_cpu = np.tile(audio_u, (-(-sample // unique), 1))[:sample]
         t0 = time.perf_counter()
         want = o.demod_decode_batch(ccfg, audio_cpu, n_threads=threads, want_llr=False, want_state=False)
         t_cpu = time.perf_counter() - t0
@@ -224,8 +238,10 @@ def main():
             "value": value, "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f32",
-            "data": f"synthetic ({unique} distinct Watterson realisations per GPU generated on the host, tiled to "
-                    f"{n_frames} frames resident in HBM; random-payload R3/4 codewords, 30 dB, 0.5 ms / 0.1 Hz)",
+            "data": (f"synthetic ({n_frames} distinct Watterson realisations per GPU generated on the device in HBM; "
+                     if args.stimulus == "device" else
+                     f"synthetic ({unique} distinct Watterson realisations per GPU generated on the host, tiled to "
+                     f"{n_frames} frames resident in HBM; ") + "random-payload R3/4 codewords, 30 dB, 0.5 ms / 0.1 Hz)",
             "config": {"workload": "OFDM 1024-FFT 16QAM R3/4, 59 carriers (15 pilots), Watterson good channel, "
                                    "post-sync entry, LDPC min-sum <= 50 iterations, "
                                    f"{n_frames} frames per GPU per step",

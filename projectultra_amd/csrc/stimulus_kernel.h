@@ -389,7 +389,8 @@ __global__ __launch_bounds__(kWave) void channel_kernel(
                 return (n < pre_len) ? preamble[n] * scale : s_in[n - pre_len];
             };
             const float h1 = sqrtf(c1.re * c1.re + c1.im * c1.im), h2 = sqrtf(c2.re * c2.re + c2.im * c2.im);
-            float o = sig(i) * g1 * h1 + sig(i - delay_samples) * g2 * h2;
+            // the reference's delay line holds delay_samples + 1 entries: the tap is delay_samples + 1 samples late
+            float o = sig(i) * g1 * h1 + sig(i - delay_samples - 1) * g2 * h2;
             float n0, n1;
             gauss_pair(key ^ 0x3333ull, (unsigned long long)i, &n0, &n1);
             o += eff_noise * n0;
