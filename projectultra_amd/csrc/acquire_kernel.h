@@ -44,6 +44,7 @@ struct AcqShared {
     static constexpr int kTwA = (1 << A) - 1;               // wave-uniform twiddles of stages 0..A-1, one run per stage
     union {
         c32 X[N + N / P];             // FFT exchange buffer, 1 pad per P entries
+        float samp[N];                // window samples for the dc sum (before the FFT input is taken)
         float terms[N / 2][4];        // per-index terms of the four correlation sums (analytic signal in registers)
         float lts_win[2 * (N + N / P)];   // audio window of one matched-filter pass (same bytes as X)
     };
@@ -70,6 +71,33 @@ __device__ __forceinline__ float acq_chain_add(float s, float x) {
     for (int k = 1; k < kWave; ++k)
         asm volatile("s_nop 1\n\tv_add_f32_dpp %0, %0, %1 wave_shr:1 row_mask:0xf bank_mask:0xf" : "+v"(y) : "v"(x));
     return lane_f(y, kWave - 1);
+}
+
+// s = 0; s += a[0]; s += a[1]; ... in order through LDS (all lanes read the same addresses: broadcast);
+// n a multiple of 32.  A dependent v_add_f32 chain advances one term per ~9 cycles against ~17 for the
+// DPP chain above, so the 1024-term DC sum goes this way; the loads of the next 16 terms are issued
+// before the current 16 are added (ping-pong register sets; the asm statements pin that order).
+__device__ __forceinline__ void acq_load16(const float* p, float4 (&r)[4]) {
+#pragma unroll
+    for (int u = 0; u < 4; ++u) r[u] = *reinterpret_cast<const float4*>(p + 4 * u);
+    asm volatile("" : "+v"(r[0].x), "+v"(r[1].x), "+v"(r[2].x), "+v"(r[3].x));
+}
+__device__ __forceinline__ float acq_add16(float s, const float4 (&r)[4]) {
+#pragma unroll
+    for (int u = 0; u < 4; ++u) { s += r[u].x; s += r[u].y; s += r[u].z; s += r[u].w; }
+    return s;
+}
+__device__ __forceinline__ float acq_ordered_sum_lds(const float* a, int n) {
+    float s = 0.0f;
+    float4 ra[4], rb[4];
+    acq_load16(a, ra);
+    for (int i = 0; i < n; i += 32) {
+        acq_load16(a + i + 16, rb);
+        s = acq_add16(s, ra);
+        acq_load16(a + ((i + 32 < n) ? i + 32 : i), ra);     // the last round re-reads a block it does not use
+        s = acq_add16(s, rb);
+    }
+    return s;
 }
 
 // Radix-2 DIT exactly as FFT::fft_impl (src/dsp/fft.cpp:89-121), register-resident like the FFT of
@@ -218,11 +246,13 @@ __device__ __forceinline__ void acq_window_metric(AcqShared<LOG2N>& sh, const Ac
 #pragma unroll
     for (int qp = 0; qp < P; ++qp) xs[qp] = win[rl + 64 * qp];
     float dc = 0.0f;                                         // x - 0.0f == x for every float (also -0.0f)
-    if (remove_dc) {                                         // dc_sum: samples 0..N-1 in order, 64 per chain
-        float dc_sum = 0.0f;
-#pragma unroll 4
-        for (int q = 0; q < P; ++q) dc_sum = acq_chain_add(dc_sum, win[lane + 64 * q]);
+    if (remove_dc) {                                         // dc_sum: samples 0..N-1 in order
+#pragma unroll
+        for (int qp = 0; qp < P; ++qp) sh.samp[rl + 64 * qp] = xs[qp];
+        wave_sync();
+        const float dc_sum = acq_ordered_sum_lds(sh.samp, N);
         dc = dc_sum / (float)N;
+        wave_sync();
     }
     c32 v[P];
     acq_analytic<LOG2N>(sh, ltw, xs, dc, v);
@@ -318,7 +348,7 @@ __device__ __forceinline__ unsigned acq_refine_lts(AcqShared<LOG2N>& sh, const D
 }
 
 template <int LOG2N>
-__global__ __launch_bounds__(kWave, 2) void acquire_kernel(
+__global__ __launch_bounds__(kWave, (LOG2N == 10) ? 2 : 3) void acquire_kernel(
     const DemodConst* __restrict__ Dp, const c32* __restrict__ twiddle, const float* __restrict__ lts_I,
     const float* __restrict__ lts_Q, float energy_ref, float sync_threshold, const float* __restrict__ audio,
     size_t stream_stride, unsigned n_samples, unsigned chunk, int n_streams, unsigned* __restrict__ found_out,
