@@ -348,7 +348,7 @@ __device__ __forceinline__ unsigned acq_refine_lts(AcqShared<LOG2N>& sh, const D
 }
 
 template <int LOG2N>
-__global__ __launch_bounds__(kWave, (LOG2N == 10) ? 2 : 3) void acquire_kernel(
+__global__ __launch_bounds__(kWave, (LOG2N == 10) ? 3 : 4) void acquire_kernel(
     const DemodConst* __restrict__ Dp, const c32* __restrict__ twiddle, const float* __restrict__ lts_I,
     const float* __restrict__ lts_Q, float energy_ref, float sync_threshold, const float* __restrict__ audio,
     size_t stream_stride, unsigned n_samples, unsigned chunk, int n_streams, unsigned* __restrict__ found_out,

@@ -389,8 +389,9 @@ __global__ __launch_bounds__(kWave) void channel_kernel(
                 return (n < pre_len) ? preamble[n] * scale : s_in[n - pre_len];
             };
             const float h1 = sqrtf(c1.re * c1.re + c1.im * c1.im), h2 = sqrtf(c2.re * c2.re + c2.im * c2.im);
-            // the reference's delay line holds delay_samples + 1 entries: the tap is delay_samples + 1 samples late
-            float o = sig(i) * g1 * h1 + sig(i - delay_samples - 1) * g2 * h2;
+            // multipath: the reference's delay line holds delay_samples + 1 entries, so the second tap is
+            // delay_samples + 1 samples late; without a delay there is a single faded path and no tap gains
+            float o = (delay_samples > 0) ? sig(i) * g1 * h1 + sig(i - delay_samples - 1) * g2 * h2 : sig(i) * h1;
             float n0, n1;
             gauss_pair(key ^ 0x3333ull, (unsigned long long)i, &n0, &n1);
             o += eff_noise * n0;
