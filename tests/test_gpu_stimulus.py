@@ -92,3 +92,41 @@ def test_watterson_statistics_match_the_oracle_generator(oracle):
     c0 = ctx.count_errors(ctx.demod_decode(a0), p0).cpu().numpy()
     co0 = ctx.count_errors(ctx.demod_decode(oa0), op0).cpu().numpy()
     assert abs(c0[1] / c0[0] - co0[1] / co0[0]) < 0.04
+
+
+CFG5_MODS = [(512, "DBPSK"), (512, "DQPSK"), (1024, "D8PSK"), (1024, "QAM16"), (1024, "QAM32")]
+CFG5_RATES = ["R1_4", "R1_2", "R2_3", "R3_4", "R5_6"]
+
+
+@pytest.mark.parametrize("fft,mod", CFG5_MODS)
+def test_cfg5_sweep_device_stimulus_vs_oracle(oracle, fft, mod):
+    """BASELINE cfg5 shape: {DBPSK, DQPSK, D8PSK, 16QAM, 32QAM} x {R1/4 .. R5/6}, 2^14 distinct frames per
+    combination generated on the device (AWGN), demodulated + decoded + counted on the device.  A random
+    subset is copied to the host and pushed through the oracle: LLRs, decoded bytes, iterations and success
+    must be bit-identical; the device counters must equal a host recount of the device's own outputs."""
+    rng = np.random.default_rng(5)
+    for rate in CFG5_RATES:
+        cfg = make_config(fft, mod, rate)
+        ctx = context_for(cfg)
+        g = ctx.geometry
+        n = 1 << 14
+        audio, payload = ctx.make_batch(n, seed=0xC0FFEE, first_frame=12345, channel="awgn", snr_db=[8.0, 14.0, 20.0][rng.integers(3)])
+        r = ctx.demod_decode(audio, want_llr=True)
+        c = ctx.count_errors(r, payload).cpu().numpy()
+        ctx.synchronize()
+        by, ok, it = r["bytes"].cpu().numpy(), r["ok"].cpu().numpy().astype(bool), r["iters"].cpu().numpy()
+        pl = payload.cpu().numpy()
+        good = ok & (by[:, : pl.shape[1]] == pl).all(axis=1)
+        assert c[0] == n and c[1] == n - good.sum() and c[4] == (~ok).sum() and c[5] == it.sum(), (mod, rate, c)
+        idx = np.sort(rng.choice(n, 48, replace=False))
+        sub = audio[torch_index(idx)].cpu().numpy()
+        want = oracle.demod_decode_batch(cfg, sub, n_threads=8, want_llr=True, want_state=False)
+        got_llr = r["llr"][torch_index(idx)].cpu().numpy()
+        assert beq(got_llr, want["llr"]), (mod, rate)
+        assert np.array_equal(by[idx], want["bytes"]) and np.array_equal(it[idx], want["iters"])
+        assert np.array_equal(ok[idx], want["ok"].astype(bool))
+
+
+def torch_index(idx):
+    import torch
+    return torch.from_numpy(np.sort(idx)).cuda()
