@@ -293,44 +293,48 @@ __device__ __forceinline__ unsigned acq_refine_lts(AcqShared<LOG2N>& sh, const D
     const unsigned coarse = sts_start + 4u * psl;
     const int back = (int)(3u * psl), fwd = (int)(psl / 2u);
     if (coarse < (unsigned)back || coarse + (unsigned)fwd + lts_len > size) return coarse;
-    // The search window goes through LDS in passes (lane l at tap i reads sample l + i of the pass's
-    // window; global loads inside the tap loop left the wave waiting on memory for most of this
-    // function).  A pass covers as many offsets as fit next to one template length.
+    // The search window goes through LDS in passes of kR*64 offsets; lane l evaluates offsets
+    // l, l + 64, .., l + 64*(kR-1) of a pass together, so one (wave-uniform, scalar-loaded) template
+    // pair serves kR accumulations and its load latency disappears behind them (one offset per lane
+    // per round spent 64 cycles per tap, most of them waiting for the template loads: 4.5 of the
+    // 15 M cycles of a stream).  Each offset's three sums still run over the taps in order.
+    constexpr int kR = 8;
+    typedef float v2f __attribute__((ext_vector_type(2)));
     const unsigned win0 = coarse - (unsigned)back;
     const int n_off = back + fwd + 1;
-    const int cap = (int)(sizeof(sh.lts_win) / sizeof(float));
-    const int per_pass = ((cap - (int)lts_len) / 64) * 64;          // offsets per pass, whole 64-lane rounds
     float best_corr = 0.0f;
     unsigned best_off = coarse;
-    for (int p0 = 0; p0 < n_off; p0 += per_pass) {
-        const int n_here = (n_off - p0 < per_pass) ? n_off - p0 : per_pass;
-        const unsigned need = (unsigned)n_here - 1u + lts_len;
+    for (int p0 = 0; p0 < n_off; p0 += kR * 64) {
+        const int n_here = (n_off - p0 < kR * 64) ? n_off - p0 : kR * 64;
+        const unsigned need = (unsigned)(kR * 64 - 1) + lts_len;                     // <= sizeof(lts_win): checked on the host
         wave_sync();
-        for (unsigned i = lane; i < need; i += kWave) sh.lts_win[i] = buf[win0 + (unsigned)p0 + i];
+        for (unsigned i = lane; i < need; i += kWave) {
+            const unsigned g = win0 + (unsigned)p0 + i;
+            sh.lts_win[i] = (g < size) ? buf[g] : 0.0f;                               // beyond the last offset of the last pass
+        }
         wave_sync();
-        for (int r0 = 0; r0 < n_here; r0 += 64) {
-            const int idx = r0 + lane;
-            const bool on = idx < n_here;
-            const int rel = on ? idx : 0;
-            const unsigned offset = win0 + (unsigned)(p0 + rel);
-            float ci = 0.0f, cq = 0.0f, er = 0.0f;
-            const float* p = sh.lts_win + rel;
-            for (unsigned i = 0; i < lts_len; i += 4) {
-                float rx[4];
+        v2f ciq[kR];
+        float er[kR];
 #pragma unroll
-                for (int u = 0; u < 4; ++u) rx[u] = p[i + u];
+        for (int r = 0; r < kR; ++r) { ciq[r] = v2f{0.0f, 0.0f}; er[r] = 0.0f; }
+        const float* p = sh.lts_win + lane;
+        for (unsigned i = 0; i < lts_len; ++i) {
+            const v2f t = {lts_I[i], lts_Q[i]};
 #pragma unroll
-                for (int u = 0; u < 4; ++u) {
-                    const float ti = lts_I[i + u], tq = lts_Q[i + u];
-                    ci += rx[u] * ti;
-                    cq += rx[u] * tq;
-                    er += rx[u] * rx[u];
-                }
+            for (int r = 0; r < kR; ++r) {
+                const float rx = p[i + 64 * r];
+                const v2f r2 = {rx, rx};
+                ciq[r] = ciq[r] + r2 * t;                     // corr_I += rx * I[i]; corr_Q += rx * Q[i] (packed, no contraction)
+                er[r] += rx * rx;                             // energy_rx += rx * rx
             }
-            const float corr_mag = sqrtf(ci * ci + cq * cq);
-            const float norm = sqrtf(er * energy_ref);
+        }
+#pragma unroll
+        for (int r = 0; r < kR; ++r) {                        // increasing offsets within a lane
+            const int idx = lane + 64 * r;
+            const float corr_mag = sqrtf(ciq[r].x * ciq[r].x + ciq[r].y * ciq[r].y);
+            const float norm = sqrtf(er[r] * energy_ref);
             const float corr = (norm > 1e-6f) ? corr_mag / norm : 0.0f;
-            if (on && corr > best_corr) { best_corr = corr; best_off = offset; }   // increasing offsets within a lane
+            if (idx < n_here && corr > best_corr) { best_corr = corr; best_off = win0 + (unsigned)(p0 + idx); }
         }
     }
     wave_sync();
