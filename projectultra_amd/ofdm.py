@@ -2,10 +2,9 @@
 for the part of its surface that is the hot path: the post-sync symbol loop and the
 presynced entry, batched on the GPU.
 
-Acquisition (the Schmidl-Cox search inside process(), src/ofdm/ofdm_sync.cpp) is the
-"next" row of the scope table and is not built: `process()` therefore takes frames that
-are already positioned at the first data symbol together with the CFO the sync stage
-would have produced (`process_synced`).
+`process()` is the chunk-fed receive of the reference: Schmidl-Cox search (scope row f1, on the GPU:
+ultra_hip_acquire_batch) -> SYNCED symbol loop.  `process_synced()` / `processPresynced()` enter past the
+search with the timing and CFO a sync stage produced.
 """
 from __future__ import annotations
 
@@ -35,6 +34,10 @@ class OFDMDemodulator:
         self._chirp_cfo = False
         self._synced = False
         self._state = None
+        self._rx = np.zeros(0, np.float32)   # everything fed so far (the search restarts from a fresh state)
+        self._chunk = None                   # samples per process() call
+        self._last_sync_offset = 0
+        self._data_start = None
 
     def setFrequencyOffset(self, cfo_hz: float) -> None:            # demodulator.cpp:805-814
         self._cfo_hz, self._cfo_phase, self._chirp_cfo = float(cfo_hz), 0.0, True
@@ -90,10 +93,34 @@ class OFDMDemodulator:
         return self._run(ctx, samples)
 
     def process(self, samples) -> bool:
-        raise NotImplementedError(
-            "OFDMDemodulator.process() includes the Schmidl-Cox preamble search "
-            "(src/ofdm/demodulator.cpp:474-600, src/ofdm/ofdm_sync.cpp), which is the next scope row "
-            "and not part of the built hot path; use process_synced() / processPresynced().")
+        """OFDMDemodulator::process (demodulator.cpp:461-700) for a stream fed in equal-sized calls (the
+        harnesses feed 960 samples; the search result depends on the chunking): SEARCHING
+        state on the GPU (ultra_hip_acquire_batch over everything fed so far), then the SYNCED symbol loop
+        once the frame's samples have arrived.  True when at least 648 soft bits are buffered."""
+        samples = np.ascontiguousarray(samples, np.float32).reshape(-1)
+        if self._chunk is None:
+            self._chunk = samples.size
+        elif samples.size > self._chunk:
+            raise ValueError("process(): calls must not grow (the chunk-fed search is emulated with a fixed call size)")
+        self._rx = np.concatenate([self._rx, samples])
+        ctx = self._context(Entry.SYNCED, None, 0)
+        if not self._synced:
+            if self._data_start is None:
+                r = ctx.acquire(self._rx.reshape(1, -1), self._chunk)
+                ctx.synchronize()
+                if not int(r["found"][0]):
+                    return False
+                self._data_start = int(r["data_start"][0])
+                self._cfo_hz, self._cfo_phase = float(r["cfo_hz"][0]), 0.0
+                self._last_sync_offset = int(r["sync_offset"][0])
+            fs = ctx.geometry.frame_samples
+            if self._rx.size < self._data_start + fs:
+                return False                 # the reference would have demodulated the symbols that are complete
+            return self._run(ctx, self._rx[self._data_start:])
+        return self._soft_bits.size >= LDPC_BLOCK_SIZE
+
+    def getLastSyncOffset(self) -> int:      # demodulator.cpp:846-848
+        return self._last_sync_offset
 
     # -- batch API --------------------------------------------------------
     def context(self, entry: Entry = Entry.SYNCED, n_data_symbols=None, training_symbols: int = 2) -> ReceiveContext:

@@ -270,3 +270,25 @@ def test_receive_from_raw_audio_equals_reference(oracle, name):
     ob, oi, ook = oracle.ldpc_decode_batch(int(cfg.code_rate), g[f"{name}__llr"][:, :648])
     assert np.array_equal(r["bytes"][:n], ob) and np.array_equal(r["iters"][:n], oi) and np.array_equal(r["ok"][:n], ook)
     assert (r["entry"][n:] == -1).all() and not r["ok"][n:].any() and not r["bytes"][n:].any() and not r["iters"][n:].any()
+
+
+@pytest.mark.parametrize("name", ["cfg3_qam16_r34", "cfg2_dqpsk_r12"])
+def test_demodulator_mirror_process_chunk_fed(name):
+    """projectultra_amd.OFDMDemodulator.process() fed 960 samples per call, as the harnesses feed the
+    reference (tools/test_nvis_mode.cpp:88-99): same sync offset, coarse CFO and soft bits as the compiled
+    reference produced for the whole frames of tests/golden/fullsync.npz."""
+    from projectultra_amd import OFDMDemodulator
+    from _util import modem_config_from_c
+    g = np.load(GOLDEN / "fullsync.npz")
+    cfg = cfg_from_array(g[f"{name}__cfg"])
+    mc, kw = modem_config_from_c(cfg)
+    for a, meta, cfo, want in zip(g[f"{name}__audio"], g[f"{name}__meta"], g[f"{name}__cfo"], g[f"{name}__llr"]):
+        d = OFDMDemodulator(mc, n_data_symbols=kw.get("n_data_symbols"))
+        ready = False
+        for i in range(0, a.size, 960):
+            ready = d.process(a[i:i + 960])
+        assert ready and d.isSynced()
+        assert d.getLastSyncOffset() == meta[1]
+        assert np.float32(d._cfo_hz).tobytes() == np.float32(cfo).tobytes()
+        soft = np.concatenate([d.getSoftBits(), d.getSoftBits()])
+        assert beq(soft[: want.size], want[: soft.size]) and soft.size >= 648
