@@ -294,4 +294,77 @@ private:
     float state_[ULTRA_HIP_STATE_FLOATS] = {0, 0, 1, 0, 0, 0, 0, 0};
 };
 
+// ---------------------------------------------------------------------------------------------
+// Schmidl-Cox flavour: mirrors ultra::OFDMNvisWaveform's receive half (src/waveform/ofdm_cox_waveform.cpp:
+// 98-138), whose detectSync/process simply feed OFDMDemodulator::process — the chunk-fed search
+// (scope row f1, ultra_hip_acquire_batch) followed by the SYNCED symbol loop.  Feed it equal-sized
+// chunks (the harnesses use 960 samples: the search result depends on the chunking).
+class HipOfdmCoxReceiver {
+public:
+    explicit HipOfdmCoxReceiver(const ModemConfig& config, uint32_t n_data_symbols, int device = 0)
+        : config_(config), ctx_(to_c_config(config, ULTRA_ENTRY_SYNCED, n_data_symbols, 0), device) {
+        detail::check(ultra_hip_get_geometry(ctx_.p, &geo_), "geometry");
+    }
+    void reset() { rx_.clear(); soft_bits_.clear(); chunk_ = 0; synced_ = false; found_ = false; }
+    bool isSynced() const { return synced_; }
+    size_t getLastSyncOffset() const { return sync_offset_; }
+    float getFrequencyOffset() const { return synced_ ? state_[ULTRA_HIP_STATE_FREQ_OFFSET_HZ] : cfo_hz_; }
+    float coarseCFO() const { return cfo_hz_; }
+    bool detectSync(SampleSpan samples, SyncResult& result, float = 0.8f) {        // ofdm_cox_waveform.cpp:98-120
+        process(samples);
+        if (!found_) return false;
+        result.detected = true;
+        result.start_sample = static_cast<int>(sync_offset_);
+        result.cfo_hz = getFrequencyOffset();
+        return true;
+    }
+    // OFDMDemodulator::process: true when at least 648 soft bits are buffered
+    bool process(SampleSpan samples) {
+        if (chunk_ == 0) chunk_ = static_cast<uint32_t>(samples.size());
+        rx_.insert(rx_.end(), samples.begin(), samples.end());
+        if (synced_) return soft_bits_.size() >= 648;
+        if (!found_) {
+            detail::DevBuf d_a(ctx_.p, rx_.size() * sizeof(float)), d_o(ctx_.p, 5 * sizeof(uint32_t));
+            detail::check(ultra_hip_memcpy_h2d(ctx_.p, d_a.d, rx_.data(), rx_.size() * sizeof(float)), "h2d");
+            uint32_t* o = static_cast<uint32_t*>(d_o.d);
+            detail::check(ultra_hip_acquire_batch(ctx_.p, static_cast<const float*>(d_a.d), rx_.size(),
+                                                  static_cast<uint32_t>(rx_.size()), chunk_, 1, o, o + 1,
+                                                  reinterpret_cast<float*>(o + 2), o + 3, o + 4), "acquire_batch");
+            uint32_t h[5];
+            detail::check(ultra_hip_memcpy_d2h(ctx_.p, h, d_o.d, sizeof(h)), "d2h");
+            if (!h[0]) return false;
+            found_ = true; data_start_ = h[1]; std::memcpy(&cfo_hz_, &h[2], sizeof(float)); sync_offset_ = h[3];
+        }
+        if (rx_.size() < size_t(data_start_) + geo_.frame_samples) return false;
+        detail::DevBuf d_a(ctx_.p, geo_.frame_samples * sizeof(float)), d_c(ctx_.p, sizeof(float)),
+            d_l(ctx_.p, geo_.llrs_per_frame * sizeof(float)), d_s(ctx_.p, ULTRA_HIP_STATE_FLOATS * sizeof(float));
+        detail::check(ultra_hip_memcpy_h2d(ctx_.p, d_a.d, rx_.data() + data_start_, geo_.frame_samples * sizeof(float)), "h2d");
+        detail::check(ultra_hip_memcpy_h2d(ctx_.p, d_c.d, &cfo_hz_, sizeof(float)), "h2d");
+        detail::check(ultra_hip_demod_batch(ctx_.p, static_cast<const float*>(d_a.d), geo_.frame_samples,
+                                            static_cast<const float*>(d_c.d), nullptr, 1, static_cast<float*>(d_l.d),
+                                            static_cast<float*>(d_s.d)), "demod_batch");
+        soft_bits_.resize(geo_.llrs_per_frame);
+        detail::check(ultra_hip_memcpy_d2h(ctx_.p, soft_bits_.data(), d_l.d, geo_.llrs_per_frame * sizeof(float)), "d2h");
+        detail::check(ultra_hip_memcpy_d2h(ctx_.p, state_, d_s.d, sizeof(state_)), "d2h");
+        synced_ = true;
+        return soft_bits_.size() >= 648;
+    }
+    std::vector<float> getSoftBits() {                                    // 648 at a time (demodulator.cpp:766-791)
+        if (soft_bits_.size() <= 648) return std::move(soft_bits_);
+        std::vector<float> out(soft_bits_.begin(), soft_bits_.begin() + 648);
+        soft_bits_.erase(soft_bits_.begin(), soft_bits_.begin() + 648);
+        return out;
+    }
+
+private:
+    ModemConfig config_;
+    detail::Ctx ctx_;
+    ultra_hip_geometry geo_{};
+    std::vector<float> rx_, soft_bits_;
+    uint32_t chunk_ = 0, data_start_ = 0, sync_offset_ = 0;
+    float cfo_hz_ = 0.0f;
+    bool synced_ = false, found_ = false;
+    float state_[ULTRA_HIP_STATE_FLOATS] = {0, 0, 1, 0, 0, 0, 0, 0};
+};
+
 }  // namespace ultra_hip

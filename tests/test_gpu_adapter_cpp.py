@@ -1,0 +1,80 @@
+"""The header-only C++ adapter (include/ultra_hip_waveform.hpp) RUN on the GPU: a small program, compiled
+on the box with g++ against libultra_hip.so, receives the whole frames of tests/golden/fullsync.npz the
+way a reference harness would (960-sample chunks -> process -> getSoftBits -> decodeSoft) and its
+outputs are compared with what the compiled reference produced."""
+import subprocess
+from pathlib import Path
+
+import numpy as np
+import pytest
+
+from _util import beq, cfg_from_array
+from conftest import GOLDEN
+
+pytestmark = pytest.mark.gpu
+ROOT = Path(__file__).resolve().parent.parent
+
+SRC = r'''
+#include "ultra_hip_waveform.hpp"
+#include <cstdio>
+#include <vector>
+using namespace ultra_hip;
+int main(int argc, char** argv) {
+    // argv: in.f32 n_samples out_llr.f32 out_bytes.bin fft carriers cp_mode guard pilot_spacing use_pilots mod rate n_data
+    FILE* f = std::fopen(argv[1], "rb");
+    const size_t n = std::stoul(argv[2]);
+    std::vector<float> audio(n);
+    if (std::fread(audio.data(), 4, n, f) != n) return 2;
+    std::fclose(f);
+    ModemConfig c;
+    c.fft_size = std::stoul(argv[5]); c.num_carriers = std::stoul(argv[6]);
+    c.cp_mode = static_cast<decltype(c.cp_mode)>(std::stoi(argv[7])); c.symbol_guard = std::stoul(argv[8]);
+    c.pilot_spacing = std::stoul(argv[9]); c.use_pilots = std::stoi(argv[10]) != 0;
+    c.modulation = static_cast<Modulation>(std::stoi(argv[11])); c.code_rate = static_cast<CodeRate>(std::stoi(argv[12]));
+    HipOfdmCoxReceiver rx(c, std::stoul(argv[13]));
+    bool ready = false;
+    for (size_t i = 0; i < n; i += 960) {                       // tools/test_nvis_mode.cpp:88-99
+        const size_t len = std::min<size_t>(960, n - i);
+        ready = rx.process(SampleSpan(audio.data() + i, len));
+    }
+    if (!ready) return 3;
+    std::vector<float> soft = rx.getSoftBits();                 // first 648
+    HipLDPCDecoder dec(c.code_rate);
+    Bytes out = dec.decodeSoft(std::span<const float>(soft.data(), soft.size()));
+    FILE* g = std::fopen(argv[3], "wb"); std::fwrite(soft.data(), 4, soft.size(), g); std::fclose(g);
+    g = std::fopen(argv[4], "wb"); std::fwrite(out.data(), 1, out.size(), g);
+    const int meta[3] = {dec.lastDecodeSuccess() ? 1 : 0, dec.lastIterations(), (int)rx.getLastSyncOffset()};
+    std::fwrite(meta, 4, 3, g); std::fclose(g);
+    float cfo = rx.coarseCFO(); g = std::fopen(argv[3], "ab"); std::fwrite(&cfo, 4, 1, g); std::fclose(g);
+    return 0;
+}
+'''
+
+
+@pytest.mark.parametrize("name", ["cfg3_qam16_r34", "cfg2_dqpsk_r12"])
+def test_cpp_adapter_receives_reference_frames(tmp_path, oracle, name):
+    g = np.load(GOLDEN / "fullsync.npz")
+    cfg = cfg_from_array(g[f"{name}__cfg"])
+    src = tmp_path / "rx.cpp"
+    src.write_text(SRC)
+    exe = tmp_path / "rx"
+    lib = ROOT / "projectultra_amd"
+    subprocess.check_call(["g++", "-O1", "-std=c++20", f"-I{ROOT / 'include'}", str(src), f"-L{lib}", "-lultra_hip",
+                           f"-Wl,-rpath,{lib}", "-o", str(exe)])
+    for t, (a, meta, cfo, want) in enumerate(zip(g[f"{name}__audio"], g[f"{name}__meta"], g[f"{name}__cfo"], g[f"{name}__llr"])):
+        fin, fl, fb = tmp_path / f"in{t}.f32", tmp_path / f"llr{t}.f32", tmp_path / f"bytes{t}.bin"
+        a.astype(np.float32).tofile(fin)
+        args = [str(exe), str(fin), str(a.size), str(fl), str(fb)] + [str(int(x)) for x in (
+            cfg.fft_size, cfg.num_carriers, cfg.cp_mode, cfg.symbol_guard, cfg.pilot_spacing, cfg.use_pilots,
+            cfg.modulation, cfg.code_rate, cfg.n_data_symbols)]
+        r = subprocess.run(args, capture_output=True, text=True, timeout=300)
+        assert r.returncode == 0, (r.returncode, r.stderr[-400:])
+        got = np.fromfile(fl, np.float32)
+        assert beq(got[:648], want[:648]), name
+        assert np.float32(got[648]).tobytes() == np.float32(cfo).tobytes()
+        raw = np.fromfile(fb, np.uint8)
+        nbytes = raw.size - 12
+        ok, iters, sync_off = np.frombuffer(raw[nbytes:].tobytes(), np.int32)
+        ob, oi, ook = oracle.ldpc_decode_batch(int(cfg.code_rate), want[:648].reshape(1, 648))
+        assert np.array_equal(raw[:nbytes], ob[0]) and ok == ook[0] and iters == oi[0]
+        assert sync_off == meta[1]
