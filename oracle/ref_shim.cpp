@@ -287,33 +287,40 @@ int ref_demod_process_coarse(const ultra_hip_config* c, const float* audio, uint
 
 // Acquisition (scope row f1): OFDMDemodulator::process in the SEARCHING state, fed in `chunk`-sample
 // calls (src/ofdm/demodulator.cpp:461-600).  Reports, per stream: whether sync was declared, after how
-// many fed samples, the Schmidl-Cox offset (last_sync_offset), the coarse CFO and the refined LTS start
-// it was declared with, and data_start = refined_lts + 2 preamble symbols (= what process() consumes,
-// :572).  The last three are re-derived on a probe demodulator holding the same buffer, calling the
-// reference's own Impl::estimateCoarseCFO / refineLTSTiming; valid while no trimming happened, i.e. for
-// streams shorter than 2*OVERLAP_SAMPLES = 40000 samples (returns -2 otherwise).
+// many fed samples, the Schmidl-Cox offset (last_sync_offset, relative to the buffer at that call), the
+// coarse CFO and the refined LTS start it was declared with, and the absolute data_start (what process()
+// erases the buffer up to, :572).  The buffer's absolute start is tracked from rx_buffer.size() after
+// every SEARCHING call (trims of :524-531,:592-597 and the overflow rule :482-487); coarse CFO and
+// refined LTS start are re-derived on a probe demodulator holding the same buffer, calling the
+// reference's own Impl::estimateCoarseCFO / refineLTSTiming.
 int ref_demod_acquire(const ultra_hip_config* c, const float* audio, uint32_t n, uint32_t chunk,
                       uint32_t* found, uint32_t* fed_at_sync, uint32_t* sync_offset, float* coarse_cfo,
                       uint32_t* refined_lts, uint32_t* data_start, float* noise_floor) {
-    if (n >= 40000) return -2;
     StderrMute mute;
     ModemConfig cfg = to_cfg(c);
     OFDMDemodulator demod(cfg);
     *found = 0; *fed_at_sync = 0; *sync_offset = 0; *coarse_cfo = 0; *refined_lts = 0; *data_start = 0;
+    size_t base = 0;                                   // absolute index of rx_buffer[0] before the next call
     for (uint32_t i = 0; i < n; i += chunk) {
         uint32_t len = std::min(chunk, n - i);
+        const size_t fed = (size_t)i + len;
         demod.process(SampleSpan(audio + i, len));
-        if (demod.isSynced()) { *found = 1; *fed_at_sync = i + len; break; }
+        if (demod.isSynced()) {
+            *found = 1; *fed_at_sync = (uint32_t)fed;
+            if (fed - base > 240000) base = fed - 20000;           // MAX_BUFFER_SAMPLES / OVERLAP_SAMPLES at the top of the call
+            break;
+        }
+        base = fed - demod.impl_->rx_buffer.size();
     }
     *noise_floor = demod.impl_->noise_floor_energy;
     if (*found) {
         *sync_offset = (uint32_t)demod.getLastSyncOffset();
         OFDMDemodulator probe(cfg);
-        probe.impl_->rx_buffer.assign(audio, audio + *fed_at_sync);
+        probe.impl_->rx_buffer.assign(audio + base, audio + *fed_at_sync);
         *coarse_cfo = probe.impl_->estimateCoarseCFO(*sync_offset);
         size_t r = probe.impl_->refineLTSTiming(*sync_offset);
         *refined_lts = (uint32_t)r;
-        *data_start = (uint32_t)(r + 2 * (cfg.fft_size + cfg.getCyclicPrefix()));
+        *data_start = (uint32_t)(base + r + 2 * (cfg.fft_size + cfg.getCyclicPrefix()));
     }
     return 0;
 }

@@ -66,3 +66,23 @@ def nonfinite_cases(rng, oracle, rate, n=12):
             llr[ix] = vals[(i + j) % len(vals)]
         out.append(llr)
     return np.stack(out)
+
+
+def long_acquisition_streams(oracle, cfg, rng):
+    """Streams longer than 2 * OVERLAP_SAMPLES = 40000 samples, so that the buffer trims of the SEARCHING
+    state run (demodulator.cpp:482-487,547-553,592-597): a 1.5 kHz tone (half-symbol periodic: Schmidl-Cox
+    fires, the LTS confirmation fails) or low noise, then a whole frame at 30 dB, then a tail."""
+    out = []
+    for kind in ("tone", "noise", "tone"):
+        payload = bytes(rng.integers(0, 256, INFO_BITS[cfg.code_rate] // 8, dtype=np.uint8))
+        a, _ = oracle.modulate_frame(cfg, oracle.ldpc_encode(int(cfg.code_rate), payload))
+        a = a * np.float32(0.5 / np.abs(a).max())
+        a = (a + rng.normal(0, np.sqrt(np.mean(a.astype(np.float64) ** 2) / 1000), a.size)).astype(np.float32)
+        n_lead = int(rng.integers(41000, 47000))
+        if kind == "tone":
+            lead = (0.2 * np.sin(2 * np.pi * 1500.0 * np.arange(n_lead) / 48000.0) + rng.normal(0, 1e-3, n_lead)).astype(np.float32)
+            lead[-3000:] = rng.normal(0, 1e-3, 3000).astype(np.float32)
+        else:
+            lead = rng.normal(0, 2e-3, n_lead).astype(np.float32)
+        out.append(np.concatenate([lead, a, rng.normal(0, 1e-3, 2500).astype(np.float32)]))
+    return out

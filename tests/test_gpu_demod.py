@@ -4,7 +4,7 @@ vs the oracle on seeded synthetic frames.  LLRs are compared BITWISE (stricter t
 import numpy as np
 import pytest
 
-from _util import INFO_BITS, beq, cfg_from_array, context_for, geometry, make_config
+from _util import INFO_BITS, beq, cfg_from_array, context_for, geometry, long_acquisition_streams, make_config
 from conftest import GOLDEN
 
 pytestmark = pytest.mark.gpu
@@ -292,3 +292,27 @@ def test_demodulator_mirror_process_chunk_fed(name):
         assert np.float32(d._cfo_hz).tobytes() == np.float32(cfo).tobytes()
         soft = np.concatenate([d.getSoftBits(), d.getSoftBits()])
         assert beq(soft[: want.size], want[: soft.size]) and soft.size >= 648
+
+
+@pytest.mark.parametrize("fft,mod,rate", [(1024, "QAM16", "R3_4"), (512, "DQPSK", "R1_2")])
+def test_acquisition_long_streams_with_trims(oracle, fft, mod, rate):
+    """Streams past 40000 samples (buffer trims, failed LTS confirmations on a tone) on the GPU == oracle
+    (== compiled reference: tests/test_oracle_vs_ref.py::test_acquisition_long_streams_with_trims)."""
+    cfg = make_config(fft, mod, rate)
+    streams = long_acquisition_streams(oracle, cfg, np.random.default_rng(21))
+    n = min(x.size for x in streams)
+    audio = np.stack([x[:n] for x in streams])
+    ctx = context_for(cfg)
+    r = ctx.acquire(audio, 960)
+    ctx.synchronize()
+    r = {k: v.cpu().numpy() for k, v in r.items()}
+    hits = 0
+    for i in range(audio.shape[0]):
+        o = oracle.acquire(cfg, audio[i], 960)
+        assert r["found"][i] == o["found"], (i, o)
+        if o["found"]:
+            hits += 1
+            assert r["data_start"][i] == o["data_start"] and r["sync_offset"][i] == o["sync_offset"], (i, o)
+            assert r["fed_at_sync"][i] == o["fed_at_sync"]
+            assert np.float32(r["cfo_hz"][i]).tobytes() == np.float32(o["coarse_cfo"]).tobytes()
+    assert hits >= 1

@@ -3,7 +3,7 @@ box that received the prebuilt .so).  Everything is compared BITWISE, stage by s
 import numpy as np
 import pytest
 
-from _util import beq, nonfinite_cases
+from _util import beq, long_acquisition_streams, nonfinite_cases
 from oracle.bindings import INFO_BITS, geometry, make_config
 
 
@@ -182,3 +182,20 @@ def test_acquisition_whole_streams(oracle, ref, fft, mod, rate, kw):
             assert np.float32(o["noise_floor"]).tobytes() == np.float32(r["noise_floor"]).tobytes(), (o, r)
             hits += o["found"]
     assert hits >= 6
+
+
+@pytest.mark.parametrize("fft,mod,rate,kw", ACQ_MODES)
+def test_acquisition_long_streams_with_trims(oracle, ref, fft, mod, rate, kw):
+    """Streams past 40000 samples: false Schmidl-Cox triggers on a tone with failing LTS confirmation, buffer
+    trims, then the real preamble.  Oracle == compiled reference on every reported quantity."""
+    cfg = make_config(fft, mod, rate, **kw)
+    found = 0
+    for x in long_acquisition_streams(oracle, cfg, np.random.default_rng(21)):
+        o = oracle.acquire(cfg, x, 960)
+        r = ref.acquire(cfg, x, 960)
+        for k in ("found", "fed_at_sync", "sync_offset", "refined_lts", "data_start"):
+            assert o[k] == r[k], (k, o, r)
+        assert np.float32(o["coarse_cfo"]).tobytes() == np.float32(r["coarse_cfo"]).tobytes(), (o, r)
+        assert np.float32(o["noise_floor"]).tobytes() == np.float32(r["noise_floor"]).tobytes(), (o, r)
+        found += o["found"]
+    assert found >= 1
