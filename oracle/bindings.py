@@ -101,6 +101,31 @@ class _Base:
     def _fn(self, name):
         return getattr(self.lib, self.prefix + name)
 
+    # -------------------------------------------------------- chirp sync
+    def chirp_detect(self, audio, threshold=0.15, sample_rate=48000.0):
+        """detectDualChirp + OFDMChirpWaveform::detectSync -> dict(success, up_chirp_start, down_chirp_start,
+        start_sample, cfo_hz, up_correlation, down_correlation)."""
+        audio = _f32(audio)
+        out = (C.c_int32 * 6)(); fout = (C.c_float * 3)()
+        rc = self._fn("chirp_detect")(C.c_float(sample_rate), _ptr(audio), C.c_uint32(audio.size), C.c_float(threshold), out, fout)
+        assert rc == 0
+        return dict(success=out[0], up_chirp_start=out[1], down_chirp_start=out[2], start_sample=out[3],
+                    cfo_hz=fout[0], up_correlation=fout[1], down_correlation=fout[2])
+
+    def chirp_generate(self, tx_cfo_hz=0.0, sample_rate=48000.0):
+        out = np.zeros(1 << 17, np.float32)
+        n = self._fn("chirp_generate")(C.c_float(sample_rate), C.c_float(tx_cfo_hz), _ptr(out), C.c_uint32(out.size))
+        assert n > 0
+        return out[:n].copy()
+
+    def chirp_templates(self, sample_rate=48000.0):
+        cap = 1 << 16
+        t = [np.zeros(cap, np.float32) for _ in range(4)]
+        e = np.zeros(2, np.float32)
+        m = self._fn("chirp_templates")(C.c_float(sample_rate), _ptr(t[0]), _ptr(t[1]), _ptr(t[2]), _ptr(t[3]), _ptr(e), C.c_uint32(cap))
+        assert m > 0
+        return [x[:m].copy() for x in t], e
+
     # ------------------------------------------------------- acquisition
     def acquire(self, cfg, audio, chunk=960):
         """SEARCHING state fed in chunk-sample calls -> dict(found, fed_at_sync, sync_offset, coarse_cfo,

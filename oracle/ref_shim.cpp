@@ -35,6 +35,9 @@
 #include "ultra/fec.hpp"
 #include "ofdm/demodulator_impl.hpp"
 #include "sim/hf_channel.hpp"
+#define private public
+#include "sync/chirp_sync.hpp"
+#undef private
 
 #include "../include/ultra_hip.h"
 
@@ -351,6 +354,49 @@ int ref_lts_templates(const ultra_hip_config* c, float* I, float* Q, uint32_t ca
     if (m > cap) return -1;
     std::memcpy(I, probe.impl_->lts_passband_I.data(), m * sizeof(float));
     std::memcpy(Q, probe.impl_->lts_passband_Q.data(), m * sizeof(float));
+    return (int)m;
+}
+
+// Chirp synchronisation (scope row f4): sync::ChirpSync with OFDMChirpWaveform's configuration
+// (ofdm_chirp_waveform.cpp:39-49) and OFDMChirpWaveform::detectSync's start_sample arithmetic (:129-172).
+static sync::ChirpConfig chirp_cfg(float sample_rate, float tx_cfo) {
+    sync::ChirpConfig cfg;
+    cfg.sample_rate = sample_rate; cfg.f_start = 300.0f; cfg.f_end = 2700.0f; cfg.duration_ms = 500.0f;
+    cfg.gap_ms = 100.0f; cfg.use_dual_chirp = true; cfg.tx_cfo_hz = tx_cfo;
+    return cfg;
+}
+int ref_chirp_detect(float sample_rate, const float* x, uint32_t n, float threshold, int32_t* out, float* fout) {
+    StderrMute mute;
+    fflush(stdout); int saved = dup(1); int nul = open("/dev/null", O_WRONLY); dup2(nul, 1); close(nul);   // detectDualChirp printf()s
+    sync::ChirpSync cs(chirp_cfg(sample_rate, 0.0f));
+    auto r = cs.detectDualChirp(SampleSpan(x, n), threshold);
+    fflush(stdout); dup2(saved, 1); close(saved);
+    out[0] = r.success ? 1 : 0; out[1] = r.success ? r.up_chirp_start : -1; out[2] = r.success ? r.down_chirp_start : -1;
+    out[3] = -1; out[4] = -1; out[5] = -1;
+    fout[0] = r.cfo_hz; fout[1] = r.up_correlation; fout[2] = r.down_correlation;
+    if (r.success) {
+        size_t chirp_samples = cs.getChirpSamples();
+        size_t gap_samples = static_cast<size_t>((uint32_t)sample_rate * 100.0f / 1000.0f);
+        out[3] = (int)(r.down_chirp_start + chirp_samples + gap_samples);
+    }
+    return 0;
+}
+int ref_chirp_generate(float sample_rate, float tx_cfo_hz, float* out, uint32_t cap) {
+    StderrMute mute;
+    sync::ChirpSync cs(chirp_cfg(sample_rate, tx_cfo_hz));
+    Samples s = cs.generate();
+    if (s.size() > cap) return -1;
+    std::memcpy(out, s.data(), s.size() * sizeof(float));
+    return (int)s.size();
+}
+int ref_chirp_templates(float sample_rate, float* up_s, float* up_c, float* dn_s, float* dn_c, float* energies, uint32_t cap) {
+    StderrMute mute;
+    sync::ChirpSync cs(chirp_cfg(sample_rate, 0.0f));
+    size_t m = cs.up_chirp_template_.size();
+    if (m > cap) return -1;
+    std::memcpy(up_s, cs.up_chirp_template_.data(), 4 * m); std::memcpy(up_c, cs.up_chirp_template_cos_.data(), 4 * m);
+    std::memcpy(dn_s, cs.down_chirp_template_.data(), 4 * m); std::memcpy(dn_c, cs.down_chirp_template_cos_.data(), 4 * m);
+    energies[0] = cs.template_energy_; energies[1] = cs.down_template_energy_;
     return (int)m;
 }
 

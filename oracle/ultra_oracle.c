@@ -1572,6 +1572,184 @@ int uo_lts_templates(const ultra_hip_config* c, float* I, float* Q, uint32_t cap
 }
 
 /* ====================================================================== */
+/* Chirp synchronisation (scope row f4): sync::ChirpSync, src/sync/chirp_sync.hpp,  */
+/* as configured by OFDMChirpWaveform (src/waveform/ofdm_chirp_waveform.cpp:39-49,   */
+/* 129-172): 300 -> 2700 Hz up chirp, 100 ms gap, down chirp, 500 ms each.          */
+/* ====================================================================== */
+typedef struct chirp_sync {
+    float fs, f_start, f_end, duration_ms, gap_ms, amplitude, tx_cfo;
+    size_t len;
+    float *up_s, *up_c, *dn_s, *dn_c;
+    float e_up, e_dn;
+} chirp_sync;
+
+static float chirp_up_phase(const chirp_sync* c, float t) {      /* chirp_sync.hpp:687-691 */
+    float T = c->duration_ms / 1000.0f;
+    float k = (c->f_end - c->f_start) / T;
+    return (float)(2.0f * M_PI * (double)(c->f_start * t + 0.5f * k * t * t));
+}
+static float chirp_down_phase(const chirp_sync* c, float t) {    /* :694-699 */
+    float T = c->duration_ms / 1000.0f;
+    float k = (c->f_end - c->f_start) / T;
+    return (float)(2.0f * M_PI * (double)(c->f_end * t - 0.5f * k * t * t));
+}
+static int chirp_init(chirp_sync* c, float sample_rate, float tx_cfo) {   /* ctor + generateTemplate :706-732 */
+    c->fs = sample_rate; c->f_start = 300.0f; c->f_end = 2700.0f; c->duration_ms = 500.0f; c->gap_ms = 100.0f;
+    c->amplitude = 0.5f; c->tx_cfo = tx_cfo;
+    c->len = (size_t)(c->fs * c->duration_ms / 1000.0f);
+    c->up_s = (float*)malloc(sizeof(float) * c->len * 4);
+    if (!c->up_s) return -1;
+    c->up_c = c->up_s + c->len; c->dn_s = c->up_c + c->len; c->dn_c = c->dn_s + c->len;
+    c->e_up = 0.0f; c->e_dn = 0.0f;
+    for (size_t i = 0; i < c->len; ++i) {
+        float t = (float)i / c->fs;
+        float ph = chirp_up_phase(c, t);
+        c->up_s[i] = sinf(ph); c->up_c[i] = cosf(ph);
+        c->e_up += c->up_s[i] * c->up_s[i];
+    }
+    for (size_t i = 0; i < c->len; ++i) {
+        float t = (float)i / c->fs;
+        float ph = chirp_down_phase(c, t);
+        c->dn_s[i] = sinf(ph); c->dn_c[i] = cosf(ph);
+        c->e_dn += c->dn_s[i] * c->dn_s[i];
+    }
+    return 0;
+}
+static void chirp_free(chirp_sync* c) { free(c->up_s); c->up_s = NULL; }
+
+/* computeComplexTemplateCorrelation, chirp_sync.hpp:532-556 */
+static float chirp_corr(const float* x, size_t n, size_t offset, const float* ts, const float* tc, size_t len, float energy) {
+    if (offset + len > n) return 0.0f;
+    float cI = 0.0f, cQ = 0.0f, se = 0.0f;
+    for (size_t i = 0; i < len; ++i) {
+        float s = x[offset + i];
+        cI += s * tc[i];
+        cQ += s * ts[i];
+        se += s * s;
+    }
+    float denom = sqrtf(se * energy);
+    if (denom < 1e-10f) return 0.0f;
+    return sqrtf(cI * cI + cQ * cQ) / denom;
+}
+
+/* detectChirpTemplate, chirp_sync.hpp:560-632 */
+static int chirp_detect_template(const float* x, size_t n, const float* ts, const float* tc, size_t len, float energy,
+                                 float threshold, float* corr_out) {
+    if (n < len) { *corr_out = 0.0f; return -1; }
+    const size_t search_len = n - len;
+    float best_corr = 0.0f; int best_pos = -1;
+    for (size_t pos = 0; pos < search_len; pos += 48) {
+        float c = chirp_corr(x, n, pos, ts, tc, len, energy);
+        if (c > best_corr) { best_corr = c; best_pos = (int)pos; }
+    }
+    if (best_pos < 0 || best_corr < threshold * 0.3f) { *corr_out = best_corr; return -1; }
+    int fine_start = best_pos - 48; if (fine_start < 0) fine_start = 0;
+    int fine_end = best_pos + 48; if (fine_end > (int)search_len) fine_end = (int)search_len;
+    for (int pos = fine_start; pos <= fine_end; ++pos) {
+        float c = chirp_corr(x, n, (size_t)pos, ts, tc, len, energy);
+        if (c > best_corr) { best_corr = c; best_pos = pos; }
+    }
+    if (best_pos > 0 && best_pos < (int)search_len - 1) {
+        float c0 = chirp_corr(x, n, (size_t)(best_pos - 1), ts, tc, len, energy);
+        float c1 = best_corr;
+        float c2 = chirp_corr(x, n, (size_t)(best_pos + 1), ts, tc, len, energy);
+        float denom = 2.0f * (c0 - 2.0f * c1 + c2);
+        if (fabsf(denom) > 1e-10f) {
+            float delta = (c0 - c2) / denom;
+            delta = f_max(-1.0f, f_min(1.0f, delta));
+            best_pos = (int)roundf((float)best_pos + delta);
+        }
+    }
+    *corr_out = best_corr;
+    return (best_corr >= threshold) ? best_pos : -1;
+}
+
+/* detectDualChirp (:349-505) + OFDMChirpWaveform::detectSync's start_sample (ofdm_chirp_waveform.cpp:129-172).
+ * out[0..5] = success, up_chirp_start, down_chirp_start, start_sample (training start), raw up_pos, raw down_pos;
+ * fout[0..2] = cfo_hz, up_correlation, down_correlation */
+int uo_chirp_detect(float sample_rate, const float* x, uint32_t n, float threshold, int32_t* out, float* fout) {
+    chirp_sync c;
+    if (chirp_init(&c, sample_rate, 0.0f) != 0) return -1;
+    for (int i = 0; i < 6; ++i) out[i] = (i == 0) ? 0 : -1;
+    fout[0] = fout[1] = fout[2] = 0.0f;
+    const size_t len = c.len, gap = (size_t)(c.fs * c.gap_ms / 1000.0f);
+    if ((size_t)n >= 2 * len + gap) {
+        float up_corr = 0.0f;
+        int up_pos = chirp_detect_template(x, n, c.up_s, c.up_c, len, c.e_up, threshold, &up_corr);
+        fout[1] = up_corr;
+        if (up_pos >= 0) {
+            out[4] = up_pos;
+            size_t ds = (size_t)up_pos + len / 2;
+            size_t expected_down = (size_t)up_pos + len + gap;
+            size_t de = expected_down + 2 * len; if (de > n) de = n;
+            if (ds < n) {
+                if (de <= ds + len) { de = ds + 2 * len; if (de > n) de = n; }
+                float dn_corr = 0.0f;
+                int dn_rel = chirp_detect_template(x + ds, de - ds, c.dn_s, c.dn_c, len, c.e_dn, threshold, &dn_corr);
+                if (dn_rel >= 0) {
+                    int dn_pos = dn_rel + (int)ds;
+                    out[5] = dn_pos; fout[2] = dn_corr;
+                    float T = c.duration_ms / 1000.0f;
+                    float chirp_rate = (c.f_end - c.f_start) / T;
+                    float cfo_to_samples = c.fs / chirp_rate;
+                    int expected_gap = (int)(len + gap);
+                    int actual_gap = dn_pos - up_pos;
+                    float gap_error = (float)(actual_gap - expected_gap);
+                    float cfo = gap_error / (2.0f * cfo_to_samples);
+                    fout[0] = cfo;
+                    if (!(fabsf(cfo) > 100.0f)) {
+                        float up_correction = cfo * cfo_to_samples, down_correction = -cfo * cfo_to_samples;
+                        out[1] = (int)roundf((float)up_pos + up_correction);
+                        out[2] = (int)roundf((float)dn_pos + down_correction);
+                        out[0] = 1;
+                        /* result.start_sample = down_chirp_start + chirp_samples + gap_samples */
+                        size_t gap2 = (size_t)((float)(uint32_t)sample_rate * 100.0f / 1000.0f);
+                        out[3] = (int)((size_t)out[2] + len + gap2);
+                    }
+                }
+            }
+        }
+    }
+    chirp_free(&c);
+    return 0;
+}
+
+/* ChirpSync::generate (:37-106): up chirp, gap, down chirp, gap */
+int uo_chirp_generate(float sample_rate, float tx_cfo_hz, float* out, uint32_t cap) {
+    chirp_sync c;
+    if (chirp_init(&c, sample_rate, tx_cfo_hz) != 0) return -1;
+    size_t len = c.len, gap = (size_t)(c.fs * c.gap_ms / 1000.0f), total = 2 * len + 2 * gap;
+    if (total > cap) { chirp_free(&c); return -1; }
+    for (size_t i = 0; i < total; ++i) out[i] = 0.0f;
+    float T = c.duration_ms / 1000.0f, k = (c.f_end - c.f_start) / T;
+    float f_up = c.f_start + c.tx_cfo, f_dn = c.f_end + c.tx_cfo;
+    for (size_t i = 0; i < len; ++i) {
+        float t = (float)i / c.fs;
+        float ph = (float)(2.0f * M_PI * (double)(f_up * t + 0.5f * k * t * t));
+        out[i] = c.amplitude * sinf(ph);
+    }
+    for (size_t i = 0; i < len; ++i) {
+        float t = (float)i / c.fs;
+        float ph = (float)(2.0f * M_PI * (double)(f_dn * t - 0.5f * k * t * t));
+        out[len + gap + i] = c.amplitude * sinf(ph);
+    }
+    chirp_free(&c);
+    return (int)total;
+}
+
+int uo_chirp_templates(float sample_rate, float* up_s, float* up_c, float* dn_s, float* dn_c, float* energies, uint32_t cap) {
+    chirp_sync c;
+    if (chirp_init(&c, sample_rate, 0.0f) != 0) return -1;
+    if (c.len > cap) { chirp_free(&c); return -1; }
+    memcpy(up_s, c.up_s, 4 * c.len); memcpy(up_c, c.up_c, 4 * c.len);
+    memcpy(dn_s, c.dn_s, 4 * c.len); memcpy(dn_c, c.dn_c, 4 * c.len);
+    energies[0] = c.e_up; energies[1] = c.e_dn;
+    int m = (int)c.len;
+    chirp_free(&c);
+    return m;
+}
+
+/* ====================================================================== */
 /* Modulator (stimulus), src/ofdm/modulator.cpp                            */
 /* ====================================================================== */
 typedef struct modulator {

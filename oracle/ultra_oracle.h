@@ -62,6 +62,12 @@ int uo_sc_metric(const ultra_hip_config* c, const float* audio, uint32_t n, uint
                  float* corr, float* p_re, float* p_im, float* energy, float* noise_floor_io, uint32_t* has_energy);
 int uo_lts_templates(const ultra_hip_config* c, float* I, float* Q, uint32_t cap);
 
+/* ---- chirp synchronisation (scope row f4): sync::ChirpSync as configured by OFDMChirpWaveform; same
+ * outputs as ref_chirp_detect / ref_chirp_generate / ref_chirp_templates (oracle/ref_shim.cpp) */
+int uo_chirp_detect(float sample_rate, const float* x, uint32_t n, float threshold, int32_t* out, float* fout);
+int uo_chirp_generate(float sample_rate, float tx_cfo_hz, float* out, uint32_t cap);
+int uo_chirp_templates(float sample_rate, float* up_s, float* up_c, float* dn_s, float* dn_c, float* energies, uint32_t cap);
+
 /* ---- demodulator ------------------------------------------------------- */
 int uo_demod_tables(const ultra_hip_config* c, int32_t* data_idx, int32_t* pilot_idx,
                     float* pilot_seq_ri, int32_t* interp_i, float* interp_alpha,

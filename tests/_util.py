@@ -86,3 +86,22 @@ def long_acquisition_streams(oracle, cfg, rng):
             lead = rng.normal(0, 2e-3, n_lead).astype(np.float32)
         out.append(np.concatenate([lead, a, rng.normal(0, 1e-3, 2500).astype(np.float32)]))
     return out
+
+
+def chirp_streams(oracle, cfg, rng, n=5):
+    """[noise lead][up chirp, gap, down chirp, gap (ChirpSync::generate, optional TX CFO)][2 training symbols +
+    data (generateTrainingSymbols + modulate)][tail], AWGN — what OFDMChirpWaveform transmits
+    (ofdm_chirp_waveform.cpp:104-127).  cfg must use the PRESYNCED entry."""
+    out = []
+    for t in range(n):
+        payload = bytes(rng.integers(0, 256, 2 * (INFO_BITS[cfg.code_rate] // 8), dtype=np.uint8))
+        body = oracle.modulate_presynced(cfg, oracle.ldpc_encode(int(cfg.code_rate), payload))
+        chirp = oracle.chirp_generate(tx_cfo_hz=[0.0, 12.5, -30.0, 55.0, 0.0][t % 5])
+        sig = np.concatenate([chirp, body * np.float32(0.5 / np.abs(body).max())])
+        snr_db = [30.0, 15.0, 8.0, 20.0, 3.0][t % 5]
+        sigma = np.sqrt(np.mean(sig.astype(np.float64) ** 2) / 10 ** (snr_db / 10))
+        lead = int(rng.integers(500, 9000))
+        x = np.concatenate([np.zeros(lead, np.float32), sig, np.zeros(3000, np.float32)])
+        out.append((x + rng.normal(0, sigma, x.size)).astype(np.float32))
+    out.append(rng.normal(0, 0.1, 70000).astype(np.float32))            # noise only
+    return out

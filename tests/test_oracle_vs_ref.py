@@ -3,7 +3,7 @@ box that received the prebuilt .so).  Everything is compared BITWISE, stage by s
 import numpy as np
 import pytest
 
-from _util import beq, long_acquisition_streams, nonfinite_cases
+from _util import beq, chirp_streams, long_acquisition_streams, nonfinite_cases
 from oracle.bindings import INFO_BITS, geometry, make_config
 
 
@@ -199,3 +199,23 @@ def test_acquisition_long_streams_with_trims(oracle, ref, fft, mod, rate, kw):
         assert np.float32(o["noise_floor"]).tobytes() == np.float32(r["noise_floor"]).tobytes(), (o, r)
         found += o["found"]
     assert found >= 1
+
+
+def test_chirp_sync(oracle, ref):
+    """Scope row f4: ChirpSync templates and TX chirps bitwise; detectDualChirp + OFDMChirpWaveform::detectSync
+    on whole transmissions (several SNRs, TX CFOs, a noise-only stream): every reported quantity equal."""
+    for a, b in zip(oracle.chirp_templates()[0], ref.chirp_templates()[0]):
+        assert beq(a, b)
+    assert beq(oracle.chirp_templates()[1], ref.chirp_templates()[1])
+    for cfo in (0.0, 17.5, -40.0):
+        assert beq(oracle.chirp_generate(cfo), ref.chirp_generate(cfo))
+    cfg = make_config(512, "DQPSK", "R1_2", entry=1)
+    hits = 0
+    for x in chirp_streams(oracle, cfg, np.random.default_rng(8)):
+        o, r = oracle.chirp_detect(x), ref.chirp_detect(x)
+        for k in ("success", "up_chirp_start", "down_chirp_start", "start_sample"):
+            assert o[k] == r[k], (k, o, r)
+        for k in ("cfo_hz", "up_correlation", "down_correlation"):
+            assert np.float32(o[k]).tobytes() == np.float32(r[k]).tobytes(), (k, o, r)
+        hits += o["success"]
+    assert hits >= 3
