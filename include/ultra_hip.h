@@ -265,6 +265,23 @@ int ultra_hip_acquire_batch(ultra_hip_ctx* ctx, const float* d_audio, size_t str
                             uint32_t chunk, size_t n_streams, uint32_t* d_found, uint32_t* d_data_start,
                             float* d_cfo_hz, uint32_t* d_sync_offset, uint32_t* d_fed_at_sync);
 
+/* Chirp synchronisation: OFDMChirpWaveform::detectSync
+ * (src/waveform/ofdm_chirp_waveform.cpp:129-172) = sync::ChirpSync::detectDualChirp
+ * (src/sync/chirp_sync.hpp:349-505; 300 -> 2700 Hz up chirp, 100 ms gap, down chirp, 500 ms each) for a
+ * batch of independent buffers.
+ *   d_detected[s]     SyncResult::detected
+ *   d_start_sample[s] SyncResult::start_sample: where the two training symbols start (-1 if not detected) —
+ *                     with d_cfo_hz the PRESYNCED entry of ultra_hip_demod_batch; the initial CFO phase is
+ *                     -2 pi cfo start_sample / fs wrapped to [-pi, pi] (OFDMChirpWaveform::process, :174-190)
+ *   d_cfo_hz[s]       SyncResult::cfo_hz (from the distance of the up and down chirp peaks)
+ *   d_correlation[s]  SyncResult::correlation = max(up, down)
+ *   d_up_chirp_start / d_down_chirp_start (nullable) the CFO-corrected chirp positions
+ * threshold: IWaveform::detectSync's argument (detectDualChirp's default is 0.15). */
+int ultra_hip_chirp_sync_batch(ultra_hip_ctx* ctx, const float* d_audio, size_t stream_stride, uint32_t n_samples,
+                               size_t n_streams, float threshold, uint32_t* d_detected, int32_t* d_start_sample,
+                               float* d_cfo_hz, float* d_correlation, int32_t* d_up_chirp_start,
+                               int32_t* d_down_chirp_start);
+
 /* End to end from raw audio: ultra_hip_acquire_batch, then the SYNCED demodulation of each stream from
  * its own data start with its own coarse CFO, then the LDPC decode of the first 648 soft bits — what
  * one OFDMDemodulator::process loop + getSoftBits + LDPCDecoder::decodeSoft does per trial in the
@@ -279,6 +296,19 @@ int ultra_hip_receive_batch(ultra_hip_ctx* ctx, const float* d_audio, size_t str
                             uint32_t chunk, size_t n_streams, float* d_llr, uint8_t* d_bytes, int32_t* d_iters,
                             uint8_t* d_ok, uint32_t* d_entry, float* d_cfo_hz);
 
+/* End to end for the chirp-synchronised waveform: ultra_hip_chirp_sync_batch, then what the caller of
+ * IWaveform does with its result (tools/test_nvis_mode.cpp; OFDMChirpWaveform::process,
+ * src/waveform/ofdm_chirp_waveform.cpp:174-215): setFrequencyOffset(cfo), process(samples from start_sample) =
+ * setFrequencyOffsetWithPhase(cfo, -2 pi cfo start / fs wrapped) + processPresynced(.., 2), then the LDPC decode
+ * of the first 648 soft bits.  The context must use ULTRA_ENTRY_PRESYNCED (2 training symbols).
+ *   d_entry[s]  (nullable) training start sample, 0xffffffff when no chirp pair was detected or the frame does
+ *               not fit in the buffer: such streams report ok = 0, iterations = 0, zero bytes
+ *   d_cfo_hz[s] (nullable) the CFO handed to the demodulator (0 for unusable streams)
+ *   d_llr       (nullable) [n_streams][llrs_per_frame] soft bits */
+int ultra_hip_chirp_receive_batch(ultra_hip_ctx* ctx, const float* d_audio, size_t stream_stride, uint32_t n_samples,
+                                  size_t n_streams, float threshold, float* d_llr, uint8_t* d_bytes, int32_t* d_iters,
+                                  uint8_t* d_ok, uint32_t* d_entry, float* d_cfo_hz);
+
 /* Transmit-side stimulus on the device: what one Monte-Carlo trial of the harnesses
  * builds before the receiver runs (tools/test_nvis_mode.cpp:35-93), for frames first_frame ..
  * first_frame + n_frames - 1: payload of floor(k/8) random bytes per codeword -> LDPCEncoder::encode
@@ -289,7 +319,7 @@ int ultra_hip_receive_batch(ultra_hip_ctx* ctx, const float* d_audio, size_t str
  *                fading restarted per frame: src/sim/hf_channel.hpp:106-168,258-275)
  *   d_audio      [n_frames][frame_stride >= frame_samples] f32
  *   d_payload    [n_frames][floor(k/8)] bytes of the first codeword (what ultra_hip_count_errors compares)
- * Payload, codewords, transmitted samples and scaling are bit-identical to oracle/ultra_oracle.c's
+ * Payload, codewords, transmitted samples and scaling are bit-identical to the test oracle's
  * uo_make_batch for the same (seed, frame index); the channels use a per-sample counter-based
  * generator and are statistically, not bitwise, equivalent to the serial CPU draws. */
 int ultra_hip_make_batch(ultra_hip_ctx* ctx, uint64_t seed, uint64_t first_frame, size_t n_frames, int channel_kind,
@@ -319,7 +349,8 @@ enum ultra_hip_kernel_class {
     ULTRA_HIP_K_LDPC = 3,       /* ldpc_decode_kernel */
     ULTRA_HIP_K_COUNT = 4,      /* count_errors_kernel */
     ULTRA_HIP_K_ACQUIRE = 5,    /* acquire_kernel */
-    ULTRA_HIP_K_N = 6
+    ULTRA_HIP_K_CHIRP = 6,      /* chirp_sync_kernel */
+    ULTRA_HIP_K_N = 7
 };
 int ultra_hip_profile_enable(ultra_hip_ctx* ctx, int enable);
 int ultra_hip_profile_read(ultra_hip_ctx* ctx, float* ms, uint32_t* launches);

@@ -15,6 +15,7 @@
 // libultra_hip.so; no HIP headers are needed by the caller.
 #pragma once
 
+#include <algorithm>
 #include <cmath>
 #include <complex>
 #include <cstdint>
@@ -201,8 +202,32 @@ public:
     CodeRate getCodeRate() const { return config_.code_rate; }
     float getFrequencyOffset() const { return cfo_hz_; }
 
-    // Acquisition is the next scope row: an external synchroniser hands in what detectSync would fill.
-    bool detectSync(SampleSpan, SyncResult& result, float = 0.3f) { result = last_sync_; return last_sync_.detected; }
+    // OFDMChirpWaveform::detectSync (src/waveform/ofdm_chirp_waveform.cpp:129-172): dual-chirp detection on the
+    // device (scope row f4, ultra_hip_chirp_sync_batch); start_sample = where the two training symbols start.
+    bool detectSync(SampleSpan samples, SyncResult& result, float threshold = 0.3f) {
+        if (!sync_ctx_.p) sync_ctx_ = detail::Ctx(to_c_config(config_, ULTRA_ENTRY_PRESYNCED, 1, 2), device_);
+        detail::DevBuf d_a(sync_ctx_.p, std::max<size_t>(samples.size(), 1) * sizeof(float)), d_o(sync_ctx_.p, 4 * sizeof(uint32_t));
+        detail::check(ultra_hip_memcpy_h2d(sync_ctx_.p, d_a.d, samples.data(), samples.size() * sizeof(float)), "h2d");
+        uint32_t* o = static_cast<uint32_t*>(d_o.d);
+        detail::check(ultra_hip_chirp_sync_batch(sync_ctx_.p, static_cast<const float*>(d_a.d), samples.size(),
+                                                 static_cast<uint32_t>(samples.size()), 1, threshold, o,
+                                                 reinterpret_cast<int32_t*>(o + 1), reinterpret_cast<float*>(o + 2),
+                                                 reinterpret_cast<float*>(o + 3), nullptr, nullptr), "chirp_sync_batch");
+        uint32_t h[4];
+        detail::check(ultra_hip_memcpy_d2h(sync_ctx_.p, h, d_o.d, sizeof(h)), "d2h");
+        result.detected = h[0] != 0;
+        std::memcpy(&result.cfo_hz, &h[2], sizeof(float));
+        std::memcpy(&result.correlation, &h[3], sizeof(float));
+        result.has_training = true;
+        if (result.detected) {
+            int32_t start; std::memcpy(&start, &h[1], sizeof(start));
+            result.start_sample = start;
+            synced_ = true; last_cfo_ = result.cfo_hz; training_start_ = start > 0 ? start : 0;
+        }
+        last_sync_ = result;
+        return result.detected;
+    }
+    // ... or an external synchroniser hands in what detectSync would have filled
     void acceptSync(const SyncResult& r) {
         last_sync_ = r; synced_ = r.detected; cfo_hz_ = r.cfo_hz; training_start_ = r.start_sample > 0 ? r.start_sample : 0;
     }
@@ -240,7 +265,9 @@ public:
     bool isSynced() const { return synced_; }
     bool hasData() const { return !soft_bits_.empty(); }
     float estimatedSNR() const { return 10.0f * std::log10(state_[ULTRA_HIP_STATE_SNR_LINEAR]); }
-    float estimatedCFO() const { return state_[ULTRA_HIP_STATE_FREQ_OFFSET_HZ]; }
+    float estimatedCFO() const {                                        // ofdm_chirp_waveform.cpp:244-252
+        return std::fabs(last_cfo_) > 0.1f ? last_cfo_ : state_[ULTRA_HIP_STATE_FREQ_OFFSET_HZ];
+    }
     std::vector<std::complex<float>> getConstellationSymbols() const { return {}; }   // GUI ring: not produced
 
     std::string getStatusString() const { return "OFDM-HIP " + std::to_string(config_.num_carriers) + " carriers"; }
@@ -284,7 +311,8 @@ private:
     }
     ModemConfig config_;
     int device_;
-    detail::Ctx ctx_;
+    detail::Ctx ctx_, sync_ctx_;
+    float last_cfo_ = 0.0f;
     uint32_t n_data_ = 0;
     float cfo_hz_ = 0.0f;
     int training_start_ = 0;

@@ -439,5 +439,42 @@ inline void build_lts_templates(const ultra_hip_config& c, const DemodConst& D, 
     energy_ref *= 0.5f;
 }
 
+// sync::ChirpSync::generateTemplate (src/sync/chirp_sync.hpp:687-732) with OFDMChirpWaveform's configuration
+// (src/waveform/ofdm_chirp_waveform.cpp:39-49): sin/cos of the up (300 -> 2700 Hz) and down chirp phases,
+// 500 ms long, and the serial float sums of sin^2 the reference keeps as template energies.
+struct ChirpHostTables {
+    std::vector<float> up_sin, up_cos, dn_sin, dn_cos;
+    float e_up = 0.0f, e_dn = 0.0f;
+    int len = 0, gap = 0, start_extra = 0;
+    float cfo_to_samples = 0.0f;
+};
+inline void build_chirp_templates(uint32_t sample_rate_u, ChirpHostTables& C) {
+    const float fs = static_cast<float>(sample_rate_u), f_start = 300.0f, f_end = 2700.0f, duration_ms = 500.0f,
+                gap_ms = 100.0f;
+    const size_t len = static_cast<size_t>(fs * duration_ms / 1000.0f);
+    const float T = duration_ms / 1000.0f;
+    const float k = (f_end - f_start) / T;
+    C.up_sin.resize(len); C.up_cos.resize(len); C.dn_sin.resize(len); C.dn_cos.resize(len);
+    C.e_up = 0.0f; C.e_dn = 0.0f;
+    for (size_t i = 0; i < len; ++i) {
+        const float t = static_cast<float>(i) / fs;
+        const float phase = (float)(2.0f * M_PI * (double)(f_start * t + 0.5f * k * t * t));     // 2.0f * M_PI is a double
+        C.up_sin[i] = sinf(phase); C.up_cos[i] = cosf(phase);
+        C.e_up += C.up_sin[i] * C.up_sin[i];
+    }
+    for (size_t i = 0; i < len; ++i) {
+        const float t = static_cast<float>(i) / fs;
+        const float phase = (float)(2.0f * M_PI * (double)(f_end * t - 0.5f * k * t * t));
+        C.dn_sin[i] = sinf(phase); C.dn_cos[i] = cosf(phase);
+        C.e_dn += C.dn_sin[i] * C.dn_sin[i];
+    }
+    C.len = (int)len;
+    C.gap = (int)static_cast<size_t>(fs * gap_ms / 1000.0f);
+    // OFDMChirpWaveform::detectSync: chirp_samples + size_t(config_.sample_rate * 100.0f / 1000.0f)
+    C.start_extra = (int)(len + static_cast<size_t>(sample_rate_u * 100.0f / 1000.0f));
+    const float chirp_rate = (f_end - f_start) / T;
+    C.cfo_to_samples = fs / chirp_rate;
+}
+
 }  // namespace ultra_hip
 #endif

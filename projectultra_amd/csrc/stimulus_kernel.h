@@ -6,7 +6,7 @@
 // (src/ofdm/modulator.cpp:202-283,348-532) -> scale the whole signal to a 0.5 peak -> channel ->
 // hand the receiver the samples from the first data symbol on.  One wavefront per frame.
 //
-// Bit-exact parts (checked against oracle/ultra_oracle.c's uo_make_batch, which is pinned to the
+// Bit-exact parts (checked against the test oracle's uo_make_batch, which is pinned to the
 // compiled reference's modulator and encoder): the payload bytes (counter-based splitmix64, the
 // oracle's generator), the encoded codewords, every transmitted sample and the peak scaling — so
 // with channel "none" the audio equals the oracle's bit for bit.

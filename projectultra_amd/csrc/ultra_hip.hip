@@ -19,6 +19,7 @@
 #include "ldpc_kernel.h"
 #include "acquire_kernel.h"
 #include "stimulus_kernel.h"
+#include "chirp_kernel.h"
 
 using namespace ultra_hip;
 
@@ -43,6 +44,10 @@ struct ultra_hip_ctx {
     float* d_ws_fstats = nullptr;
     size_t ws_fstats_frames = 0;
     int stim_ncw_raw = 0, stim_ncw_enc = 0, stim_tx_symbols = 0, stim_pre_len = 0;
+    unsigned* d_ws_chirp = nullptr;      // chirp receive: detected, start, cfo, corr, entry, offset, cfo used, phase
+    size_t ws_chirp_streams = 0;
+    float* d_chirp = nullptr;            // chirp templates: up sin, up cos, down sin, down cos
+    ChirpHostTables h_chirp{};
     unsigned* d_ws_acq = nullptr;        // receive_batch workspace: found, data_start, entry, offset [n] + cfo [n]
     size_t ws_acq_frames = 0;
     uint32_t lts_len = 0;
@@ -319,6 +324,8 @@ void ultra_hip_destroy(ultra_hip_ctx* ctx) {
     if (ctx->d_twiddle) (void)hipFree(ctx->d_twiddle);
     if (ctx->d_lts) (void)hipFree(ctx->d_lts);
     if (ctx->d_ws_acq) (void)hipFree(ctx->d_ws_acq);
+    if (ctx->d_chirp) (void)hipFree(ctx->d_chirp);
+    if (ctx->d_ws_chirp) (void)hipFree(ctx->d_ws_chirp);
     if (ctx->d_nco_tx) (void)hipFree(ctx->d_nco_tx);
     if (ctx->d_preamble) (void)hipFree(ctx->d_preamble);
     if (ctx->d_ws_fstats) (void)hipFree(ctx->d_ws_fstats);
@@ -465,6 +472,54 @@ int ultra_hip_receive_batch(ultra_hip_ctx* ctx, const float* d_audio, size_t str
     return ULTRA_HIP_OK;
 }
 
+int ultra_hip_chirp_receive_batch(ultra_hip_ctx* ctx, const float* d_audio, size_t stream_stride, uint32_t n_samples,
+                                  size_t n_streams, float threshold, float* d_llr, uint8_t* d_bytes, int32_t* d_iters,
+                                  uint8_t* d_ok, uint32_t* d_entry, float* d_cfo_hz) {
+    if (!ctx) return ULTRA_HIP_ERR_INVALID_ARG;
+    if (n_streams == 0) return ULTRA_HIP_OK;
+    if (!d_audio || !d_bytes || !d_iters || !d_ok || n_samples < ctx->geo.frame_samples)
+        return ULTRA_HIP_ERR_INVALID_ARG;
+    if (ctx->cfg.entry != ULTRA_ENTRY_PRESYNCED || ctx->geo.llrs_per_frame < (uint32_t)kLdpcN) return ULTRA_HIP_ERR_UNSUPPORTED;
+    DeviceGuard guard(ctx->device);
+    if (ctx->ws_chirp_streams < n_streams) {
+        if (ctx->d_ws_chirp) { UH_HIP(hipStreamSynchronize(ctx->stream)); (void)hipFree(ctx->d_ws_chirp); ctx->d_ws_chirp = nullptr; }
+        ctx->ws_chirp_streams = 0;
+        UH_HIP(hipMalloc(&ctx->d_ws_chirp, n_streams * 8 * sizeof(unsigned)));
+        ctx->ws_chirp_streams = n_streams;
+    }
+    unsigned* detected = ctx->d_ws_chirp;
+    int* start = reinterpret_cast<int*>(detected + n_streams);
+    float* cfo_raw = reinterpret_cast<float*>(detected + 2 * n_streams);
+    float* corr = reinterpret_cast<float*>(detected + 3 * n_streams);
+    unsigned* entry = d_entry ? d_entry : detected + 4 * n_streams;
+    unsigned* offset = detected + 5 * n_streams;
+    float* cfo = d_cfo_hz ? d_cfo_hz : reinterpret_cast<float*>(detected + 6 * n_streams);
+    float* phase = reinterpret_cast<float*>(detected + 7 * n_streams);
+    int rc = ultra_hip_chirp_sync_batch(ctx, d_audio, stream_stride, n_samples, n_streams, threshold, detected, start,
+                                        cfo_raw, corr, nullptr, nullptr);
+    if (rc != ULTRA_HIP_OK) return rc;
+    const unsigned blocks = (unsigned)((n_streams + 255) / 256);
+    hipLaunchKernelGGL(dev::chirp_entry_kernel, dim3(blocks), dim3(256), 0, ctx->stream, detected, start, cfo_raw,
+                       ctx->geo.frame_samples, n_samples, ctx->cfg.sample_rate, (int)n_streams, entry, offset, cfo, phase);
+    float* llr = d_llr;
+    if (!llr) {
+        if (ctx->ws_llr_frames < n_streams) {
+            if (ctx->d_ws_llr) { UH_HIP(hipStreamSynchronize(ctx->stream)); (void)hipFree(ctx->d_ws_llr); ctx->d_ws_llr = nullptr; }
+            UH_HIP(hipMalloc(&ctx->d_ws_llr, n_streams * (size_t)ctx->geo.llrs_per_frame * sizeof(float)));
+            ctx->ws_llr_frames = n_streams;
+        }
+        llr = ctx->d_ws_llr;
+    }
+    rc = launch_demod(ctx, d_audio, stream_stride, cfo, phase, n_streams, llr, ctx->geo.llrs_per_frame, nullptr, offset);
+    if (rc != ULTRA_HIP_OK) return rc;
+    rc = launch_ldpc(ctx, llr, ctx->geo.llrs_per_frame, n_streams, d_bytes, d_iters, d_ok, nullptr);
+    if (rc != ULTRA_HIP_OK) return rc;
+    hipLaunchKernelGGL(dev::clear_unusable_kernel, dim3(blocks), dim3(256), 0, ctx->stream, entry, (int)n_streams,
+                       d_bytes, (int)ctx->geo.decoded_bytes, d_iters, d_ok);
+    UH_HIP(hipGetLastError());
+    return ULTRA_HIP_OK;
+}
+
 int ultra_hip_make_batch(ultra_hip_ctx* ctx, uint64_t seed, uint64_t first_frame, size_t n_frames, int channel_kind,
                          float snr_db, float delay_ms, float doppler_hz, float* d_audio, size_t frame_stride,
                          uint8_t* d_payload) {
@@ -540,6 +595,41 @@ int ultra_hip_make_batch(ultra_hip_ctx* ctx, uint64_t seed, uint64_t first_frame
                        snr_db, delay_samples, fading_alpha, 0.707f, 0.707f, (unsigned long long)seed,
                        (unsigned long long)first_frame, (int)n_frames, ctx->stim_pre_len, total_len, ctx->d_preamble,
                        ctx->d_preamble + 7 * psl, ctx->d_ws_fstats, d_audio, frame_stride);
+    UH_HIP(hipGetLastError());
+    return ULTRA_HIP_OK;
+}
+
+int ultra_hip_chirp_sync_batch(ultra_hip_ctx* ctx, const float* d_audio, size_t stream_stride, uint32_t n_samples,
+                               size_t n_streams, float threshold, uint32_t* d_detected, int32_t* d_start_sample,
+                               float* d_cfo_hz, float* d_correlation, int32_t* d_up_chirp_start,
+                               int32_t* d_down_chirp_start) {
+    if (!ctx) return ULTRA_HIP_ERR_INVALID_ARG;
+    if (n_streams == 0) return ULTRA_HIP_OK;
+    if (!d_audio || !d_detected || !d_start_sample || !d_cfo_hz || !d_correlation || stream_stride < n_samples ||
+        n_streams > 0x7fffffffull || n_samples > 0x3fffffffu)
+        return ULTRA_HIP_ERR_INVALID_ARG;
+    DeviceGuard guard(ctx->device);
+    if (!ctx->d_chirp) {
+        build_chirp_templates(ctx->cfg.sample_rate, ctx->h_chirp);
+        const size_t len = (size_t)ctx->h_chirp.len;
+        std::vector<float> pairs(4 * len);                    // (cos, sin) per tap: up chirp, then down chirp
+        for (size_t i = 0; i < len; ++i) {
+            pairs[2 * i] = ctx->h_chirp.up_cos[i]; pairs[2 * i + 1] = ctx->h_chirp.up_sin[i];
+            pairs[2 * (len + i)] = ctx->h_chirp.dn_cos[i]; pairs[2 * (len + i) + 1] = ctx->h_chirp.dn_sin[i];
+        }
+        UH_HIP(hipMalloc(&ctx->d_chirp, pairs.size() * sizeof(float)));
+        UH_HIP(hipMemcpy(ctx->d_chirp, pairs.data(), pairs.size() * sizeof(float), hipMemcpyHostToDevice));
+    }
+    dev::ChirpTemplates T;
+    const size_t len = (size_t)ctx->h_chirp.len;
+    T.up = reinterpret_cast<const float2*>(ctx->d_chirp); T.dn = T.up + len;
+    T.e_up = ctx->h_chirp.e_up; T.e_dn = ctx->h_chirp.e_dn; T.len = ctx->h_chirp.len; T.gap = ctx->h_chirp.gap;
+    T.start_extra = ctx->h_chirp.start_extra; T.cfo_to_samples = ctx->h_chirp.cfo_to_samples;
+    const unsigned grid = (unsigned)std::min(n_streams, (size_t)ctx->cu_count * 9);
+    LaunchSpan span(ctx, ULTRA_HIP_K_CHIRP);
+    hipLaunchKernelGGL(dev::chirp_sync_kernel, dim3(grid), dim3(dev::kWave), 0, ctx->stream, T, d_audio, stream_stride,
+                       (int)n_samples, (int)n_streams, threshold, d_detected, d_start_sample, d_cfo_hz, d_correlation,
+                       d_up_chirp_start, d_down_chirp_start);
     UH_HIP(hipGetLastError());
     return ULTRA_HIP_OK;
 }

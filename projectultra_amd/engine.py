@@ -90,6 +90,11 @@ class ReceiveContext:
             t = t.to(device=self.device, dtype=dtype).contiguous()
         return t
 
+    @staticmethod
+    def _row_stride(t):
+        # torch reports stride 0 for a leading dimension of size 1
+        return t.stride(0) if t.shape[0] > 1 else t.shape[1]
+
     def tanner_graph(self):
         g = self.geometry
         rp = np.zeros(g.ldpc_m + 1, np.uint32)
@@ -155,7 +160,7 @@ class ReceiveContext:
         cfo, cph = self._opt(cfo_hz, n), self._opt(cfo_phase, n)
         llr = torch.empty((n, self.geometry.llrs_per_frame), dtype=torch.float32, device=self.device)
         state = torch.empty((n, _lib.STATE_FLOATS), dtype=torch.float32, device=self.device) if want_state else None
-        check(self.lib.ultra_hip_demod_batch(self._ctx, audio.data_ptr(), audio.stride(0),
+        check(self.lib.ultra_hip_demod_batch(self._ctx, audio.data_ptr(), self._row_stride(audio),
                                              cfo.data_ptr() if cfo is not None else None,
                                              cph.data_ptr() if cph is not None else None, n, llr.data_ptr(),
                                              state.data_ptr() if want_state else None), "ultra_hip_demod_batch")
@@ -173,7 +178,7 @@ class ReceiveContext:
                        iters=torch.empty(n, dtype=torch.int32, device=self.device),
                        ok=torch.empty(n, dtype=torch.uint8, device=self.device))
         llr = torch.empty((n, g.llrs_per_frame), dtype=torch.float32, device=self.device) if want_llr else None
-        check(self.lib.ultra_hip_demod_decode_batch(self._ctx, audio.data_ptr(), audio.stride(0),
+        check(self.lib.ultra_hip_demod_decode_batch(self._ctx, audio.data_ptr(), self._row_stride(audio),
                                                     cfo.data_ptr() if cfo is not None else None,
                                                     cph.data_ptr() if cph is not None else None, n,
                                                     llr.data_ptr() if want_llr else None, out["bytes"].data_ptr(),
@@ -197,10 +202,30 @@ class ReceiveContext:
                    cfo_hz=torch.zeros(n, dtype=torch.float32, device=self.device),
                    sync_offset=torch.zeros(n, dtype=torch.int32, device=self.device),
                    fed_at_sync=torch.zeros(n, dtype=torch.int32, device=self.device))
-        check(self.lib.ultra_hip_acquire_batch(self._ctx, audio.data_ptr(), audio.stride(0), ns, int(chunk), n,
+        check(self.lib.ultra_hip_acquire_batch(self._ctx, audio.data_ptr(), self._row_stride(audio), ns, int(chunk), n,
                                                out["found"].data_ptr(), out["data_start"].data_ptr(),
                                                out["cfo_hz"].data_ptr(), out["sync_offset"].data_ptr(),
                                                out["fed_at_sync"].data_ptr()), "ultra_hip_acquire_batch")
+        return out
+
+    def chirp_sync(self, audio, threshold: float = 0.15):
+        """OFDMChirpWaveform::detectSync for a batch of buffers [n][n_samples] (dual-chirp detection,
+        src/sync/chirp_sync.hpp:349-505).  Returns device tensors dict(detected, start_sample, cfo_hz,
+        correlation, up_chirp_start, down_chirp_start)."""
+        torch = _torch()
+        audio = self._dev(audio, torch.float32, "audio")
+        if audio.dim() != 2:
+            raise ValueError("audio must be [n_streams][n_samples]")
+        n, ns = audio.shape
+        i32 = lambda: torch.zeros(n, dtype=torch.int32, device=self.device)
+        f32 = lambda: torch.zeros(n, dtype=torch.float32, device=self.device)
+        out = dict(detected=i32(), start_sample=i32(), cfo_hz=f32(), correlation=f32(), up_chirp_start=i32(),
+                   down_chirp_start=i32())
+        check(self.lib.ultra_hip_chirp_sync_batch(self._ctx, audio.data_ptr(), self._row_stride(audio), ns, n, float(threshold),
+                                                  out["detected"].data_ptr(), out["start_sample"].data_ptr(),
+                                                  out["cfo_hz"].data_ptr(), out["correlation"].data_ptr(),
+                                                  out["up_chirp_start"].data_ptr(), out["down_chirp_start"].data_ptr()),
+              "ultra_hip_chirp_sync_batch")
         return out
 
     def receive(self, audio, chunk: int = 960, want_llr: bool = False):
@@ -219,10 +244,35 @@ class ReceiveContext:
                    entry=torch.empty(n, dtype=torch.int32, device=self.device),
                    cfo_hz=torch.empty(n, dtype=torch.float32, device=self.device))
         llr = torch.empty((n, g.llrs_per_frame), dtype=torch.float32, device=self.device) if want_llr else None
-        check(self.lib.ultra_hip_receive_batch(self._ctx, audio.data_ptr(), audio.stride(0), ns, int(chunk), n,
+        check(self.lib.ultra_hip_receive_batch(self._ctx, audio.data_ptr(), self._row_stride(audio), ns, int(chunk), n,
                                                llr.data_ptr() if want_llr else None, out["bytes"].data_ptr(),
                                                out["iters"].data_ptr(), out["ok"].data_ptr(), out["entry"].data_ptr(),
                                                out["cfo_hz"].data_ptr()), "ultra_hip_receive_batch")
+        if want_llr:
+            out["llr"] = llr
+        return out
+
+    def chirp_receive(self, audio, threshold: float = 0.15, want_llr: bool = False):
+        """Chirp-synchronised streams [n][n_samples] -> dual-chirp detection -> PRESYNCED demodulation from each
+        stream's training start with the chirp CFO and its accumulated phase -> LDPC decode
+        (ultra_hip_chirp_receive_batch).  Same result dict as receive()."""
+        torch = _torch()
+        audio = self._dev(audio, torch.float32, "audio")
+        if audio.dim() != 2:
+            raise ValueError("audio must be [n_streams][n_samples]")
+        n, ns = audio.shape
+        g = self.geometry
+        out = dict(bytes=torch.empty((n, g.decoded_bytes), dtype=torch.uint8, device=self.device),
+                   iters=torch.empty(n, dtype=torch.int32, device=self.device),
+                   ok=torch.empty(n, dtype=torch.uint8, device=self.device),
+                   entry=torch.empty(n, dtype=torch.int32, device=self.device),
+                   cfo_hz=torch.empty(n, dtype=torch.float32, device=self.device))
+        llr = torch.empty((n, g.llrs_per_frame), dtype=torch.float32, device=self.device) if want_llr else None
+        check(self.lib.ultra_hip_chirp_receive_batch(self._ctx, audio.data_ptr(), self._row_stride(audio), ns, n,
+                                                     float(threshold), llr.data_ptr() if want_llr else None,
+                                                     out["bytes"].data_ptr(), out["iters"].data_ptr(),
+                                                     out["ok"].data_ptr(), out["entry"].data_ptr(),
+                                                     out["cfo_hz"].data_ptr()), "ultra_hip_chirp_receive_batch")
         if want_llr:
             out["llr"] = llr
         return out
@@ -238,7 +288,7 @@ class ReceiveContext:
         payload = torch.empty((n_frames, g.ldpc_k // 8), dtype=torch.uint8, device=self.device)
         kind = dict(none=0, awgn=1, watterson=2)[channel]
         check(self.lib.ultra_hip_make_batch(self._ctx, int(seed), int(first_frame), n_frames, kind, float(snr_db),
-                                            float(delay_ms), float(doppler_hz), audio.data_ptr(), audio.stride(0),
+                                            float(delay_ms), float(doppler_hz), audio.data_ptr(), self._row_stride(audio),
                                             payload.data_ptr()), "ultra_hip_make_batch")
         return audio, payload
 
@@ -249,7 +299,7 @@ class ReceiveContext:
         check(self.lib.ultra_hip_set_deinterleave(self._ctx, int(bits_per_symbol)), "ultra_hip_set_deinterleave")
 
     KERNEL_CLASSES = ("init_state_kernel", "mix_fft_kernel", "track_kernel", "ldpc_decode_kernel", "count_errors_kernel",
-                      "acquire_kernel")
+                      "acquire_kernel", "chirp_sync_kernel")
 
     def profile_enable(self, on: bool = True):
         """Bracket every kernel launch of this context with HIP events (ultra_hip_profile_enable)."""

@@ -2,8 +2,8 @@
 47-157) on the HIP path, shaped like OFDMChirpWaveform (src/waveform/ofdm_chirp_waveform.cpp):
 an external synchroniser supplies timing + CFO, process() runs the presynced entry.
 
-Transmit-side members (generatePreamble / modulate) and detectSync belong to rows of the
-scope table that are not built (stimulus and acquisition); they raise NotImplementedError
+detectSync runs the dual-chirp detection kernel (scope row f4).  Transmit-side members
+(generatePreamble / modulate) are outside the receive path; they raise NotImplementedError
 rather than pretending."""
 from __future__ import annotations
 
@@ -31,6 +31,7 @@ class HipOfdmWaveform:
         self._config = config or ModemConfig(use_pilots=True)
         self._device = device
         self._cfo_hz = 0.0
+        self._last_cfo = 0.0
         self._training_start_sample = 0
         self._soft_bits = np.zeros(0, np.float32)
         self._synced = False
@@ -61,8 +62,20 @@ class HipOfdmWaveform:
 
     # -- RX ------------------------------------------------------------------
     def detectSync(self, samples, result: SyncResult, threshold: float = 0.3) -> bool:
-        raise NotImplementedError("acquisition (Schmidl-Cox / dual-chirp) is the next scope row; "
-                                  "pass timing and CFO in with accept_sync()")
+        """OFDMChirpWaveform::detectSync (ofdm_chirp_waveform.cpp:129-172) on the device."""
+        from .types import Entry
+        x = np.ascontiguousarray(samples, dtype=np.float32).reshape(1, -1)
+        out = self._demod.context(Entry.PRESYNCED).chirp_sync(x, threshold)
+        result.detected = bool(out["detected"].item())
+        result.correlation = float(out["correlation"].item())
+        result.cfo_hz = float(out["cfo_hz"].item())
+        result.has_training = True
+        if result.detected:
+            self._synced = True
+            self._last_cfo = result.cfo_hz
+            result.start_sample = int(out["start_sample"].item())
+            self._training_start_sample = result.start_sample
+        return result.detected
 
     def accept_sync(self, result: SyncResult) -> None:
         """Take the result of an external synchroniser (what detectSync would have filled in)."""
@@ -109,7 +122,9 @@ class HipOfdmWaveform:
     def estimatedSNR(self) -> float:
         return self._demod.getEstimatedSNR()
 
-    def estimatedCFO(self) -> float:
+    def estimatedCFO(self) -> float:         # ofdm_chirp_waveform.cpp:244-252
+        if abs(self._last_cfo) > 0.1:
+            return self._last_cfo
         return self._demod.getFrequencyOffset()
 
     # -- geometry (ofdm_cox_waveform.cpp:214-258) ------------------------------

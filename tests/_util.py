@@ -89,15 +89,18 @@ def long_acquisition_streams(oracle, cfg, rng):
 
 
 def chirp_streams(oracle, cfg, rng, n=5):
-    """[noise lead][up chirp, gap, down chirp, gap (ChirpSync::generate, optional TX CFO)][2 training symbols +
-    data (generateTrainingSymbols + modulate)][tail], AWGN — what OFDMChirpWaveform transmits
+    """[noise lead][up chirp, gap, down chirp, gap (ChirpSync::generate)][2 training symbols + data
+    (generateTrainingSymbols + modulate)][tail], frequency offsets of 0 / 12.5 / -30 / 55 Hz, AWGN — what OFDMChirpWaveform transmits
     (ofdm_chirp_waveform.cpp:104-127).  cfg must use the PRESYNCED entry."""
     out = []
     for t in range(n):
         payload = bytes(rng.integers(0, 256, 2 * (INFO_BITS[cfg.code_rate] // 8), dtype=np.uint8))
         body = oracle.modulate_presynced(cfg, oracle.ldpc_encode(int(cfg.code_rate), payload))
-        chirp = oracle.chirp_generate(tx_cfo_hz=[0.0, 12.5, -30.0, 55.0, 0.0][t % 5])
-        sig = np.concatenate([chirp, body * np.float32(0.5 / np.abs(body).max())])
+        sig = np.concatenate([oracle.chirp_generate(), body * np.float32(0.5 / np.abs(body).max())])
+        cfo = [0.0, 12.5, -30.0, 55.0, 0.0][t % 5]
+        if cfo:                                   # radio frequency error: the whole transmission shifts (harness: Hilbert + rotate)
+            from scipy.signal import hilbert
+            sig = np.real(hilbert(sig.astype(np.float64)) * np.exp(2j * np.pi * cfo * np.arange(sig.size) / 48000.0)).astype(np.float32)
         snr_db = [30.0, 15.0, 8.0, 20.0, 3.0][t % 5]
         sigma = np.sqrt(np.mean(sig.astype(np.float64) ** 2) / 10 ** (snr_db / 10))
         lead = int(rng.integers(500, 9000))
@@ -105,3 +108,15 @@ def chirp_streams(oracle, cfg, rng, n=5):
         out.append((x + rng.normal(0, sigma, x.size)).astype(np.float32))
     out.append(rng.normal(0, 0.1, 70000).astype(np.float32))            # noise only
     return out
+
+
+def chirp_initial_phase(cfo_hz, start_sample, sample_rate=48000):
+    """OFDMChirpWaveform::process (ofdm_chirp_waveform.cpp:185-189): -2 pi cfo start / fs in double, rounded to
+    float, wrapped to [-pi, pi] one float-rounded double step at a time."""
+    import math
+    ph = np.float32((((-2.0 * math.pi) * float(np.float32(cfo_hz))) * float(start_sample)) / float(sample_rate))
+    while float(ph) > math.pi:
+        ph = np.float32(float(ph) - 2.0 * math.pi)
+    while float(ph) < -math.pi:
+        ph = np.float32(float(ph) + 2.0 * math.pi)
+    return ph

@@ -78,3 +78,69 @@ def test_cpp_adapter_receives_reference_frames(tmp_path, oracle, name):
         ob, oi, ook = oracle.ldpc_decode_batch(int(cfg.code_rate), want[:648].reshape(1, 648))
         assert np.array_equal(raw[:nbytes], ob[0]) and ok == ook[0] and iters == oi[0]
         assert sync_off == meta[1]
+
+
+SRC_CHIRP = r'''
+#include "ultra_hip_waveform.hpp"
+#include <cstdio>
+#include <vector>
+using namespace ultra_hip;
+int main(int argc, char** argv) {
+    // argv: in.f32 n_samples out.f32 fft carriers cp_mode guard pilot_spacing use_pilots mod rate
+    FILE* f = std::fopen(argv[1], "rb");
+    const size_t n = std::stoul(argv[2]);
+    std::vector<float> audio(n);
+    if (std::fread(audio.data(), 4, n, f) != n) return 2;
+    std::fclose(f);
+    ModemConfig c;
+    c.fft_size = std::stoul(argv[4]); c.num_carriers = std::stoul(argv[5]);
+    c.cp_mode = static_cast<decltype(c.cp_mode)>(std::stoi(argv[6])); c.symbol_guard = std::stoul(argv[7]);
+    c.pilot_spacing = std::stoul(argv[8]); c.use_pilots = std::stoi(argv[9]) != 0;
+    c.modulation = static_cast<Modulation>(std::stoi(argv[10])); c.code_rate = static_cast<CodeRate>(std::stoi(argv[11]));
+    HipOfdmWaveform w(c);
+    SyncResult r;
+    std::vector<float> soft;
+    if (w.detectSync(SampleSpan(audio.data(), n), r, 0.15f)) {            // the harness flow: tools/test_nvis_mode.cpp
+        w.setFrequencyOffset(r.cfo_hz);
+        if (!w.process(SampleSpan(audio.data() + r.start_sample, n - r.start_sample))) return 3;
+        soft = w.getSoftBits();
+    }
+    FILE* g = std::fopen(argv[3], "wb");
+    const float head[4] = {r.detected ? 1.0f : 0.0f, (float)r.start_sample, r.cfo_hz, r.correlation};
+    std::fwrite(head, 4, 4, g); std::fwrite(soft.data(), 4, soft.size(), g); std::fclose(g);
+    return 0;
+}
+'''
+
+
+def test_cpp_adapter_chirp_waveform(tmp_path, oracle):
+    """HipOfdmWaveform::detectSync (GPU dual-chirp detection) -> setFrequencyOffset -> process -> getSoftBits from a
+    C++ program, against the oracle's detection and PRESYNCED demodulation of the same samples."""
+    from _util import chirp_initial_phase, chirp_streams, make_config
+    cfg = make_config(512, "DQPSK", "R1_2", entry=1)
+    src = tmp_path / "rxc.cpp"
+    src.write_text(SRC_CHIRP)
+    exe = tmp_path / "rxc"
+    lib = ROOT / "projectultra_amd"
+    subprocess.check_call(["g++", "-O1", "-std=c++20", f"-I{ROOT / 'include'}", str(src), f"-L{lib}", "-lultra_hip",
+                           f"-Wl,-rpath,{lib}", "-o", str(exe)])
+    streams = chirp_streams(oracle, cfg, np.random.default_rng(33), n=2)
+    for t, x in enumerate(streams):
+        fin, fo = tmp_path / f"c{t}.f32", tmp_path / f"o{t}.f32"
+        x.tofile(fin)
+        args = [str(exe), str(fin), str(x.size), str(fo)] + [str(int(v)) for v in (
+            cfg.fft_size, cfg.num_carriers, cfg.cp_mode, cfg.symbol_guard, cfg.pilot_spacing, cfg.use_pilots,
+            cfg.modulation, cfg.code_rate)]
+        r = subprocess.run(args, capture_output=True, text=True, timeout=300)
+        assert r.returncode == 0, (r.returncode, r.stderr[-400:])
+        got = np.fromfile(fo, np.float32)
+        o = oracle.chirp_detect(x)
+        assert got[0] == o["success"] and np.float32(got[2]).tobytes() == np.float32(o["cfo_hz"]).tobytes()
+        assert np.float32(got[3]).tobytes() == np.float32(max(o["up_correlation"], o["down_correlation"])).tobytes()
+        if o["success"]:
+            assert int(got[1]) == o["start_sample"]
+            want, _, _ = oracle.demod_presynced(cfg, x[o["start_sample"]:], o["cfo_hz"],
+                                                chirp_initial_phase(o["cfo_hz"], o["start_sample"], cfg.sample_rate))
+            assert beq(got[4:], want)
+        else:
+            assert got.size == 4

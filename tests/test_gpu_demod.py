@@ -316,3 +316,95 @@ def test_acquisition_long_streams_with_trims(oracle, fft, mod, rate):
             assert r["fed_at_sync"][i] == o["fed_at_sync"]
             assert np.float32(r["cfo_hz"][i]).tobytes() == np.float32(o["coarse_cfo"]).tobytes()
     assert hits >= 1
+
+
+def test_chirp_sync_matches_oracle(oracle):
+    """Scope row f4: OFDMChirpWaveform::detectSync (dual-chirp detection, ofdm_chirp_waveform.cpp:129-172,
+    chirp_sync.hpp:349-505) for a batch of buffers — detected flag, training start, chirp positions exact;
+    CFO and correlation bitwise."""
+    import torch
+    from _util import chirp_streams
+    cfg = make_config(512, "DQPSK", "R1_2", entry=1)
+    streams = chirp_streams(oracle, cfg, np.random.default_rng(8))
+    streams.append(np.zeros(60000, np.float32))                      # silence: zero denominators
+    streams.append(streams[0][:40000])                               # shorter than two chirps and a gap
+    hits = 0
+    eng = context_for(cfg)
+    for thr in (0.15, 0.6):
+        for x in streams:
+            o = oracle.chirp_detect(x, threshold=thr)
+            g = {k: v.cpu().numpy()[0] for k, v in eng.chirp_sync(torch.from_numpy(x[None, :]).cuda(), threshold=thr).items()}
+            assert int(g["detected"]) == o["success"], (o, g)
+            assert int(g["start_sample"]) == o["start_sample"], (o, g)
+            assert int(g["up_chirp_start"]) == o["up_chirp_start"] and int(g["down_chirp_start"]) == o["down_chirp_start"], (o, g)
+            assert np.float32(g["cfo_hz"]).tobytes() == np.float32(o["cfo_hz"]).tobytes(), (o, g)
+            want = max(np.float32(o["up_correlation"]), np.float32(o["down_correlation"]))
+            assert np.float32(g["correlation"]).tobytes() == np.float32(want).tobytes(), (o, g)
+            hits += o["success"]
+    assert hits >= 4
+    # batched: equal-length buffers in one launch give the same per-stream answers
+    n = min(len(x) for x in streams[:5])
+    batch = np.stack([x[:n] for x in streams[:5]] * 40)
+    g = {k: v.cpu().numpy() for k, v in eng.chirp_sync(torch.from_numpy(batch).cuda()).items()}
+    for i in range(5):
+        o = oracle.chirp_detect(batch[i])
+        for r in range(i, len(batch), 5):
+            assert int(g["detected"][r]) == o["success"] and int(g["start_sample"][r]) == o["start_sample"]
+            assert np.float32(g["cfo_hz"][r]).tobytes() == np.float32(o["cfo_hz"]).tobytes()
+
+
+def test_chirp_receive_from_raw_audio(oracle):
+    """Row f4 end to end: dual-chirp detection -> PRESYNCED demodulation from the training start with the chirp
+    CFO and its accumulated phase -> LDPC decode, against the oracle run stage by stage on each stream."""
+    import torch
+    from _util import chirp_initial_phase, chirp_streams
+    cfg = make_config(512, "DQPSK", "R1_2", entry=1)
+    g = geometry(cfg)
+    rng = np.random.default_rng(8)
+    streams = chirp_streams(oracle, cfg, rng, n=8)
+    n = max(len(x) for x in streams)
+    audio = np.stack([np.concatenate([x, rng.normal(0, 1e-3, n - len(x)).astype(np.float32)]) for x in streams])
+    audio[6, -4000:] = 0.0
+    audio[6] = np.roll(audio[6], 6000)                    # frame runs past the end of the buffer: detected but unusable
+    ctx = context_for(cfg)
+    r = {k: v.cpu().numpy() for k, v in ctx.chirp_receive(audio, want_llr=True).items()}
+    usable = 0
+    for i, x in enumerate(audio):
+        o = oracle.chirp_detect(x)
+        ok = o["success"] and o["start_sample"] + g.frame_samples <= n
+        if not ok:
+            assert r["entry"][i] == -1 and r["ok"][i] == 0 and r["iters"][i] == 0 and not r["bytes"][i].any(), (i, o)
+            continue
+        usable += 1
+        s = o["start_sample"]
+        assert r["entry"][i] == s and np.float32(r["cfo_hz"][i]).tobytes() == np.float32(o["cfo_hz"]).tobytes()
+        ph = chirp_initial_phase(o["cfo_hz"], s, cfg.sample_rate)
+        want = oracle.demod_decode_batch(cfg, x[s:s + g.frame_samples][None, :], cfo_hz=[o["cfo_hz"]], cfo_phase=[ph])
+        _check_llr(r["llr"][i], want["llr"][0], f"chirp receive stream {i}")
+        assert np.array_equal(r["bytes"][i], want["bytes"][0]) and r["iters"][i] == want["iters"][0] and r["ok"][i] == want["ok"][0]
+    assert usable >= 6 and r["ok"].sum() >= 5                # every SNR but the 3 dB stream decodes, CFO or not
+
+
+def test_waveform_mirror_detect_sync_and_process(oracle):
+    """HipOfdmWaveform used the way the harness uses IWaveform (tools/test_nvis_mode.cpp): detectSync ->
+    setFrequencyOffset(result.cfo_hz) -> process(samples from start_sample) -> getSoftBits; against
+    oracle.chirp_detect + oracle.demod_presynced on the same samples."""
+    from _util import chirp_initial_phase, chirp_streams, modem_config_from_c
+    from projectultra_amd.waveform import HipOfdmWaveform, SyncResult
+    cfg = make_config(512, "DQPSK", "R1_2", entry=1)
+    mc, _ = modem_config_from_c(cfg)
+    w = HipOfdmWaveform(mc)
+    for x in chirp_streams(oracle, cfg, np.random.default_rng(21), n=3):
+        o = oracle.chirp_detect(x, threshold=0.3)
+        res = SyncResult()
+        assert w.detectSync(x, res) == bool(o["success"])                  # IWaveform's default threshold 0.3
+        assert np.float32(res.cfo_hz).tobytes() == np.float32(o["cfo_hz"]).tobytes() and res.has_training
+        if not o["success"]:
+            continue
+        assert res.start_sample == o["start_sample"]
+        w.setFrequencyOffset(res.cfo_hz)
+        assert w.process(x[res.start_sample:])
+        want, _, _ = oracle.demod_presynced(cfg, x[res.start_sample:], o["cfo_hz"],
+                                            chirp_initial_phase(o["cfo_hz"], o["start_sample"], cfg.sample_rate))
+        _check_llr(w.getSoftBits(), want, "waveform mirror")
+        w.reset()
