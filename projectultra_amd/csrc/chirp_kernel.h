@@ -11,7 +11,8 @@
 // taps serially; each lane evaluates one candidate position and keeps exactly that order.  The 64
 // coarse candidates of a round are 48 samples apart: their samples sit in an LDS ring that is
 // refilled as the taps advance (each sample is read from memory once per round), padded by one word
-// per 48 so the lanes of a tap hit different banks; the template pair of a tap is one broadcast read.
+// per 48 so the lanes of a tap hit different banks; the template pair of a tap is wave-uniform and
+// arrives in scalar registers.
 #ifndef ULTRA_CHIRP_KERNEL_H
 #define ULTRA_CHIRP_KERNEL_H
 
@@ -31,7 +32,6 @@ constexpr int kChirpSpanCoarse = kChirpStep * 63;      // distance of the first 
 
 struct ChirpShared {
     float ring[kChirpRing + kChirpMirror];
-    float2 tmpl[kChirpStage];                          // (cos, sin) of the stage's taps
 };
 
 struct ChirpTemplates {                                // device pointers, `len` (cos, sin) pairs each
@@ -58,116 +58,102 @@ __device__ __forceinline__ float chirp_normalise(chirp_v2f ciq, float se, float 
     return sqrtf(ciq.x * ciq.x + ciq.y * ciq.y) / denom;
 }
 
-// The template taps of one stage, fetched one stage ahead and handed to LDS for broadcast reads
-struct ChirpTmplStage {
-    float2 a, b;                                       // taps s0 + lane and s0 + 64 + lane
-    __device__ __forceinline__ void fetch(const float2* __restrict__ tmpl, int s0, int len) {
-        const int lane = threadIdx.x;
-        a = (s0 + lane < len) ? tmpl[s0 + lane] : make_float2(0.0f, 0.0f);
-        b = (lane < kChirpStage - kWave && s0 + kWave + lane < len) ? tmpl[s0 + kWave + lane] : make_float2(0.0f, 0.0f);
+// Sixteen taps: template pairs in scalar registers (wave-uniform, read through the constant address space),
+// the lane's samples in vector registers.
+constexpr int kChirpGroup = 16;
+typedef float chirp_f4 __attribute__((ext_vector_type(4)));
+typedef const __attribute__((address_space(4))) chirp_f4 chirp_cquad;
+struct ChirpGroup {
+    chirp_f4 t[kChirpGroup / 2];                       // (cos, sin, cos, sin) of two taps each
+    float s[kChirpGroup];
+    __device__ __forceinline__ void load(const float* ps, const float2* __restrict__ tmpl, int tap0) {
+        chirp_cquad* pt = (chirp_cquad*)(tmpl + tap0);
+#pragma unroll
+        for (int k = 0; k < kChirpGroup / 2; ++k) t[k] = pt[k];
+#pragma unroll
+        for (int r = 0; r < kChirpGroup; ++r) s[r] = ps[r];
     }
-    __device__ __forceinline__ void store(ChirpShared& sh) const {
-        const int lane = threadIdx.x;
-        sh.tmpl[lane] = a;
-        if (lane < kChirpStage - kWave) sh.tmpl[kWave + lane] = b;
+    __device__ __forceinline__ void accumulate(chirp_v2f& ciq, float& se) const {
+#pragma unroll
+        for (int r = 0; r < kChirpGroup; ++r) {
+            const chirp_f4 q = t[r / 2];
+            chirp_tap(s[r], (r & 1) ? make_float2(q.z, q.w) : make_float2(q.x, q.y), ciq, se);
+        }
     }
 };
 
-// `n_taps` (<= kChirpStep) taps of one lane: samples ps[0..], template pairs pt[0..]
-__device__ __forceinline__ void chirp_run(const float* ps, const float2* pt, int n_taps, chirp_v2f& ciq, float& se) {
-    if (n_taps == kChirpStep) {
-#pragma unroll
-        for (int r = 0; r < kChirpStep; ++r) chirp_tap(ps[r], pt[r], ciq, se);
-    } else {
-        for (int r = 0; r < n_taps; ++r) chirp_tap(ps[r], pt[r], ciq, se);
-    }
-}
-
-// Coarse round: correlation at x[first + 48 * lane ..] for every lane < n_pos (first is a multiple of 48).
-// Sample j (relative to first) lives at ring word (j + j / 48) & 4095: the lanes of a tap read words 49 apart
-// (conflict-free), a run of 48 taps starting at a multiple of 48 is 48 consecutive words, and the window of
-// 63 * 48 + 2 * kChirpBlock samples (3479 words with padding) never overlaps itself.  Every sample is fetched
-// from memory once per round, one block ahead of its first use.
-__device__ __forceinline__ float chirp_coarse_round(ChirpShared& sh, const float* __restrict__ x, int n, int first, int n_pos,
-                                                    const float2* __restrict__ tmpl, int len, float energy) {
+// Correlation at x[first + STRIDE * lane ..] for every lane < n_pos: STRIDE 48 (coarse round; first is a
+// multiple of 48) or 1 (fine round).
+// Coarse: sample j (relative to first) lives at ring word (j + j / 48) & 4095: the lanes of a tap read words 49
+// apart (conflict-free), a run of 48 taps starting at a multiple of 48 is 48 consecutive words, and the window
+// of 63 * 48 + 2 * kChirpBlock samples (3479 words with padding) never overlaps itself.  Fine: word j & 4095.
+// Every sample is fetched from memory once per round, one block ahead of its first use.  The loop is a software
+// pipeline over groups of 16 taps: wait for group g + 1 (scalar loads share the LDS counter and return out of
+// order, so the wait is for everything), issue the loads of group g + 2, accumulate group g + 1.
+template <int STRIDE>
+__device__ __forceinline__ float chirp_round(ChirpShared& sh, const float* __restrict__ x, int n, int first, int n_pos,
+                                             const float2* __restrict__ tmpl, int len, float energy) {
     const int lane = threadIdx.x;
+    constexpr int kSpan = STRIDE * (kWave - 1);
     auto fetch = [&](int j) { const int g = first + j; return (g < n) ? x[g] : 0.0f; };
+    auto slot = [](int j) { return ((STRIDE == 1) ? j : j + j / kChirpStep) & (kChirpRing - 1); };
     auto put = [&](int j, float v) {
-        const int a = (j + j / kChirpStep) & (kChirpRing - 1);
+        const int a = slot(j);
         sh.ring[a] = v;
         if (a < kChirpMirror) sh.ring[a + kChirpRing] = v;
     };
-    ChirpTmplStage ts;
-    ts.fetch(tmpl, 0, len);
+    // the lane's samples of taps [48 run, 48 run + 48)
+    auto run_base = [&](int run) {
+        return sh.ring + ((STRIDE == 1) ? ((lane + kChirpStep * run) & (kChirpRing - 1))
+                                        : (((kChirpStep + 1) * (lane + run)) & (kChirpRing - 1)));
+    };
+    wave_sync();                                       // the previous round's reads of the ring are done
+    for (int j = lane; j < kSpan + kChirpBlock; j += kWave) put(j, fetch(j));
     wave_sync();
-    for (int j = lane; j < kChirpSpanCoarse + kChirpBlock; j += kWave) put(j, fetch(j));
     chirp_v2f ciq = {0.0f, 0.0f};
     float se = 0.0f;
     constexpr int kNew = kChirpBlock / kWave;          // samples per lane a block adds to the window
-    static_assert(kChirpBlock % kWave == 0, "refill is whole lanes");
-    for (int i0 = 0; i0 < len; i0 += kChirpBlock) {
+    static_assert(kChirpBlock % kWave == 0 && kChirpStep % kChirpGroup == 0 && (kChirpBlock / kChirpGroup) % 2 == 0,
+                  "whole lanes, whole groups, pairs of groups");
+    constexpr int kGroupsPerBlock = kChirpBlock / kChirpGroup;
+    const int full = len - len % kChirpBlock;
+    ChirpGroup ga, gb;                                 // ping-pong: one is accumulated while the other is in flight
+    auto group_ptr = [&](int tap) { return run_base(tap / kChirpStep) + tap % kChirpStep; };
+    if (full > 0) ga.load(group_ptr(0), tmpl, 0);
+    for (int i0 = 0; i0 < full; i0 += kChirpBlock) {
         float nx[kNew];
-        const int jn = i0 + kChirpBlock + kChirpSpanCoarse;
+        const int jn = i0 + kChirpBlock + kSpan;
         const bool more = i0 + kChirpBlock < len;
 #pragma unroll
         for (int k = 0; k < kNew; ++k) nx[k] = more ? fetch(jn + lane + kWave * k) : 0.0f;
+#pragma unroll 1
+        for (int g = 0; g < kGroupsPerBlock; g += 2) {
+            int tap = i0 + g * kChirpGroup;
+            // The empty asm statements pin the order the pipeline needs: [wait] < [issue next loads] and
+            // [accumulate] < [next wait]; the compiler is otherwise free to sink the arithmetic below the wait.
+            __builtin_amdgcn_s_waitcnt(0xc07f);        // lgkmcnt(0): group ga has arrived
+            asm volatile("" : "+s"(tap));
+            gb.load(group_ptr(tap + kChirpGroup), tmpl, tap + kChirpGroup);
+            ga.accumulate(ciq, se);
+            asm volatile("" : "+v"(se), "+v"(ciq));
+            __builtin_amdgcn_s_waitcnt(0xc07f);        // group gb has arrived
+            asm volatile("" : "+s"(tap));
+            if (g == kGroupsPerBlock - 2) {            // the next group belongs to the next block: widen the window first
+                if (more) {
 #pragma unroll
-        for (int st = 0; st < kChirpBlock / kChirpStage; ++st) {
-            const int s0 = i0 + st * kChirpStage;
-            if (s0 >= len) break;
-            wave_sync();                               // the previous stage's template reads are done
-            ts.store(sh);
-            wave_sync();
-            ts.fetch(tmpl, s0 + kChirpStage, len);
-#pragma unroll
-            for (int q = 0; q < kChirpStage / kChirpStep; ++q) {
-                const int t0 = s0 + q * kChirpStep;
-                const int run = (len - t0 < kChirpStep) ? len - t0 : kChirpStep;
-                if (run <= 0) break;
-                const float* ps = sh.ring + (((kChirpStep + 1) * (lane + t0 / kChirpStep)) & (kChirpRing - 1));
-                chirp_run(ps, sh.tmpl + q * kChirpStep, run, ciq, se);
+                    for (int k = 0; k < kNew; ++k) put(jn + lane + kWave * k, nx[k]);
+                }
+                wave_sync();
             }
-        }
-        if (more) {
-#pragma unroll
-            for (int k = 0; k < kNew; ++k) put(jn + lane + kWave * k, nx[k]);
-        }
-    }
-    return (lane < n_pos) ? chirp_normalise(ciq, se, energy) : 0.0f;
-}
-
-// Fine round: correlation at x[first + lane ..] for every lane < n_pos; the ring is used as a plain buffer
-// of the stage's kChirpStage + 63 samples (two halves, filled one stage ahead)
-__device__ __forceinline__ float chirp_fine_round(ChirpShared& sh, const float* __restrict__ x, int n, int first, int n_pos,
-                                                  const float2* __restrict__ tmpl, int len, float energy) {
-    const int lane = threadIdx.x;
-    constexpr int kWin = kChirpStage + kWave;          // 160 words per half (159 used)
-    constexpr int kPer = (kWin + kWave - 1) / kWave;
-    chirp_v2f ciq = {0.0f, 0.0f};
-    float se = 0.0f;
-    ChirpTmplStage ts;
-    float nx[kPer];
-    auto fetch_stage = [&](int s0) {
-        ts.fetch(tmpl, s0, len);
-#pragma unroll
-        for (int k = 0; k < kPer; ++k) { const int g = first + s0 + lane + kWave * k; nx[k] = (lane + kWave * k < kWin && g < n) ? x[g] : 0.0f; }
-    };
-    fetch_stage(0);
-    for (int s0 = 0; s0 < len; s0 += kChirpStage) {
-        wave_sync();
-        ts.store(sh);
-#pragma unroll
-        for (int k = 0; k < kPer; ++k) if (lane + kWave * k < kWin) sh.ring[lane + kWave * k] = nx[k];
-        wave_sync();
-        fetch_stage(s0 + kChirpStage);
-#pragma unroll
-        for (int q = 0; q < kChirpStage / kChirpStep; ++q) {
-            const int t0 = s0 + q * kChirpStep;
-            const int run = (len - t0 < kChirpStep) ? len - t0 : kChirpStep;
-            if (run <= 0) break;
-            chirp_run(sh.ring + lane + q * kChirpStep, sh.tmpl + q * kChirpStep, run, ciq, se);
+            // (the templates are padded by one group behind `len`)
+            ga.load(group_ptr(tap + 2 * kChirpGroup), tmpl, tap + 2 * kChirpGroup);
+            gb.accumulate(ciq, se);
+            asm volatile("" : "+v"(se), "+v"(ciq));
         }
     }
+    // taps behind the last whole block (none at 48 kHz: 24000 = 125 * 192)
+    for (int t = full; t < len; ++t)
+        chirp_tap(run_base(t / kChirpStep)[t % kChirpStep], tmpl[t], ciq, se);
     return (lane < n_pos) ? chirp_normalise(ciq, se, energy) : 0.0f;
 }
 
@@ -197,22 +183,35 @@ __device__ __forceinline__ int chirp_detect_template(ChirpShared& sh, const floa
     const int n_coarse = (search_len + kChirpStep - 1) / kChirpStep;
     for (int c0 = 0; c0 < n_coarse; c0 += kWave) {
         const int cnt = (n_coarse - c0 < kWave) ? n_coarse - c0 : kWave;
-        const float corr = chirp_coarse_round(sh, x, n, c0 * kChirpStep, cnt, tmpl, len, energy);
+        const float corr = chirp_round<kChirpStep>(sh, x, n, c0 * kChirpStep, cnt, tmpl, len, energy);
         chirp_pick(corr, (c0 + lane) * kChirpStep, lane < cnt, best_corr, best_pos);
     }
     if (best_pos < 0 || best_corr < threshold * 0.3f) { *corr_out = best_corr; return -1; }
-    // fine search around the coarse peak
+    // fine search around the coarse peak (at most 97 positions: two rounds, their correlations are kept)
     const int fine_start = (best_pos - kChirpStep > 0) ? best_pos - kChirpStep : 0;
     const int fine_end = (best_pos + kChirpStep < search_len) ? best_pos + kChirpStep : search_len;
-    for (int p0 = fine_start; p0 <= fine_end; p0 += kWave) {
+    float fine[2] = {0.0f, 0.0f};
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+        const int p0 = fine_start + k * kWave;
+        if (p0 > fine_end) break;
         const int cnt = (fine_end - p0 + 1 < kWave) ? fine_end - p0 + 1 : kWave;
-        const float corr = chirp_fine_round(sh, x, n, p0, cnt, tmpl, len, energy);
-        chirp_pick(corr, p0 + lane, lane < cnt, best_corr, best_pos);
+        fine[k] = chirp_round<1>(sh, x, n, p0, cnt, tmpl, len, energy);
+        chirp_pick(fine[k], p0 + lane, lane < cnt, best_corr, best_pos);
     }
-    // parabolic interpolation
+    // parabolic interpolation: the neighbours' correlations were computed by the fine search unless the peak
+    // sits on the edge of its range (the value at a position does not depend on the lane that computes it)
     if (best_pos > 0 && best_pos < search_len - 1) {
-        const float corr = chirp_fine_round(sh, x, n, best_pos - 1, 3, tmpl, len, energy);
-        const float c0 = lane_f(corr, 0), c1 = best_corr, c2 = lane_f(corr, 2);
+        float c0, c2;
+        if (best_pos - 1 >= fine_start && best_pos + 1 <= fine_end) {
+            const int r0 = best_pos - 1 - fine_start, r2 = best_pos + 1 - fine_start;
+            c0 = (r0 < kWave) ? lane_f(fine[0], r0) : lane_f(fine[1], r0 - kWave);
+            c2 = (r2 < kWave) ? lane_f(fine[0], r2) : lane_f(fine[1], r2 - kWave);
+        } else {
+            const float corr = chirp_round<1>(sh, x, n, best_pos - 1, 3, tmpl, len, energy);
+            c0 = lane_f(corr, 0); c2 = lane_f(corr, 2);
+        }
+        const float c1 = best_corr;
         const float denom = 2.0f * (c0 - 2.0f * c1 + c2);
         if (fabsf(denom) > 1e-10f) {
             float delta = (c0 - c2) / denom;

@@ -612,17 +612,18 @@ int ultra_hip_chirp_sync_batch(ultra_hip_ctx* ctx, const float* d_audio, size_t 
     if (!ctx->d_chirp) {
         build_chirp_templates(ctx->cfg.sample_rate, ctx->h_chirp);
         const size_t len = (size_t)ctx->h_chirp.len;
-        std::vector<float> pairs(4 * len);                    // (cos, sin) per tap: up chirp, then down chirp
+        const size_t padded = len + dev::kChirpGroup;         // the kernel prefetches one group of taps ahead
+        std::vector<float> pairs(4 * padded, 0.0f);           // (cos, sin) per tap: up chirp, then down chirp
         for (size_t i = 0; i < len; ++i) {
             pairs[2 * i] = ctx->h_chirp.up_cos[i]; pairs[2 * i + 1] = ctx->h_chirp.up_sin[i];
-            pairs[2 * (len + i)] = ctx->h_chirp.dn_cos[i]; pairs[2 * (len + i) + 1] = ctx->h_chirp.dn_sin[i];
+            pairs[2 * (padded + i)] = ctx->h_chirp.dn_cos[i]; pairs[2 * (padded + i) + 1] = ctx->h_chirp.dn_sin[i];
         }
         UH_HIP(hipMalloc(&ctx->d_chirp, pairs.size() * sizeof(float)));
         UH_HIP(hipMemcpy(ctx->d_chirp, pairs.data(), pairs.size() * sizeof(float), hipMemcpyHostToDevice));
     }
     dev::ChirpTemplates T;
     const size_t len = (size_t)ctx->h_chirp.len;
-    T.up = reinterpret_cast<const float2*>(ctx->d_chirp); T.dn = T.up + len;
+    T.up = reinterpret_cast<const float2*>(ctx->d_chirp); T.dn = T.up + len + dev::kChirpGroup;
     T.e_up = ctx->h_chirp.e_up; T.e_dn = ctx->h_chirp.e_dn; T.len = ctx->h_chirp.len; T.gap = ctx->h_chirp.gap;
     T.start_extra = ctx->h_chirp.start_extra; T.cfo_to_samples = ctx->h_chirp.cfo_to_samples;
     const unsigned grid = (unsigned)std::min(n_streams, (size_t)ctx->cu_count * 9);
