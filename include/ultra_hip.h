@@ -309,6 +309,41 @@ int ultra_hip_chirp_receive_batch(ultra_hip_ctx* ctx, const float* d_audio, size
                                   size_t n_streams, float threshold, float* d_llr, uint8_t* d_bytes, int32_t* d_iters,
                                   uint8_t* d_ok, uint32_t* d_entry, float* d_cfo_hz);
 
+/* v2 wire format (second half): what RxPipeline::processFrame does with the soft bits of
+ * a frame (src/gui/modem/rx_pipeline.cpp:283-346) for a batch of frames — detectPing (:446-472),
+ * deinterleaveCodewords (:474-491; the context's ultra_hip_set_deinterleave setting), decodeFrame (:348-444):
+ * CW0 -> v2::parseHeader (src/protocol/frame_v2.cpp:1175-1229) -> the remaining codewords ->
+ * CodewordStatus::reassemble (:952-982,1023-1044).  The context's code rate is the rate of every codeword
+ * (RxPipeline::setDataMode: R1/4 before the connection, the negotiated rate after it).
+ *   d_soft        [n_frames][frame_stride] soft bits as IWaveform::getSoftBits returns them, n_soft valid per
+ *                 frame (floor(n_soft / 648) codewords are available)
+ *   d_results     [n_frames] RxFrameResult fields + status
+ *   d_frame_data  [n_frames][frame_data_stride] RxFrameResult::frame_data of complete frames;
+ *                 frame_data_stride >= floor(n_soft / 648) * floor(k / 8)
+ * All available codewords are decoded in one batch (the result of a codeword does not depend on the others);
+ * counters only cover the codewords the header announces, as in the reference. */
+typedef struct ultra_hip_frame_result {
+    int32_t success;             /* RxFrameResult::success                                              */
+    int32_t is_ping;             /* RxFrameResult::is_ping                                              */
+    int32_t frame_type;          /* RxFrameResult::frame_type (protocol::v2::FrameType)                 */
+    int32_t codewords_ok;        /* RxFrameResult::codewords_ok                                         */
+    int32_t codewords_failed;    /* RxFrameResult::codewords_failed                                     */
+    int32_t expected_codewords;  /* RxPipeline::getExpectedCodewords(): total_cw while waiting, else 0  */
+    int32_t frame_len;           /* RxFrameResult::frame_data.size()                                    */
+    int32_t status;              /* ULTRA_HIP_FRAME_*                                                   */
+} ultra_hip_frame_result;
+enum ultra_hip_frame_status {
+    ULTRA_HIP_FRAME_CW0_FAILED = 0,        /* no codeword, or CW0 did not decode                        */
+    ULTRA_HIP_FRAME_BAD_HEADER = 1,        /* CW0 decoded, not a valid v2 header                        */
+    ULTRA_HIP_FRAME_WAITING = 2,           /* header announces more codewords than were handed in       */
+    ULTRA_HIP_FRAME_CODEWORDS_FAILED = 3,  /* some codeword of the frame did not decode                 */
+    ULTRA_HIP_FRAME_COMPLETE = 4,          /* all codewords decoded, frame_data reassembled             */
+    ULTRA_HIP_FRAME_PING = 5               /* raw "ULTR" (or its inversion) instead of a codeword       */
+};
+int ultra_hip_decode_frames_batch(ultra_hip_ctx* ctx, const float* d_soft, size_t frame_stride, uint32_t n_soft,
+                                  size_t n_frames, ultra_hip_frame_result* d_results, uint8_t* d_frame_data,
+                                  size_t frame_data_stride);
+
 /* Transmit-side stimulus on the device: what one Monte-Carlo trial of the harnesses
  * builds before the receiver runs (tools/test_nvis_mode.cpp:35-93), for frames first_frame ..
  * first_frame + n_frames - 1: payload of floor(k/8) random bytes per codeword -> LDPCEncoder::encode

@@ -323,6 +323,54 @@ private:
 };
 
 // ---------------------------------------------------------------------------------------------
+// The v2 wire format behind getSoftBits(): mirrors the decode half of ultra::gui::RxPipeline
+// (src/gui/modem/rx_pipeline.hpp:39-48,76-84; rx_pipeline.cpp:283-346,348-444) on ultra_hip_decode_frames_batch.
+struct HipRxFrameResult {                      // gui::RxFrameResult
+    bool success = false; Bytes frame_data; int frame_type = 0x10; int codewords_ok = 0; int codewords_failed = 0;
+    float snr_estimate = 0.0f; float cfo_estimate = 0.0f; bool is_ping = false;
+};
+class HipRxFrameDecoder {
+public:
+    explicit HipRxFrameDecoder(int device = 0) : device_(device) {}
+    void setDataMode(CodeRate rate, bool connected) { rate_ = rate; connected_ = connected; ctx_.reset(); }
+    void setInterleavingEnabled(bool enabled) { interleaving_ = enabled; ctx_.reset(); }
+    void setInterleaverConfig(size_t bits_per_symbol) {            // rx_pipeline.cpp:25-32: only a change builds one
+        if (bits_per_symbol != bits_per_symbol_) { bits_per_symbol_ = bits_per_symbol; configured_ = true; ctx_.reset(); }
+    }
+    int getExpectedCodewords() const { return expected_; }
+    bool isAccumulating() const { return expected_ > 0; }
+    // processFrame from `auto soft_bits = waveform->getSoftBits()` on
+    HipRxFrameResult decodeSoftBits(std::span<const float> soft_bits) {
+        HipRxFrameResult r;
+        if (soft_bits.empty()) return r;
+        if (!ctx_.p) {
+            ModemConfig c; c.code_rate = connected_ ? rate_ : CodeRate::R1_4;      // rx_pipeline.cpp:356-366
+            ctx_ = detail::Ctx(to_c_config(c, ULTRA_ENTRY_SYNCED, 44, 0), device_);
+            detail::check(ultra_hip_set_deinterleave(ctx_.p, (interleaving_ && configured_) ? uint32_t(bits_per_symbol_) : 0u),
+                          "ultra_hip_set_deinterleave");
+        }
+        ultra_hip_geometry g; detail::check(ultra_hip_get_geometry(ctx_.p, &g), "geometry");
+        const size_t n = soft_bits.size(), stride = std::max<size_t>((n / 648) * (g.ldpc_k / 8), 1);
+        detail::DevBuf d_s(ctx_.p, n * sizeof(float)), d_r(ctx_.p, sizeof(ultra_hip_frame_result)), d_d(ctx_.p, stride);
+        detail::check(ultra_hip_memcpy_h2d(ctx_.p, d_s.d, soft_bits.data(), n * sizeof(float)), "h2d");
+        detail::check(ultra_hip_decode_frames_batch(ctx_.p, static_cast<const float*>(d_s.d), n, static_cast<uint32_t>(n), 1,
+                                                    static_cast<ultra_hip_frame_result*>(d_r.d),
+                                                    static_cast<uint8_t*>(d_d.d), stride), "decode_frames_batch");
+        ultra_hip_frame_result h;
+        detail::check(ultra_hip_memcpy_d2h(ctx_.p, &h, d_r.d, sizeof(h)), "d2h");
+        r.success = h.success != 0; r.is_ping = h.is_ping != 0; r.frame_type = h.frame_type;
+        r.codewords_ok = h.codewords_ok; r.codewords_failed = h.codewords_failed; expected_ = h.expected_codewords;
+        r.frame_data.resize(size_t(h.frame_len));
+        if (h.frame_len > 0) detail::check(ultra_hip_memcpy_d2h(ctx_.p, r.frame_data.data(), d_d.d, size_t(h.frame_len)), "d2h");
+        return r;
+    }
+private:
+    int device_; CodeRate rate_ = CodeRate::R1_4; bool connected_ = false, interleaving_ = true, configured_ = false;
+    size_t bits_per_symbol_ = 60; int expected_ = 0;
+    detail::Ctx ctx_;
+};
+
+// ---------------------------------------------------------------------------------------------
 // Schmidl-Cox flavour: mirrors ultra::OFDMNvisWaveform's receive half (src/waveform/ofdm_cox_waveform.cpp:
 // 98-138), whose detectSync/process simply feed OFDMDemodulator::process — the chunk-fed search
 // (scope row f1, ultra_hip_acquire_batch) followed by the SYNCED symbol loop.  Feed it equal-sized

@@ -118,6 +118,40 @@ class _Base:
         assert n > 0
         return out[:n].copy()
 
+    # ------------------------------------------------------- v2 wire format
+    FRAME_STATUS = ("cw0_failed", "bad_header", "waiting", "codewords_failed", "complete", "ping")
+
+    def crc16(self, data: bytes) -> int:
+        fn = self._fn("crc16"); fn.restype = C.c_uint16
+        return int(fn(bytes(data), C.c_uint32(len(data))))
+
+    def v2_parse_header(self, data: bytes):
+        out = (C.c_int32 * 4)()
+        valid = self._fn("v2_parse_header")(bytes(data), C.c_uint32(len(data)), out)
+        return dict(valid=bool(valid), type=out[0], total_cw=out[1], payload_len=out[2], is_control=bool(out[3]))
+
+    def v2_decode_frame(self, rate, soft, deint_bps=0, max_iters=50):
+        """RxPipeline::processFrame from the soft bits on -> dict(success, is_ping, frame_type, codewords_ok,
+        codewords_failed, expected_codewords, status, frame_data)."""
+        soft = _f32(soft)
+        res = (C.c_int32 * 8)()
+        buf = np.zeros(8192, np.uint8)
+        rc = self._fn("v2_decode_frame")(C.c_uint32(int(rate)), C.c_uint32(deint_bps), C.c_int(max_iters), _ptr(soft),
+                                         C.c_uint32(soft.size), res, _ptr(buf, C.c_uint8), C.c_uint32(buf.size))
+        assert rc == 0, rc
+        return dict(success=res[0], is_ping=res[1], frame_type=res[2], codewords_ok=res[3], codewords_failed=res[4],
+                    expected_codewords=res[5], status=res[7], frame_data=bytes(buf[:res[6]]))
+
+    def v2_build_frame(self, rate, payload=b"", type=0x30, flags=0x01, seq=0, src_hash=0x123456, dst_hash=0xABCDEF,
+                       total_cw=-1):
+        """DataFrame/ControlFrame::serialize + encodeFrameWithLDPC -> [n_cw][81] encoded codewords."""
+        out = np.zeros((256, 81), np.uint8)
+        n = self._fn("v2_build_frame")(C.c_uint32(int(rate)), C.c_uint8(type), C.c_uint8(flags), C.c_uint16(seq),
+                                       C.c_uint32(src_hash), C.c_uint32(dst_hash), bytes(payload), C.c_uint32(len(payload)),
+                                       C.c_int(total_cw), _ptr(out, C.c_uint8), C.c_uint32(256))
+        assert n > 0, n
+        return out[:n].copy()
+
     def chirp_templates(self, sample_rate=48000.0):
         cap = 1 << 16
         t = [np.zeros(cap, np.float32) for _ in range(4)]

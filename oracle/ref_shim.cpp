@@ -37,7 +37,9 @@
 #include "sim/hf_channel.hpp"
 #define private public
 #include "sync/chirp_sync.hpp"
+#include "gui/modem/rx_pipeline.hpp"
 #undef private
+#include "protocol/frame_v2.hpp"
 
 #include "../include/ultra_hip.h"
 
@@ -624,6 +626,74 @@ int ref_harness_awgn(const ultra_hip_config* c, const uint8_t* payload, uint32_t
     std::memcpy(audio_out, signal.data(), signal.size() * sizeof(float));
     *n_audio = (uint32_t)signal.size();
     return (int)pre.size();
+}
+
+
+// ---- v2 wire format (scope row f4): RxPipeline::processFrame from the soft bits on ----
+uint16_t ref_crc16(const uint8_t* d, uint32_t n) { return protocol::v2::ControlFrame::calculateCRC(d, n); }
+
+int ref_v2_parse_header(const uint8_t* d, uint32_t n, int32_t* out) {
+    auto h = protocol::v2::parseHeader(Bytes(d, d + n));
+    out[0] = (int)h.type; out[1] = h.total_cw; out[2] = h.payload_len; out[3] = h.is_control ? 1 : 0;
+    return h.valid ? 1 : 0;
+}
+
+// the statements of processFrame (rx_pipeline.cpp:283-346) after waveform->getSoftBits(), on a fresh pipeline
+int ref_v2_decode_frame(uint32_t rate, uint32_t deint_bps, int max_iters, const float* soft, uint32_t n_soft,
+                        int32_t* res, uint8_t* frame_data, uint32_t cap) {
+    StderrMute mute;
+    namespace v2 = protocol::v2;
+    (void)max_iters;                                             // RxPipeline uses LDPCDecoder's default (50)
+    gui::RxPipeline rx("T");
+    rx.setDataMode(static_cast<CodeRate>(rate), true);           // connected: data_code_rate_ for every codeword
+    rx.setInterleavingEnabled(deint_bps != 0);
+    if (deint_bps) { rx.interleaver_bits_per_symbol_ = 0; rx.setInterleaverConfig(deint_bps); }
+    for (int i = 0; i < 8; ++i) res[i] = 0;
+    gui::RxFrameResult result;
+    res[2] = (int)result.frame_type;
+    std::vector<float> soft_bits(soft, soft + n_soft);
+    if (soft_bits.empty()) return 0;
+    if (rx.detectPing(soft_bits)) { res[0] = 1; res[1] = 1; res[2] = (int)v2::FrameType::PING; res[7] = 5; return 0; }
+    if (rx.interleaving_enabled_) soft_bits = rx.deinterleaveCodewords(soft_bits);
+    int num_codewords = static_cast<int>(soft_bits.size() / v2::LDPC_CODEWORD_BITS);
+    if (num_codewords == 0) return 0;
+    result = rx.decodeFrame(soft_bits, num_codewords);
+    res[0] = result.success; res[1] = result.is_ping; res[2] = (int)result.frame_type;
+    res[3] = result.codewords_ok; res[4] = result.codewords_failed; res[5] = rx.getExpectedCodewords();
+    res[6] = (int)result.frame_data.size();
+    res[7] = result.success ? 4 : res[5] > 0 ? 2 : result.codewords_ok == 0 ? 0 : (result.codewords_failed > 0 ? 3 : 1);
+    if (result.frame_data.size() > cap) return -1;
+    std::memcpy(frame_data, result.frame_data.data(), result.frame_data.size());
+    return 0;
+}
+
+int ref_v2_build_frame(uint32_t rate, uint8_t type, uint8_t flags, uint16_t seq, uint32_t src_hash, uint32_t dst_hash,
+                       const uint8_t* payload, uint32_t payload_len, int total_cw_override, uint8_t* codewords,
+                       uint32_t cap_cw) {
+    namespace v2 = protocol::v2;
+    Bytes frame;
+    if (v2::isControlFrame(static_cast<v2::FrameType>(type))) {
+        v2::ControlFrame f;
+        f.type = static_cast<v2::FrameType>(type); f.flags = flags; f.seq = seq; f.src_hash = src_hash; f.dst_hash = dst_hash;
+        std::memset(f.payload, 0, sizeof(f.payload));
+        std::memcpy(f.payload, payload, std::min<size_t>(payload_len, sizeof(f.payload)));
+        frame = f.serialize();
+    } else {
+        v2::DataFrame f;
+        f.type = static_cast<v2::FrameType>(type); f.flags = flags; f.seq = seq; f.src_hash = src_hash; f.dst_hash = dst_hash;
+        f.payload.assign(payload, payload + payload_len);
+        f.payload_len = static_cast<uint16_t>(payload_len);
+        f.total_cw = total_cw_override >= 0 ? static_cast<uint8_t>(total_cw_override)
+                                            : v2::DataFrame::calculateCodewords(payload_len, static_cast<CodeRate>(rate));
+        frame = f.serialize();
+    }
+    auto cws = v2::encodeFrameWithLDPC(frame, static_cast<CodeRate>(rate));
+    if (cws.size() > cap_cw) return -1;
+    for (size_t i = 0; i < cws.size(); ++i) {
+        if (cws[i].size() != 81) return -2;
+        std::memcpy(codewords + i * 81, cws[i].data(), 81);
+    }
+    return (int)cws.size();
 }
 
 }  // extern "C"

@@ -1750,6 +1750,188 @@ int uo_chirp_templates(float sample_rate, float* up_s, float* up_c, float* dn_s,
 }
 
 /* ====================================================================== */
+/* v2 wire format on the receive path (scope row f4, second half):         */
+/* RxPipeline::processFrame from the soft bits on — detectPing,            */
+/* deinterleaveCodewords, decodeFrame (src/gui/modem/rx_pipeline.cpp:       */
+/* 283-346,348-444,446-511) with v2::parseHeader / identifyCodeword /      */
+/* CodewordStatus::reassemble (src/protocol/frame_v2.cpp:952-982,          */
+/* 1023-1044,1175-1229) — and the transmit side that makes the stimulus    */
+/* (DataFrame::serialize :502-554, ControlFrame::serialize :346-382,       */
+/* encodeFrameWithLDPC :1079-1128).                                        */
+/* ====================================================================== */
+/* ControlFrame::calculateCRC, frame_v2.cpp:111-124 (CRC-16/CCITT-FALSE) */
+uint16_t uo_crc16(const uint8_t* d, uint32_t n) {
+    uint16_t crc = 0xFFFF;
+    for (uint32_t i = 0; i < n; ++i) {
+        crc ^= (uint16_t)((uint16_t)d[i] << 8);
+        for (int j = 0; j < 8; ++j) crc = (crc & 0x8000) ? (uint16_t)((crc << 1) ^ 0x1021) : (uint16_t)(crc << 1);
+    }
+    return crc;
+}
+
+static int v2_is_control(uint8_t t) {   /* isControlFrame, frame_v2.hpp:212-217 */
+    return t == 0x10 || t == 0x11 || t == 0x16 || t == 0x17 || t == 0x20 || t == 0x21 || t == 0x40;
+}
+
+/* v2::parseHeader, frame_v2.cpp:1175-1229.  out = {type, total_cw, payload_len, is_control}; returns valid */
+int uo_v2_parse_header(const uint8_t* d, uint32_t n, int32_t* out) {
+    out[0] = 0x10; out[1] = 0; out[2] = 0; out[3] = 0;          /* HeaderInfo defaults */
+    if (n < 20) return 0;
+    if (d[0] != 0x55 || d[1] != 0x4C) return 0;
+    out[0] = d[2];
+    out[3] = v2_is_control(d[2]);
+    if (out[3]) {
+        uint16_t rx = (uint16_t)((d[18] << 8) | d[19]);
+        if (rx != uo_crc16(d, 18)) return 0;
+        out[1] = 1; out[2] = 0;
+    } else {
+        out[1] = d[12];
+        out[2] = (d[13] << 8) | d[14];
+        uint16_t rx = (uint16_t)((d[15] << 8) | d[16]);
+        if (rx != uo_crc16(d, 15)) return 0;
+    }
+    return 1;
+}
+
+static const int v2_info_bits[6] = {162, 216, 324, 432, 486, 540};    /* getInfoBitsForRate, frame_v2.hpp:551-561 */
+
+/* res = {success, is_ping, frame_type, codewords_ok, codewords_failed, expected_codewords (accumulating: CW0's
+ * total_cw when fewer codewords were handed in, else 0), frame_len, status}; status: 0 no codeword / CW0 failed,
+ * 1 invalid header, 2 waiting for more codewords, 3 some codeword failed, 4 frame complete, 5 ping.
+ * deint_bps: RxPipeline::setInterleaverConfig's bits_per_symbol with interleaving enabled, 0 = disabled. */
+int uo_v2_decode_frame(uint32_t rate, uint32_t deint_bps, int max_iters, const float* soft, uint32_t n_soft,
+                       int32_t* res, uint8_t* frame_data, uint32_t cap) {
+    for (int i = 0; i < 8; ++i) res[i] = 0;
+    res[2] = 0x10;                                               /* RxFrameResult::frame_type = PROBE */
+    if (rate > 5) return -1;
+    if (n_soft == 0) return 0;                                   /* "No soft bits from waveform" */
+    /* detectPing (:446-472): hard bytes with soft > 0 -> bit 1, "ULTR" or its inversion */
+    {
+        uint8_t pb[8]; uint32_t np = 0;
+        for (uint32_t i = 0; i + 8 <= n_soft && np < 8; i += 8) {
+            uint8_t byte = 0;
+            for (int b = 0; b < 8; ++b) if (soft[i + b] > 0) byte |= (uint8_t)(1 << (7 - b));
+            pb[np++] = byte;
+        }
+        if (np >= 4) {
+            int normal = pb[0] == 0x55 && pb[1] == 0x4C && pb[2] == 0x54 && pb[3] == 0x52;
+            int inverted = pb[0] == 0xAA && pb[1] == 0xB3 && pb[2] == 0xAB && pb[3] == 0xAD;
+            if (normal || inverted) { res[0] = 1; res[1] = 1; res[2] = 0x01; res[7] = 5; return 0; }
+        }
+    }
+    const uint32_t num_cw = n_soft / 648;
+    if (num_cw == 0) return 0;
+    uint32_t perm[648], inv[648];
+    if (deint_bps) uo_channel_interleaver_perm(deint_bps, 648, perm, inv);
+    const uint32_t bytes_per_cw = (uint32_t)v2_info_bits[rate] / 8;
+    uint8_t cw0[128];
+    /* decodeSingleCodeword (:493-511): a fresh decoder per codeword, the first bytes_per_cw bytes */
+#define V2_DECODE(idx, dst, okvar)                                                              \
+    do {                                                                                        \
+        float llr_[648]; uint8_t dec_[128]; int ok_ = 0, it_ = 0;                               \
+        for (int j = 0; j < 648; ++j) llr_[j] = deint_bps ? soft[(size_t)(idx) * 648 + perm[j]] : soft[(size_t)(idx) * 648 + j]; \
+        int nb_ = uo_ldpc_decode_soft(rate, max_iters, llr_, 648, dec_, sizeof(dec_), &ok_, &it_); \
+        okvar = ok_ && nb_ >= (int)bytes_per_cw;                                                \
+        if (okvar) memcpy(dst, dec_, bytes_per_cw);                                             \
+    } while (0)
+    int ok0;
+    V2_DECODE(0, cw0, ok0);
+    if (!ok0) { res[4] = 1; return 0; }
+    res[3] = 1;
+    int32_t h[4];
+    /* RxPipeline::parseHeader (:513-527): identifyCodeword == HEADER (magic) and v2::parseHeader valid */
+    if (!uo_v2_parse_header(cw0, bytes_per_cw, h) || h[1] == 0) { res[7] = 1; return 0; }
+    res[2] = h[0];
+    const int expected = h[1];
+    if ((int)num_cw < expected) { res[5] = expected; res[7] = 2; return 0; }
+    const uint32_t expected_size = h[3] ? 20u : 17u + (uint32_t)h[2] + 2u;
+    /* CW0 decoded; CW1.. with the same rate; reassembleCodewords (:952-982) */
+    uint32_t len = 0;
+    int all_ok = 1;
+    {
+        uint32_t remaining = expected_size - len;
+        uint32_t to_copy = remaining < bytes_per_cw ? remaining : bytes_per_cw;
+        if (len + to_copy > cap) return -1;
+        memcpy(frame_data + len, cw0, to_copy); len += to_copy;
+    }
+    for (int i = 1; i < expected; ++i) {
+        uint8_t cw[128]; int ok;
+        V2_DECODE(i, cw, ok);
+        if (!ok) { res[4]++; all_ok = 0; continue; }
+        res[3]++;
+        uint32_t remaining = expected_size - len;
+        if (remaining == 0) continue;
+        if (bytes_per_cw >= 2 && cw[0] == 0xD5) {
+            uint32_t payload = bytes_per_cw - 2, to_copy = remaining < payload ? remaining : payload;
+            if (len + to_copy > cap) return -1;
+            memcpy(frame_data + len, cw + 2, to_copy); len += to_copy;
+        } else {
+            uint32_t to_copy = remaining < bytes_per_cw ? remaining : bytes_per_cw;
+            if (len + to_copy > cap) return -1;
+            memcpy(frame_data + len, cw, to_copy); len += to_copy;
+        }
+    }
+#undef V2_DECODE
+    if (all_ok) { res[0] = 1; res[6] = (int32_t)len; res[7] = 4; }
+    else res[7] = 3;
+    return 0;
+}
+
+/* Transmit side.  frame = DataFrame::serialize (type >= 0x30: header 17 + payload + CRC 2, total_cw from
+ * DataFrame::calculateCodewords(payload, rate) unless total_cw_override >= 0) or ControlFrame::serialize
+ * (control types: 20 bytes, payload = 6 bytes), then encodeFrameWithLDPC(frame, rate): CW0 = first
+ * bytes_per_cw bytes, CW1.. = 0xD5, index, payload; each zero padded and LDPC encoded to 81 bytes.
+ * Returns the number of codewords written to codewords[n][81]. */
+int uo_v2_build_frame(uint32_t rate, uint8_t type, uint8_t flags, uint16_t seq, uint32_t src_hash, uint32_t dst_hash,
+                      const uint8_t* payload, uint32_t payload_len, int total_cw_override, uint8_t* codewords,
+                      uint32_t cap_cw) {
+    if (rate > 5 || payload_len > 4096) return -1;
+    const uint32_t bytes_per_cw = (uint32_t)v2_info_bits[rate] / 8;
+    uint8_t frame[17 + 4096 + 2];
+    uint32_t total;
+    frame[0] = 0x55; frame[1] = 0x4C; frame[2] = type; frame[3] = flags;
+    frame[4] = (uint8_t)(seq >> 8); frame[5] = (uint8_t)seq;
+    frame[6] = (uint8_t)(src_hash >> 16); frame[7] = (uint8_t)(src_hash >> 8); frame[8] = (uint8_t)src_hash;
+    frame[9] = (uint8_t)(dst_hash >> 16); frame[10] = (uint8_t)(dst_hash >> 8); frame[11] = (uint8_t)dst_hash;
+    if (v2_is_control(type)) {
+        memset(frame + 12, 0, 6);
+        memcpy(frame + 12, payload, payload_len < 6 ? payload_len : 6);
+        uint16_t crc = uo_crc16(frame, 18);
+        frame[18] = (uint8_t)(crc >> 8); frame[19] = (uint8_t)crc;
+        total = 20;
+    } else {
+        total = 17 + payload_len + 2;
+        uint32_t ncw = 1;
+        if (total > bytes_per_cw) ncw = 1 + (total - bytes_per_cw + (bytes_per_cw - 2) - 1) / (bytes_per_cw - 2);
+        frame[12] = (uint8_t)(total_cw_override >= 0 ? total_cw_override : (int)ncw);
+        frame[13] = (uint8_t)(payload_len >> 8); frame[14] = (uint8_t)payload_len;
+        uint16_t h = uo_crc16(frame, 15);
+        frame[15] = (uint8_t)(h >> 8); frame[16] = (uint8_t)h;
+        if (payload_len) memcpy(frame + 17, payload, payload_len);
+        uint16_t f = uo_crc16(frame, total - 2);
+        frame[total - 2] = (uint8_t)(f >> 8); frame[total - 1] = (uint8_t)f;
+    }
+    uint32_t n = 0, offset = 0;
+    uint8_t chunk[128];
+    while (n == 0 || offset < total) {
+        if (n >= cap_cw) return -1;
+        memset(chunk, 0, sizeof(chunk));
+        if (n == 0) {
+            memcpy(chunk, frame, total < bytes_per_cw ? total : bytes_per_cw);
+            offset = bytes_per_cw;
+        } else {
+            chunk[0] = 0xD5; chunk[1] = (uint8_t)n;
+            uint32_t remaining = total - offset, room = bytes_per_cw - 2;
+            memcpy(chunk + 2, frame + offset, remaining < room ? remaining : room);
+            offset += room;
+        }
+        if (uo_ldpc_encode(rate, chunk, bytes_per_cw, codewords + (size_t)n * 81, 81) != 81) return -1;
+        ++n;
+    }
+    return (int)n;
+}
+
+/* ====================================================================== */
 /* Modulator (stimulus), src/ofdm/modulator.cpp                            */
 /* ====================================================================== */
 typedef struct modulator {

@@ -66,6 +66,14 @@ int uo_lts_templates(const ultra_hip_config* c, float* I, float* Q, uint32_t cap
  * outputs as ref_chirp_detect / ref_chirp_generate / ref_chirp_templates (oracle/ref_shim.cpp) */
 int uo_chirp_detect(float sample_rate, const float* x, uint32_t n, float threshold, int32_t* out, float* fout);
 int uo_chirp_generate(float sample_rate, float tx_cfo_hz, float* out, uint32_t cap);
+/* v2 wire format: RxPipeline::processFrame from the soft bits on, and the frame builder for stimulus */
+uint16_t uo_crc16(const uint8_t* d, uint32_t n);
+int uo_v2_parse_header(const uint8_t* d, uint32_t n, int32_t* out /*[4]*/);
+int uo_v2_decode_frame(uint32_t rate, uint32_t deint_bps, int max_iters, const float* soft, uint32_t n_soft,
+                       int32_t* res /*[8]*/, uint8_t* frame_data, uint32_t cap);
+int uo_v2_build_frame(uint32_t rate, uint8_t type, uint8_t flags, uint16_t seq, uint32_t src_hash, uint32_t dst_hash,
+                      const uint8_t* payload, uint32_t payload_len, int total_cw_override, uint8_t* codewords,
+                      uint32_t cap_cw);
 int uo_chirp_templates(float sample_rate, float* up_s, float* up_c, float* dn_s, float* dn_c, float* energies, uint32_t cap);
 
 /* ---- demodulator ------------------------------------------------------- */

@@ -11,7 +11,8 @@ from ._lib import UltraHipError, build
 
 __all__ = ["CodeRate", "CyclicPrefixMode", "Entry", "LDPC_BLOCK_SIZE", "ModemConfig", "Modulation", "presets",
            "getBitsPerSymbol", "getCodeRateValue", "info_bits", "is_differential", "UltraHipError", "build",
-           "ReceiveContext", "LDPCDecoder", "ChannelInterleaver", "OFDMDemodulator", "HipOfdmWaveform", "SyncResult"]
+           "ReceiveContext", "LDPCDecoder", "ChannelInterleaver", "OFDMDemodulator", "HipOfdmWaveform", "SyncResult",
+           "RxFrameDecoder", "RxFrameResult", "FrameType", "FrameStatus"]
 
 
 def __getattr__(name):
@@ -29,4 +30,7 @@ def __getattr__(name):
     if name in ("HipOfdmWaveform", "SyncResult"):
         from . import waveform
         return getattr(waveform, name)
+    if name in ("RxFrameDecoder", "RxFrameResult", "FrameType", "FrameStatus"):
+        from . import protocol
+        return getattr(protocol, name)
     raise AttributeError(name)

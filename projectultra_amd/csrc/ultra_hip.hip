@@ -20,6 +20,7 @@
 #include "acquire_kernel.h"
 #include "stimulus_kernel.h"
 #include "chirp_kernel.h"
+#include "frame_kernel.h"
 
 using namespace ultra_hip;
 
@@ -44,6 +45,8 @@ struct ultra_hip_ctx {
     float* d_ws_fstats = nullptr;
     size_t ws_fstats_frames = 0;
     int stim_ncw_raw = 0, stim_ncw_enc = 0, stim_tx_symbols = 0, stim_pre_len = 0;
+    uint8_t* d_ws_frame = nullptr;       // frame decode: bytes, ok, iters of every codeword
+    size_t ws_frame_cw = 0;
     unsigned* d_ws_chirp = nullptr;      // chirp receive: detected, start, cfo, corr, entry, offset, cfo used, phase
     size_t ws_chirp_streams = 0;
     float* d_chirp = nullptr;            // chirp templates: up sin, up cos, down sin, down cos
@@ -326,6 +329,7 @@ void ultra_hip_destroy(ultra_hip_ctx* ctx) {
     if (ctx->d_ws_acq) (void)hipFree(ctx->d_ws_acq);
     if (ctx->d_chirp) (void)hipFree(ctx->d_chirp);
     if (ctx->d_ws_chirp) (void)hipFree(ctx->d_ws_chirp);
+    if (ctx->d_ws_frame) (void)hipFree(ctx->d_ws_frame);
     if (ctx->d_nco_tx) (void)hipFree(ctx->d_nco_tx);
     if (ctx->d_preamble) (void)hipFree(ctx->d_preamble);
     if (ctx->d_ws_fstats) (void)hipFree(ctx->d_ws_fstats);
@@ -516,6 +520,53 @@ int ultra_hip_chirp_receive_batch(ultra_hip_ctx* ctx, const float* d_audio, size
     if (rc != ULTRA_HIP_OK) return rc;
     hipLaunchKernelGGL(dev::clear_unusable_kernel, dim3(blocks), dim3(256), 0, ctx->stream, entry, (int)n_streams,
                        d_bytes, (int)ctx->geo.decoded_bytes, d_iters, d_ok);
+    UH_HIP(hipGetLastError());
+    return ULTRA_HIP_OK;
+}
+
+int ultra_hip_decode_frames_batch(ultra_hip_ctx* ctx, const float* d_soft, size_t frame_stride, uint32_t n_soft,
+                                  size_t n_frames, ultra_hip_frame_result* d_results, uint8_t* d_frame_data,
+                                  size_t frame_data_stride) {
+    if (!ctx) return ULTRA_HIP_ERR_INVALID_ARG;
+    if (n_frames == 0) return ULTRA_HIP_OK;
+    const size_t num_cw = n_soft / (uint32_t)kLdpcN;
+    // v2::getBytesPerCodeword (src/protocol/frame_v2.hpp:551-567): its own table, 216 bits for R1/3 although
+    // the codec falls back to k = 324 for that rate
+    static const uint32_t kV2InfoBits[6] = {162, 216, 324, 432, 486, 540};
+    if (ctx->cfg.code_rate > 5) return ULTRA_HIP_ERR_UNSUPPORTED;
+    const uint32_t bytes_per_cw = kV2InfoBits[ctx->cfg.code_rate] / 8;
+    if (!d_soft || !d_results || !d_frame_data || frame_stride < n_soft || n_frames > 0x7fffffffull ||
+        frame_data_stride < num_cw * bytes_per_cw || n_frames * std::max<size_t>(num_cw, 1) > 0x7fffffffull)
+        return ULTRA_HIP_ERR_INVALID_ARG;
+    DeviceGuard guard(ctx->device);
+    const size_t total_cw = n_frames * num_cw, db = ctx->geo.decoded_bytes;
+    if (ctx->ws_frame_cw < total_cw) {
+        if (ctx->d_ws_frame) { UH_HIP(hipStreamSynchronize(ctx->stream)); (void)hipFree(ctx->d_ws_frame); ctx->d_ws_frame = nullptr; }
+        ctx->ws_frame_cw = 0;
+        UH_HIP(hipMalloc(&ctx->d_ws_frame, total_cw * (db + 1 + sizeof(int32_t)) + 16));
+        ctx->ws_frame_cw = total_cw;
+    }
+    int32_t* iters = reinterpret_cast<int32_t*>(ctx->d_ws_frame);            // 4-byte aligned part first
+    uint8_t* bytes = ctx->d_ws_frame + total_cw * sizeof(int32_t);
+    uint8_t* okv = bytes + total_cw * db;
+    size_t idx_frame = num_cw, idx_cw = 1;
+    if (num_cw > 0) {
+        if (frame_stride == num_cw * (size_t)kLdpcN) {                       // codewords back to back: one launch
+            const int rc = launch_ldpc(ctx, d_soft, kLdpcN, total_cw, bytes, iters, okv, nullptr);
+            if (rc != ULTRA_HIP_OK) return rc;
+        } else {                                                            // one launch per codeword position
+            idx_frame = 1; idx_cw = n_frames;
+            for (size_t c = 0; c < num_cw; ++c) {
+                const int rc = launch_ldpc(ctx, d_soft + c * kLdpcN, frame_stride, n_frames, bytes + c * n_frames * db,
+                                           iters + c * n_frames, okv + c * n_frames, nullptr);
+                if (rc != ULTRA_HIP_OK) return rc;
+            }
+        }
+    }
+    const unsigned blocks = (unsigned)((n_frames + 63) / 64);
+    hipLaunchKernelGGL(dev::frame_assemble_kernel, dim3(blocks), dim3(64), 0, ctx->stream, d_soft, frame_stride, n_soft,
+                       (int)n_frames, bytes, okv, (int)db, (int)bytes_per_cw, idx_frame, idx_cw,
+                       reinterpret_cast<int32_t*>(d_results), d_frame_data, frame_data_stride);
     UH_HIP(hipGetLastError());
     return ULTRA_HIP_OK;
 }

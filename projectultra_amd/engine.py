@@ -277,6 +277,25 @@ class ReceiveContext:
             out["llr"] = llr
         return out
 
+    def decode_frames(self, soft):
+        """v2 frames from their soft bits [n_frames][n_soft] (RxPipeline::processFrame behind getSoftBits:
+        ping check, per-codeword deinterleave if set_deinterleave() is on, CW0 -> header -> remaining codewords ->
+        reassembly; ultra_hip_decode_frames_batch).  Returns device tensors dict(results [n][8] int32 =
+        success, is_ping, frame_type, codewords_ok, codewords_failed, expected_codewords, frame_len, status;
+        frame_data [n][stride] uint8)."""
+        torch = _torch()
+        soft = self._dev(soft, torch.float32, "soft")
+        if soft.dim() != 2:
+            raise ValueError("soft must be [n_frames][n_soft]")
+        n, ns = soft.shape
+        stride = max((ns // 648) * (self.geometry.ldpc_k // 8), 1)
+        out = dict(results=torch.zeros((n, 8), dtype=torch.int32, device=self.device),
+                   frame_data=torch.zeros((n, stride), dtype=torch.uint8, device=self.device))
+        check(self.lib.ultra_hip_decode_frames_batch(self._ctx, soft.data_ptr(), self._row_stride(soft), ns, n,
+                                                     out["results"].data_ptr(), out["frame_data"].data_ptr(), stride),
+              "ultra_hip_decode_frames_batch")
+        return out
+
     def make_batch(self, n_frames: int, seed: int = 0x5EED, first_frame: int = 0, channel: str = "awgn",
                    snr_db: float = 30.0, delay_ms: float = 0.5, doppler_hz: float = 0.1):
         """Synthetic frames at the SYNCED entry, generated on the device (ultra_hip_make_batch): random

@@ -120,3 +120,52 @@ def chirp_initial_phase(cfo_hz, start_sample, sample_rate=48000):
     while float(ph) < -math.pi:
         ph = np.float32(float(ph) + 2.0 * math.pi)
     return ph
+
+
+def v2_frame_cases(oracle, rate, rng, deint_bps=0):
+    """Soft-bit buffers the way RxPipeline::processFrame sees them (encoded v2 frames -> +-LLR with noise
+    [-> channel-interleaved per codeword]): data frames of several payload sizes, a control frame, a frame with
+    fewer codewords than its header announces, a corrupted continuation codeword, a corrupted CW0, a bad header
+    CRC, a ping, random soft bits, and a buffer shorter than one codeword.  Returns [(name, soft)]."""
+    k8 = (162, 216, 324, 432, 486, 540)[int(rate)] // 8          # v2::getBytesPerCodeword
+    perm = oracle.channel_interleaver_perm(deint_bps)[0] if deint_bps else None
+
+    def soft_of(cws, sigma=None, extra_cw=0):
+        sigma = sigma or (0.6 if int(rate) <= 2 else 0.42)     # a few BP iterations, still decodable
+        bits = np.unpackbits(np.asarray(cws, np.uint8), axis=1).astype(np.float32)
+        y = 1.0 - 2.0 * bits + rng.normal(0, sigma, bits.shape).astype(np.float32)
+        llr = (2.0 * y / sigma ** 2).astype(np.float32)
+        if extra_cw:
+            llr = np.concatenate([llr, rng.normal(0, 2.0, (extra_cw, 648)).astype(np.float32)])
+        if perm is not None:                       # TX interleave: out[perm[i]] = in[i]
+            out = np.empty_like(llr); out[:, perm] = llr; llr = out
+        return llr.reshape(-1)
+
+    cases = []
+    for n_pay in (0, 1, k8 - 19, k8 - 18, 3 * k8, 200):
+        payload = bytes(rng.integers(0, 256, n_pay, dtype=np.uint8))
+        cases.append((f"data{n_pay}", soft_of(oracle.v2_build_frame(rate, payload, seq=n_pay))))
+    cases.append(("data_extra_codewords", soft_of(oracle.v2_build_frame(rate, b"x" * 70), extra_cw=2)))
+    cases.append(("control_ack", soft_of(oracle.v2_build_frame(rate, b"\x01\x02\x03", type=0x20, seq=7))))
+    cases.append(("control_beacon_noisy", soft_of(oracle.v2_build_frame(rate, b"", type=0x40), sigma=0.9 if int(rate) <= 2 else 0.5)))
+    full = oracle.v2_build_frame(rate, bytes(rng.integers(0, 256, 150, dtype=np.uint8)))
+    cases.append(("waiting", soft_of(full[:-1])))
+    bad = soft_of(full)
+    bad[648:2 * 648] = rng.normal(0, 3.0, 648)
+    cases.append(("cw1_garbage", bad))
+    bad0 = soft_of(full)
+    bad0[:648] = rng.normal(0, 3.0, 648)
+    cases.append(("cw0_garbage", bad0))
+    cases.append(("header_says_more", soft_of(oracle.v2_build_frame(rate, b"abc", total_cw=9))))
+    cases.append(("header_says_fewer", soft_of(oracle.v2_build_frame(rate, b"q" * 120, total_cw=2))))
+    # valid codeword whose 20 header bytes are not a v2 header (payload bytes straight into the encoder)
+    raw = np.frombuffer(oracle.ldpc_encode(int(rate), bytes(rng.integers(0, 256, k8, dtype=np.uint8))), np.uint8)[None, :]
+    cases.append(("not_a_header", soft_of(raw)))
+    hdr = bytearray(k8); hdr[0:2] = b"\x55\x4c"; hdr[2] = 0x30; hdr[12] = 3
+    cases.append(("bad_header_crc", soft_of(np.frombuffer(oracle.ldpc_encode(int(rate), bytes(hdr)), np.uint8)[None, :])))
+    ping = np.unpackbits(np.frombuffer(b"ULTR", np.uint8)).astype(np.float32)
+    cases.append(("ping", np.concatenate([4.0 * ping - 2.0, rng.normal(0, 1, 700).astype(np.float32)])))
+    cases.append(("ping_inverted", np.concatenate([2.0 - 4.0 * ping, rng.normal(0, 1, 40).astype(np.float32)])))
+    cases.append(("noise", rng.normal(0, 2.0, 3 * 648).astype(np.float32)))
+    cases.append(("short", rng.normal(0, 2.0, 100).astype(np.float32) - 5.0))
+    return cases

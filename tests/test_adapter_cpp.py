@@ -12,6 +12,9 @@ int main() {
     ultra_hip::ModemConfig c;
     ultra_hip::HipOfdmWaveform w(c);
     w.configure(ultra_hip::Modulation::DQPSK, ultra_hip::CodeRate::R1_2);
+    ultra_hip::HipRxFrameDecoder fd;
+    fd.setDataMode(ultra_hip::CodeRate::R3_4, true);
+    fd.setInterleaverConfig(176);
 #ifdef ULTRA_HIP_WITH_REFERENCE
     ultra::WaveformPtr p = std::make_unique<ultra_hip::HipOfdmWaveform>(c);   // through the plugin pointer type
     (void)p;

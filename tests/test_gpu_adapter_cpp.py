@@ -144,3 +144,53 @@ def test_cpp_adapter_chirp_waveform(tmp_path, oracle):
             assert beq(got[4:], want)
         else:
             assert got.size == 4
+
+
+SRC_FRAME = r'''
+#include "ultra_hip_waveform.hpp"
+#include <cstdio>
+#include <vector>
+using namespace ultra_hip;
+int main(int argc, char** argv) {
+    // argv: soft.f32 n out.bin rate bits_per_symbol(0 = interleaving off)
+    FILE* f = std::fopen(argv[1], "rb");
+    const size_t n = std::stoul(argv[2]);
+    std::vector<float> soft(n);
+    if (std::fread(soft.data(), 4, n, f) != n) return 2;
+    std::fclose(f);
+    HipRxFrameDecoder dec;
+    dec.setDataMode(static_cast<CodeRate>(std::stoi(argv[4])), true);
+    const size_t bps = std::stoul(argv[5]);
+    dec.setInterleavingEnabled(bps != 0);
+    if (bps) dec.setInterleaverConfig(bps);
+    HipRxFrameResult r = dec.decodeSoftBits(std::span<const float>(soft.data(), n));
+    FILE* g = std::fopen(argv[3], "wb");
+    const int head[6] = {r.success, r.is_ping, r.frame_type, r.codewords_ok, r.codewords_failed, dec.getExpectedCodewords()};
+    std::fwrite(head, 4, 6, g); std::fwrite(r.frame_data.data(), 1, r.frame_data.size(), g); std::fclose(g);
+    return 0;
+}
+'''
+
+
+@pytest.mark.parametrize("rate,bps", [(0, 0), (4, 176)])
+def test_cpp_frame_decoder(tmp_path, oracle, rate, bps):
+    """HipRxFrameDecoder::decodeSoftBits (RxPipeline's decode half) from a C++ program, against the oracle."""
+    from _util import v2_frame_cases
+    src = tmp_path / "fd.cpp"
+    src.write_text(SRC_FRAME)
+    exe = tmp_path / "fd"
+    lib = ROOT / "projectultra_amd"
+    subprocess.check_call(["g++", "-O1", "-std=c++20", f"-I{ROOT / 'include'}", str(src), f"-L{lib}", "-lultra_hip",
+                           f"-Wl,-rpath,{lib}", "-o", str(exe)])
+    for t, (name, soft) in enumerate(v2_frame_cases(oracle, rate, np.random.default_rng(3), bps)[::2]):
+        fin, fo = tmp_path / f"s{t}.f32", tmp_path / f"r{t}.bin"
+        soft.tofile(fin)
+        r = subprocess.run([str(exe), str(fin), str(soft.size), str(fo), str(rate), str(bps)], capture_output=True,
+                           text=True, timeout=300)
+        assert r.returncode == 0, (name, r.returncode, r.stderr[-400:])
+        raw = fo.read_bytes()
+        head = np.frombuffer(raw[:24], np.int32)
+        w = oracle.v2_decode_frame(rate, soft, bps)
+        assert list(head) == [w[k] for k in ("success", "is_ping", "frame_type", "codewords_ok", "codewords_failed",
+                                             "expected_codewords")], (name, head, w)
+        assert raw[24:] == w["frame_data"], name

@@ -219,3 +219,28 @@ def test_chirp_sync(oracle, ref):
             assert np.float32(o[k]).tobytes() == np.float32(r[k]).tobytes(), (k, o, r)
         hits += o["success"]
     assert hits >= 3
+
+
+@pytest.mark.parametrize("rate,bps", [(0, 0), (2, 60), (4, 176), (5, 0), (1, 0)])
+def test_v2_wire_format(oracle, ref, rate, bps):
+    """Scope row f4, second half: CRC-16, v2::parseHeader, the frame builder (DataFrame/ControlFrame::serialize +
+    encodeFrameWithLDPC) and RxPipeline::processFrame from the soft bits on (detectPing, deinterleaveCodewords,
+    decodeFrame: CW0 -> header -> remaining codewords -> reassemble) — every field of the result equal."""
+    from _util import v2_frame_cases
+    rng = np.random.default_rng(100 + rate)
+    for n in (0, 1, 15, 18, 200):
+        d = bytes(rng.integers(0, 256, n, dtype=np.uint8))
+        assert oracle.crc16(d) == ref.crc16(d)
+    assert oracle.crc16(b"123456789") == 0x29B1                       # CRC-16/CCITT-FALSE check value
+    for payload, kw in ((b"", {}), (b"hello world" * 9, dict(seq=513)), (b"\x09\x08", dict(type=0x21, flags=0x41)),
+                        (bytes(300), dict(total_cw=7, src_hash=1, dst_hash=0xFFFFFF))):
+        a, b = oracle.v2_build_frame(rate, payload, **kw), ref.v2_build_frame(rate, payload, **kw)
+        assert beq(a, b), (payload[:4], kw)
+        dec = oracle.ldpc_decode_batch(rate, (1.0 - 2.0 * np.unpackbits(a[:1], axis=1)).astype(np.float32) * 4)[0][0]
+        assert oracle.v2_parse_header(bytes(dec)) == ref.v2_parse_header(bytes(dec))
+    seen = set()
+    for name, soft in v2_frame_cases(oracle, rate, rng, bps):
+        o, r = oracle.v2_decode_frame(rate, soft, bps), ref.v2_decode_frame(rate, soft, bps)
+        assert o == r, (name, o, r)
+        seen.add(o["status"])
+    assert seen == {0, 1, 2, 3, 4, 5}
