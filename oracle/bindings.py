@@ -460,6 +460,13 @@ class Ref(_Base):
         fn(C.c_uint32(bits_per_symbol), C.c_uint32(total), _ptr(x), C.c_uint32(x.size), _ptr(out))
         return out
 
+    def channel_interleaver_perm(self, bits_per_symbol, total=648):
+        """(perm, inv) read off the reference's ChannelInterleaver::interleave: out[perm[i]] = in[i]."""
+        out = self.channel_interleaver(bits_per_symbol, np.arange(total, dtype=np.float32), total, inverse=False)
+        inv = out.astype(np.uint32)
+        perm = np.empty(total, np.uint32); perm[inv] = np.arange(total, dtype=np.uint32)
+        return perm, inv
+
     def interleaver_deinterleave(self, rows, cols, x):
         x = _f32(x); out = np.zeros_like(x)
         self.lib.ref_interleaver_deinterleave(C.c_uint32(rows), C.c_uint32(cols), _ptr(x), C.c_uint32(x.size), _ptr(out))

@@ -13,6 +13,10 @@ Fixtures
   demod.npz    per mode: SYNCED-entry audio (data symbols only), initial CFO, the reference's LLRs,
                per-symbol tracker scalars, decoded bytes / success / iterations
   presynced.npz  processPresynced cases (training + data symbols, CFO, initial phase)
+  sync.npz     acquisition (SEARCHING state fed in 960-sample chunks: found / fed / sync offset / coarse CFO /
+               refined LTS / data start) and chirp synchronisation (detectDualChirp + detectSync's start sample)
+               of whole transmissions
+  frames.npz   v2 wire format: soft bits of frames in, RxPipeline::processFrame's result out
   fullsync.npz full Schmidl-Cox receive of whole frames (OFDMDemodulator::process fed in 960-sample
                chunks): sync offset, coarse CFO, LLRs, and the data-start offset at which the
                SYNCED-entry loop reproduces those LLRs bit for bit
@@ -193,7 +197,66 @@ def fullsync():
     np.savez_compressed(OUT / "fullsync.npz", **d)
 
 
+def sync():
+    sys.path.insert(0, str(ROOT / "tests"))
+    from _util import chirp_streams, long_acquisition_streams
+    d = {}
+    lrng = np.random.default_rng(4242)
+    # Schmidl-Cox acquisition: whole frames at several SNRs / leads, one noise-only stream
+    for name, (fft, mod, rate) in dict(cfg3=(1024, "QAM16", "R3_4"), cfg2=(512, "DQPSK", "R1_2")).items():
+        cfg = make_config(fft, mod, rate)
+        g = geometry(cfg)
+        n = g.frame_samples + 7 * (fft + g.cp_len) + 3200
+        rows = []
+        for t in range(5):
+            payload = bytes(lrng.integers(0, 256, INFO_BITS[cfg.code_rate] // 8, dtype=np.uint8))
+            a, _ = r.modulate_frame(cfg, r.ldpc_encode(int(cfg.code_rate), payload))
+            a = a * np.float32(0.5 / np.abs(a).max())
+            sigma = np.sqrt(np.mean(a.astype(np.float64) ** 2) / 10 ** ([30.0, 22.0, 12.0, 26.0, 18.0][t] / 10))
+            a = (a + lrng.normal(0, sigma, a.size)).astype(np.float32)
+            lead = lrng.normal(0, 2e-4, int(lrng.integers(0, 2800))).astype(np.float32)
+            x = np.concatenate([lead, a * np.float32(0.4 + 0.15 * t)])
+            rows.append(np.concatenate([x, lrng.normal(0, 2e-4, max(0, n - x.size)).astype(np.float32)])[:n])
+        rows.append(lrng.normal(0, 0.05, n).astype(np.float32))
+        audio = np.stack(rows)
+        res = [r.acquire(cfg, x, 960) for x in audio]
+        d[f"acq_{name}__cfg"] = cfg_array(cfg)
+        d[f"acq_{name}__audio"] = audio
+        d[f"acq_{name}__ints"] = np.array([[q["found"], q["fed_at_sync"], q["sync_offset"], q["refined_lts"], q["data_start"]] for q in res], np.int64)
+        d[f"acq_{name}__cfo"] = np.array([q["coarse_cfo"] for q in res], np.float32)
+        print("acquire", name, [(q["found"], q["data_start"]) for q in res])
+    # chirp synchronisation: transmissions with 0 / 12.5 / -30 Hz offset and a noise-only buffer
+    cfg = make_config(512, "DQPSK", "R1_2", entry=1)
+    streams = chirp_streams(r, cfg, lrng, n=3)
+    streams = [streams[0], streams[1], streams[2], streams[-1][:66000]]
+    for i, x in enumerate(streams):
+        q = r.chirp_detect(x)
+        d[f"chirp{i}__audio"] = x
+        d[f"chirp{i}__ints"] = np.array([q["success"], q["up_chirp_start"], q["down_chirp_start"], q["start_sample"]], np.int64)
+        d[f"chirp{i}__floats"] = np.array([q["cfo_hz"], q["up_correlation"], q["down_correlation"]], np.float32)
+        print("chirp", i, q)
+    np.savez_compressed(OUT / "sync.npz", **d)
+
+
+def frames():
+    sys.path.insert(0, str(ROOT / "tests"))
+    from _util import v2_frame_cases
+    d = {}
+    frng = np.random.default_rng(777)
+    for rate, bps in ((0, 0), (2, 60), (4, 176)):
+        for name, soft in v2_frame_cases(r, rate, frng, bps):
+            q = r.v2_decode_frame(rate, soft, bps)
+            key = f"r{rate}_b{bps}__{name}"
+            d[key + "__soft"] = soft.astype(np.float32)
+            d[key + "__res"] = np.array([q["success"], q["is_ping"], q["frame_type"], q["codewords_ok"], q["codewords_failed"],
+                                         q["expected_codewords"], q["status"]], np.int32)
+            d[key + "__data"] = np.frombuffer(q["frame_data"], np.uint8)
+    np.savez_compressed(OUT / "frames.npz", **d)
+
+
 if __name__ == "__main__":
-    ldpc(); tables(); demod(); presynced(); fullsync()
+    which = sys.argv[1:] or ["ldpc", "tables", "demod", "presynced", "fullsync", "sync", "frames"]
+    for name in which:
+        globals()[name]()
     for f in sorted(OUT.glob("*.npz")):
         print(f.name, f.stat().st_size // 1024, "KiB")

@@ -408,3 +408,27 @@ def test_waveform_mirror_detect_sync_and_process(oracle):
                                             chirp_initial_phase(o["cfo_hz"], o["start_sample"], cfg.sample_rate))
         _check_llr(w.getSoftBits(), want, "waveform mirror")
         w.reset()
+
+
+def test_sync_golden_reference():
+    """Acquisition (row f1) and chirp synchronisation (row f4) on the GPU against the compiled reference's
+    fixtures in tests/golden/sync.npz."""
+    import torch
+    g = np.load(GOLDEN / "sync.npz")
+    for name in ("cfg3", "cfg2"):
+        cfg = cfg_from_array(g[f"acq_{name}__cfg"])
+        ctx = context_for(cfg)
+        r = {k: v.cpu().numpy() for k, v in ctx.acquire(g[f"acq_{name}__audio"], 960).items()}
+        ints, cfo = g[f"acq_{name}__ints"], g[f"acq_{name}__cfo"]
+        assert np.array_equal(r["found"], ints[:, 0])
+        ok = ints[:, 0] == 1
+        assert np.array_equal(r["fed_at_sync"][ok], ints[ok, 1]) and np.array_equal(r["sync_offset"][ok], ints[ok, 2])
+        assert np.array_equal(r["data_start"][ok], ints[ok, 4]) and beq(r["cfo_hz"][ok], cfo[ok])
+    ctx = context_for(make_config(512, "DQPSK", "R1_2", entry=1))
+    for i in range(4):
+        x = g[f"chirp{i}__audio"]
+        q = {k: v.cpu().numpy()[0] for k, v in ctx.chirp_sync(torch.from_numpy(x[None, :]).cuda()).items()}
+        ints, fl = g[f"chirp{i}__ints"], g[f"chirp{i}__floats"]
+        assert [int(q["detected"]), int(q["up_chirp_start"]), int(q["down_chirp_start"]), int(q["start_sample"])] == list(ints)
+        assert np.float32(q["cfo_hz"]).tobytes() == fl[0].tobytes()
+        assert np.float32(q["correlation"]).tobytes() == max(fl[1], fl[2]).tobytes()

@@ -132,3 +132,21 @@ def test_chirp_frame_end_to_end(oracle):
         w = oracle.v2_decode_frame(rate, llr[i, :n_soft], bps)
         _check(res[i], data[i], w, f"stream {i}")
         assert w["success"] and w["frame_data"][17:17 + len(payload)] == payload, (i, w)
+
+
+def test_frames_golden_reference():
+    """The HIP path against the compiled reference's RxPipeline results (tests/golden/frames.npz)."""
+    from conftest import GOLDEN
+    g = np.load(GOLDEN / "frames.npz")
+    keys = sorted(k[:-6] for k in g.files if k.endswith("__soft"))
+    ctxs = {}
+    for key in keys:
+        rate, bps = int(key[1]), int(key.split("__")[0].split("_b")[1])
+        if (rate, bps) not in ctxs:
+            ctxs[(rate, bps)] = context_for(make_config(512, "DQPSK", rate))
+            ctxs[(rate, bps)].set_deinterleave(bps)
+        out = ctxs[(rate, bps)].decode_frames(g[key + "__soft"][None, :])
+        res, data = out["results"].cpu().numpy()[0], out["frame_data"].cpu().numpy()[0]
+        want = g[key + "__res"]
+        assert list(res[:6]) == list(want[:6]) and res[7] == want[6], (key, res, want)
+        assert bytes(data[:res[6]]) == g[key + "__data"].tobytes(), key
