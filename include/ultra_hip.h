@@ -83,7 +83,7 @@ typedef struct ultra_hip_config {
     uint32_t num_carriers;     /* 30 / 59                                          */
     uint32_t cp_mode;          /* ultra_hip_cp_mode                                */
     uint32_t symbol_guard;     /* guard samples after each symbol                  */
-    uint32_t pilot_spacing;    /* every pilot_spacing-th carrier is a pilot        */
+    uint32_t pilot_spacing;    /* every pilot_spacing-th carrier is a pilot (>= 2 with use_pilots) */
     uint32_t use_pilots;       /* 0/1                                              */
     uint32_t modulation;       /* ultra_hip_modulation                             */
     uint32_t code_rate;        /* ultra_hip_code_rate                              */
@@ -380,12 +380,13 @@ int ultra_hip_set_deinterleave(ultra_hip_ctx* ctx, uint32_t bits_per_symbol);
 enum ultra_hip_kernel_class {
     ULTRA_HIP_K_INIT_STATE = 0, /* init_state_kernel */
     ULTRA_HIP_K_MIX_FFT = 1,    /* mix_fft_kernel: toBaseband + FFT, one launch per OFDM symbol */
-    ULTRA_HIP_K_TRACK = 2,      /* track_kernel: channel tracking + equalize + demap, one per symbol */
+    ULTRA_HIP_K_TRACK = 2,      /* track_kernel (carrier half: interpolate + equalize + demap) / train_kernel, one per symbol */
     ULTRA_HIP_K_LDPC = 3,       /* ldpc_decode_kernel */
     ULTRA_HIP_K_COUNT = 4,      /* count_errors_kernel */
     ULTRA_HIP_K_ACQUIRE = 5,    /* acquire_kernel */
     ULTRA_HIP_K_CHIRP = 6,      /* chirp_sync_kernel */
-    ULTRA_HIP_K_N = 7
+    ULTRA_HIP_K_PILOT = 7,      /* track_pilot_kernel: pilot half of the channel update, one per data symbol */
+    ULTRA_HIP_K_N = 8
 };
 int ultra_hip_profile_enable(ultra_hip_ctx* ctx, int enable);
 int ultra_hip_profile_read(ultra_hip_ctx* ctx, float* ms, uint32_t* launches);

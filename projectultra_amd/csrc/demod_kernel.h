@@ -115,7 +115,7 @@ __device__ __forceinline__ float timing_phase_of(int k, float timing, int log2_f
 // associative, so the order is kept.  Terms go through LDS: every lane reads them back with
 // wave-uniform (broadcast) addresses and runs the serial chain itself — one v_add per term instead
 // of a v_readlane + v_add pair, and chains of different sums run in different lanes (see
-// update_channel_estimate).
+// track_pilot_kernel).
 __device__ __forceinline__ float lane_f(float v, int i) {
     return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), i));
 }
@@ -409,142 +409,195 @@ __device__ __forceinline__ void interpolate_channel(TrackShared& sh, const Demod
     }
 }
 
-// updateChannelEstimate (channel_equalizer.cpp:330-595); prev = prev_pilot_phases[lane]
-__device__ __forceinline__ void update_channel_estimate(TrackShared& sh, const DemodConst& D, const LaneConst& lc,
-                                                        Track& tr, c32& prev, const c32* __restrict__ fq) {
+// The carrier half of updateChannelEstimate when the pilot half ran in track_pilot_kernel: interpolation
+// between the (already updated, already de-rotated) pilots and the timing phase re-applied to every carrier
+// (:514-567)
+__device__ __forceinline__ void finish_channel_estimate(TrackShared& sh, const DemodConst& D, const LaneConst& lc,
+                                                        const Track& tr) {
     const int lane = threadIdx.x;
-    const int np = D.n_pilot;
-    const bool is_pilot = lane < np;
-    const float alpha = (tr.snr_symbol_count == 0) ? 1.0f : 0.9f;
-
-    c32 h = mk(0.0f, 0.0f);
-    if (is_pilot) h = cdiv_pilot(fq[lc.pilot_fq], lc.pilot_seq);
-    if (!tr.cpc_init && np != 0) {                              // carrier phase recovery (:348-357)
-        const c32 h_sum = ordered_csum(sh.cbuf, h, np);         // the reference sums on every symbol, uses it here only
-        const c32 h_avg = cdivf(h_sum, (float)np);
-        const float avg_mag = cabs_(h_avg);
-        if (avg_mag > 0.01f) { tr.cpc = cdivf(cconj(h_avg), avg_mag); tr.cpc_init = 1; }
-    }
-    h = cmul(h, tr.cpc);
-    const float n2 = cnorm(h);
-
-    // per-pilot terms of the serial loops (:385-412, :420-440, :473-490)
-    float nd = 0.0f, ph = 0.0f;
-    c32 unit = mk(0.0f, 0.0f);
-    bool f_noise = false, f_cfo = false, f_tim = false;
-    if (is_pilot) {
-        if (tr.has_prev) {
-            const float pn = cnorm(prev);
-            if (pn > 1e-6f && n2 > 1e-6f) {
-                nd = cnorm(csub(h, prev));
-                f_noise = true;
-                const c32 diff = cmul(h, cconj(prev));
-                const float mag = cabs_(diff);
-                if (mag > 1e-6f) { unit = cdivf(diff, mag); f_cfo = true; }
-            }
-        }
-        if (tr.snr_symbol_count >= 3 && !(n2 < 1e-6f)) { ph = carg_(h); f_tim = true; }
-        const c32 h_old = sh.H[lc.pilot_slot];
-        sh.H[lc.pilot_slot] = cadd(cscale(h, alpha), cscale(h_old, 1.0f - alpha));
-    }
-    // All eight serial sums of the reference over the pilots (:385-412, :420-440, :473-490) at once:
-    // pilot i stores its eight terms as row i of sh.terms; lane s (mod 8) then walks column s in
-    // pilot order, so the eight chains run in eight lanes side by side (np v_adds in total instead
-    // of 8*np readlane+add pairs).  A term the reference skips is replaced by -0.0f, the exact
-    // neutral element of float addition (x + -0.0f == x bit for bit, also for x = +-0), which keeps
-    // the walk branch-free.
-    const int noise_hits = __popcll(__ballot(f_noise)), cfo_hits = __popcll(__ballot(f_cfo)),
-              tim_hits = __popcll(__ballot(f_tim));
-    if (is_pilot) {
-        const float kf = (float)lc.pilot_k;
-        float4 ta, tb;
-        ta.x = n2;
-        ta.y = f_noise ? nd : -0.0f;
-        ta.z = f_cfo ? unit.re : -0.0f;
-        ta.w = f_cfo ? unit.im : -0.0f;
-        tb.x = f_tim ? kf : -0.0f;
-        tb.y = f_tim ? (float)(lc.pilot_k * lc.pilot_k) : -0.0f;
-        tb.z = f_tim ? ph : -0.0f;
-        tb.w = f_tim ? kf * ph : -0.0f;
-        *reinterpret_cast<float4*>(&sh.terms[lane][0]) = ta;
-        *reinterpret_cast<float4*>(&sh.terms[lane][4]) = tb;
-    }
-    wave_sync();
-    float acc = 0.0f;
-    {
-        const int col = lane & 7;
-        for (int i = 0; i < np; ++i) acc += sh.terms[i][col];
-    }
-    const float s_sig = lane_f(acc, 0), s_nd = lane_f(acc, 1), s_ur = lane_f(acc, 2), s_ui = lane_f(acc, 3),
-                sum_k = lane_f(acc, 4), sum_k2 = lane_f(acc, 5), sum_phase = lane_f(acc, 6),
-                sum_k_phase = lane_f(acc, 7);
-    wave_sync();
-    const float signal_power = s_sig / (float)np;                   // NaN when np == 0 (reference quirk)
-    int noise_count = noise_hits;
-    float noise_power_sum = s_nd;
-    if (noise_count == 0) { noise_power_sum = signal_power / 31.6f; noise_count = 1; }
-
-    if (tr.has_prev && np != 0) {                               // CFO from pilot phase differences
-        const int valid = cfo_hits;
-        if (valid > 0) {
-            const c32 avg = cdivf(mk(s_ur, s_ui), (float)valid);
-            const float apd = um::atan2f_(avg.im, avg.re);
-            tr.ppc = cexpj(-apd);
-            const float residual = (float)((double)apd / D.two_pi_symbol_duration);
-            const float total = tr.freq_offset_hz + residual;
-            float a = 0.3f;
-            if (tr.symbols_since_sync < 10) {
-                const float progress = (float)tr.symbols_since_sync / 10;
-                a = 0.9f * (1.0f - progress) + 0.3f * progress;
-            }
-            if (fabsf(residual) > 10.0f) a = fmax_std(a, 0.9f);
-            tr.symbols_since_sync++;
-            tr.freq_offset_filtered = a * total + (1.0f - a) * tr.freq_offset_filtered;
-            tr.freq_offset_hz = fmax_std(-90.0f, fmin_std(90.0f, tr.freq_offset_filtered));
-        }
-    } else {
-        tr.ppc = mk(1.0f, 0.0f);
-    }
-
-    if (tr.snr_symbol_count >= 3) {                             // timing from the pilot phase slope
-        const int tv = tim_hits;
-        if (tv >= 3) {
-            const float n = (float)tv;
-            const float denom = n * sum_k2 - sum_k * sum_k;
-            if (fabsf(denom) > 1e-6f) {
-                const float slope = (n * sum_k_phase - sum_k * sum_phase) / denom;
-                const float inst = (float)((double)(slope * D.fft_f) / kTwoPi);
-                tr.timing = 0.3f * inst + (1.0f - 0.3f) * tr.timing;
-                tr.timing = fmax_std(-D.max_timing, fmin_std(D.max_timing, tr.timing));
-            }
-        }
-    }
-    if (is_pilot) prev = h;
-    tr.has_prev = (np != 0);
-
-    // coherent timing fix around the interpolation (:514-567)
     const bool fix = !D.differential && fabsf(tr.timing) > 0.1f;
-    if (fix && is_pilot) {
-        const float tp = timing_phase_of(lc.pilot_k, tr.timing, D.log2_fft);
-        sh.H[lc.pilot_slot] = cmul(sh.H[lc.pilot_slot], cexpj(-tp));
-    }
-    wave_sync();
     interpolate_channel(sh, D, lc);
     wave_sync();
-    if (fix && lane < D.n_carriers) {       // pilots then data carriers: every used slot exactly once
+    if (fix && lane < D.n_carriers) {
         const float tp = timing_phase_of(lc.slot_k, tr.timing, D.log2_fft);
         sh.H[lane] = cmul(sh.H[lane], cexpj(tp));
     }
-    if (noise_count > 1 && noise_power_sum > 0.0f) {            // (:583-592)
-        float nv = noise_power_sum / (float)(noise_count - 1);
-        if (nv < 1e-6f) nv = 1e-6f;
-        tr.noise_variance = nv;
-        float inst_snr = signal_power / nv;
-        inst_snr = fmax_std(0.1f, fmin_std(10000.0f, inst_snr));
-        tr.snr_linear = 0.3f * inst_snr + (1.0f - 0.3f) * tr.snr_linear;
-    }
-    tr.snr_symbol_count++;
     wave_sync();
+}
+
+// The pilot half of updateChannelEstimate (channel_equalizer.cpp:330-513,583-592) for 64 / G frames per
+// wavefront: G lanes per frame (G >= number of pilots), lane `sub` of a group owns pilot `sub`, and every lane
+// carries its frame's tracker scalars.  Everything here is work on <= G pilots or on per-frame scalars — in the
+// one-frame-per-wavefront layout it kept 15 of 64 lanes busy for half of the instructions of a symbol.  Every
+// serial sum of the reference keeps its order; the record in HBM carries the result to track_kernel, which
+// interpolates, equalises and demaps.
+template <int G>
+__global__ __launch_bounds__(kWave, 5) void track_pilot_kernel(const DemodConst* __restrict__ Dp, int n_frames,
+                                                               float* __restrict__ state, const c32* __restrict__ fq_all) {
+    constexpr int FPW = kWave / G;
+    constexpr int kRow = G * 8 + 8;                            // floats per group: 8 terms per pilot, padded (banks)
+    __shared__ __attribute__((aligned(16))) float s_terms[FPW][kRow];   // also the staging of the carrier-phase sum
+    __shared__ __attribute__((aligned(16))) float s_sums[FPW][8];
+    const DemodConst& D = *Dp;
+    const int lane = threadIdx.x, sub = lane % G, grp = lane / G;
+    const int N = D.fft, np = D.n_pilot;
+    const bool is_pilot = sub < np;
+    auto fq_of = [&](int bin) { return (bin < 64) ? bin : 64 + (bin - (N - 64)); };
+    const int ps = is_pilot ? D.pilot_slot[sub] : 0;
+    const int pilot_fq = fq_of(D.bin[ps]), pilot_k = D.k_of[ps];
+    const c32 pilot_seq = is_pilot ? D.pilot_seq[sub] : mk(1.0f, 0.0f);
+    const unsigned long long gmask = (G == 64) ? ~0ull : ((1ull << G) - 1ull);
+    for (int base = blockIdx.x * FPW; base < n_frames; base += gridDim.x * FPW) {
+        const bool act = base + grp < n_frames;
+        const int frame = act ? base + grp : n_frames - 1;     // idle groups shadow the last frame, stores masked
+        float* st = state + (size_t)frame * kStFloats;
+        const c32* fq = fq_all + (size_t)frame * 128;
+        Track tr;
+        tr.freq_offset_hz = st[st_cfo]; tr.freq_offset_filtered = st[st_cfo_filt]; tr.cfo_phase = st[st_cfo_phase];
+        tr.noise_variance = st[st_noise]; tr.snr_linear = st[st_snr]; tr.timing = st[st_timing];
+        tr.ppc = mk(st[st_ppc_re], st[st_ppc_im]); tr.cpc = mk(st[st_cpc_re], st[st_cpc_im]);
+        const int flags = (int)st[st_flags];
+        tr.cpc_init = flags & 1; tr.has_prev = (flags >> 1) & 1; tr.has_dprev = (flags >> 2) & 1;
+        tr.snr_symbol_count = (int)st[st_count]; tr.symbols_since_sync = (int)st[st_since];
+        const c32 h_old = is_pilot ? reinterpret_cast<const c32*>(st + kStH)[ps] : mk(0.0f, 0.0f);
+        const c32 prev = is_pilot ? reinterpret_cast<const c32*>(st + kStPrev)[sub] : mk(0.0f, 0.0f);
+        const float alpha = (tr.snr_symbol_count == 0) ? 1.0f : 0.9f;
+
+        c32 h = mk(0.0f, 0.0f);
+        if (is_pilot) h = cdiv_pilot(fq[pilot_fq], pilot_seq);
+        if (np != 0 && __any(!tr.cpc_init)) {                  // carrier phase recovery (:348-357)
+            c32* cb = reinterpret_cast<c32*>(&s_terms[grp][0]);
+            wave_sync();
+            cb[sub] = h;
+            wave_sync();
+            c32 h_sum = mk(0.0f, 0.0f);
+            for (int i = 0; i < np; ++i) h_sum = cadd(h_sum, cb[i]);
+            if (!tr.cpc_init) {
+                const c32 h_avg = cdivf(h_sum, (float)np);
+                const float avg_mag = cabs_(h_avg);
+                if (avg_mag > 0.01f) { tr.cpc = cdivf(cconj(h_avg), avg_mag); tr.cpc_init = 1; }
+            }
+        }
+        h = cmul(h, tr.cpc);
+        const float n2 = cnorm(h);
+
+        float nd = 0.0f, ph = 0.0f;
+        c32 unit = mk(0.0f, 0.0f);
+        bool f_noise = false, f_cfo = false, f_tim = false;
+        c32 h_new = h_old;
+        if (is_pilot) {
+            if (tr.has_prev) {
+                const float pn = cnorm(prev);
+                if (pn > 1e-6f && n2 > 1e-6f) {
+                    nd = cnorm(csub(h, prev));
+                    f_noise = true;
+                    const c32 diff = cmul(h, cconj(prev));
+                    const float mag = cabs_(diff);
+                    if (mag > 1e-6f) { unit = cdivf(diff, mag); f_cfo = true; }
+                }
+            }
+            if (tr.snr_symbol_count >= 3 && !(n2 < 1e-6f)) { ph = carg_(h); f_tim = true; }
+            h_new = cadd(cscale(h, alpha), cscale(h_old, 1.0f - alpha));
+        }
+        const int shift = grp * G;
+        const int noise_hits = __popcll((__ballot(f_noise) >> shift) & gmask),
+                  cfo_hits = __popcll((__ballot(f_cfo) >> shift) & gmask),
+                  tim_hits = __popcll((__ballot(f_tim) >> shift) & gmask);
+        wave_sync();
+        if (is_pilot) {
+            const float kf = (float)pilot_k;
+            float4 ta, tb;
+            ta.x = n2;
+            ta.y = f_noise ? nd : -0.0f;
+            ta.z = f_cfo ? unit.re : -0.0f;
+            ta.w = f_cfo ? unit.im : -0.0f;
+            tb.x = f_tim ? kf : -0.0f;
+            tb.y = f_tim ? (float)(pilot_k * pilot_k) : -0.0f;
+            tb.z = f_tim ? ph : -0.0f;
+            tb.w = f_tim ? kf * ph : -0.0f;
+            *reinterpret_cast<float4*>(&s_terms[grp][sub * 8]) = ta;
+            *reinterpret_cast<float4*>(&s_terms[grp][sub * 8 + 4]) = tb;
+        }
+        wave_sync();
+        if (sub < 8) {                                         // the eight serial sums, one lane each, pilot order
+            float acc = 0.0f;
+            for (int i = 0; i < np; ++i) acc += s_terms[grp][i * 8 + sub];
+            s_sums[grp][sub] = acc;
+        }
+        wave_sync();
+        const float4 sa = *reinterpret_cast<const float4*>(&s_sums[grp][0]);
+        const float4 sb = *reinterpret_cast<const float4*>(&s_sums[grp][4]);
+        const float s_sig = sa.x, s_nd = sa.y, s_ur = sa.z, s_ui = sa.w, sum_k = sb.x, sum_k2 = sb.y, sum_phase = sb.z,
+                    sum_k_phase = sb.w;
+        const float signal_power = s_sig / (float)np;                   // NaN when np == 0 (reference quirk)
+        int noise_count = noise_hits;
+        float noise_power_sum = s_nd;
+        if (noise_count == 0) { noise_power_sum = signal_power / 31.6f; noise_count = 1; }
+
+        if (tr.has_prev && np != 0) {                               // CFO from pilot phase differences
+            const int valid = cfo_hits;
+            if (valid > 0) {
+                const c32 avg = cdivf(mk(s_ur, s_ui), (float)valid);
+                const float apd = um::atan2f_(avg.im, avg.re);
+                tr.ppc = cexpj(-apd);
+                const float residual = (float)((double)apd / D.two_pi_symbol_duration);
+                const float total = tr.freq_offset_hz + residual;
+                float a = 0.3f;
+                if (tr.symbols_since_sync < 10) {
+                    const float progress = (float)tr.symbols_since_sync / 10;
+                    a = 0.9f * (1.0f - progress) + 0.3f * progress;
+                }
+                if (fabsf(residual) > 10.0f) a = fmax_std(a, 0.9f);
+                tr.symbols_since_sync++;
+                tr.freq_offset_filtered = a * total + (1.0f - a) * tr.freq_offset_filtered;
+                tr.freq_offset_hz = fmax_std(-90.0f, fmin_std(90.0f, tr.freq_offset_filtered));
+            }
+        } else {
+            tr.ppc = mk(1.0f, 0.0f);
+        }
+
+        if (tr.snr_symbol_count >= 3) {                             // timing from the pilot phase slope
+            const int tv = tim_hits;
+            if (tv >= 3) {
+                const float n = (float)tv;
+                const float denom = n * sum_k2 - sum_k * sum_k;
+                if (fabsf(denom) > 1e-6f) {
+                    const float slope = (n * sum_k_phase - sum_k * sum_phase) / denom;
+                    const float inst = (float)((double)(slope * D.fft_f) / kTwoPi);
+                    tr.timing = 0.3f * inst + (1.0f - 0.3f) * tr.timing;
+                    tr.timing = fmax_std(-D.max_timing, fmin_std(D.max_timing, tr.timing));
+                }
+            }
+        }
+        tr.has_prev = (np != 0);
+
+        // coherent timing fix: the pilots are de-rotated before the interpolation (:514-530)
+        const bool fix = !D.differential && fabsf(tr.timing) > 0.1f;
+        if (fix && is_pilot) h_new = cmul(h_new, cexpj(-timing_phase_of(pilot_k, tr.timing, D.log2_fft)));
+        if (noise_count > 1 && noise_power_sum > 0.0f) {            // (:583-592)
+            float nv = noise_power_sum / (float)(noise_count - 1);
+            if (nv < 1e-6f) nv = 1e-6f;
+            tr.noise_variance = nv;
+            float inst_snr = signal_power / nv;
+            inst_snr = fmax_std(0.1f, fmin_std(10000.0f, inst_snr));
+            tr.snr_linear = 0.3f * inst_snr + (1.0f - 0.3f) * tr.snr_linear;
+        }
+        tr.snr_symbol_count++;
+
+        if (act) {
+            if (is_pilot) {
+                reinterpret_cast<c32*>(st + kStH)[ps] = h_new;
+                reinterpret_cast<c32*>(st + kStPrev)[sub] = h;
+            }
+            if (sub == 0) {
+                st[st_cfo] = tr.freq_offset_hz; st[st_cfo_filt] = tr.freq_offset_filtered;
+                st[st_noise] = tr.noise_variance; st[st_snr] = tr.snr_linear; st[st_timing] = tr.timing;
+                st[st_ppc_re] = tr.ppc.re; st[st_ppc_im] = tr.ppc.im; st[st_cpc_re] = tr.cpc.re; st[st_cpc_im] = tr.cpc.im;
+                st[st_flags] = (float)(tr.cpc_init | (tr.has_prev << 1) | (tr.has_dprev << 2));
+                st[st_count] = (float)tr.snr_symbol_count; st[st_since] = (float)tr.symbols_since_sync;
+            }
+        }
+    }
 }
 
 // one carrier's LLRs (soft_demap.hpp), stored to out[0..bits)
@@ -821,61 +874,89 @@ __global__ __launch_bounds__(kWave, 3) void mix_fft_kernel(
 
 // mode 0: data symbol (updateChannelEstimate + equalize + demodulateSymbol)
 // mode 1: training symbol `sym` of n_train (estimateChannelFromLTS), finishing on the last one
-template <int MOD>
-__global__ __launch_bounds__(kWave, 4) void track_kernel(
-    const DemodConst* __restrict__ Dp, int n_frames, int mode, int sym, int data_sym, float* __restrict__ state,
-    const c32* __restrict__ fq_all, float* __restrict__ llr, size_t llr_stride, float* __restrict__ state_out) {
+__device__ __forceinline__ void load_track(const float* __restrict__ st, Track& tr) {
+    tr.freq_offset_hz = st[st_cfo]; tr.freq_offset_filtered = st[st_cfo_filt]; tr.cfo_phase = st[st_cfo_phase];
+    tr.noise_variance = st[st_noise]; tr.snr_linear = st[st_snr]; tr.timing = st[st_timing];
+    tr.ppc = mk(st[st_ppc_re], st[st_ppc_im]); tr.cpc = mk(st[st_cpc_re], st[st_cpc_im]);
+    const int flags = (int)st[st_flags];
+    tr.cpc_init = flags & 1; tr.has_prev = (flags >> 1) & 1; tr.has_dprev = (flags >> 2) & 1;
+    tr.snr_symbol_count = (int)st[st_count]; tr.symbols_since_sync = (int)st[st_since];
+}
+__device__ __forceinline__ void store_track(float* __restrict__ st, const Track& tr) {
+    st[st_cfo] = tr.freq_offset_hz; st[st_cfo_filt] = tr.freq_offset_filtered;
+    st[st_noise] = tr.noise_variance; st[st_snr] = tr.snr_linear; st[st_timing] = tr.timing;
+    st[st_ppc_re] = tr.ppc.re; st[st_ppc_im] = tr.ppc.im; st[st_cpc_re] = tr.cpc.re; st[st_cpc_im] = tr.cpc.im;
+    st[st_flags] = (float)(tr.cpc_init | (tr.has_prev << 1) | (tr.has_dprev << 2));
+    st[st_count] = (float)tr.snr_symbol_count; st[st_since] = (float)tr.symbols_since_sync;
+}
+__device__ __forceinline__ LaneConst lane_constants(const DemodConst& D) {
+    const int lane = threadIdx.x, N = D.fft;
+    LaneConst lc;
+    auto fq_of = [&](int bin) { return (bin < 64) ? bin : 64 + (bin - (N - 64)); };
+    const int ps = (lane < D.n_pilot) ? D.pilot_slot[lane] : 0;
+    lc.pilot_slot = ps; lc.pilot_fq = fq_of(D.bin[ps]); lc.pilot_k = D.k_of[ps];
+    lc.pilot_seq = (lane < D.n_pilot) ? D.pilot_seq[lane] : mk(1.0f, 0.0f);
+    const int dsl = (lane < D.n_data) ? D.data_slot[lane] : 0;
+    lc.data_slot = dsl; lc.data_fq = fq_of(D.bin[dsl]); lc.data_k = D.k_of[dsl];
+    const int q = (lane < D.n_interp) ? lane : 0;
+    lc.i_dst = D.interp_slot[q]; lc.i_lo = D.interp_lo[q]; lc.i_hi = D.interp_hi[q]; lc.i_alpha = D.interp_alpha[q];
+    lc.slot_k = D.k_of[(lane < D.n_carriers) ? lane : 0];
+    lc.zc = D.sync_seq[lane % D.n_carriers];
+    return lc;
+}
+
+// Training symbol `sym` of the presynced entry (estimateChannelFromLTS): one wavefront per frame
+__global__ __launch_bounds__(kWave, 4) void train_kernel(const DemodConst* __restrict__ Dp, int n_frames, int sym,
+                                                         float* __restrict__ state, const c32* __restrict__ fq_all) {
     __shared__ TrackShared sh;
     const DemodConst& D = *Dp;
     const int lane = threadIdx.x;
-    const int N = D.fft;
-    LaneConst lc;
-    {
-        auto fq_of = [&](int bin) { return (bin < 64) ? bin : 64 + (bin - (N - 64)); };
-        const int ps = (lane < D.n_pilot) ? D.pilot_slot[lane] : 0;
-        lc.pilot_slot = ps; lc.pilot_fq = fq_of(D.bin[ps]); lc.pilot_k = D.k_of[ps];
-        lc.pilot_seq = (lane < D.n_pilot) ? D.pilot_seq[lane] : mk(1.0f, 0.0f);
-        const int dsl = (lane < D.n_data) ? D.data_slot[lane] : 0;
-        lc.data_slot = dsl; lc.data_fq = fq_of(D.bin[dsl]); lc.data_k = D.k_of[dsl];
-        const int q = (lane < D.n_interp) ? lane : 0;
-        lc.i_dst = D.interp_slot[q]; lc.i_lo = D.interp_lo[q]; lc.i_hi = D.interp_hi[q]; lc.i_alpha = D.interp_alpha[q];
-        lc.slot_k = D.k_of[(lane < D.n_carriers) ? lane : 0];
-        lc.zc = D.sync_seq[lane % D.n_carriers];
-    }
+    const LaneConst lc = lane_constants(D);
     for (int frame = blockIdx.x; frame < n_frames; frame += gridDim.x) {
         float* st = state + (size_t)frame * kStFloats;
         const c32* fq = fq_all + (size_t)frame * 128;
         Track tr;
-        tr.freq_offset_hz = st[st_cfo]; tr.freq_offset_filtered = st[st_cfo_filt]; tr.cfo_phase = st[st_cfo_phase];
-        tr.noise_variance = st[st_noise]; tr.snr_linear = st[st_snr]; tr.timing = st[st_timing];
-        tr.ppc = mk(st[st_ppc_re], st[st_ppc_im]); tr.cpc = mk(st[st_cpc_re], st[st_cpc_im]);
-        const int flags = (int)st[st_flags];
-        tr.cpc_init = flags & 1; tr.has_prev = (flags >> 1) & 1; tr.has_dprev = (flags >> 2) & 1;
-        tr.snr_symbol_count = (int)st[st_count]; tr.symbols_since_sync = (int)st[st_since];
+        load_track(st, tr);
         sh.H[lane] = reinterpret_cast<const c32*>(st + kStH)[lane];
-        c32 prev = (lane < D.n_pilot) ? reinterpret_cast<const c32*>(st + kStPrev)[lane] : mk(0.0f, 0.0f);
+        wave_sync();
+        c32 lts_acc = (sym > 0 && lane < D.n_pilot) ? reinterpret_cast<const c32*>(st + kStLts)[lane] : mk(0.0f, 0.0f);
+        lts_symbol(sh, D, lc, sym, D.n_train, lts_acc, fq);
+        if (sym == D.n_train - 1) lts_finish(sh, D, lc, tr, D.n_train, lts_acc);
+        else if (lane < D.n_pilot) reinterpret_cast<c32*>(st + kStLts)[lane] = lts_acc;
+        wave_sync();
+        reinterpret_cast<c32*>(st + kStH)[lane] = sh.H[lane];
+        if (lane == 0) store_track(st, tr);
+        wave_sync();
+    }
+}
+
+// Data symbol, carrier half: the pilot half of updateChannelEstimate already ran in track_pilot_kernel; here
+// the interpolation between the pilots, the equaliser and the demapper — one wavefront per frame, one lane per
+// carrier.
+template <int MOD>
+__global__ __launch_bounds__(kWave, 6) void track_kernel(
+    const DemodConst* __restrict__ Dp, int n_frames, int data_sym, float* __restrict__ state,
+    const c32* __restrict__ fq_all, float* __restrict__ llr, size_t llr_stride, float* __restrict__ state_out) {
+    __shared__ TrackShared sh;
+    const DemodConst& D = *Dp;
+    const int lane = threadIdx.x;
+    const LaneConst lc = lane_constants(D);
+    for (int frame = blockIdx.x; frame < n_frames; frame += gridDim.x) {
+        float* st = state + (size_t)frame * kStFloats;
+        const c32* fq = fq_all + (size_t)frame * 128;
+        Track tr;
+        load_track(st, tr);
+        sh.H[lane] = reinterpret_cast<const c32*>(st + kStH)[lane];
         c32 dprev = D.differential ? reinterpret_cast<const c32*>(st + kStDprev)[lane] : mk(1.0f, 0.0f);
         wave_sync();
-        if (mode == 1) {
-            c32 lts_acc = (sym > 0 && lane < D.n_pilot) ? reinterpret_cast<const c32*>(st + kStLts)[lane] : mk(0.0f, 0.0f);
-            lts_symbol(sh, D, lc, sym, D.n_train, lts_acc, fq);
-            if (sym == D.n_train - 1) lts_finish(sh, D, lc, tr, D.n_train, lts_acc);
-            else if (lane < D.n_pilot) reinterpret_cast<c32*>(st + kStLts)[lane] = lts_acc;
-        } else {
-            if (!D.presynced || D.n_pilot != 0) update_channel_estimate(sh, D, lc, tr, prev, fq);
-            equalize_demap<MOD>(sh, D, lc, tr, dprev, fq, llr + (size_t)frame * llr_stride + (size_t)data_sym * D.llrs_per_symbol);
-        }
+        if (!D.presynced || D.n_pilot != 0) finish_channel_estimate(sh, D, lc, tr);
+        equalize_demap<MOD>(sh, D, lc, tr, dprev, fq, llr + (size_t)frame * llr_stride + (size_t)data_sym * D.llrs_per_symbol);
         wave_sync();
         // write the record back
         reinterpret_cast<c32*>(st + kStH)[lane] = sh.H[lane];
-        if (lane < D.n_pilot) reinterpret_cast<c32*>(st + kStPrev)[lane] = prev;
         if (D.differential) reinterpret_cast<c32*>(st + kStDprev)[lane] = dprev;
         if (lane == 0) {
-            st[st_cfo] = tr.freq_offset_hz; st[st_cfo_filt] = tr.freq_offset_filtered;
-            st[st_noise] = tr.noise_variance; st[st_snr] = tr.snr_linear; st[st_timing] = tr.timing;
-            st[st_ppc_re] = tr.ppc.re; st[st_ppc_im] = tr.ppc.im; st[st_cpc_re] = tr.cpc.re; st[st_cpc_im] = tr.cpc.im;
-            st[st_flags] = (float)(tr.cpc_init | (tr.has_prev << 1) | (tr.has_dprev << 2));
-            st[st_count] = (float)tr.snr_symbol_count; st[st_since] = (float)tr.symbols_since_sync;
+            store_track(st, tr);
             if (state_out) {
                 float* so = state_out + (size_t)frame * ULTRA_HIP_STATE_FLOATS;
                 so[ULTRA_HIP_STATE_FREQ_OFFSET_HZ] = tr.freq_offset_hz;

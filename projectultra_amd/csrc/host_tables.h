@@ -79,6 +79,8 @@ inline int validate_config(const ultra_hip_config& c) {
     if (c.num_carriers == 0 || c.num_carriers > (uint32_t)kMaxCarriers) return ULTRA_HIP_ERR_UNSUPPORTED;
     if (c.num_carriers + 1 >= c.fft_size) return ULTRA_HIP_ERR_INVALID_ARG;
     if (c.pilot_spacing == 0 || c.sample_rate == 0) return ULTRA_HIP_ERR_INVALID_ARG;
+    // every carrier a pilot: no data carriers, nothing to demodulate (and track_pilot_kernel holds <= 32 pilots)
+    if (c.use_pilots && c.pilot_spacing == 1) return ULTRA_HIP_ERR_UNSUPPORTED;
     if (c.cp_mode > ULTRA_CP_LONG || c.use_pilots > 1) return ULTRA_HIP_ERR_INVALID_ARG;
     if (!known_modulation(c.modulation)) return ULTRA_HIP_ERR_INVALID_ARG;
     // QAM8 has no mapper/demapper of its own in the reference (falls through to QPSK with a

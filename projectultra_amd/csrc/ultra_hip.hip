@@ -160,10 +160,30 @@ int launch_demod(ultra_hip_ctx* ctx, const float* d_audio, size_t frame_stride, 
         }
         const bool training = s < D.n_train;
         const bool last = (s == n_sym - 1);
+        if (training) {
+            LaunchSpan span(ctx, ULTRA_HIP_K_TRACK);
+            hipLaunchKernelGGL(dev::train_kernel, dim3(grid_trk), dim3(dev::kWave), 0, st, ctx->d_demod, (int)n_frames, s,
+                               ctx->d_ws_state, ctx->d_ws_fq);
+            continue;
+        }
+        // Data symbols: the pilot half of the channel update runs 4 (<= 16 pilots) or 2 (<= 32: every usable
+        // configuration, validate_config) frames per wavefront in its own kernel, the carrier half + equalise
+        // + demap one frame per wavefront.
+        if (!D.presynced || D.n_pilot != 0) {
+            LaunchSpan span(ctx, ULTRA_HIP_K_PILOT);
+            if (D.n_pilot <= 16) {
+                const unsigned g = (unsigned)std::min((n_frames + 3) / 4, (size_t)ctx->cu_count * 64);
+                hipLaunchKernelGGL(dev::track_pilot_kernel<16>, dim3(g), dim3(dev::kWave), 0, st, ctx->d_demod, (int)n_frames,
+                                   ctx->d_ws_state, ctx->d_ws_fq);
+            } else {
+                const unsigned g = (unsigned)std::min((n_frames + 1) / 2, (size_t)ctx->cu_count * 64);
+                hipLaunchKernelGGL(dev::track_pilot_kernel<32>, dim3(g), dim3(dev::kWave), 0, st, ctx->d_demod, (int)n_frames,
+                                   ctx->d_ws_state, ctx->d_ws_fq);
+            }
+        }
 #define UH_TRACK(MOD)                                                                                            \
     hipLaunchKernelGGL(dev::track_kernel<MOD>, dim3(grid_trk), dim3(dev::kWave), 0, st, ctx->d_demod, (int)n_frames,  \
-                       training ? 1 : 0, s, training ? 0 : s - D.n_train, ctx->d_ws_state, ctx->d_ws_fq, d_llr,       \
-                       llr_stride, last ? d_state : nullptr)
+                       s - D.n_train, ctx->d_ws_state, ctx->d_ws_fq, d_llr, llr_stride, last ? d_state : nullptr)
         LaunchSpan span(ctx, ULTRA_HIP_K_TRACK);
         switch (D.modulation) {
             case ULTRA_MOD_DBPSK: UH_TRACK(ULTRA_MOD_DBPSK); break;
