@@ -73,6 +73,12 @@ def main():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group(backend="nccl", rank=rank, world_size=world)   # "nccl" IS RCCL on ROCm
 
+    # the checker library is (re)built by one rank only: concurrent `make`s of N ranks would race on the .so
+    from oracle.bindings import build_oracle
+    if local_rank == 0:
+        build_oracle()
+    if world > 1:
+        dist.barrier()
     from oracle.bindings import geometry, have_ref, make_config, oracle, Ref
     from projectultra_amd import CodeRate, Modulation, ReceiveContext, presets
     from projectultra_amd.montecarlo import allreduce_counters, counters_dict, shard_range

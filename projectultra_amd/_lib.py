@@ -89,8 +89,7 @@ _LIB = None
 
 def build(force: bool = False) -> Path:
     """Compile libultra_hip.so for gfx950 in-tree (hipcc cross-compiles without a GPU)."""
-    srcs = [CSRC_DIR / n for n in ("ultra_hip.hip", "demod_kernel.h", "ldpc_kernel.h", "pinned_math.h", "phase_table.h",
-                                   "host_tables.h", "device_types.h")] + [PKG_DIR.parent / "include" / "ultra_hip.h"]
+    srcs = [CSRC_DIR / "ultra_hip.hip"] + sorted(CSRC_DIR.glob("*.h")) + [PKG_DIR.parent / "include" / "ultra_hip.h"]
     stale = (not LIB_PATH.exists()) or any(s.stat().st_mtime > LIB_PATH.stat().st_mtime for s in srcs)
     if force or stale:
         subprocess.check_call(["make", "-C", str(CSRC_DIR)] + (["-B"] if force else []))
