@@ -238,6 +238,12 @@ int ultra_hip_count_errors(ultra_hip_ctx* ctx, const uint8_t* d_bytes, const int
                            const uint8_t* d_ok, const uint8_t* d_payload, size_t payload_bytes,
                            size_t n_frames, ultra_hip_counters* d_counters);
 
+/* The one collective of the path: sum the eight Monte-Carlo counters over the ranks of an
+ * RCCL communicator, in place, on the context's stream.  rccl_comm is the host's ncclComm_t (one process
+ * per GPU, created with ncclCommInitRank; torch.distributed users call dist.all_reduce on the tensor
+ * instead).  RCCL is bound with dlopen at first use; ULTRA_HIP_ERR_UNSUPPORTED if it cannot be loaded. */
+int ultra_hip_counters_allreduce(ultra_hip_ctx* ctx, void* rccl_comm, ultra_hip_counters* d_counters);
+
 /* Block the host until everything queued on the context's stream is done. */
 int ultra_hip_synchronize(ultra_hip_ctx* ctx);
 

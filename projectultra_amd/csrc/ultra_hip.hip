@@ -7,6 +7,7 @@
 // CPU fallback exists: every entry point either runs the HIP path or fails.
 #include <hip/hip_runtime.h>
 
+#include <dlfcn.h>
 #include <cstdio>
 #include <cstring>
 #include <new>
@@ -751,6 +752,30 @@ int ultra_hip_profile_read(ultra_hip_ctx* ctx, float* ms, uint32_t* launches) {
     }
     ctx->spans.clear();
     return ULTRA_HIP_OK;
+}
+
+// RCCL is bound at first use (dlopen): single-GPU users never load it, and the library has no link-time
+// dependency on a collective runtime.
+namespace {
+typedef int (*rccl_allreduce_fn)(const void*, void*, size_t, int, int, void*, hipStream_t);
+rccl_allreduce_fn rccl_allreduce() {
+    static rccl_allreduce_fn fn = []() -> rccl_allreduce_fn {
+        void* h = dlopen("librccl.so.1", RTLD_NOW | RTLD_GLOBAL);
+        if (!h) h = dlopen("librccl.so", RTLD_NOW | RTLD_GLOBAL);
+        return h ? reinterpret_cast<rccl_allreduce_fn>(dlsym(h, "ncclAllReduce")) : nullptr;
+    }();
+    return fn;
+}
+}  // namespace
+
+int ultra_hip_counters_allreduce(ultra_hip_ctx* ctx, void* rccl_comm, ultra_hip_counters* d_counters) {
+    if (!ctx || !rccl_comm || !d_counters) return ULTRA_HIP_ERR_INVALID_ARG;
+    rccl_allreduce_fn fn = rccl_allreduce();
+    if (!fn) return ULTRA_HIP_ERR_UNSUPPORTED;
+    DeviceGuard guard(ctx->device);
+    // ncclAllReduce(send, recv, count, ncclUint64 = 5, ncclSum = 0, comm, stream), in place
+    const int rc = fn(d_counters, d_counters, sizeof(ultra_hip_counters) / sizeof(uint64_t), 5, 0, rccl_comm, ctx->stream);
+    return rc == 0 ? ULTRA_HIP_OK : ULTRA_HIP_ERR_HIP;
 }
 
 int ultra_hip_synchronize(ultra_hip_ctx* ctx) {

@@ -167,3 +167,35 @@ def test_full_size_round_trip_property(oracle):
     assert c[4] == int((ook == 0).sum()) * reps and c[5] == int(oi.sum()) * reps
     clean = np.arange(n_unique) % 4 == 0         # sigma 0.8 -> Es/N0 ~ 1.9 dB: R1/4 decodes
     assert ook[clean].mean() > 0.99
+
+
+def test_counters_allreduce_over_rccl():
+    """ultra_hip_counters_allreduce on a one-rank RCCL communicator created by the host (ncclCommInitRank through
+    ctypes): the plumbing a C++ Monte-Carlo harness uses for the single collective of the path.
+    One rank: the sum is the identity; the multi-rank reduction itself is covered on CPU with gloo."""
+    import ctypes as C
+    import torch
+    from projectultra_amd import CodeRate, LDPCDecoder
+    try:
+        rccl = C.CDLL("librccl.so.1")
+    except OSError:
+        pytest.skip("librccl.so.1 not loadable")
+    uid = (C.c_char * 128)()
+    assert rccl.ncclGetUniqueId(uid) == 0
+
+    class Uid(C.Structure):
+        _fields_ = [("internal", C.c_char * 128)]
+    u = Uid(); C.memmove(C.byref(u), uid, 128)
+    comm = C.c_void_p()
+    rccl.ncclCommInitRank.argtypes = [C.POINTER(C.c_void_p), C.c_int, Uid, C.c_int]
+    torch.cuda.set_device(0)
+    assert rccl.ncclCommInitRank(C.byref(comm), 1, u, 0) == 0
+    ctx = LDPCDecoder(CodeRate.R1_2).context
+    counters = torch.arange(1, 9, dtype=torch.int64, device="cuda") * 1000003
+    want = counters.clone()
+    from projectultra_amd._lib import check
+    check(ctx.lib.ultra_hip_counters_allreduce(ctx._ctx, comm, counters.data_ptr()), "ultra_hip_counters_allreduce")
+    ctx.synchronize()
+    assert torch.equal(counters, want)
+    rccl.ncclCommDestroy.argtypes = [C.c_void_p]
+    rccl.ncclCommDestroy(comm)
