@@ -163,12 +163,12 @@ def main():
     # Algorithmic bytes per launch = SURVEY.md 8(d)'s per-frame figure (20,581 B = 4 x 4480 audio + 4
     # + 4 x 648 LLR + 61 + 4) apportioned to the launch that moves them, x the frames of one launch:
     #   mix_fft_kernel  one OFDM symbol of audio in            4480 B/frame/launch
-    #   track_pilot_kernel  works on the per-frame records between the kernels only   0 B/frame/launch
+    #   cfo_walk_kernel, track_pilot_kernel  work on the per-frame records between the kernels only   0 B/frame/launch
     #   track_kernel    that symbol's share of the 648 LLRs     648 B/frame/launch
     #   ldpc_decode     648 LLRs in, 61 bytes + iters + ok out 2658 B/frame/launch
     roofline = None
     if rank == 0:
-        per_launch = {"mix_fft_kernel": geo.symbol_samples * 4, "track_pilot_kernel": 0, "track_kernel": 648,
+        per_launch = {"cfo_walk_kernel": 0, "mix_fft_kernel": geo.symbol_samples * 4, "track_pilot_kernel": 0, "track_kernel": 648,
                       "ldpc_decode_kernel": BYTES_PER_CW_LDPC}
         traffic_all = {}
         tf = ROOT / "profiles" / "traffic.json"              # PMC-derived HBM bytes per launch, if collected

@@ -392,7 +392,8 @@ enum ultra_hip_kernel_class {
     ULTRA_HIP_K_ACQUIRE = 5,    /* acquire_kernel */
     ULTRA_HIP_K_CHIRP = 6,      /* chirp_sync_kernel */
     ULTRA_HIP_K_PILOT = 7,      /* track_pilot_kernel: pilot half of the channel update, one per data symbol */
-    ULTRA_HIP_K_N = 8
+    ULTRA_HIP_K_WALK = 8,       /* cfo_walk_kernel: phase table of the next symbol's CFO rotation, one per symbol */
+    ULTRA_HIP_K_N = 9
 };
 int ultra_hip_profile_enable(ultra_hip_ctx* ctx, int enable);
 int ultra_hip_profile_read(ultra_hip_ctx* ctx, float* ms, uint32_t* launches);

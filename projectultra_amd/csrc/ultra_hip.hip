@@ -62,6 +62,7 @@ struct ultra_hip_ctx {
     // demodulator workspace: per-frame tracker records + the used FFT bins of the symbol in flight
     float* d_ws_state = nullptr;
     c32* d_ws_fq = nullptr;
+    unsigned* d_ws_seg = nullptr;       // per-frame CFO phase tables (cfo_walk_kernel -> mix_fft_kernel)
     size_t ws_demod_frames = 0;
     hipEvent_t ev_begin = nullptr, ev_end = nullptr;
     int cu_count = 256;
@@ -127,9 +128,11 @@ int launch_demod(ultra_hip_ctx* ctx, const float* d_audio, size_t frame_stride, 
         UH_HIP(hipStreamSynchronize(ctx->stream));
         if (ctx->d_ws_state) { (void)hipFree(ctx->d_ws_state); ctx->d_ws_state = nullptr; }
         if (ctx->d_ws_fq) { (void)hipFree(ctx->d_ws_fq); ctx->d_ws_fq = nullptr; }
+        if (ctx->d_ws_seg) { (void)hipFree(ctx->d_ws_seg); ctx->d_ws_seg = nullptr; }
         ctx->ws_demod_frames = 0;
         UH_HIP(hipMalloc(&ctx->d_ws_state, n_frames * (size_t)dev::kStFloats * sizeof(float)));
         UH_HIP(hipMalloc(&ctx->d_ws_fq, n_frames * (size_t)128 * sizeof(c32)));
+        UH_HIP(hipMalloc(&ctx->d_ws_seg, n_frames * (size_t)dev::kSegTabWords * sizeof(unsigned)));
         ctx->ws_demod_frames = n_frames;
     }
     // one wavefront per frame in every kernel; grids are capped (grid-stride over frames) so a huge
@@ -149,15 +152,20 @@ int launch_demod(ultra_hip_ctx* ctx, const float* d_audio, size_t frame_stride, 
     for (int s = 0; s < n_sym; ++s) {
         if (D.log2_fft != 10 && D.log2_fft != 9) return ULTRA_HIP_ERR_UNSUPPORTED;
         {
+            LaunchSpan span(ctx, ULTRA_HIP_K_WALK);
+            hipLaunchKernelGGL(dev::cfo_walk_kernel, dim3((unsigned)((n_frames + 255) / 256)), dim3(256), 0, st, ctx->d_demod,
+                               (int)n_frames, ctx->d_ws_state, ctx->d_ws_seg);
+        }
+        {
             LaunchSpan span(ctx, ULTRA_HIP_K_MIX_FFT);
             if (D.log2_fft == 10)
                 hipLaunchKernelGGL(dev::mix_fft_kernel<10>, dim3(grid_fft), dim3(dev::kWave), 0, st, ctx->d_demod,
                                    ctx->d_nco, ctx->d_twiddle, d_audio, frame_stride, d_frame_offset, (int)n_frames, s,
-                                   ctx->d_ws_state, ctx->d_ws_fq);
+                                   ctx->d_ws_state, ctx->d_ws_fq, ctx->d_ws_seg);
             else
                 hipLaunchKernelGGL(dev::mix_fft_kernel<9>, dim3(grid_fft), dim3(dev::kWave), 0, st, ctx->d_demod,
                                    ctx->d_nco, ctx->d_twiddle, d_audio, frame_stride, d_frame_offset, (int)n_frames, s,
-                                   ctx->d_ws_state, ctx->d_ws_fq);
+                                   ctx->d_ws_state, ctx->d_ws_fq, ctx->d_ws_seg);
         }
         const bool training = s < D.n_train;
         const bool last = (s == n_sym - 1);
@@ -357,6 +365,7 @@ void ultra_hip_destroy(ultra_hip_ctx* ctx) {
     if (ctx->d_ws_llr) (void)hipFree(ctx->d_ws_llr);
     if (ctx->d_ws_state) (void)hipFree(ctx->d_ws_state);
     if (ctx->d_ws_fq) (void)hipFree(ctx->d_ws_fq);
+    if (ctx->d_ws_seg) (void)hipFree(ctx->d_ws_seg);
     if (ctx->ev_begin) (void)hipEventDestroy(ctx->ev_begin);
     if (ctx->ev_end) (void)hipEventDestroy(ctx->ev_end);
     delete ctx;

@@ -318,7 +318,7 @@ class ReceiveContext:
         check(self.lib.ultra_hip_set_deinterleave(self._ctx, int(bits_per_symbol)), "ultra_hip_set_deinterleave")
 
     KERNEL_CLASSES = ("init_state_kernel", "mix_fft_kernel", "track_kernel", "ldpc_decode_kernel", "count_errors_kernel",
-                      "acquire_kernel", "chirp_sync_kernel", "track_pilot_kernel")
+                      "acquire_kernel", "chirp_sync_kernel", "track_pilot_kernel", "cfo_walk_kernel")
 
     def profile_enable(self, on: bool = True):
         """Bracket every kernel launch of this context with HIP events (ultra_hip_profile_enable)."""
