@@ -302,6 +302,15 @@ __device__ __forceinline__ void symbol_to_freq(FftShared<LOG2N>& sh, const Demod
                 if (i0 >= 0 && ilast < covered && ilast < nstart) {          // the usual case: one segment
 #pragma unroll
                     for (int j = 0; j < P; ++j) ph[j] = um::phase_table_eval(cur, i0 + j);
+                } else if (i0 >= 0 && ilast < covered && ilast < sh.seg_start[sg + 2]) {
+                    // one boundary inside the window (every frame has a few such lanes): both segments, select
+                    const um::PhaseSeg nxt = sh.seg[sg + 1];
+#pragma unroll
+                    for (int j = 0; j < P; ++j) {
+                        const int i = i0 + j;
+                        const float a = um::phase_table_eval(cur, i), b = um::phase_table_eval(nxt, i);
+                        ph[j] = (i < nstart) ? a : b;
+                    }
                 } else {
 #pragma unroll
                     for (int j = 0; j < P; ++j) {
