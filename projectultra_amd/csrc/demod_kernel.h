@@ -79,6 +79,9 @@ __device__ __forceinline__ float cnorm(c32 a) { return a.re * a.re + a.im * a.im
 __device__ __forceinline__ float cabs_(c32 a) { return um::hypotf_(a.re, a.im); }
 __device__ __forceinline__ float carg_(c32 a) { return um::atan2f_(a.im, a.re); }
 __device__ __forceinline__ c32 cexpj(float t) { float sn, cs; um::sincosf_(t, &sn, &cs); return mk(cs, sn); }
+// the same values for |t| < 120 (or NaN), without the range branches of sincosf: the tracker's angles are an
+// atan2f result or a timing phase 2 pi k tau / N with |tau| <= 50 N / 512 (|t| < 20)
+__device__ __forceinline__ c32 cexpj_bounded(float t) { float sn, cs; um::sincosf_bounded_(t, &sn, &cs); return mk(cs, sn); }
 __device__ __forceinline__ float fmin_std(float a, float b) { return (b < a) ? b : a; }  // std::min(a, b)
 __device__ __forceinline__ float fmax_std(float a, float b) { return (a < b) ? b : a; }  // std::max(a, b)
 
@@ -444,7 +447,7 @@ __device__ __forceinline__ void finish_channel_estimate(TrackShared& sh, const D
     wave_sync();
     if (fix && lane < D.n_carriers) {
         const float tp = timing_phase_of(lc.slot_k, tr.timing, D.log2_fft);
-        sh.H[lane] = cmul(sh.H[lane], cexpj(tp));
+        sh.H[lane] = cmul(sh.H[lane], cexpj_bounded(tp));
     }
     wave_sync();
 }
@@ -563,7 +566,7 @@ __global__ __launch_bounds__(kWave, 5) void track_pilot_kernel(const DemodConst*
             if (valid > 0) {
                 const c32 avg = cdivf(mk(s_ur, s_ui), (float)valid);
                 const float apd = um::atan2f_(avg.im, avg.re);
-                tr.ppc = cexpj(-apd);
+                tr.ppc = cexpj_bounded(-apd);
                 const float residual = (float)((double)apd / D.two_pi_symbol_duration);
                 const float total = tr.freq_offset_hz + residual;
                 float a = 0.3f;
@@ -597,7 +600,7 @@ __global__ __launch_bounds__(kWave, 5) void track_pilot_kernel(const DemodConst*
 
         // coherent timing fix: the pilots are de-rotated before the interpolation (:514-530)
         const bool fix = !D.differential && fabsf(tr.timing) > 0.1f;
-        if (fix && is_pilot) h_new = cmul(h_new, cexpj(-timing_phase_of(pilot_k, tr.timing, D.log2_fft)));
+        if (fix && is_pilot) h_new = cmul(h_new, cexpj_bounded(-timing_phase_of(pilot_k, tr.timing, D.log2_fft)));
         if (noise_count > 1 && noise_power_sum > 0.0f) {            // (:583-592)
             float nv = noise_power_sum / (float)(noise_count - 1);
             if (nv < 1e-6f) nv = 1e-6f;
@@ -742,7 +745,7 @@ __device__ __forceinline__ void equalize_demap(TrackShared& sh, const DemodConst
         if (is_data) {
             const c32 received = fq[lc.data_fq], h = sh.H[lc.data_slot];
             const float h_power = cnorm(h);
-            const c32 tc = cexpj(timing_phase_of(lc.data_k, tr.timing, D.log2_fft));
+            const c32 tc = cexpj_bounded(timing_phase_of(lc.data_k, tr.timing, D.log2_fft));
             if (h_power > 1e-6f) {
                 const c32 t = cdivf(cmul(received, cconj(h)), h_power);
                 eq = cmul(cmul(t, tr.ppc), tc);
