@@ -104,7 +104,10 @@ def test_full_sync_equivalence(name):
 SYNTH = [("QAM16", "R3_4", 1024, {}, "watterson"), ("DQPSK", "R1_2", 512, {}, "awgn"),
          ("QAM32", "R3_4", 1024, {}, "watterson"), ("D8PSK", "R3_4", 1024, dict(pilot_spacing=2), "awgn"),
          ("QPSK", "R2_3", 512, {}, "watterson"), ("DBPSK", "R1_4", 512, {}, "awgn"),
-         ("QAM64", "R5_6", 512, {}, "awgn"), ("QAM16", "R1_2", 1024, dict(n_data_symbols=10), "watterson")]
+         ("QAM64", "R5_6", 512, {}, "awgn"), ("QAM16", "R1_2", 1024, dict(n_data_symbols=10), "watterson"),
+         # 30 pilots: the pilot kernel's two-frames-per-wavefront instance
+         ("QAM16", "R1_2", 1024, dict(pilot_spacing=2), "watterson"),
+         ("DQPSK", "R1_2", 1024, dict(pilot_spacing=2, use_pilots=1), "awgn")]
 
 
 @pytest.mark.parametrize("mod,rate,fft,kw,chan", SYNTH)
@@ -131,7 +134,8 @@ def test_synthetic_batch_vs_oracle(oracle, mod, rate, fft, kw, chan, snr):
 
 
 @pytest.mark.parametrize("mod,rate,fft,kw", [("QAM16", "R3_4", 1024, {}), ("DQPSK", "R1_2", 512, {}),
-                                             ("D8PSK", "R3_4", 1024, dict(pilot_spacing=2)), ("QPSK", "R1_2", 512, {})])
+                                             ("D8PSK", "R3_4", 1024, dict(pilot_spacing=2)), ("QPSK", "R1_2", 512, {}),
+                                             ("QAM16", "R1_2", 1024, dict(pilot_spacing=2))])
 def test_synthetic_presynced_vs_oracle(oracle, mod, rate, fft, kw):
     cfg = make_config(fft, mod, rate, entry=1, **kw)
     n = 96

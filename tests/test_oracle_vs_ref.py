@@ -52,7 +52,8 @@ def test_fft_nco_cdiv(oracle, ref):
 CASES = [("QAM16", "R3_4", 1024, {}), ("DQPSK", "R1_2", 512, {}), ("QPSK", "R1_2", 512, {}), ("QAM32", "R3_4", 1024, {}),
          ("D8PSK", "R3_4", 1024, dict(pilot_spacing=2)), ("DBPSK", "R1_4", 512, {}), ("BPSK", "R1_2", 512, {}),
          ("QAM64", "R3_4", 512, {}), ("QAM256", "R5_6", 512, {}), ("DQPSK", "R1_4", 512, dict(use_pilots=1)),
-         ("QAM16", "R2_3", 1024, dict(n_data_symbols=12))]
+         ("QAM16", "R2_3", 1024, dict(n_data_symbols=12)),
+         ("QAM16", "R1_2", 1024, dict(pilot_spacing=2)), ("DQPSK", "R1_2", 1024, dict(pilot_spacing=2, use_pilots=1))]   # 30 pilots
 
 
 @pytest.mark.parametrize("mod,rate,fft,kw", CASES)
@@ -84,7 +85,7 @@ def test_tables_modulator_demodulator(oracle, ref, mod, rate, fft, kw):
 
 @pytest.mark.parametrize("mod,rate,fft,kw", [("DQPSK", "R1_2", 512, {}), ("QAM16", "R3_4", 1024, {}),
                                              ("D8PSK", "R3_4", 1024, dict(pilot_spacing=2)), ("QPSK", "R1_2", 512, {}),
-                                             ("DBPSK", "R1_4", 512, {})])
+                                             ("DBPSK", "R1_4", 512, {}), ("QAM16", "R1_2", 1024, dict(pilot_spacing=2))])
 def test_presynced(oracle, ref, mod, rate, fft, kw):
     cfg = make_config(fft, mod, rate, entry=1, **kw)
     g = geometry(cfg)
