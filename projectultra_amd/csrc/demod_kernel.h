@@ -243,6 +243,17 @@ __device__ __forceinline__ void symbol_to_freq(FftShared<LOG2N>& sh, const Demod
     const bool cfo_on = fabsf(freq_offset_hz) > 0.01f;
     c32 v[P];
     const float* stage = reinterpret_cast<const float*>(sh.X);
+    // this frame's phase table (cfo_walk_kernel): requested before the wait for the audio, which covers both
+    int tab_ns = 0, tab_covered = 0, tab_start = 0x7fffffff;
+    float tab_pnext = 0.0f, tab_base = 0.0f, tab_step = 0.0f;
+    if (cfo_on && seg_tab) {
+        tab_ns = (int)seg_tab[0]; tab_covered = (int)seg_tab[1]; tab_pnext = __uint_as_float(seg_tab[2]);
+        if (lane < tab_ns) {
+            tab_start = (int)seg_tab[4 + 3 * lane];
+            tab_base = __uint_as_float(seg_tab[5 + 3 * lane]);
+            tab_step = __uint_as_float(seg_tab[6 + 3 * lane]);
+        }
+    }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                            // staged audio has landed
     wave_sync();
     float xs[P];
@@ -275,12 +286,8 @@ __device__ __forceinline__ void symbol_to_freq(FftShared<LOG2N>& sh, const Demod
             int ns;
             if (done == 0 && seg_tab) {
                 // the first round (almost always the only one) was walked by cfo_walk_kernel, one lane per frame
-                ns = (int)seg_tab[0]; covered = (int)seg_tab[1]; pnext = __uint_as_float(seg_tab[2]);
-                if (lane < ns) {
-                    my_start = (int)seg_tab[4 + 3 * lane];
-                    my_base = __uint_as_float(seg_tab[5 + 3 * lane]);
-                    my_step = __uint_as_float(seg_tab[6 + 3 * lane]);
-                }
+                ns = tab_ns; covered = tab_covered; pnext = tab_pnext;
+                my_start = tab_start; my_base = tab_base; my_step = tab_step;
             } else {
                 ns = um::phase_table_walk(pcur, inc, D.sym_len - done, kPhaseCap, &covered, &pnext,
                                           [&](int k, int start, float base, float step) {
