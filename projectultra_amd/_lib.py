@@ -14,7 +14,7 @@ PKG_DIR = Path(__file__).resolve().parent
 LIB_PATH = PKG_DIR / "libultra_hip.so"
 CSRC_DIR = PKG_DIR / "csrc"
 
-ULTRA_HIP_ABI_VERSION = 2
+ULTRA_HIP_ABI_VERSION = 3
 STATE_FLOATS = 8
 
 
