@@ -432,8 +432,8 @@ __device__ __forceinline__ void interpolate_channel(TrackShared& sh, const Demod
         if (lo >= 0 && hi >= 0) {
             const c32 H1 = sh.H[lo], H2 = sh.H[hi];
             const c32 pd = cmul(H2, cconj(H1));
-            const float phase_diff = fabsf(um::atan2f_(pd.im, pd.re));
-            if (phase_diff > 1.5708f) sh.H[dst] = (lc.i_alpha < 0.5f) ? H1 : H2;
+            // std::abs(std::arg(H2 * conj(H1))) > 1.5708f: decided from the signs except in a sliver (pinned_math.h)
+            if (um::atan2f_beyond_right_angle(pd.im, pd.re)) sh.H[dst] = (lc.i_alpha < 0.5f) ? H1 : H2;
             else sh.H[dst] = cadd(cscale(H1, 1.0f - lc.i_alpha), cscale(H2, lc.i_alpha));
         } else if (lo >= 0) {
             sh.H[dst] = sh.H[lo];

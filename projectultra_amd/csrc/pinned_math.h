@@ -324,5 +324,19 @@ UM_FN float hypotf_(float x, float y) {
     return (float)sqrt(dx * dx + dy * dy);
 }
 
+// fabsf(atan2f(y, x)) > 1.5708f — the test of interpolateChannel (channel_equalizer.cpp:613-617) — without the
+// arctangent in all but a sliver of cases.  1.5708f = 1.57080006... lies 3.7e-6 above pi/2:
+//   * x with a clear sign bit (and not NaN): the angle is in [-pi/2, pi/2], atan2f returns at most the float
+//     next to pi/2 (1.57079637), the test is false whatever y is (a NaN result compares false as well);
+//   * x negative with |x| * 2^16 > |y|: the angle is at least pi/2 + atan(2^-16) = pi/2 + 1.5e-5 from zero,
+//     a hundred float steps beyond the constant: true;
+//   * everything else (x = -0, |x| tiny against |y|, infinities against infinities, NaN): the arctangent.
+UM_FN bool atan2f_beyond_right_angle(float y, float x) {
+    const uint32_t ux = as_u32(x);
+    if (ux <= 0x7f800000u) return false;
+    if ((ux & 0x7fffffffu) <= 0x7f800000u && fabsf(x) * 65536.0f > fabsf(y)) return true;
+    return fabsf(atan2f_(y, x)) > 1.5708f;
+}
+
 }  // namespace um
 #endif

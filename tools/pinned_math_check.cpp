@@ -3,6 +3,7 @@
 //   g++ -O2 -std=c++17 -ffp-contract=off -mfma -pthread tools/pinned_math_check.cpp -o /tmp/pmc -lm
 //   /tmp/pmc full      # all 2^32 floats for sinf/cosf/sincosf/atanf, 2^31 random pairs atan2f/hypotf
 //   /tmp/pmc quick     # strided subset (used by tests/test_pinned_math.py)
+//   /tmp/pmc pairs     # only the two-argument functions and the right-angle test, 2^31 pairs
 // Prints one line per function: "<name> checked=<n> mismatches=<m>".  Exit code 1 on any mismatch.
 #include <cmath>
 #include <cstdint>
@@ -25,15 +26,16 @@ static inline uint64_t splitmix(uint64_t& s) {
 
 int main(int argc, char** argv) {
     bool full = argc > 1 && !strcmp(argv[1], "full");
+    const bool pairs_only = argc > 1 && !strcmp(argv[1], "pairs");   // 2^31 pairs, no single-argument sweep
     const unsigned T = std::max(1u, std::thread::hardware_concurrency());
     const uint64_t stride = full ? 1 : 1021;            // prime stride for the quick subset
-    const uint64_t pairs = full ? (1ull << 31) : (1ull << 24);
-    std::atomic<uint64_t> bad[7]; for (auto& b : bad) b = 0;
-    std::atomic<uint64_t> cnt[7]; for (auto& c : cnt) c = 0;
+    const uint64_t pairs = (full || pairs_only) ? (1ull << 31) : (1ull << 24);
+    std::atomic<uint64_t> bad[8]; for (auto& b : bad) b = 0;
+    std::atomic<uint64_t> cnt[8]; for (auto& c : cnt) c = 0;
     std::vector<std::thread> th;
     for (unsigned t = 0; t < T; ++t) th.emplace_back([&, t] {
-        uint64_t lb[7] = {0}, lc[7] = {0};
-        for (uint64_t u = t * stride; u < (1ull << 32); u += (uint64_t)T * stride) {
+        uint64_t lb[8] = {0}, lc[8] = {0};
+        for (uint64_t u = t * stride; !pairs_only && u < (1ull << 32); u += (uint64_t)T * stride) {
             float x = um::as_f32((uint32_t)u);
             float s, c; sincosf(x, &s, &c);
             lc[0]++; if (!same(um::sinf_(x), sinf(x))) { if (lb[0]++ < 3) fprintf(stderr, "sinf %08x\n", (unsigned)u); }
@@ -58,6 +60,10 @@ int main(int argc, char** argv) {
             else { y = um::as_f32((a & 0x807fffffu) | 0x3f000000u); x = um::as_f32((b & 0x807fffffu) | 0x3f800000u); }
             lc[4]++; if (!same(um::atan2f_(y, x), atan2f(y, x))) { if (lb[4]++ < 3) fprintf(stderr, "atan2f %a %a\n", y, x); }
             lc[5]++; if (!same(um::hypotf_(y, x), hypotf(y, x))) { if (lb[5]++ < 3) fprintf(stderr, "hypotf %a %a\n", y, x); }
+            // the right-angle test: the same pairs, and pairs on the sliver around -x/y = 2^-16 .. 2^-19 and at x = -0
+            float yy = y, xx = x;
+            if (i % 8 >= 4) { xx = -fabsf(y) * um::as_f32(0x35800000u + (b >> 6) % 0x04000000u); if (i % 16 >= 12) xx = (b & 1) ? -0.0f : 0.0f; }
+            lc[7]++; if (um::atan2f_beyond_right_angle(yy, xx) != (fabsf(atan2f(yy, xx)) > 1.5708f)) { if (lb[7]++ < 3) fprintf(stderr, "right-angle %a %a\n", yy, xx); }
         }
         // atan2f/hypotf special values grid
         if (t == 0) {
@@ -66,14 +72,15 @@ int main(int argc, char** argv) {
             for (float y : sp) for (float x : sp) {
                 lc[4]++; if (!same(um::atan2f_(y, x), atan2f(y, x))) lb[4]++;
                 lc[5]++; if (!same(um::hypotf_(y, x), hypotf(y, x))) lb[5]++;
+                lc[7]++; if (um::atan2f_beyond_right_angle(y, x) != (fabsf(atan2f(y, x)) > 1.5708f)) lb[7]++;
             }
         }
-        for (int k = 0; k < 7; ++k) { bad[k] += lb[k]; cnt[k] += lc[k]; }
+        for (int k = 0; k < 8; ++k) { bad[k] += lb[k]; cnt[k] += lc[k]; }
     });
     for (auto& x : th) x.join();
-    const char* names[7] = {"sinf", "cosf", "sincosf", "atanf", "atan2f", "hypotf", "sincosf_bounded"};
+    const char* names[8] = {"sinf", "cosf", "sincosf", "atanf", "atan2f", "hypotf", "sincosf_bounded", "right_angle_test"};
     int rc = 0;
-    for (int k = 0; k < 7; ++k) {
+    for (int k = 0; k < 8; ++k) {
         printf("%s checked=%llu mismatches=%llu\n", names[k], (unsigned long long)cnt[k].load(), (unsigned long long)bad[k].load());
         if (bad[k].load()) rc = 1;
     }
