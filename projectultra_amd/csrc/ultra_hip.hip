@@ -181,11 +181,11 @@ int launch_demod(ultra_hip_ctx* ctx, const float* d_audio, size_t frame_stride, 
         if (!D.presynced || D.n_pilot != 0) {
             LaunchSpan span(ctx, ULTRA_HIP_K_PILOT);
             if (D.n_pilot <= 16) {
-                const unsigned g = (unsigned)std::min((n_frames + 3) / 4, (size_t)ctx->cu_count * 64);
+                const unsigned g = (unsigned)std::min((n_frames + 3) / 4, (size_t)ctx->cu_count * 256);
                 hipLaunchKernelGGL(dev::track_pilot_kernel<16>, dim3(g), dim3(dev::kWave), 0, st, ctx->d_demod, (int)n_frames,
                                    ctx->d_ws_state, ctx->d_ws_fq);
             } else {
-                const unsigned g = (unsigned)std::min((n_frames + 1) / 2, (size_t)ctx->cu_count * 64);
+                const unsigned g = (unsigned)std::min((n_frames + 1) / 2, (size_t)ctx->cu_count * 512);
                 hipLaunchKernelGGL(dev::track_pilot_kernel<32>, dim3(g), dim3(dev::kWave), 0, st, ctx->d_demod, (int)n_frames,
                                    ctx->d_ws_state, ctx->d_ws_fq);
             }
