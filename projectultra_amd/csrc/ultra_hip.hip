@@ -139,8 +139,9 @@ int launch_demod(ultra_hip_ctx* ctx, const float* d_audio, size_t frame_stride, 
     // batch stays one launch per stage and per-workgroup constants are loaded once
     // Many short-lived workgroups (a few frames each) beat one resident set looping over the batch:
     // the hardware dispatcher rebalances CUs/XCDs that run slower (measured 7.19 -> 6.49 ms for the
-    // demodulator stage at 2^18 frames; sweep in profiles/README.md).
-    const unsigned grid_fft = (unsigned)std::min(n_frames, (size_t)ctx->cu_count * 384);
+    // demodulator stage at 2^18 frames; sweep in profiles/README.md; re-swept after the walk moved out of
+    // mix_fft_kernel: 96..192 workgroups per CU are level, 384 is 2.5 % slower).
+    const unsigned grid_fft = (unsigned)std::min(n_frames, (size_t)ctx->cu_count * 128);
     const unsigned grid_trk = (unsigned)std::min(n_frames, (size_t)ctx->cu_count * 128);
     hipStream_t st = ctx->stream;
     {
