@@ -1,0 +1,41 @@
+"""Randomised parity soak (run on the GPU box): many mode / rate / channel / SNR / CFO combinations, a few
+thousand frames each, HIP path vs the oracle on the host cores — LLRs, decoded bytes, iteration counts and the
+tracker state compared BITWISE.    python3 tools/soak_parity.py [frames_per_case] [seed]"""
+import itertools, sys, time
+import numpy as np, torch
+sys.path.insert(0, "."); sys.path.insert(0, "tests")
+from oracle.bindings import Oracle, make_config
+from _util import context_for
+
+n = int(sys.argv[1]) if len(sys.argv) > 1 else 4096
+seed = int(sys.argv[2]) if len(sys.argv) > 2 else 1
+o = Oracle()
+rng = np.random.default_rng(seed)
+modes = [(1024, "QAM16", "R3_4", {}), (1024, "QAM16", "R1_2", {}), (1024, "QAM32", "R3_4", {}), (1024, "QAM32", "R1_2", {}),
+         (1024, "DQPSK", "R1_2", {}), (1024, "D8PSK", "R3_4", {}), (512, "DQPSK", "R1_2", {}), (512, "QPSK", "R2_3", {}),
+         (512, "DBPSK", "R1_4", {}), (512, "BPSK", "R1_2", {}), (512, "QAM64", "R5_6", {}), (512, "QAM256", "R5_6", {}),
+         (1024, "QAM16", "R2_3", dict(pilot_spacing=2)), (1024, "DQPSK", "R1_4", dict(pilot_spacing=2, use_pilots=1)),
+         (512, "DQPSK", "R1_4", dict(use_pilots=1)), (1024, "QPSK", "R1_2", dict(pilot_spacing=3))]
+total = bad = 0
+t0 = time.time()
+for (fft, mod, rate, kw), (chan, snr) in itertools.product(modes, (("watterson", 30.0), ("watterson", 14.0), ("awgn", 22.0), ("awgn", 6.0))):
+    for entry in (0, 1):
+        cfg = make_config(fft, mod, rate, entry=entry, **kw)
+        audio, payload = o.make_batch(cfg, n, seed=int(rng.integers(1 << 30)), channel=chan, snr_db=snr, n_threads=64)
+        cfo = rng.normal(0, 8.0, n).astype(np.float32)
+        cfo[rng.random(n) < 0.1] = 0.0
+        cfo[rng.random(n) < 0.02] *= 10.0                    # tracker saturation at +-90 Hz
+        ph = rng.uniform(-3.1, 3.1, n).astype(np.float32) if entry == 1 else None
+        want = o.demod_decode_batch(cfg, audio, cfo_hz=cfo, cfo_phase=ph, n_threads=64)
+        ctx = context_for(cfg)
+        r = ctx.demod_decode(audio, cfo_hz=cfo, cfo_phase=ph, want_llr=True)
+        ctx.synchronize()
+        ok = (np.array_equal(r["llr"].cpu().numpy().view(np.uint32), want["llr"].view(np.uint32))
+              and np.array_equal(r["bytes"].cpu().numpy(), want["bytes"]) and np.array_equal(r["iters"].cpu().numpy(), want["iters"])
+              and np.array_equal(r["ok"].cpu().numpy(), want["ok"]))
+        total += n
+        if not ok:
+            bad += 1
+            print("MISMATCH", fft, mod, rate, kw, chan, snr, "entry", entry)
+print(f"soak: {total} frames in {len(modes) * 8} cases, {bad} mismatching cases, {time.time() - t0:.0f} s")
+sys.exit(1 if bad else 0)
