@@ -189,6 +189,20 @@ def main():
                              "ms_per_step": ms_total / args.steps, "algorithmic_bytes_per_launch": alg,
                              "GBps": alg / (avg * 1e-3) / 1e9, "frac": alg / (avg * 1e-3) / 1e9 / HBM_PEAK_GBPS,
                              "traffic": traffic_all.get(name)}
+        # The decoder's real limiter is the LDS pipeline, not HBM: report its utilisation next to the HBM figure.
+        # One codeword-iteration issues 36 ds_read_b32 (2 cycles each for 64 lanes) and 36 ds_write_b32 (4 cycles:
+        # address + data) = 216 LDS cycles on the CU's single LDS pipeline; a codeword that
+        # converges at iteration `it` executes it + 1 iterations, a failing one max_iterations.
+        if "ldpc_decode_kernel" in kernels and world == 1:
+            props = torch.cuda.get_device_properties(0)
+            clock_hz = 2.4e9                                   # MI355X peak engine clock (MI355X_MICROARCH.md)
+            executed = stats["iters_sum"] + (stats["frames"] - stats["ldpc_fail"])
+            lds_cycles = 216.0 * executed
+            avail = kernels["ldpc_decode_kernel"]["avg_launch_ms"] * 1e-3 * clock_hz * props.multi_processor_count
+            kernels["ldpc_decode_kernel"]["lds"] = {"lds_cycles_per_codeword_iteration": 216,
+                                                    "codeword_iterations_per_launch": executed,
+                                                    "compute_units": props.multi_processor_count, "clock_hz": clock_hz,
+                                                    "frac_of_lds_peak": lds_cycles / avail}
         dom = max(kernels, key=lambda k: kernels[k]["ms_per_step"])
         roofline = {"bound": "hbm", "kernel": dom, "achieved": kernels[dom]["GBps"], "peak": HBM_PEAK_GBPS,
                     "unit": "GB/s", "frac": kernels[dom]["frac"], "traffic": kernels[dom]["traffic"],
