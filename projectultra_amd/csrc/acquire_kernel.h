@@ -34,6 +34,7 @@ namespace dev {
 // demodulator_constants.hpp:41-53
 constexpr unsigned kAcqMinSearch = 4000u, kAcqMaxBuffer = 240000u, kAcqOverlap = 20000u, kAcqStep = 8u,
                    kAcqPlateauWindow = 300u, kAcqMinPlateau = 15u;
+constexpr int kAcqCache = 256;
 
 template <int LOG2N>
 struct AcqShared {
@@ -47,9 +48,14 @@ struct AcqShared {
         float samp[N];                // window samples for the dc sum (before the FFT input is taken)
         float terms[N / 2][4];        // per-index terms of the four correlation sums (analytic signal in registers)
         float lts_win[2 * (N + N / P)];   // audio window of one matched-filter pass (same bytes as X)
+        float grp[(N + 8 * kWave) / 8 * 9];   // samples of 64 candidate windows 8 apart, 1 pad per 8 (acq_group_dc)
     };
     c32 twB[kTwB];                    // twiddles of stages A..2A-1, one contiguous run per stage (as in mix_fft_kernel)
     c32 twA[kTwA + 1];
+    // Metric cache of the stream (direct-mapped by absolute window offset / 8): the search restarts at
+    // offset 0 on every process() call, so most candidates of a call were already evaluated by the call before.
+    unsigned ctag[kAcqCache];
+    float cval[kAcqCache];
 };
 
 // per-lane twiddles of stages 2A..LOG2N-1 (k = lane + 64*(t & (ht-1))), loop-invariant: kept in registers
@@ -97,6 +103,48 @@ __device__ __forceinline__ float acq_ordered_sum_lds(const float* a, int n) {
         acq_load16(a + ((i + 32 < n) ? i + 32 : i), ra);     // the last round re-reads a block it does not use
         s = acq_add16(s, rb);
     }
+    return s;
+}
+
+// DC sums of 64 candidate windows in ONE chain pass.  measureSchmidlCoxCorrelation (ofdm_sync.cpp:131-140)
+// sums the N samples of its window in order before anything else; the candidates the search and the
+// plateau scan visit lie 8 samples apart, so lane g walks the window that starts 8 g samples behind
+// `first` — 64 chains side by side for the price (N dependent adds) the single broadcast walk paid per
+// candidate.  The N + 504 samples sit in LDS with one pad word per 8 samples: sample 8 g + n lies at word
+// 9 g + n + n / 8, so the lanes of a step read words 9 apart (all 32 banks), and a run of 16 terms is 17
+// consecutive words (immediate offsets).  Windows may run past the samples fed so far (the stream is
+// all in memory; a candidate is only ever USED once its window is inside the fed part, and its value does
+// not depend on when it was summed); past the end of the stream they read zeros and are never used.
+template <int LOG2N>
+__device__ __forceinline__ void acq_gload16(const float* q, float (&r)[16]) {
+#pragma unroll
+    for (int u = 0; u < 16; ++u) r[u] = q[u + (u >> 3)];
+    asm volatile("" : "+v"(r[0]), "+v"(r[1]), "+v"(r[2]), "+v"(r[3]), "+v"(r[4]), "+v"(r[5]), "+v"(r[6]), "+v"(r[7]),
+                      "+v"(r[8]), "+v"(r[9]), "+v"(r[10]), "+v"(r[11]), "+v"(r[12]), "+v"(r[13]), "+v"(r[14]), "+v"(r[15]));
+}
+template <int LOG2N>
+__device__ __forceinline__ float acq_group_dc(AcqShared<LOG2N>& sh, const float* __restrict__ all, unsigned first,
+                                              unsigned n_samples) {
+    constexpr int N = 1 << LOG2N;
+    const int lane = threadIdx.x;
+    for (unsigned s0 = 0; s0 < (unsigned)(N + 8 * kWave); s0 += kWave) {
+        const unsigned sidx = s0 + (unsigned)lane, g = first + sidx;
+        sh.grp[sidx + (sidx >> 3)] = (g < n_samples) ? all[g] : 0.0f;
+    }
+    wave_sync();
+    const float* q = sh.grp + 9 * lane;
+    float s = 0.0f, ra[16], rb[16];
+    acq_gload16<LOG2N>(q, ra);
+    for (int i = 0; i < N; i += 32) {
+        acq_gload16<LOG2N>(q + 18, rb);
+#pragma unroll
+        for (int u = 0; u < 16; ++u) s += ra[u];
+        acq_gload16<LOG2N>((i + 32 < N) ? q + 36 : q, ra);    // the last round re-reads a block it does not use
+#pragma unroll
+        for (int u = 0; u < 16; ++u) s += rb[u];
+        q += 36;
+    }
+    wave_sync();                                             // grp aliases the FFT exchange buffer
     return s;
 }
 
@@ -230,13 +278,13 @@ __device__ __forceinline__ void acq_half_sums(AcqShared<LOG2N>& sh, const c32 (&
 }
 
 // The half-symbol autocorrelation of the analytic signal of the N samples at `win`: P, R1, R2.
-// remove_dc: subtract the mean first (measureSchmidlCoxCorrelation, ofdm_sync.cpp:131-140);
-// estimateCoarseCFO (:241) takes the raw samples.  ONE instance of this code serves the search, the
+// dc_sum: the in-order sum of the window's samples (measureSchmidlCoxCorrelation subtracts the mean first,
+// ofdm_sync.cpp:131-140; it comes from acq_group_dc), +0 for estimateCoarseCFO (:241), which takes the raw samples.  ONE instance of this code serves the search, the
 // plateau scan and the CFO estimate (see the state machine in acquire_kernel): three inlined copies
 // cost 239 VGPRs.
 template <int LOG2N>
 __device__ __forceinline__ void acq_window_metric(AcqShared<LOG2N>& sh, const AcqLaneTw<LOG2N>& ltw,
-                                                  const float* __restrict__ win, bool remove_dc, c32* P_out, float* R1,
+                                                  const float* __restrict__ win, float dc_sum, c32* P_out, float* R1,
                                                   float* R2) {
     constexpr int N = 1 << LOG2N;
     constexpr int P = AcqShared<LOG2N>::P;
@@ -245,15 +293,7 @@ __device__ __forceinline__ void acq_window_metric(AcqShared<LOG2N>& sh, const Ac
     float xs[P];
 #pragma unroll
     for (int qp = 0; qp < P; ++qp) xs[qp] = win[rl + 64 * qp];
-    float dc = 0.0f;                                         // x - 0.0f == x for every float (also -0.0f)
-    if (remove_dc) {                                         // dc_sum: samples 0..N-1 in order
-#pragma unroll
-        for (int qp = 0; qp < P; ++qp) sh.samp[rl + 64 * qp] = xs[qp];
-        wave_sync();
-        const float dc_sum = acq_ordered_sum_lds(sh.samp, N);
-        dc = dc_sum / (float)N;
-        wave_sync();
-    }
+    const float dc = dc_sum / (float)N;                      // dc_sum = +0 when no dc is removed: x - 0.0f == x for every float
     c32 v[P];
     acq_analytic<LOG2N>(sh, ltw, xs, dc, v);
     acq_half_sums<LOG2N>(sh, v, P_out, R1, R2);
@@ -387,6 +427,10 @@ __global__ __launch_bounds__(kWave, (LOG2N == 10) ? 3 : 4) void acquire_kernel(
         const float* all = audio + (size_t)stream * stream_stride;
         unsigned base = 0, fed = 0, found = 0, so_out = 0, ds_out = 0, fed_at = 0;
         float cfo = 0.0f, noise_floor = 0.0f;
+        unsigned grp_first = 0xffffffffu;                     // window start of lane 0 of the current DC group
+        float grp_dc = 0.0f;                                  // lane g: dc sum of the window at grp_first + 8 g
+        for (int c = lane; c < kAcqCache; c += kWave) sh.ctag[c] = 0xffffffffu;
+        wave_sync();
         while (fed < n_samples && !found) {
             fed += (n_samples - fed < chunk) ? (n_samples - fed) : chunk;
             unsigned size = fed - base;
@@ -424,7 +468,27 @@ __global__ __launch_bounds__(kWave, (LOG2N == 10) ? 3 : 4) void acquire_kernel(
                 const bool in_range = off + (unsigned)D.cp + (unsigned)N <= size;
                 c32 Pm = mk(0.0f, 0.0f);
                 float R1 = 0.0f, R2 = 0.0f;
-                if (in_range) acq_window_metric<LOG2N>(sh, ltw, buf + off + D.cp, mode != kCfo, &Pm, &R1, &R2);
+                const unsigned wabs = base + off + (unsigned)D.cp;       // absolute first sample of the window
+                const unsigned slot = (wabs >> 3) & (unsigned)(kAcqCache - 1);
+                bool cached = false;
+                float corr = 0.0f;
+                if (in_range && mode != kCfo) {                          // wave-uniform (broadcast reads made scalar)
+                    const unsigned tag = (unsigned)__builtin_amdgcn_readfirstlane((int)sh.ctag[slot]);
+                    const float val = __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(sh.cval[slot])));
+                    if (tag == wabs) { cached = true; corr = val; }
+                }
+                if (in_range && !cached) {
+                    float dc_sum = 0.0f;
+                    if (mode != kCfo) {
+                        const unsigned d = wabs - grp_first;              // candidate (d / 8) of the current group?
+                        if (wabs < grp_first || (d & 7u) != 0u || d >= 8u * kWave) {
+                            grp_first = wabs;
+                            grp_dc = acq_group_dc<LOG2N>(sh, all, wabs, n_samples);
+                        }
+                        dc_sum = lane_f(grp_dc, (int)((wabs - grp_first) >> 3));
+                    }
+                    acq_window_metric<LOG2N>(sh, ltw, all + wabs, dc_sum, &Pm, &R1, &R2);
+                }
                 if (mode == kCfo) {
                     if (in_range) {
                         const float phase = um::atan2f_(Pm.im, Pm.re);
@@ -436,10 +500,12 @@ __global__ __launch_bounds__(kWave, (LOG2N == 10) ? 3 : 4) void acquire_kernel(
                     found_sync = true;
                     break;
                 }
-                float corr = 0.0f;
-                if (in_range) {
+                if (in_range && !cached) {
                     const float normalization = sqrtf(R1 * R2);
                     corr = (normalization < 1e-10f) ? 0.0f : cabs_(Pm) / normalization;
+                    wave_sync();
+                    if (lane == 0) { sh.ctag[slot] = wabs; sh.cval[slot] = corr; }
+                    wave_sync();
                 }
                 if (mode == kSearch) {
                     if (corr > sync_threshold) { mode = kPlateau; j = 0; plateau = 0; peak = corr; peak_pos = i; }
