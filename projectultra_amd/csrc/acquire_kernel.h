@@ -58,11 +58,13 @@ struct AcqShared {
     float cval[kAcqCache];
 };
 
-// per-lane twiddles of stages 2A..LOG2N-1 (k = lane + 64*(t & (ht-1))), loop-invariant: kept in registers
+// per-lane twiddles of stages 2A..LOG2N-1 (k = lane + 64*(t & (ht-1))): read from the L2-resident table at
+// every use, as mix_fft_kernel does (kept in registers they cost 24 VGPRs for the whole kernel, and the kernel
+// spilled: 692 B of scratch per lane, reloaded inside the FFTs)
 template <int LOG2N>
 struct AcqLaneTw {
-    static constexpr int P = (1 << LOG2N) / kWave;
-    c32 w[P - 1];                     // stage s (pair distance ht = 2^(s-6) in t) uses w[(ht - 1) + (t & (ht - 1))]
+    const c32* __restrict__ table;     // twiddle[k], k < N/2
+    __device__ __forceinline__ c32 at(int s, int c) const { return table[((int)threadIdx.x + 64 * c) << (LOG2N - 1 - s)]; }
 };
 
 // In-order sum across the wavefront without LDS: returns ((..((s + x[lane 0]) + x[lane 1]) + ..) + x[lane 63]).
@@ -198,7 +200,7 @@ __device__ __forceinline__ void acq_fft(AcqShared<LOG2N>& sh, const AcqLaneTw<LO
 #pragma unroll
         for (int t = 0; t < P; ++t) {
             if (t & ht) continue;
-            const c32 w = tw(ltw.w[(ht - 1) + (t & (ht - 1))]);
+            const c32 w = tw(ltw.at(s, t & (ht - 1)));
             UH_BUTTERFLY(v[t], v[t + ht], w);
         }
     }
@@ -391,6 +393,37 @@ __device__ __forceinline__ unsigned acq_refine_lts(AcqShared<LOG2N>& sh, const D
     return (m > 0.0f) ? w : coarse;                      // no offset beat 0: best_offset stays at coarse_lts_start
 }
 
+// Out-of-line entries of the four phases.  The 1024-point instance inlined into ONE function needs far more
+// than the 168 VGPRs that three wavefronts per SIMD leave (81 spilled, reloaded inside the FFTs); as separate
+// functions every phase gets its own register allocation (4 spilled) and the calls — a few hundred per
+// stream, each worth thousands of cycles — cost nothing measurable: 27.5 -> 25.0 ms per 16384 cfg3 streams.
+// The 512-point instance fits inlined and is faster that way (6.8 against 7.7 ms).
+template <int LOG2N>
+__device__ __attribute__((noinline)) bool acq_has_energy_call(AcqShared<LOG2N>& sh, const float* __restrict__ buf,
+                                                              unsigned size, unsigned offset, unsigned window_len,
+                                                              float& noise_floor) {
+    return acq_has_energy<LOG2N>(sh, buf, size, offset, window_len, noise_floor);
+}
+template <int LOG2N>
+__device__ __attribute__((noinline)) float acq_group_dc_call(AcqShared<LOG2N>& sh, const float* __restrict__ all,
+                                                             unsigned first, unsigned n_samples) {
+    return acq_group_dc<LOG2N>(sh, all, first, n_samples);
+}
+template <int LOG2N>
+__device__ __attribute__((noinline)) void acq_window_metric_call(AcqShared<LOG2N>& sh, const AcqLaneTw<LOG2N>& ltw,
+                                                                 const float* __restrict__ win, float dc_sum, c32* P_out,
+                                                                 float* R1, float* R2) {
+    acq_window_metric<LOG2N>(sh, ltw, win, dc_sum, P_out, R1, R2);
+}
+template <int LOG2N>
+__device__ __attribute__((noinline)) unsigned acq_refine_lts_call(AcqShared<LOG2N>& sh, const DemodConst& D,
+                                                                  const float* __restrict__ lts_I,
+                                                                  const float* __restrict__ lts_Q, float energy_ref,
+                                                                  const float* __restrict__ buf, unsigned size,
+                                                                  unsigned sts_start) {
+    return acq_refine_lts<LOG2N>(sh, D, lts_I, lts_Q, energy_ref, buf, size, sts_start);
+}
+
 template <int LOG2N>
 __global__ __launch_bounds__(kWave, (LOG2N == 10) ? 3 : 4) void acquire_kernel(
     const DemodConst* __restrict__ Dp, const c32* __restrict__ twiddle, const float* __restrict__ lts_I,
@@ -399,18 +432,14 @@ __global__ __launch_bounds__(kWave, (LOG2N == 10) ? 3 : 4) void acquire_kernel(
     unsigned* __restrict__ data_start_out, float* __restrict__ cfo_out, unsigned* __restrict__ sync_offset_out,
     unsigned* __restrict__ fed_out) {
     constexpr int N = 1 << LOG2N;
+    constexpr bool kCalls = (LOG2N == 10);                   // phases as out-of-line functions, see above
     __shared__ AcqShared<LOG2N> sh;
     const DemodConst& D = *Dp;
     const int lane = threadIdx.x;
     AcqLaneTw<LOG2N> ltw;
+    ltw.table = twiddle;
     {
         constexpr int P = AcqShared<LOG2N>::P, A = AcqShared<LOG2N>::A;
-#pragma unroll
-        for (int s = 2 * A; s < LOG2N; ++s) {                // stage s: pair distance ht = 2^(s-6) in t, k = lane + 64*c, c < ht
-            const int ht = 1 << (s - 6);
-#pragma unroll
-            for (int c = 0; c < ht; ++c) ltw.w[(ht - 1) + c] = twiddle[(lane + 64 * c) << (LOG2N - 1 - s)];
-        }
         for (int idx = lane; idx < AcqShared<LOG2N>::kTwB; idx += kWave) {
             const int sA = 31 - __clz(idx / P + 1);          // stage - A: runs start at P*(2^sA - 1)
             const int k = idx - P * ((1 << sA) - 1);
@@ -453,7 +482,10 @@ __global__ __launch_bounds__(kWave, (LOG2N == 10) ? 3 : 4) void acquire_kernel(
                 unsigned off;
                 if (mode == kSearch) {
                     if (i >= search_end) break;
-                    if (!acq_has_energy<LOG2N>(sh, buf, size, i, corr_win, noise_floor)) { i += corr_win / 2u; continue; }
+                    bool energetic;
+                    if constexpr (kCalls) energetic = acq_has_energy_call<LOG2N>(sh, buf, size, i, corr_win, noise_floor);
+                    else energetic = acq_has_energy<LOG2N>(sh, buf, size, i, corr_win, noise_floor);
+                    if (!energetic) { i += corr_win / 2u; continue; }
                     off = i;
                 } else if (mode == kPlateau) {
                     if (!(j <= kAcqPlateauWindow && i + j + preamble_total < size)) {
@@ -483,11 +515,13 @@ __global__ __launch_bounds__(kWave, (LOG2N == 10) ? 3 : 4) void acquire_kernel(
                         const unsigned d = wabs - grp_first;              // candidate (d / 8) of the current group?
                         if (wabs < grp_first || (d & 7u) != 0u || d >= 8u * kWave) {
                             grp_first = wabs;
-                            grp_dc = acq_group_dc<LOG2N>(sh, all, wabs, n_samples);
+                            if constexpr (kCalls) grp_dc = acq_group_dc_call<LOG2N>(sh, all, wabs, n_samples);
+                            else grp_dc = acq_group_dc<LOG2N>(sh, all, wabs, n_samples);
                         }
                         dc_sum = lane_f(grp_dc, (int)((wabs - grp_first) >> 3));
                     }
-                    acq_window_metric<LOG2N>(sh, ltw, all + wabs, dc_sum, &Pm, &R1, &R2);
+                    if constexpr (kCalls) acq_window_metric_call<LOG2N>(sh, ltw, all + wabs, dc_sum, &Pm, &R1, &R2);
+                    else acq_window_metric<LOG2N>(sh, ltw, all + wabs, dc_sum, &Pm, &R1, &R2);
                 }
                 if (mode == kCfo) {
                     if (in_range) {
@@ -517,7 +551,9 @@ __global__ __launch_bounds__(kWave, (LOG2N == 10) ? 3 : 4) void acquire_kernel(
                 }
             }
             if (found_sync) {
-                const unsigned refined = acq_refine_lts<LOG2N>(sh, D, lts_I, lts_Q, energy_ref, buf, size, so);
+                unsigned refined;
+                if constexpr (kCalls) refined = acq_refine_lts_call<LOG2N>(sh, D, lts_I, lts_Q, energy_ref, buf, size, so);
+                else refined = acq_refine_lts<LOG2N>(sh, D, lts_I, lts_Q, energy_ref, buf, size, so);
                 if (refined == 0xffffffffu) {
                     if (size > kAcqOverlap * 2u) {
                         unsigned trim = so + psl;

@@ -142,12 +142,7 @@ template <int LOG2N>
 __device__ __forceinline__ void stim_load_tables(AcqShared<LOG2N>& sh, AcqLaneTw<LOG2N>& ltw, const c32* __restrict__ twiddle) {
     constexpr int P = AcqShared<LOG2N>::P, A = AcqShared<LOG2N>::A;
     const int lane = threadIdx.x;
-#pragma unroll
-    for (int s = 2 * A; s < LOG2N; ++s) {
-        const int ht = 1 << (s - 6);
-#pragma unroll
-        for (int c = 0; c < ht; ++c) ltw.w[(ht - 1) + c] = twiddle[(lane + 64 * c) << (LOG2N - 1 - s)];
-    }
+    ltw.table = twiddle;
     for (int idx = lane; idx < AcqShared<LOG2N>::kTwB; idx += kWave) {
         const int sA = 31 - __clz(idx / P + 1);
         const int k = idx - P * ((1 << sA) - 1);
