@@ -45,10 +45,10 @@ struct AcqShared {
     static constexpr int kTwA = (1 << A) - 1;               // wave-uniform twiddles of stages 0..A-1, one run per stage
     union {
         c32 X[N + N / P];             // FFT exchange buffer, 1 pad per P entries
-        float samp[N];                // window samples for the dc sum (before the FFT input is taken)
         float terms[N / 2][4];        // per-index terms of the four correlation sums (analytic signal in registers)
         float lts_win[2 * (N + N / P)];   // audio window of one matched-filter pass (same bytes as X)
         float grp[(N + 8 * kWave) / 8 * 9];   // samples of 64 candidate windows 8 apart, 1 pad per 8 (acq_group_dc)
+        float gsq[kWave + 2 * ((2 * (N + N / 2) + 15) / 16)];   // (cp <= N / 2) squares of every 8th sample under 64 gate windows (acq_group_energy)
     };
     c32 twB[kTwB];                    // twiddles of stages A..2A-1, one contiguous run per stage (as in mix_fft_kernel)
     c32 twA[kTwA + 1];
@@ -66,47 +66,6 @@ struct AcqLaneTw {
     const c32* __restrict__ table;     // twiddle[k], k < N/2
     __device__ __forceinline__ c32 at(int s, int c) const { return table[((int)threadIdx.x + 64 * c) << (LOG2N - 1 - s)]; }
 };
-
-// In-order sum across the wavefront without LDS: returns ((..((s + x[lane 0]) + x[lane 1]) + ..) + x[lane 63]).
-// 63 dependent DPP adds (wave_shr:1: lane k takes lane k-1's running value; lane 0 has no source and
-// keeps its own, s + x0): after step m lane m holds the sum of the first m + 1 terms.  A broadcast
-// walk through LDS costs the same chain of adds plus ~27 LDS cycles per 16-byte read (measured), and
-// the LDS pipe was what bounded this kernel.  "s_nop 1": the two wait states the hardware needs between a
-// VALU write and a DPP read of the same VGPR (the compiler does not see inside the asm).
-__device__ __forceinline__ float acq_chain_add(float s, float x) {
-    float y = (threadIdx.x == 0) ? s + x : x;
-#pragma unroll
-    for (int k = 1; k < kWave; ++k)
-        asm volatile("s_nop 1\n\tv_add_f32_dpp %0, %0, %1 wave_shr:1 row_mask:0xf bank_mask:0xf" : "+v"(y) : "v"(x));
-    return lane_f(y, kWave - 1);
-}
-
-// s = 0; s += a[0]; s += a[1]; ... in order through LDS (all lanes read the same addresses: broadcast);
-// n a multiple of 32.  A dependent v_add_f32 chain advances one term per ~9 cycles against ~17 for the
-// DPP chain above, so the 1024-term DC sum goes this way; the loads of the next 16 terms are issued
-// before the current 16 are added (ping-pong register sets; the asm statements pin that order).
-__device__ __forceinline__ void acq_load16(const float* p, float4 (&r)[4]) {
-#pragma unroll
-    for (int u = 0; u < 4; ++u) r[u] = *reinterpret_cast<const float4*>(p + 4 * u);
-    asm volatile("" : "+v"(r[0].x), "+v"(r[1].x), "+v"(r[2].x), "+v"(r[3].x));
-}
-__device__ __forceinline__ float acq_add16(float s, const float4 (&r)[4]) {
-#pragma unroll
-    for (int u = 0; u < 4; ++u) { s += r[u].x; s += r[u].y; s += r[u].z; s += r[u].w; }
-    return s;
-}
-__device__ __forceinline__ float acq_ordered_sum_lds(const float* a, int n) {
-    float s = 0.0f;
-    float4 ra[4], rb[4];
-    acq_load16(a, ra);
-    for (int i = 0; i < n; i += 32) {
-        acq_load16(a + i + 16, rb);
-        s = acq_add16(s, ra);
-        acq_load16(a + ((i + 32 < n) ? i + 32 : i), ra);     // the last round re-reads a block it does not use
-        s = acq_add16(s, rb);
-    }
-    return s;
-}
 
 // DC sums of 64 candidate windows in ONE chain pass.  measureSchmidlCoxCorrelation (ofdm_sync.cpp:131-140)
 // sums the N samples of its window in order before anything else; the candidates the search and the
@@ -301,20 +260,37 @@ __device__ __forceinline__ void acq_window_metric(AcqShared<LOG2N>& sh, const Ac
     acq_half_sums<LOG2N>(sh, v, P_out, R1, R2);
 }
 
-// Impl::hasMinimumEnergy
+// Impl::hasMinimumEnergy's sum for 64 candidates at once.  The gate squares every 16th sample of its window
+// and adds the squares in order; the candidates of the search lie 8 samples apart, so candidate g needs the
+// squares of samples first + 8 (g + 2 t), t = 0 .. count-1: every square is formed ONCE (one multiplication
+// per sample instead of one per sample and candidate), parked in LDS, and lane g walks g, g + 2, g + 4, ..
+// — 64 in-order sums for count additions (consecutive lanes read consecutive words; the DPP chain spent 63
+// dependent adds of ~17 cycles per 64 terms of ONE candidate).  Lane g returns candidate g's sum.
 template <int LOG2N>
-__device__ __forceinline__ bool acq_has_energy(AcqShared<LOG2N>& sh, const float* __restrict__ buf, unsigned size,
-                                               unsigned offset, unsigned window_len, float& noise_floor) {
-    if (offset + window_len > size) return false;
+__device__ __forceinline__ float acq_group_energy(AcqShared<LOG2N>& sh, const float* __restrict__ all, unsigned first,
+                                                  int count, unsigned n_samples) {
     const int lane = threadIdx.x;
-    const int count = (int)((window_len + 15u) / 16u);          // i = 0, 16, ... < window_len
-    float sum_sq = 0.0f;
-    for (int t0 = 0; t0 < count; t0 += kWave) {
-        const int t = t0 + lane;
-        float sq = -0.0f;                                           // beyond the last sample: exact no-op in the sum
-        if (t < count) { const float v = buf[offset + 16u * (unsigned)t]; sq = v * v; }
-        sum_sq = acq_chain_add(sum_sq, sq);
+    const int n_sq = kWave + 2 * count;
+    for (int k = lane; k < n_sq; k += kWave) {
+        const unsigned g = first + 8u * (unsigned)k;
+        const float v = (g < n_samples) ? all[g] : 0.0f;          // windows past the end of the stream are never used
+        sh.gsq[k] = v * v;
     }
+    wave_sync();
+    const float* q = sh.gsq + lane;
+    float sum = 0.0f;
+    int t = 0;
+    for (; t + 4 <= count; t += 4) {
+        const float a = q[2 * t], b = q[2 * t + 2], c = q[2 * t + 4], d = q[2 * t + 6];
+        sum += a; sum += b; sum += c; sum += d;
+    }
+    for (; t < count; ++t) sum += q[2 * t];
+    wave_sync();                                             // gsq aliases the FFT exchange buffer
+    return sum;
+}
+
+// Impl::hasMinimumEnergy (the sum comes from acq_group_energy)
+__device__ __forceinline__ bool acq_energy_gate(float sum_sq, int count, float& noise_floor) {
     const float energy = sum_sq / (float)count;
     if (noise_floor < 1e-20f) noise_floor = energy * 0.1f;
     if (energy < noise_floor) noise_floor = energy;
@@ -399,10 +375,9 @@ __device__ __forceinline__ unsigned acq_refine_lts(AcqShared<LOG2N>& sh, const D
 // stream, each worth thousands of cycles — cost nothing measurable: 27.5 -> 25.0 ms per 16384 cfg3 streams.
 // The 512-point instance fits inlined and is faster that way (6.8 against 7.7 ms).
 template <int LOG2N>
-__device__ __attribute__((noinline)) bool acq_has_energy_call(AcqShared<LOG2N>& sh, const float* __restrict__ buf,
-                                                              unsigned size, unsigned offset, unsigned window_len,
-                                                              float& noise_floor) {
-    return acq_has_energy<LOG2N>(sh, buf, size, offset, window_len, noise_floor);
+__device__ __attribute__((noinline)) float acq_group_energy_call(AcqShared<LOG2N>& sh, const float* __restrict__ all,
+                                                                 unsigned first, int count, unsigned n_samples) {
+    return acq_group_energy<LOG2N>(sh, all, first, count, n_samples);
 }
 template <int LOG2N>
 __device__ __attribute__((noinline)) float acq_group_dc_call(AcqShared<LOG2N>& sh, const float* __restrict__ all,
@@ -452,10 +427,13 @@ __global__ __launch_bounds__(kWave, (LOG2N == 10) ? 3 : 4) void acquire_kernel(
         wave_sync();
     }
     const unsigned psl = (unsigned)(N + D.cp), preamble_total = psl * 6u, corr_win = psl * 2u;
+    const int gate_count = (int)((corr_win + 15u) / 16u);    // i = 0, 16, .. < window_len
     for (int stream = blockIdx.x; stream < n_streams; stream += gridDim.x) {
         const float* all = audio + (size_t)stream * stream_stride;
         unsigned base = 0, fed = 0, found = 0, so_out = 0, ds_out = 0, fed_at = 0;
         float cfo = 0.0f, noise_floor = 0.0f;
+        unsigned gate_first = 0xffffffffu;                    // window start of lane 0 of the current energy-gate group
+        float gate_sum = 0.0f;                                // lane g: sum of squares of the gate window at gate_first + 8 g
         unsigned grp_first = 0xffffffffu;                     // window start of lane 0 of the current DC group
         float grp_dc = 0.0f;                                  // lane g: dc sum of the window at grp_first + 8 g
         for (int c = lane; c < kAcqCache; c += kWave) sh.ctag[c] = 0xffffffffu;
@@ -482,9 +460,16 @@ __global__ __launch_bounds__(kWave, (LOG2N == 10) ? 3 : 4) void acquire_kernel(
                 unsigned off;
                 if (mode == kSearch) {
                     if (i >= search_end) break;
-                    bool energetic;
-                    if constexpr (kCalls) energetic = acq_has_energy_call<LOG2N>(sh, buf, size, i, corr_win, noise_floor);
-                    else energetic = acq_has_energy<LOG2N>(sh, buf, size, i, corr_win, noise_floor);
+                    bool energetic = false;
+                    if (i + corr_win <= size) {                      // hasMinimumEnergy: window inside the buffer
+                        const unsigned gabs = base + i, d = gabs - gate_first;
+                        if (gabs < gate_first || (d & 7u) != 0u || d >= 8u * kWave) {
+                            gate_first = gabs;
+                            if constexpr (kCalls) gate_sum = acq_group_energy_call<LOG2N>(sh, all, gabs, gate_count, n_samples);
+                            else gate_sum = acq_group_energy<LOG2N>(sh, all, gabs, gate_count, n_samples);
+                        }
+                        energetic = acq_energy_gate(lane_f(gate_sum, (int)((gabs - gate_first) >> 3)), gate_count, noise_floor);
+                    }
                     if (!energetic) { i += corr_win / 2u; continue; }
                     off = i;
                 } else if (mode == kPlateau) {

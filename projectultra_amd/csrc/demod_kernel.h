@@ -899,8 +899,11 @@ __global__ __launch_bounds__(256) void cfo_walk_kernel(const DemodConst* __restr
     tab[0] = (unsigned)ns; tab[1] = (unsigned)covered; tab[2] = __float_as_uint(pnext);
 }
 
+// Launch bound 2, occupancy 3: with the bound at 3 the register allocator stops at 168 VGPRs and spills two of
+// them (12 B of scratch, reloaded per frame); with the looser bound it still settles on 168 — three wavefronts
+// per SIMD — and spills nothing (0.767 -> 0.743 ms per 2^18-frame launch).  LDS caps the CU at 14 workgroups anyway.
 template <int LOG2N>
-__global__ __launch_bounds__(kWave, 3) void mix_fft_kernel(
+__global__ __launch_bounds__(kWave, 2) void mix_fft_kernel(
     const DemodConst* __restrict__ Dp, const c32* __restrict__ nco, const c32* __restrict__ twiddle,
     const float* __restrict__ audio, size_t frame_stride, const unsigned* __restrict__ frame_offset, int n_frames,
     int sym, float* __restrict__ state, c32* __restrict__ fq, const unsigned* __restrict__ seg_tab) {
