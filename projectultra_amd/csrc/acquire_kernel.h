@@ -331,21 +331,32 @@ __device__ __forceinline__ unsigned acq_refine_lts(AcqShared<LOG2N>& sh, const D
             sh.lts_win[i] = (g < size) ? buf[g] : 0.0f;                               // beyond the last offset of the last pass
         }
         wave_sync();
-        v2f ciq[kR];
-        float er[kR];
+        v2f ciq[kR], er2[kR / 2];                                 // er2[r / 2] = (energy_rx of offset r, of offset r + 1)
 #pragma unroll
-        for (int r = 0; r < kR; ++r) { ciq[r] = v2f{0.0f, 0.0f}; er[r] = 0.0f; }
+        for (int r = 0; r < kR; ++r) ciq[r] = v2f{0.0f, 0.0f};
+#pragma unroll
+        for (int r = 0; r < kR / 2; ++r) er2[r] = v2f{0.0f, 0.0f};
         const float* p = sh.lts_win + lane;
         for (unsigned i = 0; i < lts_len; ++i) {
             const v2f t = {lts_I[i], lts_Q[i]};
 #pragma unroll
-            for (int r = 0; r < kR; ++r) {
-                const float rx = p[i + 64 * r];
-                const v2f r2 = {rx, rx};
-                ciq[r] = ciq[r] + r2 * t;                     // corr_I += rx * I[i]; corr_Q += rx * Q[i] (packed, no contraction)
-                er[r] += rx * rx;                             // energy_rx += rx * rx
+            for (int r = 0; r < kR; r += 2) {
+                // corr_I += rx * I[i]; corr_Q += rx * Q[i]; energy_rx += rx * rx — packed, never contracted.  The two
+                // samples of a register pair (one ds_read2st64_b32) multiply the scalar template pair through operand
+                // selection: (I, Q) * (lo, lo) and (I, Q) * (hi, hi) — the compiler copied `hi` into a fresh pair first
+                // (4 of the 28 VALU instructions per tap).
+                const v2f rx = {p[i + 64 * r], p[i + 64 * (r + 1)]};
+                v2f m0, m1;
+                asm("v_pk_mul_f32 %0, %1, %2 op_sel_hi:[1,0]" : "=v"(m0) : "s"(t), "v"(rx));
+                asm("v_pk_mul_f32 %0, %1, %2 op_sel:[0,1] op_sel_hi:[1,1]" : "=v"(m1) : "s"(t), "v"(rx));
+                ciq[r] = ciq[r] + m0;
+                ciq[r + 1] = ciq[r + 1] + m1;
+                er2[r / 2] = er2[r / 2] + rx * rx;
             }
         }
+        float er[kR];
+#pragma unroll
+        for (int r = 0; r < kR; r += 2) { er[r] = er2[r / 2].x; er[r + 1] = er2[r / 2].y; }
 #pragma unroll
         for (int r = 0; r < kR; ++r) {                        // increasing offsets within a lane
             const int idx = lane + 64 * r;
@@ -369,9 +380,9 @@ __device__ __forceinline__ unsigned acq_refine_lts(AcqShared<LOG2N>& sh, const D
     return (m > 0.0f) ? w : coarse;                      // no offset beat 0: best_offset stays at coarse_lts_start
 }
 
-// Out-of-line entries of the four phases.  The 1024-point instance inlined into ONE function needs far more
+// Out-of-line entries of the search phases.  The 1024-point instance inlined into ONE function needs far more
 // than the 168 VGPRs that three wavefronts per SIMD leave (81 spilled, reloaded inside the FFTs); as separate
-// functions every phase gets its own register allocation (4 spilled) and the calls — a few hundred per
+// functions every phase gets its own register allocation (a handful spilled) and the calls — a few hundred per
 // stream, each worth thousands of cycles — cost nothing measurable: 27.5 -> 25.0 ms per 16384 cfg3 streams.
 // The 512-point instance fits inlined and is faster that way (6.8 against 7.7 ms).
 template <int LOG2N>
@@ -390,15 +401,6 @@ __device__ __attribute__((noinline)) void acq_window_metric_call(AcqShared<LOG2N
                                                                  float* R1, float* R2) {
     acq_window_metric<LOG2N>(sh, ltw, win, dc_sum, P_out, R1, R2);
 }
-template <int LOG2N>
-__device__ __attribute__((noinline)) unsigned acq_refine_lts_call(AcqShared<LOG2N>& sh, const DemodConst& D,
-                                                                  const float* __restrict__ lts_I,
-                                                                  const float* __restrict__ lts_Q, float energy_ref,
-                                                                  const float* __restrict__ buf, unsigned size,
-                                                                  unsigned sts_start) {
-    return acq_refine_lts<LOG2N>(sh, D, lts_I, lts_Q, energy_ref, buf, size, sts_start);
-}
-
 template <int LOG2N>
 __global__ __launch_bounds__(kWave, (LOG2N == 10) ? 3 : 4) void acquire_kernel(
     const DemodConst* __restrict__ Dp, const c32* __restrict__ twiddle, const float* __restrict__ lts_I,
@@ -536,9 +538,9 @@ __global__ __launch_bounds__(kWave, (LOG2N == 10) ? 3 : 4) void acquire_kernel(
                 }
             }
             if (found_sync) {
-                unsigned refined;
-                if constexpr (kCalls) refined = acq_refine_lts_call<LOG2N>(sh, D, lts_I, lts_Q, energy_ref, buf, size, so);
-                else refined = acq_refine_lts<LOG2N>(sh, D, lts_I, lts_Q, energy_ref, buf, size, so);
+                // inlined in both instances: its templates then come through scalar loads (kernel arguments), out of
+                // line they are per-lane flat loads the loop waits for at every tap (22.2 against 20.1 ms)
+                const unsigned refined = acq_refine_lts<LOG2N>(sh, D, lts_I, lts_Q, energy_ref, buf, size, so);
                 if (refined == 0xffffffffu) {
                     if (size > kAcqOverlap * 2u) {
                         unsigned trim = so + psl;
