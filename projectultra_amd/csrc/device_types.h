@@ -64,7 +64,12 @@ struct LdpcConst {
 //   row_mask / act_mask random 32-bit masks of the syndrome filter (act_mask = xor of the row masks
 //                       of the variable's checks)
 //   row_col             variable index of each information edge (exact parity check, rare path)
-// The parity bit k+i of row i never touches LDS: its message stays in a register of the row's lane.
+// Rows are held in SLOT order: sorted by information degree, highest first (row_id[slot] = check index i, whose
+// parity bit is variable k + i), and the active variables likewise by degree, so that the lanes of a round have
+// (nearly) the same degree.  prof_* pack, four bits per round, the largest and the smallest degree of the
+// round's lanes (rows: over the rows that exist; variables: over all 64 lanes, an idle lane counting 0): the
+// kernel is instantiated on these profiles and touches exactly the slots a round has.
+// The parity bit of a row never touches LDS: its message stays in a register of the row's lane.
 constexpr int kLdpcPlanDmax = 14;
 constexpr int kLdpcPlanMaxActive = 576;
 constexpr int kLdpcPlanMaxRows = 512;
@@ -79,6 +84,9 @@ struct LdpcPlan {
     uint8_t act_deg[kLdpcPlanMaxActive];
     uint32_t act_mask[kLdpcPlanMaxActive];
     uint16_t act_addr[kLdpcPlanMaxActive * kLdpcPlanDmax];
+    uint16_t row_id[kLdpcPlanMaxRows];
+    uint64_t prof_rmax, prof_rmin, prof_vmax, prof_vmin;
+    int32_t row_identity, _pad2;
 };
 
 }  // namespace ultra_hip

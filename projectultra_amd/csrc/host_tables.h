@@ -217,33 +217,47 @@ inline int build_ldpc_plan(const LdpcConst& L, LdpcPlan& P) {
     P.k = L.k; P.m = L.m; P.n = L.n; P.edges = L.edges; P.max_iterations = L.max_iterations;
     P.decoded_bytes = L.decoded_bytes;
     if (L.m > kLdpcPlanMaxRows) return ULTRA_HIP_ERR_UNSUPPORTED;
-    bool rows_full = true;
-    for (int i = 0; i < L.m; ++i) {
+    // slots: rows by information degree, highest first (stable: equal degrees keep their order)
+    std::vector<int> slot_row(L.m), slot_of(L.m);
+    for (int i = 0; i < L.m; ++i) slot_row[i] = i;
+    std::stable_sort(slot_row.begin(), slot_row.end(), [&](int a, int b) {
+        return (L.row_ptr[a + 1] - L.row_ptr[a]) > (L.row_ptr[b + 1] - L.row_ptr[b]);
+    });
+    bool rows_full = true, identity = true;
+    for (int sl = 0; sl < L.m; ++sl) {
+        const int i = slot_row[sl];
+        slot_of[i] = sl;
+        identity = identity && i == sl;
         const int deg = L.row_ptr[i + 1] - L.row_ptr[i];
         if (deg < 2 || deg > 7) return ULTRA_HIP_ERR_UNSUPPORTED;          // 1..6 info bits + the parity bit
         if (L.col[L.row_ptr[i + 1] - 1] != L.k + i) return ULTRA_HIP_ERR_UNSUPPORTED;   // identity part last
-        P.row_deg[i] = (uint8_t)deg;
+        P.row_deg[sl] = (uint8_t)deg;
+        P.row_id[sl] = (uint16_t)i;
         rows_full = rows_full && deg == 7;
-        for (int t = 0; t < 6; ++t) { P.row_addr[6 * i + t] = 0xFFFF; P.row_col[6 * i + t] = 0xFFFF; }
+        for (int t = 0; t < 6; ++t) { P.row_addr[6 * sl + t] = 0xFFFF; P.row_col[6 * sl + t] = 0xFFFF; }
     }
+    P.row_identity = identity ? 1 : 0;
     for (int j = L.k; j < L.n; ++j)
         if (L.var_ptr[j + 1] - L.var_ptr[j] != 1) return ULTRA_HIP_ERR_UNSUPPORTED;
     int dmax = 0;
     for (int j = 0; j < L.k; ++j) dmax = std::max(dmax, (int)(L.var_ptr[j + 1] - L.var_ptr[j]));
     if (dmax > kLdpcPlanDmax) return ULTRA_HIP_ERR_UNSUPPORTED;
 
-    // active variables, full-degree ones first
-    std::vector<int> act_of(L.k, -1);
+    // active variables by degree, highest first
+    std::vector<int> act_of(L.k, -1), act_list;
+    for (int j = 0; j < L.k; ++j)
+        if (L.var_ptr[j + 1] - L.var_ptr[j] > 0) act_list.push_back(j);
+    std::stable_sort(act_list.begin(), act_list.end(), [&](int a, int b) {
+        return (L.var_ptr[a + 1] - L.var_ptr[a]) > (L.var_ptr[b + 1] - L.var_ptr[b]);
+    });
+    if ((int)act_list.size() > kLdpcPlanMaxActive) return ULTRA_HIP_ERR_UNSUPPORTED;
     int na = 0, n_full = 0;
-    for (int pass = 0; pass < 2; ++pass)
-        for (int j = 0; j < L.k; ++j) {
-            const int deg = L.var_ptr[j + 1] - L.var_ptr[j];
-            if (deg == 0 || (pass == 0) != (deg == dmax)) continue;
-            if (na >= kLdpcPlanMaxActive) return ULTRA_HIP_ERR_UNSUPPORTED;
-            act_of[j] = na; P.act_var[na] = (uint16_t)j; P.act_deg[na] = (uint8_t)deg;
-            ++na;
-            if (pass == 0) ++n_full;
-        }
+    for (int j : act_list) {
+        const int deg = L.var_ptr[j + 1] - L.var_ptr[j];
+        act_of[j] = na; P.act_var[na] = (uint16_t)j; P.act_deg[na] = (uint8_t)deg;
+        ++na;
+        if (deg == dmax) ++n_full;
+    }
 
     // syndrome-filter masks
     std::mt19937 mrng(0xF117E5u);
@@ -257,9 +271,10 @@ inline int build_ldpc_plan(const LdpcConst& L, LdpcPlan& P) {
         const int a = act_of[j];
         for (int q = 0; q < L.var_ptr[j + 1] - L.var_ptr[j]; ++q) {
             const int e = L.var_edge[L.var_ptr[j] + q];                     // ascending check order
-            int row = 0;
-            while (!(L.row_ptr[row] <= e && e < L.row_ptr[row + 1])) ++row;
-            const int t = e - L.row_ptr[row];
+            int check = 0;
+            while (!(L.row_ptr[check] <= e && e < L.row_ptr[check + 1])) ++check;
+            const int t = e - L.row_ptr[check];
+            const int row = slot_of[check];                                 // the row's slot
             info.push_back({row, t, a, q});
             const int cgroup = ((row / 64) * 6 + t) * 2 + ((row % 64) / 32);         // check-step half-wave
             const int vgroup = ((a / 64) * kLdpcPlanDmax + q) * 2 + ((a % 64) / 32);  // variable-step half-wave
@@ -285,6 +300,19 @@ inline int build_ldpc_plan(const LdpcConst& L, LdpcPlan& P) {
     P.var_rounds = (na + 63) / 64;
     P.var_rounds_full = n_full / 64;
     P.rows_full = rows_full ? 1 : 0;
+    if (P.row_rounds > 16 || P.var_rounds > 16) return ULTRA_HIP_ERR_UNSUPPORTED;
+    for (int r = 0; r < P.row_rounds; ++r) {                                // degree profiles, 4 bits per round
+        int mx = 0, mn = 15;
+        for (int sl = 64 * r; sl < std::min(L.m, 64 * r + 64); ++sl) { mx = std::max(mx, P.row_deg[sl] - 1); mn = std::min(mn, P.row_deg[sl] - 1); }
+        P.prof_rmax |= (uint64_t)mx << (4 * r);
+        P.prof_rmin |= (uint64_t)mn << (4 * r);
+    }
+    for (int r = 0; r < P.var_rounds; ++r) {
+        int mx = 0, mn = 15;
+        for (int a = 64 * r; a < 64 * r + 64; ++a) { const int d = (a < na) ? P.act_deg[a] : 0; mx = std::max(mx, d); mn = std::min(mn, d); }
+        P.prof_vmax |= (uint64_t)mx << (4 * r);
+        P.prof_vmin |= (uint64_t)mn << (4 * r);
+    }
     return ULTRA_HIP_OK;
 }
 

@@ -43,6 +43,8 @@
 #define ULTRA_LDPC_KERNEL_H
 
 #include <hip/hip_runtime.h>
+#include <type_traits>
+#include <utility>
 #include "device_types.h"
 
 namespace ultra_hip {
@@ -76,15 +78,73 @@ __device__ __forceinline__ unsigned wave_xor(unsigned v) {
            (unsigned)__builtin_amdgcn_readlane((int)v, 32) ^ (unsigned)__builtin_amdgcn_readlane((int)v, 48);
 }
 
-// RR = ceil(m / 64) row rounds, VR = ceil(n_active / 64) variable rounds, DMAX = max variable degree,
-// ROWS_FULL = every row has 6 information edges (R3/4, R5/6).  The first P.var_rounds_full
-// variable rounds hold only variables of degree DMAX in all 64 lanes (no predicates).
+// Leave-one-out minima of n magnitudes (bit patterns) under a cap: mn[i] = min(cap, min_{j != i} a[j]).
+// Unsigned minima are exact and associative, so any network gives the reference's value.  n = 7 (a full row:
+// six information edges and the parity bit) is the hand-counted 12-operation network; the general case runs a
+// prefix and a suffix chain.
+template <int n>
+__device__ __forceinline__ void leave_one_out_min(const unsigned (&a)[7], unsigned cap, unsigned (&mn)[7]) {
+    if constexpr (n == 7) {
+        const unsigned L2 = umin3(a[0], a[1], cap);             // min of edges 0..1
+        const unsigned L4 = umin3(L2, a[2], a[3]);              // 0..3
+        const unsigned L6 = umin3(L4, a[4], a[5]);              // 0..5
+        const unsigned R4 = umin3(a[5], a[6], cap);             // 5..6
+        const unsigned R3 = umin2(R4, a[4]);                    // 4..6
+        const unsigned R2 = umin3(R4, a[4], a[3]);              // 3..6
+        mn[0] = umin3(R2, a[2], a[1]);
+        mn[1] = umin3(a[0], R2, a[2]);
+        mn[2] = umin2(L2, R2);
+        mn[3] = umin3(L2, a[2], R3);
+        mn[4] = umin2(L4, R4);
+        mn[5] = umin3(L4, a[4], a[6]);
+        mn[6] = L6;
+    } else if constexpr (n == 2) {
+        mn[0] = umin2(a[1], cap);
+        mn[1] = umin2(a[0], cap);
+    } else if constexpr (n == 3) {
+        mn[0] = umin3(a[1], a[2], cap);
+        mn[1] = umin3(a[0], a[2], cap);
+        mn[2] = umin3(a[0], a[1], cap);
+    } else {
+        // pre[i] = min(cap, a[0..i-1]), suf[i] = min(a[i..n-1]); mn[i] = min(pre[i], suf[i+1])
+        unsigned pre[7], suf[7];
+        pre[0] = cap;
+#pragma unroll
+        for (int i = 1; i < n; ++i) pre[i] = umin2(pre[i - 1], a[i - 1]);
+        suf[n - 1] = a[n - 1];
+#pragma unroll
+        for (int i = n - 2; i >= 1; --i) suf[i] = umin2(suf[i + 1], a[i]);
+#pragma unroll
+        for (int i = 0; i < n - 1; ++i) mn[i] = umin2(pre[i], suf[i + 1]);
+        mn[n - 1] = pre[n - 1];
+    }
+}
+
+// compile-time loop: f(std::integral_constant<int, 0>), f(<1>), ... (the round index selects template arguments)
+template <int... Is, class F>
+__device__ __forceinline__ void ldpc_static_for(std::integer_sequence<int, Is...>, F&& f) {
+    (f(std::integral_constant<int, Is>{}), ...);
+}
+
+__host__ __device__ constexpr int ldpc_prof(unsigned long long p, int r) { return (int)((p >> (4 * r)) & 15ull); }
+__host__ __device__ constexpr int ldpc_prof_max(unsigned long long p, int n) {
+    int m = 0;
+    for (int r = 0; r < n; ++r) m = ldpc_prof(p, r) > m ? ldpc_prof(p, r) : m;
+    return m;
+}
+
+// RR = ceil(m / 64) row rounds, VR = ceil(n_active / 64) variable rounds.  RMAX / RMIN / VMAX / VMIN: the plan's
+// degree profiles (LdpcPlan::prof_*, four bits per round): round r of the check step touches information-edge
+// slots t < RMAX_r, without a per-lane test where t < RMIN_r; round r of the variable step touches edges
+// q < VMAX_r, unconditionally where q < VMIN_r.  ROW_ID: the rows are permuted (LdpcPlan::row_id).
 // WAVES = resident wavefronts per SIMD the register budget is sized for (5 -> 96 VGPRs, 4 -> 128, 3 -> 168).
-template <int RR, int VR, int DMAX, bool ROWS_FULL, bool WANT_TOTAL, int WAVES>
+template <int RR, int VR, unsigned long long RMAX, unsigned long long RMIN, unsigned long long VMAX,
+          unsigned long long VMIN, bool ROW_ID, bool WANT_TOTAL, int WAVES>
 __global__ __launch_bounds__(kLdpcThreads, WAVES) void ldpc_decode_kernel(
     const LdpcPlan* __restrict__ Pp, const float* __restrict__ llr, size_t llr_stride, int n_cw,
     uint8_t* __restrict__ bytes, int32_t* __restrict__ iters, uint8_t* __restrict__ okv,
     float* __restrict__ llr_total, unsigned int* __restrict__ work_counter, int llr_step) {
+    constexpr int DMAX = ldpc_prof_max(VMAX, VR);
     extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
     const LdpcPlan& P = *Pp;
     const int lane = threadIdx.x;
@@ -94,7 +154,7 @@ __global__ __launch_bounds__(kLdpcThreads, WAVES) void ldpc_decode_kernel(
     float* llr_s = reinterpret_cast<float*>(hard + 656);                 // [648] staging of the input
 
     // ---- per-lane slice of the Tanner graph, kept in registers for the whole launch ----
-    bool row_ok[RR];                // row exists
+    bool row_ok[RR];                // row (slot) exists
     int raddr[RR][6];               // LDS word address of information edge t of the row, -1 if none
     unsigned rmask[RR];
 #pragma unroll
@@ -104,6 +164,7 @@ __global__ __launch_bounds__(kLdpcThreads, WAVES) void ldpc_decode_kernel(
         rmask[r] = row_ok[r] ? P.row_mask[row] : 0u;
 #pragma unroll
         for (int t = 0; t < 6; ++t) {
+            if (t >= ldpc_prof(RMAX, r)) continue;
             const int a = row_ok[r] ? (int)P.row_addr[row * 6 + t] : 0xFFFF;
             raddr[r][t] = (a == 0xFFFF) ? -1 : a;
         }
@@ -118,8 +179,11 @@ __global__ __launch_bounds__(kLdpcThreads, WAVES) void ldpc_decode_kernel(
         var_deg[r] = on ? P.act_deg[a] : 0;
         vmask[r] = on ? P.act_mask[a] : 0u;
 #pragma unroll
-        for (int t = 0; t < DMAX; ++t) vaddr[r][t] = on ? P.act_addr[a * kLdpcPlanDmax + t] : 0;
+        for (int t = 0; t < DMAX; ++t)
+            if (t < ldpc_prof(VMAX, r)) vaddr[r][t] = on ? P.act_addr[a * kLdpcPlanDmax + t] : 0;
     }
+    // parity bit of the row in slot r * 64 + lane: variable k + row_id
+    auto parity_var = [&](int r) -> int { return k + (ROW_ID ? (int)P.row_id[r * 64 + lane] : r * 64 + lane); };
 
     // Work queue: kLdpcQueues interleaved queues (queue q serves codewords q, q + Q, q + 2Q, ...), each
     // with its own counter in its own cache line.  A single counter serialises in L2 at ~11.6 ns per
@@ -170,12 +234,15 @@ __global__ __launch_bounds__(kLdpcThreads, WAVES) void ldpc_decode_kernel(
             llr_v[r] = llr_s[var_j[r]];
             hv[r] = false;
 #pragma unroll
-            for (int t = 0; t < DMAX; ++t)
-                if (t < var_deg[r]) msg[vaddr[r][t]] = llr_v[r];              // v2c = llr_in[col]
+            for (int t = 0; t < DMAX; ++t) {                                   // v2c = llr_in[col]
+                if (t >= ldpc_prof(VMAX, r)) continue;
+                if (t < ldpc_prof(VMIN, r)) msg[vaddr[r][t]] = llr_v[r];
+                else if (t < var_deg[r]) msg[vaddr[r][t]] = llr_v[r];
+            }
         }
 #pragma unroll
         for (int r = 0; r < RR; ++r) {
-            llr_p[r] = row_ok[r] ? llr_s[k + r * 64 + lane] : 0.0f;
+            llr_p[r] = row_ok[r] ? llr_s[parity_var(r)] : 0.0f;
             vpar[r] = llr_p[r];                                                // v2c of the parity bit
             hpar[r] = false;
         }
@@ -218,95 +285,81 @@ __global__ __launch_bounds__(kLdpcThreads, WAVES) void ldpc_decode_kernel(
             // (FLT_MAX in iteration 0, whose inputs are the unclamped channel values).
             unsigned f = 0u;                                               // this lane's share of the syndrome filter
             const unsigned cap = (it == 0) ? 0x7f7fffffu : 0x42480000u;    // FLT_MAX : 50.0f
-#pragma unroll
-            for (int r = 0; r < RR; ++r) {
+            ldpc_static_for(std::make_integer_sequence<int, RR>{}, [&](auto round) {
+                constexpr int r = decltype(round)::value;
                 if (row_ok[r]) {
+                    constexpr int rmax = ldpc_prof(RMAX, r), rmin = ldpc_prof(RMIN, r);   // information-edge slots of the round
                     float v[7];
 #pragma unroll
                     for (int t = 0; t < 6; ++t) {
-                        if (ROWS_FULL) v[t] = msg[raddr[r][t]];
+                        if (t >= rmax) continue;
+                        if (t < rmin) v[t] = msg[raddr[r][t]];
                         else v[t] = (raddr[r][t] >= 0) ? msg[raddr[r][t]] : kFltMax;   // missing edge: neutral
                     }
-                    v[6] = vpar[r];
+                    v[rmax] = vpar[r];
                     // Signs as lane masks (SGPR pairs): the row parity and each edge's "all others"
                     // sign are scalar xors; the sign is applied with one select between mag and -mag.
                     // Magnitudes as unsigned integers (|x| bit patterns order like the values; NaN and
                     // inf patterns exceed FLT_MAX's, so capping at FLT_MAX ignores them exactly as the
-                    // reference's `abs < min` update starting from FLT_MAX does).  Leave-one-out minima
-                    // of 7 values in 12 min/min3 operations.
-                    unsigned a[7];
+                    // reference's `abs < min` update starting from FLT_MAX does).
+                    unsigned a[7], mn[7];
                     bool ng[7], par = false;
 #pragma unroll
-                    for (int t = 0; t < 7; ++t) {
+                    for (int t = 0; t <= rmax; ++t) {
                         a[t] = __float_as_uint(v[t]) & 0x7fffffffu;
                         ng[t] = v[t] < 0;
                         par ^= ng[t];
                     }
-                    const unsigned L2 = umin3(a[0], a[1], cap);             // min of edges 0..1
-                    const unsigned L4 = umin3(L2, a[2], a[3]);              // 0..3
-                    const unsigned L6 = umin3(L4, a[4], a[5]);              // 0..5
-                    const unsigned R4 = umin3(a[5], a[6], cap);             // 5..6
-                    const unsigned R3 = umin2(R4, a[4]);                    // 4..6
-                    const unsigned R2 = umin3(R4, a[4], a[3]);              // 3..6
-                    unsigned mn[7];
-                    mn[0] = umin3(R2, a[2], a[1]);
-                    mn[1] = umin3(a[0], R2, a[2]);
-                    mn[2] = umin2(L2, R2);
-                    mn[3] = umin3(L2, a[2], R3);
-                    mn[4] = umin2(L4, R4);
-                    mn[5] = umin3(L4, a[4], a[6]);
-                    mn[6] = L6;
+                    leave_one_out_min<rmax + 1>(a, cap, mn);
 #pragma unroll
                     for (int t = 0; t < 6; ++t) {
+                        if (t >= rmax) continue;
                         const float mag = __uint_as_float(mn[t]) * 0.75f;
                         const float c = (par != ng[t]) ? -mag : mag;           // sign * min * 0.75f
-                        if (ROWS_FULL) msg[raddr[r][t]] = c;
+                        if (t < rmin) msg[raddr[r][t]] = c;
                         else if (raddr[r][t] >= 0) msg[raddr[r][t]] = c;
                     }
-                    const float mag6 = __uint_as_float(mn[6]) * 0.75f;
-                    const float c_last = (par != ng[6]) ? -mag6 : mag6;
-                    const float total_p = llr_p[r] + c_last;               // parity bit k+row
+                    const float mag6 = __uint_as_float(mn[rmax]) * 0.75f;
+                    const float c_last = (par != ng[rmax]) ? -mag6 : mag6;
+                    const float total_p = llr_p[r] + c_last;               // parity bit of the row
                     hpar[r] = total_p < 0;
                     f ^= hpar[r] ? rmask[r] : 0u;
                     vpar[r] = total_p - c_last;                            // clamp deferred, see `cap`
-                    if (WANT_TOTAL) llr_total[(size_t)cw * kLdpcN + k + r * 64 + lane] = total_p;
+                    if (WANT_TOTAL) llr_total[(size_t)cw * kLdpcN + parity_var(r)] = total_p;
                 }
-            }
+            });
             __syncthreads();
             // ---- totals + variable step for the information bits that have checks ----
-#pragma unroll
-            for (int r = 0; r < VR; ++r) {
-                if (r < P.var_rounds_full) {                               // wave-uniform: all 64 lanes, degree DMAX
+            ldpc_static_for(std::make_integer_sequence<int, VR>{}, [&](auto round) {
+                constexpr int r = decltype(round)::value;
+                constexpr int vmax = ldpc_prof(VMAX, r), vmin = ldpc_prof(VMIN, r);
+                const int d = var_deg[r];
+                if (vmin > 0 || d > 0) {                                   // vmin > 0: all 64 lanes hold a variable
                     float c[DMAX];
 #pragma unroll
-                    for (int t = 0; t < DMAX; ++t) c[t] = msg[vaddr[r][t]];
+                    for (int t = 0; t < DMAX; ++t) {
+                        if (t >= vmax) continue;
+                        if (t < vmin) c[t] = msg[vaddr[r][t]];
+                        else c[t] = (t < d) ? msg[vaddr[r][t]] : 0.0f;
+                    }
                     float tot = llr_v[r];
 #pragma unroll
-                    for (int t = 0; t < DMAX; ++t) tot += c[t];             // ascending check order
+                    for (int t = 0; t < DMAX; ++t) {                       // ascending check order
+                        if (t >= vmax) continue;
+                        if (t < vmin) tot += c[t];
+                        else if (t < d) tot += c[t];
+                    }
                     hv[r] = tot < 0;
                     f ^= hv[r] ? vmask[r] : 0u;
 #pragma unroll
-                    for (int t = 0; t < DMAX; ++t) msg[vaddr[r][t]] = tot - c[t];   // clamp deferred to the reader
-                    if (WANT_TOTAL) llr_total[(size_t)cw * kLdpcN + var_j[r]] = tot;
-                } else {
-                    const int d = var_deg[r];
-                    if (d > 0) {
-                        float c[DMAX];
-#pragma unroll
-                        for (int t = 0; t < DMAX; ++t) c[t] = (t < d) ? msg[vaddr[r][t]] : 0.0f;
-                        float tot = llr_v[r];
-#pragma unroll
-                        for (int t = 0; t < DMAX; ++t)
-                            if (t < d) tot += c[t];                        // ascending check order
-                        hv[r] = tot < 0;
-                        f ^= hv[r] ? vmask[r] : 0u;
-#pragma unroll
-                        for (int t = 0; t < DMAX; ++t)
-                            if (t < d) msg[vaddr[r][t]] = tot - c[t];
-                        if (WANT_TOTAL) llr_total[(size_t)cw * kLdpcN + var_j[r]] = tot;
+                    for (int t = 0; t < DMAX; ++t) {                       // clamp deferred to the reader
+                        if (t >= vmax) continue;
+                        if (t < vmin) msg[vaddr[r][t]] = tot - c[t];
+                        else if (t < d) msg[vaddr[r][t]] = tot - c[t];
                     }
+                    if (WANT_TOTAL) llr_total[(size_t)cw * kLdpcN + var_j[r]] = tot;
                 }
-            }
+            });
             F = wave_xor(f);
             __syncthreads();
             ++it;

@@ -242,7 +242,7 @@ __global__ __launch_bounds__(kWave, 2) void stimulus_kernel(
                 unsigned char s = 0;
 #pragma unroll
                 for (int t = 0; t < 6; ++t) { const unsigned col = L.row_col[i * 6 + t]; if (col != 0xFFFFu) s ^= sh.bits[c * kLdpcN + col]; }
-                sh.bits[c * kLdpcN + k + i] = s;
+                sh.bits[c * kLdpcN + k + L.row_id[i]] = s;                   // plan rows are slots: parity bit of check row_id[i]
             }
         }
         wave_sync();
