@@ -241,14 +241,13 @@ int launch_ldpc(ultra_hip_ctx* ctx, const float* d_llr, size_t llr_stride, size_
                                (int)ctx->deint_step);                                                           \
     } while (0)
     // One instance per degree profile of the reference's six codes (LdpcPlan::prof_*, four bits per round, round 0
-    // lowest; tools/ldpc_plan_check.cpp prints them): the kernel touches exactly the edge slots a round has.  A
-    // graph with another profile runs on a generic instance of its shape (every slot tested per lane).
+    // lowest; tools/ldpc_plan_check.cpp prints them): the kernel touches exactly the edge slots a round has.  The
+    // API takes no other graph (code_rate selects one of the six); a plan that matches none is refused.
     // Register budgets (last argument: wavefronts per SIMD) measured with tools/ldpc_bench.py.
     auto is = [&](int rr, int vr, uint64_t rmax, uint64_t rmin, uint64_t vmax, uint64_t vmin, bool rid) {
         return P.row_rounds == rr && P.var_rounds == vr && P.prof_rmax == rmax && P.prof_rmin == rmin &&
                P.prof_vmax == vmax && P.prof_vmin == vmin && (P.row_identity == 0) == rid;
     };
-    auto fits = [&](int rr, int vr, int dm) { return P.row_rounds <= rr && P.var_rounds <= vr && P.dmax <= dm; };
     if (is(2, 4, 0x66ull, 0x66ull, 0x3333ull, 0x333ull, false))                                                 // R5/6
         UH_LDPC_LAUNCH(2, 4, 0x66ull, 0x66ull, 0x3333ull, 0x333ull, false, 5);
     else if (is(3, 6, 0x666ull, 0x666ull, 0x333333ull, 0x33333ull, false))                                      // R3/4
@@ -261,9 +260,6 @@ int launch_ldpc(ultra_hip_ctx* ctx, const float* d_llr, size_t llr_stride, size_
         UH_LDPC_LAUNCH(6, 6, 0x133566ull, 0x113356ull, 0x444446ull, 0x44444ull, true, 4);
     else if (is(8, 3, 0x22345566ull, 0x12234566ull, 0xccdull, 0xccull, true))                                   // R1/4
         UH_LDPC_LAUNCH(8, 3, 0x22345566ull, 0x12234566ull, 0xccdull, 0xccull, true, 3);
-    else if (fits(4, 7, 3)) UH_LDPC_LAUNCH(4, 7, 0x6666ull, 0ull, 0x3333333ull, 0ull, true, 4);                 // generic shapes
-    else if (fits(6, 6, 6)) UH_LDPC_LAUNCH(6, 6, 0x666666ull, 0ull, 0x666666ull, 0ull, true, 4);
-    else if (fits(8, 3, 14)) UH_LDPC_LAUNCH(8, 3, 0x66666666ull, 0ull, 0xeeeull, 0ull, true, 3);
     else return ULTRA_HIP_ERR_UNSUPPORTED;
 #undef UH_LDPC_LAUNCH
     UH_HIP(hipGetLastError());

@@ -24,6 +24,13 @@ int main() {
         int info_edges = L.edges - L.m;
         printf("rate %u rc %d info_edges %d unique_addr %zu msg_words %d row_rounds %d var_rounds %d (full %d) rows_full %d dmax %d conflicts %d\n",
                rate, rc, info_edges, used.size(), P.msg_words, P.row_rounds, P.var_rounds, P.var_rounds_full, P.rows_full, P.dmax, bad);
+        printf("        profile: rmax 0x%llxull rmin 0x%llxull vmax 0x%llxull vmin 0x%llxull row_identity %d\n",
+               (unsigned long long)P.prof_rmax, (unsigned long long)P.prof_rmin, (unsigned long long)P.prof_vmax,
+               (unsigned long long)P.prof_vmin, P.row_identity);
+        // row_id is a permutation of the checks and the slots are sorted by degree
+        std::set<int> ids;
+        for (int sl = 0; sl < L.m; sl++) { ids.insert(P.row_id[sl]); if (sl > 0 && P.row_deg[sl] > P.row_deg[sl - 1]) bad++; }
+        if ((int)ids.size() != L.m) bad++;
         if (rc != 0 || bad != 0 || (int)used.size() != info_edges) total_bad++;
     }
     return total_bad ? 1 : 0;

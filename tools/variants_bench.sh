@@ -5,6 +5,6 @@ cp projectultra_amd/libultra_hip.so /tmp/libultra_hip.keep
 for v in build/v_*.so; do
   cp $v projectultra_amd/libultra_hip.so
   echo "== $v"
-  ${@:-python3 tools/acquire_bench.py 4096} 2>&1 | grep -E "fft|Error|error" 
+  ${@:-python3 tools/acquire_bench.py 4096} 2>&1 | grep -v "amdgpu.ids"
 done
 cp /tmp/libultra_hip.keep projectultra_amd/libultra_hip.so
