@@ -45,3 +45,25 @@ def test_ldpc_plan_is_conflict_free(tmp_path):
     out = subprocess.run([str(exe)], capture_output=True, text=True, timeout=300)
     assert out.returncode == 0, out.stdout + out.stderr
     assert out.stdout.count("conflicts 0") == 6, out.stdout
+
+
+def test_ldpc_kernel_instances_cover_the_six_profiles(tmp_path):
+    """The LDPC kernel is instantiated per degree profile (csrc/ultra_hip.hip, UH_LDPC_LAUNCH); a plan
+    whose profile matches no instance is refused at run time.  Checked here without a GPU: every rate's
+    profile as the plan builder computes it names one instance of the dispatcher, with the slots sorted
+    by degree and row_id a permutation (the checker's own exit code)."""
+    import re
+    exe = tmp_path / "lpc"
+    subprocess.check_call(["g++", "-O1", "-std=c++17", "-I" + str(ROOT / "projectultra_amd" / "csrc"),
+                           str(ROOT / "tools" / "ldpc_plan_check.cpp"), "-o", str(exe)])
+    out = subprocess.run([str(exe)], capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stdout + out.stderr
+    profiles = re.findall(r"profile: rmax (0x[0-9a-f]+ull) rmin (0x[0-9a-f]+ull) vmax (0x[0-9a-f]+ull) "
+                          r"vmin (0x[0-9a-f]+ull) row_identity (\d)", out.stdout)
+    assert len(profiles) == 6, out.stdout
+    src = (ROOT / "projectultra_amd" / "csrc" / "ultra_hip.hip").read_text()
+    launches = re.findall(r"UH_LDPC_LAUNCH\(\d+, \d+, (0x[0-9a-f]+ull), (0x[0-9a-f]+ull), (0x[0-9a-f]+ull), "
+                          r"(0x[0-9a-f]+ull), (true|false), \d\);", src)
+    have = {(a, b, c, d, rid == "true") for a, b, c, d, rid in launches}
+    for rmax, rmin, vmax, vmin, ident in profiles:
+        assert (rmax, rmin, vmax, vmin, ident == "0") in have, (rmax, rmin, vmax, vmin, ident)
