@@ -69,6 +69,12 @@ struct LdpcConst {
 // (nearly) the same degree.  prof_* pack, four bits per round, the largest and the smallest degree of the
 // round's lanes (rows: over the rows that exist; variables: over all 64 lanes, an idle lane counting 0): the
 // kernel is instantiated on these profiles and touches exactly the slots a round has.
+// linear != 0 (codes whose rows all have six information edges and whose variables all have the same degree but a
+// few): the message of edge q of the variable in lane l of round r lives at word (r * dmax + q) * 64 + l, so the
+// variable step reads lane-linearly and stores with ds_write_addtid_b32 (no address registers, half the store
+// cost); the variables' lanes and the rows' half-waves are then chosen on the host so that the CHECK step's
+// gathers still meet 32 distinct banks (build_ldpc_plan_linear).  Row slots / variable slots may then have gaps:
+// a slot exists iff row_deg / act_deg is non-zero.
 // The parity bit of a row never touches LDS: its message stays in a register of the row's lane.
 constexpr int kLdpcPlanDmax = 14;
 constexpr int kLdpcPlanMaxActive = 576;
@@ -86,7 +92,7 @@ struct LdpcPlan {
     uint16_t act_addr[kLdpcPlanMaxActive * kLdpcPlanDmax];
     uint16_t row_id[kLdpcPlanMaxRows];
     uint64_t prof_rmax, prof_rmin, prof_vmax, prof_vmin;
-    int32_t row_identity, _pad2;
+    int32_t row_identity, linear;
 };
 
 }  // namespace ultra_hip

@@ -212,7 +212,162 @@ inline uint32_t channel_interleaver_step(uint32_t bits_per_symbol, uint32_t tota
     return (uint32_t)(n + 1);
 }
 
-inline int build_ldpc_plan(const LdpcConst& L, LdpcPlan& P) {
+// The lane-linear layout (LdpcPlan::linear).  Every edge of the variable in lane l has LDS bank l mod 32, so the
+// check step's gather of slot t over a half-wave of rows is conflict-free iff those rows' t-th edges go to
+// variables of 32 different banks.  Rows are dealt into the 2 * row_rounds half-waves evenly (27 of 32 lanes for
+// the codes at hand, which is the slack that makes this solvable), variables into banks under the capacity of two
+// lanes per round and bank, and a short annealing run swaps variables between banks and rows between half-waves
+// until no (half-wave, bank) cell holds more than six edges; a bipartite multigraph of maximum degree six is
+// six-edge-colourable (Koenig), which then gives every edge of a half-wave its slot.  Deterministic (fixed seeds).
+// Returns ULTRA_HIP_ERR_UNSUPPORTED when the code does not qualify or no assignment was found.
+inline int build_ldpc_plan_linear(const LdpcConst& L, LdpcPlan& P) {
+    P = LdpcPlan{};
+    P.k = L.k; P.m = L.m; P.n = L.n; P.edges = L.edges; P.max_iterations = L.max_iterations;
+    P.decoded_bytes = L.decoded_bytes;
+    for (int i = 0; i < L.m; ++i) {
+        if (L.row_ptr[i + 1] - L.row_ptr[i] != 7) return ULTRA_HIP_ERR_UNSUPPORTED;      // six information edges + parity
+        if (L.col[L.row_ptr[i + 1] - 1] != L.k + i) return ULTRA_HIP_ERR_UNSUPPORTED;
+    }
+    for (int j = L.k; j < L.n; ++j)
+        if (L.var_ptr[j + 1] - L.var_ptr[j] != 1) return ULTRA_HIP_ERR_UNSUPPORTED;
+    auto vdeg = [&](int j) { return (int)(L.var_ptr[j + 1] - L.var_ptr[j]); };
+    std::vector<int> act_list;
+    int dmax = 0;
+    for (int j = 0; j < L.k; ++j) if (vdeg(j) > 0) { act_list.push_back(j); dmax = std::max(dmax, vdeg(j)); }
+    std::stable_sort(act_list.begin(), act_list.end(), [&](int a, int b) { return vdeg(a) > vdeg(b); });
+    const int na = (int)act_list.size();
+    const int VR = (na + 63) / 64, RR = (L.m + 63) / 64, NG = 2 * RR;
+    if (dmax > 4 || VR > 9 || RR > 8 || VR * 64 > kLdpcPlanMaxActive) return ULTRA_HIP_ERR_UNSUPPORTED;
+    const int per_group = (L.m + NG - 1) / NG;
+    if (per_group > 32) return ULTRA_HIP_ERR_UNSUPPORTED;
+    const int n_fullv = (VR - 1) * 64;                        // variables of the full rounds (sorted order)
+    for (int a = 0; a < n_fullv; ++a) if (vdeg(act_list[a]) != dmax) return ULTRA_HIP_ERR_UNSUPPORTED;
+
+    // rows of each variable (information edges only)
+    std::vector<std::vector<int>> var_rows(L.k);
+    for (int i = 0; i < L.m; ++i)
+        for (int e = L.row_ptr[i]; e + 1 < L.row_ptr[i + 1]; ++e) var_rows[L.col[e]].push_back(i);
+
+    std::mt19937 rng(0x1DEA5u);
+    std::vector<int> bank(L.k, -1), grp(L.m);
+    // initial deal: full-round variables round-robin over the banks (capacity 2 * (VR - 1) each), the last round's
+    // variables over distinct banks; rows round-robin over the half-waves
+    for (int a = 0; a < na; ++a) bank[act_list[a]] = (a < n_fullv) ? a % 32 : (a - n_fullv) % 32;
+    for (int i = 0; i < L.m; ++i) grp[i] = i % NG;
+    std::vector<int> cnt(NG * 32, 0);
+    for (int i = 0; i < L.m; ++i)
+        for (int e = L.row_ptr[i]; e + 1 < L.row_ptr[i + 1]; ++e) cnt[grp[i] * 32 + bank[L.col[e]]]++;
+    auto over = [](int c) { return c > 6 ? c - 6 : 0; };
+    long cost = 0;
+    for (int c : cnt) cost += over(c);
+    double T = 1.0;
+    auto bump = [&](int g, int b, int s) { const int o = over(cnt[g * 32 + b]); cnt[g * 32 + b] += s; return over(cnt[g * 32 + b]) - o; };
+    std::uniform_real_distribution<double> U(0.0, 1.0);
+    for (long it = 0; cost > 0 && it < 4000000; ++it) {
+        long d = 0;
+        if (U(rng) < 0.6) {
+            // swap the banks of two variables of the same capacity class (both full-round or both last-round)
+            const int a1 = (int)(rng() % na), a2 = (int)(rng() % na);
+            if ((a1 < n_fullv) != (a2 < n_fullv)) continue;
+            const int v = act_list[a1], w = act_list[a2], bv = bank[v], bw = bank[w];
+            if (bv == bw) continue;
+            for (int r : var_rows[v]) { d += bump(grp[r], bv, -1); d += bump(grp[r], bw, +1); }
+            for (int r : var_rows[w]) { d += bump(grp[r], bw, -1); d += bump(grp[r], bv, +1); }
+            if (d <= 0 || U(rng) < std::exp(-(double)d / T)) { bank[v] = bw; bank[w] = bv; cost += d; }
+            else {
+                for (int r : var_rows[v]) { bump(grp[r], bv, +1); bump(grp[r], bw, -1); }
+                for (int r : var_rows[w]) { bump(grp[r], bw, +1); bump(grp[r], bv, -1); }
+            }
+        } else {
+            const int r1 = (int)(rng() % L.m), r2 = (int)(rng() % L.m), g1 = grp[r1], g2 = grp[r2];
+            if (g1 == g2) continue;
+            for (int e = L.row_ptr[r1]; e + 1 < L.row_ptr[r1 + 1]; ++e) { d += bump(g1, bank[L.col[e]], -1); d += bump(g2, bank[L.col[e]], +1); }
+            for (int e = L.row_ptr[r2]; e + 1 < L.row_ptr[r2 + 1]; ++e) { d += bump(g2, bank[L.col[e]], -1); d += bump(g1, bank[L.col[e]], +1); }
+            if (d <= 0 || U(rng) < std::exp(-(double)d / T)) { grp[r1] = g2; grp[r2] = g1; cost += d; }
+            else {
+                for (int e = L.row_ptr[r1]; e + 1 < L.row_ptr[r1 + 1]; ++e) { bump(g1, bank[L.col[e]], +1); bump(g2, bank[L.col[e]], -1); }
+                for (int e = L.row_ptr[r2]; e + 1 < L.row_ptr[r2 + 1]; ++e) { bump(g2, bank[L.col[e]], +1); bump(g1, bank[L.col[e]], -1); }
+            }
+        }
+        T = std::max(0.05, T * 0.99999);
+    }
+    if (cost > 0) return ULTRA_HIP_ERR_UNSUPPORTED;
+
+    // variable slots: bank b owns lanes b and b + 32 of every round
+    std::vector<int> act_of(L.k, -1);
+    {
+        std::vector<int> used_full(32, 0), used_last(32, 0);
+        for (int a = 0; a < na; ++a) {
+            const int j = act_list[a], b = bank[j];
+            int slot;
+            if (a < n_fullv) { const int u = used_full[b]++; slot = (u / 2) * 64 + b + 32 * (u % 2); if (u / 2 >= VR - 1) return ULTRA_HIP_ERR_UNSUPPORTED; }
+            else { const int u = used_last[b]++; if (u >= 2) return ULTRA_HIP_ERR_UNSUPPORTED; slot = (VR - 1) * 64 + b + 32 * u; }
+            act_of[j] = slot;
+            P.act_var[slot] = (uint16_t)j; P.act_deg[slot] = (uint8_t)vdeg(j);
+        }
+    }
+    // row slots: half-wave g = lanes 32 * (g % 2) .. of round g / 2
+    std::vector<int> slot_of(L.m);
+    {
+        std::vector<int> used(NG, 0);
+        for (int i = 0; i < L.m; ++i) {
+            const int g = grp[i], u = used[g]++;
+            if (u >= 32) return ULTRA_HIP_ERR_UNSUPPORTED;
+            slot_of[i] = (g / 2) * 64 + (g % 2) * 32 + u;
+        }
+    }
+    for (int sl = 0; sl < RR * 64; ++sl)
+        for (int t = 0; t < 6; ++t) { P.row_addr[6 * sl + t] = 0xFFFF; P.row_col[6 * sl + t] = 0xFFFF; }
+    std::mt19937 mrng(0xF117E5u);
+    std::vector<uint32_t> mask_of(L.m);
+    for (int i = 0; i < L.m; ++i) mask_of[i] = (uint32_t)mrng();
+    bool identity = true;
+    for (int i = 0; i < L.m; ++i) {
+        const int sl = slot_of[i];
+        P.row_deg[sl] = 7; P.row_id[sl] = (uint16_t)i; P.row_mask[sl] = mask_of[i];
+        identity = identity && sl == i;
+    }
+    // slots of the edges: per half-wave a six-edge-colouring of rows x banks
+    std::vector<int> q_of_edge(L.edges, -1);                  // position of the edge among its variable's edges (ascending check)
+    for (int j = 0; j < L.k; ++j)
+        for (int q = 0; q < vdeg(j); ++q) q_of_edge[L.var_edge[L.var_ptr[j] + q]] = q;
+    for (int g = 0; g < NG; ++g) {
+        std::vector<int> rows_g;
+        for (int i = 0; i < L.m; ++i) if (grp[i] == g) rows_g.push_back(i);
+        std::vector<std::pair<int, int>> ed;
+        std::vector<int> eid;
+        for (size_t li = 0; li < rows_g.size(); ++li)
+            for (int e = L.row_ptr[rows_g[li]]; e + 1 < L.row_ptr[rows_g[li] + 1]; ++e) { ed.push_back({(int)li, bank[L.col[e]]}); eid.push_back(e); }
+        std::vector<int> colour;
+        bipartite_edge_colouring((int)rows_g.size(), 32, ed, 6, colour);
+        for (size_t x = 0; x < ed.size(); ++x) {
+            const int e = eid[x], i = rows_g[ed[x].first], t = colour[x], j = L.col[e], a = act_of[j], q = q_of_edge[e];
+            if (t < 0 || t >= 6 || q < 0) return ULTRA_HIP_ERR_UNSUPPORTED;
+            const int addr = ((a / 64) * dmax + q) * 64 + (a % 64);
+            P.row_addr[6 * slot_of[i] + t] = (uint16_t)addr;
+            P.row_col[6 * slot_of[i] + t] = (uint16_t)j;
+            P.act_addr[a * kLdpcPlanDmax + q] = (uint16_t)addr;
+            P.act_mask[a] ^= mask_of[i];
+        }
+    }
+    P.msg_words = VR * dmax * 64;
+    P.n_active = na; P.dmax = dmax;
+    P.row_rounds = RR; P.var_rounds = VR;
+    P.var_rounds_full = VR - 1; P.rows_full = 1;
+    P.row_identity = identity ? 1 : 0;
+    P.linear = 1;
+    for (int r = 0; r < RR; ++r) { P.prof_rmax |= 6ull << (4 * r); P.prof_rmin |= 6ull << (4 * r); }
+    for (int r = 0; r < VR; ++r) {
+        int mx = 0, mn = 15;
+        for (int a = 64 * r; a < 64 * r + 64; ++a) { mx = std::max(mx, (int)P.act_deg[a]); mn = std::min(mn, (int)P.act_deg[a]); }
+        P.prof_vmax |= (uint64_t)mx << (4 * r);
+        P.prof_vmin |= (uint64_t)mn << (4 * r);
+    }
+    return ULTRA_HIP_OK;
+}
+
+inline int build_ldpc_plan(const LdpcConst& L, LdpcPlan& P, bool allow_linear = true) {
+    if (allow_linear && build_ldpc_plan_linear(L, P) == ULTRA_HIP_OK) return ULTRA_HIP_OK;
     P = LdpcPlan{};
     P.k = L.k; P.m = L.m; P.n = L.n; P.edges = L.edges; P.max_iterations = L.max_iterations;
     P.decoded_bytes = L.decoded_bytes;

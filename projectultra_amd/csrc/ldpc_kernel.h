@@ -138,8 +138,9 @@ __host__ __device__ constexpr int ldpc_prof_max(unsigned long long p, int n) {
 // slots t < RMAX_r, without a per-lane test where t < RMIN_r; round r of the variable step touches edges
 // q < VMAX_r, unconditionally where q < VMIN_r.  ROW_ID: the rows are permuted (LdpcPlan::row_id).
 // WAVES = resident wavefronts per SIMD the register budget is sized for (5 -> 96 VGPRs, 4 -> 128, 3 -> 168).
+// LINEAR: the plan's lane-linear layout (LdpcPlan::linear): the variable step addresses its messages by lane.
 template <int RR, int VR, unsigned long long RMAX, unsigned long long RMIN, unsigned long long VMAX,
-          unsigned long long VMIN, bool ROW_ID, bool WANT_TOTAL, int WAVES>
+          unsigned long long VMIN, bool ROW_ID, bool LINEAR, bool WANT_TOTAL, int WAVES>
 __global__ __launch_bounds__(kLdpcThreads, WAVES) void ldpc_decode_kernel(
     const LdpcPlan* __restrict__ Pp, const float* __restrict__ llr, size_t llr_stride, int n_cw,
     uint8_t* __restrict__ bytes, int32_t* __restrict__ iters, uint8_t* __restrict__ okv,
@@ -160,7 +161,7 @@ __global__ __launch_bounds__(kLdpcThreads, WAVES) void ldpc_decode_kernel(
 #pragma unroll
     for (int r = 0; r < RR; ++r) {
         const int row = r * 64 + lane;
-        row_ok[r] = row < m;
+        row_ok[r] = P.row_deg[row] != 0;                       // slots may have gaps (linear layout)
         rmask[r] = row_ok[r] ? P.row_mask[row] : 0u;
 #pragma unroll
         for (int t = 0; t < 6; ++t) {
@@ -174,14 +175,29 @@ __global__ __launch_bounds__(kLdpcThreads, WAVES) void ldpc_decode_kernel(
 #pragma unroll
     for (int r = 0; r < VR; ++r) {
         const int a = r * 64 + lane;
-        const bool on = a < P.n_active;
+        const bool on = P.act_deg[a] != 0;
         var_j[r] = on ? P.act_var[a] : 0;
         var_deg[r] = on ? P.act_deg[a] : 0;
         vmask[r] = on ? P.act_mask[a] : 0u;
 #pragma unroll
         for (int t = 0; t < DMAX; ++t)
-            if (t < ldpc_prof(VMAX, r)) vaddr[r][t] = on ? P.act_addr[a * kLdpcPlanDmax + t] : 0;
+            if (!LINEAR && t < ldpc_prof(VMAX, r)) vaddr[r][t] = on ? P.act_addr[a * kLdpcPlanDmax + t] : 0;
     }
+    // Message of edge t of the variable in this lane of round r.  LINEAR: word (r * DMAX + t) * 64 + lane — the
+    // load is a lane-linear ds_read_b32 with an immediate offset, the store a ds_write_addtid_b32 (address = M0 +
+    // offset + 4 * lane: no address register, 2 instead of 4 LDS cycles).
+    const unsigned msg_lds = (unsigned)(size_t)msg;           // LDS byte address of the message array
+    auto vload = [&](int r, int t) -> float { return LINEAR ? msg[(r * DMAX + t) * 64 + lane] : msg[vaddr[r][t]]; };
+    auto vstore = [&](int r, int t, float x) {
+        if constexpr (LINEAR) {
+            // s_nop: the wait state the hardware needs between an SALU write of M0 and an add-TID LDS instruction
+            // (the compiler's hazard recogniser does not look inside the asm)
+            asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tds_write_addtid_b32 %0"
+                         :: "v"(x), "s"(msg_lds + (unsigned)((r * DMAX + t) * 256)) : "m0", "memory");
+        } else {
+            msg[vaddr[r][t]] = x;
+        }
+    };
     // parity bit of the row in slot r * 64 + lane: variable k + row_id
     auto parity_var = [&](int r) -> int { return k + (ROW_ID ? (int)P.row_id[r * 64 + lane] : r * 64 + lane); };
 
@@ -236,8 +252,8 @@ __global__ __launch_bounds__(kLdpcThreads, WAVES) void ldpc_decode_kernel(
 #pragma unroll
             for (int t = 0; t < DMAX; ++t) {                                   // v2c = llr_in[col]
                 if (t >= ldpc_prof(VMAX, r)) continue;
-                if (t < ldpc_prof(VMIN, r)) msg[vaddr[r][t]] = llr_v[r];
-                else if (t < var_deg[r]) msg[vaddr[r][t]] = llr_v[r];
+                if (t < ldpc_prof(VMIN, r)) vstore(r, t, llr_v[r]);
+                else if (t < var_deg[r]) vstore(r, t, llr_v[r]);
             }
         }
 #pragma unroll
@@ -339,8 +355,8 @@ __global__ __launch_bounds__(kLdpcThreads, WAVES) void ldpc_decode_kernel(
 #pragma unroll
                     for (int t = 0; t < DMAX; ++t) {
                         if (t >= vmax) continue;
-                        if (t < vmin) c[t] = msg[vaddr[r][t]];
-                        else c[t] = (t < d) ? msg[vaddr[r][t]] : 0.0f;
+                        if (t < vmin) c[t] = vload(r, t);
+                        else c[t] = (t < d) ? vload(r, t) : 0.0f;
                     }
                     float tot = llr_v[r];
 #pragma unroll
@@ -354,8 +370,8 @@ __global__ __launch_bounds__(kLdpcThreads, WAVES) void ldpc_decode_kernel(
 #pragma unroll
                     for (int t = 0; t < DMAX; ++t) {                       // clamp deferred to the reader
                         if (t >= vmax) continue;
-                        if (t < vmin) msg[vaddr[r][t]] = tot - c[t];
-                        else if (t < d) msg[vaddr[r][t]] = tot - c[t];
+                        if (t < vmin) vstore(r, t, tot - c[t]);
+                        else if (t < d) vstore(r, t, tot - c[t]);
                     }
                     if (WANT_TOTAL) llr_total[(size_t)cw * kLdpcN + var_j[r]] = tot;
                 }

@@ -238,7 +238,8 @@ __global__ __launch_bounds__(kWave, 2) void stimulus_kernel(
         }
         wave_sync();
         for (int c = 0; c < ncw; ++c) {
-            for (int i = lane; i < m; i += kWave) {
+            for (int i = lane; i < L.row_rounds * 64; i += kWave) {          // row slots (may have gaps)
+                if (L.row_deg[i] == 0) continue;
                 unsigned char s = 0;
 #pragma unroll
                 for (int t = 0; t < 6; ++t) { const unsigned col = L.row_col[i * 6 + t]; if (col != 0xFFFFu) s ^= sh.bits[c * kLdpcN + col]; }

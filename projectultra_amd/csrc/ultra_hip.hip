@@ -224,18 +224,18 @@ int launch_ldpc(ultra_hip_ctx* ctx, const float* d_llr, size_t llr_stride, size_
     UH_HIP(hipMemsetAsync(counter, 0, dev::kLdpcQueueWords * sizeof(unsigned int), ctx->stream));
     // WV = wavefronts per SIMD the instance's registers are budgeted for; the grid is one resident set
     // (bounded by LDS: one codeword's messages + staging per workgroup)
-#define UH_LDPC_LAUNCH(RR, VR, RMAX, RMIN, VMAX, VMIN, RID, WV)                                                  \
+#define UH_LDPC_LAUNCH(RR, VR, RMAX, RMIN, VMAX, VMIN, RID, LIN, WV)                                                 \
     do {                                                                                                        \
         LaunchSpan span(ctx, ULTRA_HIP_K_LDPC);                                                                 \
         const size_t per_cu = std::max<size_t>(1, std::min<size_t>(4 * (WV), (size_t)(160 * 1024) / lds));      \
         const unsigned grid = (unsigned)std::min(n_cw, (size_t)ctx->cu_count * per_cu);                         \
         if (d_llr_total)                                                                                        \
-            hipLaunchKernelGGL((dev::ldpc_decode_kernel<RR, VR, RMAX, RMIN, VMAX, VMIN, RID, true, WV>),        \
+            hipLaunchKernelGGL((dev::ldpc_decode_kernel<RR, VR, RMAX, RMIN, VMAX, VMIN, RID, LIN, true, WV>),        \
                                dim3(grid), dim3(dev::kLdpcThreads), lds, ctx->stream, ctx->d_plan, d_llr,       \
                                llr_stride, (int)n_cw, d_bytes, d_iters, d_ok, d_llr_total, counter,             \
                                (int)ctx->deint_step);                                                           \
         else                                                                                                    \
-            hipLaunchKernelGGL((dev::ldpc_decode_kernel<RR, VR, RMAX, RMIN, VMAX, VMIN, RID, false, WV>),       \
+            hipLaunchKernelGGL((dev::ldpc_decode_kernel<RR, VR, RMAX, RMIN, VMAX, VMIN, RID, LIN, false, WV>),       \
                                dim3(grid), dim3(dev::kLdpcThreads), lds, ctx->stream, ctx->d_plan, d_llr,       \
                                llr_stride, (int)n_cw, d_bytes, d_iters, d_ok, d_llr_total, counter,             \
                                (int)ctx->deint_step);                                                           \
@@ -244,22 +244,26 @@ int launch_ldpc(ultra_hip_ctx* ctx, const float* d_llr, size_t llr_stride, size_
     // lowest; tools/ldpc_plan_check.cpp prints them): the kernel touches exactly the edge slots a round has.  The
     // API takes no other graph (code_rate selects one of the six); a plan that matches none is refused.
     // Register budgets (last argument: wavefronts per SIMD) measured with tools/ldpc_bench.py.
-    auto is = [&](int rr, int vr, uint64_t rmax, uint64_t rmin, uint64_t vmax, uint64_t vmin, bool rid) {
+    auto is = [&](int rr, int vr, uint64_t rmax, uint64_t rmin, uint64_t vmax, uint64_t vmin, bool rid, bool lin) {
         return P.row_rounds == rr && P.var_rounds == vr && P.prof_rmax == rmax && P.prof_rmin == rmin &&
-               P.prof_vmax == vmax && P.prof_vmin == vmin && (P.row_identity == 0) == rid;
+               P.prof_vmax == vmax && P.prof_vmin == vmin && (P.row_identity == 0) == rid && (P.linear != 0) == lin;
     };
-    if (is(2, 4, 0x66ull, 0x66ull, 0x3333ull, 0x333ull, false))                                                 // R5/6
-        UH_LDPC_LAUNCH(2, 4, 0x66ull, 0x66ull, 0x3333ull, 0x333ull, false, 5);
-    else if (is(3, 6, 0x666ull, 0x666ull, 0x333333ull, 0x33333ull, false))                                      // R3/4
-        UH_LDPC_LAUNCH(3, 6, 0x666ull, 0x666ull, 0x333333ull, 0x33333ull, false, 5);
-    else if (is(4, 7, 0x6666ull, 0x4666ull, 0x3333333ull, 0x333333ull, true))                                   // R2/3
-        UH_LDPC_LAUNCH(4, 7, 0x6666ull, 0x4666ull, 0x3333333ull, 0x333333ull, true, 4);
-    else if (is(6, 6, 0x124566ull, 0x112456ull, 0x444445ull, 0x44444ull, true))                                 // R1/2
-        UH_LDPC_LAUNCH(6, 6, 0x124566ull, 0x112456ull, 0x444445ull, 0x44444ull, true, 4);
-    else if (is(6, 6, 0x133566ull, 0x113356ull, 0x444446ull, 0x44444ull, true))                                 // R1/3
-        UH_LDPC_LAUNCH(6, 6, 0x133566ull, 0x113356ull, 0x444446ull, 0x44444ull, true, 4);
-    else if (is(8, 3, 0x22345566ull, 0x12234566ull, 0xccdull, 0xccull, true))                                   // R1/4
-        UH_LDPC_LAUNCH(8, 3, 0x22345566ull, 0x12234566ull, 0xccdull, 0xccull, true, 3);
+    if (is(2, 4, 0x66ull, 0x66ull, 0x3333ull, 0x333ull, true, true))                                            // R5/6
+        UH_LDPC_LAUNCH(2, 4, 0x66ull, 0x66ull, 0x3333ull, 0x333ull, true, true, 5);
+    else if (is(3, 6, 0x666ull, 0x666ull, 0x333333ull, 0x33333ull, true, true))                                 // R3/4
+        UH_LDPC_LAUNCH(3, 6, 0x666ull, 0x666ull, 0x333333ull, 0x33333ull, true, true, 5);
+    else if (is(2, 4, 0x66ull, 0x66ull, 0x3333ull, 0x333ull, false, false))                                     // R5/6, arbitrary addresses
+        UH_LDPC_LAUNCH(2, 4, 0x66ull, 0x66ull, 0x3333ull, 0x333ull, false, false, 5);
+    else if (is(3, 6, 0x666ull, 0x666ull, 0x333333ull, 0x33333ull, false, false))                               // R3/4, arbitrary addresses
+        UH_LDPC_LAUNCH(3, 6, 0x666ull, 0x666ull, 0x333333ull, 0x33333ull, false, false, 5);
+    else if (is(4, 7, 0x6666ull, 0x4666ull, 0x3333333ull, 0x333333ull, true, false))                            // R2/3
+        UH_LDPC_LAUNCH(4, 7, 0x6666ull, 0x4666ull, 0x3333333ull, 0x333333ull, true, false, 4);
+    else if (is(6, 6, 0x124566ull, 0x112456ull, 0x444445ull, 0x44444ull, true, false))                          // R1/2
+        UH_LDPC_LAUNCH(6, 6, 0x124566ull, 0x112456ull, 0x444445ull, 0x44444ull, true, false, 4);
+    else if (is(6, 6, 0x133566ull, 0x113356ull, 0x444446ull, 0x44444ull, true, false))                          // R1/3
+        UH_LDPC_LAUNCH(6, 6, 0x133566ull, 0x113356ull, 0x444446ull, 0x44444ull, true, false, 4);
+    else if (is(8, 3, 0x22345566ull, 0x12234566ull, 0xccdull, 0xccull, true, false))                            // R1/4
+        UH_LDPC_LAUNCH(8, 3, 0x22345566ull, 0x12234566ull, 0xccdull, 0xccull, true, false, 3);
     else return ULTRA_HIP_ERR_UNSUPPORTED;
 #undef UH_LDPC_LAUNCH
     UH_HIP(hipGetLastError());

@@ -62,8 +62,10 @@ def test_ldpc_kernel_instances_cover_the_six_profiles(tmp_path):
                           r"vmin (0x[0-9a-f]+ull) row_identity (\d)", out.stdout)
     assert len(profiles) == 6, out.stdout
     src = (ROOT / "projectultra_amd" / "csrc" / "ultra_hip.hip").read_text()
+    linear = re.findall(r"^\s+linear (\d)", out.stdout, re.M)
+    assert len(linear) == 6, out.stdout
     launches = re.findall(r"UH_LDPC_LAUNCH\(\d+, \d+, (0x[0-9a-f]+ull), (0x[0-9a-f]+ull), (0x[0-9a-f]+ull), "
-                          r"(0x[0-9a-f]+ull), (true|false), \d\);", src)
-    have = {(a, b, c, d, rid == "true") for a, b, c, d, rid in launches}
-    for rmax, rmin, vmax, vmin, ident in profiles:
-        assert (rmax, rmin, vmax, vmin, ident == "0") in have, (rmax, rmin, vmax, vmin, ident)
+                          r"(0x[0-9a-f]+ull), (true|false), (true|false), \d\);", src)
+    have = {(a, b, c, d, rid == "true", lin == "true") for a, b, c, d, rid, lin in launches}
+    for (rmax, rmin, vmax, vmin, ident), lin in zip(profiles, linear):
+        assert (rmax, rmin, vmax, vmin, ident == "0", lin == "1") in have, (rmax, rmin, vmax, vmin, ident, lin)
