@@ -11,9 +11,10 @@
 //
 // Value-identical reformulations (every float operation the reference performs is performed
 // here on the same operands in the same order):
-//   * check step: "min over all others" of |v| as unsigned-integer minima of the |v| bit patterns
-//     (order-isomorphic for non-NaN values; NaN/inf patterns exceed FLT_MAX's and lose against the
-//     FLT_MAX seed exactly as in the reference's `abs < min` update); the sign is the row's sign
+//   * check step: "min over all others" of |v| as v_min3_f32 with |.| source modifiers (minNum: a NaN loses
+//     against a number and an infinity against the FLT_MAX seed, exactly as in the reference's `abs < min`
+//     update; the raw channel values are canonicalised where they become messages, so no signalling NaN
+//     reaches a minimum); the sign is the row's sign
 //     parity with edge e's own sign removed (`v < 0`: -0.0 and NaN count as positive, as in the
 //     reference), applied to min*0.75f by selecting mag or -mag.
 //   * var step: clamp(x, -50, 50) = std::max(-50.0f, std::min(50.0f, x)) keeps the sign of x (NaN
@@ -56,13 +57,6 @@ constexpr int kLdpcQueueStride = 32;  // unsigned ints between their counters (1
 constexpr int kLdpcQueueWords = kLdpcQueues * kLdpcQueueStride;
 constexpr float kFltMax = 3.402823466e+38f;
 
-__device__ __forceinline__ unsigned umin2(unsigned x, unsigned y) { return x < y ? x : y; }
-__device__ __forceinline__ unsigned umin3(unsigned x, unsigned y, unsigned z) {
-    unsigned r;
-    asm("v_min3_u32 %0, %1, %2, %3" : "=v"(r) : "v"(x), "v"(y), "v"(z));
-    return r;
-}
-
 __host__ __device__ inline size_t ldpc_lds_bytes(int msg_words) {
     return (size_t)msg_words * sizeof(float) + 656 + 648 * sizeof(float);
 }
@@ -78,44 +72,58 @@ __device__ __forceinline__ unsigned wave_xor(unsigned v) {
            (unsigned)__builtin_amdgcn_readlane((int)v, 32) ^ (unsigned)__builtin_amdgcn_readlane((int)v, 48);
 }
 
-// Leave-one-out minima of n magnitudes (bit patterns) under a cap: mn[i] = min(cap, min_{j != i} a[j]).
-// Unsigned minima are exact and associative, so any network gives the reference's value.  n = 7 (a full row:
-// six information edges and the parity bit) is the hand-counted 12-operation network; the general case runs a
-// prefix and a suffix chain.
+// min(|x|, |y|, |z|) and min(|x|, |y|) in one instruction each: the |.| is a source modifier of v_min3_f32 /
+// v_min_f32, so the magnitudes are never formed separately.  IEEE minNum semantics: a NaN operand loses against a
+// number, an infinity against the finite cap — exactly the reference's `if (abs < min) min = abs` update that
+// starts from FLT_MAX (iteration 0) or from the clamp value 50 (see the check step).
+__device__ __forceinline__ float fmin3abs(float x, float y, float z) {
+    float r;
+    asm("v_min3_f32 %0, |%1|, |%2|, |%3|" : "=v"(r) : "v"(x), "v"(y), "v"(z));
+    return r;
+}
+__device__ __forceinline__ float fmin2abs(float x, float y) {
+    float r;
+    asm("v_min_f32_e64 %0, |%1|, |%2|" : "=v"(r) : "v"(x), "v"(y));
+    return r;
+}
+
+// Leave-one-out minima of n magnitudes under a cap: mn[i] = min(cap, min_{j != i} |v[j]|).  Minima are exact and
+// associative, so any network gives the reference's value.  n = 7 (a full row: six information edges and the
+// parity bit) is the hand-counted 12-operation network; the general case runs a prefix and a suffix chain.
 template <int n>
-__device__ __forceinline__ void leave_one_out_min(const unsigned (&a)[7], unsigned cap, unsigned (&mn)[7]) {
+__device__ __forceinline__ void leave_one_out_min(const float (&a)[7], float cap, float (&mn)[7]) {
     if constexpr (n == 7) {
-        const unsigned L2 = umin3(a[0], a[1], cap);             // min of edges 0..1
-        const unsigned L4 = umin3(L2, a[2], a[3]);              // 0..3
-        const unsigned L6 = umin3(L4, a[4], a[5]);              // 0..5
-        const unsigned R4 = umin3(a[5], a[6], cap);             // 5..6
-        const unsigned R3 = umin2(R4, a[4]);                    // 4..6
-        const unsigned R2 = umin3(R4, a[4], a[3]);              // 3..6
-        mn[0] = umin3(R2, a[2], a[1]);
-        mn[1] = umin3(a[0], R2, a[2]);
-        mn[2] = umin2(L2, R2);
-        mn[3] = umin3(L2, a[2], R3);
-        mn[4] = umin2(L4, R4);
-        mn[5] = umin3(L4, a[4], a[6]);
+        const float L2 = fmin3abs(a[0], a[1], cap);             // min of edges 0..1
+        const float L4 = fmin3abs(L2, a[2], a[3]);              // 0..3
+        const float L6 = fmin3abs(L4, a[4], a[5]);              // 0..5
+        const float R4 = fmin3abs(a[5], a[6], cap);             // 5..6
+        const float R3 = fmin2abs(R4, a[4]);                    // 4..6
+        const float R2 = fmin3abs(R4, a[4], a[3]);              // 3..6
+        mn[0] = fmin3abs(R2, a[2], a[1]);
+        mn[1] = fmin3abs(a[0], R2, a[2]);
+        mn[2] = fmin2abs(L2, R2);
+        mn[3] = fmin3abs(L2, a[2], R3);
+        mn[4] = fmin2abs(L4, R4);
+        mn[5] = fmin3abs(L4, a[4], a[6]);
         mn[6] = L6;
     } else if constexpr (n == 2) {
-        mn[0] = umin2(a[1], cap);
-        mn[1] = umin2(a[0], cap);
+        mn[0] = fmin2abs(a[1], cap);
+        mn[1] = fmin2abs(a[0], cap);
     } else if constexpr (n == 3) {
-        mn[0] = umin3(a[1], a[2], cap);
-        mn[1] = umin3(a[0], a[2], cap);
-        mn[2] = umin3(a[0], a[1], cap);
+        mn[0] = fmin3abs(a[1], a[2], cap);
+        mn[1] = fmin3abs(a[0], a[2], cap);
+        mn[2] = fmin3abs(a[0], a[1], cap);
     } else {
-        // pre[i] = min(cap, a[0..i-1]), suf[i] = min(a[i..n-1]); mn[i] = min(pre[i], suf[i+1])
-        unsigned pre[7], suf[7];
+        // pre[i] = min(cap, |a[0..i-1]|), suf[i] = min(|a[i..n-1]|); mn[i] = min(pre[i], suf[i+1])
+        float pre[7], suf[7];
         pre[0] = cap;
 #pragma unroll
-        for (int i = 1; i < n; ++i) pre[i] = umin2(pre[i - 1], a[i - 1]);
+        for (int i = 1; i < n; ++i) pre[i] = fmin2abs(pre[i - 1], a[i - 1]);
         suf[n - 1] = a[n - 1];
 #pragma unroll
-        for (int i = n - 2; i >= 1; --i) suf[i] = umin2(suf[i + 1], a[i]);
+        for (int i = n - 2; i >= 1; --i) suf[i] = fmin2abs(suf[i + 1], a[i]);
 #pragma unroll
-        for (int i = 0; i < n - 1; ++i) mn[i] = umin2(pre[i], suf[i + 1]);
+        for (int i = 0; i < n - 1; ++i) mn[i] = fmin2abs(pre[i], suf[i + 1]);
         mn[n - 1] = pre[n - 1];
     }
 }
@@ -252,14 +260,19 @@ __global__ __launch_bounds__(kLdpcThreads, WAVES) void ldpc_decode_kernel(
 #pragma unroll
             for (int t = 0; t < DMAX; ++t) {                                   // v2c = llr_in[col]
                 if (t >= ldpc_prof(VMAX, r)) continue;
-                if (t < ldpc_prof(VMIN, r)) vstore(r, t, llr_v[r]);
-                else if (t < var_deg[r]) vstore(r, t, llr_v[r]);
+                // The first messages are the raw channel values.  A signalling NaN among them would come out of
+                // v_min_f32 quieted instead of being skipped (IEEE mode), so the message copy is canonicalised: a
+                // quiet NaN with the same sign — every later message is an arithmetic result and quiet anyway;
+                // numbers, zeros, denormals and infinities pass unchanged.
+                const float first = __builtin_canonicalizef(llr_v[r]);
+                if (t < ldpc_prof(VMIN, r)) vstore(r, t, first);
+                else if (t < var_deg[r]) vstore(r, t, first);
             }
         }
 #pragma unroll
         for (int r = 0; r < RR; ++r) {
             llr_p[r] = row_ok[r] ? llr_s[parity_var(r)] : 0.0f;
-            vpar[r] = llr_p[r];                                                // v2c of the parity bit
+            vpar[r] = __builtin_canonicalizef(llr_p[r]);                       // v2c of the parity bit (quiet, see above)
             hpar[r] = false;
         }
         __syncthreads();
@@ -300,7 +313,7 @@ __global__ __launch_bounds__(kLdpcThreads, WAVES) void ldpc_decode_kernel(
             // messages are stored unclamped and the two seeds of the minimum chains carry the cap
             // (FLT_MAX in iteration 0, whose inputs are the unclamped channel values).
             unsigned f = 0u;                                               // this lane's share of the syndrome filter
-            const unsigned cap = (it == 0) ? 0x7f7fffffu : 0x42480000u;    // FLT_MAX : 50.0f
+            const float cap = (it == 0) ? kFltMax : 50.0f;
             ldpc_static_for(std::make_integer_sequence<int, RR>{}, [&](auto round) {
                 constexpr int r = decltype(round)::value;
                 if (row_ok[r]) {
@@ -315,27 +328,24 @@ __global__ __launch_bounds__(kLdpcThreads, WAVES) void ldpc_decode_kernel(
                     v[rmax] = vpar[r];
                     // Signs as lane masks (SGPR pairs): the row parity and each edge's "all others"
                     // sign are scalar xors; the sign is applied with one select between mag and -mag.
-                    // Magnitudes as unsigned integers (|x| bit patterns order like the values; NaN and
-                    // inf patterns exceed FLT_MAX's, so capping at FLT_MAX ignores them exactly as the
-                    // reference's `abs < min` update starting from FLT_MAX does).
-                    unsigned a[7], mn[7];
+                    // Magnitudes only ever appear as |.| source modifiers of the minima (leave_one_out_min).
+                    float mn[7];
                     bool ng[7], par = false;
 #pragma unroll
                     for (int t = 0; t <= rmax; ++t) {
-                        a[t] = __float_as_uint(v[t]) & 0x7fffffffu;
                         ng[t] = v[t] < 0;
                         par ^= ng[t];
                     }
-                    leave_one_out_min<rmax + 1>(a, cap, mn);
+                    leave_one_out_min<rmax + 1>(v, cap, mn);
 #pragma unroll
                     for (int t = 0; t < 6; ++t) {
                         if (t >= rmax) continue;
-                        const float mag = __uint_as_float(mn[t]) * 0.75f;
+                        const float mag = mn[t] * 0.75f;
                         const float c = (par != ng[t]) ? -mag : mag;           // sign * min * 0.75f
                         if (t < rmin) msg[raddr[r][t]] = c;
                         else if (raddr[r][t] >= 0) msg[raddr[r][t]] = c;
                     }
-                    const float mag6 = __uint_as_float(mn[rmax]) * 0.75f;
+                    const float mag6 = mn[rmax] * 0.75f;
                     const float c_last = (par != ng[rmax]) ? -mag6 : mag6;
                     const float total_p = llr_p[r] + c_last;               // parity bit of the row
                     hpar[r] = total_p < 0;

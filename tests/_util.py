@@ -61,9 +61,13 @@ def nonfinite_cases(rng, oracle, rate, n=12):
         bits = np.unpackbits(np.frombuffer(enc, np.uint8))[:648].astype(np.float32)
         llr = ((2 * (1 - 2 * bits) + rng.normal(0, 1.6, 648)) / 0.8).astype(np.float32)
         idx = rng.choice(648, 24, replace=False)
-        vals = [np.nan, np.inf, -np.inf, 3e38, -3e38, -0.0, 75.0, -75.0]
+        # as bit patterns: quiet NaN, +-inf, +-3e38, -0.0, +-75, signalling NaNs of both signs (a float assignment
+        # would quiet them), denormals of both signs
+        vals = [0x7fc00000, 0x7f800000, 0xff800000, 0x7f61b1e6, 0xff61b1e6, 0x80000000, 0x42960000, 0xc2960000,
+                0x7fa00000, 0xffa00001, 0x000002ca, 0x800002ca]
+        bits32 = llr.view(np.uint32)
         for j, ix in enumerate(idx[: 3 * (i % 8) + 1]):
-            llr[ix] = vals[(i + j) % len(vals)]
+            bits32[ix] = vals[(i + j) % len(vals)]
         out.append(llr)
     return np.stack(out)
 
