@@ -189,17 +189,19 @@ def main():
                              "ms_per_step": ms_total / args.steps, "algorithmic_bytes_per_launch": alg,
                              "GBps": alg / (avg * 1e-3) / 1e9, "frac": alg / (avg * 1e-3) / 1e9 / HBM_PEAK_GBPS,
                              "traffic": traffic_all.get(name)}
-        # The decoder's real limiter is the LDS pipeline, not HBM: report its utilisation next to the HBM figure.
-        # One codeword-iteration issues 36 ds_read_b32 (2 cycles each for 64 lanes) and 36 ds_write_b32 (4 cycles:
-        # address + data) = 216 LDS cycles on the CU's single LDS pipeline; a codeword that
-        # converges at iteration `it` executes it + 1 iterations, a failing one max_iterations.
+        # The decoder's limiters are its VALU issue and the LDS pipeline, not HBM: report the LDS utilisation next to
+        # the HBM figure.  One codeword-iteration of the R3/4 instance issues 36 ds_read_b32 (2 cycles each for 64
+        # lanes), 18 ds_write_b32 (4 cycles: address + data, the check step's scattered stores) and 18
+        # ds_write_addtid_b32 (2 cycles: the variable step's lane-linear stores) = 180 LDS cycles on the CU's single
+        # LDS pipeline; a codeword that converges at iteration `it` executes it + 1 iterations, a
+        # failing one max_iterations.
         if "ldpc_decode_kernel" in kernels and world == 1:
             props = torch.cuda.get_device_properties(0)
             clock_hz = 2.4e9                                   # MI355X peak engine clock (MI355X_MICROARCH.md)
             executed = stats["iters_sum"] + (stats["frames"] - stats["ldpc_fail"])
-            lds_cycles = 216.0 * executed
+            lds_cycles = 180.0 * executed
             avail = kernels["ldpc_decode_kernel"]["avg_launch_ms"] * 1e-3 * clock_hz * props.multi_processor_count
-            kernels["ldpc_decode_kernel"]["lds"] = {"lds_cycles_per_codeword_iteration": 216,
+            kernels["ldpc_decode_kernel"]["lds"] = {"lds_cycles_per_codeword_iteration": 180,
                                                     "codeword_iterations_per_launch": executed,
                                                     "compute_units": props.multi_processor_count, "clock_hz": clock_hz,
                                                     "frac_of_lds_peak": lds_cycles / avail}
@@ -215,8 +217,8 @@ def main():
                             "latency/VALU-bound (double-precision sincos of the CFO rotation, 1024-point FFT through "
                             "LDS), and the reference decodes only ~11 % of these frames (R3/4 leaves 161 info bits "
                             "unchecked, the two-tap channel nulls 1 kHz), so most codewords run all 50 BP iterations "
-                            "and ldpc_decode_kernel is LDS-bound (~216 LDS cycles per codeword-iteration, "
-                            "conflict-free). path_GBps = frames/s x 20,581 B (SURVEY 8d) for one GPU"}
+                            "and ldpc_decode_kernel is bound by VALU issue (~200 instructions per codeword-iteration) and "
+                            "the LDS pipeline (180 cycles per codeword-iteration, conflict-free). path_GBps = frames/s x 20,581 B (SURVEY 8d) for one GPU"}
 
     # ---- CPU baseline: the oracle on the host cores, bounded sample (rank 0, N=1 only) ----------
     cpu = None
