@@ -224,10 +224,15 @@ inline int build_ldpc_plan_linear(const LdpcConst& L, LdpcPlan& P) {
     P = LdpcPlan{};
     P.k = L.k; P.m = L.m; P.n = L.n; P.edges = L.edges; P.max_iterations = L.max_iterations;
     P.decoded_bytes = L.decoded_bytes;
+    // rows: six information edges + parity, but for a few shorter ones, which stay in the last half-wave
+    auto rdeg = [&](int i) { return (int)(L.row_ptr[i + 1] - L.row_ptr[i]); };
+    int n_short = 0;
     for (int i = 0; i < L.m; ++i) {
-        if (L.row_ptr[i + 1] - L.row_ptr[i] != 7) return ULTRA_HIP_ERR_UNSUPPORTED;      // six information edges + parity
+        if (rdeg(i) < 2 || rdeg(i) > 7) return ULTRA_HIP_ERR_UNSUPPORTED;
         if (L.col[L.row_ptr[i + 1] - 1] != L.k + i) return ULTRA_HIP_ERR_UNSUPPORTED;
+        if (rdeg(i) != 7) ++n_short;
     }
+    if (n_short > 4) return ULTRA_HIP_ERR_UNSUPPORTED;
     for (int j = L.k; j < L.n; ++j)
         if (L.var_ptr[j + 1] - L.var_ptr[j] != 1) return ULTRA_HIP_ERR_UNSUPPORTED;
     auto vdeg = [&](int j) { return (int)(L.var_ptr[j + 1] - L.var_ptr[j]); };
@@ -253,7 +258,17 @@ inline int build_ldpc_plan_linear(const LdpcConst& L, LdpcPlan& P) {
     // initial deal: full-round variables round-robin over the banks (capacity 2 * (VR - 1) each), the last round's
     // variables over distinct banks; rows round-robin over the half-waves
     for (int a = 0; a < na; ++a) bank[act_list[a]] = (a < n_fullv) ? a % 32 : (a - n_fullv) % 32;
-    for (int i = 0; i < L.m; ++i) grp[i] = i % NG;
+    {
+        int dealt = 0;
+        for (int i = 0; i < L.m; ++i) {
+            if (rdeg(i) != 7) { grp[i] = NG - 1; continue; }
+            grp[i] = dealt % NG;
+            if (grp[i] == NG - 1 && dealt / NG >= per_group - n_short) grp[i] = (dealt + 1) % (NG - 1);   // room for the short rows
+            ++dealt;
+        }
+        std::vector<int> fill(NG, 0);
+        for (int i = 0; i < L.m; ++i) if (++fill[grp[i]] > 32) return ULTRA_HIP_ERR_UNSUPPORTED;
+    }
     std::vector<int> cnt(NG * 32, 0);
     for (int i = 0; i < L.m; ++i)
         for (int e = L.row_ptr[i]; e + 1 < L.row_ptr[i + 1]; ++e) cnt[grp[i] * 32 + bank[L.col[e]]]++;
@@ -280,7 +295,7 @@ inline int build_ldpc_plan_linear(const LdpcConst& L, LdpcPlan& P) {
             }
         } else {
             const int r1 = (int)(rng() % L.m), r2 = (int)(rng() % L.m), g1 = grp[r1], g2 = grp[r2];
-            if (g1 == g2) continue;
+            if (g1 == g2 || rdeg(r1) != 7 || rdeg(r2) != 7) continue;
             for (int e = L.row_ptr[r1]; e + 1 < L.row_ptr[r1 + 1]; ++e) { d += bump(g1, bank[L.col[e]], -1); d += bump(g2, bank[L.col[e]], +1); }
             for (int e = L.row_ptr[r2]; e + 1 < L.row_ptr[r2 + 1]; ++e) { d += bump(g2, bank[L.col[e]], -1); d += bump(g1, bank[L.col[e]], +1); }
             if (d <= 0 || U(rng) < std::exp(-(double)d / T)) { grp[r1] = g2; grp[r2] = g1; cost += d; }
@@ -324,7 +339,7 @@ inline int build_ldpc_plan_linear(const LdpcConst& L, LdpcPlan& P) {
     bool identity = true;
     for (int i = 0; i < L.m; ++i) {
         const int sl = slot_of[i];
-        P.row_deg[sl] = 7; P.row_id[sl] = (uint16_t)i; P.row_mask[sl] = mask_of[i];
+        P.row_deg[sl] = (uint8_t)rdeg(i); P.row_id[sl] = (uint16_t)i; P.row_mask[sl] = mask_of[i];
         identity = identity && sl == i;
     }
     // slots of the edges: per half-wave a six-edge-colouring of rows x banks
@@ -340,6 +355,20 @@ inline int build_ldpc_plan_linear(const LdpcConst& L, LdpcPlan& P) {
             for (int e = L.row_ptr[rows_g[li]]; e + 1 < L.row_ptr[rows_g[li] + 1]; ++e) { ed.push_back({(int)li, bank[L.col[e]]}); eid.push_back(e); }
         std::vector<int> colour;
         bipartite_edge_colouring((int)rows_g.size(), 32, ed, 6, colour);
+        // The kernel expects the edges of a row in slots 0 .. degree-1.  A permutation of the six colours keeps the
+        // colouring proper, so the colours a short row uses are renamed to the first ones (one short row per
+        // half-wave at most: two would need compatible colour sets).
+        {
+            int short_li = -1;
+            for (size_t li = 0; li < rows_g.size(); ++li)
+                if (rdeg(rows_g[li]) != 7) { if (short_li >= 0) return ULTRA_HIP_ERR_UNSUPPORTED; short_li = (int)li; }
+            if (short_li >= 0) {
+                int perm[6] = {-1, -1, -1, -1, -1, -1}, next = 0;
+                for (size_t x = 0; x < ed.size(); ++x) if (ed[x].first == short_li) perm[colour[x]] = next++;
+                for (int c = 0; c < 6; ++c) if (perm[c] < 0) perm[c] = next++;
+                for (size_t x = 0; x < ed.size(); ++x) colour[x] = perm[colour[x]];
+            }
+        }
         for (size_t x = 0; x < ed.size(); ++x) {
             const int e = eid[x], i = rows_g[ed[x].first], t = colour[x], j = L.col[e], a = act_of[j], q = q_of_edge[e];
             if (t < 0 || t >= 6 || q < 0) return ULTRA_HIP_ERR_UNSUPPORTED;
@@ -353,10 +382,15 @@ inline int build_ldpc_plan_linear(const LdpcConst& L, LdpcPlan& P) {
     P.msg_words = VR * dmax * 64;
     P.n_active = na; P.dmax = dmax;
     P.row_rounds = RR; P.var_rounds = VR;
-    P.var_rounds_full = VR - 1; P.rows_full = 1;
+    P.var_rounds_full = VR - 1; P.rows_full = n_short == 0 ? 1 : 0;
     P.row_identity = identity ? 1 : 0;
     P.linear = 1;
-    for (int r = 0; r < RR; ++r) { P.prof_rmax |= 6ull << (4 * r); P.prof_rmin |= 6ull << (4 * r); }
+    for (int r = 0; r < RR; ++r) {
+        int mx = 0, mn = 15;
+        for (int sl = 64 * r; sl < 64 * r + 64; ++sl) if (P.row_deg[sl]) { mx = std::max(mx, P.row_deg[sl] - 1); mn = std::min(mn, P.row_deg[sl] - 1); }
+        P.prof_rmax |= (uint64_t)mx << (4 * r);
+        P.prof_rmin |= (uint64_t)mn << (4 * r);
+    }
     for (int r = 0; r < VR; ++r) {
         int mx = 0, mn = 15;
         for (int a = 64 * r; a < 64 * r + 64; ++a) { mx = std::max(mx, (int)P.act_deg[a]); mn = std::min(mn, (int)P.act_deg[a]); }

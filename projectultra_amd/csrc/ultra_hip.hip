@@ -256,7 +256,9 @@ int launch_ldpc(ultra_hip_ctx* ctx, const float* d_llr, size_t llr_stride, size_
         UH_LDPC_LAUNCH(2, 4, 0x66ull, 0x66ull, 0x3333ull, 0x333ull, false, false, 5);
     else if (is(3, 6, 0x666ull, 0x666ull, 0x333333ull, 0x33333ull, false, false))                               // R3/4, arbitrary addresses
         UH_LDPC_LAUNCH(3, 6, 0x666ull, 0x666ull, 0x333333ull, 0x33333ull, false, false, 5);
-    else if (is(4, 7, 0x6666ull, 0x4666ull, 0x3333333ull, 0x333333ull, true, false))                            // R2/3
+    else if (is(4, 7, 0x6666ull, 0x4666ull, 0x3333333ull, 0x333333ull, true, true))                             // R2/3
+        UH_LDPC_LAUNCH(4, 7, 0x6666ull, 0x4666ull, 0x3333333ull, 0x333333ull, true, true, 5);
+    else if (is(4, 7, 0x6666ull, 0x4666ull, 0x3333333ull, 0x333333ull, true, false))                            // R2/3, arbitrary addresses
         UH_LDPC_LAUNCH(4, 7, 0x6666ull, 0x4666ull, 0x3333333ull, 0x333333ull, true, false, 4);
     else if (is(6, 6, 0x124566ull, 0x112456ull, 0x444445ull, 0x44444ull, true, false))                          // R1/2
         UH_LDPC_LAUNCH(6, 6, 0x124566ull, 0x112456ull, 0x444445ull, 0x44444ull, true, false, 4);

@@ -36,6 +36,8 @@ int main() {
             if (!P.linear && sl > 0 && P.row_deg[sl] > P.row_deg[sl - 1]) bad++;      // sorted by degree (arbitrary-address plans)
         }
         if ((int)ids.size() != L.m || n_slots != L.m) bad++;
+        for (int sl = 0; sl < P.row_rounds * 64; sl++)          // a row's edges sit in slots 0 .. degree-2 (the parity edge is the last)
+            for (int t = 0; t < 6; t++) if (P.row_deg[sl] && (P.row_addr[6 * sl + t] != 0xFFFF) != (t < P.row_deg[sl] - 1)) bad++;
         for (int a = 0; a < P.var_rounds * 64; a++) if (P.act_deg[a]) { ++n_vars; var_edges += P.act_deg[a]; }
         if (n_vars != P.n_active || var_edges != info_edges) bad++;
         // every edge is known to both sides under the same address
