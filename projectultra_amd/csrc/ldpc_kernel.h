@@ -252,11 +252,14 @@ __global__ __launch_bounds__(kLdpcThreads, WAVES) void ldpc_decode_kernel(
         }
         __syncthreads();
         float llr_v[VR], llr_p[RR], vpar[RR];
-        bool hpar[RR], hv[VR];                                             // hard decisions as lane masks
+        // Hard decisions: the totals themselves are kept (tot < 0 is evaluated where a decision is needed — the
+        // rare exact parity test and the output); a bool that lives across iterations costs a 0/1 VGPR and one more
+        // instruction per round to materialise it.
+        float tpar[RR], tvar[VR];
 #pragma unroll
         for (int r = 0; r < VR; ++r) {
             llr_v[r] = llr_s[var_j[r]];
-            hv[r] = false;
+            tvar[r] = 0.0f;
 #pragma unroll
             for (int t = 0; t < DMAX; ++t) {                                   // v2c = llr_in[col]
                 if (t >= ldpc_prof(VMAX, r)) continue;
@@ -273,7 +276,7 @@ __global__ __launch_bounds__(kLdpcThreads, WAVES) void ldpc_decode_kernel(
         for (int r = 0; r < RR; ++r) {
             llr_p[r] = row_ok[r] ? llr_s[parity_var(r)] : 0.0f;
             vpar[r] = __builtin_canonicalizef(llr_p[r]);                       // v2c of the parity bit (quiet, see above)
-            hpar[r] = false;
+            tpar[r] = 0.0f;
         }
         __syncthreads();
         const int cw_next = claim();                       // llr_s is free from here on
@@ -286,14 +289,14 @@ __global__ __launch_bounds__(kLdpcThreads, WAVES) void ldpc_decode_kernel(
                 // ---- exact parity test (checkParity :139-151); reached once per converged codeword ----
 #pragma unroll
                 for (int r = 0; r < VR; ++r)
-                    if (var_deg[r] > 0) hard[var_j[r]] = hv[r] ? 1 : 0;
+                    if (var_deg[r] > 0) hard[var_j[r]] = (tvar[r] < 0) ? 1 : 0;
                 __syncthreads();
                 int bad = 0;
 #pragma unroll
                 for (int r = 0; r < RR; ++r) {
                     if (row_ok[r]) {
                         const int row = r * 64 + lane;
-                        int s = hpar[r] ? 1 : 0;
+                        int s = (tpar[r] < 0) ? 1 : 0;
                         for (int t = 0; t < 6; ++t) {
                             const unsigned c = P.row_col[row * 6 + t];
                             if (c != 0xFFFFu) s ^= hard[c];
@@ -348,8 +351,8 @@ __global__ __launch_bounds__(kLdpcThreads, WAVES) void ldpc_decode_kernel(
                     const float mag6 = mn[rmax] * 0.75f;
                     const float c_last = (par != ng[rmax]) ? -mag6 : mag6;
                     const float total_p = llr_p[r] + c_last;               // parity bit of the row
-                    hpar[r] = total_p < 0;
-                    f ^= hpar[r] ? rmask[r] : 0u;
+                    tpar[r] = total_p;
+                    f ^= (total_p < 0) ? rmask[r] : 0u;
                     vpar[r] = total_p - c_last;                            // clamp deferred, see `cap`
                     if (WANT_TOTAL) llr_total[(size_t)cw * kLdpcN + parity_var(r)] = total_p;
                 }
@@ -375,8 +378,8 @@ __global__ __launch_bounds__(kLdpcThreads, WAVES) void ldpc_decode_kernel(
                         if (t < vmin) tot += c[t];
                         else if (t < d) tot += c[t];
                     }
-                    hv[r] = tot < 0;
-                    f ^= hv[r] ? vmask[r] : 0u;
+                    tvar[r] = tot;
+                    f ^= (tot < 0) ? vmask[r] : 0u;
 #pragma unroll
                     for (int t = 0; t < DMAX; ++t) {                       // clamp deferred to the reader
                         if (t >= vmax) continue;
@@ -396,7 +399,7 @@ __global__ __launch_bounds__(kLdpcThreads, WAVES) void ldpc_decode_kernel(
         if (!ok && P.max_iterations > 0) {                                 // on success `hard` was just refreshed
 #pragma unroll
             for (int r = 0; r < VR; ++r)
-                if (var_deg[r] > 0) hard[var_j[r]] = hv[r] ? 1 : 0;
+                if (var_deg[r] > 0) hard[var_j[r]] = (tvar[r] < 0) ? 1 : 0;
             __syncthreads();
         }
         uint8_t* ob = bytes + (size_t)cw * P.decoded_bytes;
