@@ -249,7 +249,7 @@ int launch_ldpc(ultra_hip_ctx* ctx, const float* d_llr, size_t llr_stride, size_
                P.prof_vmax == vmax && P.prof_vmin == vmin && (P.row_identity == 0) == rid && (P.linear != 0) == lin;
     };
     if (is(2, 4, 0x66ull, 0x66ull, 0x3333ull, 0x333ull, true, true))                                            // R5/6
-        UH_LDPC_LAUNCH(2, 4, 0x66ull, 0x66ull, 0x3333ull, 0x333ull, true, true, 5);
+        UH_LDPC_LAUNCH(2, 4, 0x66ull, 0x66ull, 0x3333ull, 0x333ull, true, true, 6);
     else if (is(3, 6, 0x666ull, 0x666ull, 0x333333ull, 0x33333ull, true, true))                                 // R3/4
         UH_LDPC_LAUNCH(3, 6, 0x666ull, 0x666ull, 0x333333ull, 0x33333ull, true, true, 5);
     else if (is(2, 4, 0x66ull, 0x66ull, 0x3333ull, 0x333ull, false, false))                                     // R5/6, arbitrary addresses
