@@ -334,8 +334,8 @@ public:
     explicit HipRxFrameDecoder(int device = 0) : device_(device) {}
     void setDataMode(CodeRate rate, bool connected) { rate_ = rate; connected_ = connected; ctx_.reset(); }
     void setInterleavingEnabled(bool enabled) { interleaving_ = enabled; ctx_.reset(); }
-    void setInterleaverConfig(size_t bits_per_symbol) {            // rx_pipeline.cpp:25-32: only a change builds one
-        if (bits_per_symbol != bits_per_symbol_) { bits_per_symbol_ = bits_per_symbol; configured_ = true; ctx_.reset(); }
+    void setInterleaverConfig(size_t bits_per_symbol) {            // rx_pipeline.cpp:24-31
+        if (bits_per_symbol != bits_per_symbol_) { bits_per_symbol_ = bits_per_symbol; ctx_.reset(); }
     }
     int getExpectedCodewords() const { return expected_; }
     bool isAccumulating() const { return expected_ > 0; }
@@ -346,7 +346,7 @@ public:
         if (!ctx_.p) {
             ModemConfig c; c.code_rate = connected_ ? rate_ : CodeRate::R1_4;      // rx_pipeline.cpp:356-366
             ctx_ = detail::Ctx(to_c_config(c, ULTRA_ENTRY_SYNCED, 44, 0), device_);
-            detail::check(ultra_hip_set_deinterleave(ctx_.p, (interleaving_ && configured_) ? uint32_t(bits_per_symbol_) : 0u),
+            detail::check(ultra_hip_set_deinterleave(ctx_.p, interleaving_ ? uint32_t(bits_per_symbol_) : 0u),
                           "ultra_hip_set_deinterleave");
         }
         ultra_hip_geometry g; detail::check(ultra_hip_get_geometry(ctx_.p, &g), "geometry");
@@ -365,8 +365,9 @@ public:
         return r;
     }
 private:
-    int device_; CodeRate rate_ = CodeRate::R1_4; bool connected_ = false, interleaving_ = true, configured_ = false;
-    size_t bits_per_symbol_ = 60; int expected_ = 0;
+    int device_; CodeRate rate_ = CodeRate::R1_4; bool connected_ = false, interleaving_ = true;
+    size_t bits_per_symbol_ = 60;           // the constructor's ChannelInterleaver(60, 648): rx_pipeline.cpp:13-18
+    int expected_ = 0;
     detail::Ctx ctx_;
 };
 

@@ -646,8 +646,12 @@ int ref_v2_decode_frame(uint32_t rate, uint32_t deint_bps, int max_iters, const 
     (void)max_iters;                                             // RxPipeline uses LDPCDecoder's default (50)
     gui::RxPipeline rx("T");
     rx.setDataMode(static_cast<CodeRate>(rate), true);           // connected: data_code_rate_ for every codeword
-    rx.setInterleavingEnabled(deint_bps != 0);
-    if (deint_bps) { rx.interleaver_bits_per_symbol_ = 0; rx.setInterleaverConfig(deint_bps); }
+    // deint_bps = 0xffffffff leaves the pipeline as constructed (ChannelInterleaver(60, 648), interleaving on:
+    // rx_pipeline.cpp:13-18, rx_pipeline.hpp:177,182); otherwise exactly the two public setters
+    if (deint_bps != 0xffffffffu) {
+        rx.setInterleavingEnabled(deint_bps != 0);
+        if (deint_bps) rx.setInterleaverConfig(deint_bps);
+    }
     for (int i = 0; i < 8; ++i) res[i] = 0;
     gui::RxFrameResult result;
     res[2] = (int)result.frame_type;

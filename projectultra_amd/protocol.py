@@ -45,8 +45,9 @@ class RxFrameDecoder:
         self._rate = CodeRate.R1_4
         self._connected = False
         self._interleaving = True
-        self._bits_per_symbol = 60                 # rx_pipeline.hpp:181 (an interleaver exists only once configured)
-        self._configured = False
+        # the constructor already builds ChannelInterleaver(60, 648) and interleaving is on (rx_pipeline.cpp:13-18,
+        # rx_pipeline.hpp:177,182): a default decoder deinterleaves with 60 bits per symbol
+        self._bits_per_symbol = 60
         self._ctx = {}
         self._expected = 0
 
@@ -56,9 +57,8 @@ class RxFrameDecoder:
     def setInterleavingEnabled(self, enabled: bool) -> None:
         self._interleaving = bool(enabled)
 
-    def setInterleaverConfig(self, bits_per_symbol: int) -> None:   # rx_pipeline.cpp:25-32: only a change builds one
-        if bits_per_symbol != self._bits_per_symbol:
-            self._bits_per_symbol, self._configured = int(bits_per_symbol), True
+    def setInterleaverConfig(self, bits_per_symbol: int) -> None:   # rx_pipeline.cpp:24-31
+        self._bits_per_symbol = int(bits_per_symbol)
 
     def getExpectedCodewords(self) -> int:
         return self._expected
@@ -68,7 +68,7 @@ class RxFrameDecoder:
 
     def _context(self) -> ReceiveContext:
         rate = self._rate if self._connected else CodeRate.R1_4          # rx_pipeline.cpp:356-366
-        bps = self._bits_per_symbol if (self._interleaving and self._configured) else 0
+        bps = self._bits_per_symbol if self._interleaving else 0   # deinterleaveCodewords, rx_pipeline.cpp:474-477
         key = (rate, bps)
         if key not in self._ctx:
             ctx = ReceiveContext(ModemConfig(code_rate=rate), device=self._device)

@@ -149,10 +149,11 @@ def test_cpp_adapter_chirp_waveform(tmp_path, oracle):
 SRC_FRAME = r'''
 #include "ultra_hip_waveform.hpp"
 #include <cstdio>
+#include <string>
 #include <vector>
 using namespace ultra_hip;
 int main(int argc, char** argv) {
-    // argv: soft.f32 n out.bin rate bits_per_symbol(0 = interleaving off)
+    // argv: soft.f32 n out.bin rate bits_per_symbol(0 = interleaving off, "default" = no setter call at all)
     FILE* f = std::fopen(argv[1], "rb");
     const size_t n = std::stoul(argv[2]);
     std::vector<float> soft(n);
@@ -160,9 +161,11 @@ int main(int argc, char** argv) {
     std::fclose(f);
     HipRxFrameDecoder dec;
     dec.setDataMode(static_cast<CodeRate>(std::stoi(argv[4])), true);
-    const size_t bps = std::stoul(argv[5]);
-    dec.setInterleavingEnabled(bps != 0);
-    if (bps) dec.setInterleaverConfig(bps);
+    if (std::string(argv[5]) != "default") {
+        const size_t bps = std::stoul(argv[5]);
+        dec.setInterleavingEnabled(bps != 0);
+        if (bps) dec.setInterleaverConfig(bps);
+    }
     HipRxFrameResult r = dec.decodeSoftBits(std::span<const float>(soft.data(), n));
     FILE* g = std::fopen(argv[3], "wb");
     const int head[6] = {r.success, r.is_ping, r.frame_type, r.codewords_ok, r.codewords_failed, dec.getExpectedCodewords()};
@@ -172,9 +175,12 @@ int main(int argc, char** argv) {
 '''
 
 
-@pytest.mark.parametrize("rate,bps", [(0, 0), (4, 176)])
+@pytest.mark.parametrize("rate,bps", [(0, 0), (4, 176), (0, "default")])
 def test_cpp_frame_decoder(tmp_path, oracle, rate, bps):
-    """HipRxFrameDecoder::decodeSoftBits (RxPipeline's decode half) from a C++ program, against the oracle."""
+    """HipRxFrameDecoder::decodeSoftBits (RxPipeline's decode half) from a C++ program, against the oracle.
+    "default": no setter is called — like a default-constructed RxPipeline (ChannelInterleaver(60, 648), interleaving
+    on: rx_pipeline.cpp:13-18) the decoder deinterleaves with 60 bits per symbol."""
+    arg, bps = str(bps), (60 if bps == "default" else bps)
     from _util import v2_frame_cases
     src = tmp_path / "fd.cpp"
     src.write_text(SRC_FRAME)
@@ -185,7 +191,7 @@ def test_cpp_frame_decoder(tmp_path, oracle, rate, bps):
     for t, (name, soft) in enumerate(v2_frame_cases(oracle, rate, np.random.default_rng(3), bps)[::2]):
         fin, fo = tmp_path / f"s{t}.f32", tmp_path / f"r{t}.bin"
         soft.tofile(fin)
-        r = subprocess.run([str(exe), str(fin), str(soft.size), str(fo), str(rate), str(bps)], capture_output=True,
+        r = subprocess.run([str(exe), str(fin), str(soft.size), str(fo), str(rate), arg], capture_output=True,
                            text=True, timeout=300)
         assert r.returncode == 0, (name, r.returncode, r.stderr[-400:])
         raw = fo.read_bytes()

@@ -88,6 +88,36 @@ def test_frame_decoder_mirror(oracle):
     assert r.frame_data == oracle.v2_decode_frame(4, tx.reshape(-1), 176)["frame_data"]
 
 
+def test_frame_decoder_default_deinterleaves(oracle):
+    """A default-constructed RxFrameDecoder behaves like a default-constructed gui::RxPipeline: interleaving on,
+    ChannelInterleaver(60, 648) (rx_pipeline.cpp:13-18) — frames of a default transmitter decode without any setter
+    call, setInterleaverConfig(60) changes nothing, plain (non-interleaved) frames fail CW0.  The reference's own
+    answer for the same soft bits is checked where the compiled reference is present."""
+    from oracle.bindings import have_ref, Ref
+    from projectultra_amd import RxFrameDecoder
+    from _util import v2_frame_cases
+    rng = np.random.default_rng(4242)
+    ref = Ref() if have_ref() else None
+    dec, dec60 = RxFrameDecoder(), RxFrameDecoder()
+    dec60.setInterleaverConfig(60)
+    n_ok = 0
+    for name, soft in v2_frame_cases(oracle, 0, rng, 60):
+        want = oracle.v2_decode_frame(0, soft, 60)
+        if ref is not None:
+            assert want == ref.v2_decode_frame(0, soft, 0xFFFFFFFF), name
+        for d in (dec, dec60):
+            r = d.decode_soft_bits(soft)
+            assert (int(r.success), int(r.is_ping), r.codewords_ok, r.codewords_failed, r.frame_data) == \
+                (want["success"], want["is_ping"], want["codewords_ok"], want["codewords_failed"], want["frame_data"]), name
+        n_ok += want["success"]
+    assert n_ok >= 6
+    cws = oracle.v2_build_frame(0, b"plain", seq=1)
+    soft = (4.0 * (1.0 - 2.0 * np.unpackbits(cws, axis=1))).astype(np.float32).reshape(-1)
+    assert not dec.decode_soft_bits(soft).success
+    dec.setInterleavingEnabled(False)
+    assert dec.decode_soft_bits(soft).success
+
+
 def test_chirp_frame_end_to_end(oracle):
     """A multi-codeword v2 data frame the way the production link carries it: DataFrame -> LDPC codewords ->
     channel interleaver per codeword -> chirp + training + DQPSK symbols -> frequency offset + AWGN; received by

@@ -245,3 +245,25 @@ def test_v2_wire_format(oracle, ref, rate, bps):
         assert o == r, (name, o, r)
         seen.add(o["status"])
     assert seen >= {0, 1, 2, 4, 5} and (rate == 1 or 3 in seen)      # (R1/3's garbage codeword happens to decode)
+
+
+def test_v2_default_pipeline_deinterleaves(oracle, ref):
+    """A default-constructed RxPipeline already owns ChannelInterleaver(60, 648) with interleaving enabled
+    (rx_pipeline.cpp:13-18, rx_pipeline.hpp:177,182): without any setter call it deinterleaves with 60 bits per
+    symbol, and setInterleaverConfig(60) changes nothing.  The host mirrors (RxFrameDecoder, HipRxFrameDecoder)
+    follow this; here the reference itself is the witness."""
+    from _util import v2_frame_cases
+    rng = np.random.default_rng(4242)
+    AS_CONSTRUCTED = 0xFFFFFFFF
+    n_ok = 0
+    for name, soft in v2_frame_cases(oracle, 0, rng, 60):
+        as_built = ref.v2_decode_frame(0, soft, AS_CONSTRUCTED)
+        assert as_built == ref.v2_decode_frame(0, soft, 60) == oracle.v2_decode_frame(0, soft, 60), name
+        n_ok += as_built["success"]
+    assert n_ok >= 6
+    # and frames sent WITHOUT interleaving fail CW0 on a default pipeline (they would pass with interleaving off)
+    cws = oracle.v2_build_frame(0, b"plain", seq=1)
+    soft = (4.0 * (1.0 - 2.0 * np.unpackbits(cws, axis=1))).astype(np.float32).reshape(-1)
+    assert ref.v2_decode_frame(0, soft, 0)["success"] == 1
+    assert ref.v2_decode_frame(0, soft, AS_CONSTRUCTED)["success"] == 0
+
