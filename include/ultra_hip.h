@@ -33,7 +33,7 @@
 extern "C" {
 #endif
 
-#define ULTRA_HIP_ABI_VERSION 3
+#define ULTRA_HIP_ABI_VERSION 4
 
 /* ultra::Modulation (include/ultra/types.hpp:27-39) — same numeric values. */
 enum ultra_hip_modulation {
@@ -215,9 +215,9 @@ int ultra_hip_demod_batch(ultra_hip_ctx* ctx, const float* d_audio, size_t frame
 #define ULTRA_HIP_STATE_RESERVED       7
 
 /*
- * Fused receive path: demodulate, keep the first 648 LLRs of each frame on
- * chip, LDPC-decode them.  Same arguments as the two calls above; d_llr may be
- * NULL (LLRs are then never written to HBM).
+ * The whole receive path in one call: demodulate (one set of launches per OFDM symbol), then LDPC-decode the
+ * first 648 LLRs of each frame.  Same arguments as the two calls above; d_llr may be NULL — the LLRs then
+ * travel through a workspace of the context in HBM (llrs_per_frame floats per frame) instead of a caller buffer.
  * Replaces the per-frame body of the reference's Monte-Carlo harnesses
  * (tools/test_nvis_mode.cpp:88-113): demod.process → getSoftBits → first 648
  * → decoder.decodeSoft.
@@ -367,6 +367,22 @@ int ultra_hip_make_batch(ultra_hip_ctx* ctx, uint64_t seed, uint64_t first_frame
                          float snr_db, float delay_ms, float doppler_hz, float* d_audio, size_t frame_stride,
                          uint8_t* d_payload);
 
+/* LDPC-only stimulus on the device (BASELINE.json configs[3]: "LDPC R1/4 ... SNR sweep -11..+30 dB"):
+ * codewords first_cw .. first_cw + n_cw - 1 of the context's code rate as BPSK over AWGN, handed to the decoder as
+ * LLRs 2y / sigma^2 with sigma^2 = 1 / (2 Es/N0).  The reference has no LDPC-only SNR harness (its decoder tests
+ * build +-LLR vectors by hand, tests/test_comprehensive_modem.cpp:185-240), so the generator is this build's; it keeps
+ * the harness shape of tools/test_mode_snr.cpp:18-109 (random payload of floor(k/8) bytes -> LDPCEncoder::encode,
+ * src/fec/ldpc_encoder.cpp:193-257 -> noise -> decodeSoft -> compare the payload bytes) and the sign convention
+ * LLR > 0 <=> bit 0.
+ *   d_llr      [n_cw][648] f32
+ *   d_payload  [n_cw][floor(k/8)] bytes (what ultra_hip_count_errors compares)
+ * Payload bytes are those of ultra_hip_make_batch for the same (seed, index).  The noise is counter-based
+ * Box-Muller with libm-exact logf / sincosf / sqrtf (csrc/pinned_math.h), so the test oracle's twin
+ * (uo_make_llr_batch, plain libm calls) reproduces every LLR bit for bit: any codeword of any sweep point can be
+ * regenerated and decoded on the host. */
+int ultra_hip_make_llr_batch(ultra_hip_ctx* ctx, uint64_t seed, uint64_t first_cw, size_t n_cw, float esn0_db,
+                             float* d_llr, uint8_t* d_payload);
+
 /* Channel deinterleaver of the production receive path, fused into the decoder's LLR load.
  * Replaces RxPipeline::setInterleaverConfig(bits_per_symbol) + deinterleaveCodewords
  * (src/gui/modem/rx_pipeline.cpp:24-31,475-491): every 648-LLR codeword handed to
@@ -409,7 +425,7 @@ int ultra_hip_memset(ultra_hip_ctx* ctx, void* d_dst, int value, size_t bytes);
 /* Device self-test of the pinned libm restatement (projectultra_amd/csrc/
  * pinned_math.h): out[i] = fn(a[i] [, b[i]]) evaluated on the GPU, so tests
  * can compare with the host libm the reference calls.
- * fn: 0 sinf, 1 cosf, 2 atanf, 3 atan2f(a, b), 4 hypotf(a, b). */
+ * fn: 0 sinf, 1 cosf, 2 atanf, 3 atan2f(a, b), 4 hypotf(a, b), 5 logf, 6 sqrtf (the last two: stimulus only). */
 int ultra_hip_selftest_math(ultra_hip_ctx* ctx, int fn, const float* d_a, const float* d_b,
                             float* d_out, size_t n);
 

@@ -223,6 +223,28 @@ class _Base:
         assert rc == 0
         return (out, iters, ok, total) if want_total else (out, iters, ok)
 
+    def ldpc_decode_batch_mt(self, rate, llr, n_threads, max_iters=50):
+        """uo_ldpc_decode_batch over worker threads (the timed CPU leg of the LDPC-only bench)."""
+        llr = _f32(llr).reshape(-1, 648)
+        n = llr.shape[0]
+        nbytes = (INFO_BITS[rate] + 7) // 8
+        out = np.zeros((n, nbytes), np.uint8)
+        iters = np.zeros(n, np.int32)
+        ok = np.zeros(n, np.uint8)
+        rc = self._fn("ldpc_decode_batch_mt")(C.c_uint32(rate), C.c_int(max_iters), _ptr(llr), C.c_uint32(n), C.c_int(n_threads),
+                                              _ptr(out, C.c_uint8), C.c_uint32(nbytes), _ptr(iters, C.c_int32), _ptr(ok, C.c_uint8))
+        assert rc == 0
+        return out, iters, ok
+
+    def make_llr_batch(self, rate, n, esn0_db, seed=0x5EED, c0=0):
+        """BPSK-over-AWGN LLRs of codewords c0 .. c0+n-1 (twin of ultra_hip_make_llr_batch) -> (llr [n][648], payload)."""
+        llr = np.zeros((n, 648), np.float32)
+        payload = np.zeros((n, INFO_BITS[rate] // 8), np.uint8)
+        rc = self._fn("make_llr_batch")(C.c_uint32(rate), C.c_uint64(seed), C.c_uint64(c0), C.c_uint32(n), C.c_float(esn0_db),
+                                        _ptr(llr), _ptr(payload, C.c_uint8))
+        assert rc == 0, rc
+        return llr, payload
+
     # -------------------------------------------------------------- DSP
     def fft_forward(self, x):
         x = np.ascontiguousarray(x, np.complex64)

@@ -365,6 +365,35 @@ int uo_ldpc_decode_batch(uint32_t rate, int max_iters, const float* llr, uint32_
     return 0;
 }
 
+/* The same over n_threads worker threads (disjoint codeword ranges): the timed CPU leg of the LDPC-only bench. */
+typedef struct dec_job { uint32_t rate; int max_iters; const float* llr; uint32_t n0, n1; uint8_t* out; uint32_t bpc;
+                         int32_t* iters; uint8_t* ok; int rc; } dec_job;
+static void* dec_worker(void* arg) {
+    dec_job* j = (dec_job*)arg;
+    j->rc = uo_ldpc_decode_batch(j->rate, j->max_iters, j->llr + (size_t)LDPC_N * j->n0, j->n1 - j->n0,
+                                 j->out + (size_t)j->bpc * j->n0, j->bpc, j->iters + j->n0, j->ok + j->n0, NULL);
+    return NULL;
+}
+int uo_ldpc_decode_batch_mt(uint32_t rate, int max_iters, const float* llr, uint32_t n_cw, int n_threads,
+                            uint8_t* out, uint32_t bytes_per_cw, int32_t* iters, uint8_t* ok) {
+    if (n_threads < 1) n_threads = 1;
+    if ((uint32_t)n_threads > n_cw) n_threads = n_cw ? (int)n_cw : 1;
+    (void)ldpc_get(rate);                              /* build the code before the threads start */
+    dec_job* jobs = (dec_job*)calloc((size_t)n_threads, sizeof(dec_job));
+    pthread_t* th = (pthread_t*)calloc((size_t)n_threads, sizeof(pthread_t));
+    for (int t = 0; t < n_threads; ++t) {
+        dec_job* j = &jobs[t];
+        j->rate = rate; j->max_iters = max_iters; j->llr = llr; j->out = out; j->bpc = bytes_per_cw; j->iters = iters; j->ok = ok;
+        j->n0 = (uint32_t)((uint64_t)n_cw * (uint64_t)t / (uint64_t)n_threads);
+        j->n1 = (uint32_t)((uint64_t)n_cw * (uint64_t)(t + 1) / (uint64_t)n_threads);
+        if (n_threads == 1) dec_worker(j); else pthread_create(&th[t], NULL, dec_worker, j);
+    }
+    int rc = 0;
+    for (int t = 0; t < n_threads; ++t) { if (n_threads > 1) pthread_join(th[t], NULL); if (jobs[t].rc) rc = jobs[t].rc; }
+    free(jobs); free(th);
+    return rc;
+}
+
 /* Interleaver(rows, cols)::deinterleave(soft), src/fec/ldpc_decoder.cpp:454-466,530-540 */
 int uo_interleaver_deinterleave(uint32_t rows, uint32_t cols, const float* in, uint32_t n, float* out) {
     size_t np = (size_t)rows * cols;
@@ -2262,4 +2291,57 @@ int uo_make_batch(const ultra_hip_config* c, uint64_t seed, uint64_t f0, uint32_
     for (int t = 0; t < n_threads; ++t) { if (n_threads > 1) pthread_join(th[t], NULL); if (jobs[t].rc) rc = jobs[t].rc; }
     free(jobs); free(th);
     return rc;
+}
+
+/* ---------------------------------------------------------------------- */
+/* BPSK-over-AWGN LLR stimulus — twin of the device's   */
+/* ultra_hip_make_llr_batch.  Build-defined (the reference has no LDPC-only */
+/* SNR harness); harness shape of tools/test_mode_snr.cpp:18-109: random    */
+/* payload of floor(k/8) bytes -> LDPCEncoder::encode (ldpc_encoder.cpp:    */
+/* 193-257) -> noise -> LLR.  Every step is ONE IEEE float operation or a   */
+/* libm call (logf, sqrtf, sinf, cosf), so the device, whose kernels carry  */
+/* bit-exact restatements of those libm functions, produces the same bits.  */
+/* ---------------------------------------------------------------------- */
+static inline uint64_t splitmix_at(uint64_t s0, uint64_t n) {      /* output of call n (0-based) of splitmix64 seeded s0 */
+    uint64_t z = s0 + (n + 1ull) * 0x9E3779B97F4A7C15ull;
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+    return z ^ (z >> 31);
+}
+static inline void gauss_pair_exact(uint64_t key, uint64_t n, float* g0, float* g1) {
+    uint64_t z = splitmix_at(key, n);
+    float u1 = ((float)((z >> 40) & 0xFFFFFFull) + 1.0f) * (1.0f / 16777216.0f);   /* (0, 1] */
+    float u2 = (float)((z >> 8) & 0xFFFFFFull) * (1.0f / 16777216.0f);             /* [0, 1) */
+    float rad = sqrtf(-2.0f * logf(u1));
+    float ang = 6.283185307179586f * u2;
+    *g0 = rad * cosf(ang);
+    *g1 = rad * sinf(ang);
+}
+int uo_make_llr_batch(uint32_t rate, uint64_t seed, uint64_t c0, uint32_t n_cw, float esn0_db,
+                      float* llr_out, uint8_t* payload_out) {
+    const ldpc_code* code = ldpc_get(rate);
+    int k = code->k, pb = k / 8;
+    double esn0 = pow(10.0, (double)esn0_db / 10.0);
+    float sigma2 = (float)(1.0 / (2.0 * esn0));
+    float sigma = (float)sqrt(1.0 / (2.0 * esn0));
+    uint8_t enc[96];
+    for (uint32_t w = 0; w < n_cw; ++w) {
+        uint64_t c = c0 + w;
+        uint64_t s0 = (seed ^ c) * 0xD1342543DE82EF95ull + 0x5EEDull;
+        uint8_t* pl = payload_out + (size_t)w * (size_t)pb;
+        for (int b = 0; b < pb; ++b) pl[b] = (uint8_t)(splitmix_at(s0, (uint64_t)b) >> 56);
+        if (uo_ldpc_encode(rate, pl, (uint32_t)pb, enc, sizeof(enc)) != 81) return -1;
+        uint64_t key = ((seed ^ (c * 0x100000001B3ull)) * 0x9E3779B97F4A7C15ull + 0xC4A77E1ull) ^ 0x4444ull;
+        float* out = llr_out + (size_t)LDPC_N * w;
+        for (int p = 0; p < LDPC_N / 2; ++p) {
+            float g0, g1;
+            gauss_pair_exact(key, (uint64_t)p, &g0, &g1);
+            int b0 = (enc[(2 * p) / 8] >> (7 - (2 * p) % 8)) & 1, b1 = (enc[(2 * p + 1) / 8] >> (7 - (2 * p + 1) % 8)) & 1;
+            float x0 = b0 ? -1.0f : 1.0f, x1 = b1 ? -1.0f : 1.0f;
+            float y0 = x0 + sigma * g0, y1 = x1 + sigma * g1;
+            out[2 * p] = (2.0f * y0) / sigma2;
+            out[2 * p + 1] = (2.0f * y1) / sigma2;
+        }
+    }
+    return 0;
 }

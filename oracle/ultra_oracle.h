@@ -45,6 +45,12 @@ int uo_ldpc_decode_soft(uint32_t rate, int max_iters, const float* llr, uint32_t
 int uo_ldpc_decode_batch(uint32_t rate, int max_iters, const float* llr, uint32_t n_cw,
                          uint8_t* out, uint32_t bytes_per_cw, int32_t* iters, uint8_t* ok,
                          float* llr_total_out);
+int uo_ldpc_decode_batch_mt(uint32_t rate, int max_iters, const float* llr, uint32_t n_cw, int n_threads,
+                            uint8_t* out, uint32_t bytes_per_cw, int32_t* iters, uint8_t* ok);
+/* BPSK-over-AWGN LLRs 2y/sigma^2, sigma^2 = 1/(2 Es/N0), of codewords c0 .. c0+n_cw-1: twin of
+ * ultra_hip_make_llr_batch, bit for bit (libm logf/sqrtf/sinf/cosf).  llr_out [n_cw][648], payload_out [n_cw][k/8]. */
+int uo_make_llr_batch(uint32_t rate, uint64_t seed, uint64_t c0, uint32_t n_cw, float esn0_db,
+                      float* llr_out, uint8_t* payload_out);
 int uo_interleaver_deinterleave(uint32_t rows, uint32_t cols, const float* in, uint32_t n, float* out);
 int uo_channel_interleaver_perm(uint32_t bits_per_symbol, uint32_t total, uint32_t* perm, uint32_t* inv);
 

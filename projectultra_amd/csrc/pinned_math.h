@@ -324,6 +324,49 @@ UM_FN float hypotf_(float x, float y) {
     return (float)sqrt(dx * dx + dy * dy);
 }
 
+// glibc 2.35 logf (sysdeps/ieee754/flt-32/e_logf.c = ARM optimized-routines logf: 16-entry table of (1/c, log c),
+// degree-3 polynomial in double, one rounding to float), the FMA build x86-64 dispatches (`__logf_fma`; operation
+// order read from the disassembly of this image's libm.so.6, table and coefficients from its .rodata — they agree
+// with the published logf_data.c).  NOT on the receive path: the Monte-Carlo stimulus generators' Box-Muller
+// transform uses it (stimulus_kernel.h, ultra_hip_make_llr_batch) so that the test oracle, which calls libm's logf,
+// reproduces the device's noise bit for bit.  Checked against libm over every float (tools/pinned_math_check.cpp).
+UM_FN float logf_(float x) {
+    const double invc[16] = {0x1.661ec79f8f3bep+0, 0x1.571ed4aaf883dp+0, 0x1.49539f0f010bp+0, 0x1.3c995b0b80385p+0,
+                             0x1.30d190c8864a5p+0, 0x1.25e227b0b8eap+0, 0x1.1bb4a4a1a343fp+0, 0x1.12358f08ae5bap+0,
+                             0x1.0953f419900a7p+0, 0x1p+0, 0x1.e608cfd9a47acp-1, 0x1.ca4b31f026aap-1,
+                             0x1.b2036576afce6p-1, 0x1.9c2d163a1aa2dp-1, 0x1.886e6037841edp-1, 0x1.767dcf5534862p-1};
+    const double logc[16] = {-0x1.57bf7808caadep-2, -0x1.2bef0a7c06ddbp-2, -0x1.01eae7f513a67p-2, -0x1.b31d8a68224e9p-3,
+                             -0x1.6574f0ac07758p-3, -0x1.1aa2bc79c81p-3, -0x1.a4e76ce8c0e5ep-4, -0x1.1973c5a611cccp-4,
+                             -0x1.252f438e10c1ep-5, 0x0p+0, 0x1.aa5aa5df25984p-5, 0x1.c5e53aa362eb4p-4,
+                             0x1.526e57720db08p-3, 0x1.bc2860d22477p-3, 0x1.1058bc8a07ee1p-2, 0x1.4043057b6ee09p-2};
+    const double ln2 = 0x1.62e42fefa39efp-1;
+    const double A0 = -0x1.00ea348b88334p-2, A1 = 0x1.5575b0be00b6ap-2, A2 = -0x1.ffffef20a4123p-2;
+    uint32_t ix = as_u32(x);
+    if (ix == 0x3f800000u) return 0.0f;                          // log(1) = +0 in every rounding mode
+    if (ix - 0x00800000u >= 0x7f800000u - 0x00800000u) {         // zero, subnormal, negative, inf, NaN
+        if (ix * 2u == 0u) return -INFINITY;                     // log(+-0) = -inf (errno aside)
+        if (ix == 0x7f800000u) return x;                         // log(inf) = inf
+        if ((ix & 0x80000000u) || ix * 2u >= 0xff000000u) return (x - x) / (x - x);   // negative or NaN -> NaN
+        ix = as_u32(x * 0x1p23f);                                // subnormal: normalise
+        ix -= 23u << 23;
+    }
+    const uint32_t tmp = ix - 0x3f330000u;
+    const int i = (int)((tmp >> 19) & 15u);
+    const int k = (int32_t)tmp >> 23;
+    const uint32_t iz = ix - (tmp & 0xff800000u);
+    const double z = (double)as_f32(iz);
+    // table lookup as selects (a dynamically indexed local array would live in scratch memory on the GPU)
+    double ic = invc[0], lc = logc[0];
+    for (int t = 1; t < 16; ++t) { if (i == t) { ic = invc[t]; lc = logc[t]; } }
+    const double r = fma(z, ic, -1.0);
+    const double y0 = fma((double)k, ln2, lc);
+    const double r2 = r * r;
+    double y = fma(A1, r, A2);
+    y = fma(A0, r2, y);
+    y = fma(y, r2, y0 + r);
+    return (float)y;
+}
+
 // fabsf(atan2f(y, x)) > 1.5708f — the test of interpolateChannel (channel_equalizer.cpp:613-617) — without the
 // arctangent in all but a sliver of cases.  1.5708f = 1.57080006... lies 3.7e-6 above pi/2:
 //   * x with a clear sign bit (and not NaN): the angle is in [-pi/2, pi/2], atan2f returns at most the float

@@ -397,6 +397,68 @@ __global__ __launch_bounds__(kWave) void channel_kernel(
     }
 }
 
+// ---- BPSK-over-AWGN LLR stimulus (BASELINE configs[3]: the LDPC-only SNR sweep) -----------------
+// Counter-based standard normal pair for (key, n) with libm-exact arithmetic: Box-Muller on two 24-bit uniforms,
+// logf / sincosf from pinned_math.h (bit-identical to glibc 2.35's), correctly rounded sqrtf, every other step one
+// IEEE float operation.  The test oracle's twin (uo_make_llr_batch) calls libm and reproduces every LLR bit for bit,
+// so any codeword of any sweep point can be regenerated and decoded on the host.
+__device__ __forceinline__ void gauss_pair_exact(unsigned long long key, unsigned long long n, float* g0, float* g1) {
+    const unsigned long long z = splitmix_at(key, n);
+    const float u1 = ((float)((z >> 40) & 0xFFFFFFull) + 1.0f) * (1.0f / 16777216.0f);     // (0, 1]
+    const float u2 = (float)((z >> 8) & 0xFFFFFFull) * (1.0f / 16777216.0f);               // [0, 1)
+    const float rad = sqrtf(-2.0f * um::logf_(u1));
+    float sn, cs;
+    um::sincosf_(6.283185307179586f * u2, &sn, &cs);
+    *g0 = rad * cs;
+    *g1 = rad * sn;
+}
+
+// One wavefront per codeword c = c0 + i: payload bytes (the stream of stimulus_kernel / uo_make_batch for frame c)
+// -> LDPCEncoder::encode (src/fec/ldpc_encoder.cpp:193-257: k information bits, zeros behind the payload, parity
+// i = xor of the row's information bits) -> BPSK x = 1 - 2 bit (LLR > 0 <=> bit 0, docs/INVARIANTS.md:213-222)
+// -> y = x + sigma * n -> LLR = 2 y / sigma^2.  sigma, sigma2: floats computed by the host from Es/N0.
+__global__ __launch_bounds__(kWave) void llr_stimulus_kernel(const LdpcPlan* __restrict__ Pp, unsigned long long seed,
+                                                             unsigned long long c0, int n_cw, int payload_bytes, float sigma,
+                                                             float sigma2, float* __restrict__ llr,
+                                                             unsigned char* __restrict__ payload_out) {
+    __shared__ unsigned char bits[kLdpcN + 8];
+    const LdpcPlan& L = *Pp;
+    const int lane = threadIdx.x;
+    const int k = L.k;
+    for (int cw = blockIdx.x; cw < n_cw; cw += gridDim.x) {
+        const unsigned long long c = c0 + (unsigned long long)cw;
+        const unsigned long long s0 = (seed ^ c) * 0xD1342543DE82EF95ull + 0x5EEDull;
+        for (int j = lane; j < k; j += kWave) bits[j] = 0;
+        wave_sync();
+        for (int b = lane; b < payload_bytes; b += kWave) {
+            const unsigned char byte = (unsigned char)(splitmix_at(s0, (unsigned long long)b) >> 56);
+            payload_out[(size_t)cw * payload_bytes + b] = byte;
+#pragma unroll
+            for (int t = 0; t < 8; ++t) bits[8 * b + t] = (unsigned char)((byte >> (7 - t)) & 1);
+        }
+        wave_sync();
+        for (int i = lane; i < L.row_rounds * 64; i += kWave) {              // row slots (may have gaps)
+            if (L.row_deg[i] == 0) continue;
+            unsigned char s = 0;
+#pragma unroll
+            for (int t = 0; t < 6; ++t) { const unsigned col = L.row_col[i * 6 + t]; if (col != 0xFFFFu) s ^= bits[col]; }
+            bits[k + L.row_id[i]] = s;
+        }
+        wave_sync();
+        const unsigned long long key = ((seed ^ (c * 0x100000001B3ull)) * 0x9E3779B97F4A7C15ull + 0xC4A77E1ull) ^ 0x4444ull;
+        float* out = llr + (size_t)cw * kLdpcN;
+        for (int p = lane; p < kLdpcN / 2; p += kWave) {                     // noise pair p -> bits 2p, 2p + 1
+            float g0, g1;
+            gauss_pair_exact(key, (unsigned long long)p, &g0, &g1);
+            const float x0 = bits[2 * p] ? -1.0f : 1.0f, x1 = bits[2 * p + 1] ? -1.0f : 1.0f;
+            const float y0 = x0 + sigma * g0, y1 = x1 + sigma * g1;
+            out[2 * p] = (2.0f * y0) / sigma2;
+            out[2 * p + 1] = (2.0f * y1) / sigma2;
+        }
+        wave_sync();
+    }
+}
+
 }  // namespace dev
 }  // namespace ultra_hip
 #endif

@@ -8,6 +8,7 @@
 #include <hip/hip_runtime.h>
 
 #include <dlfcn.h>
+#include <cmath>
 #include <cstdio>
 #include <cstring>
 #include <new>
@@ -700,6 +701,25 @@ int ultra_hip_make_batch(ultra_hip_ctx* ctx, uint64_t seed, uint64_t first_frame
     return ULTRA_HIP_OK;
 }
 
+int ultra_hip_make_llr_batch(ultra_hip_ctx* ctx, uint64_t seed, uint64_t first_cw, size_t n_cw, float esn0_db,
+                             float* d_llr, uint8_t* d_payload) {
+    if (!ctx) return ULTRA_HIP_ERR_INVALID_ARG;
+    if (n_cw == 0) return ULTRA_HIP_OK;
+    if (!d_llr || !d_payload || n_cw > 0x7fffffffull || !(esn0_db > -100.0f && esn0_db < 100.0f))
+        return ULTRA_HIP_ERR_INVALID_ARG;
+    DeviceGuard guard(ctx->device);
+    // sigma^2 = N0 / 2 = 1 / (2 Es/N0) for unit-energy BPSK; both as floats, from one double evaluation
+    const double esn0 = std::pow(10.0, (double)esn0_db / 10.0);
+    const float sigma2 = (float)(1.0 / (2.0 * esn0));
+    const float sigma = (float)std::sqrt(1.0 / (2.0 * esn0));
+    const unsigned grid = (unsigned)std::min(n_cw, (size_t)ctx->cu_count * 64);
+    hipLaunchKernelGGL(dev::llr_stimulus_kernel, dim3(grid), dim3(dev::kWave), 0, ctx->stream, ctx->d_plan,
+                       (unsigned long long)seed, (unsigned long long)first_cw, (int)n_cw, (int)ctx->geo.ldpc_k / 8, sigma,
+                       sigma2, d_llr, d_payload);
+    UH_HIP(hipGetLastError());
+    return ULTRA_HIP_OK;
+}
+
 int ultra_hip_chirp_sync_batch(ultra_hip_ctx* ctx, const float* d_audio, size_t stream_stride, uint32_t n_samples,
                                size_t n_streams, float threshold, uint32_t* d_detected, int32_t* d_start_sample,
                                float* d_cfo_hz, float* d_correlation, int32_t* d_up_chirp_start,
@@ -869,7 +889,7 @@ int ultra_hip_memset(ultra_hip_ctx* ctx, void* d_dst, int value, size_t bytes) {
 
 // Device self-test of pinned_math.h: evaluates fn over n inputs on the GPU so
 // the tests can compare with the host libm (not part of the reference surface).
-//   fn: 0 sinf, 1 cosf, 2 atanf, 3 atan2f(a, b), 4 hypotf(a, b)
+//   fn: 0 sinf, 1 cosf, 2 atanf, 3 atan2f(a, b), 4 hypotf(a, b), 5 logf, 6 sqrtf
 __global__ void pinned_math_kernel(int fn, const float* a, const float* b, float* out, int n) {
     int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
@@ -879,13 +899,15 @@ __global__ void pinned_math_kernel(int fn, const float* a, const float* b, float
         case 1: r = um::cosf_(a[i]); break;
         case 2: r = um::atanf_(a[i]); break;
         case 3: r = um::atan2f_(a[i], b[i]); break;
+        case 5: r = um::logf_(a[i]); break;
+        case 6: r = sqrtf(a[i]); break;                       // correctly rounded (-fhip-fp32-correctly-rounded-divide-sqrt)
         default: r = um::hypotf_(a[i], b[i]); break;
     }
     out[i] = r;
 }
 
 int ultra_hip_selftest_math(ultra_hip_ctx* ctx, int fn, const float* d_a, const float* d_b, float* d_out, size_t n) {
-    if (!ctx || !d_a || !d_out || fn < 0 || fn > 4 || (fn >= 3 && !d_b) || n > 0x7fffffffull)
+    if (!ctx || !d_a || !d_out || fn < 0 || fn > 6 || ((fn == 3 || fn == 4) && !d_b) || n > 0x7fffffffull)
         return ULTRA_HIP_ERR_INVALID_ARG;
     if (n == 0) return ULTRA_HIP_OK;
     DeviceGuard guard(ctx->device);

@@ -311,6 +311,32 @@ class ReceiveContext:
                                             payload.data_ptr()), "ultra_hip_make_batch")
         return audio, payload
 
+    def make_llr_batch(self, n_cw: int, esn0_db: float, seed: int = 0x5EED, first_cw: int = 0, out=None):
+        """BPSK-over-AWGN LLRs of n_cw random codewords of the context's rate, generated on the device
+        (ultra_hip_make_llr_batch; SURVEY.md 8d cfg4).  Returns (llr [n][648] f32, payload [n][k // 8] u8); `out` may
+        hand in that pair to be overwritten.  Bit-identical to the oracle's uo_make_llr_batch."""
+        torch = _torch()
+        g = self.geometry
+        if out is None:
+            llr = torch.empty((n_cw, LDPC_BLOCK_SIZE), dtype=torch.float32, device=self.device)
+            payload = torch.empty((n_cw, g.ldpc_k // 8), dtype=torch.uint8, device=self.device)
+        else:
+            llr, payload = out
+            self._check_out(llr, (n_cw, LDPC_BLOCK_SIZE), torch.float32, "llr")
+            self._check_out(payload, (n_cw, g.ldpc_k // 8), torch.uint8, "payload")
+        check(self.lib.ultra_hip_make_llr_batch(self._ctx, int(seed), int(first_cw), n_cw, float(esn0_db), llr.data_ptr(),
+                                                payload.data_ptr()), "ultra_hip_make_llr_batch")
+        return llr, payload
+
+    def _check_out(self, t, shape, dtype, what):
+        """A caller-supplied output tensor goes to the kernels as a raw pointer: refuse anything but the exact
+        shape / dtype / device, contiguous."""
+        torch = _torch()
+        if (not isinstance(t, torch.Tensor) or tuple(t.shape) != tuple(shape) or t.dtype != dtype
+                or t.device != self.device or not t.is_contiguous()):
+            raise _lib.UltraHipError(-1, f"output tensor '{what}' must be a contiguous {dtype} tensor of shape "
+                                         f"{tuple(shape)} on {self.device}")
+
     def set_deinterleave(self, bits_per_symbol: int):
         """RxPipeline::setInterleaverConfig + deinterleaveCodewords (rx_pipeline.cpp:24-31,475-491): every
         codeword is passed through ChannelInterleaver(bits_per_symbol, 648)::deinterleave before it is

@@ -196,6 +196,31 @@ def test_device_math_matches_host_libm():
         assert beq(got, want), (name, np.flatnonzero(got.view(np.uint32) != want.view(np.uint32))[:5])
 
 
+def test_device_logf_sqrtf_match_host_libm():
+    """The two libm functions of the stimulus generators' Box-Muller transform, evaluated ON THE GPU: logf
+    (pinned_math.h, glibc 2.35's FMA build) and the correctly rounded sqrtf — over (0, 1] on the 24-bit grid the
+    generator draws from, and over arbitrary floats incl. zeros, subnormals, negatives, infinities and NaN."""
+    import ctypes, ctypes.util
+    libm = ctypes.CDLL(ctypes.util.find_library("m"))
+    for f in ("logf", "sqrtf"):
+        getattr(libm, f).restype = ctypes.c_float; getattr(libm, f).argtypes = [ctypes.c_float]
+    ctx = context_for(make_config(512, "DQPSK", "R1_2"))
+    rng = np.random.default_rng(23)
+    grid = ((rng.integers(0, 1 << 24, 150_000).astype(np.float32) + 1.0) * np.float32(2.0 ** -24)).astype(np.float32)
+    anyf = rng.integers(0, 1 << 32, 150_000, dtype=np.uint64).astype(np.uint32).view(np.float32)
+    special = np.array([0.0, -0.0, 1.0, 2.0 ** -24, 1e-45, 1.1754942e-38, 1.17549435e-38, -1.0, np.inf, -np.inf, np.nan,
+                        3.4028235e38, 0.99999994, 1.0000001], np.float32)
+    a = np.concatenate([special, grid, anyf])
+    for fn, name in ((5, "logf"), (6, "sqrtf")):
+        got = ctx.selftest_math(fn, a)
+        ctx.synchronize()
+        got = got.cpu().numpy()
+        f = getattr(libm, name)
+        want = np.array([f(x) for x in a.tolist()], np.float32)
+        same = (got.view(np.uint32) == want.view(np.uint32)) | (np.isnan(got) & np.isnan(want))
+        assert same.all(), (name, a[~same][:5], got[~same][:5], want[~same][:5])
+
+
 @pytest.mark.parametrize("fft,mod,rate", [(1024, "QAM16", "R3_4"), (512, "DQPSK", "R1_2")])
 def test_acquisition_matches_oracle(oracle, fft, mod, rate):
     """Scope row f1: the chunk-fed Schmidl-Cox search + coarse CFO + LTS refinement on the GPU equals the

@@ -169,6 +169,51 @@ def test_full_size_round_trip_property(oracle):
     assert ook[clean].mean() > 0.99
 
 
+@pytest.mark.parametrize("rate,esn0_db", [(0, -11.0), (0, -3.0), (2, 0.5), (3, 2.5), (4, 3.5), (5, 30.0), (1, -1.0)])
+def test_llr_stimulus_bitwise_vs_oracle(oracle, rate, esn0_db):
+    """ultra_hip_make_llr_batch (BASELINE configs[3] stimulus: random payload -> encode -> BPSK -> AWGN -> 2y/sigma^2,
+    on the device) against the oracle's twin, which calls libm: payload bytes and every LLR bit for bit, at a
+    ragged batch size and a codeword offset; then the decode of those LLRs, exactly."""
+    from projectultra_amd import CodeRate, LDPCDecoder
+    ctx = LDPCDecoder(CodeRate(rate)).context
+    n, c0, seed = 1500 + 37, (1 << 33) + 12345, 0xABCDEF12345
+    llr, payload = ctx.make_llr_batch(n, esn0_db, seed=seed, first_cw=c0)
+    r = ctx.ldpc_decode(llr)
+    ctx.synchronize()
+    want_llr, want_payload = oracle.make_llr_batch(rate, n, esn0_db, seed=seed, c0=c0)
+    assert np.array_equal(payload.cpu().numpy(), want_payload)
+    got = llr.cpu().numpy()
+    assert beq(got, want_llr), np.argwhere(got.view(np.uint32) != want_llr.view(np.uint32))[:5]
+    ob, oi, ook = oracle.ldpc_decode_batch(rate, want_llr)
+    assert np.array_equal(r["bytes"].cpu().numpy(), ob) and np.array_equal(r["iters"].cpu().numpy(), oi)
+    assert np.array_equal(r["ok"].cpu().numpy(), ook)
+    # the same codewords in two halves (a sharded sweep generates disjoint index ranges): identical bits
+    half = n // 2
+    a, _ = ctx.make_llr_batch(half, esn0_db, seed=seed, first_cw=c0)
+    b, _ = ctx.make_llr_batch(n - half, esn0_db, seed=seed, first_cw=c0 + half)
+    assert beq(np.concatenate([a.cpu().numpy(), b.cpu().numpy()]), want_llr)
+
+
+def test_llr_stimulus_noise_statistics(oracle):
+    """The generator's noise is N(0, sigma^2) with sigma^2 = 1/(2 Es/N0): mean, variance, kurtosis and the tail mass of
+    y - x over 2^14 codewords, and independence from the payload (different seeds give different noise)."""
+    from projectultra_amd import CodeRate, LDPCDecoder
+    ctx = LDPCDecoder(CodeRate.R1_2).context
+    n, snr = 1 << 14, 1.0
+    llr, payload = ctx.make_llr_batch(n, snr, seed=99)
+    ctx.synchronize()
+    s2 = 1.0 / (2.0 * 10.0 ** (snr / 10.0))
+    y = llr.cpu().numpy().astype(np.float64) * s2 / 2.0
+    enc = np.stack([np.unpackbits(np.frombuffer(oracle.ldpc_encode(2, bytes(p)), np.uint8))[:648] for p in payload.cpu().numpy()[:256]])
+    z = (y[:256] - (1.0 - 2.0 * enc)) / np.sqrt(s2)
+    assert abs(z.mean()) < 0.01 and abs(z.var() - 1.0) < 0.01 and abs(((z - z.mean()) ** 4).mean() / z.var() ** 2 - 3.0) < 0.05
+    assert abs((np.abs(z) > 3.0).mean() - 0.0027) < 0.0006
+    # whole batch: |y| is +-1 plus noise, so E[y^2] = 1 + sigma^2
+    assert abs((y ** 2).mean() - (1.0 + s2)) < 0.003
+    other, _ = ctx.make_llr_batch(64, snr, seed=100)
+    assert not np.array_equal(other.cpu().numpy(), llr[:64].cpu().numpy())
+
+
 def test_counters_allreduce_over_rccl():
     """ultra_hip_counters_allreduce on a one-rank RCCL communicator created by the host (ncclCommInitRank through
     ctypes): the plumbing a C++ Monte-Carlo harness uses for the single collective of the path.

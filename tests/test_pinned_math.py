@@ -14,7 +14,7 @@ def test_quick_subset_matches_libm(tmp_path):
     out = subprocess.run([str(exe), "quick"], capture_output=True, text=True, timeout=300)
     assert out.returncode == 0, out.stdout + out.stderr
     lines = dict(l.split()[0:1] + [l] for l in out.stdout.splitlines())
-    for fn in ("sinf", "cosf", "sincosf", "sincosf_bounded", "atanf", "atan2f", "hypotf", "right_angle_test"):
+    for fn in ("sinf", "cosf", "sincosf", "sincosf_bounded", "atanf", "atan2f", "hypotf", "right_angle_test", "logf"):
         assert "mismatches=0" in lines[fn], lines[fn]
 
 
@@ -22,6 +22,12 @@ def test_exhaustive_record_is_clean():
     txt = (ROOT / "profiles" / "r01_pinned_math_exhaustive.txt").read_text()
     assert txt.count("mismatches=0") == 8 and "checked=4294967296" in txt and "mismatches=0" in txt.splitlines()[-1]
     assert "right_angle_test checked=2147483904 mismatches=0" in txt
+
+
+def test_exhaustive_record_round2_includes_logf():
+    """logf (the Box-Muller of the LLR stimulus generator) over all 2^32 floats, next to a re-run of the others."""
+    txt = (ROOT / "profiles" / "r02_pinned_math_exhaustive.txt").read_text()
+    assert "logf checked=4294967296 mismatches=0" in txt and txt.count("mismatches=0") == 9
 
 
 def test_phase_table_equals_serial_recurrence(tmp_path):

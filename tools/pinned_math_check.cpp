@@ -1,7 +1,7 @@
 // tools/pinned_math_check.cpp — host check of projectultra_amd/csrc/pinned_math.h
 // against the libm of this machine (the functions the reference binary calls).
 //   g++ -O2 -std=c++17 -ffp-contract=off -mfma -pthread tools/pinned_math_check.cpp -o /tmp/pmc -lm
-//   /tmp/pmc full      # all 2^32 floats for sinf/cosf/sincosf/atanf, 2^31 random pairs atan2f/hypotf
+//   /tmp/pmc full      # all 2^32 floats for sinf/cosf/sincosf/atanf/logf, 2^31 random pairs atan2f/hypotf
 //   /tmp/pmc quick     # strided subset (used by tests/test_pinned_math.py)
 //   /tmp/pmc pairs     # only the two-argument functions and the right-angle test, 2^31 pairs
 // Prints one line per function: "<name> checked=<n> mismatches=<m>".  Exit code 1 on any mismatch.
@@ -30,11 +30,11 @@ int main(int argc, char** argv) {
     const unsigned T = std::max(1u, std::thread::hardware_concurrency());
     const uint64_t stride = full ? 1 : 1021;            // prime stride for the quick subset
     const uint64_t pairs = (full || pairs_only) ? (1ull << 31) : (1ull << 24);
-    std::atomic<uint64_t> bad[8]; for (auto& b : bad) b = 0;
-    std::atomic<uint64_t> cnt[8]; for (auto& c : cnt) c = 0;
+    std::atomic<uint64_t> bad[9]; for (auto& b : bad) b = 0;
+    std::atomic<uint64_t> cnt[9]; for (auto& c : cnt) c = 0;
     std::vector<std::thread> th;
     for (unsigned t = 0; t < T; ++t) th.emplace_back([&, t] {
-        uint64_t lb[8] = {0}, lc[8] = {0};
+        uint64_t lb[9] = {0}, lc[9] = {0};
         for (uint64_t u = t * stride; !pairs_only && u < (1ull << 32); u += (uint64_t)T * stride) {
             float x = um::as_f32((uint32_t)u);
             float s, c; sincosf(x, &s, &c);
@@ -47,6 +47,7 @@ int main(int argc, char** argv) {
                 lc[6]++; if (!same(bs, s) || !same(bc, c)) { if (lb[6]++ < 3) fprintf(stderr, "sincosf_bounded %08x\n", (unsigned)u); }
             }
             lc[3]++; if (!same(um::atanf_(x), atanf(x))) { if (lb[3]++ < 3) fprintf(stderr, "atanf %08x\n", (unsigned)u); }
+            lc[8]++; if (!same(um::logf_(x), logf(x))) { if (lb[8]++ < 3) fprintf(stderr, "logf %08x\n", (unsigned)u); }
         }
         uint64_t seed = 0x1234 + t;
         for (uint64_t i = t; i < pairs; i += T) {
@@ -75,12 +76,12 @@ int main(int argc, char** argv) {
                 lc[7]++; if (um::atan2f_beyond_right_angle(y, x) != (fabsf(atan2f(y, x)) > 1.5708f)) lb[7]++;
             }
         }
-        for (int k = 0; k < 8; ++k) { bad[k] += lb[k]; cnt[k] += lc[k]; }
+        for (int k = 0; k < 9; ++k) { bad[k] += lb[k]; cnt[k] += lc[k]; }
     });
     for (auto& x : th) x.join();
-    const char* names[8] = {"sinf", "cosf", "sincosf", "atanf", "atan2f", "hypotf", "sincosf_bounded", "right_angle_test"};
+    const char* names[9] = {"sinf", "cosf", "sincosf", "atanf", "atan2f", "hypotf", "sincosf_bounded", "right_angle_test", "logf"};
     int rc = 0;
-    for (int k = 0; k < 8; ++k) {
+    for (int k = 0; k < 9; ++k) {
         printf("%s checked=%llu mismatches=%llu\n", names[k], (unsigned long long)cnt[k].load(), (unsigned long long)bad[k].load());
         if (bad[k].load()) rc = 1;
     }
