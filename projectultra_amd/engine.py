@@ -64,6 +64,7 @@ class ReceiveContext:
         self.device = torch.device("cuda", self.device_index)
         with torch.cuda.device(self.device):
             stream = torch.cuda.current_stream().cuda_stream
+        self._stream = stream
         self._ctx = C.c_void_p()
         check(self.lib.ultra_hip_create(C.byref(self.cfg), self.device_index, C.c_void_p(stream), C.byref(self._ctx)),
               "ultra_hip_create")
@@ -115,15 +116,38 @@ class ReceiveContext:
         return float(ms.value)
 
     # ------------------------------------------------------------ hot path
-    def ldpc_decode(self, llr, want_total: bool = False):
+    def _result_buffers(self, n, out):
+        """dict(bytes [n][ceil(k/8)] u8, iters [n] i32, ok [n] u8): fresh, or the caller's (checked: they reach the
+        kernels as raw pointers)."""
+        torch = _torch()
+        g = self.geometry
+        if out is None:
+            return dict(bytes=torch.empty((n, g.decoded_bytes), dtype=torch.uint8, device=self.device),
+                        iters=torch.empty(n, dtype=torch.int32, device=self.device),
+                        ok=torch.empty(n, dtype=torch.uint8, device=self.device))
+        self._check_out(out["bytes"], (n, g.decoded_bytes), torch.uint8, "bytes")
+        self._check_out(out["iters"], (n,), torch.int32, "iters")
+        self._check_out(out["ok"], (n,), torch.uint8, "ok")
+        return dict(bytes=out["bytes"], iters=out["iters"], ok=out["ok"])
+
+    def _check_stream(self):
+        """The context launches on the stream that was current when it was created; torch allocates and frees the
+        tensors handed to it on whatever stream is current NOW.  A different current stream would let the caching
+        allocator reuse a temporary before the queued kernels have read it, so it is refused."""
+        torch = _torch()
+        with torch.cuda.device(self.device):
+            cur = torch.cuda.current_stream().cuda_stream
+        if cur != self._stream:
+            raise _lib.UltraHipError(-1, "ReceiveContext was created on another HIP stream than torch's current one; "
+                                         "create one context per stream")
+
+    def ldpc_decode(self, llr, want_total: bool = False, out=None):
         """[n][648] f32 LLRs -> dict(bytes [n][ceil(k/8)] u8, iters [n] i32, ok [n] u8[, llr_total])."""
         torch = _torch()
+        self._check_stream()
         llr = self._dev(llr, torch.float32, "llr").reshape(-1, LDPC_BLOCK_SIZE)
         n = llr.shape[0]
-        g = self.geometry
-        out = dict(bytes=torch.empty((n, g.decoded_bytes), dtype=torch.uint8, device=self.device),
-                   iters=torch.empty(n, dtype=torch.int32, device=self.device),
-                   ok=torch.empty(n, dtype=torch.uint8, device=self.device))
+        out = self._result_buffers(n, out)
         total = torch.empty((n, LDPC_BLOCK_SIZE), dtype=torch.float32, device=self.device) if want_total else None
         check(self.lib.ultra_hip_ldpc_decode_batch(self._ctx, llr.data_ptr(), n, out["bytes"].data_ptr(),
                                                    out["iters"].data_ptr(), out["ok"].data_ptr(),
@@ -155,6 +179,7 @@ class ReceiveContext:
     def demod(self, audio, cfo_hz=None, cfo_phase=None, want_state: bool = False):
         """audio [n][>=frame_samples] f32 -> LLRs [n][llrs_per_frame] (+ tracker state [n][8])."""
         torch = _torch()
+        self._check_stream()
         audio = self._frames(audio)
         n = audio.shape[0]
         cfo, cph = self._opt(cfo_hz, n), self._opt(cfo_phase, n)
@@ -169,14 +194,12 @@ class ReceiveContext:
     def demod_decode(self, audio, cfo_hz=None, cfo_phase=None, want_llr: bool = False, out=None):
         """Fused receive path -> dict(bytes, iters, ok[, llr])."""
         torch = _torch()
+        self._check_stream()
         audio = self._frames(audio)
         n = audio.shape[0]
         cfo, cph = self._opt(cfo_hz, n), self._opt(cfo_phase, n)
         g = self.geometry
-        if out is None:
-            out = dict(bytes=torch.empty((n, g.decoded_bytes), dtype=torch.uint8, device=self.device),
-                       iters=torch.empty(n, dtype=torch.int32, device=self.device),
-                       ok=torch.empty(n, dtype=torch.uint8, device=self.device))
+        out = self._result_buffers(n, out)
         llr = torch.empty((n, g.llrs_per_frame), dtype=torch.float32, device=self.device) if want_llr else None
         check(self.lib.ultra_hip_demod_decode_batch(self._ctx, audio.data_ptr(), self._row_stride(audio),
                                                     cfo.data_ptr() if cfo is not None else None,

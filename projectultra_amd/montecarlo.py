@@ -31,6 +31,7 @@ def counters_dict(counters) -> dict:
     d["fer"] = d["frame_errors"] / d["frames"] if d["frames"] else float("nan")
     d["ber"] = d["bit_errors"] / d["info_bits"] if d["info_bits"] else float("nan")
     d["mean_iters"] = d["iters_sum"] / d["frames"] if d["frames"] else float("nan")
+    d["undetected_rate"] = d["undetected_errors"] / d["frames"] if d["frames"] else float("nan")
     return d
 
 

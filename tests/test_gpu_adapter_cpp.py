@@ -230,3 +230,37 @@ def test_cpp_monte_carlo_harness(tmp_path):
         torch.cuda.synchronize()
         c = [int(v) for v in c.tolist()]
         assert (c[0], c[1], c[2], c[4], c[5]) == (frames, ferr, berr, lfail, iters), (mod, rate, c)
+
+
+def test_cpp_sweep_harness_equals_python_driver(tmp_path):
+    """tools/sweep_hip.cpp — the configs[3] / configs[4] sweeps as a native harness (C++ over the C-ABI, RCCL
+    communicator from ncclCommInitAll, one all-reduce per point).  Same generators, per-point seeds and sharding as
+    projectultra_amd/sweep.py: every counter of every point equals the Python driver's."""
+    import re
+    from projectultra_amd import CodeRate, Modulation
+    from projectultra_amd.sweep import ldpc_snr_sweep, mode_sweep
+    exe = tmp_path / "sweep_hip"
+    lib = ROOT / "projectultra_amd"
+    subprocess.check_call(["g++", "-O2", "-std=c++20", f"-I{ROOT / 'include'}", str(ROOT / "tools" / "sweep_hip.cpp"),
+                           f"-L{lib}", "-lultra_hip", f"-Wl,-rpath,{lib}", "-ldl", "-pthread", "-o", str(exe)])
+    pat = re.compile(r"^POINT (\S+) (-?[\d.]+) (\d+) (\d+) (\d+) (\d+) (\d+) (\d+) (\d+)", re.M)
+    keys = ("frames", "frame_errors", "bit_errors", "info_bits", "ldpc_fail", "iters_sum", "undetected_errors")
+
+    r = subprocess.run([str(exe), "--config", "cfg4", "--trials", "20000", "--snr-from", "-6", "--snr-to", "0", "--snr-step", "2",
+                        "--seed", "77", "--batch", "7000"], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-400:] + r.stderr[-400:]
+    rows = pat.findall(r.stdout)
+    want = ldpc_snr_sweep(CodeRate.R1_4, [-6.0, -4.0, -2.0, 0.0], 20000, seed=77, batch=5000)
+    assert len(rows) == 4
+    for row, p in zip(rows, want):
+        assert float(row[1]) == p.snr_db and [int(v) for v in row[2:]] == [p.counters[k] for k in keys], (row, p.counters)
+
+    r = subprocess.run([str(exe), "--config", "cfg5", "--trials", "2048", "--snr-from", "0", "--snr-to", "12", "--snr-step", "12",
+                        "--seed", "5"], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-400:] + r.stderr[-400:]
+    rows = pat.findall(r.stdout)
+    want = mode_sweep(None, [0.0, 12.0], frames_per_point=2048, seed=5)
+    assert len(rows) == 50
+    for row, p in zip(rows, want):
+        assert row[0] == p.label.replace(" ", "_") and [int(v) for v in row[2:]] == [p.counters[k] for k in keys], (row, p.counters)
+

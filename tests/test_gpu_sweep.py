@@ -1,0 +1,99 @@
+"""GPU parity of the sweep drivers (BASELINE configs[3]/[4]) at one rank: every counter of every point against the
+committed curve / the oracle, and a host recount of the device's own outputs."""
+import json
+
+import numpy as np
+import pytest
+
+from _sweep_stub import OracleLdpcShard, count
+from _util import beq
+from conftest import GOLDEN
+
+pytestmark = pytest.mark.gpu
+
+
+def test_ldpc_sweep_equals_committed_curves():
+    """configs[3] shape: HipLdpcShard under ldpc_snr_sweep reproduces tests/golden/sweep_ldpc.json — counters the
+    oracle computed on the host for the same (seed, trial indices, Es/N0) — EXACTLY, for four rates from far below
+    capacity (-11 dB: every codeword runs all 50 iterations) to +30 dB (parity passes at iteration 0).  The batch
+    size does not divide the trial count: ragged last batch."""
+    from projectultra_amd import CodeRate
+    from projectultra_amd.sweep import curves_document, ldpc_snr_sweep
+    for d in json.loads((GOLDEN / "sweep_ldpc.json").read_text()):
+        (label, want), = d["curves"].items()
+        pts = ldpc_snr_sweep(CodeRate(d["rate"]), [p["snr_db"] for p in want], d["n_codewords"], seed=d["seed"], batch=1500)
+        got = curves_document("ldpc_snr_sweep", pts, rate=d["rate"])["curves"][label]
+        for g, w in zip(got, want):
+            g.pop("seconds")
+            assert g == w, (label, g, w)
+
+
+@pytest.mark.parametrize("rate,snrs", [(0, [-5.0, -3.0, 1.0]), (4, [1.0, 6.0])])
+def test_ldpc_sweep_recount_and_subsample(oracle, rate, snrs):
+    """2^15 codewords per point: the device counters equal (a) a host recount of the device's own decode outputs over
+    ALL trials and (b) the oracle's counters over all trials (generator and decoder both bit-identical); a 2^12
+    subsample per point is compared LLR by LLR and byte by byte."""
+    from projectultra_amd import CodeRate
+    from projectultra_amd.sweep import HipLdpcShard, point_seed, run_point
+    n = 1 << 15
+    shard = HipLdpcShard(CodeRate(rate), batch=10000)
+    stub = OracleLdpcShard(rate, n_threads=16)
+    for i, snr in enumerate(snrs):
+        seed = point_seed(0xBEEF, i)
+        kept = []
+
+        def keep(c0, llr, payload, r):
+            kept.append((c0, llr[:4096].cpu().numpy() if c0 == 0 else None, payload.cpu().numpy(), r["bytes"].cpu().numpy(),
+                         r["iters"].cpu().numpy(), r["ok"].cpu().numpy()))
+        c = run_point(shard, n, snr, seed, keep=keep).numpy()
+        recount = sum(count(k[3], k[4], k[5], k[2]) for k in kept)
+        assert np.array_equal(c, recount), (snr, c, recount)
+        assert np.array_equal(c, stub.run(0, n, snr, seed).numpy()), snr
+        want_llr, want_payload = oracle.make_llr_batch(rate, 4096, snr, seed=seed, c0=0)
+        assert beq(kept[0][1], want_llr) and np.array_equal(kept[0][2][:4096], want_payload)
+        ob, oi, ook = oracle.ldpc_decode_batch_mt(rate, want_llr, 16)
+        assert np.array_equal(kept[0][3][:4096], ob) and np.array_equal(kept[0][4][:4096], oi) and np.array_equal(kept[0][5][:4096], ook)
+
+
+def test_mode_sweep_recount_and_subsample(oracle):
+    """configs[4] shape, three cells x three SNR points x 2^13 frames (AWGN, batches of 3000): device counters equal the
+    host recount of the device's outputs; a 256-frame subsample per point goes through the oracle (LLRs bitwise, bytes,
+    iterations, success); FER falls along the SNR axis."""
+    from oracle.bindings import make_config
+    from projectultra_amd import CodeRate, Modulation
+    from projectultra_amd.sweep import HipModemShard, nvis_cell_config, point_seed, run_point
+    n = 1 << 13
+    for ci, (mod, rate, snrs) in enumerate([(Modulation.DQPSK, CodeRate.R1_2, [-3.0, 0.0, 3.0]),
+                                            (Modulation.QAM16, CodeRate.R3_4, [3.0, 6.0, 12.0]),
+                                            (Modulation.D8PSK, CodeRate.R2_3, [0.0, 4.0, 9.0])]):
+        mc = nvis_cell_config(mod, rate)
+        cfg = make_config(1024, mod.name, rate.name)
+        shard = HipModemShard(mc, channel="awgn", batch=3000)
+        fers = []
+        for i, snr in enumerate(snrs):
+            kept = []
+
+            def keep(f0, audio, payload, r):
+                kept.append((f0, audio[:256].cpu().numpy() if f0 == 0 else None, payload.cpu().numpy(), r["bytes"].cpu().numpy(),
+                             r["iters"].cpu().numpy(), r["ok"].cpu().numpy(), r["llr"][:256].cpu().numpy() if f0 == 0 else None))
+            c = run_point(shard, n, snr, point_seed(77 + ci, i), keep=keep).numpy()
+            assert np.array_equal(c, sum(count(k[3], k[4], k[5], k[2]) for k in kept)), (mod, rate, snr)
+            want = oracle.demod_decode_batch(cfg, kept[0][1], n_threads=16, want_llr=True, want_state=False)
+            assert beq(kept[0][6], want["llr"]), (mod, rate, snr)
+            assert np.array_equal(kept[0][3][:256], want["bytes"]) and np.array_equal(kept[0][4][:256], want["iters"])
+            assert np.array_equal(kept[0][5][:256], want["ok"])
+            fers.append(c[1] / c[0])
+        assert fers[0] > fers[-1] and fers[0] > 0.5 and fers[-1] < 0.02, (mod, rate, fers)
+
+
+def test_mode_sweep_full_grid_counts():
+    """All 25 cells of configs[4] x two SNR points x 1024 frames through mode_sweep itself: every point counts its
+    frames, labels and seeds are those of the grid, and the curves document holds 25 curves."""
+    from projectultra_amd.sweep import CFG5_MODULATIONS, CFG5_RATES, curves_document, mode_sweep
+    pts = mode_sweep(None, [0.0, 18.0], frames_per_point=1024, batch=1024)
+    assert len(pts) == 50 and len({p.seed for p in pts}) == 50
+    doc = curves_document("mode_sweep", pts, channel="awgn")
+    assert len(doc["curves"]) == len(CFG5_MODULATIONS) * len(CFG5_RATES) and doc["total_trials"] == 50 * 1024
+    for label, curve in doc["curves"].items():
+        assert [p["frames"] for p in curve] == [1024, 1024] and curve[0]["fer"] >= curve[1]["fer"], label
+    assert doc["curves"]["DBPSK R1_4"][1]["fer"] == 0.0 and doc["curves"]["QAM32 R5_6"][0]["fer"] == 1.0
