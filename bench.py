@@ -1,25 +1,35 @@
 #!/usr/bin/env python3
-"""bench.py — headline benchmark of the batched OFDM-demodulate + LDPC-decode receive path.
+"""bench.py — benchmarks of the batched OFDM-demodulate + LDPC-decode receive path, one line per BASELINE config.
 
-    python bench.py --gpus N --steps K --warmup W
+    python bench.py [--config cfg3] --gpus N --steps K --warmup W
     (N > 1: python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...)
 
-Metric (BASELINE.json): OFDM-1024 16QAM R3/4 frames decoded/sec; achieved HBM GB/s.
-A "step" = one pass of the fused hot path (demodulate 4 data symbols -> first 648 LLRs ->
-LDPC scaled-min-sum <= 50 iterations -> error counters -> ONE all-reduce of the 8 counters)
-over this rank's batch of frames, inputs already resident in HBM.  Frames shard
-embarrassingly: every rank owns `--frames` frames (weak scaling), nothing crosses GPUs on
-the data path; the only collective is the 64-byte counter all-reduce (RCCL over xGMI).
+--config (default cfg3 = BASELINE.json's headline metric and configs[2]):
+  cfg3  OFDM-1024 16QAM R3/4, 59 carriers (15 pilots), Watterson "good" 30 dB, post-sync entry, 2^18 frames per GPU
+  cfg2  OFDM-512 DQPSK R1/2, 30 carriers, AWGN, 65,536 frames per GPU                       (configs[1])
+  cfg4  LDPC R1/4 Es/N0 sweep -11..+30 dB, BPSK/AWGN LLRs, 2^17 codewords per point per GPU  (configs[3]: 2^20 on 8 GPUs)
+  cfg5  {DBPSK,DQPSK,D8PSK,16QAM,32QAM} x {R1/4..R5/6} x 11 SNR points, 1,920 frames per point per GPU
+                                                                                         (configs[4]: 2^22 on 8 GPUs)
+  raw   cfg3 from raw audio: Schmidl-Cox acquisition + demodulation + decode (ultra_hip_receive_batch), 2^16 streams
 
-Prints ONE JSON line on rank 0 (see the driver contract) with two extra objects:
-  roofline     dominant kernel: algorithmic bytes per launch / measured HIP-event time
-  cpu_baseline the oracle ("port") timed on the host cores on a bounded sample
+A "step" = one pass of the configuration's hot path over this rank's batch of synthetic input, inputs already resident
+in HBM (generated on the device before the timed region), ending in the configuration's collective: ONE all-reduce of
+the eight uint64 counters per step (cfg2/cfg3/raw) or per sweep point (cfg4/cfg5).  Trials shard embarrassingly; per-GPU
+work is fixed as N grows (weak scaling).
+
+Prints ONE JSON line on rank 0 (see the driver contract) with the extra objects
+  roofline      dominant kernel: algorithmic bytes per launch / mean launch duration (HIP events), HBM and LDS/VALU view
+  cpu_baseline  the compiled reference (oracle/_ref, kind "reference") timed on the host's physical cores on a bounded
+                sample of the same workload, with the oracle port beside it
+  collective    backend, world size and mean latency of the counter all-reduce
 """
 from __future__ import annotations
 
 import argparse
+import fcntl
 import json
 import os
+import subprocess
 import sys
 import time
 from pathlib import Path
@@ -30,33 +40,477 @@ ROOT = Path(__file__).resolve().parent
 sys.path.insert(0, str(ROOT))
 
 HBM_PEAK_GBPS = 8000.0          # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
-# algorithmic bytes per frame for the fused path, cfg3 geometry
-#   4*1120*4 audio + 4 cfo in; 648*4 LLR + 61 decoded bytes + 4 iters/status out
-BYTES_AUDIO = 4 * 1120 * 4
-BYTES_PER_FRAME_FUSED = BYTES_AUDIO + 4 + 648 * 4 + 61 + 4          # 20,581
-BYTES_PER_FRAME_DEMOD = BYTES_AUDIO + 4 + 704 * 4                   # demod kernel alone: 704 LLRs written
-BYTES_PER_CW_LDPC = 648 * 4 + 61 + 4 + 1                            # LDPC kernel alone
+CLOCK_HZ = 2.4e9                # MI355X peak engine clock (MI355X_MICROARCH.md); the chip holds ~2.3 GHz under these kernels
+# LDS-pipeline cycles per wave-instruction (MI355X_MICROARCH.md, LDS table; re-measured in profiles/r02_issue_table.txt)
+LDS_CYC = dict(read_b32=2, write_b32=4, write_addtid_b32=2)
 
 
 def parse():
     ap = argparse.ArgumentParser()
+    ap.add_argument("--config", choices=("cfg2", "cfg3", "cfg4", "cfg5", "raw"), default="cfg3")
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--frames", type=int, default=1 << 18, help="frames per GPU per step")
-    ap.add_argument("--unique", type=int, default=8192, help="distinct synthetic frames generated on the host")
-    ap.add_argument("--snr-db", type=float, default=30.0)
-    ap.add_argument("--stimulus", choices=("host", "device"), default="device",
-                    help="device (default): every frame distinct, generated on the GPU (ultra_hip_make_batch, scope row f2: "
-                         "payload / encoder / modulator bit-identical to the oracle's generator, channel statistically "
-                         "equivalent); host: --unique frames from the oracle's TX chain, tiled in HBM")
+    ap.add_argument("--frames", type=int, default=0, help="trials per GPU per step (per sweep point for cfg4/cfg5); 0 = the config's size")
+    ap.add_argument("--snr-db", type=float, default=None, help="cfg2/cfg3/raw: channel SNR (default 30 dB cfg3/raw, 3 dB cfg2)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-sample", type=int, default=0, help="frames for the CPU baseline (0 = auto)")
+    ap.add_argument("--cpu-sample", type=int, default=0, help="trials for the CPU baseline (0 = auto)")
+    ap.add_argument("--no-build", action="store_true",
+                    help="do not (re)build the checker libraries; REQUIRED under rocprofv3, whose preloaded library "
+                         "initialises the GPU before main() — the compiler must never be started from such a process")
     return ap.parse_args()
 
 
+def ensure_built(no_build: bool):
+    """Build the CHECKER libraries (oracle/libultra_oracle.so, and oracle/_ref when /root/reference exists) BEFORE
+    anything touches the GPU, under a file lock so that the N ranks of a multi-GPU run do not race.  The product
+    library is never built here: it must exist (there is no CPU fallback).  After this, oracle.bindings never
+    starts the compiler again in this process (ULTRA_ORACLE_NO_BUILD)."""
+    lib = ROOT / "projectultra_amd" / "libultra_hip.so"
+    if not lib.exists():
+        raise SystemExit(f"{lib} is missing — run `python -c 'import __graft_entry__ as g; g.build()'` first")
+    src, so = ROOT / "oracle" / "ultra_oracle.c", ROOT / "oracle" / "libultra_oracle.so"
+    stale = (not so.exists()) or so.stat().st_mtime < src.stat().st_mtime
+    if no_build:
+        if stale:
+            raise SystemExit("oracle/libultra_oracle.so is missing or stale and --no-build was given — run "
+                             "`python -c 'import __graft_entry__ as g; g.build()'` (or bench.py once without --no-build) first")
+    else:
+        with open(ROOT / "oracle" / ".build.lock", "w") as lock:
+            fcntl.flock(lock, fcntl.LOCK_EX)
+            subprocess.check_call(["make", "-s", "-C", str(ROOT / "oracle"), "libultra_oracle.so"], stdout=subprocess.DEVNULL)
+            if Path("/root/reference/src").is_dir():
+                subprocess.check_call(["make", "-s", "-C", str(ROOT / "oracle"), "_ref/libultra_ref.so"], stdout=subprocess.DEVNULL)
+    os.environ["ULTRA_ORACLE_NO_BUILD"] = "1"
+
+
+def host_cpu():
+    """(model string, physical cores, logical CPUs) from /proc/cpuinfo."""
+    model, cores, logical = "unknown", set(), 0
+    try:
+        phys = core = None
+        for line in open("/proc/cpuinfo"):
+            k, _, v = line.partition(":")
+            k, v = k.strip(), v.strip()
+            if k == "model name":
+                model = v
+            elif k == "processor":
+                logical += 1
+            elif k == "physical id":
+                phys = v
+            elif k == "core id":
+                core = v
+            elif not k and phys is not None:
+                cores.add((phys, core)); phys = core = None
+        if phys is not None:
+            cores.add((phys, core))
+    except OSError:
+        pass
+    logical = logical or (os.cpu_count() or 1)
+    n_phys = len(cores) or logical
+    usable = n_phys
+    try:
+        usable = max(1, min(usable, len(os.sched_getaffinity(0))))      # never more workers than this process may use
+    except AttributeError:
+        pass
+    # a container's CPU share (cgroup quota): more runnable threads than that only thrash (profiles/r02_cpu_scaling.txt:
+    # on the GPU box, 16 CPUs' worth of quota on a 128-core host, both CPU legs peak at 16-32 threads and fall beyond)
+    quota = None
+    try:
+        q, per = open("/sys/fs/cgroup/cpu.max").read().split()[:2]                       # cgroup v2
+        if q != "max":
+            quota = float(q) / float(per)
+    except (OSError, ValueError):
+        try:
+            q = float(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())               # cgroup v1
+            per = float(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+            if q > 0:
+                quota = q / per
+        except (OSError, ValueError):
+            pass
+    if quota is not None:
+        usable = max(1, min(usable, int(quota + 0.5)))
+    return model, usable, n_phys, logical, quota
+
+
+def pick_threads(cores, run):
+    """Worker threads for the CPU legs: run(n_threads) -> trials/s on a small sample, tried at the usable core count and
+    at fractions of it.  A container may own far fewer CPUs than the host shows without exposing its quota (the GPU
+    box: 128 cores visible, about 16 CPUs' worth of share — profiles/r02_cpu_scaling.txt), and more runnable threads
+    than that only thrash; the fastest count is used for every leg and reported as `cores`."""
+    cands = sorted({c for c in (cores, cores // 2, cores // 4, cores // 8, 32, 16) if 1 <= c <= cores}, reverse=True)
+    rates = {c: run(c) for c in cands}
+    return max(rates, key=rates.get), rates
+
+
+def best_of(fn, runs=3):
+    best, out = None, None
+    for _ in range(runs):
+        t0 = time.perf_counter()
+        out = fn()
+        dt = time.perf_counter() - t0
+        best = dt if best is None else min(best, dt)
+    return best, out
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# workloads
+# ------------------------------------------------------------------------------------------------------------------
+class ModemWorkload:
+    """cfg2 / cfg3: post-sync demodulate + decode + count of n frames (ultra_hip_demod_decode_batch)."""
+
+    def __init__(self, name, args, rank, world, torch):
+        from projectultra_amd import CodeRate, ModemConfig, Modulation, ReceiveContext, presets
+        from projectultra_amd.montecarlo import shard_range
+        self.name, self.torch = name, torch
+        if name == "cfg3":
+            mc = presets.nvis_mode().with_mode(Modulation.QAM16, CodeRate.R3_4)
+            mc.pilot_spacing = 4                           # tools/test_nvis_mode.cpp:208-212
+            self.n = args.frames or (1 << 18)
+            self.channel, self.snr_db = "watterson", 30.0 if args.snr_db is None else args.snr_db
+            self.metric = "OFDM-1024 16QAM R3/4 frames decoded/sec"
+            self.what = "OFDM 1024-FFT 16QAM R3/4, 59 carriers (15 pilots), Watterson good channel (0.5 ms / 0.1 Hz)"
+            self.oracle_cfg = (1024, "QAM16", "R3_4")
+        else:
+            mc = ModemConfig().with_mode(Modulation.DQPSK, CodeRate.R1_2)      # tools/test_mode_snr.cpp:21-31
+            self.n = args.frames or (1 << 16)
+            self.channel, self.snr_db = "awgn", 3.0 if args.snr_db is None else args.snr_db
+            self.metric = "OFDM-512 DQPSK R1/2 frames decoded/sec"
+            self.what = "OFDM 512-FFT DQPSK R1/2, 30 carriers (no pilots), AWGN"
+            self.oracle_cfg = (512, "DQPSK", "R1_2")
+        self.unit = "frames/s"
+        self.ctx = ReceiveContext(mc)
+        g = self.geo = self.ctx.geometry
+        lo, _ = shard_range(self.n * world, rank, world)           # global frame ids of this rank
+        t0 = time.time()
+        self.d_audio, self.d_payload = self.ctx.make_batch(self.n, seed=0x5EED, first_frame=lo, channel=self.channel,
+                                                           snr_db=self.snr_db, delay_ms=0.5, doppler_hz=0.1)
+        torch.cuda.synchronize()
+        self.t_gen = time.time() - t0
+        self.out = dict(bytes=torch.empty((self.n, g.decoded_bytes), dtype=torch.uint8, device="cuda"),
+                        iters=torch.empty(self.n, dtype=torch.int32, device="cuda"),
+                        ok=torch.empty(self.n, dtype=torch.uint8, device="cuda"))
+        self.counters = torch.zeros(8, dtype=torch.int64, device="cuda")
+        self.units_per_step = self.n
+        self.points_per_step = 1
+        # SURVEY.md 8(d): audio in + cfo in; 648 LLRs + decoded bytes + iters/status out
+        self.bytes_audio = g.frame_samples * 4
+        self.bytes_per_unit = self.bytes_audio + 4 + 648 * 4 + g.decoded_bytes + 4
+        n_sym = self.ctx.cfg.n_data_symbols
+        self.per_launch = {"cfo_walk_kernel": 0, "mix_fft_kernel": g.symbol_samples * 4, "track_pilot_kernel": 0,
+                           "track_kernel": -(-648 * 4 // n_sym), "ldpc_decode_kernel": 648 * 4 + g.decoded_bytes + 4 + 1}
+        self.launch_units = self.n
+        self.data = (f"synthetic ({self.n} distinct {self.channel} realisations per GPU generated on the device in HBM; "
+                     f"random-payload codewords, {self.snr_db:g} dB)")
+        self.workload = f"{self.what}, post-sync entry, LDPC min-sum <= 50 iterations, {self.n} frames per GPU per step"
+        self.parallelism = f"frames sharded over {world} GPU(s), one counter all-reduce per step"
+
+    def step(self, allreduce):
+        self.counters.zero_()
+        r = self.ctx.demod_decode(self.d_audio, out=self.out)
+        self.ctx.count_errors(r, self.d_payload, self.counters)
+        allreduce(self.counters)
+
+    def contexts(self):
+        return [self.ctx]
+
+    def cpu_baseline(self, cores, sample):
+        from oracle.bindings import have_ref, make_config, oracle, Ref
+        ccfg = make_config(*self.oracle_cfg)
+        o = oracle()
+        probe = self.d_audio[:min(self.n, 2048)].cpu().numpy()
+
+        def rate(t):
+            t0 = time.perf_counter()
+            o.demod_decode_batch(ccfg, probe, n_threads=t, want_llr=False, want_state=False)
+            return probe.shape[0] / (time.perf_counter() - t0)
+        cores, self.thread_probe = pick_threads(cores, rate)
+        sample = sample or min(self.n, 1024 * cores)        # about a second of the reference on every worker
+        audio = self.d_audio[:sample].cpu().numpy()
+        got = {k: v[:sample].cpu().numpy() for k, v in self.out.items()}
+        res = {}
+        t_port, want = best_of(lambda: o.demod_decode_batch(ccfg, audio, n_threads=cores, want_llr=False, want_state=False))
+        res["port"] = dict(value=sample / t_port, unit="frames/s", cores=cores, kind="port", seconds=t_port,
+                           gpu_matches_bitwise=bool(all(np.array_equal(got[k], want[k]) for k in ("bytes", "iters", "ok"))))
+        if have_ref():
+            ref = Ref()
+            t_ref, rr = best_of(lambda: ref.demod_decode_batch_mt(ccfg, audio, cores))
+            res["reference"] = dict(value=sample / t_ref, unit="frames/s", cores=cores, kind="reference", seconds=t_ref,
+                                    gpu_matches_bitwise=bool(all(np.array_equal(got[k], rr[k]) for k in ("bytes", "iters", "ok"))))
+        self.cores_used = cores
+        return res, f"first {sample} frames of the same batch (copied from the device), post-sync demodulate + decode"
+
+
+class RawWorkload(ModemWorkload):
+    """raw: cfg3 end to end from raw audio — Schmidl-Cox acquisition (chunk-fed search, energy gate, coarse CFO, LTS
+    refinement), SYNCED demodulation from each stream's own data start, decode (ultra_hip_receive_batch)."""
+
+    def __init__(self, args, rank, world, torch):
+        from projectultra_amd import CodeRate, Modulation, ReceiveContext, presets
+        from projectultra_amd.montecarlo import shard_range
+        self.name, self.torch = "raw", torch
+        mc = presets.nvis_mode().with_mode(Modulation.QAM16, CodeRate.R3_4)
+        mc.pilot_spacing = 4
+        self.n = args.frames or (1 << 16)
+        self.channel, self.snr_db = "awgn", 30.0 if args.snr_db is None else args.snr_db
+        self.metric = "OFDM-1024 16QAM R3/4 raw-audio streams received/sec (acquisition + demodulation + decode)"
+        self.unit = "streams/s"
+        self.oracle_cfg = (1024, "QAM16", "R3_4")
+        self.ctx = ReceiveContext(mc)
+        g = self.geo = self.ctx.geometry
+        lo, _ = shard_range(self.n * world, rank, world)
+        t0 = time.time()
+        self.lead, self.tail = 1120, 960
+        self.d_audio, self.d_payload = self.ctx.make_raw_batch(self.n, seed=0x5EED, first_frame=lo, channel=self.channel,
+                                                               snr_db=self.snr_db, lead=self.lead, tail=self.tail)
+        torch.cuda.synchronize()
+        self.t_gen = time.time() - t0
+        self.n_samples = self.d_audio.shape[1]
+        self.out = None
+        self.counters = torch.zeros(8, dtype=torch.int64, device="cuda")
+        self.units_per_step = self.n
+        self.points_per_step = 1
+        self.bytes_audio = self.n_samples * 4
+        self.bytes_per_unit = self.bytes_audio + g.decoded_bytes + 4 + 4 + 4
+        n_sym = self.ctx.cfg.n_data_symbols
+        self.per_launch = {"acquire_kernel": self.n_samples * 4, "cfo_walk_kernel": 0, "mix_fft_kernel": g.symbol_samples * 4,
+                           "track_pilot_kernel": 0, "track_kernel": -(-648 * 4 // n_sym),
+                           "ldpc_decode_kernel": 648 * 4 + g.decoded_bytes + 4 + 1}
+        self.launch_units = self.n
+        self.data = (f"synthetic ({self.n} distinct raw streams per GPU generated on the device in HBM: {self.lead} samples of "
+                     f"noise, preamble, 4 data symbols, {self.tail} samples of noise; AWGN {self.snr_db:g} dB)")
+        self.workload = (f"OFDM 1024-FFT 16QAM R3/4 from raw audio ({self.n_samples} samples per stream, fed in 960-sample "
+                         f"chunks): Schmidl-Cox acquisition + demodulation + LDPC decode, {self.n} streams per GPU per step")
+        self.parallelism = f"streams sharded over {world} GPU(s), one counter all-reduce per step"
+
+    def step(self, allreduce):
+        self.counters.zero_()
+        self.out = self.ctx.receive(self.d_audio, chunk=960)
+        self.ctx.count_errors(self.out, self.d_payload, self.counters)
+        allreduce(self.counters)
+
+    def cpu_baseline(self, cores, sample):
+        from oracle.bindings import make_config, oracle
+        ccfg = make_config(*self.oracle_cfg)
+        cores = min(cores, 32)                   # see pick_threads: more runnable threads than the container's share thrash
+        self.cores_used = cores
+        sample = sample or min(self.n, 16 * cores)
+        audio = self.d_audio[:sample].cpu().numpy()
+        o = oracle()
+        import concurrent.futures as cf
+
+        def one(a):
+            acq = o.acquire(ccfg, a, chunk=960)
+            return acq
+        def run():
+            with cf.ThreadPoolExecutor(cores) as ex:
+                return list(ex.map(one, audio))
+        t, acq = best_of(run, runs=1)
+        got = self.out["entry"][:sample].cpu().numpy()
+        want = np.array([a["data_start"] if a["found"] else -1 for a in acq], np.int64)
+        res = {"port": dict(value=sample / t, unit="streams/s", cores=cores, kind="port", seconds=t,
+                            note="acquisition only (98 % of the reference's CPU time on this path); the post-sync part is the cfg3 line",
+                            gpu_matches_bitwise=bool(np.array_equal(np.where(got < 0, -1, got), want)))}
+        return res, f"first {sample} raw streams of the same batch, Schmidl-Cox acquisition"
+
+
+class LdpcSweepWorkload:
+    """cfg4: the whole Es/N0 sweep of one LDPC code per step — 42 points x n codewords per GPU, LLRs of every point
+    resident in HBM, one all-reduce per point."""
+
+    def __init__(self, args, rank, world, torch):
+        from projectultra_amd import CodeRate
+        from projectultra_amd.montecarlo import shard_range
+        from projectultra_amd.sweep import CFG4_SNR_POINTS, HipLdpcShard, point_seed
+        self.name, self.torch = "cfg4", torch
+        self.n = args.frames or (1 << 17)
+        self.snrs = list(CFG4_SNR_POINTS)
+        self.shard = HipLdpcShard(CodeRate.R1_4, batch=self.n)
+        self.ctx = self.shard.ctx
+        g = self.geo = self.ctx.geometry
+        lo, _ = shard_range(self.n * world, rank, world)
+        t0 = time.time()
+        P = len(self.snrs)
+        self.d_llr = torch.empty((P, self.n, 648), dtype=torch.float32, device="cuda")
+        self.d_payload = torch.empty((P, self.n, g.ldpc_k // 8), dtype=torch.uint8, device="cuda")
+        for i, snr in enumerate(self.snrs):
+            self.ctx.make_llr_batch(self.n, snr, seed=point_seed(0x5EED, i), first_cw=lo, out=(self.d_llr[i], self.d_payload[i]))
+        torch.cuda.synchronize()
+        self.t_gen = time.time() - t0
+        self.out = dict(bytes=torch.empty((P, self.n, g.decoded_bytes), dtype=torch.uint8, device="cuda"),
+                        iters=torch.empty((P, self.n), dtype=torch.int32, device="cuda"),
+                        ok=torch.empty((P, self.n), dtype=torch.uint8, device="cuda"))
+        self.counters = torch.zeros((P, 8), dtype=torch.int64, device="cuda")
+        self.units_per_step = self.n * P
+        self.points_per_step = P
+        self.metric = "LDPC R1/4 codewords decoded/sec over the Es/N0 sweep -11..+30 dB"
+        self.unit = "codewords/s"
+        self.bytes_per_unit = 648 * 4 + g.decoded_bytes + 4                   # SURVEY.md 8(d): 2,617 B per codeword
+        self.per_launch = {"ldpc_decode_kernel": 648 * 4 + g.decoded_bytes + 4 + 1}
+        self.launch_units = self.n
+        self.data = (f"synthetic ({P} Es/N0 points x {self.n} distinct random R1/4 codewords per GPU, BPSK over AWGN, LLR = 2y/sigma^2, "
+                     f"generated on the device in HBM: {self.d_llr.numel() * 4 / 1e9:.1f} GB resident)")
+        self.workload = (f"LDPC R1/4 (k=162, m=486) scaled min-sum <= 50 iterations, Es/N0 sweep -11..+30 dB in 1 dB steps, "
+                         f"{self.n} codewords per point per GPU per step")
+        self.parallelism = f"codewords of every point sharded over {world} GPU(s), one counter all-reduce per point"
+
+    def step(self, allreduce):
+        self.counters.zero_()
+        for i in range(len(self.snrs)):
+            r = self.ctx.ldpc_decode(self.d_llr[i], out={k: v[i] for k, v in self.out.items()})
+            self.ctx.count_errors(r, self.d_payload[i], self.counters[i])
+            allreduce(self.counters[i])
+
+    def contexts(self):
+        return [self.ctx]
+
+    def curves(self):
+        from projectultra_amd.montecarlo import counters_dict
+        return {"LDPC R1_4": [dict(snr_db=s, **counters_dict(c)) for s, c in zip(self.snrs, self.counters.cpu())]}
+
+    def cpu_baseline(self, cores, sample):
+        from oracle.bindings import have_ref, oracle, Ref
+        o = oracle()
+        probe = self.d_llr[8:12, :256].reshape(-1, 648).cpu().numpy()         # around the waterfall
+
+        def rate(t):
+            t0 = time.perf_counter()
+            o.ldpc_decode_batch_mt(0, probe, t)
+            return probe.shape[0] / (time.perf_counter() - t0)
+        cores, self.thread_probe = pick_threads(cores, rate)
+        per = sample or 48 * cores                                          # codewords per point
+        per = min(per, self.n)
+        llr = self.d_llr[:, :per].reshape(-1, 648).cpu().numpy()
+        got = {k: v[:, :per].reshape((-1,) + tuple(v.shape[2:])).cpu().numpy() for k, v in self.out.items()}
+        res = {}
+        t, w = best_of(lambda: o.ldpc_decode_batch_mt(0, llr, cores))
+        res["port"] = dict(value=llr.shape[0] / t, unit="codewords/s", cores=cores, kind="port", seconds=t,
+                           gpu_matches_bitwise=bool(np.array_equal(got["bytes"], w[0]) and np.array_equal(got["iters"], w[1])
+                                                    and np.array_equal(got["ok"], w[2])))
+        if have_ref():
+            ref = Ref()
+            t, w = best_of(lambda: ref.ldpc_decode_batch_mt(0, llr, cores))
+            res["reference"] = dict(value=llr.shape[0] / t, unit="codewords/s", cores=cores, kind="reference", seconds=t,
+                                    gpu_matches_bitwise=bool(np.array_equal(got["bytes"], w[0]) and np.array_equal(got["iters"], w[1])
+                                                             and np.array_equal(got["ok"], w[2])))
+        self.cores_used = cores
+        return res, f"first {per} codewords of each of the {len(self.snrs)} points (same LLRs, copied from the device), LDPCDecoder::decodeSoft"
+
+
+class ModeSweepWorkload:
+    """cfg5: the 5 x 5 mode/rate grid x 11 SNR points per step — one receive context per cell, n frames per point per
+    GPU, audio of every point resident in HBM, one all-reduce per point."""
+
+    def __init__(self, args, rank, world, torch):
+        from projectultra_amd.montecarlo import shard_range
+        from projectultra_amd.sweep import CFG5_MODULATIONS, CFG5_RATES, CFG5_SNR_POINTS, HipModemShard, nvis_cell_config, point_seed
+        self.name, self.torch = "cfg5", torch
+        self.n = args.frames or 1920
+        self.snrs = list(CFG5_SNR_POINTS)
+        self.cells = [(m, r) for m in CFG5_MODULATIONS for r in CFG5_RATES]
+        lo, _ = shard_range(self.n * world, rank, world)
+        t0 = time.time()
+        self.shards, self.audio, self.payload, self.outs = [], [], [], []
+        resident = 0
+        for ci, (m, r) in enumerate(self.cells):
+            sh = HipModemShard(nvis_cell_config(m, r), channel="awgn", batch=self.n)
+            g = sh.ctx.geometry
+            a_cell, p_cell = [], []
+            for si, snr in enumerate(self.snrs):
+                a, p = sh.ctx.make_batch(self.n, seed=point_seed(0x5EED, ci * len(self.snrs) + si), first_frame=lo, channel="awgn", snr_db=snr)
+                a_cell.append(a); p_cell.append(p); resident += a.numel() * 4
+            self.shards.append(sh); self.audio.append(a_cell); self.payload.append(p_cell)
+            self.outs.append(dict(bytes=torch.empty((self.n, g.decoded_bytes), dtype=torch.uint8, device="cuda"),
+                                  iters=torch.empty(self.n, dtype=torch.int32, device="cuda"),
+                                  ok=torch.empty(self.n, dtype=torch.uint8, device="cuda")))
+        torch.cuda.synchronize()
+        self.t_gen = time.time() - t0
+        P = len(self.cells) * len(self.snrs)
+        self.counters = torch.zeros((P, 8), dtype=torch.int64, device="cuda")
+        self.units_per_step = self.n * P
+        self.points_per_step = P
+        self.metric = "adaptive-mode Monte-Carlo frames decoded/sec (5 modulations x 5 code rates x 11 SNR points)"
+        self.unit = "frames/s"
+        self.bytes_per_unit = resident / (self.n * P) + 4 + 648 * 4 + 60 + 4      # mean over the grid
+        # per launch and frame: one symbol of audio (1120 samples) into mix_fft; the LLRs out of track_kernel and the
+        # decoder's in/out differ from cell to cell (mean over the grid used)
+        self.per_launch = {"mix_fft_kernel": 1120 * 4, "ldpc_decode_kernel": 648 * 4 + 50 + 4 + 1}
+        self.launch_units = self.n
+        self.geo = self.shards[0].ctx.geometry
+        self.data = (f"synthetic ({P} points x {self.n} distinct frames per GPU generated on the device in HBM, AWGN; "
+                     f"{resident / 1e9:.1f} GB of audio resident)")
+        self.workload = (f"{{DBPSK,DQPSK,D8PSK,16QAM,32QAM}} x {{R1/4,R1/2,R2/3,R3/4,R5/6}} on OFDM 1024-FFT / 59 carriers, SNR "
+                         f"{self.snrs[0]:g}..{self.snrs[-1]:g} dB in 3 dB steps, post-sync entry, {self.n} frames per point per GPU per step")
+        self.parallelism = f"frames of every point sharded over {world} GPU(s), one counter all-reduce per point"
+
+    def step(self, allreduce):
+        self.counters.zero_()
+        k = 0
+        for sh, a_cell, p_cell, out in zip(self.shards, self.audio, self.payload, self.outs):
+            for a, p in zip(a_cell, p_cell):
+                r = sh.ctx.demod_decode(a, out=out)
+                sh.ctx.count_errors(r, p, self.counters[k])
+                allreduce(self.counters[k])
+                k += 1
+
+    def contexts(self):
+        return [sh.ctx for sh in self.shards]
+
+    def curves(self):
+        from projectultra_amd.montecarlo import counters_dict
+        c = self.counters.cpu()
+        S = len(self.snrs)
+        return {f"{m.name} {r.name}": [dict(snr_db=s, **counters_dict(c[ci * S + si])) for si, s in enumerate(self.snrs)]
+                for ci, (m, r) in enumerate(self.cells)}
+
+    def cpu_baseline(self, cores, sample):
+        from oracle.bindings import have_ref, make_config, oracle, Ref
+        o = oracle()
+        ref = Ref() if have_ref() else None
+        ccfg0 = make_config(1024, "QAM16", "R3_4")
+        probe = self.audio[18][8][:512].cpu().numpy()                       # the 16QAM R3/4 cell
+
+        def rate(t):
+            t0 = time.perf_counter()
+            o.demod_decode_batch(ccfg0, probe, n_threads=t, want_llr=False, want_state=False)
+            return probe.shape[0] / (time.perf_counter() - t0)
+        cores, self.thread_probe = pick_threads(cores, rate)
+        per = min(sample or max(8, 4 * cores), self.n)                      # frames per point
+        t_port = t_ref = 0.0
+        ok_port = ok_ref = True
+        total = 0
+        for (m, r), sh, a_cell in zip(self.cells, self.shards, self.audio):
+            ccfg = make_config(1024, m.name, r.name)
+            audio = np.concatenate([a[:per].cpu().numpy() for a in a_cell])
+            got = sh.ctx.demod_decode(self.torch.from_numpy(audio).cuda())
+            got = {k: v.cpu().numpy() for k, v in got.items()}
+            t0 = time.perf_counter()
+            w = o.demod_decode_batch(ccfg, audio, n_threads=cores, want_llr=False, want_state=False)
+            t_port += time.perf_counter() - t0
+            ok_port &= all(np.array_equal(got[k], w[k]) for k in ("bytes", "iters", "ok"))
+            if ref is not None:
+                t0 = time.perf_counter()
+                w = ref.demod_decode_batch_mt(ccfg, audio, cores)
+                t_ref += time.perf_counter() - t0
+                ok_ref &= all(np.array_equal(got[k], w[k]) for k in ("bytes", "iters", "ok"))
+            total += audio.shape[0]
+        res = {"port": dict(value=total / t_port, unit="frames/s", cores=cores, kind="port", seconds=t_port, gpu_matches_bitwise=bool(ok_port))}
+        if ref is not None:
+            res["reference"] = dict(value=total / t_ref, unit="frames/s", cores=cores, kind="reference", seconds=t_ref,
+                                    gpu_matches_bitwise=bool(ok_ref))
+        self.cores_used = cores
+        return res, f"first {per} frames of each of the {len(self.cells) * len(self.snrs)} points (same audio, copied from the device)"
+
+
+# ------------------------------------------------------------------------------------------------------------------
 def main():
     args = parse()
+    ensure_built(args.no_build)                     # before anything initialises the GPU
+    # stdout carries exactly ONE line (the JSON): whatever libraries print there meanwhile (RCCL's version banner at
+    # communicator creation) goes to stderr instead
+    sys.stdout.flush()
+    saved_stdout = os.dup(1)
+    os.dup2(2, 1)
     import torch
     import torch.distributed as dist
 
@@ -70,216 +524,175 @@ def main():
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the receive path has no CPU fallback")
     torch.cuda.set_device(local_rank)
-    if world > 1:
+    distributed = "RANK" in os.environ and "WORLD_SIZE" in os.environ      # launched by torch.distributed.run (also for N = 1)
+    backend = None
+    if distributed:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29500")
         dist.init_process_group(backend="nccl", rank=rank, world_size=world)   # "nccl" IS RCCL on ROCm
+        backend = dist.get_backend()
 
-    # the checker library is (re)built by one rank only: concurrent `make`s of N ranks would race on the .so
-    from oracle.bindings import build_oracle
-    if local_rank == 0:
-        build_oracle()
-    if world > 1:
-        dist.barrier()
-    from oracle.bindings import geometry, have_ref, make_config, oracle, Ref
-    from projectultra_amd import CodeRate, Modulation, ReceiveContext, presets
-    from projectultra_amd.montecarlo import allreduce_counters, counters_dict, shard_range
+    from projectultra_amd.montecarlo import counters_dict
 
-    # ---- workload: BASELINE.json configs[2] geometry -----------------------------------------
-    mc = presets.nvis_mode().with_mode(Modulation.QAM16, CodeRate.R3_4)
-    mc.pilot_spacing = 4                           # tools/test_nvis_mode.cpp:208-212
-    ccfg = make_config(1024, "QAM16", "R3_4")      # same config as a POD for the oracle
-    geo = geometry(ccfg)
-    assert geo.frame_samples * 4 == BYTES_AUDIO and geo.llrs_per_frame == 704 and geo.decoded_bytes == 61
-    n_frames = args.frames
-    unique = min(args.unique, n_frames)
-    reps = -(-n_frames // unique)
-    glob_lo, _ = shard_range(n_frames * world, rank, world)    # global frame ids of this rank
-
-    # ---- synthetic stimulus: TX chain + Watterson "good" (0.5 ms / 0.1 Hz) ----------------------
-    o = oracle()
-    ctx = ReceiveContext(mc)
-    t0 = time.time()
-    if args.stimulus == "device":
-        # every frame of the rank distinct, generated in HBM (payload/encoder/modulator bit-identical to the
-        # oracle's generator, channel statistically equivalent: tests/test_gpu_stimulus.py)
-        d_audio, d_payload = ctx.make_batch(n_frames, seed=0x5EED, first_frame=glob_lo, channel="watterson",
-                                            snr_db=args.snr_db, delay_ms=0.5, doppler_hz=0.1)
-        torch.cuda.synchronize()
-        unique = n_frames
-        audio_u = None
+    if args.config in ("cfg2", "cfg3"):
+        wl = ModemWorkload(args.config, args, rank, world, torch)
+    elif args.config == "raw":
+        wl = RawWorkload(args, rank, world, torch)
+    elif args.config == "cfg4":
+        wl = LdpcSweepWorkload(args, rank, world, torch)
     else:
-        audio_u, payload_u = o.make_batch(ccfg, unique, seed=0x5EED, f0=glob_lo, channel="watterson",
-                                          snr_db=args.snr_db, delay_ms=0.5, doppler_hz=0.1)
-        d_audio_u = torch.from_numpy(audio_u).cuda()
-        d_audio = d_audio_u.repeat(reps, 1)[:n_frames].contiguous()        # [n_frames][4480] f32, resident in HBM
-        d_payload = torch.from_numpy(payload_u).cuda().repeat(reps, 1)[:n_frames].contiguous()
-        del d_audio_u
-    t_gen = time.time() - t0
-    out = dict(bytes=torch.empty((n_frames, geo.decoded_bytes), dtype=torch.uint8, device="cuda"),
-               iters=torch.empty(n_frames, dtype=torch.int32, device="cuda"),
-               ok=torch.empty(n_frames, dtype=torch.uint8, device="cuda"))
-    counters = torch.zeros(8, dtype=torch.int64, device="cuda")
+        wl = ModeSweepWorkload(args, rank, world, torch)
 
-    def step():
-        counters.zero_()
-        r = ctx.demod_decode(d_audio, out=out)
-        ctx.count_errors(r, d_payload, counters)
-        allreduce_counters(counters)               # the single collective of the path
-        return r
+    # the single collective of the path; timed with HIP events on the launch stream when profiling
+    ar_events = []
+
+    def allreduce(t):
+        if not distributed:
+            return
+        if ar_events is not None and allreduce.timed:
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record(); dist.all_reduce(t, op=dist.ReduceOp.SUM); e1.record()
+            ar_events.append((e0, e1))
+        else:
+            dist.all_reduce(t, op=dist.ReduceOp.SUM)
+    allreduce.timed = False
 
     def barrier():
-        if world > 1:
+        if distributed:
             dist.barrier()
         torch.cuda.synchronize()
 
     for _ in range(args.warmup):
-        step()
+        wl.step(allreduce)
     barrier()
     t0 = time.perf_counter()
     for _ in range(args.steps):
-        step()
+        wl.step(allreduce)
     barrier()
     elapsed = time.perf_counter() - t0
-    # The same K steps once more (all ranks: the step holds the collective) with, on rank 0, every
-    # kernel launch bracketed by HIP events on the launch stream (ultra_hip_profile_enable): per-kernel
-    # durations for the roofline object.  Kept out of the timed region because the ~22 event records
-    # per step cost ~1.7 % of a step.
-    prof = None
+    # The same K steps once more (all ranks: the step holds the collective) with, on rank 0, every kernel launch
+    # bracketed by HIP events on the launch stream (ultra_hip_profile_enable) and every all-reduce by a pair of stream
+    # events: per-kernel durations for the roofline object.  Kept out of the timed region: the event records cost ~2 %.
+    prof = {}
     if rank == 0:
-        ctx.profile_read()
-        ctx.profile_enable(True)
+        for c in wl.contexts():
+            c.profile_read(); c.profile_enable(True)
+    allreduce.timed = True
     for _ in range(args.steps):
-        step()
+        wl.step(allreduce)
     barrier()
+    allreduce.timed = False
     if rank == 0:
-        ctx.profile_enable(False)
-        prof = ctx.profile_read()
+        for c in wl.contexts():
+            c.profile_enable(False)
+            for k, (ms, cnt) in c.profile_read().items():
+                a = prof.setdefault(k, [0.0, 0]); a[0] += ms; a[1] += cnt
+    ar_us = float(np.mean([a.elapsed_time(b) for a, b in ar_events]) * 1e3) if ar_events else None
     t_max = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
-    if world > 1:
+    if distributed:
         dist.all_reduce(t_max, op=dist.ReduceOp.MAX)
     elapsed = float(t_max.item())
-    stats = counters_dict(counters.cpu())
+    last = wl.counters.reshape(-1, 8).sum(dim=0).cpu()
+    stats = counters_dict(last)
+    expect = wl.units_per_step * world
+    assert stats["frames"] == expect, f"counted {stats['frames']} trials per step, expected {expect}"
 
-    # ---- roofline of the dominant kernel (largest share of the step), rank 0 ------------------
-    # Algorithmic bytes per launch = SURVEY.md 8(d)'s per-frame figure (20,581 B = 4 x 4480 audio + 4
-    # + 4 x 648 LLR + 61 + 4) apportioned to the launch that moves them, x the frames of one launch:
-    #   mix_fft_kernel  one OFDM symbol of audio in            4480 B/frame/launch
-    #   cfo_walk_kernel, track_pilot_kernel  work on the per-frame records between the kernels only   0 B/frame/launch
-    #   track_kernel    that symbol's share of the 648 LLRs     648 B/frame/launch
-    #   ldpc_decode     648 LLRs in, 61 bytes + iters + ok out 2658 B/frame/launch
+    # ---- roofline of the dominant kernel (largest share of the step), rank 0 --------------------------------------
     roofline = None
     if rank == 0:
-        per_launch = {"cfo_walk_kernel": 0, "mix_fft_kernel": geo.symbol_samples * 4, "track_pilot_kernel": 0, "track_kernel": 648,
-                      "ldpc_decode_kernel": BYTES_PER_CW_LDPC}
-        traffic_all = {}
-        tf = ROOT / "profiles" / "traffic.json"              # PMC-derived HBM bytes per launch, if collected
+        kernels = {}
+        for name, (ms_total, launches) in prof.items():
+            if launches == 0:
+                continue
+            avg = ms_total / launches
+            alg = wl.launch_units * wl.per_launch.get(name, 0)
+            kernels[name] = {"avg_launch_ms": avg, "launches_per_step": launches / args.steps, "ms_per_step": ms_total / args.steps,
+                             "algorithmic_bytes_per_launch": alg, "GBps": alg / (avg * 1e-3) / 1e9,
+                             "frac": alg / (avg * 1e-3) / 1e9 / HBM_PEAK_GBPS}
+        dom = max(kernels, key=lambda k: kernels[k]["ms_per_step"])
+        props = torch.cuda.get_device_properties(0)
+        roofline = {"bound": "hbm", "kernel": dom, "achieved": kernels[dom]["GBps"], "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                    "frac": kernels[dom]["frac"], "traffic": None, "launch_ms": kernels[dom]["avg_launch_ms"],
+                    "algorithmic_bytes_per_launch": kernels[dom]["algorithmic_bytes_per_launch"],
+                    "path_GBps": wl.units_per_step * wl.bytes_per_unit * args.steps / elapsed / 1e9,
+                    "kernels": kernels}
+        # PMC-derived HBM bytes per launch, if collected for THIS build and batch size (tools/collect_profiles.sh
+        # writes profiles/traffic.json with the commit and the batch size it was measured at)
+        tf = ROOT / "profiles" / "traffic.json"
         if tf.exists():
             try:
                 t = json.loads(tf.read_text())
-                if t.get("n_frames") == n_frames:
-                    traffic_all = {k: v["hbm_bytes_per_launch"] for k, v in t.get("kernels", {}).items()}
+                if t.get("n_frames") == wl.launch_units and t.get("config", "cfg3") == args.config:
+                    roofline["traffic"] = t.get("kernels", {}).get(dom, {}).get("hbm_bytes_per_launch")
+                    roofline["traffic_source"] = {"file": "profiles/traffic.json", "commit": t.get("commit"), "collected": t.get("collected")}
             except Exception:
-                traffic_all = {}
-        kernels = {}
-        for name, (ms_total, launches) in prof.items():
-            if launches == 0 or name not in per_launch:
-                continue
-            avg = ms_total / launches
-            alg = n_frames * per_launch[name]
-            kernels[name] = {"avg_launch_ms": avg, "launches_per_step": launches / args.steps,
-                             "ms_per_step": ms_total / args.steps, "algorithmic_bytes_per_launch": alg,
-                             "GBps": alg / (avg * 1e-3) / 1e9, "frac": alg / (avg * 1e-3) / 1e9 / HBM_PEAK_GBPS,
-                             "traffic": traffic_all.get(name)}
-        # The decoder's limiters are its VALU issue and the LDS pipeline, not HBM: report the LDS utilisation next to
-        # the HBM figure.  One codeword-iteration of the R3/4 instance issues 36 ds_read_b32 (2 cycles each for 64
-        # lanes), 18 ds_write_b32 (4 cycles: address + data, the check step's scattered stores) and 18
-        # ds_write_addtid_b32 (2 cycles: the variable step's lane-linear stores) = 180 LDS cycles on the CU's single
-        # LDS pipeline; a codeword that converges at iteration `it` executes it + 1 iterations, a
-        # failing one max_iterations.
-        if "ldpc_decode_kernel" in kernels and world == 1:
-            props = torch.cuda.get_device_properties(0)
-            clock_hz = 2.4e9                                   # MI355X peak engine clock (MI355X_MICROARCH.md)
-            executed = stats["iters_sum"] + (stats["frames"] - stats["ldpc_fail"])
-            lds_cycles = 180.0 * executed
-            avail = kernels["ldpc_decode_kernel"]["avg_launch_ms"] * 1e-3 * clock_hz * props.multi_processor_count
-            kernels["ldpc_decode_kernel"]["lds"] = {"lds_cycles_per_codeword_iteration": 180,
-                                                    "codeword_iterations_per_launch": executed,
-                                                    "compute_units": props.multi_processor_count, "clock_hz": clock_hz,
-                                                    "frac_of_lds_peak": lds_cycles / avail}
-        dom = max(kernels, key=lambda k: kernels[k]["ms_per_step"])
-        roofline = {"bound": "hbm", "kernel": dom, "achieved": kernels[dom]["GBps"], "peak": HBM_PEAK_GBPS,
-                    "unit": "GB/s", "frac": kernels[dom]["frac"], "traffic": kernels[dom]["traffic"],
-                    "launch_ms": kernels[dom]["avg_launch_ms"],
-                    "algorithmic_bytes_per_launch": kernels[dom]["algorithmic_bytes_per_launch"],
-                    "kernels": kernels,
-                    "path_GBps": n_frames * BYTES_PER_FRAME_FUSED * args.steps / elapsed / 1e9,
-                    "note": "achieved = algorithmic bytes per launch / mean launch duration (HIP events around every "
-                            "launch of a repeat of the timed steps). The path is not HBM-bound at this operating point: mix_fft is "
-                            "latency/VALU-bound (double-precision sincos of the CFO rotation, 1024-point FFT through "
-                            "LDS), and the reference decodes only ~11 % of these frames (R3/4 leaves 161 info bits "
-                            "unchecked, the two-tap channel nulls 1 kHz), so most codewords run all 50 BP iterations "
-                            "and ldpc_decode_kernel is bound by VALU issue (~200 instructions per codeword-iteration) and "
-                            "the LDS pipeline (180 cycles per codeword-iteration, conflict-free). path_GBps = frames/s x 20,581 B (SURVEY 8d) for one GPU"}
+                pass
+        # What actually bounds the decoder: the CU's single LDS pipeline.  One codeword-iteration of the lane-linear
+        # instances (R2/3, R3/4, R5/6) issues E gather reads + E scattered stores (check step) and E lane-linear reads +
+        # E add-TID stores (variable step), E = information-edge slots of the instance's degree profile; the other
+        # instances issue one read and one address+data store per slot and step.  Cycles per wave-instruction: MI355X_MICROARCH.md's LDS
+        # table, re-measured in profiles/r02_issue_table.txt.  A codeword that converges at iteration `it` executes
+        # it + 1 iterations, a failing one max_iterations.
+        if dom == "ldpc_decode_kernel" and wl.name in ("cfg3", "cfg4", "raw"):
+            rate = int(wl.ctx.cfg.code_rate)
+            # (LDS read/store pairs per iteration over both steps, lane-linear layout?) per code
+            pairs, linear = {0: (70, False), 1: (49, False), 2: (49, False), 3: (48, True), 4: (36, True), 5: (24, True)}[rate]
+            if linear:      # half of the stores are the variable step's add-TID stores
+                cyc = pairs * LDS_CYC["read_b32"] + pairs // 2 * LDS_CYC["write_b32"] + pairs // 2 * LDS_CYC["write_addtid_b32"]
+            else:
+                cyc = pairs * (LDS_CYC["read_b32"] + LDS_CYC["write_b32"])
+            executed = stats["iters_sum"] / world + (stats["frames"] - stats["ldpc_fail"]) / world
+            avail = kernels[dom]["ms_per_step"] * 1e-3 * CLOCK_HZ * props.multi_processor_count
+            frac = cyc * executed / avail
+            roofline.update({"bound": "lds", "lds": {"cycles_per_codeword_iteration": cyc, "codeword_iterations_per_step": executed,
+                                                     "compute_units": props.multi_processor_count, "clock_hz": CLOCK_HZ,
+                                                     "achieved_lds_cycles_per_s": cyc * executed / (kernels[dom]["ms_per_step"] * 1e-3),
+                                                     "peak_lds_cycles_per_s": CLOCK_HZ * props.multi_processor_count,
+                                                     "frac_of_lds_peak": frac},
+                             "hbm_frac": kernels[dom]["frac"]})
+        roofline["note"] = ("achieved = algorithmic bytes per launch / mean launch duration (HIP events around every launch of a "
+                            "repeat of the timed steps); bound = what limits the dominant kernel: 'lds' for the LDPC decoder (its "
+                            "check/variable message exchange saturates the CU's LDS pipeline; HBM fraction kept as hbm_frac), 'hbm' "
+                            "otherwise. DESIGN.md 4/6 derive both from profiles/r02_*")
 
-    # ---- CPU baseline: the oracle on the host cores, bounded sample (rank 0, N=1 only) ----------
+    # ---- CPU baseline: the compiled reference on the host's physical cores, bounded sample (rank 0, N=1 only) ----
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        cores = os.cpu_count() or 1
-        threads = min(cores, 64)
-        # bounded sample: ~10-20 core-seconds of CPU work (the first frames of this rank's batch)
-        sample = args.cpu_sample or min(n_frames, 1024 * threads)
-        if audio_u is None:
-            audio_cpu = d_audio[:sample].cpu().numpy()          # device stimulus: copy the sample to the host
-        else:
-            audio_cpu = np.tile(audio_u, (-(-sample // unique), 1))[:sample]
-        t0 = time.perf_counter()
-        want = o.demod_decode_batch(ccfg, audio_cpu, n_threads=threads, want_llr=False, want_state=False)
-        t_cpu = time.perf_counter() - t0
-        audio_ref = np.ascontiguousarray(audio_cpu[:512])           # sample of the compiled reference, below
-        del audio_cpu
-        got = {k: v[:sample].cpu().numpy() for k, v in out.items()}
-        parity = bool(np.array_equal(got["bytes"], want["bytes"]) and np.array_equal(got["iters"], want["iters"])
-                      and np.array_equal(got["ok"], want["ok"]))
-        cpu = {"value": sample / t_cpu, "unit": "frames/s", "cores": threads, "kind": "port",
-               "sample": f"first {sample} frames of the same batch, oracle/ultra_oracle.c, one worker thread per core "
-                         f"({threads} of {cores} logical CPUs)",
-               "seconds": t_cpu, "gpu_matches_cpu_bitwise": parity}
-        if have_ref():
-            nref = min(512, sample)
-            t0 = time.perf_counter()
-            rr = Ref().demod_decode_batch(ccfg, audio_ref[:nref])
-            t_ref = time.perf_counter() - t0
-            cpu["reference_1core"] = {"value": nref / t_ref, "unit": "frames/s", "cores": 1, "kind": "reference",
-                                      "sample": f"first {nref} frames, compiled reference (oracle/_ref), 1 thread",
-                                      "gpu_matches_reference_bitwise": bool(
-                                          np.array_equal(got["bytes"][:nref], rr["bytes"])
-                                          and np.array_equal(got["iters"][:nref], rr["iters"]))}
+        model, cores, physical, logical, quota = host_cpu()
+        res, sample = wl.cpu_baseline(cores, args.cpu_sample)
+        head = res.get("reference", res["port"])
+        cores = getattr(wl, "cores_used", cores)
+        cpu = dict(value=head["value"], unit=head["unit"], cores=cores, kind=head["kind"], sample=sample, cpu_model=model,
+                   thread_probe_trials_per_s=getattr(wl, "thread_probe", None),
+                   physical_cores=physical, logical_cpus=logical, cgroup_cpu_quota=quota,
+                   threads="one worker thread per usable core: the physical cores, capped by the affinity mask and the container's "
+                           "CPU quota where visible, then the fastest of {all, 1/2, 1/4, 1/8, 32, 16} on a probe sample "
+                           "(thread_probe_trials_per_s); disjoint trial ranges, best of 3",
+                   gpu_matches_cpu_bitwise=head["gpu_matches_bitwise"], legs=res)
 
     if rank == 0:
-        total_frames = n_frames * world * args.steps
-        value = total_frames / elapsed
+        total = wl.units_per_step * world * args.steps
+        value = total / elapsed
         line = {
-            "metric": "OFDM-1024 16QAM R3/4 frames decoded/sec",
-            "value": value, "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
-            "vs_baseline": None, "dtype": "f32",
-            "data": (f"synthetic ({n_frames} distinct Watterson realisations per GPU generated on the device in HBM; "
-                     if args.stimulus == "device" else
-                     f"synthetic ({unique} distinct Watterson realisations per GPU generated on the host, tiled to "
-                     f"{n_frames} frames resident in HBM; ") + "random-payload R3/4 codewords, 30 dB, 0.5 ms / 0.1 Hz)",
-            "config": {"workload": "OFDM 1024-FFT 16QAM R3/4, 59 carriers (15 pilots), Watterson good channel, "
-                                   "post-sync entry, LDPC min-sum <= 50 iterations, "
-                                   f"{n_frames} frames per GPU per step",
-                       "frames_per_gpu": n_frames, "bytes_per_frame": BYTES_PER_FRAME_FUSED,
-                       "parallelism": f"frames sharded over {world} GPU(s), one counter all-reduce per step"},
-            "achieved_hbm_GBps": value * BYTES_PER_FRAME_FUSED / 1e9,
-            "hbm_frac_of_peak": value * BYTES_PER_FRAME_FUSED / 1e9 / (HBM_PEAK_GBPS * world),
-            "fer": stats["fer"], "ber": stats["ber"], "mean_bp_iterations": stats["mean_iters"],
-            "frames_counted": stats["frames"], "stimulus_seconds": t_gen,
+            "metric": wl.metric, "value": value, "unit": wl.unit, "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f32", "data": wl.data,
+            "config": {"workload": wl.workload, "name": args.config, "trials_per_gpu_per_step": wl.units_per_step,
+                       "bytes_per_trial": wl.bytes_per_unit, "parallelism": wl.parallelism},
+            "achieved_hbm_GBps": value * wl.bytes_per_unit / 1e9,
+            "hbm_frac_of_peak": value * wl.bytes_per_unit / 1e9 / (HBM_PEAK_GBPS * world),
+            "fer": stats["fer"], "ber": stats["ber"], "mean_bp_iterations": stats["mean_iters"], "trials_counted": stats["frames"],
+            "stimulus_seconds": wl.t_gen,
+            "collective": {"backend": backend or "none (single process, no process group)", "world_size": dist.get_world_size() if distributed else 1,
+                           "op": "all_reduce(SUM) of 8 x int64", "per_step": wl.points_per_step, "allreduce_us": ar_us},
             "roofline": roofline, "cpu_baseline": cpu,
         }
-        print(json.dumps(line))
-    if world > 1:
+        if hasattr(wl, "curves"):
+            line["curves"] = wl.curves()
+        sys.stdout.flush()
+        os.dup2(saved_stdout, 1)
+        print(json.dumps(line), flush=True)
+    if distributed:
         dist.destroy_process_group()
 
 

@@ -367,6 +367,15 @@ int ultra_hip_make_batch(ultra_hip_ctx* ctx, uint64_t seed, uint64_t first_frame
                          float snr_db, float delay_ms, float doppler_hz, float* d_audio, size_t frame_stride,
                          uint8_t* d_payload);
 
+/* The same transmission as a RAW stream for the end-to-end entry (ultra_hip_receive_batch): `lead` samples of
+ * silence, the preamble (OFDMModulator::generatePreamble, 7 symbols), the frame's data symbols, `tail` samples of
+ * silence; scaled to a 0.5 peak; channel_kind 0 none, 1 AWGN on every sample of the stream at snr_db relative to the
+ * mean power of the transmission (tools/test_nvis_mode.cpp:62-86).
+ *   d_audio  [n_streams][stream_stride >= lead + 7 (fft + cp) + frame_samples + tail] f32 */
+int ultra_hip_make_raw_batch(ultra_hip_ctx* ctx, uint64_t seed, uint64_t first_frame, size_t n_streams, int channel_kind,
+                             float snr_db, uint32_t lead, uint32_t tail, float* d_audio, size_t stream_stride,
+                             uint8_t* d_payload);
+
 /* LDPC-only stimulus on the device (BASELINE.json configs[3]: "LDPC R1/4 ... SNR sweep -11..+30 dB"):
  * codewords first_cw .. first_cw + n_cw - 1 of the context's code rate as BPSK over AWGN, handed to the decoder as
  * LLRs 2y / sigma^2 with sigma^2 = 1 / (2 Es/N0).  The reference has no LDPC-only SNR harness (its decoder tests

@@ -84,7 +84,11 @@ def _ptr(a, t=C.c_float):
 
 
 def build_oracle(force=False):
-    """Compile oracle/libultra_oracle.so (and oracle/_ref when /root/reference exists)."""
+    """Compile oracle/libultra_oracle.so (and oracle/_ref when /root/reference exists).  ULTRA_ORACLE_NO_BUILD=1
+    (set by bench.py after its own, pre-GPU build step) turns it into a no-op: a process that has initialised the GPU
+    must not start the compiler."""
+    if os.environ.get("ULTRA_ORACLE_NO_BUILD") == "1" and not force:
+        return
     if force or not ORACLE_SO.exists() or ORACLE_SO.stat().st_mtime < (HERE / "ultra_oracle.c").stat().st_mtime:
         subprocess.check_call(["make", "-C", str(HERE), "libultra_oracle.so"], stdout=subprocess.DEVNULL)
     if REFERENCE_ROOT.is_dir() and (force or not REF_SO.exists()
@@ -453,6 +457,21 @@ class Ref(_Base):
                                              _ptr(cfo) if cfo is not None else None, C.c_uint32(n),
                                              _ptr(by, C.c_uint8), C.c_uint32(g.decoded_bytes), _ptr(it, C.c_int32),
                                              _ptr(ok, C.c_uint8))
+        assert rc == 0
+        return dict(bytes=by, iters=it, ok=ok)
+
+    def demod_decode_batch_mt(self, cfg, audio, n_threads, cfo_hz=None):
+        """The same over worker threads (one OFDMDemodulator / LDPCDecoder per thread): the reference's CPU path on all
+        host cores."""
+        audio = _f32(audio)
+        g = geometry(cfg)
+        n, stride = audio.shape
+        by = np.zeros((n, g.decoded_bytes), np.uint8); it = np.zeros(n, np.int32); ok = np.zeros(n, np.uint8)
+        cfo = _f32(cfo_hz) if cfo_hz is not None else None
+        rc = self.lib.ref_demod_decode_batch_mt(C.byref(cfg), _ptr(audio), C.c_size_t(stride),
+                                                _ptr(cfo) if cfo is not None else None, C.c_uint32(n), C.c_int(n_threads),
+                                                _ptr(by, C.c_uint8), C.c_uint32(g.decoded_bytes), _ptr(it, C.c_int32),
+                                                _ptr(ok, C.c_uint8))
         assert rc == 0
         return dict(bytes=by, iters=it, ok=ok)
 

@@ -20,6 +20,7 @@
 #include <cstdint>
 #include <cstdio>
 #include <cstring>
+#include <thread>
 #include <memory>
 #include <mutex>
 #include <random>
@@ -40,6 +41,7 @@
 #include "gui/modem/rx_pipeline.hpp"
 #undef private
 #include "protocol/frame_v2.hpp"
+#include "ultra/logging.hpp"
 
 #include "../include/ultra_hip.h"
 
@@ -508,6 +510,76 @@ int ref_demod_decode_batch(const ultra_hip_config* c, const float* audio, size_t
         iters_out[f] = dec.lastIterations();
         ok_out[f] = dec.lastDecodeSuccess() ? 1 : 0;
     }
+    return 0;
+}
+
+// The two batch entries over worker threads — one OFDMDemodulator / LDPCDecoder per thread, disjoint frame ranges: the
+// reference's CPU path timed on all host cores (bench.py's cpu_baseline, kind "reference").
+int ref_demod_decode_batch_mt(const ultra_hip_config* c, const float* audio, size_t frame_stride, const float* cfo_hz,
+                              uint32_t n_frames, int n_threads, uint8_t* bytes_out, uint32_t bytes_per_frame,
+                              int32_t* iters_out, uint8_t* ok_out) {
+    StderrMute mute;                                   // once, around all threads (it redirects the process's fd 2)
+    // as the reference's own harnesses do before they run trials (tools/test_mode_snr.cpp:123, tools/test_nvis_mode.cpp:
+    // 132): without it every LOG_* call formats its message under one global mutex (include/ultra/logging.hpp:58-66)
+    const LogLevel saved_level = g_log_level;
+    setLogLevel(LogLevel::WARN);
+    if (n_threads < 1) n_threads = 1;
+    std::vector<std::thread> th;
+    std::vector<int> rc((size_t)n_threads, 0);
+    for (int t = 0; t < n_threads; ++t) {
+        const uint32_t n0 = (uint32_t)((uint64_t)n_frames * t / n_threads), n1 = (uint32_t)((uint64_t)n_frames * (t + 1) / n_threads);
+        th.emplace_back([=, &rc] {
+            ModemConfig cfg = to_cfg(c);
+            OFDMDemodulator demod(cfg);
+            LDPCDecoder dec(cfg.code_rate);
+            dec.setMaxIterations((int)c->max_iterations);
+            auto* im = demod.impl_.get();
+            const size_t S = im->symbol_samples;
+            for (uint32_t f = n0; f < n1; ++f) {
+                const float* a = audio + (size_t)f * frame_stride;
+                float cfo = cfo_hz ? cfo_hz[f] : 0.0f;
+                demod.reset();
+                im->freq_offset_hz = cfo; im->freq_offset_filtered = cfo; im->freq_correction_phase = 0.0f;
+                im->symbols_since_sync = 0;
+                im->state.store(OFDMDemodulator::Impl::State::SYNCED);
+                im->carrier_phase_initialized = false; im->carrier_phase_correction = Complex(1, 0);
+                im->timing_offset_samples = 0.0f;
+                for (uint32_t s = 0; s < c->n_data_symbols; ++s) {
+                    auto bb = im->toBaseband(SampleSpan(a + (size_t)s * S, S));
+                    auto fd = im->extractSymbol(bb, 0);
+                    im->updateChannelEstimate(fd);
+                    auto eq = im->equalize(fd);
+                    im->demodulateSymbol(eq, cfg.modulation);
+                }
+                if (im->soft_bits.size() < 648) { ok_out[f] = 0; iters_out[f] = 0; std::memset(bytes_out + (size_t)f * bytes_per_frame, 0, bytes_per_frame); continue; }
+                Bytes r = dec.decodeSoft(std::span<const float>(im->soft_bits.data(), 648));
+                if (r.size() != bytes_per_frame) { rc[(size_t)t] = -1; return; }
+                std::memcpy(bytes_out + (size_t)f * bytes_per_frame, r.data(), r.size());
+                iters_out[f] = dec.lastIterations();
+                ok_out[f] = dec.lastDecodeSuccess() ? 1 : 0;
+            }
+        });
+    }
+    for (auto& x : th) x.join();
+    setLogLevel(saved_level);
+    for (int v : rc) if (v) return v;
+    return 0;
+}
+
+int ref_ldpc_decode_batch_mt(uint32_t rate, int max_iters, const float* llr, uint32_t n_cw, int n_threads,
+                             uint8_t* out, uint32_t bytes_per_cw, int32_t* iters, uint8_t* ok) {
+    if (n_threads < 1) n_threads = 1;
+    std::vector<std::thread> th;
+    std::vector<int> rc((size_t)n_threads, 0);
+    for (int t = 0; t < n_threads; ++t) {
+        const uint32_t n0 = (uint32_t)((uint64_t)n_cw * t / n_threads), n1 = (uint32_t)((uint64_t)n_cw * (t + 1) / n_threads);
+        th.emplace_back([=, &rc] {
+            rc[(size_t)t] = ref_ldpc_decode_batch(rate, max_iters, llr + 648ull * n0, n1 - n0, out + (size_t)bytes_per_cw * n0,
+                                                  bytes_per_cw, iters + n0, ok + n0);
+        });
+    }
+    for (auto& x : th) x.join();
+    for (int v : rc) if (v) return v;
     return 0;
 }
 

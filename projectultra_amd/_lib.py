@@ -74,6 +74,7 @@ PROTOTYPES = {
     "ultra_hip_counters_allreduce": (_i, [_vp, _vp, _vp]),
     "ultra_hip_receive_batch": (_i, [_vp, _vp, _sz, C.c_uint32, C.c_uint32, _sz, _vp, _vp, _vp, _vp, _vp, _vp]),
     "ultra_hip_make_batch": (_i, [_vp, C.c_uint64, C.c_uint64, _sz, _i, C.c_float, C.c_float, C.c_float, _vp, _sz, _vp]),
+    "ultra_hip_make_raw_batch": (_i, [_vp, C.c_uint64, C.c_uint64, _sz, _i, C.c_float, C.c_uint32, C.c_uint32, _vp, _sz, _vp]),
     "ultra_hip_make_llr_batch": (_i, [_vp, C.c_uint64, C.c_uint64, _sz, C.c_float, _vp, _vp]),
     "ultra_hip_set_deinterleave": (_i, [_vp, C.c_uint32]),
     "ultra_hip_profile_enable": (_i, [_vp, _i]),

@@ -397,6 +397,40 @@ __global__ __launch_bounds__(kWave) void channel_kernel(
     }
 }
 
+// Raw-audio streams for the end-to-end receive path (ultra_hip_receive_batch): [lead samples of noise][preamble]
+// [the frame's data symbols, written unscaled by stimulus_kernel at offset lead + pre_len][tail samples of noise].
+// The whole signal is scaled to a 0.5 peak and AWGN at snr_db relative to the mean power of preamble + modulator
+// output is added to EVERY sample of the stream (kind 1; kind 0: scaling only) — the harness of
+// tools/test_nvis_mode.cpp:62-86 with silence around the transmission.
+__global__ __launch_bounds__(kWave) void raw_stream_kernel(
+    const DemodConst* __restrict__ Dp, int kind, float snr_db, unsigned long long seed, unsigned long long f0, int n_frames,
+    int lead, int pre_len, int tail, int total_len, const float* __restrict__ preamble, const float* __restrict__ pre_stats,
+    const float* __restrict__ fstats, float* __restrict__ audio, size_t stream_stride) {
+    const DemodConst& D = *Dp;
+    const int lane = threadIdx.x;
+    const int frame_len = D.frame_samples;
+    const int n_out = lead + pre_len + frame_len + tail;
+    for (int frame = blockIdx.x; frame < n_frames; frame += gridDim.x) {
+        const unsigned long long f = f0 + (unsigned long long)frame;
+        const unsigned long long key = (seed ^ (f * 0x100000001B3ull)) * 0x9E3779B97F4A7C15ull + 0xC4A77E1ull;
+        float* a = audio + (size_t)frame * stream_stride;
+        const float mx = fmaxf(pre_stats[0], fstats[2 * (size_t)frame]);
+        const float scale = 0.5f / mx;
+        const float power = (pre_stats[1] + fstats[2 * (size_t)frame + 1]) * scale * scale / (float)total_len;
+        const float nstd = (kind == 1) ? sqrtf(power / powf(10.0f, snr_db / 10.0f)) : 0.0f;
+        for (int i = lane; i < n_out; i += 2 * kWave) {
+            float n0 = 0.0f, n1 = 0.0f;
+            if (kind == 1) gauss_pair(key, (unsigned long long)i, &n0, &n1);
+            auto sig = [&](int j) -> float {
+                if (j < lead || j >= lead + pre_len + frame_len) return 0.0f;
+                return ((j < lead + pre_len) ? preamble[j - lead] : a[j]) * scale;
+            };
+            a[i] = sig(i) + nstd * n0;
+            if (i + kWave < n_out) a[i + kWave] = sig(i + kWave) + nstd * n1;
+        }
+    }
+}
+
 // ---- BPSK-over-AWGN LLR stimulus (BASELINE configs[3]: the LDPC-only SNR sweep) -----------------
 // Counter-based standard normal pair for (key, n) with libm-exact arithmetic: Box-Muller on two 24-bit uniforms,
 // logf / sincosf from pinned_math.h (bit-identical to glibc 2.35's), correctly rounded sqrtf, every other step one

@@ -273,6 +273,79 @@ int launch_ldpc(ultra_hip_ctx* ctx, const float* d_llr, size_t llr_stride, size_
     return ULTRA_HIP_OK;
 }
 
+// One-time stimulus tables of a context (TX oscillator, preamble, frame layout): built into locals and published only
+// when every step has succeeded, so a failed allocation or copy cannot leave half an initialisation behind.
+int stimulus_tables(ultra_hip_ctx* ctx) {
+    if (ctx->d_nco_tx) return ULTRA_HIP_OK;
+    const DemodConst& D = ctx->h_demod;
+    const int N = D.fft, psl = N + D.cp;
+    // frame layout of the harness (uo_make_batch): enough codewords to fill the frame's LLRs
+    const int k = (int)ctx->geo.ldpc_k, pb = k / 8;
+    const int ncw_raw = ((int)ctx->geo.llrs_per_frame + kLdpcN - 1) / kLdpcN;
+    const int nraw = ncw_raw * pb;
+    const int ncw_enc = (nraw * 8 + k - 1) / k;           // LDPCEncoder::encode: one codeword per k bits of input
+    const int bps = D.n_data * D.bits;
+    const int n_tx = (ncw_enc * kLdpcN + bps - 1) / bps;  // OFDMModulator::modulate: symbols until the bytes run out
+    if (ncw_enc > dev::kStimMaxCw || nraw > dev::kStimMaxCw * 72 || n_tx < D.n_data_sym) return ULTRA_HIP_ERR_UNSUPPORTED;
+    if (D.log2_fft != 10 && D.log2_fft != 9) return ULTRA_HIP_ERR_UNSUPPORTED;
+    // TX oscillator: NCO(center_freq) from phase 0 at the first STS sample, one pass over the STS, one over
+    // the LTS, then every sample of every data symbol incl. guards (modulator.cpp:479-532, quirk 6)
+    const size_t total = (size_t)2 * psl + (size_t)n_tx * D.sym_len;
+    std::vector<c32> nco(total);
+    const double two_pi = 2.0 * M_PI;
+    const float step = (float)((two_pi * (double)(float)ctx->cfg.center_freq) / (double)(float)ctx->cfg.sample_rate);
+    float acc = 0.0f;
+    for (size_t i = 0; i < total; ++i) {
+        nco[i] = c32{cosf(acc), sinf(acc)};
+        acc += step;
+        if ((double)acc > two_pi) acc = (float)((double)acc - two_pi);
+        if (acc < 0.0f) acc = (float)((double)acc + two_pi);
+    }
+    c32* d_nco_tx = nullptr;
+    float* d_preamble = nullptr;
+    auto fail = [&](int code) { if (d_nco_tx) (void)hipFree(d_nco_tx); if (d_preamble) (void)hipFree(d_preamble); return code; };
+    if (hipMalloc(&d_nco_tx, total * sizeof(c32)) != hipSuccess) return fail(ULTRA_HIP_ERR_OOM);
+    if (hipMemcpy(d_nco_tx, nco.data(), total * sizeof(c32), hipMemcpyHostToDevice) != hipSuccess) return fail(ULTRA_HIP_ERR_HIP);
+    if (hipMalloc(&d_preamble, ((size_t)7 * psl + 2) * sizeof(float)) != hipSuccess) return fail(ULTRA_HIP_ERR_OOM);
+    if (D.log2_fft == 10)
+        hipLaunchKernelGGL(dev::preamble_kernel<10>, dim3(1), dim3(dev::kWave), 0, ctx->stream, ctx->d_demod,
+                           ctx->d_twiddle, d_nco_tx, d_preamble, d_preamble + 7 * psl);
+    else
+        hipLaunchKernelGGL(dev::preamble_kernel<9>, dim3(1), dim3(dev::kWave), 0, ctx->stream, ctx->d_demod,
+                           ctx->d_twiddle, d_nco_tx, d_preamble, d_preamble + 7 * psl);
+    if (hipGetLastError() != hipSuccess) return fail(ULTRA_HIP_ERR_HIP);
+    ctx->stim_ncw_raw = ncw_raw; ctx->stim_ncw_enc = ncw_enc; ctx->stim_tx_symbols = n_tx; ctx->stim_pre_len = 7 * psl;
+    ctx->d_preamble = d_preamble;
+    ctx->d_nco_tx = d_nco_tx;                              // published last: the guard of the next call
+    return ULTRA_HIP_OK;
+}
+
+// payload -> encode -> modulate of frames first_frame .. + n_frames - 1 into d_audio rows (unscaled) + per-frame stats
+int launch_stimulus(ultra_hip_ctx* ctx, uint64_t seed, uint64_t first_frame, size_t n_frames, float* d_audio, size_t frame_stride,
+                    uint8_t* d_payload) {
+    const DemodConst& D = ctx->h_demod;
+    if (ctx->ws_fstats_frames < n_frames) {
+        if (ctx->d_ws_fstats) { UH_HIP(hipStreamSynchronize(ctx->stream)); (void)hipFree(ctx->d_ws_fstats); ctx->d_ws_fstats = nullptr; }
+        ctx->ws_fstats_frames = 0;
+        UH_HIP(hipMalloc(&ctx->d_ws_fstats, n_frames * 2 * sizeof(float)));
+        ctx->ws_fstats_frames = n_frames;
+    }
+    const int pb = (int)ctx->geo.ldpc_k / 8;
+    const unsigned grid = (unsigned)std::min(n_frames, (size_t)ctx->cu_count * 32);
+    if (D.log2_fft == 10)
+        hipLaunchKernelGGL(dev::stimulus_kernel<10>, dim3(grid), dim3(dev::kWave), 0, ctx->stream, ctx->d_demod, ctx->d_plan,
+                           ctx->d_twiddle, ctx->d_nco_tx, (unsigned long long)seed, (unsigned long long)first_frame,
+                           (int)n_frames, ctx->stim_ncw_raw * pb, ctx->stim_ncw_enc, pb, ctx->stim_tx_symbols, d_audio,
+                           frame_stride, d_payload, ctx->d_ws_fstats);
+    else
+        hipLaunchKernelGGL(dev::stimulus_kernel<9>, dim3(grid), dim3(dev::kWave), 0, ctx->stream, ctx->d_demod, ctx->d_plan,
+                           ctx->d_twiddle, ctx->d_nco_tx, (unsigned long long)seed, (unsigned long long)first_frame,
+                           (int)n_frames, ctx->stim_ncw_raw * pb, ctx->stim_ncw_enc, pb, ctx->stim_tx_symbols, d_audio,
+                           frame_stride, d_payload, ctx->d_ws_fstats);
+    UH_HIP(hipGetLastError());
+    return ULTRA_HIP_OK;
+}
+
 }  // namespace
 
 extern "C" {
@@ -634,69 +707,48 @@ int ultra_hip_make_batch(ultra_hip_ctx* ctx, uint64_t seed, uint64_t first_frame
     DeviceGuard guard(ctx->device);
     const DemodConst& D = ctx->h_demod;
     const int N = D.fft, psl = N + D.cp;
-    if (!ctx->d_nco_tx) {                                     // one-time tables of this context
-        // frame layout of the harness (uo_make_batch): enough codewords to fill the frame's LLRs
-        const int k = (int)ctx->geo.ldpc_k, pb = k / 8;
-        const int ncw_raw = ((int)ctx->geo.llrs_per_frame + kLdpcN - 1) / kLdpcN;
-        const int nraw = ncw_raw * pb;
-        const int ncw_enc = (nraw * 8 + k - 1) / k;           // LDPCEncoder::encode: one codeword per k bits of input
-        const int bps = D.n_data * D.bits;
-        const int n_tx = (ncw_enc * kLdpcN + bps - 1) / bps;  // OFDMModulator::modulate: symbols until the bytes run out
-        if (ncw_enc > dev::kStimMaxCw || nraw > dev::kStimMaxCw * 72 || n_tx < D.n_data_sym) return ULTRA_HIP_ERR_UNSUPPORTED;
-        // TX oscillator: NCO(center_freq) from phase 0 at the first STS sample, one pass over the STS, one over
-        // the LTS, then every sample of every data symbol incl. guards (modulator.cpp:479-532, quirk 6)
-        const size_t total = (size_t)2 * psl + (size_t)n_tx * D.sym_len;
-        std::vector<c32> nco(total);
-        const double two_pi = 2.0 * M_PI;
-        const float step = (float)((two_pi * (double)(float)ctx->cfg.center_freq) / (double)(float)ctx->cfg.sample_rate);
-        float acc = 0.0f;
-        for (size_t i = 0; i < total; ++i) {
-            nco[i] = c32{cosf(acc), sinf(acc)};
-            acc += step;
-            if ((double)acc > two_pi) acc = (float)((double)acc - two_pi);
-            if (acc < 0.0f) acc = (float)((double)acc + two_pi);
-        }
-        UH_HIP(hipMalloc(&ctx->d_nco_tx, total * sizeof(c32)));
-        UH_HIP(hipMemcpy(ctx->d_nco_tx, nco.data(), total * sizeof(c32), hipMemcpyHostToDevice));
-        UH_HIP(hipMalloc(&ctx->d_preamble, ((size_t)7 * psl + 2) * sizeof(float)));
-        if (D.log2_fft == 10)
-            hipLaunchKernelGGL(dev::preamble_kernel<10>, dim3(1), dim3(dev::kWave), 0, ctx->stream, ctx->d_demod,
-                               ctx->d_twiddle, ctx->d_nco_tx, ctx->d_preamble, ctx->d_preamble + 7 * psl);
-        else
-            hipLaunchKernelGGL(dev::preamble_kernel<9>, dim3(1), dim3(dev::kWave), 0, ctx->stream, ctx->d_demod,
-                               ctx->d_twiddle, ctx->d_nco_tx, ctx->d_preamble, ctx->d_preamble + 7 * psl);
-        ctx->stim_ncw_raw = ncw_raw; ctx->stim_ncw_enc = ncw_enc; ctx->stim_tx_symbols = n_tx; ctx->stim_pre_len = 7 * psl;
-    }
-    if (ctx->ws_fstats_frames < n_frames) {
-        if (ctx->d_ws_fstats) { UH_HIP(hipStreamSynchronize(ctx->stream)); (void)hipFree(ctx->d_ws_fstats); ctx->d_ws_fstats = nullptr; }
-        ctx->ws_fstats_frames = 0;
-        UH_HIP(hipMalloc(&ctx->d_ws_fstats, n_frames * 2 * sizeof(float)));
-        ctx->ws_fstats_frames = n_frames;
-    }
-    const int pb = (int)ctx->geo.ldpc_k / 8;
+    // every check before the first launch (a kernel launched with half-initialised tables could fault)
+    const size_t lds = (channel_kind == 2) ? (size_t)D.frame_samples * sizeof(float) : 0;
+    if (lds > 64 * 1024) return ULTRA_HIP_ERR_UNSUPPORTED;
+    { const int rc = stimulus_tables(ctx); if (rc != ULTRA_HIP_OK) return rc; }
+    { const int rc = launch_stimulus(ctx, seed, first_frame, n_frames, d_audio, frame_stride, d_payload); if (rc != ULTRA_HIP_OK) return rc; }
     const unsigned grid = (unsigned)std::min(n_frames, (size_t)ctx->cu_count * 32);
-    if (D.log2_fft == 10)
-        hipLaunchKernelGGL(dev::stimulus_kernel<10>, dim3(grid), dim3(dev::kWave), 0, ctx->stream, ctx->d_demod, ctx->d_plan,
-                           ctx->d_twiddle, ctx->d_nco_tx, (unsigned long long)seed, (unsigned long long)first_frame,
-                           (int)n_frames, ctx->stim_ncw_raw * pb, ctx->stim_ncw_enc, pb, ctx->stim_tx_symbols, d_audio,
-                           frame_stride, d_payload, ctx->d_ws_fstats);
-    else
-        hipLaunchKernelGGL(dev::stimulus_kernel<9>, dim3(grid), dim3(dev::kWave), 0, ctx->stream, ctx->d_demod, ctx->d_plan,
-                           ctx->d_twiddle, ctx->d_nco_tx, (unsigned long long)seed, (unsigned long long)first_frame,
-                           (int)n_frames, ctx->stim_ncw_raw * pb, ctx->stim_ncw_enc, pb, ctx->stim_tx_symbols, d_audio,
-                           frame_stride, d_payload, ctx->d_ws_fstats);
     // channel
     const float fs = (float)ctx->cfg.sample_rate;
     const int delay_samples = (int)(size_t)(delay_ms * fs / 1000.0f);
     const float normalized_doppler = doppler_hz / fs;
     const float fading_alpha = (float)(1.0 - std::exp((double)-2.0f * M_PI * (double)normalized_doppler));
     const int total_len = ctx->stim_pre_len + ctx->stim_tx_symbols * D.sym_len;
-    const size_t lds = (channel_kind == 2) ? (size_t)D.frame_samples * sizeof(float) : 0;
-    if (lds > 64 * 1024) return ULTRA_HIP_ERR_UNSUPPORTED;
     hipLaunchKernelGGL(dev::channel_kernel, dim3(grid), dim3(dev::kWave), lds, ctx->stream, ctx->d_demod, channel_kind,
                        snr_db, delay_samples, fading_alpha, 0.707f, 0.707f, (unsigned long long)seed,
                        (unsigned long long)first_frame, (int)n_frames, ctx->stim_pre_len, total_len, ctx->d_preamble,
                        ctx->d_preamble + 7 * psl, ctx->d_ws_fstats, d_audio, frame_stride);
+    UH_HIP(hipGetLastError());
+    return ULTRA_HIP_OK;
+}
+
+int ultra_hip_make_raw_batch(ultra_hip_ctx* ctx, uint64_t seed, uint64_t first_frame, size_t n_streams, int channel_kind,
+                             float snr_db, uint32_t lead, uint32_t tail, float* d_audio, size_t stream_stride,
+                             uint8_t* d_payload) {
+    if (!ctx) return ULTRA_HIP_ERR_INVALID_ARG;
+    if (n_streams == 0) return ULTRA_HIP_OK;
+    if (ctx->cfg.entry != ULTRA_ENTRY_SYNCED) return ULTRA_HIP_ERR_UNSUPPORTED;
+    const DemodConst& D = ctx->h_demod;
+    const int psl = D.fft + D.cp;
+    const size_t n_out = (size_t)lead + (size_t)7 * psl + ctx->geo.frame_samples + tail;
+    if (!d_audio || !d_payload || stream_stride < n_out || channel_kind < 0 || channel_kind > 1 || n_streams > 0x7fffffffull ||
+        n_out > 0x3fffffffull)
+        return ULTRA_HIP_ERR_INVALID_ARG;
+    DeviceGuard guard(ctx->device);
+    { const int rc = stimulus_tables(ctx); if (rc != ULTRA_HIP_OK) return rc; }
+    // the modulator's data symbols land where the stream has them: behind the lead and the preamble
+    { const int rc = launch_stimulus(ctx, seed, first_frame, n_streams, d_audio + lead + ctx->stim_pre_len, stream_stride, d_payload);
+      if (rc != ULTRA_HIP_OK) return rc; }
+    const unsigned grid = (unsigned)std::min(n_streams, (size_t)ctx->cu_count * 32);
+    const int total_len = ctx->stim_pre_len + ctx->stim_tx_symbols * D.sym_len;
+    hipLaunchKernelGGL(dev::raw_stream_kernel, dim3(grid), dim3(dev::kWave), 0, ctx->stream, ctx->d_demod, channel_kind, snr_db,
+                       (unsigned long long)seed, (unsigned long long)first_frame, (int)n_streams, (int)lead, ctx->stim_pre_len,
+                       (int)tail, total_len, ctx->d_preamble, ctx->d_preamble + 7 * psl, ctx->d_ws_fstats, d_audio, stream_stride);
     UH_HIP(hipGetLastError());
     return ULTRA_HIP_OK;
 }

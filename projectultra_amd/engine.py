@@ -334,6 +334,21 @@ class ReceiveContext:
                                             payload.data_ptr()), "ultra_hip_make_batch")
         return audio, payload
 
+    def make_raw_batch(self, n_streams: int, seed: int = 0x5EED, first_frame: int = 0, channel: str = "awgn",
+                       snr_db: float = 30.0, lead: int = 1120, tail: int = 960):
+        """Raw-audio streams for receive(): [lead silence][preamble][data symbols][tail silence], 0.5 peak, AWGN on every
+        sample (ultra_hip_make_raw_batch).  Returns (audio [n][lead + preamble + frame_samples + tail], payload)."""
+        torch = _torch()
+        g = self.geometry
+        n_out = lead + 7 * (self.config.fft_size + g.cp_len) + g.frame_samples + tail
+        audio = torch.empty((n_streams, n_out), dtype=torch.float32, device=self.device)
+        payload = torch.empty((n_streams, g.ldpc_k // 8), dtype=torch.uint8, device=self.device)
+        kind = dict(none=0, awgn=1)[channel]
+        check(self.lib.ultra_hip_make_raw_batch(self._ctx, int(seed), int(first_frame), n_streams, kind, float(snr_db), int(lead),
+                                                int(tail), audio.data_ptr(), self._row_stride(audio), payload.data_ptr()),
+              "ultra_hip_make_raw_batch")
+        return audio, payload
+
     def make_llr_batch(self, n_cw: int, esn0_db: float, seed: int = 0x5EED, first_cw: int = 0, out=None):
         """BPSK-over-AWGN LLRs of n_cw random codewords of the context's rate, generated on the device
         (ultra_hip_make_llr_batch; SURVEY.md 8d cfg4).  Returns (llr [n][648] f32, payload [n][k // 8] u8); `out` may

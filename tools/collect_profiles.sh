@@ -1,19 +1,24 @@
 #!/bin/bash
-# Round-end evidence (run on the GPU box from the repo root):  bash tools/collect_profiles.sh <tag>
-#   gpurun_out/<tag>/bench.json         python3 bench.py (defaults, with the CPU baseline)
-#   gpurun_out/<tag>/kernel_stats.csv   rocprofv3 --kernel-trace --stats of bench.py --steps 3 --warmup 1
-#   gpurun_out/<tag>/traffic.json       HBM bytes per launch from separate --pmc FETCH_SIZE / WRITE_SIZE passes
+# Round-end evidence (run on the GPU box from the repo root):  bash tools/collect_profiles.sh <tag> [config] [commit]
+#   gpurun_out/<tag>/bench_<config>.json        python3 bench.py --config <config> (defaults, with the CPU baseline)
+#   gpurun_out/<tag>/kernel_stats_<config>.csv  rocprofv3 --kernel-trace --stats of bench.py --steps 3 --warmup 1
+#   gpurun_out/<tag>/traffic_<config>.json      HBM bytes per launch from separate --pmc FETCH_SIZE / WRITE_SIZE passes
+# The checker libraries are (re)built by the FIRST, unprofiled run; every run under rocprofv3 passes --no-build: the
+# profiler's preloaded library initialises the GPU before main(), and such a process must never start a compiler.
 set -u
-TAG=${1:-r01}
+TAG=${1:-r02}
+CFG=${2:-cfg3}
+COMMIT=${3:-unknown}
 OUT=gpurun_out/$TAG
 mkdir -p "$OUT"
 export TMPDIR=/tmp
-timeout 900 python3 bench.py > "$OUT/bench.json" 2> "$OUT/bench.err"; echo "bench rc=$?"
-timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/ks" -o run -- python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline > "$OUT/ks.log" 2>&1; echo "stats rc=$?"
-cp "$OUT/ks/run_kernel_stats.csv" "$OUT/kernel_stats.csv" 2>/dev/null
+timeout -k 10 900 python3 bench.py --config $CFG > "$OUT/bench_$CFG.json" 2> "$OUT/bench_$CFG.err"; echo "bench rc=$?"
+timeout -k 10 600 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/ks" -o run -- python3 bench.py --config $CFG --steps 3 --warmup 1 --no-cpu-baseline --no-build > "$OUT/ks_$CFG.log" 2>&1; echo "stats rc=$?"
+cp "$OUT/ks/run_kernel_stats.csv" "$OUT/kernel_stats_$CFG.csv" 2>/dev/null
 for c in FETCH_SIZE WRITE_SIZE; do
-  timeout 600 rocprofv3 --kernel-trace --output-format csv --pmc $c -d "$OUT/pmc_$c" -o run -- python3 bench.py --steps 1 --warmup 0 --no-cpu-baseline > "$OUT/pmc_$c.log" 2>&1; echo "pmc $c rc=$?"
+  timeout -k 10 600 rocprofv3 --kernel-trace --output-format csv --pmc $c -d "$OUT/pmc_$c" -o run -- python3 bench.py --config $CFG --steps 1 --warmup 0 --no-cpu-baseline --no-build > "$OUT/pmc_${c}_$CFG.log" 2>&1; echo "pmc $c rc=$?"
 done
-python3 tools/traffic_from_pmc.py "$OUT" > "$OUT/traffic.json"
+UNITS=$(python3 -c "import json;print(json.load(open('$OUT/bench_$CFG.json'))['roofline']['algorithmic_bytes_per_launch'] and json.load(open('$OUT/bench_$CFG.json'))['config']['trials_per_gpu_per_step'] // json.load(open('$OUT/bench_$CFG.json'))['collective']['per_step'])")
+python3 tools/traffic_from_pmc.py "$OUT" $CFG $UNITS $COMMIT > "$OUT/traffic_$CFG.json"
 rm -rf "$OUT/ks" "$OUT"/pmc_*/ 2>/dev/null
-cat "$OUT/bench.json"; head -8 "$OUT/kernel_stats.csv" | cut -c1-160; cat "$OUT/traffic.json"
+head -c 600 "$OUT/bench_$CFG.json"; echo; head -12 "$OUT/kernel_stats_$CFG.csv" | cut -c1-170; cat "$OUT/traffic_$CFG.json"

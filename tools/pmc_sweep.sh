@@ -7,6 +7,10 @@ PROG=${PMC_PROG:-bench.py}
 ARGS=${@:---steps 2 --warmup 1 --no-cpu-baseline}
 export TMPDIR=/tmp
 mkdir -p "$OUT"
+# the checker libraries are built HERE, by an unprofiled process; every profiled run passes --no-build (the profiler's
+# preloaded library initialises the GPU before main(), and such a process must never start a compiler)
+python3 -c "import bench; bench.ensure_built(False)" || exit 1
+case "$PROG" in bench.py) ARGS="$ARGS --no-build";; esac
 PASSES=(
  "SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS"
  "SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_ANY SQ_WAIT_INST_ANY SQ_WAIT_INST_LDS SQ_INSTS_VMEM_RD"
