@@ -95,5 +95,25 @@ struct LdpcPlan {
     int32_t row_identity, linear;
 };
 
+// Execution plan of the "totals" LDPC kernel (ldpc_totals_kernel.h) for the codes whose rows all have six (R2/3:
+// five or six) information edges and whose variables have degree <= 4 — R2/3, R3/4, R5/6.  One total per variable
+// lives in the lane-linear LDS array T[round][lane]; the check-to-variable messages live in the lane-linear array
+// R[round][slot][lane]; each side gathers from the other's array.  LDS byte offsets (from the dynamic LDS base):
+//   T words      [0, var_rounds * 256)                     word (round * 64 + lane) = the variable in that slot
+//   T pad word   at t_pad: +FLT_MAX (the phantom operand of a row with fewer than six information edges)
+//   R words      [r_base, r_base + row_rounds * 6 * 256)   word ((round * 6 + t) * 64 + lane) = edge slot t of the row
+//   R pad word   at r_pad: -0.0f (the neutral addend of a variable with fewer than dmax edges)
+//   staging      stage_v [var_rounds][64], stage_p [row_rounds][64]: channel LLRs of the NEXT codeword, slot-indexed
+constexpr int kTPlanRowRounds = 4, kTPlanVarRounds = 7, kTPlanDmax = 4;
+struct LdpcTPlan {
+    int32_t valid, k, m, n, max_iterations, decoded_bytes, row_rounds, var_rounds, dmax;
+    int32_t t_pad, r_base, r_pad, stage_v, stage_p, lds_bytes, extra_cycles, _pad[2];
+    uint16_t row_check[kTPlanRowRounds * 64];             // slot -> check index i (parity bit = variable k + i); 0xFFFF: empty
+    uint16_t row_taddr[kTPlanRowRounds * 64 * 6];         // byte offset of the T word gathered by edge slot t (t_pad: none)
+    uint16_t var_id[kTPlanVarRounds * 64];                // slot -> variable index; 0xFFFF: empty
+    uint16_t var_caddr[kTPlanVarRounds * 64 * kTPlanDmax];  // byte offset of the R word of edge q, ascending check order (r_pad: none)
+    uint16_t var_slot_of[kLdpcN];                         // variable -> slot; 0xFFFF: the variable has no check
+};
+
 }  // namespace ultra_hip
 #endif

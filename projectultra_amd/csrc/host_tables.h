@@ -19,6 +19,11 @@
 
 #include "../../include/ultra_hip.h"
 #include "device_types.h"
+#ifndef ULTRA_LDPC_NO_PLACEMENT
+#include "ldpc_placement.h"
+#else       // tools/ldpc_place.cpp, which GENERATES that header, compiles without it
+namespace ultra_hip { inline bool ldpc_placement(uint32_t, const uint16_t**, int*, const uint16_t**, int*) { return false; } }
+#endif
 
 namespace ultra_hip {
 
@@ -397,6 +402,75 @@ inline int build_ldpc_plan_linear(const LdpcConst& L, LdpcPlan& P) {
         P.prof_vmax |= (uint64_t)mx << (4 * r);
         P.prof_vmin |= (uint64_t)mn << (4 * r);
     }
+    return ULTRA_HIP_OK;
+}
+
+// Plan of the totals kernel from the embedded placement (ldpc_placement.h, generated by tools/ldpc_place.cpp): validated
+// against the code's graph — slots unique and in range, at most six edges per (row half-wave, variable bank) cell —, then
+// every edge gets its gather instruction on the row side by a six-edge-colouring per row half-wave (conflict-free by
+// construction); the variable side gathers in ascending check order (residual collisions there cost cycles, never
+// correctness: P.extra_cycles).  ULTRA_HIP_ERR_UNSUPPORTED when the code has no placement or it does not fit.
+inline int build_ldpc_tplan(const LdpcConst& L, uint32_t rate, LdpcTPlan& P) {
+    P = LdpcTPlan{};
+    const uint16_t *vs = nullptr, *rs = nullptr;
+    int nv = 0, nr = 0;
+    if (!ldpc_placement(rate, &vs, &nv, &rs, &nr) || nv != L.k || nr != L.m) return ULTRA_HIP_ERR_UNSUPPORTED;
+    int na = 0, dmax = 0;
+    for (int j = 0; j < L.k; ++j) { const int d = L.var_ptr[j + 1] - L.var_ptr[j]; if (d > 0) ++na; dmax = std::max(dmax, d); }
+    const int VR = (na + 63) / 64, RR = (L.m + 63) / 64;
+    if (VR > kTPlanVarRounds || RR > kTPlanRowRounds || dmax > kTPlanDmax || dmax < 1) return ULTRA_HIP_ERR_UNSUPPORTED;
+    for (int j = L.k; j < L.n; ++j) if (L.var_ptr[j + 1] - L.var_ptr[j] != 1) return ULTRA_HIP_ERR_UNSUPPORTED;
+    P.k = L.k; P.m = L.m; P.n = L.n; P.max_iterations = L.max_iterations; P.decoded_bytes = L.decoded_bytes;
+    P.row_rounds = RR; P.var_rounds = VR; P.dmax = dmax;
+    P.t_pad = VR * 256; P.r_base = P.t_pad + 16; P.r_pad = P.r_base + RR * 6 * 256; P.stage_v = P.r_pad + 16;
+    P.stage_p = P.stage_v + VR * 256; P.lds_bytes = P.stage_p + RR * 256;
+    for (auto& x : P.row_check) x = 0xFFFF;
+    for (auto& x : P.var_id) x = 0xFFFF;
+    for (auto& x : P.var_slot_of) x = 0xFFFF;
+    for (auto& x : P.row_taddr) x = (uint16_t)P.t_pad;
+    for (auto& x : P.var_caddr) x = (uint16_t)P.r_pad;
+    for (int j = 0; j < L.k; ++j) {
+        const int d = L.var_ptr[j + 1] - L.var_ptr[j];
+        if ((d > 0) != (vs[j] != 0xFFFF)) return ULTRA_HIP_ERR_UNSUPPORTED;
+        if (d == 0) continue;
+        if (vs[j] >= VR * 64 || P.var_id[vs[j]] != 0xFFFF) return ULTRA_HIP_ERR_UNSUPPORTED;
+        P.var_id[vs[j]] = (uint16_t)j; P.var_slot_of[j] = vs[j];
+    }
+    for (int i = 0; i < L.m; ++i) {
+        const int d = L.row_ptr[i + 1] - L.row_ptr[i];
+        if (d < 2 || d > 7 || L.col[L.row_ptr[i + 1] - 1] != L.k + i) return ULTRA_HIP_ERR_UNSUPPORTED;
+        if (rs[i] >= RR * 64 || P.row_check[rs[i]] != 0xFFFF) return ULTRA_HIP_ERR_UNSUPPORTED;
+        P.row_check[rs[i]] = (uint16_t)i;
+    }
+    // row side: per half-wave a six-edge-colouring of rows x variable banks
+    std::vector<int> slot_t(L.edges, -1);
+    for (int g = 0; g < 2 * RR; ++g) {
+        std::vector<int> rows_g;
+        for (int l = 0; l < 32; ++l) if (P.row_check[g * 32 + l] != 0xFFFF) rows_g.push_back(P.row_check[g * 32 + l]);
+        std::vector<std::pair<int, int>> ed; std::vector<int> eid; int cell[32] = {0};
+        for (size_t li = 0; li < rows_g.size(); ++li)
+            for (int e = L.row_ptr[rows_g[li]]; e + 1 < L.row_ptr[rows_g[li] + 1]; ++e) {
+                const int b = vs[L.col[e]] % 32;
+                if (++cell[b] > 6) return ULTRA_HIP_ERR_UNSUPPORTED;
+                ed.push_back({(int)li, b}); eid.push_back(e);
+            }
+        std::vector<int> colour;
+        bipartite_edge_colouring((int)rows_g.size(), 32, ed, 6, colour);
+        for (size_t x = 0; x < ed.size(); ++x) { if (colour[x] < 0 || colour[x] >= 6) return ULTRA_HIP_ERR_UNSUPPORTED; slot_t[eid[x]] = colour[x]; }
+    }
+    std::vector<int> layer(2 * VR * dmax * 32, 0);
+    for (int i = 0; i < L.m; ++i)
+        for (int e = L.row_ptr[i]; e + 1 < L.row_ptr[i + 1]; ++e) {
+            const int j = L.col[e], t = slot_t[e], rsl = rs[i], vsl = vs[j];
+            int q = -1;
+            for (int x = L.var_ptr[j]; x < L.var_ptr[j + 1]; ++x) if (L.var_edge[x] == e) q = x - L.var_ptr[j];
+            if (q < 0 || t < 0) return ULTRA_HIP_ERR_UNSUPPORTED;
+            P.row_taddr[rsl * 6 + t] = (uint16_t)(vsl * 4);
+            P.var_caddr[vsl * kTPlanDmax + q] = (uint16_t)(P.r_base + (((rsl / 64) * 6 + t) * 64 + rsl % 64) * 4);
+            layer[((vsl / 32) * dmax + q) * 32 + rsl % 32]++;
+        }
+    for (int hq = 0; hq < 2 * VR * dmax; ++hq) { int mx = 1; for (int u = 0; u < 32; ++u) mx = std::max(mx, layer[hq * 32 + u]); P.extra_cycles += mx - 1; }
+    P.valid = 1;
     return ULTRA_HIP_OK;
 }
 

@@ -1,0 +1,268 @@
+// ldpc_totals_kernel.h — LDPC(648) scaled-min-sum decode for gfx950, "totals" formulation: one wavefront per codeword,
+// HALF the LDS traffic of the message-passing kernel (ldpc_kernel.h) for the codes it covers (R2/3, R3/4, R5/6).
+//
+// Same arithmetic as LDPCDecoder::Impl::decodeBP (src/fec/ldpc_decoder.cpp:153-259) — see ldpc_kernel.h's header for
+// the value-identical reformulations shared with it (minima with |.| modifiers and minNum semantics, signs as lane
+// masks, the +-50 clamp deferred to the reader, parity bits in the registers of their row's lane, unchecked variables
+// untouched).  What differs is WHO computes the variable-to-check message and what travels through LDS:
+//
+//   reference / message kernel   variable step:  v2c[e] = clamp(total[j] - c2v[e])  per EDGE, stored, read by the row
+//   here                          the variable publishes ONE number, total[j]; the ROW computes total[j] - c2v[e] with
+//                                 its own previous c2v[e], which it kept in a register.  Same operands, same operation.
+//
+// LDS per codeword-iteration (R3/4: 3 row rounds, 6 variable rounds, 18 edge slots):
+//   row side       18 gathers of totals (ds_read_b32, 2 cycles)      18 lane-linear stores of c2v (ds_write_addtid_b32, 2)
+//   variable side  18 gathers of c2v   (ds_read_b32, 2 cycles)        6 lane-linear stores of totals (add-TID, 2)
+//   = 120 LDS-pipeline cycles (+ the plan's residual gather collisions, P.extra_cycles) against 180 of the message kernel,
+//   whose check step stores through address registers (ds_write_b32: 4 cycles each).
+// Both gathers are made conflict-free by WHERE variables and rows sit (tools/ldpc_place.cpp -> ldpc_placement.h ->
+// build_ldpc_tplan).  The stopping test needs no extra pass: a row that has gathered the totals of its variables
+// evaluates its own parity equation on them — the exact checkParity (:139-151) of the PREVIOUS iteration, decided at
+// the top of the next one from the very gathers the check step needs anyway.
+#ifndef ULTRA_LDPC_TOTALS_KERNEL_H
+#define ULTRA_LDPC_TOTALS_KERNEL_H
+
+#include <hip/hip_runtime.h>
+#include "device_types.h"
+#include "ldpc_kernel.h"
+
+namespace ultra_hip {
+namespace dev {
+
+// RR row rounds, VR variable rounds, D = largest variable degree (LdpcTPlan).  WAVES: wavefronts per SIMD the register
+// budget is sized for.  WANT_TOTAL: also write the final a-posteriori LLRs (parity tests).
+template <int RR, int VR, int D, bool WANT_TOTAL, int WAVES>
+__global__ __launch_bounds__(kLdpcThreads, WAVES) void ldpc_totals_kernel(
+    const LdpcTPlan* __restrict__ Pp, const float* __restrict__ llr, size_t llr_stride, int n_cw,
+    uint8_t* __restrict__ bytes, int32_t* __restrict__ iters, uint8_t* __restrict__ okv,
+    float* __restrict__ llr_total, unsigned int* __restrict__ work_counter, int llr_step) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
+    const LdpcTPlan& P = *Pp;
+    const int lane = threadIdx.x;
+    // The LDS layout is a function of the instance (build_ldpc_tplan uses the same formulas and ultra_hip.hip checks
+    // them): compile-time offsets, and the plan's scalars in locals — the "memory" clobber of the store asm would
+    // otherwise make the compiler reload them from the plan inside the iteration loop.
+    constexpr unsigned T_PAD = VR * 256, R_BASE = T_PAD + 16, R_PAD = R_BASE + RR * 6 * 256, STAGE_V = R_PAD + 16,
+                       STAGE_P = STAGE_V + VR * 256;
+    const int k = P.k, max_iterations = P.max_iterations, decoded_bytes = P.decoded_bytes;
+    auto ldsf = [&](unsigned byte_off) -> float& { return *reinterpret_cast<float*>(lds_raw + byte_off); };
+    const unsigned lds_base = (unsigned)(size_t)lds_raw;
+    // lane-linear store: word (plane_byte_off / 4 + lane) <- x, no address register (ds_write_addtid_b32: 2 LDS cycles)
+    auto store_linear = [&](unsigned plane_byte_off, float x) {
+        asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tds_write_addtid_b32 %0" :: "v"(x), "s"(lds_base + plane_byte_off) : "m0", "memory");
+    };
+
+    // ---- per-lane slice of the plan, in registers for the whole launch ----
+    bool row_on[RR], var_on[VR];
+    unsigned taddr[RR][6], caddr[VR][D];
+#pragma unroll
+    for (int r = 0; r < RR; ++r) {
+        row_on[r] = P.row_check[r * 64 + lane] != 0xFFFFu;
+#pragma unroll
+        for (int t = 0; t < 6; ++t) taddr[r][t] = P.row_taddr[(r * 64 + lane) * 6 + t];
+    }
+#pragma unroll
+    for (int r = 0; r < VR; ++r) {
+        var_on[r] = P.var_id[r * 64 + lane] != 0xFFFFu;
+#pragma unroll
+        for (int q = 0; q < D; ++q) caddr[r][q] = P.var_caddr[(r * 64 + lane) * kTPlanDmax + q];
+    }
+    if (lane == 0) { ldsf(T_PAD) = kFltMax; ldsf(R_PAD) = -0.0f; }
+
+    // Work queue and prefetch as in ldpc_decode_kernel: kLdpcQueues interleaved queues; the next codeword is claimed and
+    // its LLRs are fetched (asynchronously, straight into the slot-indexed staging planes) while the current one decodes.
+    int queue = (int)(blockIdx.x % kLdpcQueues), dry = 0;
+    auto claim = [&]() -> int {
+        for (;;) {
+            int ticket = 0;
+            if (lane == 0) ticket = (int)atomicAdd(work_counter + queue * kLdpcQueueStride, 1u);
+            const int c = __builtin_amdgcn_readfirstlane(ticket) * kLdpcQueues + queue;
+            if (c < n_cw) return c;
+            if (++dry == kLdpcQueues) return -1;
+            queue = (queue + 1) % kLdpcQueues;
+        }
+    };
+    // channel LLR index of variable j: the production path's channel deinterleaver fused as a gather index
+    // (ChannelInterleaver::deinterleave, ldpc_decoder.cpp:609-617: out[j] = in[(j * step) % 648]; step 1 = identity)
+    auto src_index = [&](int j) -> unsigned { return (unsigned)(j * llr_step) % (unsigned)kLdpcN; };
+    auto fetch = [&](int c) {
+        const float* src = llr + (size_t)c * llr_stride;
+        float* stage_v = reinterpret_cast<float*>(lds_raw + STAGE_V);
+        float* stage_p = reinterpret_cast<float*>(lds_raw + STAGE_P);
+#pragma unroll
+        for (int r = 0; r < VR; ++r) {
+            const unsigned j = P.var_id[r * 64 + lane];
+            if (j != 0xFFFFu) __builtin_amdgcn_global_load_lds(src + src_index((int)j), stage_v + r * 64, 4, 0, 0);
+        }
+#pragma unroll
+        for (int r = 0; r < RR; ++r) {
+            const unsigned i = P.row_check[r * 64 + lane];
+            if (i != 0xFFFFu) __builtin_amdgcn_global_load_lds(src + src_index(k + (int)i), stage_p + r * 64, 4, 0, 0);
+        }
+    };
+
+    // Lanes without a row / variable in some round run the SAME instruction stream on harmless operands (their gather
+    // addresses point to the pad words, their lane-linear stores hit words nobody reads) instead of branching around
+    // it: every divergent `if` costs the scalar unit an exec save, a branch and a restore, and the scalar unit — one
+    // instruction per ~4 cycles per SIMD (profiles/r02_issue_table.txt) — is what this loop saturates first.  Only the
+    // parity verdict needs the row masks.
+    unsigned long long row_mask[RR];
+#pragma unroll
+    for (int r = 0; r < RR; ++r) row_mask[r] = __ballot(row_on[r]);
+    // This kernel owns the whole LDS allocation of its workgroup (dynamic only), so the array starts at LDS address 0
+    // and the add-TID stores can name their plane by an immediate offset behind M0 = 0.  Should a toolchain ever place
+    // it elsewhere, refuse to run rather than store to the wrong words.
+    if (lds_base != 0u) { if (blockIdx.x == 0 && lane == 0 && n_cw > 0) { iters[0] = -1; okv[0] = 0; } return; }
+
+    int cw = claim();
+    if (cw >= 0) fetch(cw);
+    while (cw >= 0) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // staged LLRs have landed
+        __syncthreads();
+        float llr_v[VR], llr_p[RR], c2v[RR][7];
+#pragma unroll
+        for (int r = 0; r < VR; ++r) {
+            llr_v[r] = ldsf(STAGE_V + (unsigned)(r * 64 + lane) * 4u);        // an empty slot reads a stale word: never used
+            store_linear((unsigned)(r * 256), llr_v[r]);                       // total before any iteration = llr_in
+        }
+#pragma unroll
+        for (int r = 0; r < RR; ++r) {
+            llr_p[r] = ldsf(STAGE_P + (unsigned)(r * 64 + lane) * 4u);
+#pragma unroll
+            for (int t = 0; t < 7; ++t) c2v[r][t] = 0.0f;                      // check_to_var starts at 0 (:175)
+        }
+        __syncthreads();
+        const int cw_next = claim();                                          // the staging planes are free from here on
+        if (cw_next >= 0) fetch(cw_next);
+
+        int it = 0, ok = 0;
+        float tpar[RR];                                                        // total of the row's parity bit (WANT_TOTAL)
+        for (;;) {
+            // ---- row phase: gather totals; parity equations of the previous iteration; check step ----
+            const float cap = (it == 0) ? kFltMax : 50.0f;                    // clamp deferred to the reader, see ldpc_kernel.h
+            // checkParity (:139-151) passes iff EVERY row's equation holds.  Round 0's rows are always evaluated; the
+            // other rounds only while no failing row has been seen — far from convergence the first round settles it.
+            bool all_hold = it > 0;                                            // wave-uniform
+            ldpc_static_for(std::make_integer_sequence<int, RR>{}, [&](auto round) {
+                constexpr int r = decltype(round)::value;
+                float v[7], mn[7], tot[6];
+                bool ng[7], par = false;
+                // total of the parity bit after the previous iteration: llr_in + c2v (:206-213; the bit has one edge)
+                const float tp = llr_p[r] + c2v[r][6];
+                if (WANT_TOTAL) tpar[r] = tp;
+#pragma unroll
+                for (int t = 0; t < 6; ++t) tot[t] = ldsf(taddr[r][t]);
+                if (all_hold) {                                                // uniform branch
+                    bool synd = tp < 0;
+#pragma unroll
+                    for (int t = 0; t < 6; ++t) synd ^= (tot[t] < 0);          // hard decisions of :227-230
+                    all_hold = (__ballot(synd) & row_mask[r]) == 0ull;
+                }
+#pragma unroll
+                for (int t = 0; t < 6; ++t) v[t] = tot[t] - c2v[r][t];         // var_to_check = llr_total - check_to_var (:216-219)
+                v[6] = tp - c2v[r][6];
+#pragma unroll
+                for (int t = 0; t < 7; ++t) { ng[t] = v[t] < 0; par ^= ng[t]; }
+                leave_one_out_min<7>(v, cap, mn);
+#pragma unroll
+                for (int t = 0; t < 7; ++t) {
+                    const float mag = mn[t] * 0.75f;
+                    c2v[r][t] = (par != ng[t]) ? -mag : mag;                   // sign * min * 0.75f (:201)
+                }
+                // six lane-linear stores, planes named by immediate offsets behind M0 = 0 (one SALU pair for all six)
+                asm volatile("s_mov_b32 m0, 0\n\ts_nop 0\n\t"
+                             "ds_write_addtid_b32 %0 offset:%6\n\tds_write_addtid_b32 %1 offset:%7\n\t"
+                             "ds_write_addtid_b32 %2 offset:%8\n\tds_write_addtid_b32 %3 offset:%9\n\t"
+                             "ds_write_addtid_b32 %4 offset:%10\n\tds_write_addtid_b32 %5 offset:%11"
+                             :: "v"(c2v[r][0]), "v"(c2v[r][1]), "v"(c2v[r][2]), "v"(c2v[r][3]), "v"(c2v[r][4]), "v"(c2v[r][5]),
+                                "n"(R_BASE + (r * 6 + 0) * 256), "n"(R_BASE + (r * 6 + 1) * 256), "n"(R_BASE + (r * 6 + 2) * 256),
+                                "n"(R_BASE + (r * 6 + 3) * 256), "n"(R_BASE + (r * 6 + 4) * 256), "n"(R_BASE + (r * 6 + 5) * 256)
+                             : "m0", "memory");
+            });
+            if (all_hold) { ok = 1; --it; break; }                             // checkParity passed after iteration it - 1
+            if (it >= max_iterations) break;
+            __syncthreads();
+            // ---- variable phase: total = llr_in + sum of the check messages in ascending check order (:206-213) ----
+            float tots[VR];
+            ldpc_static_for(std::make_integer_sequence<int, VR>{}, [&](auto round) {
+                constexpr int r = decltype(round)::value;
+                float c[D];
+#pragma unroll
+                for (int q = 0; q < D; ++q) c[q] = ldsf(caddr[r][q]);         // a missing edge reads the pad word: -0.0f
+                float tot = llr_v[r];
+#pragma unroll
+                for (int q = 0; q < D; ++q) tot += c[q];
+                tots[r] = tot;
+            });
+            {
+                static_assert(VR >= 4 && VR <= 7, "variable rounds of the covered codes");
+                // ONE asm statement (M0 must not change between its write and the stores): the phase's lane-linear stores
+                if constexpr (VR == 4)
+                    asm volatile("s_mov_b32 m0, 0\n\ts_nop 0\n\tds_write_addtid_b32 %0\n\tds_write_addtid_b32 %1 offset:256\n\t"
+                                 "ds_write_addtid_b32 %2 offset:512\n\tds_write_addtid_b32 %3 offset:768"
+                                 :: "v"(tots[0]), "v"(tots[1]), "v"(tots[2]), "v"(tots[3]) : "m0", "memory");
+                else if constexpr (VR == 5)
+                    asm volatile("s_mov_b32 m0, 0\n\ts_nop 0\n\tds_write_addtid_b32 %0\n\tds_write_addtid_b32 %1 offset:256\n\t"
+                                 "ds_write_addtid_b32 %2 offset:512\n\tds_write_addtid_b32 %3 offset:768\n\tds_write_addtid_b32 %4 offset:1024"
+                                 :: "v"(tots[0]), "v"(tots[1]), "v"(tots[2]), "v"(tots[3]), "v"(tots[VR > 4 ? 4 : 0]) : "m0", "memory");
+                else if constexpr (VR == 6)
+                    asm volatile("s_mov_b32 m0, 0\n\ts_nop 0\n\tds_write_addtid_b32 %0\n\tds_write_addtid_b32 %1 offset:256\n\t"
+                                 "ds_write_addtid_b32 %2 offset:512\n\tds_write_addtid_b32 %3 offset:768\n\tds_write_addtid_b32 %4 offset:1024\n\t"
+                                 "ds_write_addtid_b32 %5 offset:1280"
+                                 :: "v"(tots[0]), "v"(tots[1]), "v"(tots[2]), "v"(tots[3]), "v"(tots[VR > 4 ? 4 : 0]), "v"(tots[VR > 5 ? 5 : 0])
+                                 : "m0", "memory");
+                else
+                    asm volatile("s_mov_b32 m0, 0\n\ts_nop 0\n\tds_write_addtid_b32 %0\n\tds_write_addtid_b32 %1 offset:256\n\t"
+                                 "ds_write_addtid_b32 %2 offset:512\n\tds_write_addtid_b32 %3 offset:768\n\tds_write_addtid_b32 %4 offset:1024\n\t"
+                                 "ds_write_addtid_b32 %5 offset:1280\n\tds_write_addtid_b32 %6 offset:1536"
+                                 :: "v"(tots[0]), "v"(tots[1]), "v"(tots[2]), "v"(tots[3]), "v"(tots[VR > 4 ? 4 : 0]), "v"(tots[VR > 5 ? 5 : 0]),
+                                    "v"(tots[VR > 6 ? 6 : 0]) : "m0", "memory");
+            }
+            __syncthreads();
+            ++it;
+        }
+        const int iters_out = ok ? it : max_iterations;
+        __syncthreads();
+
+        // ---- outputs: hard decisions of the k information bits packed MSB-first (:238-258) ----
+        // Totals of the checked variables are in T (those of the last completed iteration — the row phase does not
+        // touch T); an unchecked variable's total is its channel LLR, read again from memory.
+        const float* src = llr + (size_t)cw * llr_stride;
+        uint8_t* ob = bytes + (size_t)cw * decoded_bytes;
+        for (int b = lane; b < decoded_bytes; b += kLdpcThreads) {
+            unsigned v = 0;
+#pragma unroll
+            for (int t = 0; t < 8; ++t) {
+                const int j = 8 * b + t;
+                unsigned bit = 0;
+                if (j < k) {
+                    const unsigned sl = P.var_slot_of[j];
+                    const float tot = (sl != 0xFFFFu) ? ldsf(sl * 4u) : src[src_index(j)];
+                    bit = (tot < 0) ? 1u : 0u;
+                }
+                v = (v << 1) | bit;
+            }
+            ob[b] = (uint8_t)v;
+        }
+        if (WANT_TOTAL) {
+            float* ot = llr_total + (size_t)cw * kLdpcN;
+            for (int j = lane; j < k; j += kLdpcThreads) {
+                const unsigned sl = P.var_slot_of[j];
+                ot[j] = (sl != 0xFFFFu) ? ldsf(sl * 4u) : src[src_index(j)];
+            }
+#pragma unroll
+            for (int r = 0; r < RR; ++r) {
+                const unsigned i = P.row_check[r * 64 + lane];
+                // no iteration ran (max_iterations == 0): the totals are the channel values themselves
+                if (i != 0xFFFFu) ot[k + (int)i] = (max_iterations > 0) ? tpar[r] : llr_p[r];
+            }
+        }
+        if (lane == 0) { iters[cw] = iters_out; okv[cw] = (uint8_t)ok; }
+        __syncthreads();                                                       // T is rewritten by the next codeword
+        cw = cw_next;
+    }
+}
+
+}  // namespace dev
+}  // namespace ultra_hip
+#endif

@@ -10,6 +10,7 @@
 #include <dlfcn.h>
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <new>
 #include <vector>
@@ -19,6 +20,7 @@
 #include "host_tables.h"
 #include "demod_kernel.h"
 #include "ldpc_kernel.h"
+#include "ldpc_totals_kernel.h"
 #include "acquire_kernel.h"
 #include "stimulus_kernel.h"
 #include "chirp_kernel.h"
@@ -36,6 +38,8 @@ struct ultra_hip_ctx {
     DemodConst* d_demod = nullptr;
     LdpcPlan h_plan{};
     LdpcPlan* d_plan = nullptr;
+    LdpcTPlan h_tplan{};                 // totals kernel (R2/3, R3/4, R5/6): valid = 0 -> the message kernel decodes
+    LdpcTPlan* d_tplan = nullptr;
     unsigned int* d_work = nullptr;      // work-queue heads of the LDPC kernel (one per launch slot)
     int work_slot = 0;
     c32* d_nco = nullptr;
@@ -220,9 +224,41 @@ int launch_ldpc(ultra_hip_ctx* ctx, const float* d_llr, size_t llr_stride, size_
     // persistent workgroups (one wavefront each) pull codewords from an atomic counter; every
     // launch uses its own counter word, zeroed on the stream just before the launch
     const LdpcPlan& P = ctx->h_plan;
-    const size_t lds = dev::ldpc_lds_bytes(P.msg_words);
     unsigned int* counter = ctx->d_work + (size_t)(ctx->work_slot++ & 15) * dev::kLdpcQueueWords;
     UH_HIP(hipMemsetAsync(counter, 0, dev::kLdpcQueueWords * sizeof(unsigned int), ctx->stream));
+    // The totals formulation (ldpc_totals_kernel.h: one total per variable through LDS, the row subtracts its own
+    // message) where the code has a placement; same results bit for bit, two thirds of the LDS cycles.
+    if (ctx->h_tplan.valid) {
+        const LdpcTPlan& T = ctx->h_tplan;
+        const size_t tlds = (size_t)T.lds_bytes;
+        // the kernel derives its LDS offsets from its template arguments with the builder's formulas
+        if (T.t_pad != T.var_rounds * 256 || T.r_base != T.t_pad + 16 || T.r_pad != T.r_base + T.row_rounds * 6 * 256 ||
+            T.stage_v != T.r_pad + 16 || T.stage_p != T.stage_v + T.var_rounds * 256 || T.lds_bytes != T.stage_p + T.row_rounds * 256)
+            return ULTRA_HIP_ERR_UNSUPPORTED;
+#define UH_TOTALS_LAUNCH(RR, VR, D, WV)                                                                           \
+    do {                                                                                                          \
+        LaunchSpan span(ctx, ULTRA_HIP_K_LDPC);                                                                   \
+        const size_t per_cu = std::max<size_t>(1, std::min<size_t>(4 * (WV), (size_t)(160 * 1024) / tlds));       \
+        const unsigned grid = (unsigned)std::min(n_cw, (size_t)ctx->cu_count * per_cu);                           \
+        if (d_llr_total)                                                                                          \
+            hipLaunchKernelGGL((dev::ldpc_totals_kernel<RR, VR, D, true, WV>), dim3(grid), dim3(dev::kLdpcThreads), tlds, \
+                               ctx->stream, ctx->d_tplan, d_llr, llr_stride, (int)n_cw, d_bytes, d_iters, d_ok,   \
+                               d_llr_total, counter, (int)ctx->deint_step);                                       \
+        else                                                                                                      \
+            hipLaunchKernelGGL((dev::ldpc_totals_kernel<RR, VR, D, false, WV>), dim3(grid), dim3(dev::kLdpcThreads), tlds, \
+                               ctx->stream, ctx->d_tplan, d_llr, llr_stride, (int)n_cw, d_bytes, d_iters, d_ok,   \
+                               d_llr_total, counter, (int)ctx->deint_step);                                       \
+    } while (0)
+        bool launched = true;
+        if (T.row_rounds == 3 && T.var_rounds == 6 && T.dmax == 3) UH_TOTALS_LAUNCH(3, 6, 3, 5);                  // R3/4
+        else if (T.row_rounds == 2 && T.var_rounds == 4 && T.dmax == 3) UH_TOTALS_LAUNCH(2, 4, 3, 6);             // R5/6
+        else if (T.row_rounds == 4 && T.var_rounds == 7 && T.dmax == 3) UH_TOTALS_LAUNCH(4, 7, 3, 4);             // R2/3
+        else if (T.row_rounds == 4 && T.var_rounds == 7 && T.dmax == 4) UH_TOTALS_LAUNCH(4, 7, 4, 4);
+        else launched = false;
+#undef UH_TOTALS_LAUNCH
+        if (launched) { UH_HIP(hipGetLastError()); return ULTRA_HIP_OK; }
+    }
+    const size_t lds = dev::ldpc_lds_bytes(P.msg_words);
     // WV = wavefronts per SIMD the instance's registers are budgeted for; the grid is one resident set
     // (bounded by LDS: one codeword's messages + staging per workgroup)
 #define UH_LDPC_LAUNCH(RR, VR, RMAX, RMIN, VMAX, VMIN, RID, LIN, WV)                                                 \
@@ -405,6 +441,10 @@ int ultra_hip_create(const ultra_hip_config* cfg, int device, void* stream, ultr
     if (ctx->h_ldpc.edges > kLdpcMaxEdges || ctx->h_ldpc.m > kLdpcMaxChecks) { delete ctx; return ULTRA_HIP_ERR_UNSUPPORTED; }
     rc = build_ldpc_plan(ctx->h_ldpc, ctx->h_plan);
     if (rc != ULTRA_HIP_OK) { delete ctx; return rc; }
+    // ULTRA_HIP_LDPC_MESSAGES=1 keeps the message-passing kernel for every rate (A/B measurements, parity tests of both)
+    const char* force_messages = std::getenv("ULTRA_HIP_LDPC_MESSAGES");
+    if (!(force_messages && force_messages[0] == '1')) (void)build_ldpc_tplan(ctx->h_ldpc, cfg->code_rate, ctx->h_tplan);
+    ctx->h_tplan.max_iterations = ctx->h_ldpc.max_iterations;
 
     DeviceGuard guard(device);
     if (!guard.ok) { delete ctx; return ULTRA_HIP_ERR_NO_DEVICE; }
@@ -415,11 +455,13 @@ int ultra_hip_create(const ultra_hip_config* cfg, int device, void* stream, ultr
     auto fail = [&](int code) { ultra_hip_destroy(ctx); return code; };
     if (hipMalloc(&ctx->d_demod, sizeof(DemodConst)) != hipSuccess) return fail(ULTRA_HIP_ERR_OOM);
     if (hipMalloc(&ctx->d_plan, sizeof(LdpcPlan)) != hipSuccess) return fail(ULTRA_HIP_ERR_OOM);
+    if (hipMalloc(&ctx->d_tplan, sizeof(LdpcTPlan)) != hipSuccess) return fail(ULTRA_HIP_ERR_OOM);
     if (hipMalloc(&ctx->d_work, 16 * dev::kLdpcQueueWords * sizeof(unsigned int)) != hipSuccess) return fail(ULTRA_HIP_ERR_OOM);
     if (hipMalloc(&ctx->d_nco, nco.size() * sizeof(c32)) != hipSuccess) return fail(ULTRA_HIP_ERR_OOM);
     if (hipMalloc(&ctx->d_twiddle, tw.size() * sizeof(c32)) != hipSuccess) return fail(ULTRA_HIP_ERR_OOM);
     if (hipMemcpy(ctx->d_demod, &ctx->h_demod, sizeof(DemodConst), hipMemcpyHostToDevice) != hipSuccess ||
         hipMemcpy(ctx->d_plan, &ctx->h_plan, sizeof(LdpcPlan), hipMemcpyHostToDevice) != hipSuccess ||
+        hipMemcpy(ctx->d_tplan, &ctx->h_tplan, sizeof(LdpcTPlan), hipMemcpyHostToDevice) != hipSuccess ||
         hipMemcpy(ctx->d_nco, nco.data(), nco.size() * sizeof(c32), hipMemcpyHostToDevice) != hipSuccess ||
         hipMemcpy(ctx->d_twiddle, tw.data(), tw.size() * sizeof(c32), hipMemcpyHostToDevice) != hipSuccess)
         return fail(ULTRA_HIP_ERR_HIP);
@@ -443,6 +485,7 @@ void ultra_hip_destroy(ultra_hip_ctx* ctx) {
     DeviceGuard guard(ctx->device);
     if (ctx->d_demod) (void)hipFree(ctx->d_demod);
     if (ctx->d_plan) (void)hipFree(ctx->d_plan);
+    if (ctx->d_tplan) (void)hipFree(ctx->d_tplan);
     if (ctx->d_work) (void)hipFree(ctx->d_work);
     for (auto& sp : ctx->spans) { (void)hipEventDestroy(sp.e0); (void)hipEventDestroy(sp.e1); }
     for (auto e : ctx->spare_events) (void)hipEventDestroy(e);
