@@ -100,9 +100,9 @@ struct LdpcPlan {
 // lives in the lane-linear LDS array T[round][lane]; the check-to-variable messages live in the lane-linear array
 // R[round][slot][lane]; each side gathers from the other's array.  LDS byte offsets (from the dynamic LDS base):
 //   T words      [0, var_rounds * 256)                     word (round * 64 + lane) = the variable in that slot
-//   T pad word   at t_pad: +FLT_MAX (the phantom operand of a row with fewer than six information edges)
+//   T pad words  32 at t_pad (one per bank): +FLT_MAX (the phantom operand of a row with fewer than six information edges)
 //   R words      [r_base, r_base + row_rounds * 6 * 256)   word ((round * 6 + t) * 64 + lane) = edge slot t of the row
-//   R pad word   at r_pad: -0.0f (the neutral addend of a variable with fewer than dmax edges)
+//   R pad words  32 at r_pad (one per bank): -0.0f (the neutral addend of a variable with fewer than dmax edges)
 //   staging      stage_v [var_rounds][64], stage_p [row_rounds][64]: channel LLRs of the NEXT codeword, slot-indexed
 constexpr int kTPlanRowRounds = 4, kTPlanVarRounds = 7, kTPlanDmax = 4;
 struct LdpcTPlan {

@@ -422,7 +422,8 @@ inline int build_ldpc_tplan(const LdpcConst& L, uint32_t rate, LdpcTPlan& P) {
     for (int j = L.k; j < L.n; ++j) if (L.var_ptr[j + 1] - L.var_ptr[j] != 1) return ULTRA_HIP_ERR_UNSUPPORTED;
     P.k = L.k; P.m = L.m; P.n = L.n; P.max_iterations = L.max_iterations; P.decoded_bytes = L.decoded_bytes;
     P.row_rounds = RR; P.var_rounds = VR; P.dmax = dmax;
-    P.t_pad = VR * 256; P.r_base = P.t_pad + 16; P.r_pad = P.r_base + RR * 6 * 256; P.stage_v = P.r_pad + 16;
+    // pads: 32 words each (one per bank), so that a pad read can sit in a bank the instruction's real reads leave free
+    P.t_pad = VR * 256; P.r_base = P.t_pad + 128; P.r_pad = P.r_base + RR * 6 * 256; P.stage_v = P.r_pad + 128;
     P.stage_p = P.stage_v + VR * 256; P.lds_bytes = P.stage_p + RR * 256;
     for (auto& x : P.row_check) x = 0xFFFF;
     for (auto& x : P.var_id) x = 0xFFFF;
@@ -470,6 +471,35 @@ inline int build_ldpc_tplan(const LdpcConst& L, uint32_t rate, LdpcTPlan& P) {
             layer[((vsl / 32) * dmax + q) * 32 + rsl % 32]++;
         }
     for (int hq = 0; hq < 2 * VR * dmax; ++hq) { int mx = 1; for (int u = 0; u < 32; ++u) mx = std::max(mx, layer[hq * 32 + u]); P.extra_cycles += mx - 1; }
+    // Every lane runs every gather (ldpc_totals_kernel.h has no divergent branches), so the operands of lanes without a
+    // row / variable, and of missing edges, must not cost LDS cycles either: an idle lane repeats the address of an
+    // active lane of its half-wave (identical addresses broadcast), a missing edge reads the pad word of a bank the
+    // half-wave's real reads leave free.
+    auto fix_half = [&](uint16_t* addr, int n_lanes_base, int stride, int pad_base, auto is_active, auto is_real) {
+        bool used[32] = {false};
+        int donor = -1;
+        for (int l = 0; l < 32; ++l) {
+            const int lane = n_lanes_base + l;
+            if (is_active(lane) && is_real(lane)) { used[(addr[lane * stride] / 4) % 32] = true; if (donor < 0) donor = lane; }
+        }
+        for (int l = 0; l < 32; ++l) {
+            const int lane = n_lanes_base + l;
+            if (is_active(lane) && is_real(lane)) continue;
+            if (!is_active(lane) && donor >= 0) { addr[lane * stride] = addr[donor * stride]; continue; }
+            int b = 0; while (b < 32 && used[b]) ++b;          // a pad read: free bank (or bank 0 if the half is full)
+            if (b == 32) b = 0;
+            used[b] = true;
+            addr[lane * stride] = (uint16_t)(pad_base + 4 * b);
+        }
+    };
+    for (int g = 0; g < 2 * RR; ++g)
+        for (int t = 0; t < 6; ++t)
+            fix_half(P.row_taddr + t, g * 32, 6, P.t_pad, [&](int lane) { return P.row_check[lane] != 0xFFFF; },
+                     [&](int lane) { return P.row_taddr[lane * 6 + t] < P.t_pad; });
+    for (int h = 0; h < 2 * VR; ++h)
+        for (int q = 0; q < dmax; ++q)
+            fix_half(P.var_caddr + q, h * 32, kTPlanDmax, P.r_pad, [&](int lane) { return P.var_id[lane] != 0xFFFF; },
+                     [&](int lane) { return P.var_caddr[lane * kTPlanDmax + q] < P.r_pad; });
     P.valid = 1;
     return ULTRA_HIP_OK;
 }

@@ -42,7 +42,7 @@ __global__ __launch_bounds__(kLdpcThreads, WAVES) void ldpc_totals_kernel(
     // The LDS layout is a function of the instance (build_ldpc_tplan uses the same formulas and ultra_hip.hip checks
     // them): compile-time offsets, and the plan's scalars in locals — the "memory" clobber of the store asm would
     // otherwise make the compiler reload them from the plan inside the iteration loop.
-    constexpr unsigned T_PAD = VR * 256, R_BASE = T_PAD + 16, R_PAD = R_BASE + RR * 6 * 256, STAGE_V = R_PAD + 16,
+    constexpr unsigned T_PAD = VR * 256, R_BASE = T_PAD + 128, R_PAD = R_BASE + RR * 6 * 256, STAGE_V = R_PAD + 128,
                        STAGE_P = STAGE_V + VR * 256;
     const int k = P.k, max_iterations = P.max_iterations, decoded_bytes = P.decoded_bytes;
     auto ldsf = [&](unsigned byte_off) -> float& { return *reinterpret_cast<float*>(lds_raw + byte_off); };
@@ -67,7 +67,7 @@ __global__ __launch_bounds__(kLdpcThreads, WAVES) void ldpc_totals_kernel(
 #pragma unroll
         for (int q = 0; q < D; ++q) caddr[r][q] = P.var_caddr[(r * 64 + lane) * kTPlanDmax + q];
     }
-    if (lane == 0) { ldsf(T_PAD) = kFltMax; ldsf(R_PAD) = -0.0f; }
+    if (lane < 32) { ldsf(T_PAD + 4u * lane) = kFltMax; ldsf(R_PAD + 4u * lane) = -0.0f; }      // one pad word per bank
 
     // Work queue and prefetch as in ldpc_decode_kernel: kLdpcQueues interleaved queues; the next codeword is claimed and
     // its LLRs are fetched (asynchronously, straight into the slot-indexed staging planes) while the current one decodes.

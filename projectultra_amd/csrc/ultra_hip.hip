@@ -232,8 +232,8 @@ int launch_ldpc(ultra_hip_ctx* ctx, const float* d_llr, size_t llr_stride, size_
         const LdpcTPlan& T = ctx->h_tplan;
         const size_t tlds = (size_t)T.lds_bytes;
         // the kernel derives its LDS offsets from its template arguments with the builder's formulas
-        if (T.t_pad != T.var_rounds * 256 || T.r_base != T.t_pad + 16 || T.r_pad != T.r_base + T.row_rounds * 6 * 256 ||
-            T.stage_v != T.r_pad + 16 || T.stage_p != T.stage_v + T.var_rounds * 256 || T.lds_bytes != T.stage_p + T.row_rounds * 256)
+        if (T.t_pad != T.var_rounds * 256 || T.r_base != T.t_pad + 128 || T.r_pad != T.r_base + T.row_rounds * 6 * 256 ||
+            T.stage_v != T.r_pad + 128 || T.stage_p != T.stage_v + T.var_rounds * 256 || T.lds_bytes != T.stage_p + T.row_rounds * 256)
             return ULTRA_HIP_ERR_UNSUPPORTED;
 #define UH_TOTALS_LAUNCH(RR, VR, D, WV)                                                                           \
     do {                                                                                                          \

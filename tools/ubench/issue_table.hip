@@ -17,7 +17,8 @@
 enum Kind {
     K_ADD_F32, K_MUL_F32, K_FMA_F32, K_MIN3_ABS, K_MIN2_ABS, K_CMP_SGPR, K_CNDMASK_NEG, K_CMP_CNDMASK, K_MOV, K_ADD_U32,
     K_XOR, K_PK_ADD, K_PK_MUL, K_FMA_F64, K_MUL_F64, K_ADD_F64, K_CVT_F64_F32, K_CVT_F32_F64, K_RCP_F32, K_XOR_DPP,
-    K_READLANE, K_SALU_XOR64, K_MIX_LDPC_ROW,
+    K_READLANE, K_SALU_XOR64, K_MIX_LDPC_ROW, K_BFI, K_AND_OR, K_MIN3_PLAIN, K_MIN2_E32, K_AND, K_CMP_GT_I32, K_CMP_VCC, K_CNDMASK_VCC,
+    K_SDWA_ADD, K_LSHL_OR, K_SUB_F32,
     K_DS_READ_B32, K_DS_READ_B64, K_DS_READ2_B32, K_DS_READ_B128, K_DS_WRITE_B32, K_DS_WRITE_ADDTID, K_DS_WRITE_B64,
     K_DS_MIX_LDPC, K_N
 };
@@ -25,10 +26,13 @@ static const char* kNames[K_N] = {
     "v_add_f32", "v_mul_f32", "v_fma_f32", "v_min3_f32 |x|,|y|,|z|", "v_min_f32_e64 |x|,|y|", "v_cmp_lt_f32 -> sgpr pair",
     "v_cndmask_b32 x,-x,sgpr", "v_cmp + v_cndmask (pair)", "v_mov_b32", "v_add_u32", "v_xor_b32", "v_pk_add_f32", "v_pk_mul_f32",
     "v_fma_f64", "v_mul_f64", "v_add_f64", "v_cvt_f64_f32", "v_cvt_f32_f64", "v_rcp_f32", "v_xor_b32 dpp quad_perm",
-    "v_readlane_b32", "s_xor_b64", "ldpc row mix (7cmp 12min 7mul 7cnd)",
+    "v_readlane_b32", "s_xor_b64", "ldpc row mix (7cmp 12min 7mul 7cnd)", "v_bfi_b32", "v_and_or_b32", "v_min3_f32 (no modifiers)",
+    "v_min_f32_e32", "v_and_b32", "v_cmp_gt_i32 -> sgpr pair", "v_cmp_lt_f32 -> vcc (e32)", "v_cndmask_b32 (vcc, e32)",
+    "v_add_u32_sdwa WORD_1", "v_lshl_or_b32", "v_sub_f32",
     "ds_read_b32", "ds_read_b64", "ds_read2_b32", "ds_read_b128", "ds_write_b32", "ds_write_addtid_b32", "ds_write_b64",
     "ldpc lds mix (2 rd,1 wr,1 addtid)"};
-static const int kInstrPerBlock[K_N] = {8, 8, 8, 8, 8, 8, 8, 8, 8, 8, 8, 8, 8, 8, 8, 8, 8, 8, 8, 8, 8, 8, 33, 8, 8, 8, 8, 8, 8, 8, 8};
+static const int kInstrPerBlock[K_N] = {8, 8, 8, 8, 8, 8, 8, 8, 8, 8, 8, 8, 8, 8, 8, 8, 8, 8, 8, 8, 8, 8, 33, 8, 8, 8, 8, 8, 8, 8, 8, 8, 8, 8,
+                                        8, 8, 8, 8, 8, 8, 8, 8};
 
 template <int KIND>
 __global__ __launch_bounds__(64) void k(unsigned long long* cyc, float* sink, int iters, unsigned* arrive) {
@@ -183,7 +187,58 @@ __global__ __launch_bounds__(64) void k(unsigned long long* cyc, float* sink, in
                       "=&v"(l6), "=&v"(r4), "=&v"(r3), "=&v"(r2), "=&v"(n0), "=&v"(n1), "=&v"(n2), "=&v"(n3), "=&v"(n4), "=&v"(n5),
                       "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6)
                     : "v"(a7) : "scc");
-            } else if constexpr (KIND == K_DS_READ_B32) {
+            } else if constexpr (KIND == K_BFI)
+                asm volatile("v_bfi_b32 %0, %4, %0, %1\n v_bfi_b32 %1, %4, %1, %2\n v_bfi_b32 %2, %4, %2, %3\n v_bfi_b32 %3, %4, %3, %0\n"
+                             "v_bfi_b32 %0, %4, %0, %2\n v_bfi_b32 %1, %4, %1, %3\n v_bfi_b32 %2, %4, %2, %0\n v_bfi_b32 %3, %4, %3, %1"
+                             : "+v"(u0), "+v"(u1), "+v"(u2), "+v"(u3) : "v"(0x7fffffffu));
+            else if constexpr (KIND == K_AND_OR)
+                asm volatile("v_and_or_b32 %0, %0, %4, %1\n v_and_or_b32 %1, %1, %4, %2\n v_and_or_b32 %2, %2, %4, %3\n v_and_or_b32 %3, %3, %4, %0\n"
+                             "v_and_or_b32 %0, %0, %4, %2\n v_and_or_b32 %1, %1, %4, %3\n v_and_or_b32 %2, %2, %4, %0\n v_and_or_b32 %3, %3, %4, %1"
+                             : "+v"(u0), "+v"(u1), "+v"(u2), "+v"(u3) : "v"(0x80000000u));
+            else if constexpr (KIND == K_MIN3_PLAIN)
+                asm volatile("v_min3_f32 %0, %0, %1, %2\n v_min3_f32 %1, %1, %2, %3\n v_min3_f32 %2, %2, %3, %4\n"
+                             "v_min3_f32 %3, %3, %4, %5\n v_min3_f32 %4, %4, %5, %6\n v_min3_f32 %5, %5, %6, %7\n"
+                             "v_min3_f32 %6, %6, %7, %0\n v_min3_f32 %7, %7, %0, %1"
+                             : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7));
+            else if constexpr (KIND == K_MIN2_E32)
+                asm volatile("v_min_f32_e32 %0, %0, %1\n v_min_f32_e32 %1, %1, %2\n v_min_f32_e32 %2, %2, %3\n v_min_f32_e32 %3, %3, %4\n"
+                             "v_min_f32_e32 %4, %4, %5\n v_min_f32_e32 %5, %5, %6\n v_min_f32_e32 %6, %6, %7\n v_min_f32_e32 %7, %7, %0"
+                             : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7));
+            else if constexpr (KIND == K_AND)
+                asm volatile("v_and_b32 %0, %0, %1\n v_and_b32 %1, %1, %2\n v_and_b32 %2, %2, %3\n v_and_b32 %3, %3, %0\n"
+                             "v_and_b32 %0, %0, %2\n v_and_b32 %1, %1, %3\n v_and_b32 %2, %2, %0\n v_and_b32 %3, %3, %1"
+                             : "+v"(u0), "+v"(u1), "+v"(u2), "+v"(u3));
+            else if constexpr (KIND == K_CMP_GT_I32)
+                asm volatile("v_cmp_gt_i32_e64 %0, 0, %2\n v_cmp_gt_i32_e64 %1, 0, %3\n v_cmp_gt_i32_e64 %0, 0, %4\n v_cmp_gt_i32_e64 %1, 0, %5\n"
+                             "v_cmp_gt_i32_e64 %0, 0, %2\n v_cmp_gt_i32_e64 %1, 0, %3\n v_cmp_gt_i32_e64 %0, 0, %4\n v_cmp_gt_i32_e64 %1, 0, %5"
+                             : "+s"(s0), "+s"(s1) : "v"(u0), "v"(u1), "v"(u2), "v"(u3));
+            else if constexpr (KIND == K_CMP_VCC)
+                asm volatile("v_cmp_lt_f32 vcc, %0, %1\n v_cmp_lt_f32 vcc, %1, %2\n v_cmp_lt_f32 vcc, %2, %3\n v_cmp_lt_f32 vcc, %3, %0\n"
+                             "v_cmp_lt_f32 vcc, %0, %2\n v_cmp_lt_f32 vcc, %1, %3\n v_cmp_lt_f32 vcc, %2, %0\n v_cmp_lt_f32 vcc, %3, %1"
+                             :: "v"(a0), "v"(a1), "v"(a2), "v"(a3) : "vcc");
+            else if constexpr (KIND == K_CNDMASK_VCC)
+                asm volatile("v_cndmask_b32 %0, %0, %1, vcc\n v_cndmask_b32 %1, %1, %2, vcc\n v_cndmask_b32 %2, %2, %3, vcc\n v_cndmask_b32 %3, %3, %0, vcc\n"
+                             "v_cndmask_b32 %0, %0, %2, vcc\n v_cndmask_b32 %1, %1, %3, vcc\n v_cndmask_b32 %2, %2, %0, vcc\n v_cndmask_b32 %3, %3, %1, vcc"
+                             : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3) : : "vcc");
+            else if constexpr (KIND == K_SDWA_ADD)
+                asm volatile("v_add_u32_sdwa %0, %0, %1 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:WORD_1\n"
+                             "v_add_u32_sdwa %1, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:WORD_1\n"
+                             "v_add_u32_sdwa %2, %2, %3 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:WORD_1\n"
+                             "v_add_u32_sdwa %3, %3, %0 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:WORD_1\n"
+                             "v_add_u32_sdwa %0, %0, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:WORD_1\n"
+                             "v_add_u32_sdwa %1, %1, %3 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:WORD_1\n"
+                             "v_add_u32_sdwa %2, %2, %0 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:WORD_1\n"
+                             "v_add_u32_sdwa %3, %3, %1 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:WORD_1"
+                             : "+v"(u0), "+v"(u1), "+v"(u2), "+v"(u3));
+            else if constexpr (KIND == K_LSHL_OR)
+                asm volatile("v_lshl_or_b32 %0, %0, 1, %1\n v_lshl_or_b32 %1, %1, 1, %2\n v_lshl_or_b32 %2, %2, 1, %3\n v_lshl_or_b32 %3, %3, 1, %0\n"
+                             "v_lshl_or_b32 %0, %0, 1, %2\n v_lshl_or_b32 %1, %1, 1, %3\n v_lshl_or_b32 %2, %2, 1, %0\n v_lshl_or_b32 %3, %3, 1, %1"
+                             : "+v"(u0), "+v"(u1), "+v"(u2), "+v"(u3));
+            else if constexpr (KIND == K_SUB_F32)
+                asm volatile("v_sub_f32 %0, %0, %8\n v_sub_f32 %1, %1, %8\n v_sub_f32 %2, %2, %8\n v_sub_f32 %3, %3, %8\n"
+                             "v_sub_f32 %4, %4, %8\n v_sub_f32 %5, %5, %8\n v_sub_f32 %6, %6, %8\n v_sub_f32 %7, %7, %8"
+                             : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7) : "v"(b0));
+            else if constexpr (KIND == K_DS_READ_B32) {
                 float q0, q1, q2, q3, q4, q5, q6, q7;
                 asm volatile("ds_read_b32 %0, %8\n ds_read_b32 %1, %8 offset:256\n ds_read_b32 %2, %8 offset:512\n ds_read_b32 %3, %8 offset:768\n"
                              "ds_read_b32 %4, %8 offset:1024\n ds_read_b32 %5, %8 offset:1280\n ds_read_b32 %6, %8 offset:1536\n ds_read_b32 %7, %8 offset:1792\n"
@@ -272,7 +327,7 @@ void run(int cus) {
         // percentile is used so that one straggling CU cannot set it) over the instructions of all W wavefronts.
         const double med = (double)h[(size_t)grid * 99 / 100];
         g_p50[KIND][g_col % 6] = (double)h[grid / 2] / ((double)iters * 16 * kInstrPerBlock[KIND] * ((KIND >= K_DS_READ_B32) ? 4 * w : w));
-        g_clock_sum += med / ((double)rt[grid / 2] * 10e-9) * 1e-9; g_clock_n += 1;   // shader GHz while this ran
+        g_clock_sum += (double)h[grid / 2] / ((double)rt[grid / 2] * 10e-9) * 1e-9; g_clock_n += 1;   // shader GHz while this ran (median lifetime in both clocks)
         const double n = (double)iters * 16 * kInstrPerBlock[KIND];
         // VALU/SALU: cycles of the SIMD per wave-instruction; LDS: cycles of the CU's LDS pipeline per wave-instruction
         const double per = med / (n * (is_lds ? 4 * w : w));
