@@ -187,7 +187,11 @@ int ultra_hip_ldpc_decode_batch(ultra_hip_ctx* ctx, const float* d_llr, size_t n
  * samples starting at the configured entry point.
  *   d_audio    [n_frames] rows of `frame_stride` floats (>= frame_samples)
  *   d_cfo_hz   [n_frames] f32 or NULL (=0): initial freq_offset_hz
- *              (OFDMDemodulator::setFrequencyOffset / coarse CFO from sync)
+ *              (OFDMDemodulator::setFrequencyOffset / coarse CFO from sync).  ULTRA_ENTRY_PRESYNCED: a NaN entry
+ *              means "the frequency offset was never set on this demodulator" — processPresynced then takes it
+ *              from the two training symbols (Impl::estimateCFOFromTraining, src/ofdm/ofdm_sync.cpp:278-380,
+ *              demodulator.cpp:920-925) and starts the correction phase at 0; NULL or a number is a preset,
+ *              trusted offset (:918-919)
  *   d_cfo_phase[n_frames] f32 or NULL (=0): initial freq_correction_phase
  *              (OFDMDemodulator::setFrequencyOffsetWithPhase)
  *   d_llr      [n_frames][llrs_per_frame] f32: soft bits in the order
@@ -403,6 +407,13 @@ int ultra_hip_make_llr_batch(ultra_hip_ctx* ctx, uint64_t seed, uint64_t first_c
  * The legacy Modem's Interleaver(32,32) (src/modem/modem.cpp:116,161) reads past the 648 soft
  * bits it is given and is not reproduced. */
 int ultra_hip_set_deinterleave(ultra_hip_ctx* ctx, uint32_t bits_per_symbol);
+
+/* The same fusion for ANY permutation of the 648 soft bits of a codeword: out[j] = in[h_index[j]], n = 648, every
+ * entry < 648 (validated: the kernel gathers through the table).  Covers the reference's row-column Interleaver
+ * (src/fec/ldpc_decoder.cpp:454-466; deinterleave(soft) :530-540 is out[i] = in[permutation_[i]], permutation_[i] =
+ * (i % cols) * rows + i / cols — e.g. Interleaver(6, 108) of tools/test_throughput.cpp:78-134 and any other 648-entry
+ * layout).  Takes precedence over ultra_hip_set_deinterleave; h_index = NULL or n = 0 switches the table off. */
+int ultra_hip_set_deinterleave_table(ultra_hip_ctx* ctx, const uint16_t* h_index, uint32_t n);
 
 /* Per-kernel timing (diagnostics; bench.py's roofline object uses it): while enabled, every kernel
  * launch of this context is bracketed by a pair of HIP events on the context's stream.  read()

@@ -308,13 +308,17 @@ class _Base:
         return llr, d
 
     def demod_presynced(self, cfg, audio, cfo_hz=0.0, cfo_phase=0.0):
+        """processPresynced after setFrequencyOffsetWithPhase(cfo_hz, cfo_phase); cfo_hz = None: the offset was never
+        set (training-symbol estimate, ofdm_sync.cpp:278-380)."""
         audio = _f32(audio)
+        has_cfo = cfo_hz is not None
+        cfo_hz = cfo_hz if has_cfo else 0.0
         g = geometry(cfg)
         cap = g.llrs_per_frame + 4096
         llr = np.zeros(cap, np.float32)
         H = np.zeros(cfg.fft_size, np.complex64)
         scal = np.zeros(8, np.float32)
-        n = self._fn("demod_presynced")(C.byref(cfg), _ptr(audio), C.c_uint32(audio.size), C.c_int(1),
+        n = self._fn("demod_presynced")(C.byref(cfg), _ptr(audio), C.c_uint32(audio.size), C.c_int(1 if has_cfo else 0),
                                         C.c_float(cfo_hz), C.c_float(cfo_phase), _ptr(llr), C.c_uint32(cap),
                                         _ptr(H.view(np.float32)), _ptr(scal))
         assert n >= 0

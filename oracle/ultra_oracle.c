@@ -1216,12 +1216,54 @@ int uo_demod_synced(const ultra_hip_config* c, const float* audio, uint32_t n_sy
     return n;
 }
 
-/* OFDMDemodulator::processPresynced after setFrequencyOffsetWithPhase,
- * src/ofdm/demodulator.cpp:816-825,854-985 (chirp-CFO-trusted branch) */
+/* OFDMDemodulator::Impl::estimateCFOFromTraining(samples, num_symbols, coarse_cfo_hz = 0), src/ofdm/ofdm_sync.cpp:278-380:
+ * the first two training symbols mixed to baseband by a FRESH NCO(center_freq), correlated FFT part against FFT part;
+ * CFO = arg(P) fs / (2 pi sym_len), 0 when the normalised correlation is below 0.3, clamped to +-fs / (2 sym_len). */
+static float estimate_cfo_from_training(const demod* d, const float* samples, size_t num_symbols) {
+    if (num_symbols < 2) return 0.0f;
+    const ultra_hip_config* c = &d->cfg;
+    const size_t fft_len = c->fft_size, cp_len = d->cp, sym_len = d->symbol_samples, total = 2 * sym_len;
+    nco mix;
+    nco_init(&mix, (float)c->center_freq, (float)c->sample_rate);
+    cf* bb = (cf*)malloc(sizeof(cf) * total);
+    for (size_t i = 0; i < total; ++i) {
+        cf osc = nco_next(&mix);
+        bb[i] = c_make(samples[i] * osc.re, samples[i] * -osc.im);        /* float * conj(osc); coarse_cfo = 0: no rotation */
+    }
+    cf P = c_make(0.0f, 0.0f);
+    float E1 = 0.0f, E2 = 0.0f;
+    const size_t s1 = cp_len, s2 = sym_len + cp_len;
+    for (size_t i = 0; i < fft_len; ++i) {
+        if (s1 + i < total && s2 + i < total) {
+            cf z1 = bb[s1 + i], z2 = bb[s2 + i];
+            P = c_add(P, c_mul(c_conj(z1), z2));
+            E1 += c_norm(z1);
+            E2 += c_norm(z2);
+        }
+    }
+    free(bb);
+    float corr_mag = c_abs(P) / sqrtf(E1 * E2 + 1e-10f);
+    if (corr_mag < 0.3f) return 0.0f;
+    float phase = atan2f(P.im, P.re);
+    /* phase * config.sample_rate / (2.0f * M_PI * sym_len): float * (float)uint32, then a double division */
+    float cfo_hz = (float)((double)(phase * (float)c->sample_rate) / ((double)2.0f * M_PI * (double)sym_len));
+    float max_cfo = (float)c->sample_rate / (2.0f * (float)sym_len);
+    return f_max(-max_cfo, f_min(max_cfo, cfo_hz));
+}
+
+/* OFDMDemodulator::processPresynced, src/ofdm/demodulator.cpp:854-985.  cfo_hz finite: after
+ * setFrequencyOffset[WithPhase] (:805-825, the chirp-CFO-trusted branch :918-919).  cfo_hz NaN: the frequency offset
+ * was never set on this demodulator — with two or more training symbols the CFO comes from estimateCFOFromTraining
+ * (:920-925), else it stays 0 (:926-928); the correction phase starts at 0. */
 static int demod_presynced_run(demod* d, const float* audio, size_t n_samples, float cfo_hz, float cfo_phase,
                                cf* bb, cf* freq, cf* eq) {
     const ultra_hip_config* c = &d->cfg;
     if (n_samples < d->symbol_samples) return 0;
+    if (cfo_hz != cfo_hz) {
+        cfo_phase = 0.0f;
+        cfo_hz = (c->training_symbols >= 2 && n_samples >= 2 * (size_t)d->symbol_samples)
+                     ? estimate_cfo_from_training(d, audio, c->training_symbols) : 0.0f;
+    }
     d->freq_offset_hz = cfo_hz; d->freq_offset_filtered = cfo_hz; d->freq_correction_phase = cfo_phase;
     d->mixer.phase = 0;
     for (uint32_t i = 0; i < c->fft_size; ++i) d->channel_estimate[i] = c_make(1, 0);
@@ -1245,7 +1287,7 @@ static int demod_presynced_run(demod* d, const float* audio, size_t n_samples, f
 int uo_demod_presynced(const ultra_hip_config* c, const float* audio, uint32_t n_samples,
                        int has_cfo, float cfo_hz, float cfo_phase,
                        float* llr_out, uint32_t llr_cap, float* H_out, float* scal_out) {
-    if (!has_cfo) return -2; /* training-based CFO estimate (ofdm_sync.cpp:278-380) is out of scope */
+    if (!has_cfo) cfo_hz = NAN;              /* never set: the training-symbol estimate (ofdm_sync.cpp:278-380) */
     demod* d = (demod*)malloc(sizeof(demod));
     if (demod_init(d, c) != 0) { free(d); return -1; }
     d->soft = llr_out; d->soft_cap = llr_cap; d->n_soft = 0;

@@ -11,7 +11,7 @@ from ._lib import UltraHipError, build
 
 __all__ = ["CodeRate", "CyclicPrefixMode", "Entry", "LDPC_BLOCK_SIZE", "ModemConfig", "Modulation", "presets",
            "getBitsPerSymbol", "getCodeRateValue", "info_bits", "is_differential", "UltraHipError", "build",
-           "ReceiveContext", "LDPCDecoder", "ChannelInterleaver", "OFDMDemodulator", "HipOfdmWaveform", "SyncResult",
+           "ReceiveContext", "LDPCDecoder", "ChannelInterleaver", "Interleaver", "OFDMDemodulator", "HipOfdmWaveform", "SyncResult",
            "RxFrameDecoder", "RxFrameResult", "FrameType", "FrameStatus"]
 
 
@@ -21,7 +21,7 @@ def __getattr__(name):
     if name == "ReceiveContext":
         from .engine import ReceiveContext
         return ReceiveContext
-    if name in ("LDPCDecoder", "ChannelInterleaver"):
+    if name in ("LDPCDecoder", "ChannelInterleaver", "Interleaver"):
         from . import fec
         return getattr(fec, name)
     if name == "OFDMDemodulator":

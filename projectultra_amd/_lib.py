@@ -77,6 +77,7 @@ PROTOTYPES = {
     "ultra_hip_make_raw_batch": (_i, [_vp, C.c_uint64, C.c_uint64, _sz, _i, C.c_float, C.c_uint32, C.c_uint32, _vp, _sz, _vp]),
     "ultra_hip_make_llr_batch": (_i, [_vp, C.c_uint64, C.c_uint64, _sz, C.c_float, _vp, _vp]),
     "ultra_hip_set_deinterleave": (_i, [_vp, C.c_uint32]),
+    "ultra_hip_set_deinterleave_table": (_i, [_vp, _vp, C.c_uint32]),
     "ultra_hip_profile_enable": (_i, [_vp, _i]),
     "ultra_hip_profile_read": (_i, [_vp, C.POINTER(C.c_float), C.POINTER(C.c_uint32)]),
     "ultra_hip_malloc": (_i, [_vp, _sz, C.POINTER(_vp)]),

@@ -873,6 +873,47 @@ __global__ __launch_bounds__(kWave) void init_state_kernel(const float* __restri
     }
 }
 
+// OFDMDemodulator::Impl::estimateCFOFromTraining (src/ofdm/ofdm_sync.cpp:278-380, called with coarse_cfo = 0 from
+// processPresynced when the frequency offset was never set: demodulator.cpp:920-925) for the frames whose initial CFO is
+// NaN ("never set", ultra_hip.h): the first two training symbols times conj(NCO) — the oscillator table starts at phase 0
+// like the estimator's fresh NCO —, then P = sum conj(z1) z2, E1, E2 over the FFT parts, summed serially in the
+// reference's order: one LANE per frame (a rare entry; the frame's samples are read through the cache).
+__global__ __launch_bounds__(256) void train_cfo_kernel(const DemodConst* __restrict__ Dp, const c32* __restrict__ nco,
+                                                        const float* __restrict__ audio, size_t frame_stride,
+                                                        const unsigned* __restrict__ frame_offset, const float* __restrict__ cfo_in,
+                                                        int n_frames, float* __restrict__ state) {
+    const DemodConst& D = *Dp;
+    const int frame = blockIdx.x * blockDim.x + threadIdx.x;
+    if (frame >= n_frames || !cfo_in) return;
+    const float given = cfo_in[frame];
+    if (given == given) return;                                        // a preset CFO is trusted (:918-919)
+    float* st = state + (size_t)frame * kStFloats;
+    float cfo = 0.0f;
+    if (D.n_train >= 2) {
+        const float* x = audio + (size_t)frame * frame_stride + (frame_offset ? frame_offset[frame] : 0u);
+        const int N = D.fft, cp = D.cp, S = D.sym_len;
+        c32 P = mk(0.0f, 0.0f);
+        float E1 = 0.0f, E2 = 0.0f;
+        for (int i = 0; i < N; ++i) {
+            const c32 o1 = nco[cp + i], o2 = nco[S + cp + i];
+            const float a1 = x[cp + i], a2 = x[S + cp + i];
+            const c32 z1 = mk(a1 * o1.re, a1 * -o1.im), z2 = mk(a2 * o2.re, a2 * -o2.im);   // float * conj(osc)
+            const c32 pr = cmul(mk(z1.re, -z1.im), z2);
+            P = mk(P.re + pr.re, P.im + pr.im);
+            E1 += z1.re * z1.re + z1.im * z1.im;
+            E2 += z2.re * z2.re + z2.im * z2.im;
+        }
+        const float corr = um::hypotf_(P.re, P.im) / sqrtf(E1 * E2 + 1e-10f);
+        if (!(corr < 0.3f)) {
+            const float phase = um::atan2f_(P.im, P.re);
+            cfo = (float)((double)(phase * D.sample_rate) / ((double)2.0f * 3.14159265358979323846 * (double)S));
+            const float max_cfo = D.sample_rate / (2.0f * (float)S);
+            cfo = fmaxf(-max_cfo, fminf(max_cfo, cfo));               // std::max(-m, std::min(m, x)); a NaN x ends at +m in both
+        }
+    }
+    st[st_cfo] = cfo; st[st_cfo_filt] = cfo; st[st_cfo_phase] = 0.0f;
+}
+
 // toBaseband + extractSymbol/FFT of symbol `sym` of every frame.
 // The serial part of the CFO rotation — the exact jump table of the float phase recurrence for the coming
 // symbol (phase_table.h) — is scalar work per frame: here one LANE per frame (in mix_fft_kernel the whole

@@ -152,7 +152,8 @@ template <int RR, int VR, unsigned long long RMAX, unsigned long long RMIN, unsi
 __global__ __launch_bounds__(kLdpcThreads, WAVES) void ldpc_decode_kernel(
     const LdpcPlan* __restrict__ Pp, const float* __restrict__ llr, size_t llr_stride, int n_cw,
     uint8_t* __restrict__ bytes, int32_t* __restrict__ iters, uint8_t* __restrict__ okv,
-    float* __restrict__ llr_total, unsigned int* __restrict__ work_counter, int llr_step) {
+    float* __restrict__ llr_total, unsigned int* __restrict__ work_counter, int llr_step,
+    const uint16_t* __restrict__ llr_perm) {
     constexpr int DMAX = ldpc_prof_max(VMAX, VR);
     extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
     const LdpcPlan& P = *Pp;
@@ -232,12 +233,16 @@ __global__ __launch_bounds__(kLdpcThreads, WAVES) void ldpc_decode_kernel(
     // 648 floats -> llr_s, 64 per instruction.  The channel deinterleaver of the production receive
     // path (RxPipeline::deinterleaveCodewords, rx_pipeline.cpp:475-491 -> ChannelInterleaver::deinterleave,
     // ldpc_decoder.cpp:609-617: out[j] = in[(j * step) % 648]) is fused into this copy as the gather
-    // index; llr_step == 1 is the identity.
+    // index; llr_step == 1 is the identity.  llr_perm (nullable): a general gather table out[j] = in[llr_perm[j]]
+    // (ultra_hip_set_deinterleave_table: any 648-entry permutation, e.g. the row-column Interleaver::deinterleave,
+    // ldpc_decoder.cpp:454-466,530-540) takes precedence over the step.
     auto fetch = [&](int c) {
         const float* src = llr + (size_t)c * llr_stride;
         for (int j0 = 0; j0 < n; j0 += kLdpcThreads)
             if (j0 + lane < n)
-                __builtin_amdgcn_global_load_lds(src + (unsigned)((j0 + lane) * llr_step) % (unsigned)kLdpcN, llr_s + j0, 4, 0, 0);
+                __builtin_amdgcn_global_load_lds(src + (llr_perm ? (unsigned)llr_perm[j0 + lane]
+                                                                 : (unsigned)((j0 + lane) * llr_step) % (unsigned)kLdpcN),
+                                                 llr_s + j0, 4, 0, 0);
     };
     int cw = claim();
     if (cw >= 0) fetch(cw);

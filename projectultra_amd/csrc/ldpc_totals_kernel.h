@@ -35,7 +35,8 @@ template <int RR, int VR, int D, bool WANT_TOTAL, int WAVES>
 __global__ __launch_bounds__(kLdpcThreads, WAVES) void ldpc_totals_kernel(
     const LdpcTPlan* __restrict__ Pp, const float* __restrict__ llr, size_t llr_stride, int n_cw,
     uint8_t* __restrict__ bytes, int32_t* __restrict__ iters, uint8_t* __restrict__ okv,
-    float* __restrict__ llr_total, unsigned int* __restrict__ work_counter, int llr_step) {
+    float* __restrict__ llr_total, unsigned int* __restrict__ work_counter, int llr_step,
+    const uint16_t* __restrict__ llr_perm) {
     extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
     const LdpcTPlan& P = *Pp;
     const int lane = threadIdx.x;
@@ -84,7 +85,8 @@ __global__ __launch_bounds__(kLdpcThreads, WAVES) void ldpc_totals_kernel(
     };
     // channel LLR index of variable j: the production path's channel deinterleaver fused as a gather index
     // (ChannelInterleaver::deinterleave, ldpc_decoder.cpp:609-617: out[j] = in[(j * step) % 648]; step 1 = identity)
-    auto src_index = [&](int j) -> unsigned { return (unsigned)(j * llr_step) % (unsigned)kLdpcN; };
+    // llr_perm (nullable): a general gather table out[j] = in[llr_perm[j]] (ultra_hip_set_deinterleave_table)
+    auto src_index = [&](int j) -> unsigned { return llr_perm ? (unsigned)llr_perm[j] : (unsigned)(j * llr_step) % (unsigned)kLdpcN; };
     auto fetch = [&](int c) {
         const float* src = llr + (size_t)c * llr_stride;
         float* stage_v = reinterpret_cast<float*>(lds_raw + STAGE_V);

@@ -73,6 +73,7 @@ struct ultra_hip_ctx {
     int cu_count = 256;
     // per-kernel profiling (ultra_hip_profile_*): recorded (class, start, stop) triples + spare events
     uint32_t deint_step = 1;             // ChannelInterleaver step fused into the LDPC LLR load (1 = off)
+    uint16_t* d_deint_table = nullptr;   // general gather table of the fused deinterleave (nullptr = use the step)
     bool profiling = false;
     struct Span { int kind; hipEvent_t e0, e1; };
     std::vector<Span> spans;
@@ -153,6 +154,11 @@ int launch_demod(ultra_hip_ctx* ctx, const float* d_audio, size_t frame_stride, 
         LaunchSpan span(ctx, ULTRA_HIP_K_INIT_STATE);
         hipLaunchKernelGGL(dev::init_state_kernel, dim3(grid_trk), dim3(dev::kWave), 0, st, d_cfo_hz, d_cfo_phase,
                            (int)n_frames, ctx->d_ws_state);
+    }
+    if (D.presynced && d_cfo_hz) {
+        // frames whose initial CFO is NaN ("never set"): estimateCFOFromTraining, demodulator.cpp:920-925
+        hipLaunchKernelGGL(dev::train_cfo_kernel, dim3((unsigned)((n_frames + 255) / 256)), dim3(256), 0, st, ctx->d_demod, ctx->d_nco,
+                           d_audio, frame_stride, d_frame_offset, d_cfo_hz, (int)n_frames, ctx->d_ws_state);
     }
     const int n_sym = D.n_train + D.n_data_sym;
     for (int s = 0; s < n_sym; ++s) {
@@ -243,11 +249,11 @@ int launch_ldpc(ultra_hip_ctx* ctx, const float* d_llr, size_t llr_stride, size_
         if (d_llr_total)                                                                                          \
             hipLaunchKernelGGL((dev::ldpc_totals_kernel<RR, VR, D, true, WV>), dim3(grid), dim3(dev::kLdpcThreads), tlds, \
                                ctx->stream, ctx->d_tplan, d_llr, llr_stride, (int)n_cw, d_bytes, d_iters, d_ok,   \
-                               d_llr_total, counter, (int)ctx->deint_step);                                       \
+                               d_llr_total, counter, (int)ctx->deint_step, ctx->d_deint_table);                                       \
         else                                                                                                      \
             hipLaunchKernelGGL((dev::ldpc_totals_kernel<RR, VR, D, false, WV>), dim3(grid), dim3(dev::kLdpcThreads), tlds, \
                                ctx->stream, ctx->d_tplan, d_llr, llr_stride, (int)n_cw, d_bytes, d_iters, d_ok,   \
-                               d_llr_total, counter, (int)ctx->deint_step);                                       \
+                               d_llr_total, counter, (int)ctx->deint_step, ctx->d_deint_table);                                       \
     } while (0)
         bool launched = true;
         if (T.row_rounds == 3 && T.var_rounds == 6 && T.dmax == 3) UH_TOTALS_LAUNCH(3, 6, 3, 5);                  // R3/4
@@ -270,12 +276,12 @@ int launch_ldpc(ultra_hip_ctx* ctx, const float* d_llr, size_t llr_stride, size_
             hipLaunchKernelGGL((dev::ldpc_decode_kernel<RR, VR, RMAX, RMIN, VMAX, VMIN, RID, LIN, true, WV>),        \
                                dim3(grid), dim3(dev::kLdpcThreads), lds, ctx->stream, ctx->d_plan, d_llr,       \
                                llr_stride, (int)n_cw, d_bytes, d_iters, d_ok, d_llr_total, counter,             \
-                               (int)ctx->deint_step);                                                           \
+                               (int)ctx->deint_step, ctx->d_deint_table);                                                           \
         else                                                                                                    \
             hipLaunchKernelGGL((dev::ldpc_decode_kernel<RR, VR, RMAX, RMIN, VMAX, VMIN, RID, LIN, false, WV>),       \
                                dim3(grid), dim3(dev::kLdpcThreads), lds, ctx->stream, ctx->d_plan, d_llr,       \
                                llr_stride, (int)n_cw, d_bytes, d_iters, d_ok, d_llr_total, counter,             \
-                               (int)ctx->deint_step);                                                           \
+                               (int)ctx->deint_step, ctx->d_deint_table);                                                           \
     } while (0)
     // One instance per degree profile of the reference's six codes (LdpcPlan::prof_*, four bits per round, round 0
     // lowest; tools/ldpc_plan_check.cpp prints them): the kernel touches exactly the edge slots a round has.  The
@@ -486,6 +492,7 @@ void ultra_hip_destroy(ultra_hip_ctx* ctx) {
     if (ctx->d_demod) (void)hipFree(ctx->d_demod);
     if (ctx->d_plan) (void)hipFree(ctx->d_plan);
     if (ctx->d_tplan) (void)hipFree(ctx->d_tplan);
+    if (ctx->d_deint_table) (void)hipFree(ctx->d_deint_table);
     if (ctx->d_work) (void)hipFree(ctx->d_work);
     for (auto& sp : ctx->spans) { (void)hipEventDestroy(sp.e0); (void)hipEventDestroy(sp.e1); }
     for (auto e : ctx->spare_events) (void)hipEventDestroy(e);
@@ -873,6 +880,21 @@ int ultra_hip_set_deinterleave(ultra_hip_ctx* ctx, uint32_t bits_per_symbol) {
     if (!ctx) return ULTRA_HIP_ERR_INVALID_ARG;
     if (bits_per_symbol >= (uint32_t)kLdpcN) return ULTRA_HIP_ERR_INVALID_ARG;
     ctx->deint_step = bits_per_symbol ? channel_interleaver_step(bits_per_symbol, (uint32_t)kLdpcN) : 1u;
+    return ULTRA_HIP_OK;
+}
+
+int ultra_hip_set_deinterleave_table(ultra_hip_ctx* ctx, const uint16_t* h_index, uint32_t n) {
+    if (!ctx) return ULTRA_HIP_ERR_INVALID_ARG;
+    DeviceGuard guard(ctx->device);
+    if (!h_index || n == 0) {                                   // off: back to the step (ultra_hip_set_deinterleave)
+        if (ctx->d_deint_table) { UH_HIP(hipStreamSynchronize(ctx->stream)); (void)hipFree(ctx->d_deint_table); ctx->d_deint_table = nullptr; }
+        return ULTRA_HIP_OK;
+    }
+    if (n != (uint32_t)kLdpcN) return ULTRA_HIP_ERR_INVALID_ARG;
+    for (uint32_t j = 0; j < n; ++j) if (h_index[j] >= (uint16_t)kLdpcN) return ULTRA_HIP_ERR_INVALID_ARG;   // the kernel gathers through it
+    if (!ctx->d_deint_table) UH_HIP(hipMalloc(&ctx->d_deint_table, kLdpcN * sizeof(uint16_t)));
+    UH_HIP(hipMemcpyAsync(ctx->d_deint_table, h_index, kLdpcN * sizeof(uint16_t), hipMemcpyHostToDevice, ctx->stream));
+    UH_HIP(hipStreamSynchronize(ctx->stream));
     return ULTRA_HIP_OK;
 }
 

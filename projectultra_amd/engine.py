@@ -381,6 +381,16 @@ class ReceiveContext:
         decoded, fused into the decoder's LLR load.  0 switches it off."""
         check(self.lib.ultra_hip_set_deinterleave(self._ctx, int(bits_per_symbol)), "ultra_hip_set_deinterleave")
 
+    def set_deinterleave_table(self, index):
+        """Fuse an arbitrary permutation of the 648 soft bits into the decoder's LLR load: out[j] = in[index[j]]
+        (ultra_hip_set_deinterleave_table; e.g. Interleaver(rows, cols).permutation).  None switches it off."""
+        if index is None:
+            check(self.lib.ultra_hip_set_deinterleave_table(self._ctx, None, 0), "ultra_hip_set_deinterleave_table")
+            return
+        idx = np.ascontiguousarray(index, dtype=np.uint16).reshape(-1)
+        check(self.lib.ultra_hip_set_deinterleave_table(self._ctx, idx.ctypes.data_as(C.c_void_p), idx.size),
+              "ultra_hip_set_deinterleave_table")
+
     KERNEL_CLASSES = ("init_state_kernel", "mix_fft_kernel", "track_kernel", "ldpc_decode_kernel", "count_errors_kernel",
                       "acquire_kernel", "chirp_sync_kernel", "track_pilot_kernel", "cfo_walk_kernel")
 

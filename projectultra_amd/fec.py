@@ -79,6 +79,12 @@ class LDPCDecoder:
         self._deinterleave = int(bits_per_symbol)
         self._ctx.set_deinterleave(self._deinterleave)
 
+    def setDeinterleaveTable(self, index) -> None:
+        """Fuse any 648-entry permutation (out[j] = in[index[j]], e.g. Interleaver(6, 108).permutation) into the
+        decoder's LLR load; None switches it off."""
+        self._deinterleave_table = None if index is None else np.ascontiguousarray(index, np.uint16).copy()
+        self._ctx.set_deinterleave_table(self._deinterleave_table)
+
     # ---------------------------------------------------------------------
     def _rebuild(self):
         if self._ctx is not None:
@@ -87,10 +93,37 @@ class LDPCDecoder:
         self._ctx = ReceiveContext(cfg, max_iterations=self._max_iterations, device=self._device)
         if getattr(self, "_deinterleave", 0):
             self._ctx.set_deinterleave(self._deinterleave)
+        if getattr(self, "_deinterleave_table", None) is not None:
+            self._ctx.set_deinterleave_table(self._deinterleave_table)
 
     @property
     def context(self) -> ReceiveContext:
         return self._ctx
+
+
+class Interleaver:
+    """Host mirror of ultra::Interleaver (include/ultra/fec.hpp, src/fec/ldpc_decoder.cpp:454-540): row-column transpose,
+    permutation[i] = (i % cols) * rows + i // cols; interleave(soft): out[permutation[i]] = in[i]; deinterleave(soft):
+    out[i] = in[permutation[i]].  The receive side runs fused on the GPU: LDPCDecoder.setDeinterleaveTable(il.permutation)."""
+
+    def __init__(self, rows: int, cols: int):
+        self.rows, self.cols = int(rows), int(cols)
+        i = np.arange(self.rows * self.cols, dtype=np.int64)
+        self.permutation = (i % self.cols) * self.rows + i // self.cols
+
+    def interleave(self, soft_bits) -> np.ndarray:            # :519-527
+        x = np.ascontiguousarray(soft_bits, dtype=np.float32).reshape(-1)
+        out = np.zeros(x.size, np.float32)
+        n = min(x.size, self.permutation.size)
+        out[self.permutation[:n]] = x[:n]
+        return out
+
+    def deinterleave(self, soft_bits) -> np.ndarray:          # :530-540
+        x = np.ascontiguousarray(soft_bits, dtype=np.float32).reshape(-1)
+        out = np.zeros(x.size, np.float32)
+        n = min(x.size, self.permutation.size)
+        out[:n] = x[self.permutation[:n]]
+        return out
 
 
 class ChannelInterleaver:

@@ -70,16 +70,14 @@ class OFDMDemodulator:
         sym = self.config.getSymbolDuration()
         if samples.size < sym:
             return False
-        if not self._chirp_cfo:
-            raise NotImplementedError(
-                "processPresynced without setFrequencyOffset*: the training-symbol CFO estimator "
-                "(src/ofdm/ofdm_sync.cpp:278-380) belongs to the acquisition row that is not built")
         n_sym = samples.size // sym - training_symbols
         if n_sym <= 0:
             self._soft_bits = np.zeros(0, np.float32)
             return False
         ctx = self._context(Entry.PRESYNCED, n_sym, training_symbols)
-        return self._run(ctx, samples)
+        # a frequency offset that was never set travels as NaN: the library then estimates it from the two training
+        # symbols (Impl::estimateCFOFromTraining, ofdm_sync.cpp:278-380; demodulator.cpp:920-925)
+        return self._run(ctx, samples, never_set=not self._chirp_cfo)
 
     def process_synced(self, samples, cfo_hz: float = 0.0) -> bool:
         """SYNCED-state symbol loop of process() (demodulator.cpp:672-697) on a frame that
@@ -136,9 +134,9 @@ class OFDMDemodulator:
                                             device=self._device)
         return self._ctx[key]
 
-    def _run(self, ctx, samples) -> bool:
+    def _run(self, ctx, samples, never_set: bool = False) -> bool:
         fs = ctx.geometry.frame_samples
-        llr, state = ctx.demod(samples[:fs].reshape(1, fs), cfo_hz=np.array([self._cfo_hz], np.float32),
+        llr, state = ctx.demod(samples[:fs].reshape(1, fs), cfo_hz=np.array([np.nan if never_set else self._cfo_hz], np.float32),
                                cfo_phase=np.array([self._cfo_phase], np.float32), want_state=True)
         ctx.synchronize()
         self._soft_bits = np.concatenate([self._soft_bits, llr[0].cpu().numpy()])

@@ -196,6 +196,51 @@ def test_device_math_matches_host_libm():
         assert beq(got, want), (name, np.flatnonzero(got.view(np.uint32) != want.view(np.uint32))[:5])
 
 
+@pytest.mark.parametrize("mod,rate,fft,kw", [("DQPSK", "R1_2", 512, {}), ("QAM16", "R3_4", 1024, {}), ("D8PSK", "R2_3", 1024, dict(pilot_spacing=2))])
+def test_presynced_training_cfo_estimate(oracle, mod, rate, fft, kw):
+    """ULTRA_ENTRY_PRESYNCED with a NaN initial CFO = processPresynced on a demodulator whose frequency offset was never
+    set: the CFO comes from the two training symbols (estimateCFOFromTraining, ofdm_sync.cpp:278-380).  Frequency-shifted
+    frames at several SNRs, a noise-only buffer (correlation gate), mixed in one batch with frames that DO carry a preset
+    CFO: LLRs bitwise, the tracker's final CFO bitwise, against the oracle (pinned to the reference for this branch by
+    tests/test_oracle_vs_ref.py::test_presynced_without_a_preset_cfo); and the host mirror OFDMDemodulator without
+    setFrequencyOffset."""
+    from scipy.signal import hilbert
+    from projectultra_amd import OFDMDemodulator
+    from _util import modem_config_from_c
+    cfg = make_config(fft, mod, rate, entry=1, **kw)
+    g = geometry(cfg)
+    rng = np.random.default_rng(15)
+    frames, cfo_in = [], []
+    for trial in range(12):
+        enc = oracle.ldpc_encode(cfg.code_rate, bytes(rng.integers(0, 256, INFO_BITS[cfg.code_rate] // 8, dtype=np.uint8)))
+        a = oracle.modulate_presynced(cfg, enc)
+        x = a * np.float32(0.5 / np.abs(a).max())
+        shift = [0.0, 4.0, -7.5, 12.0, -15.0, 30.0][trial % 6]
+        if shift:
+            x = np.real(hilbert(x.astype(np.float64)) * np.exp(2j * np.pi * shift * np.arange(x.size) / 48000.0)).astype(np.float32)
+        snr = [40.0, 30.0, 20.0, 12.0, 6.0, 25.0][trial % 6]
+        x = (x + rng.normal(0, np.sqrt(np.mean(x.astype(np.float64) ** 2) / 10 ** (snr / 10)), x.size)).astype(np.float32)
+        if trial == 11:
+            x = rng.normal(0, 0.1, x.size).astype(np.float32)
+        frames.append(x[:g.frame_samples])
+        cfo_in.append(np.nan if trial % 3 != 2 else float(shift))      # every third frame has a preset (trusted) CFO
+    audio, cfo_in = np.stack(frames), np.array(cfo_in, np.float32)
+    ctx = context_for(cfg)
+    llr, state = ctx.demod(audio, cfo_hz=cfo_in, want_state=True)
+    ctx.synchronize()
+    llr, state = llr.cpu().numpy(), state.cpu().numpy()
+    for i in range(len(frames)):
+        want, _, scal = oracle.demod_presynced(cfg, frames[i], None if np.isnan(cfo_in[i]) else float(cfo_in[i]), 0.0)
+        assert beq(llr[i, :want.size], want), (mod, i)
+        assert beq(state[i, 0], scal[0]), (mod, i, state[i, 0], scal[0])
+    mc, kwc = modem_config_from_c(cfg)
+    d = OFDMDemodulator(mc)
+    d.processPresynced(frames[1], training_symbols=2)                   # no setFrequencyOffset* call before
+    want, _, _ = oracle.demod_presynced(cfg, frames[1], None)
+    got = np.concatenate([d.getSoftBits() for _ in range(8)])
+    assert beq(got[:want.size], want[:got.size]) and got.size > 0
+
+
 def test_device_logf_sqrtf_match_host_libm():
     """The two libm functions of the stimulus generators' Box-Muller transform, evaluated ON THE GPU: logf
     (pinned_math.h, glibc 2.35's FMA build) and the correctly rounded sqrtf — over (0, 1] on the 24-bit grid the

@@ -144,6 +144,34 @@ def test_fused_channel_deinterleaver(oracle, rate, bps):
     assert np.array_equal(r0["bytes"], ob0) and np.array_equal(r0["iters"], oi0)
 
 
+@pytest.mark.parametrize("rate,rows,cols", [(2, 6, 108), (4, 6, 108), (0, 24, 27), (5, 108, 6)])
+def test_fused_deinterleave_table(oracle, rate, rows, cols):
+    """ultra_hip_set_deinterleave_table: ANY 648-entry permutation fused into the decoder's LLR load — here the reference's
+    row-column Interleaver (ldpc_decoder.cpp:454-540; Interleaver(6, 108) is what tools/test_throughput.cpp builds).
+    Interleaved noisy codewords decode exactly as the oracle decodes the oracle-deinterleaved LLRs; the table takes
+    precedence over the ChannelInterleaver step and switches off again; bad tables are refused."""
+    from projectultra_amd import CodeRate, Interleaver, LDPCDecoder
+    from projectultra_amd._lib import UltraHipError
+    il = Interleaver(rows, cols)
+    llr, _ = noisy_codewords(oracle, rate, 300, [0.6, 0.9, 1.3], seed=21)
+    tx = np.stack([il.interleave(c) for c in llr])                       # what the channel delivers
+    want_in = np.stack([oracle.interleaver_deinterleave(rows, cols, c) for c in tx])
+    assert beq(want_in, llr)
+    ob, oi, ook = oracle.ldpc_decode_batch(rate, want_in)
+    d = LDPCDecoder(CodeRate(rate))
+    d.setDeinterleave(60)                                                # the table below wins over the step
+    d.setDeinterleaveTable(il.permutation)
+    r = d.decode_batch(tx)
+    assert np.array_equal(r["bytes"], ob) and np.array_equal(r["iters"], oi) and np.array_equal(r["ok"], ook)
+    d.setDeinterleaveTable(None); d.setDeinterleave(0)
+    r0 = d.decode_batch(tx)
+    ob0, oi0, _ = oracle.ldpc_decode_batch(rate, tx)
+    assert np.array_equal(r0["bytes"], ob0) and np.array_equal(r0["iters"], oi0)
+    for bad in (np.arange(647), np.full(648, 648), np.arange(648) + 1):
+        with pytest.raises(UltraHipError):
+            d.context.set_deinterleave_table(bad)
+
+
 def test_full_size_round_trip_property(oracle):
     """BASELINE cfg4 shape at 2^18 codewords: encode -> BPSK/AWGN -> decode; every frame the decoder
     declares OK must equal its payload or be counted as undetected; high-SNR frames all decode."""
@@ -244,3 +272,53 @@ def test_counters_allreduce_over_rccl():
     assert torch.equal(counters, want)
     rccl.ncclCommDestroy.argtypes = [C.c_void_p]
     rccl.ncclCommDestroy(comm)
+
+
+RCCL_WORKER = r'''
+import ctypes as C, os, sys, torch, torch.distributed as dist
+sys.path.insert(0, sys.argv[1])
+rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+torch.cuda.set_device(rank)
+dist.init_process_group("gloo", rank=rank, world_size=world)          # only to hand the RCCL unique id around
+rccl = C.CDLL("librccl.so.1")
+class Uid(C.Structure):
+    _fields_ = [("internal", C.c_char * 128)]
+u = Uid()
+if rank == 0:
+    assert rccl.ncclGetUniqueId(C.byref(u)) == 0
+t = torch.frombuffer(bytearray(bytes(u)), dtype=torch.uint8).clone()
+dist.broadcast(t, 0)
+C.memmove(C.byref(u), bytes(t.tolist()), 128)
+comm = C.c_void_p()
+rccl.ncclCommInitRank.argtypes = [C.POINTER(C.c_void_p), C.c_int, Uid, C.c_int]
+assert rccl.ncclCommInitRank(C.byref(comm), world, u, rank) == 0
+from projectultra_amd import CodeRate, LDPCDecoder
+from projectultra_amd._lib import check
+ctx = LDPCDecoder(CodeRate.R1_2).context
+counters = (torch.arange(1, 9, dtype=torch.int64, device="cuda") * 1000003) * (rank + 1)
+check(ctx.lib.ultra_hip_counters_allreduce(ctx._ctx, comm, counters.data_ptr()), "ultra_hip_counters_allreduce")
+ctx.synchronize()
+want = torch.arange(1, 9, dtype=torch.int64) * 1000003 * sum(r + 1 for r in range(world))
+assert torch.equal(counters.cpu(), want), (counters, want)
+rccl.ncclCommDestroy.argtypes = [C.c_void_p]; rccl.ncclCommDestroy(comm)
+dist.destroy_process_group()
+print("rank", rank, "ok")
+'''
+
+
+def test_counters_allreduce_over_rccl_two_ranks(tmp_path):
+    """ultra_hip_counters_allreduce over a TWO-rank RCCL communicator, one process per GPU — runs where the box shows at
+    least two devices (the round's GPU box shows one: skipped there; the 8-GPU scaling run is the driver's)."""
+    import os, subprocess, sys
+    import torch
+    if torch.cuda.device_count() < 2:
+        pytest.skip("needs two GPUs")
+    script = tmp_path / "w.py"
+    script.write_text(RCCL_WORKER)
+    root = str(__import__("pathlib").Path(__file__).resolve().parent.parent)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1",
+           "--master-port", str(30500 + os.getpid() % 1000), str(script), root]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=300, env=dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0"))
+    assert r.returncode == 0, r.stdout[-1500:] + r.stderr[-1500:]
+    assert r.stdout.count("ok") == 2
+

@@ -94,6 +94,38 @@ def test_watterson_statistics_match_the_oracle_generator(oracle):
     assert abs(c0[1] / c0[0] - co0[1] / co0[0]) < 0.04
 
 
+@pytest.mark.parametrize("name,delay_ms,doppler_hz,snr_db", [("moderate", 1.0, 0.5, 20.0), ("poor", 2.0, 1.0, 20.0), ("flutter", 0.5, 10.0, 20.0)])
+def test_watterson_presets_match_the_oracle_generator(oracle, name, delay_ms, doppler_hz, snr_db):
+    """The reference's other Watterson presets (itu_r_f1487::moderate / poor / flutter, src/sim/hf_channel.hpp:421-470:
+    1 ms / 0.5 Hz, 2 ms / 1 Hz, 0.5 ms / 10 Hz) on the device generator: at 10 Hz Doppler the fading moves through 2.6
+    periods inside one frame, which is what the chunk-parallel evaluation of the fading filters has to get right.  8192
+    device frames against 2048 frames of the oracle's serial generator: mean and spread of the per-frame power, the
+    receive path's FER and mean BP iterations, and the fading's rate of change (lag-1-symbol correlation of the symbol
+    powers) within sampling tolerance."""
+    cfg = make_config(1024, "QAM16", "R1_2", pilot_spacing=4)
+    ctx = context_for(cfg)
+    n, n_cpu = 8192, 2048
+    audio, payload = ctx.make_batch(n, seed=321, channel="watterson", snr_db=snr_db, delay_ms=delay_ms, doppler_hz=doppler_hz)
+    ctx.synchronize()
+    oa, op = oracle.make_batch(cfg, n_cpu, seed=321, channel="watterson", snr_db=snr_db, delay_ms=delay_ms, doppler_hz=doppler_hz)
+    a = audio.cpu().numpy().astype(np.float64)
+    p_gpu, p_cpu = (a ** 2).mean(axis=1), (oa.astype(np.float64) ** 2).mean(axis=1)
+    assert abs(p_gpu.mean() / p_cpu.mean() - 1.0) < 0.05, (name, p_gpu.mean(), p_cpu.mean())
+    assert abs(p_gpu.std() / p_cpu.std() - 1.0) < 0.15, (name, p_gpu.std(), p_cpu.std())
+    # how fast the envelope moves inside a frame: correlation of consecutive symbols' powers
+    S = ctx.geometry.symbol_samples
+
+    def sym_corr(x):
+        ps = (x[:, : (x.shape[1] // S) * S].reshape(x.shape[0], -1, S) ** 2).mean(axis=2)
+        ps = ps / ps.mean(axis=1, keepdims=True)
+        return float(np.mean((ps[:, 1:] - 1.0) * (ps[:, :-1] - 1.0)))
+    assert abs(sym_corr(a) - sym_corr(oa.astype(np.float64))) < 0.02 + 0.15 * abs(sym_corr(oa.astype(np.float64))), (name, sym_corr(a), sym_corr(oa.astype(np.float64)))
+    c = ctx.count_errors(ctx.demod_decode(audio), payload).cpu().numpy()
+    co = ctx.count_errors(ctx.demod_decode(oa), op).cpu().numpy()
+    assert abs(c[1] / c[0] - co[1] / co[0]) < 0.035, (name, c[1] / c[0], co[1] / co[0])
+    assert abs(c[5] / c[0] - co[5] / co[0]) < 1.5, (name, c[5] / c[0], co[5] / co[0])
+
+
 CFG5_MODS = [(512, "DBPSK"), (512, "DQPSK"), (1024, "D8PSK"), (1024, "QAM16"), (1024, "QAM32")]
 CFG5_RATES = ["R1_4", "R1_2", "R2_3", "R3_4", "R5_6"]
 

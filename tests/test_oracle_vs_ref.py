@@ -103,6 +103,36 @@ def test_presynced(oracle, ref, mod, rate, fft, kw):
         assert beq(la, lb) and beq(Ha, Hb) and beq(sa, sb), (mod, trial)
 
 
+@pytest.mark.parametrize("mod,rate,fft,kw", [("DQPSK", "R1_2", 512, {}), ("QAM16", "R3_4", 1024, {}), ("D8PSK", "R2_3", 1024, dict(pilot_spacing=2))])
+def test_presynced_without_a_preset_cfo(oracle, ref, mod, rate, fft, kw):
+    """processPresynced on a demodulator whose frequency offset was never set (demodulator.cpp:920-925): the CFO comes from
+    estimateCFOFromTraining (ofdm_sync.cpp:278-380) — two training symbols mixed down by a fresh NCO, correlated, arg(P)
+    scaled, gated at |corr| >= 0.3 and clamped.  Frames with a real frequency shift (so the estimate is not 0), clean and
+    noisy, and a noise-only buffer (correlation below the gate): LLRs, H and the tracker scalars equal the reference's."""
+    from scipy.signal import hilbert
+    cfg = make_config(fft, mod, rate, entry=1, **kw)
+    g = geometry(cfg)
+    rng = np.random.default_rng(15)
+    est = []
+    for trial in range(7):
+        enc = oracle.ldpc_encode(cfg.code_rate, bytes(rng.integers(0, 256, INFO_BITS[cfg.code_rate] // 8, dtype=np.uint8)))
+        a = oracle.modulate_presynced(cfg, enc)
+        x = a * np.float32(0.5 / np.abs(a).max())
+        shift = [0.0, 4.0, -7.5, 12.0, -15.0, 30.0, 0.0][trial]       # 30 Hz: beyond the unambiguous range of the 1024-FFT symbol
+        if shift:
+            x = np.real(hilbert(x.astype(np.float64)) * np.exp(2j * np.pi * shift * np.arange(x.size) / 48000.0)).astype(np.float32)
+        snr = [40.0, 30.0, 20.0, 12.0, 6.0, 25.0, 0.0][trial]
+        x = (x + rng.normal(0, np.sqrt(np.mean(x.astype(np.float64) ** 2) / 10 ** (snr / 10)), x.size)).astype(np.float32)
+        if trial == 6:
+            x = rng.normal(0, 0.1, x.size).astype(np.float32)            # no signal: the correlation gate returns 0
+        x = x[:g.frame_samples]
+        la, Ha, sa = oracle.demod_presynced(cfg, x, None)
+        lb, Hb, sb = ref.demod_presynced(cfg, x, None)
+        assert beq(la, lb) and beq(Ha, Hb) and beq(sa, sb), (mod, trial, sa, sb)
+        est.append(float(sb[0]))
+    assert any(e != 0.0 for e in est[:6]) and len(set(est[:6])) >= 4          # the estimator did run and produced distinct values
+
+
 def test_reference_batch_baseline_equals_oracle_batch(oracle, ref):
     cfg = make_config(1024, "QAM16", "R3_4")
     audio, _ = oracle.make_batch(cfg, 48, seed=9, channel="watterson", snr_db=30.0)
