@@ -43,6 +43,17 @@ HBM_PEAK_GBPS = 8000.0          # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
 CLOCK_HZ = 2.4e9                # MI355X peak engine clock (MI355X_MICROARCH.md); the chip holds ~2.3 GHz under these kernels
 # LDS-pipeline cycles per wave-instruction (MI355X_MICROARCH.md, LDS table; re-measured in profiles/r02_issue_table.txt)
 LDS_CYC = dict(read_b32=2, write_b32=4, write_addtid_b32=2)
+# Compute-side roofline: issue cycles per unit of work and kernel, = (dynamic instruction counts per unit from rocprofv3
+# --pmc SQ_INSTS_VALU / _SALU / _LDS, profiles/r02_sq_counters.txt) x (measured cost per instruction of the kernel's own
+# opcode mix, profiles/r02_issue_table.txt), as tools/issue_model.py derives them into profiles/r02_issue_model.txt.
+#   valu / salu: cycles of ONE SIMD per unit (a CU has 4 SIMDs); lds: cycles of the CU's single LDS pipeline per unit.
+#   unit: "cw_iteration" = one executed BP iteration of one codeword; "frame" = one frame of one launch.
+ISSUE_CYCLES = {
+    "ldpc_totals R3/4": dict(unit="cw_iteration", valu=165 * 3.40, salu=76.5 * 4.19, lds=61.6 * 2.13),
+    "mix_fft_kernel": dict(unit="frame", valu=1139 * 3.51, salu=136 * 4.19, lds=81.4 * 3.52),
+    "track_kernel": dict(unit="frame", valu=202 * 3.27, salu=104 * 4.19, lds=20.9 * 3.93),
+    "track_pilot_kernel": dict(unit="frame", valu=133 * 3.39, salu=55.5 * 4.19, lds=4.75 * 5.08),
+}
 
 
 def parse():
@@ -633,7 +644,28 @@ def main():
         # instances issue one read and one address+data store per slot and step.  Cycles per wave-instruction: MI355X_MICROARCH.md's LDS
         # table, re-measured in profiles/r02_issue_table.txt.  A codeword that converges at iteration `it` executes
         # it + 1 iterations, a failing one max_iterations.
-        if dom == "ldpc_decode_kernel" and wl.name in ("cfg3", "cfg4", "raw"):
+        # compute-side view of every kernel with a derived issue model: which unit is busiest, and how busy
+        def issue_view(name, key, units, ms):
+            m = ISSUE_CYCLES[key]
+            t = ms * 1e-3 * CLOCK_HZ
+            cu = props.multi_processor_count
+            u = dict(valu=m["valu"] * units / (4 * cu * t), salu=m["salu"] * units / (4 * cu * t), lds=m["lds"] * units / (cu * t))
+            kernels[name]["issue"] = dict(unit=m["unit"], units_per_step=units, cycles_per_unit={k: m[k] for k in ("valu", "salu", "lds")},
+                                          busy_frac=u, clock_hz=CLOCK_HZ, source="profiles/r02_issue_model.txt")
+            return u
+        if wl.name == "cfg3":
+            executed = stats["iters_sum"] / world + (stats["frames"] - stats["ldpc_fail"]) / world
+            views = {"ldpc_decode_kernel": issue_view("ldpc_decode_kernel", "ldpc_totals R3/4", executed, kernels["ldpc_decode_kernel"]["ms_per_step"])}
+            for kname in ("mix_fft_kernel", "track_kernel", "track_pilot_kernel"):
+                if kname in kernels:
+                    views[kname] = issue_view(kname, kname, wl.launch_units * kernels[kname]["launches_per_step"], kernels[kname]["ms_per_step"])
+            if dom in views:
+                res = max(views[dom], key=views[dom].get)
+                roofline.update({"bound": res, "compute": {"resource": {"valu": "vector issue (4 SIMDs per CU)", "salu": "scalar issue",
+                                                                        "lds": "LDS pipeline"}[res],
+                                                           "frac": views[dom][res], "all": views[dom]},
+                                 "hbm_frac": kernels[dom]["frac"]})
+        if dom == "ldpc_decode_kernel" and wl.name == "cfg4":       # the message-passing kernel (R1/4 has no totals placement)
             rate = int(wl.ctx.cfg.code_rate)
             # (LDS read/store pairs per iteration over both steps, lane-linear layout?) per code
             pairs, linear = {0: (70, False), 1: (49, False), 2: (49, False), 3: (48, True), 4: (36, True), 5: (24, True)}[rate]
@@ -650,10 +682,11 @@ def main():
                                                      "peak_lds_cycles_per_s": CLOCK_HZ * props.multi_processor_count,
                                                      "frac_of_lds_peak": frac},
                              "hbm_frac": kernels[dom]["frac"]})
-        roofline["note"] = ("achieved = algorithmic bytes per launch / mean launch duration (HIP events around every launch of a "
-                            "repeat of the timed steps); bound = what limits the dominant kernel: 'lds' for the LDPC decoder (its "
-                            "check/variable message exchange saturates the CU's LDS pipeline; HBM fraction kept as hbm_frac), 'hbm' "
-                            "otherwise. DESIGN.md 4/6 derive both from profiles/r02_*")
+        roofline["note"] = ("achieved/peak/frac = HBM view: algorithmic bytes per launch / mean launch duration (HIP events around every "
+                            "launch of a repeat of the timed steps) against 8 TB/s. bound = the busiest unit of the dominant kernel where an "
+                            "issue model exists (compute.frac: issue cycles from PMC instruction counts x measured per-opcode costs, "
+                            "profiles/r02_issue_model.txt, over the cycles the launch had; kernels.*.issue for the others); 'lds' with the "
+                            "cycle model of DESIGN.md 4.2 for the message-passing decoder (cfg4); 'hbm' otherwise")
 
     # ---- CPU baseline: the compiled reference on the host's physical cores, bounded sample (rank 0, N=1 only) ----
     cpu = None
