@@ -183,19 +183,24 @@ __global__ __launch_bounds__(kLdpcThreads, WAVES) void ldpc_totals_kernel(
             });
             if (all_hold) { ok = 1; --it; break; }                             // checkParity passed after iteration it - 1
             if (it >= max_iterations) break;
-            __syncthreads();
+            __syncthreads();                  // one wavefront per workgroup: an LDS drain (measured: no cost against leaving it out)
             // ---- variable phase: total = llr_in + sum of the check messages in ascending check order (:206-213) ----
             float tots[VR];
-            ldpc_static_for(std::make_integer_sequence<int, VR>{}, [&](auto round) {
-                constexpr int r = decltype(round)::value;
-                float c[D];
+            {
+                // all gathers of the phase first, then the sums: one wait for the lot instead of one per round
+                float c[VR][D];
 #pragma unroll
-                for (int q = 0; q < D; ++q) c[q] = ldsf(caddr[r][q]);         // a missing edge reads the pad word: -0.0f
-                float tot = llr_v[r];
+                for (int r = 0; r < VR; ++r)
 #pragma unroll
-                for (int q = 0; q < D; ++q) tot += c[q];
-                tots[r] = tot;
-            });
+                    for (int q = 0; q < D; ++q) c[r][q] = ldsf(caddr[r][q]);  // a missing edge reads a pad word: -0.0f
+#pragma unroll
+                for (int r = 0; r < VR; ++r) {
+                    float tot = llr_v[r];
+#pragma unroll
+                    for (int q = 0; q < D; ++q) tot += c[r][q];
+                    tots[r] = tot;
+                }
+            }
             {
                 static_assert(VR >= 4 && VR <= 7, "variable rounds of the covered codes");
                 // ONE asm statement (M0 must not change between its write and the stores): the phase's lane-linear stores
