@@ -5,7 +5,7 @@ mode table around that (tools/test_nvis_mode.cpp:169-260; tests/regression_matri
 success rates).  BASELINE.json configs[3] and [4] are those loops at Monte-Carlo scale:
 
   configs[3]  LDPC R1/4, 50-iteration min-sum, Es/N0 sweep -11 .. +30 dB, 2^20 codewords per point
-  configs[4]  {DBPSK, DQPSK, D8PSK, 16QAM, 32QAM} x {R1/4, R1/2, R2/3, R3/4, R5/6} BER/FER curves, 2^22 frames
+  configs[4]  {DBPSK, DQPSK, D8PSK, 16QAM, 32QAM} x {R1/4, R1/3, R1/2, R2/3, R3/4, R5/6} BER/FER curves, 2^22 frames
 
 Shape here: the trials of ONE point are a contiguous index range [0, n); rank r of W owns
 shard_range(n, r, W), generates the stimulus of exactly those indices on its own GPU (counter-based generators:
@@ -31,9 +31,9 @@ from .types import CodeRate, Modulation, ModemConfig, is_differential, presets
 CFG4_SNR_POINTS = tuple(float(s) for s in range(-11, 31))
 # BASELINE.json configs[4]: the mode x rate grid ("DPSK" = the reference's DBPSK, types.hpp:27-39)
 CFG5_MODULATIONS = (Modulation.DBPSK, Modulation.DQPSK, Modulation.D8PSK, Modulation.QAM16, Modulation.QAM32)
-CFG5_RATES = (CodeRate.R1_4, CodeRate.R1_2, CodeRate.R2_3, CodeRate.R3_4, CodeRate.R5_6)
+CFG5_RATES = (CodeRate.R1_4, CodeRate.R1_3, CodeRate.R1_2, CodeRate.R2_3, CodeRate.R3_4, CodeRate.R5_6)
 # AWGN SNR over the whole audio band as the reference harness defines it (tools/test_nvis_mode.cpp:78-86): the 59
-# carriers occupy ~6 % of it, so the waterfalls of the 25 cells lie between about -10 and +20 dB
+# carriers occupy ~6 % of it, so the waterfalls of the 30 cells lie between about -10 and +20 dB
 CFG5_SNR_POINTS = tuple(float(s) for s in range(-9, 22, 3))
 
 

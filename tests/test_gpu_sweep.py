@@ -87,13 +87,13 @@ def test_mode_sweep_recount_and_subsample(oracle):
 
 
 def test_mode_sweep_full_grid_counts():
-    """All 25 cells of configs[4] x two SNR points x 1024 frames through mode_sweep itself: every point counts its
-    frames, labels and seeds are those of the grid, and the curves document holds 25 curves."""
+    """All 30 cells of configs[4] x two SNR points x 1024 frames through mode_sweep itself: every point counts its
+    frames, labels and seeds are those of the grid, and the curves document holds 30 curves."""
     from projectultra_amd.sweep import CFG5_MODULATIONS, CFG5_RATES, curves_document, mode_sweep
     pts = mode_sweep(None, [0.0, 18.0], frames_per_point=1024, batch=1024)
     assert len(pts) == 50 and len({p.seed for p in pts}) == 50
     doc = curves_document("mode_sweep", pts, channel="awgn")
-    assert len(doc["curves"]) == len(CFG5_MODULATIONS) * len(CFG5_RATES) and doc["total_trials"] == 50 * 1024
+    assert len(doc["curves"]) == len(CFG5_MODULATIONS) * len(CFG5_RATES) and doc["total_trials"] == 60 * 1024
     for label, curve in doc["curves"].items():
         assert [p["frames"] for p in curve] == [1024, 1024] and curve[0]["fer"] >= curve[1]["fer"], label
     assert doc["curves"]["DBPSK R1_4"][1]["fer"] == 0.0 and doc["curves"]["QAM32 R5_6"][0]["fer"] == 1.0

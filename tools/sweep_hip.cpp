@@ -6,7 +6,7 @@
 //   g++ -O2 -std=c++20 -Iinclude tools/sweep_hip.cpp -Lprojectultra_amd -lultra_hip -Wl,-rpath,$PWD/projectultra_amd \
 //       -ldl -pthread -o sweep_hip
 //   ./sweep_hip --config cfg4 [--trials 1048576] [--gpus N] [--snr-from -11 --snr-to 30 --snr-step 1]
-//   ./sweep_hip --config cfg5 [--trials 15360]   [--gpus N]
+//   ./sweep_hip --config cfg5 [--trials 12800]   [--gpus N]
 //
 // Multi-GPU (one process, one host thread and one context per device): the trials of a point are the index range
 // [0, n); device g owns [g n / G, (g + 1) n / G), generates exactly those trials in its own HBM, decodes them, counts on
@@ -118,7 +118,7 @@ int main(int argc, char** argv) {
     }
     const bool cfg4 = config == "cfg4";
     if (!cfg4 && config != "cfg5") { std::fprintf(stderr, "--config cfg4|cfg5\n"); return 2; }
-    if (!trials) trials = cfg4 ? (1ull << 20) : 15360;
+    if (!trials) trials = cfg4 ? (1ull << 20) : 12800;
     if (snr_from > 1e8) { snr_from = cfg4 ? -11 : -9; snr_to = cfg4 ? 30 : 21; snr_step = cfg4 ? 1 : 3; }
     if (!batch) batch = cfg4 ? (1u << 20) : (1u << 16);
     const int visible = ultra_hip_device_count();
@@ -141,10 +141,10 @@ int main(int argc, char** argv) {
     static const char* rate_names[] = {"R1_4", "R1_3", "R1_2", "R2_3", "R3_4", "R5_6"};
     if (cfg4) {
         cells.push_back({Modulation::DQPSK, static_cast<CodeRate>(rate_arg), std::string("LDPC_") + rate_names[rate_arg % 6]});
-    } else {                                                   // tools/test_nvis_mode.cpp:172-185 widened to BASELINE's 5 x 5 grid
+    } else {                                                   // tools/test_nvis_mode.cpp:172-185 widened to BASELINE's 5 x 6 grid
         const std::pair<Modulation, const char*> mods[] = {{Modulation::DBPSK, "DBPSK"}, {Modulation::DQPSK, "DQPSK"},
                                                            {Modulation::D8PSK, "D8PSK"}, {Modulation::QAM16, "QAM16"}, {Modulation::QAM32, "QAM32"}};
-        const CodeRate rates[] = {CodeRate::R1_4, CodeRate::R1_2, CodeRate::R2_3, CodeRate::R3_4, CodeRate::R5_6};
+        const CodeRate rates[] = {CodeRate::R1_4, CodeRate::R1_3, CodeRate::R1_2, CodeRate::R2_3, CodeRate::R3_4, CodeRate::R5_6};
         for (const auto& m : mods) for (CodeRate r : rates)
             cells.push_back({m.first, r, std::string(m.second) + "_" + rate_names[static_cast<unsigned>(r)]});
     }
