@@ -1060,7 +1060,11 @@ __global__ __launch_bounds__(kWave, 6) void track_kernel(
         reinterpret_cast<c32*>(st + kStH)[lane] = sh.H[lane];
         if (D.differential) reinterpret_cast<c32*>(st + kStDprev)[lane] = dprev;
         if (lane == 0) {
-            store_track(st, tr);
+            // only what the carrier half owns (equalize_demap: pilot_phase_correction, has_dprev) — the rest of the
+            // record's scalars belong to the pilot half and to mix_fft_kernel, which may already be working on the
+            // next symbol of this frame on the main stream (launch_demod)
+            st[st_ppc_re] = tr.ppc.re; st[st_ppc_im] = tr.ppc.im;
+            st[st_flags] = (float)(tr.cpc_init | (tr.has_prev << 1) | (tr.has_dprev << 2));
             if (state_out) {
                 float* so = state_out + (size_t)frame * ULTRA_HIP_STATE_FLOATS;
                 so[ULTRA_HIP_STATE_FREQ_OFFSET_HZ] = tr.freq_offset_hz;

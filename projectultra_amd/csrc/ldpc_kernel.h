@@ -90,13 +90,26 @@ __device__ __forceinline__ float fmin2abs(float x, float y) {
 // Leave-one-out minima of n magnitudes under a cap: mn[i] = min(cap, min_{j != i} |v[j]|).  Minima are exact and
 // associative, so any network gives the reference's value.  n = 7 (a full row: six information edges and the
 // parity bit) is the hand-counted 12-operation network; the general case runs a prefix and a suffix chain.
+// The cap is wave-uniform (FLT_MAX in iteration 0, 50 afterwards): as a scalar operand of the minimum it needs no
+// vector register and no per-round v_mov / v_cndmask to materialise it (one SGPR source per VOP3 instruction on gfx9).
+__device__ __forceinline__ float fmin3abs_cap(float x, float y, float cap) {
+    float r;
+    asm("v_min3_f32 %0, |%1|, |%2|, %3" : "=v"(r) : "v"(x), "v"(y), "s"(__float_as_int(cap)));
+    return r;
+}
+__device__ __forceinline__ float fmin2abs_cap(float x, float cap) {
+    float r;
+    asm("v_min_f32_e64 %0, |%1|, %2" : "=v"(r) : "v"(x), "s"(__float_as_int(cap)));
+    return r;
+}
+
 template <int n>
 __device__ __forceinline__ void leave_one_out_min(const float (&a)[7], float cap, float (&mn)[7]) {
     if constexpr (n == 7) {
-        const float L2 = fmin3abs(a[0], a[1], cap);             // min of edges 0..1
+        const float L2 = fmin3abs_cap(a[0], a[1], cap);         // min of edges 0..1
         const float L4 = fmin3abs(L2, a[2], a[3]);              // 0..3
         const float L6 = fmin3abs(L4, a[4], a[5]);              // 0..5
-        const float R4 = fmin3abs(a[5], a[6], cap);             // 5..6
+        const float R4 = fmin3abs_cap(a[5], a[6], cap);         // 5..6
         const float R3 = fmin2abs(R4, a[4]);                    // 4..6
         const float R2 = fmin3abs(R4, a[4], a[3]);              // 3..6
         mn[0] = fmin3abs(R2, a[2], a[1]);
@@ -107,23 +120,24 @@ __device__ __forceinline__ void leave_one_out_min(const float (&a)[7], float cap
         mn[5] = fmin3abs(L4, a[4], a[6]);
         mn[6] = L6;
     } else if constexpr (n == 2) {
-        mn[0] = fmin2abs(a[1], cap);
-        mn[1] = fmin2abs(a[0], cap);
+        mn[0] = fmin2abs_cap(a[1], cap);
+        mn[1] = fmin2abs_cap(a[0], cap);
     } else if constexpr (n == 3) {
-        mn[0] = fmin3abs(a[1], a[2], cap);
-        mn[1] = fmin3abs(a[0], a[2], cap);
-        mn[2] = fmin3abs(a[0], a[1], cap);
+        mn[0] = fmin3abs_cap(a[1], a[2], cap);
+        mn[1] = fmin3abs_cap(a[0], a[2], cap);
+        mn[2] = fmin3abs_cap(a[0], a[1], cap);
     } else {
         // pre[i] = min(cap, |a[0..i-1]|), suf[i] = min(|a[i..n-1]|); mn[i] = min(pre[i], suf[i+1])
         float pre[7], suf[7];
-        pre[0] = cap;
+        pre[1] = fmin2abs_cap(a[0], cap);
 #pragma unroll
-        for (int i = 1; i < n; ++i) pre[i] = fmin2abs(pre[i - 1], a[i - 1]);
+        for (int i = 2; i < n; ++i) pre[i] = fmin2abs(pre[i - 1], a[i - 1]);
         suf[n - 1] = a[n - 1];
 #pragma unroll
         for (int i = n - 2; i >= 1; --i) suf[i] = fmin2abs(suf[i + 1], a[i]);
+        mn[0] = fmin2abs_cap(suf[1], cap);
 #pragma unroll
-        for (int i = 0; i < n - 1; ++i) mn[i] = fmin2abs(pre[i], suf[i + 1]);
+        for (int i = 1; i < n - 1; ++i) mn[i] = fmin2abs(pre[i], suf[i + 1]);
         mn[n - 1] = pre[n - 1];
     }
 }
