@@ -623,13 +623,23 @@ __global__ __launch_bounds__(kWave, 5) void track_pilot_kernel(const DemodConst*
                 reinterpret_cast<c32*>(st + kStH)[ps] = h_new;
                 reinterpret_cast<c32*>(st + kStPrev)[sub] = h;
             }
-            if (sub == 0) {
-                st[st_cfo] = tr.freq_offset_hz; st[st_cfo_filt] = tr.freq_offset_filtered;
-                st[st_noise] = tr.noise_variance; st[st_snr] = tr.snr_linear; st[st_timing] = tr.timing;
-                st[st_ppc_re] = tr.ppc.re; st[st_ppc_im] = tr.ppc.im; st[st_cpc_re] = tr.cpc.re; st[st_cpc_im] = tr.cpc.im;
-                st[st_flags] = (float)(tr.cpc_init | (tr.has_prev << 1) | (tr.has_dprev << 2));
-                st[st_count] = (float)tr.snr_symbol_count; st[st_since] = (float)tr.symbols_since_sync;
-            }
+            // Every lane of the group carries the frame's scalars: lane `sub` stores scalar `sub` — one store
+            // instruction per wavefront writing 52 contiguous bytes per record, where lane 0 storing all twelve was
+            // twelve instructions of four 4-byte writes each.  st_cfo_phase belongs to mix_fft_kernel.
+            static_assert(st_since == 12 && st_cfo_phase == 2 && G >= 13, "scalar block layout");
+            float mine = tr.freq_offset_hz;
+            mine = (sub == st_cfo_filt) ? tr.freq_offset_filtered : mine;
+            mine = (sub == st_noise) ? tr.noise_variance : mine;
+            mine = (sub == st_snr) ? tr.snr_linear : mine;
+            mine = (sub == st_timing) ? tr.timing : mine;
+            mine = (sub == st_ppc_re) ? tr.ppc.re : mine;
+            mine = (sub == st_ppc_im) ? tr.ppc.im : mine;
+            mine = (sub == st_cpc_re) ? tr.cpc.re : mine;
+            mine = (sub == st_cpc_im) ? tr.cpc.im : mine;
+            mine = (sub == st_flags) ? (float)(tr.cpc_init | (tr.has_prev << 1) | (tr.has_dprev << 2)) : mine;
+            mine = (sub == st_count) ? (float)tr.snr_symbol_count : mine;
+            mine = (sub == st_since) ? (float)tr.symbols_since_sync : mine;
+            if (sub <= st_since && sub != st_cfo_phase) st[sub] = mine;
         }
     }
 }
