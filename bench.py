@@ -409,8 +409,10 @@ class LdpcSweepWorkload:
 
 
 class ModeSweepWorkload:
-    """cfg5: the 5 x 5 mode/rate grid x 11 SNR points per step — one receive context per cell, n frames per point per
-    GPU, audio of every point resident in HBM, one all-reduce per point."""
+    """cfg5: the 5 x 6 mode/rate grid x 11 SNR points per step — one receive context per cell, n frames per point per
+    GPU, audio of every point resident in HBM.  The 11 points of a cell go through demodulate + decode as ONE batch (the
+    receive path does not depend on the SNR, frames are independent; with ~2 k frames per point the path is otherwise
+    bound by launch latency), are counted per point, and the cell's [11][8] counter block is all-reduced once."""
 
     def __init__(self, args, rank, world, torch):
         from projectultra_amd.montecarlo import shard_range
@@ -419,50 +421,54 @@ class ModeSweepWorkload:
         self.n = args.frames or 1920
         self.snrs = list(CFG5_SNR_POINTS)
         self.cells = [(m, r) for m in CFG5_MODULATIONS for r in CFG5_RATES]
-        lo, _ = shard_range(self.n * world, rank, world)
+        S, n = len(self.snrs), self.n
+        lo, _ = shard_range(n * world, rank, world)
         t0 = time.time()
         self.shards, self.audio, self.payload, self.outs = [], [], [], []
         resident = 0
         for ci, (m, r) in enumerate(self.cells):
-            sh = HipModemShard(nvis_cell_config(m, r), channel="awgn", batch=self.n)
+            sh = HipModemShard(nvis_cell_config(m, r), channel="awgn", batch=n)
             g = sh.ctx.geometry
-            a_cell, p_cell = [], []
+            audio = torch.empty((S * n, g.frame_samples), dtype=torch.float32, device="cuda")
+            payload = torch.empty((S * n, g.ldpc_k // 8), dtype=torch.uint8, device="cuda")
             for si, snr in enumerate(self.snrs):
-                a, p = sh.ctx.make_batch(self.n, seed=point_seed(0x5EED, ci * len(self.snrs) + si), first_frame=lo, channel="awgn", snr_db=snr)
-                a_cell.append(a); p_cell.append(p); resident += a.numel() * 4
-            self.shards.append(sh); self.audio.append(a_cell); self.payload.append(p_cell)
-            self.outs.append(dict(bytes=torch.empty((self.n, g.decoded_bytes), dtype=torch.uint8, device="cuda"),
-                                  iters=torch.empty(self.n, dtype=torch.int32, device="cuda"),
-                                  ok=torch.empty(self.n, dtype=torch.uint8, device="cuda")))
+                sh.ctx.make_batch(n, seed=point_seed(0x5EED, ci * S + si), first_frame=lo, channel="awgn", snr_db=snr,
+                                  out=(audio[si * n:(si + 1) * n], payload[si * n:(si + 1) * n]))
+            resident += audio.numel() * 4
+            self.shards.append(sh); self.audio.append(audio); self.payload.append(payload)
+            self.outs.append(dict(bytes=torch.empty((S * n, g.decoded_bytes), dtype=torch.uint8, device="cuda"),
+                                  iters=torch.empty(S * n, dtype=torch.int32, device="cuda"),
+                                  ok=torch.empty(S * n, dtype=torch.uint8, device="cuda")))
         torch.cuda.synchronize()
         self.t_gen = time.time() - t0
-        P = len(self.cells) * len(self.snrs)
+        P = len(self.cells) * S
         self.counters = torch.zeros((P, 8), dtype=torch.int64, device="cuda")
-        self.units_per_step = self.n * P
+        self.units_per_step = n * P
         self.points_per_step = P
-        self.metric = "adaptive-mode Monte-Carlo frames decoded/sec (5 modulations x 5 code rates x 11 SNR points)"
+        self.collectives_per_step = len(self.cells)
+        self.collective_op = f"all_reduce(SUM) of {S} x 8 x int64 (the points of one mode/rate cell)"
+        self.metric = "adaptive-mode Monte-Carlo frames decoded/sec (5 modulations x 6 code rates x 11 SNR points)"
         self.unit = "frames/s"
-        self.bytes_per_unit = resident / (self.n * P) + 4 + 648 * 4 + 60 + 4      # mean over the grid
+        self.bytes_per_unit = resident / (n * P) + 4 + 648 * 4 + 60 + 4      # mean over the grid
         # per launch and frame: one symbol of audio (1120 samples) into mix_fft; the LLRs out of track_kernel and the
         # decoder's in/out differ from cell to cell (mean over the grid used)
         self.per_launch = {"mix_fft_kernel": 1120 * 4, "ldpc_decode_kernel": 648 * 4 + 50 + 4 + 1}
-        self.launch_units = self.n
+        self.launch_units = n * S
         self.geo = self.shards[0].ctx.geometry
-        self.data = (f"synthetic ({P} points x {self.n} distinct frames per GPU generated on the device in HBM, AWGN; "
+        self.data = (f"synthetic ({P} points x {n} distinct frames per GPU generated on the device in HBM, AWGN; "
                      f"{resident / 1e9:.1f} GB of audio resident)")
-        self.workload = (f"{{DBPSK,DQPSK,D8PSK,16QAM,32QAM}} x {{R1/4,R1/2,R2/3,R3/4,R5/6}} on OFDM 1024-FFT / 59 carriers, SNR "
-                         f"{self.snrs[0]:g}..{self.snrs[-1]:g} dB in 3 dB steps, post-sync entry, {self.n} frames per point per GPU per step")
-        self.parallelism = f"frames of every point sharded over {world} GPU(s), one counter all-reduce per point"
+        self.workload = (f"{{DBPSK,DQPSK,D8PSK,16QAM,32QAM}} x {{R1/4,R1/3,R1/2,R2/3,R3/4,R5/6}} on OFDM 1024-FFT / 59 carriers, SNR "
+                         f"{self.snrs[0]:g}..{self.snrs[-1]:g} dB in 3 dB steps, post-sync entry, {n} frames per point per GPU per step, "
+                         f"the {S} points of a cell in one batch")
+        self.parallelism = f"frames of every point sharded over {world} GPU(s), one all-reduce of the counter block per mode/rate cell"
 
     def step(self, allreduce):
         self.counters.zero_()
-        k = 0
-        for sh, a_cell, p_cell, out in zip(self.shards, self.audio, self.payload, self.outs):
-            for a, p in zip(a_cell, p_cell):
-                r = sh.ctx.demod_decode(a, out=out)
-                sh.ctx.count_errors(r, p, self.counters[k])
-                allreduce(self.counters[k])
-                k += 1
+        S, n = len(self.snrs), self.n
+        for ci, (sh, audio, payload, out) in enumerate(zip(self.shards, self.audio, self.payload, self.outs)):
+            r = sh.ctx.demod_decode(audio, out=out)
+            sh.ctx.count_errors_points(r, payload, self.counters[ci * S:(ci + 1) * S])
+            allreduce(self.counters[ci * S:(ci + 1) * S])
 
     def contexts(self):
         return [sh.ctx for sh in self.shards]
@@ -479,7 +485,9 @@ class ModeSweepWorkload:
         o = oracle()
         ref = Ref() if have_ref() else None
         ccfg0 = make_config(1024, "QAM16", "R3_4")
-        probe = self.audio[18][8][:512].cpu().numpy()                       # the 16QAM R3/4 cell
+        S, n = len(self.snrs), self.n
+        c16 = next(i for i, (m, r) in enumerate(self.cells) if (m.name, r.name) == ("QAM16", "R3_4"))
+        probe = self.audio[c16][8 * n:8 * n + min(512, n)].cpu().numpy()     # the 16QAM R3/4 cell, 15 dB
 
         def rate(t):
             t0 = time.perf_counter()
@@ -492,7 +500,7 @@ class ModeSweepWorkload:
         total = 0
         for (m, r), sh, a_cell in zip(self.cells, self.shards, self.audio):
             ccfg = make_config(1024, m.name, r.name)
-            audio = np.concatenate([a[:per].cpu().numpy() for a in a_cell])
+            audio = np.concatenate([a_cell[si * n:si * n + per].cpu().numpy() for si in range(S)])
             got = sh.ctx.demod_decode(self.torch.from_numpy(audio).cuda())
             got = {k: v.cpu().numpy() for k, v in got.items()}
             t0 = time.perf_counter()
@@ -717,7 +725,8 @@ def main():
             "fer": stats["fer"], "ber": stats["ber"], "mean_bp_iterations": stats["mean_iters"], "trials_counted": stats["frames"],
             "stimulus_seconds": wl.t_gen,
             "collective": {"backend": backend or "none (single process, no process group)", "world_size": dist.get_world_size() if distributed else 1,
-                           "op": "all_reduce(SUM) of 8 x int64", "per_step": wl.points_per_step, "allreduce_us": ar_us},
+                           "op": getattr(wl, "collective_op", "all_reduce(SUM) of 8 x int64"),
+                           "per_step": getattr(wl, "collectives_per_step", wl.points_per_step), "allreduce_us": ar_us},
             "roofline": roofline, "cpu_baseline": cpu,
         }
         if hasattr(wl, "curves"):

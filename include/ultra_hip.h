@@ -242,6 +242,13 @@ int ultra_hip_count_errors(ultra_hip_ctx* ctx, const uint8_t* d_bytes, const int
                            const uint8_t* d_ok, const uint8_t* d_payload, size_t payload_bytes,
                            size_t n_frames, ultra_hip_counters* d_counters);
 
+/* The same for a batch that holds several sweep points back to back (the points of one BER/FER curve share their
+ * demodulate + decode launches — the receive path does not depend on the SNR, tools/test_mode_snr.cpp:126-160 is a
+ * loop over it): frames [p * frames_per_point, (p + 1) * frames_per_point) accumulate into d_counters[p]. */
+int ultra_hip_count_errors_points(ultra_hip_ctx* ctx, const uint8_t* d_bytes, const int32_t* d_iters,
+                                  const uint8_t* d_ok, const uint8_t* d_payload, size_t payload_bytes,
+                                  size_t n_points, size_t frames_per_point, ultra_hip_counters* d_counters);
+
 /* The one collective of the path: sum the eight Monte-Carlo counters over the ranks of an
  * RCCL communicator, in place, on the context's stream.  rccl_comm is the host's ncclComm_t (one process
  * per GPU, created with ncclCommInitRank; torch.distributed users call dist.all_reduce on the tensor

@@ -469,9 +469,14 @@ __global__ __launch_bounds__(256) void count_errors_kernel(
     const uint8_t* __restrict__ bytes, size_t bytes_stride, const int32_t* __restrict__ iters,
     const uint8_t* __restrict__ okv, const uint8_t* __restrict__ payload, int payload_bytes,
     int n_frames, unsigned long long* __restrict__ counters) {
+    // blockIdx.y = sweep point: frames [y * n_frames, (y + 1) * n_frames) accumulate into counters[8 * y ..]
+    // (ultra_hip_count_errors_points; the single-point entry launches one row)
     __shared__ unsigned long long acc[8];
     if (threadIdx.x < 8) acc[threadIdx.x] = 0;
     __syncthreads();
+    const size_t first = (size_t)blockIdx.y * (size_t)n_frames;
+    bytes += first * bytes_stride; iters += first; okv += first; payload += first * (size_t)payload_bytes;
+    counters += 8 * (size_t)blockIdx.y;
     unsigned long long c[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     for (int f = blockIdx.x * blockDim.x + threadIdx.x; f < n_frames; f += gridDim.x * blockDim.x) {
         const uint8_t* d = bytes + (size_t)f * bytes_stride;

@@ -876,6 +876,24 @@ int ultra_hip_count_errors(ultra_hip_ctx* ctx, const uint8_t* d_bytes, const int
     return ULTRA_HIP_OK;
 }
 
+int ultra_hip_count_errors_points(ultra_hip_ctx* ctx, const uint8_t* d_bytes, const int32_t* d_iters, const uint8_t* d_ok,
+                                  const uint8_t* d_payload, size_t payload_bytes, size_t n_points, size_t frames_per_point,
+                                  ultra_hip_counters* d_counters) {
+    if (!ctx) return ULTRA_HIP_ERR_INVALID_ARG;
+    if (n_points == 0 || frames_per_point == 0) return ULTRA_HIP_OK;
+    if (!d_bytes || !d_iters || !d_ok || !d_payload || !d_counters || payload_bytes == 0 ||
+        payload_bytes > ctx->geo.decoded_bytes || frames_per_point > 0x7fffffffull || n_points > 65535)
+        return ULTRA_HIP_ERR_INVALID_ARG;
+    DeviceGuard guard(ctx->device);
+    const unsigned gx = (unsigned)std::min<size_t>((frames_per_point + 255) / 256, (size_t)ctx->cu_count * 8);
+    LaunchSpan span(ctx, ULTRA_HIP_K_COUNT);
+    hipLaunchKernelGGL(dev::count_errors_kernel, dim3(gx, (unsigned)n_points), dim3(256), 0, ctx->stream, d_bytes,
+                       (size_t)ctx->geo.decoded_bytes, d_iters, d_ok, d_payload, (int)payload_bytes, (int)frames_per_point,
+                       reinterpret_cast<unsigned long long*>(d_counters));
+    UH_HIP(hipGetLastError());
+    return ULTRA_HIP_OK;
+}
+
 int ultra_hip_set_deinterleave(ultra_hip_ctx* ctx, uint32_t bits_per_symbol) {
     if (!ctx) return ULTRA_HIP_ERR_INVALID_ARG;
     if (bits_per_symbol >= (uint32_t)kLdpcN) return ULTRA_HIP_ERR_INVALID_ARG;

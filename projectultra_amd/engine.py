@@ -320,14 +320,20 @@ class ReceiveContext:
         return out
 
     def make_batch(self, n_frames: int, seed: int = 0x5EED, first_frame: int = 0, channel: str = "awgn",
-                   snr_db: float = 30.0, delay_ms: float = 0.5, doppler_hz: float = 0.1):
+                   snr_db: float = 30.0, delay_ms: float = 0.5, doppler_hz: float = 0.1, out=None):
         """Synthetic frames at the SYNCED entry, generated on the device (ultra_hip_make_batch): random
         payload -> encode -> preamble + modulate -> 0.5 peak -> channel.  Returns (audio [n][frame_samples],
-        payload [n][k // 8]) device tensors.  Bit-identical to the oracle's uo_make_batch for channel "none"."""
+        payload [n][k // 8]) device tensors; `out` may hand in that pair (e.g. row slices of a larger batch) to be
+        overwritten.  Bit-identical to the oracle's uo_make_batch for channel "none"."""
         torch = _torch()
         g = self.geometry
-        audio = torch.empty((n_frames, g.frame_samples), dtype=torch.float32, device=self.device)
-        payload = torch.empty((n_frames, g.ldpc_k // 8), dtype=torch.uint8, device=self.device)
+        if out is None:
+            audio = torch.empty((n_frames, g.frame_samples), dtype=torch.float32, device=self.device)
+            payload = torch.empty((n_frames, g.ldpc_k // 8), dtype=torch.uint8, device=self.device)
+        else:
+            audio, payload = out
+            self._check_out(audio, (n_frames, g.frame_samples), torch.float32, "audio")
+            self._check_out(payload, (n_frames, g.ldpc_k // 8), torch.uint8, "payload")
         kind = dict(none=0, awgn=1, watterson=2)[channel]
         check(self.lib.ultra_hip_make_batch(self._ctx, int(seed), int(first_frame), n_frames, kind, float(snr_db),
                                             float(delay_ms), float(doppler_hz), audio.data_ptr(), self._row_stride(audio),
@@ -415,6 +421,21 @@ class ReceiveContext:
         check(self.lib.ultra_hip_count_errors(self._ctx, result["bytes"].data_ptr(), result["iters"].data_ptr(),
                                               result["ok"].data_ptr(), payload.data_ptr(), pb, n,
                                               counters.data_ptr()), "ultra_hip_count_errors")
+        return counters
+
+    def count_errors_points(self, result, payload, counters):
+        """The counters of a batch that holds n_points sweep points of equal size back to back: rows
+        [p * n, (p + 1) * n) accumulate into counters[p] (device int64 [n_points][8]); one launch."""
+        torch = _torch()
+        payload = self._dev(payload, torch.uint8, "payload")
+        rows, pb = payload.shape
+        self._check_out(counters, (counters.shape[0], 8), torch.int64, "counters")
+        n_points = counters.shape[0]
+        if n_points == 0 or rows % n_points != 0 or result["iters"].shape[0] != rows:
+            raise _lib.UltraHipError(-1, "count_errors_points: the batch must hold counters.shape[0] points of equal size")
+        check(self.lib.ultra_hip_count_errors_points(self._ctx, result["bytes"].data_ptr(), result["iters"].data_ptr(),
+                                                     result["ok"].data_ptr(), payload.data_ptr(), pb, n_points, rows // n_points,
+                                                     counters.data_ptr()), "ultra_hip_count_errors_points")
         return counters
 
     def selftest_math(self, fn: int, a, b=None):

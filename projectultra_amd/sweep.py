@@ -11,7 +11,8 @@ Shape here: the trials of ONE point are a contiguous index range 
 shard_range(n, r, W), generates the stimulus of exactly those indices on its own GPU (counter-based generators:
 the union over ranks is the same set of trials whatever W is), pushes them through the HIP path in batches,
 accumulates the eight uint64 counters on the device, and the ranks meet in ONE all-reduce per point (64 bytes;
-RCCL over xGMI with the "nccl" backend, gloo in the CPU tests).  Nothing else crosses GPUs.
+RCCL over xGMI with the "nccl" backend, gloo in the CPU tests) — per CURVE for the mode sweep, whose points share
+their launches (HipModemShard.run_points) and reduce as one [points][8] block.  Nothing else crosses GPUs.
 
 The per-shard work is behind a small interface (`run(lo, hi, snr_db, seed) -> int64[8]`): HipLdpcShard and
 HipModemShard are the product; the CPU tests drive the same loops with a stub that counts on the host.
@@ -106,6 +107,7 @@ class HipModemShard:
         self.batch = int(batch)
         self._torch = torch
         self._out = None
+        self._pts = None
 
     def run(self, lo: int, hi: int, snr_db: float, seed: int, keep=None):
         torch = self._torch
@@ -126,6 +128,41 @@ class HipModemShard:
             self.ctx.count_errors(r, payload, counters)
             if keep is not None:
                 keep(f0, audio, payload, r)
+        return counters
+
+    def run_points(self, lo: int, hi: int, snr_points: Sequence[float], seeds: Sequence[int]):
+        """Frames [lo, hi) of SEVERAL points of this cell as one batch per demodulate + decode (the receive path does
+        not depend on the SNR — only the stimulus does — and frames are independent, so the points of a curve share
+        launches: with a few thousand frames per point the path is otherwise bound by launch latency, ~30 launches
+        per point).  Per-point stimulus and per-point counters; returns device int64 [len(snr_points)][8], row i equal
+        to run(lo, hi, snr_points[i], seeds[i])."""
+        torch = self._torch
+        g, dev = self.ctx.geometry, self.ctx.device
+        n, P = hi - lo, len(snr_points)
+        counters = torch.zeros((P, 8), dtype=torch.int64, device=dev)
+        if n <= 0 or P == 0:
+            return counters
+        if n > self.batch:                                         # a point larger than a batch: the per-point loop
+            for i in range(P):
+                counters[i] = self.run(lo, hi, float(snr_points[i]), int(seeds[i]))
+            return counters
+        per = max(1, self.batch // n)                              # points per batch
+        rows = min(per, P) * n
+        if self._pts is None or self._pts["audio"].shape[0] < rows:
+            self._pts = dict(audio=torch.empty((rows, g.frame_samples), dtype=torch.float32, device=dev),
+                             payload=torch.empty((rows, g.ldpc_k // 8), dtype=torch.uint8, device=dev),
+                             bytes=torch.empty((rows, g.decoded_bytes), dtype=torch.uint8, device=dev),
+                             iters=torch.empty(rows, dtype=torch.int32, device=dev),
+                             ok=torch.empty(rows, dtype=torch.uint8, device=dev))
+        b = self._pts
+        for p0 in range(0, P, per):
+            k = min(per, P - p0)
+            for i in range(k):
+                self.ctx.make_batch(n, seed=int(seeds[p0 + i]), first_frame=lo, channel=self.channel, snr_db=float(snr_points[p0 + i]),
+                                    delay_ms=self.delay_ms, doppler_hz=self.doppler_hz,
+                                    out=(b["audio"][i * n:(i + 1) * n], b["payload"][i * n:(i + 1) * n]))
+            r = self.ctx.demod_decode(b["audio"][:k * n], out={q: b[q][:k * n] for q in ("bytes", "iters", "ok")})
+            self.ctx.count_errors_points(r, b["payload"][:k * n], counters[p0:p0 + k])
         return counters
 
 
@@ -160,12 +197,25 @@ def sweep(label: str, shard, snr_points: Sequence[float], n_trials: int, seed: i
           world: int = 1, group=None, first_point_index: int = 0, on_point: Optional[Callable] = None) -> List[SweepPoint]:
     """The SNR loop around the trial loop (tools/test_mode_snr.cpp:126-160) for one code / mode."""
     out = []
-    for i, snr in enumerate(snr_points):
-        ps = point_seed(seed, first_point_index + i)
+    seeds = [point_seed(seed, first_point_index + i) for i in range(len(snr_points))]
+    if hasattr(shard, "run_points"):
+        # the curve's points share launches (HipModemShard.run_points); ONE all-reduce of the [points][8] block
+        lo, hi = shard_range(n_trials, rank, world)
         t0 = time.perf_counter()
-        c = run_point(shard, n_trials, snr, ps, rank, world, group)
-        p = SweepPoint(label=label, snr_db=float(snr), trials=int(n_trials), seed=ps, counters=counters_dict(c),
-                       seconds=time.perf_counter() - t0)
+        block = allreduce_counters(shard.run_points(lo, hi, [float(x) for x in snr_points], seeds), group=group).cpu()
+        dt = (time.perf_counter() - t0) / max(len(snr_points), 1)
+        per_point = [(block[i], dt) for i in range(len(snr_points))]
+    else:
+        per_point = None
+    for i, snr in enumerate(snr_points):
+        ps = seeds[i]
+        if per_point is not None:
+            c, dt = per_point[i]
+        else:
+            t0 = time.perf_counter()
+            c = run_point(shard, n_trials, snr, ps, rank, world, group)
+            dt = time.perf_counter() - t0
+        p = SweepPoint(label=label, snr_db=float(snr), trials=int(n_trials), seed=ps, counters=counters_dict(c), seconds=dt)
         if p.counters["frames"] != n_trials:
             raise RuntimeError(f"sweep point {label} @ {snr} dB counted {p.counters['frames']} of {n_trials} trials")
         out.append(p)

@@ -44,3 +44,7 @@ class OracleModemShard:
                                            n_threads=self.n_threads)
         r = self.o.demod_decode_batch(self.cfg, audio, n_threads=self.n_threads, want_llr=False, want_state=False)
         return torch.from_numpy(count(r["bytes"], r["iters"], r["ok"], payload))
+
+    def run_points(self, lo, hi, snr_points, seeds):
+        """HipModemShard.run_points' contract: row i = run(lo, hi, snr_points[i], seeds[i]); the driver reduces the block."""
+        return torch.stack([self.run(lo, hi, s, sd) for s, sd in zip(snr_points, seeds)]) if len(snr_points) else torch.zeros((0, 8), dtype=torch.int64)

@@ -260,7 +260,7 @@ def test_cpp_sweep_harness_equals_python_driver(tmp_path):
     assert r.returncode == 0, r.stdout[-400:] + r.stderr[-400:]
     rows = pat.findall(r.stdout)
     want = mode_sweep(None, [0.0, 12.0], frames_per_point=2048, seed=5)
-    assert len(rows) == 50
+    assert len(rows) == 60
     for row, p in zip(rows, want):
         assert row[0] == p.label.replace(" ", "_") and [int(v) for v in row[2:]] == [p.counters[k] for k in keys], (row, p.counters)
 

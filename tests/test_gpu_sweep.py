@@ -91,9 +91,30 @@ def test_mode_sweep_full_grid_counts():
     frames, labels and seeds are those of the grid, and the curves document holds 30 curves."""
     from projectultra_amd.sweep import CFG5_MODULATIONS, CFG5_RATES, curves_document, mode_sweep
     pts = mode_sweep(None, [0.0, 18.0], frames_per_point=1024, batch=1024)
-    assert len(pts) == 50 and len({p.seed for p in pts}) == 50
+    assert len(pts) == 60 and len({p.seed for p in pts}) == 60
     doc = curves_document("mode_sweep", pts, channel="awgn")
     assert len(doc["curves"]) == len(CFG5_MODULATIONS) * len(CFG5_RATES) and doc["total_trials"] == 60 * 1024
     for label, curve in doc["curves"].items():
         assert [p["frames"] for p in curve] == [1024, 1024] and curve[0]["fer"] >= curve[1]["fer"], label
     assert doc["curves"]["DBPSK R1_4"][1]["fer"] == 0.0 and doc["curves"]["QAM32 R5_6"][0]["fer"] == 1.0
+
+
+def test_run_points_equals_run_per_point():
+    """The points of a curve sharing their launches (HipModemShard.run_points: one demodulate + decode per batch of
+    points) give, row by row, exactly the counters of one run() per point — whatever the grouping: all points in one
+    batch, two per batch, a ragged last group, and a point larger than the batch (per-point fallback)."""
+    from projectultra_amd import CodeRate, Modulation
+    from projectultra_amd.sweep import HipModemShard, nvis_cell_config, point_seed
+    snrs = [-3.0, 0.0, 3.0, 6.0, 9.0]
+    seeds = [point_seed(5, i) for i in range(len(snrs))]
+    for mod, rate in [(Modulation.DQPSK, CodeRate.R1_2), (Modulation.QAM16, CodeRate.R3_4)]:
+        mc = nvis_cell_config(mod, rate)
+        want = None
+        for batch in (1 << 14, 1500, 700, 300):                   # 5, 2, 1 points per batch of 700 frames; 300 < 700: fallback
+            shard = HipModemShard(mc, channel="awgn", batch=batch)
+            if want is None:
+                want = np.stack([shard.run(100, 800, s, sd).cpu().numpy() for s, sd in zip(snrs, seeds)])
+                assert want[0, 1] > want[-1, 1] and (want[:, 0] == 700).all()
+            got = shard.run_points(100, 800, snrs, seeds).cpu().numpy()
+            assert np.array_equal(got, want), (mod, rate, batch)
+        assert shard.run_points(5, 5, snrs, seeds).sum().item() == 0

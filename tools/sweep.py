@@ -7,7 +7,8 @@
                               --master-port P tools/sweep.py --config cfg4 ...
 
 cfg4: LDPC R1/4 (or --rate), BPSK over AWGN, one point per dB from -11 to +30 dB Es/N0, --trials codewords per point
-      (2^20 in BASELINE.json) sharded over the ranks, ONE all-reduce of the eight counters per point.
+      (2^20 in BASELINE.json) sharded over the ranks, ONE all-reduce of the eight counters per point (cfg5: of the
+      [points][8] block per curve — the points of a curve share their launches).
 cfg5: {DBPSK, DQPSK, D8PSK, 16QAM, 32QAM} x {R1/4, R1/3, R1/2, R2/3, R3/4, R5/6} on the NVIS geometry (1024-FFT, 59 carriers,
       tools/test_nvis_mode.cpp:195-212), --trials frames per point; the default 30 cells x 11 SNR points x 12,800 frames
       = 4,224,000 frames, the 2^22 of BASELINE.json.
