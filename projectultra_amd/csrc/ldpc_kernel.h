@@ -250,13 +250,18 @@ __global__ __launch_bounds__(kLdpcThreads, WAVES) void ldpc_decode_kernel(
     // index; llr_step == 1 is the identity.  llr_perm (nullable): a general gather table out[j] = in[llr_perm[j]]
     // (ultra_hip_set_deinterleave_table: any 648-entry permutation, e.g. the row-column Interleaver::deinterleave,
     // ldpc_decoder.cpp:454-466,530-540) takes precedence over the step.
+    // The table case is a separate loop behind ONE uniform branch: with the choice made per load, every asynchronous
+    // copy sat behind a conditional index load and its wait (measured on the R1/4 sweep: 10 ms of 73 per 5.5 M codewords).
     auto fetch = [&](int c) {
         const float* src = llr + (size_t)c * llr_stride;
-        for (int j0 = 0; j0 < n; j0 += kLdpcThreads)
-            if (j0 + lane < n)
-                __builtin_amdgcn_global_load_lds(src + (llr_perm ? (unsigned)llr_perm[j0 + lane]
-                                                                 : (unsigned)((j0 + lane) * llr_step) % (unsigned)kLdpcN),
-                                                 llr_s + j0, 4, 0, 0);
+        if (llr_perm) {
+            for (int j0 = 0; j0 < n; j0 += kLdpcThreads)
+                if (j0 + lane < n) __builtin_amdgcn_global_load_lds(src + (unsigned)llr_perm[j0 + lane], llr_s + j0, 4, 0, 0);
+        } else {
+            for (int j0 = 0; j0 < n; j0 += kLdpcThreads)
+                if (j0 + lane < n)
+                    __builtin_amdgcn_global_load_lds(src + (unsigned)((j0 + lane) * llr_step) % (unsigned)kLdpcN, llr_s + j0, 4, 0, 0);
+        }
     };
     int cw = claim();
     if (cw >= 0) fetch(cw);
@@ -303,27 +308,45 @@ __global__ __launch_bounds__(kLdpcThreads, WAVES) void ldpc_decode_kernel(
 
         int it = 0, ok = 0;
         unsigned F = 1u;                                                       // syndrome filter of iteration it-1
-        for (;;) {
+        // exact parity test (checkParity :139-151) on the byte array `hard` and the given totals of the parity bits
+        auto rows_hold = [&](const float (&par_total)[RR]) -> bool {
+            int bad = 0;
+#pragma unroll
+            for (int r = 0; r < RR; ++r) {
+                if (row_ok[r]) {
+                    const int row = r * 64 + lane;
+                    int s = (par_total[r] < 0) ? 1 : 0;
+                    for (int t = 0; t < 6; ++t) {
+                        const unsigned c = P.row_col[row * 6 + t];
+                        if (c != 0xFFFFu) s ^= hard[c];
+                    }
+                    bad |= s;
+                }
+            }
+            return __ballot(bad != 0) == 0ull;
+        };
+        // A codeword whose channel hard decisions already satisfy every row converges at iteration 0 with exactly those
+        // bits (in a satisfied row the product of the other edges' signs is the edge's own sign: every check message
+        // pushes its variable further the way it already points, no total changes sign — for any input, a NaN counting
+        // as + like `x < 0` does).  So the filter is first evaluated on the channel values; when it vanishes the exact
+        // test runs on them (`hard` holds their decisions), and the decode ends before its first iteration instead of
+        // after it.  Kept OUT of the iteration loop: reaching the test from iteration 0 inside it cost the loop 20 %.
+        if (!WANT_TOTAL && P.max_iterations > 0) {
+            unsigned f0 = 0u;
+#pragma unroll
+            for (int r = 0; r < VR; ++r) f0 ^= (llr_v[r] < 0) ? vmask[r] : 0u;
+#pragma unroll
+            for (int r = 0; r < RR; ++r) f0 ^= (llr_p[r] < 0) ? rmask[r] : 0u;
+            if (wave_xor(f0) == 0u && rows_hold(llr_p)) ok = 1;
+        }
+        while (!ok) {
             if (it > 0 && F == 0u) {
-                // ---- exact parity test (checkParity :139-151); reached once per converged codeword ----
+                // ---- reached once per converged codeword ----
 #pragma unroll
                 for (int r = 0; r < VR; ++r)
                     if (var_deg[r] > 0) hard[var_j[r]] = (tvar[r] < 0) ? 1 : 0;
                 __syncthreads();
-                int bad = 0;
-#pragma unroll
-                for (int r = 0; r < RR; ++r) {
-                    if (row_ok[r]) {
-                        const int row = r * 64 + lane;
-                        int s = (tpar[r] < 0) ? 1 : 0;
-                        for (int t = 0; t < 6; ++t) {
-                            const unsigned c = P.row_col[row * 6 + t];
-                            if (c != 0xFFFFu) s ^= hard[c];
-                        }
-                        bad |= s;
-                    }
-                }
-                if (__ballot(bad != 0) == 0ull) { ok = 1; --it; break; }
+                if (rows_hold(tpar)) { ok = 1; --it; break; }
             }
             if (it >= P.max_iterations) break;
 

@@ -87,20 +87,29 @@ __global__ __launch_bounds__(kLdpcThreads, WAVES) void ldpc_totals_kernel(
     // (ChannelInterleaver::deinterleave, ldpc_decoder.cpp:609-617: out[j] = in[(j * step) % 648]; step 1 = identity)
     // llr_perm (nullable): a general gather table out[j] = in[llr_perm[j]] (ultra_hip_set_deinterleave_table)
     auto src_index = [&](int j) -> unsigned { return llr_perm ? (unsigned)llr_perm[j] : (unsigned)(j * llr_step) % (unsigned)kLdpcN; };
+    // Source element of each staging slot of this lane: a property of the launch, not of the codeword — computed once
+    // (the plan lookup, the table lookup or the modulo would otherwise sit in front of every asynchronous copy).
+    unsigned short src_v[VR], src_p[RR];
+#pragma unroll
+    for (int r = 0; r < VR; ++r) {
+        const unsigned j = P.var_id[r * 64 + lane];
+        src_v[r] = (j != 0xFFFFu) ? (unsigned short)src_index((int)j) : (unsigned short)0xFFFFu;
+    }
+#pragma unroll
+    for (int r = 0; r < RR; ++r) {
+        const unsigned i = P.row_check[r * 64 + lane];
+        src_p[r] = (i != 0xFFFFu) ? (unsigned short)src_index(k + (int)i) : (unsigned short)0xFFFFu;
+    }
     auto fetch = [&](int c) {
         const float* src = llr + (size_t)c * llr_stride;
         float* stage_v = reinterpret_cast<float*>(lds_raw + STAGE_V);
         float* stage_p = reinterpret_cast<float*>(lds_raw + STAGE_P);
 #pragma unroll
-        for (int r = 0; r < VR; ++r) {
-            const unsigned j = P.var_id[r * 64 + lane];
-            if (j != 0xFFFFu) __builtin_amdgcn_global_load_lds(src + src_index((int)j), stage_v + r * 64, 4, 0, 0);
-        }
+        for (int r = 0; r < VR; ++r)
+            if (src_v[r] != 0xFFFFu) __builtin_amdgcn_global_load_lds(src + src_v[r], stage_v + r * 64, 4, 0, 0);
 #pragma unroll
-        for (int r = 0; r < RR; ++r) {
-            const unsigned i = P.row_check[r * 64 + lane];
-            if (i != 0xFFFFu) __builtin_amdgcn_global_load_lds(src + src_index(k + (int)i), stage_p + r * 64, 4, 0, 0);
-        }
+        for (int r = 0; r < RR; ++r)
+            if (src_p[r] != 0xFFFFu) __builtin_amdgcn_global_load_lds(src + src_p[r], stage_p + r * 64, 4, 0, 0);
     };
 
     // Lanes without a row / variable in some round run the SAME instruction stream on harmless operands (their gather
@@ -144,7 +153,12 @@ __global__ __launch_bounds__(kLdpcThreads, WAVES) void ldpc_totals_kernel(
             const float cap = (it == 0) ? kFltMax : 50.0f;                    // clamp deferred to the reader, see ldpc_kernel.h
             // checkParity (:139-151) passes iff EVERY row's equation holds.  Round 0's rows are always evaluated; the
             // other rounds only while no failing row has been seen — far from convergence the first round settles it.
-            bool all_hold = it > 0;                                            // wave-uniform
+            // Iteration 0 gathers the channel values themselves (T = llr_in, check_to_var = 0): if THEIR hard decisions
+            // satisfy every row, the reference converges at iteration 0 with exactly those bits — in a satisfied row the
+            // product of the other edges' signs is the edge's own sign, so every check message pushes its variable
+            // further the way it already points and no total changes sign (any input: a NaN counts as +, as `x < 0` does).
+            // The decode then ends here, after the verdict, instead of after one full iteration and the next one's gathers.
+            bool all_hold = it > 0 || (!WANT_TOTAL && max_iterations > 0);     // wave-uniform
             ldpc_static_for(std::make_integer_sequence<int, RR>{}, [&](auto round) {
                 constexpr int r = decltype(round)::value;
                 float v[7], mn[7], tot[6];
@@ -181,7 +195,7 @@ __global__ __launch_bounds__(kLdpcThreads, WAVES) void ldpc_totals_kernel(
                                 "n"(R_BASE + (r * 6 + 3) * 256), "n"(R_BASE + (r * 6 + 4) * 256), "n"(R_BASE + (r * 6 + 5) * 256)
                              : "m0", "memory");
             });
-            if (all_hold) { ok = 1; --it; break; }                             // checkParity passed after iteration it - 1
+            if (all_hold) { ok = 1; if (it > 0) --it; break; }                 // checkParity passed after iteration it - 1 (or holds at 0)
             if (it >= max_iterations) break;
             __syncthreads();                  // one wavefront per workgroup: an LDS drain (measured: no cost against leaving it out)
             // ---- variable phase: total = llr_in + sum of the check messages in ascending check order (:206-213) ----
