@@ -173,3 +173,25 @@ def v2_frame_cases(oracle, rate, rng, deint_bps=0):
     cases.append(("noise", rng.normal(0, 2.0, 3 * 648).astype(np.float32)))
     cases.append(("short", rng.normal(0, 2.0, 100).astype(np.float32) - 5.0))
     return cases
+
+
+def valid_special_codewords(rng, oracle, rate, n=48):
+    """Codewords whose channel HARD decisions satisfy every row although the magnitudes are anything: zeros, negative
+    zeros and NaNs on bit-0 positions (`x < 0` is false for all three), denormals, infinities, 3e38.  Row i: kind i % 4 —
+    0 wild palette, 1 tame, 2 tame with one bit flipped (no longer valid), 3 wild with one bit flipped; row 0 is the
+    all-zero word.  The reference ends kinds 0 and 1 at iteration 0 (ldpc_decoder.cpp:227-235)."""
+    k = INFO_BITS[rate]
+    llr = np.zeros((n, 648), np.float32)
+    pal0 = np.array([0.0, -0.0, np.nan, 1e-45, 1e-40, 0.5, 7.25, 50.0, 1e30, 3e38, np.inf], np.float32)      # bit 0
+    pal1 = -np.array([1e-45, 1e-40, 0.5, 7.25, 50.0, 1e30, 3e38, np.inf], np.float32)                       # bit 1
+    for i in range(n):
+        pl = bytes(rng.integers(0, 256, k // 8, dtype=np.uint8)) if i else bytes(k // 8)
+        bits = np.unpackbits(np.frombuffer(oracle.ldpc_encode(rate, pl), np.uint8))[:648]
+        kind = i % 4
+        p0 = pal0 if kind in (0, 3) else pal0[5:8]
+        p1 = pal1 if kind in (0, 3) else pal1[2:5]
+        llr[i] = np.where(bits == 0, p0[rng.integers(0, len(p0), 648)], p1[rng.integers(0, len(p1), 648)])
+        if kind >= 2:
+            j = int(rng.integers(0, 648))
+            llr[i, j] = np.float32(-3.0) if bits[j] == 0 else np.float32(3.0)
+    return llr

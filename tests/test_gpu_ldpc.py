@@ -5,7 +5,7 @@ fixtures in tests/golden/ldpc.npz come straight from the compiled reference."""
 import numpy as np
 import pytest
 
-from _util import INFO_BITS, beq, noisy_codewords, nonfinite_cases
+from _util import INFO_BITS, beq, noisy_codewords, nonfinite_cases, valid_special_codewords
 from conftest import GOLDEN
 
 pytestmark = pytest.mark.gpu
@@ -322,3 +322,24 @@ def test_counters_allreduce_over_rccl_two_ranks(tmp_path):
     assert r.returncode == 0, r.stdout[-1500:] + r.stderr[-1500:]
     assert r.stdout.count("ok") == 2
 
+
+
+@pytest.mark.parametrize("rate", RATES)
+def test_valid_codewords_with_special_magnitudes_end_at_iteration_0(oracle, rate):
+    """Codewords whose channel hard decisions already satisfy every row: the kernels end them before the first
+    iteration (bits = the channel decisions, iterations = 0), which must be what the reference's iteration 0 produces
+    for ANY magnitudes — zeros, negative zeros and NaNs on bit-0 positions (`x < 0` is false for all three), denormals,
+    infinities, 3e38, one flipped-but-still-valid all-zero word — and, one bit away from valid, must not trigger."""
+    llr = valid_special_codewords(np.random.default_rng(900 + rate), oracle, rate)
+    d = _decoder(rate)
+    ob, oi, ook, ototal = oracle.ldpc_decode_batch(rate, llr, want_total=True)
+    assert (oi[0::4] == 0).all() and (ook[0::4] == 1).all() and (oi[1::4] == 0).all()      # the reference ends them at 0
+    assert (oi[2::4] > 0).any()
+    r = d.decode_batch(llr)                                     # the shortcut's path
+    assert np.array_equal(r["iters"], oi) and np.array_equal(r["ok"], ook) and np.array_equal(r["bytes"], ob)
+    r = d.decode_batch(llr, want_total=True)                    # the full iteration (totals wanted)
+    assert np.array_equal(r["iters"], oi) and np.array_equal(r["ok"], ook) and np.array_equal(r["bytes"], ob)
+    got = np.asarray(r["llr_total"])
+    assert np.array_equal(np.isnan(got), np.isnan(ototal))
+    both_nan = np.isnan(got)
+    assert beq(np.where(both_nan, np.float32(0), got), np.where(both_nan, np.float32(0), ototal))

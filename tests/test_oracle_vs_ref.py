@@ -3,7 +3,7 @@ box that received the prebuilt .so).  Everything is compared BITWISE, stage by s
 import numpy as np
 import pytest
 
-from _util import beq, chirp_streams, long_acquisition_streams, nonfinite_cases
+from _util import beq, chirp_streams, long_acquisition_streams, nonfinite_cases, valid_special_codewords
 from oracle.bindings import INFO_BITS, geometry, make_config
 
 
@@ -28,6 +28,20 @@ def test_fec_nonfinite_inputs(oracle, ref):
     for rate in range(6):
         for llr in nonfinite_cases(rng, oracle, rate):
             assert oracle.ldpc_decode_soft(rate, llr) == ref.ldpc_decode_soft(rate, llr)
+
+
+def test_fec_valid_codewords_with_special_magnitudes(oracle, ref):
+    """What the HIP kernels' iteration-0 shortcut relies on, on the compiled reference itself: a word whose channel hard
+    decisions satisfy every row is decoded to exactly those bits with lastIterations() == 0, whatever the magnitudes."""
+    for rate in range(6):
+        llr = valid_special_codewords(np.random.default_rng(900 + rate), oracle, rate, n=24)
+        for i, row in enumerate(llr):
+            want = ref.ldpc_decode_soft(rate, row)
+            assert oracle.ldpc_decode_soft(rate, row) == want, (rate, i)
+            if i % 4 < 2:
+                out, ok, iters = want[:3]
+                hard = np.packbits((row[:INFO_BITS[rate]] < 0).astype(np.uint8)).tobytes()
+                assert ok and iters == 0 and bytes(out)[:len(hard)] == hard, (rate, i)
 
 
 def test_interleavers(oracle, ref):
