@@ -132,7 +132,9 @@ def parse_pmc(path):
 
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument("--pmc", default=str(ROOT / "profiles" / "r02_sq_counters.txt"))
+    ap.add_argument("--pmc", nargs="*", default=[str(ROOT / "profiles" / f) for f in ("r02_sq_counters.txt", "r02_sq_counters_cfg4.txt",
+                                                                                     "r02_sq_counters_raw.txt", "r02_sq_counters_chirp.txt")],
+                    help="pmc_sweep.sh summaries (kernels of later files do not replace those of earlier ones)")
     ap.add_argument("--asm", default="")
     ap.add_argument("--cus", type=int, default=256)
     args = ap.parse_args()
@@ -145,7 +147,11 @@ def main():
                                        "-fhip-fp32-correctly-rounded-divide-sqrt", "-S", "--cuda-device-only", "-o", "-", str(src)],
                                       stderr=subprocess.DEVNULL, cwd=src.parent).decode()
     fns = functions(asm)
-    pmc = parse_pmc(args.pmc) if Path(args.pmc).exists() else {}
+    pmc = {}
+    for f in args.pmc:
+        if Path(f).exists():
+            for k, v in parse_pmc(f).items():
+                pmc.setdefault(k, v)
     clk = costs["clock_ghz"] * 1e9
     print(f"# costs (profiles/r02_issue_table.txt, W = 5 wavefronts per SIMD): 2-cycle class {costs['fast']:.2f}, 4-cycle class {costs['slow']:.2f}, "
           f"8-cycle class {costs['eight']:.2f}, readlane {costs['readlane']:.2f}, scalar {costs['salu']:.2f} cycles per wave-instruction; clock {costs['clock_ghz']:.3f} GHz")
@@ -154,7 +160,7 @@ def main():
             ("ldpc_decode_kernelILi8ELi3E", "ldpc_decode_kernel<8, 3", True),
             ("mix_fft_kernelILi10E", "mix_fft_kernel<10>", False), ("track_kernelILi6E", "track_kernel<6>", False),
             ("track_pilot_kernelILi16E", "track_pilot_kernel<16>", False), ("cfo_walk_kernel", "cfo_walk_kernel", False),
-            ("acquire_kernelILi10E", "acquire_kernel<10>", False)]
+            ("acquire_kernelILi10E", "acquire_kernel<10>", False), ("chirp_sync_kernel", "chirp_sync_kernel", False)]
     for key, pmc_key, is_ldpc in want:
         names = [n for n in fns if key in n and ("Lb0ELi" in n or not is_ldpc or "totals" in n)]
         if is_ldpc and "decode_kernel" in key:
