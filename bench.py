@@ -49,10 +49,10 @@ LDS_CYC = dict(read_b32=2, write_b32=4, write_addtid_b32=2)
 #   valu / salu: cycles of ONE SIMD per unit (a CU has 4 SIMDs); lds: cycles of the CU's single LDS pipeline per unit.
 #   unit: "cw_iteration" = one executed BP iteration of one codeword; "frame" = one frame of one launch.
 ISSUE_CYCLES = {
-    "ldpc_totals R3/4": dict(unit="cw_iteration", valu=165 * 3.40, salu=76.5 * 4.19, lds=61.6 * 2.13),
+    "ldpc_totals R3/4": dict(unit="cw_iteration", valu=162.5 * 3.38, salu=80.4 * 4.19, lds=61.5 * 2.13),
     "mix_fft_kernel": dict(unit="frame", valu=1139 * 3.51, salu=136 * 4.19, lds=81.4 * 3.52),
-    "track_kernel": dict(unit="frame", valu=202 * 3.27, salu=104 * 4.19, lds=20.9 * 3.93),
-    "track_pilot_kernel": dict(unit="frame", valu=133 * 3.39, salu=55.5 * 4.19, lds=4.75 * 5.08),
+    "track_kernel": dict(unit="frame", valu=195 * 3.28, salu=104 * 4.19, lds=20.9 * 3.93),
+    "track_pilot_kernel": dict(unit="frame", valu=143.7 * 3.46, salu=57.4 * 4.19, lds=4.75 * 5.08),
 }
 
 
