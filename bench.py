@@ -53,6 +53,8 @@ ISSUE_CYCLES = {
     "mix_fft_kernel": dict(unit="frame", valu=1139 * 3.51, salu=136 * 4.19, lds=81.4 * 3.52),
     "track_kernel": dict(unit="frame", valu=195 * 3.28, salu=104 * 4.19, lds=20.9 * 3.93),
     "track_pilot_kernel": dict(unit="frame", valu=143.7 * 3.46, salu=57.4 * 4.19, lds=4.75 * 5.08),
+    # per raw stream of 14,400 samples at 30 dB (profiles/r02_sq_counters_raw.txt: 65,536 streams per launch)
+    "acquire_kernel": dict(unit="stream", valu=952.8e3 * 3.35, salu=134.7e3 * 4.19, lds=166.4e3 * 3.33),
 }
 
 
@@ -673,6 +675,12 @@ def main():
                                                                         "lds": "LDS pipeline"}[res],
                                                            "frac": views[dom][res], "all": views[dom]},
                                  "hbm_frac": kernels[dom]["frac"]})
+        if wl.name == "raw" and dom == "acquire_kernel":
+            v = issue_view(dom, "acquire_kernel", wl.launch_units * kernels[dom]["launches_per_step"], kernels[dom]["ms_per_step"])
+            res = max(v, key=v.get)
+            roofline.update({"bound": res, "compute": {"resource": {"valu": "vector issue (4 SIMDs per CU)", "salu": "scalar issue",
+                                                                    "lds": "LDS pipeline"}[res], "frac": v[res], "all": v},
+                             "hbm_frac": kernels[dom]["frac"]})
         if dom == "ldpc_decode_kernel" and wl.name == "cfg4":       # the message-passing kernel (R1/4 has no totals placement)
             rate = int(wl.ctx.cfg.code_rate)
             # (LDS read/store pairs per iteration over both steps, lane-linear layout?) per code

@@ -6,7 +6,10 @@ out = sys.argv[1]
 config = sys.argv[2] if len(sys.argv) > 2 else "cfg3"
 units = int(sys.argv[3]) if len(sys.argv) > 3 else 262144
 commit = sys.argv[4] if len(sys.argv) > 4 else None
-KEYS = ("ldpc_decode_kernel", "mix_fft_kernel", "track_pilot_kernel", "track_kernel", "cfo_walk_kernel", "init_state_kernel",
+# (substring of the kernel name, key in the output) — the key is the kernel CLASS bench.py reports (ultra_hip_kernel_class):
+# both decoders (ldpc_totals_kernel for R2/3 .. R5/6, ldpc_decode_kernel otherwise) are "ldpc_decode_kernel" there
+ALIASES = {"ldpc_totals_kernel": "ldpc_decode_kernel"}
+KEYS = ("ldpc_totals_kernel", "ldpc_decode_kernel", "mix_fft_kernel", "track_pilot_kernel", "track_kernel", "cfo_walk_kernel", "init_state_kernel",
         "count_errors_kernel", "acquire_kernel", "train_kernel")
 acc = collections.defaultdict(lambda: collections.defaultdict(list))
 for c in ("FETCH_SIZE", "WRITE_SIZE"):
@@ -16,7 +19,7 @@ for c in ("FETCH_SIZE", "WRITE_SIZE"):
             name = r["Kernel_Name"]
             for key in KEYS:                       # first match wins: track_pilot_kernel before track_kernel
                 if key in name:
-                    acc[key][c].append(float(r["Counter_Value"]) * 1024.0)
+                    acc[ALIASES.get(key, key)][c].append(float(r["Counter_Value"]) * 1024.0)
                     break
 res = {"config": config, "n_frames": units, "commit": commit, "collected": time.strftime("%Y-%m-%dT%H:%M:%SZ", time.gmtime()),
        "method": "rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate passes (bench.py --steps 1 --warmup 0 --no-build), "
