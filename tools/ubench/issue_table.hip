@@ -18,7 +18,7 @@ enum Kind {
     K_ADD_F32, K_MUL_F32, K_FMA_F32, K_MIN3_ABS, K_MIN2_ABS, K_CMP_SGPR, K_CNDMASK_NEG, K_CMP_CNDMASK, K_MOV, K_ADD_U32,
     K_XOR, K_PK_ADD, K_PK_MUL, K_FMA_F64, K_MUL_F64, K_ADD_F64, K_CVT_F64_F32, K_CVT_F32_F64, K_RCP_F32, K_XOR_DPP,
     K_READLANE, K_SALU_XOR64, K_MIX_LDPC_ROW, K_BFI, K_AND_OR, K_MIN3_PLAIN, K_MIN2_E32, K_AND, K_CMP_GT_I32, K_CMP_VCC, K_CNDMASK_VCC,
-    K_SDWA_ADD, K_LSHL_OR, K_SUB_F32,
+    K_SDWA_ADD, K_LSHL_OR, K_SUB_F32, K_CVT_I32_F64, K_CVT_F64_I32, K_TRUNC_F64, K_FLOOR_F64,
     K_DS_READ_B32, K_DS_READ_B64, K_DS_READ2_B32, K_DS_READ_B128, K_DS_WRITE_B32, K_DS_WRITE_ADDTID, K_DS_WRITE_B64,
     K_DS_MIX_LDPC, K_N
 };
@@ -28,10 +28,10 @@ static const char* kNames[K_N] = {
     "v_fma_f64", "v_mul_f64", "v_add_f64", "v_cvt_f64_f32", "v_cvt_f32_f64", "v_rcp_f32", "v_xor_b32 dpp quad_perm",
     "v_readlane_b32", "s_xor_b64", "ldpc row mix (7cmp 12min 7mul 7cnd)", "v_bfi_b32", "v_and_or_b32", "v_min3_f32 (no modifiers)",
     "v_min_f32_e32", "v_and_b32", "v_cmp_gt_i32 -> sgpr pair", "v_cmp_lt_f32 -> vcc (e32)", "v_cndmask_b32 (vcc, e32)",
-    "v_add_u32_sdwa WORD_1", "v_lshl_or_b32", "v_sub_f32",
+    "v_add_u32_sdwa WORD_1", "v_lshl_or_b32", "v_sub_f32", "v_cvt_i32_f64", "v_cvt_f64_i32", "v_trunc_f64", "v_floor_f64",
     "ds_read_b32", "ds_read_b64", "ds_read2_b32", "ds_read_b128", "ds_write_b32", "ds_write_addtid_b32", "ds_write_b64",
     "ldpc lds mix (2 rd,1 wr,1 addtid)"};
-static const int kInstrPerBlock[K_N] = {8, 8, 8, 8, 8, 8, 8, 8, 8, 8, 8, 8, 8, 8, 8, 8, 8, 8, 8, 8, 8, 8, 33, 8, 8, 8, 8, 8, 8, 8, 8, 8, 8, 8,
+static const int kInstrPerBlock[K_N] = {8, 8, 8, 8, 8, 8, 8, 8, 8, 8, 8, 8, 8, 8, 8, 8, 8, 8, 8, 8, 8, 8, 33, 8, 8, 8, 8, 8, 8, 8, 8, 8, 8, 8, 8, 8, 8, 8,
                                         8, 8, 8, 8, 8, 8, 8, 8};
 
 template <int KIND>
@@ -238,6 +238,22 @@ __global__ __launch_bounds__(64) void k(unsigned long long* cyc, float* sink, in
                 asm volatile("v_sub_f32 %0, %0, %8\n v_sub_f32 %1, %1, %8\n v_sub_f32 %2, %2, %8\n v_sub_f32 %3, %3, %8\n"
                              "v_sub_f32 %4, %4, %8\n v_sub_f32 %5, %5, %8\n v_sub_f32 %6, %6, %8\n v_sub_f32 %7, %7, %8"
                              : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7) : "v"(b0));
+            else if constexpr (KIND == K_CVT_I32_F64)
+                asm volatile("v_cvt_i32_f64 %0, %4\n v_cvt_i32_f64 %1, %5\n v_cvt_i32_f64 %2, %6\n v_cvt_i32_f64 %3, %7\n"
+                             "v_cvt_i32_f64 %0, %5\n v_cvt_i32_f64 %1, %6\n v_cvt_i32_f64 %2, %7\n v_cvt_i32_f64 %3, %4"
+                             : "+v"(u0), "+v"(u1), "+v"(u2), "+v"(u3) : "v"(d0), "v"(d1), "v"(d2), "v"(d3));
+            else if constexpr (KIND == K_CVT_F64_I32)
+                asm volatile("v_cvt_f64_i32 %0, %4\n v_cvt_f64_i32 %1, %5\n v_cvt_f64_i32 %2, %6\n v_cvt_f64_i32 %3, %7\n"
+                             "v_cvt_f64_i32 %0, %5\n v_cvt_f64_i32 %1, %6\n v_cvt_f64_i32 %2, %7\n v_cvt_f64_i32 %3, %4"
+                             : "+v"(d0), "+v"(d1), "+v"(d2), "+v"(d3) : "v"(u0), "v"(u1), "v"(u2), "v"(u3));
+            else if constexpr (KIND == K_TRUNC_F64)
+                asm volatile("v_trunc_f64 %0, %0\n v_trunc_f64 %1, %1\n v_trunc_f64 %2, %2\n v_trunc_f64 %3, %3\n"
+                             "v_trunc_f64 %0, %0\n v_trunc_f64 %1, %1\n v_trunc_f64 %2, %2\n v_trunc_f64 %3, %3"
+                             : "+v"(d0), "+v"(d1), "+v"(d2), "+v"(d3));
+            else if constexpr (KIND == K_FLOOR_F64)
+                asm volatile("v_floor_f64 %0, %0\n v_floor_f64 %1, %1\n v_floor_f64 %2, %2\n v_floor_f64 %3, %3\n"
+                             "v_floor_f64 %0, %0\n v_floor_f64 %1, %1\n v_floor_f64 %2, %2\n v_floor_f64 %3, %3"
+                             : "+v"(d0), "+v"(d1), "+v"(d2), "+v"(d3));
             else if constexpr (KIND == K_DS_READ_B32) {
                 float q0, q1, q2, q3, q4, q5, q6, q7;
                 asm volatile("ds_read_b32 %0, %8\n ds_read_b32 %1, %8 offset:256\n ds_read_b32 %2, %8 offset:512\n ds_read_b32 %3, %8 offset:768\n"
