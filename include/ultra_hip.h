@@ -378,6 +378,16 @@ int ultra_hip_make_batch(ultra_hip_ctx* ctx, uint64_t seed, uint64_t first_frame
                          float snr_db, float delay_ms, float doppler_hz, float* d_audio, size_t frame_stride,
                          uint8_t* d_payload);
 
+/* The radio's tuning error as the harnesses model it: WattersonChannel::applyCFO (src/sim/hf_channel.hpp:161-232 — mix
+ * down from 1500 Hz, 48-tap running mean, rotate by the offset, mix back up), applied by WattersonChannel::process after
+ * the noise when abs(cfo_hz) > 0.001 (:163-165).  Every row is shifted by a freshly constructed channel (phase 0), as
+ * the harnesses build one channel per trial; rows shorter than 256 samples and offsets within +-0.001 Hz are copied
+ * unchanged, as the reference leaves them.  Out of place (d_out must not alias d_in); bit-identical to the reference
+ * (the oracle's uo_channel_apply_cfo is pinned to it and the tests compare bitwise).
+ *   d_in  [n_frames][in_stride >= n_samples] f32      d_out [n_frames][out_stride >= n_samples] f32 */
+int ultra_hip_channel_cfo_batch(ultra_hip_ctx* ctx, const float* d_in, size_t in_stride, float* d_out, size_t out_stride,
+                                uint32_t n_samples, size_t n_frames, float cfo_hz);
+
 /* The same transmission as a RAW stream for the end-to-end entry (ultra_hip_receive_batch): `lead` samples of
  * silence, the preamble (OFDMModulator::generatePreamble, 7 symbols), the frame's data symbols, `tail` samples of
  * silence; scaled to a 0.5 peak; channel_kind 0 none, 1 AWGN on every sample of the stream at snr_db relative to the

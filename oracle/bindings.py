@@ -389,6 +389,12 @@ class Oracle(_Base):
         assert rc == 0
         return dict(llr=llr, state=state, bytes=by, iters=it, ok=ok)
 
+    def channel_apply_cfo(self, x, cfo_hz, sample_rate=48000):
+        """WattersonChannel::applyCFO of a fresh channel (hf_channel.hpp:161-232) -> shifted copy."""
+        x = _f32(x).copy()
+        assert self.lib.uo_channel_apply_cfo(C.c_float(cfo_hz), C.c_uint32(sample_rate), _ptr(x), C.c_uint32(x.size)) == 0
+        return x
+
     def watterson(self, x, snr_db, delay_ms, doppler_hz, seed, g1=0.707, g2=0.707, fading=1, multipath=1, noise=1):
         x = _f32(x); out = np.zeros_like(x)
         self.lib.uo_watterson(C.c_float(snr_db), C.c_float(delay_ms), C.c_float(doppler_hz), C.c_float(g1),
@@ -420,6 +426,11 @@ class Ref(_Base):
         if not REF_SO.exists():
             raise FileNotFoundError(f"{REF_SO} not built (needs /root/reference in this container)")
         super().__init__(REF_SO)
+
+    def channel_apply_cfo(self, x, cfo_hz, sample_rate=48000):
+        x = _f32(x).copy()
+        assert self.lib.ref_channel_apply_cfo(C.c_float(cfo_hz), _ptr(x), C.c_uint32(x.size)) == 0
+        return x
 
     def watterson(self, x, snr_db, delay_ms, doppler_hz, seed, g1=0.707, g2=0.707, fading=1, multipath=1, noise=1):
         x = _f32(x); out = np.zeros_like(x)

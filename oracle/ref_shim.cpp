@@ -235,6 +235,18 @@ int ref_watterson(float snr_db, float delay_ms, float doppler_hz, float g1, floa
     return 0;
 }
 
+// WattersonChannel::applyCFO (src/sim/hf_channel.hpp:161-232) of a freshly constructed channel, in place.
+int ref_channel_apply_cfo(float cfo_hz, float* samples, uint32_t n) {
+    sim::WattersonChannel::Config cc;
+    cc.cfo_hz = cfo_hz;
+    cc.sample_rate = 48000;
+    sim::WattersonChannel ch(cc, 1);
+    Samples s(samples, samples + n);
+    ch.applyCFO(s);
+    std::memcpy(samples, s.data(), n * sizeof(float));
+    return 0;
+}
+
 // -------------------------------------------------------------- demodulator
 
 // Full reference receive: fresh demodulator, feed `chunk`-sample pieces

@@ -2211,6 +2211,49 @@ static inline float crng_gauss(crng* r) {
     return (float)(rad * cos(ang));
 }
 
+/* WattersonChannel::applyCFO of a freshly constructed channel (src/sim/hf_channel.hpp:95-101,161-232): the radio's
+ * tuning error as the harnesses model it — mix the passband signal down from 1500 Hz, 48-tap running-mean lowpass,
+ * rotate at baseband by the CFO, mix back up.  Called by process() after the noise when abs(cfo_hz) > 0.001 (:163-165);
+ * buffers shorter than 256 samples pass unchanged (:173).  In place. */
+int uo_channel_apply_cfo(float cfo_hz, uint32_t sample_rate, float* samples, uint32_t n) {
+    if (n < 256) return 0;
+    const float fc = 1500.0f;
+    const float fs = (float)sample_rate;
+    const float phase_inc = (float)((((double)2.0f * M_PI) * (double)cfo_hz) / (double)sample_rate);     /* :101 */
+    float* I_bb = (float*)malloc(4 * (size_t)n * sizeof(float));
+    if (!I_bb) return -1;
+    float *Q_bb = I_bb + n, *I_filt = Q_bb + n, *Q_filt = I_filt + n;
+    for (uint32_t i = 0; i < n; ++i) {
+        const float t = (float)i / fs;
+        const float mix_phase = (float)(((((double)2.0f * M_PI) * (double)fc)) * (double)t);
+        I_bb[i] = samples[i] * cosf(mix_phase);
+        Q_bb[i] = samples[i] * sinf(mix_phase);
+    }
+    const uint32_t win = 48;
+    float I_sum = 0, Q_sum = 0;
+    for (uint32_t i = 0; i < n; ++i) {
+        I_sum += I_bb[i];
+        Q_sum += Q_bb[i];
+        if (i >= win) { I_sum -= I_bb[i - win]; Q_sum -= Q_bb[i - win]; }
+        const uint32_t cnt = (i + 1 < win) ? i + 1 : win;
+        I_filt[i] = I_sum / (float)cnt;
+        Q_filt[i] = Q_sum / (float)cnt;
+    }
+    float phase = 0.0f;
+    for (uint32_t i = 0; i < n; ++i) {
+        const float t = (float)i / fs;
+        const float mix_phase = (float)(((((double)2.0f * M_PI) * (double)fc)) * (double)t);
+        const float cfo_cos = cosf(phase), cfo_sin = sinf(phase);
+        const float I_cfo = I_filt[i] * cfo_cos - Q_filt[i] * cfo_sin;
+        const float Q_cfo = I_filt[i] * cfo_sin + Q_filt[i] * cfo_cos;
+        samples[i] = 2.0f * (I_cfo * cosf(mix_phase) - Q_cfo * sinf(mix_phase));
+        phase += phase_inc;
+        if ((double)phase > (double)2.0f * M_PI) phase = (float)((double)phase - (double)2.0f * M_PI);
+    }
+    free(I_bb);
+    return 0;
+}
+
 /* WattersonChannel ctor + process, src/sim/hf_channel.hpp:66-168,258-275 */
 int uo_watterson(float snr_db, float delay_ms, float doppler_hz, float g1, float g2,
                  int fading, int multipath, int noise, uint64_t seed,

@@ -113,6 +113,8 @@ int uo_modulate_presynced(const ultra_hip_config* c, const uint8_t* encoded, uin
 int uo_watterson(float snr_db, float delay_ms, float doppler_hz, float g1, float g2,
                  int fading, int multipath, int noise, uint64_t seed,
                  const float* in, uint32_t n, float* out);
+/* WattersonChannel::applyCFO of a fresh channel (src/sim/hf_channel.hpp:161-232), in place. */
+int uo_channel_apply_cfo(float cfo_hz, uint32_t sample_rate, float* samples, uint32_t n);
 /* Synthetic batch for tests/bench: for frame f in [f0, f0+n): payload bytes
  * from a counter RNG (seed ^ f), LDPC encode, preamble+modulate, scale to 0.5
  * peak, channel (kind 0 = none, 1 = AWGN, 2 = Watterson), then keep the

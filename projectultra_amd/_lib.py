@@ -65,6 +65,7 @@ PROTOTYPES = {
     "ultra_hip_demod_decode_batch": (_i, [_vp, _vp, _sz, _vp, _vp, _sz, _vp, _vp, _vp, _vp]),
     "ultra_hip_count_errors": (_i, [_vp, _vp, _vp, _vp, _vp, _sz, _sz, _vp]),
     "ultra_hip_count_errors_points": (_i, [_vp, _vp, _vp, _vp, _vp, _sz, _sz, _sz, _vp]),
+    "ultra_hip_channel_cfo_batch": (_i, [_vp, _vp, _sz, _vp, _sz, C.c_uint32, _sz, C.c_float]),
     "ultra_hip_synchronize": (_i, [_vp]),
     "ultra_hip_timer_begin": (_i, [_vp]),
     "ultra_hip_timer_end": (_i, [_vp, C.POINTER(C.c_float)]),

@@ -493,6 +493,65 @@ __global__ __launch_bounds__(kWave) void llr_stimulus_kernel(const LdpcPlan* __r
     }
 }
 
+// ---- WattersonChannel::applyCFO (src/sim/hf_channel.hpp:161-232): the radio's tuning error as the harnesses model it ----
+// Mix the passband signal down from 1500 Hz, 48-tap running-mean lowpass, rotate at baseband, mix back up.  Every
+// frame sees a freshly constructed channel (phase 0, sample index from 0), so the two oscillator sequences — the
+// 1500 Hz mixer and the CFO rotator with its serial float phase recurrence — are the same for every frame of a call:
+// cfo_tables_kernel writes them once (the rotator by one lane, in the reference's order), cfo_shift_kernel then walks
+// one frame per lane with the running sums in the reference's order.  Same operations on the same operands as the
+// reference, libm through pinned_math.h: bit-identical to the oracle's uo_channel_apply_cfo, which is pinned to the
+// compiled reference.
+__global__ __launch_bounds__(256) void cfo_tables_kernel(float phase_inc, float fs, double two_pi_fc, int n,
+                                                         c32* __restrict__ mixer, c32* __restrict__ rotator) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) {
+        const float t = (float)i / fs;
+        const float mix_phase = (float)(two_pi_fc * (double)t);
+        float sn, cs;
+        um::sincosf_(mix_phase, &sn, &cs);
+        mixer[i] = mk(cs, sn);
+    }
+    if (i == 0) {
+        float phase = 0.0f;
+        for (int j = 0; j < n; ++j) {
+            float sn, cs;
+            um::sincosf_(phase, &sn, &cs);
+            rotator[j] = mk(cs, sn);
+            phase += phase_inc;
+            if ((double)phase > kTwoPi) phase = (float)((double)phase - kTwoPi);
+        }
+    }
+}
+
+__global__ __launch_bounds__(64) void cfo_shift_kernel(const float* __restrict__ in, size_t in_stride, float* __restrict__ out,
+                                                       size_t out_stride, int n, int n_frames,
+                                                       const c32* __restrict__ mixer, const c32* __restrict__ rotator) {
+    const int f = blockIdx.x * blockDim.x + threadIdx.x;
+    if (f >= n_frames) return;
+    const float* x = in + (size_t)f * in_stride;
+    float* y = out + (size_t)f * out_stride;
+    constexpr int kWin = 48;
+    float i_sum = 0.0f, q_sum = 0.0f;
+    for (int i = 0; i < n; ++i) {
+        const c32 m = mixer[i];
+        const float xi = x[i];
+        i_sum += xi * m.re;
+        q_sum += xi * m.im;
+        if (i >= kWin) {
+            const c32 mo = mixer[i - kWin];
+            const float xo = x[i - kWin];
+            i_sum -= xo * mo.re;
+            q_sum -= xo * mo.im;
+        }
+        const float cnt = (float)((i + 1 < kWin) ? i + 1 : kWin);
+        const float i_filt = i_sum / cnt, q_filt = q_sum / cnt;
+        const c32 r = rotator[i];
+        const float i_cfo = i_filt * r.re - q_filt * r.im;
+        const float q_cfo = i_filt * r.im + q_filt * r.re;
+        y[i] = 2.0f * (i_cfo * m.re - q_cfo * m.im);
+    }
+}
+
 }  // namespace dev
 }  // namespace ultra_hip
 #endif

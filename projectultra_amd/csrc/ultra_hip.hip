@@ -49,6 +49,8 @@ struct ultra_hip_ctx {
     c32* d_nco_tx = nullptr;
     float* d_preamble = nullptr;         // 7 preamble symbols + [max |x|, sum x^2]
     float* d_ws_fstats = nullptr;
+    c32* d_ws_cfo = nullptr;             // channel CFO shift: mixer and rotator sequences of one call (2 x n samples)
+    size_t ws_cfo_samples = 0;
     size_t ws_fstats_frames = 0;
     int stim_ncw_raw = 0, stim_ncw_enc = 0, stim_tx_symbols = 0, stim_pre_len = 0;
     uint8_t* d_ws_frame = nullptr;       // frame decode: bytes, ok, iters of every codeword
@@ -506,6 +508,7 @@ void ultra_hip_destroy(ultra_hip_ctx* ctx) {
     if (ctx->d_nco_tx) (void)hipFree(ctx->d_nco_tx);
     if (ctx->d_preamble) (void)hipFree(ctx->d_preamble);
     if (ctx->d_ws_fstats) (void)hipFree(ctx->d_ws_fstats);
+    if (ctx->d_ws_cfo) (void)hipFree(ctx->d_ws_cfo);
     if (ctx->d_ws_llr) (void)hipFree(ctx->d_ws_llr);
     if (ctx->d_ws_state) (void)hipFree(ctx->d_ws_state);
     if (ctx->d_ws_fq) (void)hipFree(ctx->d_ws_fq);
@@ -773,6 +776,40 @@ int ultra_hip_make_batch(ultra_hip_ctx* ctx, uint64_t seed, uint64_t first_frame
                        snr_db, delay_samples, fading_alpha, 0.707f, 0.707f, (unsigned long long)seed,
                        (unsigned long long)first_frame, (int)n_frames, ctx->stim_pre_len, total_len, ctx->d_preamble,
                        ctx->d_preamble + 7 * psl, ctx->d_ws_fstats, d_audio, frame_stride);
+    UH_HIP(hipGetLastError());
+    return ULTRA_HIP_OK;
+}
+
+int ultra_hip_channel_cfo_batch(ultra_hip_ctx* ctx, const float* d_in, size_t in_stride, float* d_out, size_t out_stride,
+                                uint32_t n_samples, size_t n_frames, float cfo_hz) {
+    if (!ctx) return ULTRA_HIP_ERR_INVALID_ARG;
+    if (n_frames == 0 || n_samples == 0) return ULTRA_HIP_OK;
+    if (!d_in || !d_out || d_in == d_out || in_stride < n_samples || out_stride < n_samples || n_frames > 0x7fffffffull ||
+        n_samples > 0x3fffffffu || !(cfo_hz == cfo_hz))
+        return ULTRA_HIP_ERR_INVALID_ARG;
+    DeviceGuard guard(ctx->device);
+    // process() shifts only when abs(cfo) > 0.001 (hf_channel.hpp:163), applyCFO only buffers of 256 samples or more (:173)
+    if (!(std::fabs(cfo_hz) > 0.001f) || n_samples < 256) {
+        UH_HIP(hipMemcpy2DAsync(d_out, out_stride * sizeof(float), d_in, in_stride * sizeof(float), (size_t)n_samples * sizeof(float),
+                                n_frames, hipMemcpyDeviceToDevice, ctx->stream));
+        return ULTRA_HIP_OK;
+    }
+    if (ctx->ws_cfo_samples < n_samples) {
+        if (ctx->d_ws_cfo) { UH_HIP(hipStreamSynchronize(ctx->stream)); (void)hipFree(ctx->d_ws_cfo); ctx->d_ws_cfo = nullptr; }
+        ctx->ws_cfo_samples = 0;
+        UH_HIP(hipMalloc(&ctx->d_ws_cfo, 2 * (size_t)n_samples * sizeof(c32)));
+        ctx->ws_cfo_samples = n_samples;
+    }
+    const uint32_t fs_u = ctx->cfg.sample_rate;
+    // cfo_phase_inc_ = 2.0f * M_PI * actual_cfo_hz_ / config.sample_rate (:101): double arithmetic, narrowed once
+    const float phase_inc = (float)((((double)2.0f * M_PI) * (double)cfo_hz) / (double)fs_u);
+    const double two_pi_fc = ((double)2.0f * M_PI) * (double)1500.0f;
+    c32* mixer = ctx->d_ws_cfo;
+    c32* rotator = ctx->d_ws_cfo + n_samples;
+    hipLaunchKernelGGL(dev::cfo_tables_kernel, dim3((n_samples + 255) / 256), dim3(256), 0, ctx->stream, phase_inc, (float)fs_u,
+                       two_pi_fc, (int)n_samples, mixer, rotator);
+    hipLaunchKernelGGL(dev::cfo_shift_kernel, dim3((unsigned)((n_frames + 63) / 64)), dim3(64), 0, ctx->stream, d_in, in_stride, d_out,
+                       out_stride, (int)n_samples, (int)n_frames, mixer, rotator);
     UH_HIP(hipGetLastError());
     return ULTRA_HIP_OK;
 }

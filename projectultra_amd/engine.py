@@ -320,7 +320,7 @@ class ReceiveContext:
         return out
 
     def make_batch(self, n_frames: int, seed: int = 0x5EED, first_frame: int = 0, channel: str = "awgn",
-                   snr_db: float = 30.0, delay_ms: float = 0.5, doppler_hz: float = 0.1, out=None):
+                   snr_db: float = 30.0, delay_ms: float = 0.5, doppler_hz: float = 0.1, out=None, cfo_hz: float = 0.0):
         """Synthetic frames at the SYNCED entry, generated on the device (ultra_hip_make_batch): random
         payload -> encode -> preamble + modulate -> 0.5 peak -> channel.  Returns (audio [n][frame_samples],
         payload [n][k // 8]) device tensors; `out` may hand in that pair (e.g. row slices of a larger batch) to be
@@ -338,7 +338,26 @@ class ReceiveContext:
         check(self.lib.ultra_hip_make_batch(self._ctx, int(seed), int(first_frame), n_frames, kind, float(snr_db),
                                             float(delay_ms), float(doppler_hz), audio.data_ptr(), self._row_stride(audio),
                                             payload.data_ptr()), "ultra_hip_make_batch")
+        if abs(float(cfo_hz)) > 0.001:           # WattersonChannel::process shifts after the noise (hf_channel.hpp:161-165)
+            shifted = self.channel_cfo(audio, cfo_hz)
+            if out is None:
+                audio = shifted
+            else:
+                audio.copy_(shifted)
         return audio, payload
+
+    def channel_cfo(self, audio, cfo_hz: float):
+        """The channel's carrier frequency offset (WattersonChannel::applyCFO, hf_channel.hpp:161-232; every row by a fresh
+        channel) applied to a batch of audio rows -> new tensor.  Bit-identical to the reference."""
+        torch = _torch()
+        audio = self._dev(audio, torch.float32, "audio")
+        if audio.dim() != 2:
+            raise _lib.UltraHipError(-1, "channel_cfo: audio must be [n_frames][n_samples]")
+        out = torch.empty_like(audio)
+        check(self.lib.ultra_hip_channel_cfo_batch(self._ctx, audio.data_ptr(), self._row_stride(audio), out.data_ptr(),
+                                                   self._row_stride(out), audio.shape[1], audio.shape[0], float(cfo_hz)),
+              "ultra_hip_channel_cfo_batch")
+        return out
 
     def make_raw_batch(self, n_streams: int, seed: int = 0x5EED, first_frame: int = 0, channel: str = "awgn",
                        snr_db: float = 30.0, lead: int = 1120, tail: int = 960):

@@ -44,6 +44,18 @@ def test_fec_valid_codewords_with_special_magnitudes(oracle, ref):
                 assert ok and iters == 0 and bytes(out)[:len(hard)] == hard, (rate, i)
 
 
+def test_channel_cfo(oracle, ref):
+    """WattersonChannel::applyCFO (hf_channel.hpp:161-232): mix down from 1500 Hz, 48-tap running mean, rotate, mix up —
+    float libm calls and running sums in the reference's order, bitwise; buffers under 256 samples pass unchanged."""
+    rng = np.random.default_rng(8)
+    for n, cfo in ((255, 20.0), (256, 20.0), (4480, 35.5), (4480, -12.25), (12320, 50.0), (9000, 0.0025)):
+        t = np.arange(n) / 48000.0
+        x = (0.3 * np.cos(2 * np.pi * 1300.0 * t) + 0.2 * np.sin(2 * np.pi * 1950.0 * t) + rng.normal(0, 0.05, n)).astype(np.float32)
+        a, b = oracle.channel_apply_cfo(x, cfo), ref.channel_apply_cfo(x, cfo)
+        assert beq(a, b), (n, cfo)
+        assert (n < 256) == bool(beq(a, x))
+
+
 def test_interleavers(oracle, ref):
     x = np.random.default_rng(2).normal(size=648).astype(np.float32)
     assert beq(oracle.interleaver_deinterleave(6, 108, x), ref.interleaver_deinterleave(6, 108, x))
