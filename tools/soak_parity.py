@@ -1,6 +1,7 @@
 """Randomised parity soak (run on the GPU box): many mode / rate / channel / SNR / CFO combinations, a few
 thousand frames each, HIP path vs the oracle on the host cores — LLRs, decoded bytes, iteration counts and the
-tracker state compared BITWISE.    python3 tools/soak_parity.py [frames_per_case] [seed]"""
+tracker state compared BITWISE; presynced cases with the CFO "never set" for a tenth of the frames (training-symbol
+estimate), half of the cases with the channel's own CFO shift on their first rows (device shift vs oracle shift).    python3 tools/soak_parity.py [frames_per_case] [seed]"""
 import itertools, sys, time
 import numpy as np, torch
 sys.path.insert(0, "."); sys.path.insert(0, "tests")
@@ -26,11 +27,25 @@ for (fft, mod, rate, kw), (chan, snr) in itertools.product(modes, (("watterson",
         cfo[rng.random(n) < 0.1] = 0.0
         cfo[rng.random(n) < 0.02] *= 10.0                    # tracker saturation at +-90 Hz
         ph = rng.uniform(-3.1, 3.1, n).astype(np.float32) if entry == 1 else None
-        want = o.demod_decode_batch(cfg, audio, cfo_hz=cfo, cfo_phase=ph, n_threads=64)
+        if entry == 1:
+            cfo[rng.random(n) < 0.1] = np.nan               # "never set": estimateCFOFromTraining (ofdm_sync.cpp:278-380)
         ctx = context_for(cfg)
+        chan_ok = True
+        if rng.random() < 0.5:
+            # the channel's own carrier offset (WattersonChannel::applyCFO) on the first rows: device shift == oracle shift,
+            # bitwise, and the receive path then runs on the shifted audio with a coarse estimate near it
+            chan_cfo = float(rng.uniform(-30.0, 30.0))
+            m = min(n, 512)
+            shifted = np.stack([o.channel_apply_cfo(row, chan_cfo) for row in audio[:m]])
+            dev = ctx.channel_cfo(torch.from_numpy(audio[:m]).cuda(), chan_cfo).cpu().numpy()
+            chan_ok = np.array_equal(dev.view(np.uint32), shifted.view(np.uint32))
+            audio[:m] = shifted
+            keep_nan = np.isnan(cfo[:m])
+            cfo[:m] = np.where(keep_nan, np.nan, chan_cfo + rng.normal(0, 1.0, m)).astype(np.float32)
+        want = o.demod_decode_batch(cfg, audio, cfo_hz=cfo, cfo_phase=ph, n_threads=64)
         r = ctx.demod_decode(audio, cfo_hz=cfo, cfo_phase=ph, want_llr=True)
         ctx.synchronize()
-        ok = (np.array_equal(r["llr"].cpu().numpy().view(np.uint32), want["llr"].view(np.uint32))
+        ok = chan_ok and (np.array_equal(r["llr"].cpu().numpy().view(np.uint32), want["llr"].view(np.uint32))
               and np.array_equal(r["bytes"].cpu().numpy(), want["bytes"]) and np.array_equal(r["iters"].cpu().numpy(), want["iters"])
               and np.array_equal(r["ok"].cpu().numpy(), want["ok"]))
         total += n
