@@ -194,13 +194,21 @@ constexpr int kStH = 16;            // c32 H[64]
 constexpr int kStPrev = 16 + 128;   // c32 prev_pilot_phases[64]
 constexpr int kStDprev = 16 + 256;  // c32 dbpsk_prev_equalized[64]
 constexpr int kStLts = 16 + 384;    // c32 h_sum_pilot[64] (presynced)
-constexpr int kStFloats = 16 + 512;
+// Coherent layouts with pilots: between symbols only the PILOTS' channel estimates are state (every other carrier is
+// interpolated afresh per symbol, channel_equalizer.cpp:515-567), so they travel by pilot index in one cache line of
+// their own — the pilot half then reads and writes 128 contiguous bytes instead of every fourth entry of H[64], and the
+// carrier half does not move the 512-byte H array at all.  (The two tracking kernels run at the memory system's
+// practical ceiling; this takes a third of their traffic.)  Records are 19 cache lines; the pilots' region starts on a line.
+constexpr int kStHp = 16 + 512 + 16;                    // c32 Hp[32] at byte 2176 = line 17 of the record
+constexpr int kStFloats = kStHp + 64;                   // 2432 bytes = 19 lines
 enum { st_cfo = 0, st_cfo_filt, st_cfo_phase, st_noise, st_snr, st_timing, st_ppc_re, st_ppc_im, st_cpc_re, st_cpc_im,
        st_flags, st_count, st_since };
 constexpr int kFqFloats = 256;      // c32 Fq[128] per frame: bins [0,64) and [N-64,N)
 // Per-frame phase table of the next symbol's CFO rotation (cfo_walk_kernel -> mix_fft_kernel), 32-bit words:
 // number of segments, samples covered, phase after them (float bits), reserved; then {start, base, step} each.
 constexpr int kSegTabWords = 4 + 3 * kPhaseCap;
+
+__device__ __forceinline__ bool compact_pilot_state(const DemodConst& D) { return !D.differential && D.n_pilot > 0; }
 
 template <int A> __device__ __forceinline__ constexpr int bitrev_small(int q) {
     int r = 0;
@@ -500,7 +508,9 @@ __global__ __launch_bounds__(kWave, 5) void track_pilot_kernel(const DemodConst*
         const int flags = (int)st[st_flags];
         tr.cpc_init = flags & 1; tr.has_prev = (flags >> 1) & 1; tr.has_dprev = (flags >> 2) & 1;
         tr.snr_symbol_count = (int)st[st_count]; tr.symbols_since_sync = (int)st[st_since];
-        const c32 h_old = is_pilot ? reinterpret_cast<const c32*>(st + kStH)[ps] : mk(0.0f, 0.0f);
+        const bool compact = compact_pilot_state(D);
+        const c32 h_old = !is_pilot ? mk(0.0f, 0.0f)
+                          : compact ? reinterpret_cast<const c32*>(st + kStHp)[sub] : reinterpret_cast<const c32*>(st + kStH)[ps];
         const c32 prev = is_pilot ? reinterpret_cast<const c32*>(st + kStPrev)[sub] : mk(0.0f, 0.0f);
         const float alpha = (tr.snr_symbol_count == 0) ? 1.0f : 0.9f;
 
@@ -626,8 +636,11 @@ __global__ __launch_bounds__(kWave, 5) void track_pilot_kernel(const DemodConst*
         tr.snr_symbol_count++;
 
         if (act) {
+            // (whole 128-byte lines of Hp and of prev_pilot_phases: lanes behind the last pilot write zeros nobody reads)
+            if (compact && sub < ((np + 15) & ~15)) reinterpret_cast<c32*>(st + kStHp)[sub] = is_pilot ? h_new : mk(0.0f, 0.0f);
+            if (compact && !is_pilot && sub < ((np + 15) & ~15)) reinterpret_cast<c32*>(st + kStPrev)[sub] = mk(0.0f, 0.0f);
             if (is_pilot) {
-                reinterpret_cast<c32*>(st + kStH)[ps] = h_new;
+                if (!compact) reinterpret_cast<c32*>(st + kStH)[ps] = h_new;
                 reinterpret_cast<c32*>(st + kStPrev)[sub] = h;
             }
             // Every lane of the group carries the frame's scalars: lane `sub` stores scalar `sub` — one store
@@ -872,11 +885,14 @@ __device__ __forceinline__ void lts_finish(TrackShared& sh, const DemodConst& D,
 // block of processPresynced :868-905).
 __global__ __launch_bounds__(kWave) void init_state_kernel(const float* __restrict__ cfo_hz,
                                                            const float* __restrict__ cfo_phase, int n_frames,
-                                                           float* __restrict__ state) {
+                                                           float* __restrict__ state, int compact) {
     const int lane = threadIdx.x;
     for (int frame = blockIdx.x; frame < n_frames; frame += gridDim.x) {
         float* st = state + (size_t)frame * kStFloats;
-        reinterpret_cast<c32*>(st + kStH)[lane] = mk(1.0f, 0.0f);
+        // channel_estimate = (1, 0) everywhere: the pilots' line for the compact layouts (the training kernel, where there
+        // is one, works on the full array and fills both), the whole array otherwise
+        if (!compact) reinterpret_cast<c32*>(st + kStH)[lane] = mk(1.0f, 0.0f);
+        if (lane < 32) reinterpret_cast<c32*>(st + kStHp)[lane] = mk(1.0f, 0.0f);
         if (lane < 16) {
             float v = 0.0f;
             const float cfo = cfo_hz ? cfo_hz[frame] : 0.0f;
@@ -1046,6 +1062,7 @@ __global__ __launch_bounds__(kWave, 4) void train_kernel(const DemodConst* __res
         else if (lane < D.n_pilot) reinterpret_cast<c32*>(st + kStLts)[lane] = lts_acc;
         wave_sync();
         reinterpret_cast<c32*>(st + kStH)[lane] = sh.H[lane];
+        if (lane < D.n_pilot) reinterpret_cast<c32*>(st + kStHp)[lane] = sh.H[lc.pilot_slot];      // compact_pilot_state
         if (lane == 0) store_track(st, tr);
         wave_sync();
     }
@@ -1067,14 +1084,18 @@ __global__ __launch_bounds__(kWave, 6) void track_kernel(
         const c32* fq = fq_all + (size_t)frame * 128;
         Track tr;
         load_track(st, tr);
-        sh.H[lane] = reinterpret_cast<const c32*>(st + kStH)[lane];
+        const bool compact = compact_pilot_state(D);
+        if (!compact) sh.H[lane] = reinterpret_cast<const c32*>(st + kStH)[lane];
+        else if (lane < D.n_pilot) sh.H[lc.pilot_slot] = reinterpret_cast<const c32*>(st + kStHp)[lane];   // the rest is interpolated before it is read
         c32 dprev = D.differential ? reinterpret_cast<const c32*>(st + kStDprev)[lane] : mk(1.0f, 0.0f);
         wave_sync();
         if (!D.presynced || D.n_pilot != 0) finish_channel_estimate(sh, D, lc, tr);
         equalize_demap<MOD>(sh, D, lc, tr, dprev, fq, llr + (size_t)frame * llr_stride + (size_t)data_sym * D.llrs_per_symbol);
         wave_sync();
         // write the record back
-        reinterpret_cast<c32*>(st + kStH)[lane] = sh.H[lane];
+        if (!compact) reinterpret_cast<c32*>(st + kStH)[lane] = sh.H[lane];
+        else if (lane < ((D.n_pilot + 15) & ~15))               // whole 128-byte lines: no partial-sector writes
+            reinterpret_cast<c32*>(st + kStHp)[lane] = (lane < D.n_pilot) ? sh.H[lc.pilot_slot] : mk(0.0f, 0.0f);
         if (D.differential) reinterpret_cast<c32*>(st + kStDprev)[lane] = dprev;
         if (lane == 0) {
             // only what the carrier half owns (equalize_demap: pilot_phase_correction, has_dprev) — the rest of the

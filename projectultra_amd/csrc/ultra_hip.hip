@@ -154,8 +154,10 @@ int launch_demod(ultra_hip_ctx* ctx, const float* d_audio, size_t frame_stride, 
     hipStream_t st = ctx->stream;
     {
         LaunchSpan span(ctx, ULTRA_HIP_K_INIT_STATE);
+        // compact pilot state (demod_kernel.h, kStHp) and no training symbols that read the full H array first
+        const int compact = (!D.differential && D.n_pilot > 0 && D.n_train == 0) ? 1 : 0;
         hipLaunchKernelGGL(dev::init_state_kernel, dim3(grid_trk), dim3(dev::kWave), 0, st, d_cfo_hz, d_cfo_phase,
-                           (int)n_frames, ctx->d_ws_state);
+                           (int)n_frames, ctx->d_ws_state, compact);
     }
     if (D.presynced && d_cfo_hz) {
         // frames whose initial CFO is NaN ("never set"): estimateCFOFromTraining, demodulator.cpp:920-925
