@@ -51,8 +51,8 @@ LDS_CYC = dict(read_b32=2, write_b32=4, write_addtid_b32=2)
 ISSUE_CYCLES = {
     "ldpc_totals R3/4": dict(unit="cw_iteration", valu=162.5 * 3.38, salu=80.4 * 4.19, lds=61.5 * 2.13),
     "mix_fft_kernel": dict(unit="frame", valu=1120 * 3.44, salu=136 * 4.19, lds=81.4 * 3.54),
-    "track_kernel": dict(unit="frame", valu=195 * 3.28, salu=104 * 4.19, lds=20.9 * 3.93),
-    "track_pilot_kernel": dict(unit="frame", valu=143.7 * 3.46, salu=57.4 * 4.19, lds=4.75 * 5.08),
+    "track_kernel": dict(unit="frame", valu=198.5 * 3.30, salu=118 * 4.19, lds=20.9 * 3.94),
+    "track_pilot_kernel": dict(unit="frame", valu=151 * 3.48, salu=61.8 * 4.19, lds=4.75 * 5.08),
     # per raw stream of 14,400 samples at 30 dB (profiles/r02_sq_counters_raw.txt: 65,536 streams per launch)
     "acquire_kernel": dict(unit="stream", valu=952.8e3 * 3.35, salu=134.7e3 * 4.19, lds=166.4e3 * 3.33),
 }
