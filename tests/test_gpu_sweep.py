@@ -118,3 +118,40 @@ def test_run_points_equals_run_per_point():
             got = shard.run_points(100, 800, snrs, seeds).cpu().numpy()
             assert np.array_equal(got, want), (mod, rate, batch)
         assert shard.run_points(5, 5, snrs, seeds).sum().item() == 0
+
+
+def test_round2_entries_refuse_bad_arguments():
+    """The C-ABI entries added this round check what they are handed before any kernel is launched (a faulting kernel can
+    take the whole host down): aliasing / short strides for the channel CFO shift, a point count the grid cannot hold or
+    null pointers for the per-point counters, counters that are not [points][8] in the Python wrapper."""
+    import ctypes as C
+    import torch
+    from projectultra_amd import CodeRate, Modulation, UltraHipError
+    from projectultra_amd.sweep import HipModemShard, nvis_cell_config
+    shard = HipModemShard(nvis_cell_config(Modulation.QAM16, CodeRate.R3_4), channel="awgn", batch=256)
+    ctx = shard.ctx
+    lib, h = ctx.lib, ctx._ctx
+    audio, payload = ctx.make_batch(64, seed=3, snr_db=20.0)
+    out = torch.empty_like(audio)
+    a, o, n = audio.data_ptr(), out.data_ptr(), audio.shape[1]
+    assert lib.ultra_hip_channel_cfo_batch(h, a, n, a, n, n, 64, C.c_float(10.0)) != 0          # in place
+    assert lib.ultra_hip_channel_cfo_batch(h, a, n - 1, o, n, n, 64, C.c_float(10.0)) != 0      # stride shorter than the row
+    assert lib.ultra_hip_channel_cfo_batch(h, a, n, o, n, n, 64, C.c_float(float("nan"))) != 0
+    assert lib.ultra_hip_channel_cfo_batch(h, None, n, o, n, n, 64, C.c_float(10.0)) != 0
+    assert lib.ultra_hip_channel_cfo_batch(h, a, n, o, n, n, 0, C.c_float(10.0)) == 0           # nothing to do
+    r = ctx.demod_decode(audio)
+    cnt = torch.zeros((4, 8), dtype=torch.int64, device=audio.device)
+    pb = payload.shape[1]
+    args = (r["bytes"].data_ptr(), r["iters"].data_ptr(), r["ok"].data_ptr(), payload.data_ptr())
+    assert lib.ultra_hip_count_errors_points(h, *args, pb, 70000, 1, cnt.data_ptr()) != 0       # more points than grid rows
+    assert lib.ultra_hip_count_errors_points(h, *args, 0, 4, 16, cnt.data_ptr()) != 0           # no payload bytes
+    assert lib.ultra_hip_count_errors_points(h, args[0], None, args[2], args[3], pb, 4, 16, cnt.data_ptr()) != 0
+    assert lib.ultra_hip_count_errors_points(h, *args, pb, 0, 16, cnt.data_ptr()) == 0          # nothing to do
+    ctx.count_errors_points(r, payload, cnt)
+    assert cnt[:, 0].tolist() == [16, 16, 16, 16]
+    with pytest.raises(UltraHipError):
+        ctx.count_errors_points(r, payload, torch.zeros((3, 8), dtype=torch.int64, device=audio.device))   # 64 rows, 3 points
+    with pytest.raises(UltraHipError):
+        ctx.count_errors_points(r, payload, torch.zeros((4, 7), dtype=torch.int64, device=audio.device))
+    with pytest.raises(UltraHipError):
+        ctx.make_batch(64, seed=3, out=(audio[:, :100], payload))                                 # not the generator's shape
