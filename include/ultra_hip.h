@@ -160,6 +160,12 @@ int ultra_hip_create(const ultra_hip_config* cfg, int device, void* stream, ultr
 /* Replaces the destructors of the two classes above. */
 void ultra_hip_destroy(ultra_hip_ctx* ctx);
 
+/* Size the context's per-frame workspaces (tracker records, FFT bins, phase tables, the LLR workspace of the fused
+ * entry) for batches of up to n_frames, so that no later call has to synchronise the stream and allocate.  The
+ * workspaces otherwise grow on demand, inside the first call that needs more.  (≈ 5.5 KB + 4 * llrs_per_frame bytes
+ * per frame.) */
+int ultra_hip_reserve(ultra_hip_ctx* ctx, size_t n_frames);
+
 /* Geometry of a live context. */
 int ultra_hip_get_geometry(const ultra_hip_ctx* ctx, ultra_hip_geometry* geo);
 

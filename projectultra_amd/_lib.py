@@ -64,6 +64,7 @@ PROTOTYPES = {
     "ultra_hip_demod_batch": (_i, [_vp, _vp, _sz, _vp, _vp, _sz, _vp, _vp]),
     "ultra_hip_demod_decode_batch": (_i, [_vp, _vp, _sz, _vp, _vp, _sz, _vp, _vp, _vp, _vp]),
     "ultra_hip_count_errors": (_i, [_vp, _vp, _vp, _vp, _vp, _sz, _sz, _vp]),
+    "ultra_hip_reserve": (_i, [_vp, _sz]),
     "ultra_hip_count_errors_points": (_i, [_vp, _vp, _vp, _vp, _vp, _sz, _sz, _sz, _vp]),
     "ultra_hip_channel_cfo_batch": (_i, [_vp, _vp, _sz, _vp, _sz, C.c_uint32, _sz, C.c_float]),
     "ultra_hip_synchronize": (_i, [_vp]),

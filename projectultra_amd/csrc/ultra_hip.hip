@@ -127,22 +127,36 @@ struct DeviceGuard {
     ~DeviceGuard() { if (prev >= 0) (void)hipSetDevice(prev); }
 };
 
+// The per-frame workspaces grow on demand (a stream synchronisation and hipMalloc inside the call that first needs
+// them); ultra_hip_reserve sizes them up front.
+int ensure_demod_workspace(ultra_hip_ctx* ctx, size_t n_frames) {
+    if (ctx->ws_demod_frames >= n_frames) return ULTRA_HIP_OK;
+    UH_HIP(hipStreamSynchronize(ctx->stream));
+    if (ctx->d_ws_state) { (void)hipFree(ctx->d_ws_state); ctx->d_ws_state = nullptr; }
+    if (ctx->d_ws_fq) { (void)hipFree(ctx->d_ws_fq); ctx->d_ws_fq = nullptr; }
+    if (ctx->d_ws_seg) { (void)hipFree(ctx->d_ws_seg); ctx->d_ws_seg = nullptr; }
+    ctx->ws_demod_frames = 0;
+    UH_HIP(hipMalloc(&ctx->d_ws_state, n_frames * (size_t)dev::kStFloats * sizeof(float)));
+    UH_HIP(hipMalloc(&ctx->d_ws_fq, n_frames * (size_t)128 * sizeof(c32)));
+    UH_HIP(hipMalloc(&ctx->d_ws_seg, n_frames * (size_t)dev::kSegTabWords * sizeof(unsigned)));
+    ctx->ws_demod_frames = n_frames;
+    return ULTRA_HIP_OK;
+}
+int ensure_llr_workspace(ultra_hip_ctx* ctx, size_t n_frames) {
+    if (ctx->ws_llr_frames >= n_frames) return ULTRA_HIP_OK;
+    if (ctx->d_ws_llr) { UH_HIP(hipStreamSynchronize(ctx->stream)); (void)hipFree(ctx->d_ws_llr); ctx->d_ws_llr = nullptr; }
+    ctx->ws_llr_frames = 0;
+    UH_HIP(hipMalloc(&ctx->d_ws_llr, n_frames * (size_t)ctx->geo.llrs_per_frame * sizeof(float)));
+    ctx->ws_llr_frames = n_frames;
+    return ULTRA_HIP_OK;
+}
+
 int launch_demod(ultra_hip_ctx* ctx, const float* d_audio, size_t frame_stride, const float* d_cfo_hz,
                  const float* d_cfo_phase, size_t n_frames, float* d_llr, size_t llr_stride, float* d_state,
                  const unsigned* d_frame_offset = nullptr) {
     if (n_frames == 0) return ULTRA_HIP_OK;
     const DemodConst& D = ctx->h_demod;
-    if (ctx->ws_demod_frames < n_frames) {
-        UH_HIP(hipStreamSynchronize(ctx->stream));
-        if (ctx->d_ws_state) { (void)hipFree(ctx->d_ws_state); ctx->d_ws_state = nullptr; }
-        if (ctx->d_ws_fq) { (void)hipFree(ctx->d_ws_fq); ctx->d_ws_fq = nullptr; }
-        if (ctx->d_ws_seg) { (void)hipFree(ctx->d_ws_seg); ctx->d_ws_seg = nullptr; }
-        ctx->ws_demod_frames = 0;
-        UH_HIP(hipMalloc(&ctx->d_ws_state, n_frames * (size_t)dev::kStFloats * sizeof(float)));
-        UH_HIP(hipMalloc(&ctx->d_ws_fq, n_frames * (size_t)128 * sizeof(c32)));
-        UH_HIP(hipMalloc(&ctx->d_ws_seg, n_frames * (size_t)dev::kSegTabWords * sizeof(unsigned)));
-        ctx->ws_demod_frames = n_frames;
-    }
+    { const int rc_ws = ensure_demod_workspace(ctx, n_frames); if (rc_ws != ULTRA_HIP_OK) return rc_ws; }
     // one wavefront per frame in every kernel; grids are capped (grid-stride over frames) so a huge
     // batch stays one launch per stage and per-workgroup constants are loaded once
     // Many short-lived workgroups (a few frames each) beat one resident set looping over the batch:
@@ -520,6 +534,15 @@ void ultra_hip_destroy(ultra_hip_ctx* ctx) {
     delete ctx;
 }
 
+int ultra_hip_reserve(ultra_hip_ctx* ctx, size_t n_frames) {
+    if (!ctx || n_frames > 0x7fffffffull) return ULTRA_HIP_ERR_INVALID_ARG;
+    if (n_frames == 0) return ULTRA_HIP_OK;
+    DeviceGuard guard(ctx->device);
+    int rc = ensure_demod_workspace(ctx, n_frames);
+    if (rc == ULTRA_HIP_OK) rc = ensure_llr_workspace(ctx, n_frames);
+    return rc;
+}
+
 int ultra_hip_get_geometry(const ultra_hip_ctx* ctx, ultra_hip_geometry* geo) {
     if (!ctx || !geo) return ULTRA_HIP_ERR_INVALID_ARG;
     *geo = ctx->geo;
@@ -567,11 +590,7 @@ int ultra_hip_demod_decode_batch(ultra_hip_ctx* ctx, const float* d_audio, size_
     DeviceGuard guard(ctx->device);
     float* llr = d_llr;
     if (!llr) {
-        if (ctx->ws_llr_frames < n_frames) {
-            if (ctx->d_ws_llr) { UH_HIP(hipStreamSynchronize(ctx->stream)); (void)hipFree(ctx->d_ws_llr); ctx->d_ws_llr = nullptr; }
-            UH_HIP(hipMalloc(&ctx->d_ws_llr, n_frames * (size_t)ctx->geo.llrs_per_frame * sizeof(float)));
-            ctx->ws_llr_frames = n_frames;
-        }
+        { const int rc_ws = ensure_llr_workspace(ctx, n_frames); if (rc_ws != ULTRA_HIP_OK) return rc_ws; }
         llr = ctx->d_ws_llr;
     }
     int rc = launch_demod(ctx, d_audio, frame_stride, d_cfo_hz, d_cfo_phase, n_frames, llr,
@@ -638,11 +657,7 @@ int ultra_hip_receive_batch(ultra_hip_ctx* ctx, const float* d_audio, size_t str
                        ctx->geo.frame_samples, n_samples, (int)n_streams, entry, offset);
     float* llr = d_llr;
     if (!llr) {
-        if (ctx->ws_llr_frames < n_streams) {
-            if (ctx->d_ws_llr) { UH_HIP(hipStreamSynchronize(ctx->stream)); (void)hipFree(ctx->d_ws_llr); ctx->d_ws_llr = nullptr; }
-            UH_HIP(hipMalloc(&ctx->d_ws_llr, n_streams * (size_t)ctx->geo.llrs_per_frame * sizeof(float)));
-            ctx->ws_llr_frames = n_streams;
-        }
+        { const int rc_ws = ensure_llr_workspace(ctx, n_streams); if (rc_ws != ULTRA_HIP_OK) return rc_ws; }
         llr = ctx->d_ws_llr;
     }
     rc = launch_demod(ctx, d_audio, stream_stride, cfo, nullptr, n_streams, llr, ctx->geo.llrs_per_frame, nullptr, offset);
@@ -686,11 +701,7 @@ int ultra_hip_chirp_receive_batch(ultra_hip_ctx* ctx, const float* d_audio, size
                        ctx->geo.frame_samples, n_samples, ctx->cfg.sample_rate, (int)n_streams, entry, offset, cfo, phase);
     float* llr = d_llr;
     if (!llr) {
-        if (ctx->ws_llr_frames < n_streams) {
-            if (ctx->d_ws_llr) { UH_HIP(hipStreamSynchronize(ctx->stream)); (void)hipFree(ctx->d_ws_llr); ctx->d_ws_llr = nullptr; }
-            UH_HIP(hipMalloc(&ctx->d_ws_llr, n_streams * (size_t)ctx->geo.llrs_per_frame * sizeof(float)));
-            ctx->ws_llr_frames = n_streams;
-        }
+        { const int rc_ws = ensure_llr_workspace(ctx, n_streams); if (rc_ws != ULTRA_HIP_OK) return rc_ws; }
         llr = ctx->d_ws_llr;
     }
     rc = launch_demod(ctx, d_audio, stream_stride, cfo, phase, n_streams, llr, ctx->geo.llrs_per_frame, nullptr, offset);

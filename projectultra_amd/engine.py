@@ -346,6 +346,11 @@ class ReceiveContext:
                 audio.copy_(shifted)
         return audio, payload
 
+    def reserve(self, n_frames: int):
+        """Size the context's workspaces for batches of up to n_frames (otherwise they grow inside the first call that needs
+        more, with a stream synchronisation and an allocation)."""
+        check(self.lib.ultra_hip_reserve(self._ctx, int(n_frames)), "ultra_hip_reserve")
+
     def channel_cfo(self, audio, cfo_hz: float):
         """The channel's carrier frequency offset (WattersonChannel::applyCFO, hf_channel.hpp:161-232; every row by a fresh
         channel) applied to a batch of audio rows -> new tensor.  Bit-identical to the reference."""

@@ -139,6 +139,9 @@ def test_round2_entries_refuse_bad_arguments():
     assert lib.ultra_hip_channel_cfo_batch(h, a, n, o, n, n, 64, C.c_float(float("nan"))) != 0
     assert lib.ultra_hip_channel_cfo_batch(h, None, n, o, n, n, 64, C.c_float(10.0)) != 0
     assert lib.ultra_hip_channel_cfo_batch(h, a, n, o, n, n, 0, C.c_float(10.0)) == 0           # nothing to do
+    ctx.reserve(4096)                                            # workspaces sized up front: no allocation inside the calls below
+    with pytest.raises(UltraHipError):
+        ctx.reserve(1 << 40)
     r = ctx.demod_decode(audio)
     cnt = torch.zeros((4, 8), dtype=torch.int64, device=audio.device)
     pb = payload.shape[1]
