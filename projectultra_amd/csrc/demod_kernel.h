@@ -1084,6 +1084,12 @@ __global__ __launch_bounds__(kWave, 6) void track_kernel(
         const c32* fq = fq_all + (size_t)frame * 128;
         Track tr;
         load_track(st, tr);
+        // A layout without pilots leaves the pilot half of updateChannelEstimate three scalar effects (no pilot phase
+        // differences: pilot_phase_correction = 1, :421-470; prev_pilot_phases stays empty; ++snr_symbol_count, :595) —
+        // taken here instead of in a track_pilot_kernel launch of their own (SYNCED entry; the presynced entry without
+        // pilots never ran the estimate, demodulator.cpp:936-960).
+        const bool scalar_pilot_half = D.n_pilot == 0 && !D.presynced;
+        if (scalar_pilot_half) { tr.ppc = mk(1.0f, 0.0f); tr.has_prev = 0; tr.snr_symbol_count++; }
         const bool compact = compact_pilot_state(D);
         if (!compact) sh.H[lane] = reinterpret_cast<const c32*>(st + kStH)[lane];
         else if (lane < D.n_pilot) sh.H[lc.pilot_slot] = reinterpret_cast<const c32*>(st + kStHp)[lane];   // the rest is interpolated before it is read
@@ -1103,6 +1109,7 @@ __global__ __launch_bounds__(kWave, 6) void track_kernel(
             // next symbol of this frame on the main stream (launch_demod)
             st[st_ppc_re] = tr.ppc.re; st[st_ppc_im] = tr.ppc.im;
             st[st_flags] = (float)(tr.cpc_init | (tr.has_prev << 1) | (tr.has_dprev << 2));
+            if (scalar_pilot_half) st[st_count] = (float)tr.snr_symbol_count;
             if (state_out) {
                 float* so = state_out + (size_t)frame * ULTRA_HIP_STATE_FLOATS;
                 so[ULTRA_HIP_STATE_FREQ_OFFSET_HZ] = tr.freq_offset_hz;

@@ -208,7 +208,7 @@ int launch_demod(ultra_hip_ctx* ctx, const float* d_audio, size_t frame_stride, 
         // Data symbols: the pilot half of the channel update runs 4 (<= 16 pilots) or 2 (<= 32: every usable
         // configuration, validate_config) frames per wavefront in its own kernel, the carrier half + equalise
         // + demap one frame per wavefront.
-        if (!D.presynced || D.n_pilot != 0) {
+        if (D.n_pilot != 0) {                          // without pilots the half is three scalar updates: track_kernel takes them
             LaunchSpan span(ctx, ULTRA_HIP_K_PILOT);
             if (D.n_pilot <= 16) {
                 const unsigned g = (unsigned)std::min((n_frames + 3) / 4, (size_t)ctx->cu_count * 256);
