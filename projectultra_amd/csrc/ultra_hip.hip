@@ -179,9 +179,13 @@ int launch_demod(ultra_hip_ctx* ctx, const float* d_audio, size_t frame_stride, 
                            d_audio, frame_stride, d_frame_offset, d_cfo_hz, (int)n_frames, ctx->d_ws_state);
     }
     const int n_sym = D.n_train + D.n_data_sym;
+    // No pilots, SYNCED entry, no initial offsets: nothing on the path ever estimates a CFO (that is the pilot half's job),
+    // it is 0 for every frame and every symbol, mix_fft_kernel never rotates — no phase tables to walk.
+    const bool cfo_is_zero = !D.presynced && D.n_pilot == 0 && d_cfo_hz == nullptr;
+    const unsigned* seg_tab = cfo_is_zero ? nullptr : ctx->d_ws_seg;
     for (int s = 0; s < n_sym; ++s) {
         if (D.log2_fft != 10 && D.log2_fft != 9) return ULTRA_HIP_ERR_UNSUPPORTED;
-        {
+        if (!cfo_is_zero) {
             LaunchSpan span(ctx, ULTRA_HIP_K_WALK);
             hipLaunchKernelGGL(dev::cfo_walk_kernel, dim3((unsigned)((n_frames + 255) / 256)), dim3(256), 0, st, ctx->d_demod,
                                (int)n_frames, ctx->d_ws_state, ctx->d_ws_seg);
@@ -191,11 +195,11 @@ int launch_demod(ultra_hip_ctx* ctx, const float* d_audio, size_t frame_stride, 
             if (D.log2_fft == 10)
                 hipLaunchKernelGGL(dev::mix_fft_kernel<10>, dim3(grid_fft), dim3(dev::kWave), 0, st, ctx->d_demod,
                                    ctx->d_nco, ctx->d_twiddle, d_audio, frame_stride, d_frame_offset, (int)n_frames, s,
-                                   ctx->d_ws_state, ctx->d_ws_fq, ctx->d_ws_seg);
+                                   ctx->d_ws_state, ctx->d_ws_fq, seg_tab);
             else
                 hipLaunchKernelGGL(dev::mix_fft_kernel<9>, dim3(grid_fft), dim3(dev::kWave), 0, st, ctx->d_demod,
                                    ctx->d_nco, ctx->d_twiddle, d_audio, frame_stride, d_frame_offset, (int)n_frames, s,
-                                   ctx->d_ws_state, ctx->d_ws_fq, ctx->d_ws_seg);
+                                   ctx->d_ws_state, ctx->d_ws_fq, seg_tab);
         }
         const bool training = s < D.n_train;
         const bool last = (s == n_sym - 1);
