@@ -980,7 +980,7 @@ template <int LOG2N>
 __global__ __launch_bounds__(kWave, 2) void mix_fft_kernel(
     const DemodConst* __restrict__ Dp, const c32* __restrict__ nco, const c32* __restrict__ twiddle,
     const float* __restrict__ audio, size_t frame_stride, const unsigned* __restrict__ frame_offset, int n_frames,
-    int sym, float* __restrict__ state, c32* __restrict__ fq, const unsigned* __restrict__ seg_tab) {
+    int sym, float* __restrict__ state, c32* __restrict__ fq, const unsigned* __restrict__ seg_tab, int n_sym_batch) {
     __shared__ FftShared<LOG2N> sh;
     const DemodConst& D = *Dp;
     const int lane = threadIdx.x;
@@ -993,19 +993,27 @@ __global__ __launch_bounds__(kWave, 2) void mix_fft_kernel(
         }
     }
     wave_sync();
-    const size_t sym_off = (size_t)sym * D.sym_len;
+    // n_sym_batch == 1: symbol `sym` of every frame (the tracker's CFO of symbol s comes out of symbol s - 1).
+    // n_sym_batch > 1: symbols sym .. sym + n_sym_batch - 1 of every frame in ONE launch, work item w = s * n_frames + frame,
+    // bins to fq[w] — for the layouts where the CFO is identically zero (no pilots, SYNCED entry, no initial offsets:
+    // launch_demod), whose symbols do not depend on each other here; the CFO phase is then not touched.
     // frame f starts at audio + f * frame_stride (+ frame_offset[f]: per-stream data start from the acquisition)
-    auto frame_base = [&](int f) { return audio + (size_t)f * frame_stride + (frame_offset ? frame_offset[f] : 0u) + sym_off; };
-    if ((int)blockIdx.x < n_frames) prefetch_symbol<LOG2N>(sh, D, frame_base((int)blockIdx.x));
-    for (int frame = blockIdx.x; frame < n_frames; frame += gridDim.x) {
+    auto item_base = [&](int w) {
+        const int f = (n_sym_batch > 1) ? w % n_frames : w, ds = (n_sym_batch > 1) ? w / n_frames : 0;
+        return audio + (size_t)f * frame_stride + (frame_offset ? frame_offset[f] : 0u) + (size_t)(sym + ds) * D.sym_len;
+    };
+    const int total = n_frames * n_sym_batch;
+    if ((int)blockIdx.x < total) prefetch_symbol<LOG2N>(sh, D, item_base((int)blockIdx.x));
+    for (int w = blockIdx.x; w < total; w += gridDim.x) {
+        const int frame = (n_sym_batch > 1) ? w % n_frames : w, ds = (n_sym_batch > 1) ? w / n_frames : 0;
         float* st = state + (size_t)frame * kStFloats;
         const float cfo = st[st_cfo];
         float phase = st[st_cfo_phase];
-        symbol_to_freq<LOG2N>(sh, D, cfo, phase, nco + sym_off, twiddle, fq + (size_t)frame * 128,
+        symbol_to_freq<LOG2N>(sh, D, cfo, phase, nco + (size_t)(sym + ds) * D.sym_len, twiddle, fq + (size_t)w * 128,
                               seg_tab ? seg_tab + (size_t)frame * kSegTabWords : nullptr);
-        if (lane == 0) st[st_cfo_phase] = phase;
-        const int next = frame + (int)gridDim.x;
-        if (next < n_frames) prefetch_symbol<LOG2N>(sh, D, frame_base(next));
+        if (lane == 0 && n_sym_batch == 1) st[st_cfo_phase] = phase;
+        const int next = w + (int)gridDim.x;
+        if (next < total) prefetch_symbol<LOG2N>(sh, D, item_base(next));
     }
 }
 

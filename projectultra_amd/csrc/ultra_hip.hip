@@ -71,6 +71,7 @@ struct ultra_hip_ctx {
     c32* d_ws_fq = nullptr;
     unsigned* d_ws_seg = nullptr;       // per-frame CFO phase tables (cfo_walk_kernel -> mix_fft_kernel)
     size_t ws_demod_frames = 0;
+    size_t ws_fq_rows = 0;
     hipEvent_t ev_begin = nullptr, ev_end = nullptr;
     int cu_count = 256;
     // per-kernel profiling (ultra_hip_profile_*): recorded (class, start, stop) triples + spare events
@@ -133,13 +134,21 @@ int ensure_demod_workspace(ultra_hip_ctx* ctx, size_t n_frames) {
     if (ctx->ws_demod_frames >= n_frames) return ULTRA_HIP_OK;
     UH_HIP(hipStreamSynchronize(ctx->stream));
     if (ctx->d_ws_state) { (void)hipFree(ctx->d_ws_state); ctx->d_ws_state = nullptr; }
-    if (ctx->d_ws_fq) { (void)hipFree(ctx->d_ws_fq); ctx->d_ws_fq = nullptr; }
     if (ctx->d_ws_seg) { (void)hipFree(ctx->d_ws_seg); ctx->d_ws_seg = nullptr; }
     ctx->ws_demod_frames = 0;
     UH_HIP(hipMalloc(&ctx->d_ws_state, n_frames * (size_t)dev::kStFloats * sizeof(float)));
-    UH_HIP(hipMalloc(&ctx->d_ws_fq, n_frames * (size_t)128 * sizeof(c32)));
     UH_HIP(hipMalloc(&ctx->d_ws_seg, n_frames * (size_t)dev::kSegTabWords * sizeof(unsigned)));
     ctx->ws_demod_frames = n_frames;
+    return ULTRA_HIP_OK;
+}
+// used FFT bins: one row of 128 per frame — per frame AND symbol where all symbols are transformed in one launch
+int ensure_fq_workspace(ultra_hip_ctx* ctx, size_t rows) {
+    if (ctx->ws_fq_rows >= rows) return ULTRA_HIP_OK;
+    UH_HIP(hipStreamSynchronize(ctx->stream));
+    if (ctx->d_ws_fq) { (void)hipFree(ctx->d_ws_fq); ctx->d_ws_fq = nullptr; }
+    ctx->ws_fq_rows = 0;
+    UH_HIP(hipMalloc(&ctx->d_ws_fq, rows * (size_t)128 * sizeof(c32)));
+    ctx->ws_fq_rows = rows;
     return ULTRA_HIP_OK;
 }
 int ensure_llr_workspace(ultra_hip_ctx* ctx, size_t n_frames) {
@@ -183,30 +192,45 @@ int launch_demod(ultra_hip_ctx* ctx, const float* d_audio, size_t frame_stride, 
     // it is 0 for every frame and every symbol, mix_fft_kernel never rotates — no phase tables to walk.
     const bool cfo_is_zero = !D.presynced && D.n_pilot == 0 && d_cfo_hz == nullptr;
     const unsigned* seg_tab = cfo_is_zero ? nullptr : ctx->d_ws_seg;
+    if (D.log2_fft != 10 && D.log2_fft != 9) return ULTRA_HIP_ERR_UNSUPPORTED;
+    // ... and no symbol's transform depends on the symbol before it: ALL symbols of all frames in one launch (a grid of
+    // n_frames * n_sym items instead of n_sym launches that each ramp up and drain), bins to one Fq row per frame and symbol
+    const bool all_symbols_at_once = cfo_is_zero && n_sym > 1 && n_frames * (size_t)n_sym < 0x7fffffffull;
+    { const int rc_fq = ensure_fq_workspace(ctx, all_symbols_at_once ? n_frames * (size_t)n_sym : n_frames); if (rc_fq != ULTRA_HIP_OK) return rc_fq; }
+    if (all_symbols_at_once) {
+        LaunchSpan span(ctx, ULTRA_HIP_K_MIX_FFT);
+        const unsigned g = (unsigned)std::min(n_frames * (size_t)n_sym, (size_t)ctx->cu_count * 128);
+        if (D.log2_fft == 10)
+            hipLaunchKernelGGL(dev::mix_fft_kernel<10>, dim3(g), dim3(dev::kWave), 0, st, ctx->d_demod, ctx->d_nco, ctx->d_twiddle,
+                               d_audio, frame_stride, d_frame_offset, (int)n_frames, 0, ctx->d_ws_state, ctx->d_ws_fq, seg_tab, n_sym);
+        else
+            hipLaunchKernelGGL(dev::mix_fft_kernel<9>, dim3(g), dim3(dev::kWave), 0, st, ctx->d_demod, ctx->d_nco, ctx->d_twiddle,
+                               d_audio, frame_stride, d_frame_offset, (int)n_frames, 0, ctx->d_ws_state, ctx->d_ws_fq, seg_tab, n_sym);
+    }
     for (int s = 0; s < n_sym; ++s) {
-        if (D.log2_fft != 10 && D.log2_fft != 9) return ULTRA_HIP_ERR_UNSUPPORTED;
+        c32* fq_s = ctx->d_ws_fq + (all_symbols_at_once ? (size_t)s * n_frames * 128 : (size_t)0);
         if (!cfo_is_zero) {
             LaunchSpan span(ctx, ULTRA_HIP_K_WALK);
             hipLaunchKernelGGL(dev::cfo_walk_kernel, dim3((unsigned)((n_frames + 255) / 256)), dim3(256), 0, st, ctx->d_demod,
                                (int)n_frames, ctx->d_ws_state, ctx->d_ws_seg);
         }
-        {
+        if (!all_symbols_at_once) {
             LaunchSpan span(ctx, ULTRA_HIP_K_MIX_FFT);
             if (D.log2_fft == 10)
                 hipLaunchKernelGGL(dev::mix_fft_kernel<10>, dim3(grid_fft), dim3(dev::kWave), 0, st, ctx->d_demod,
                                    ctx->d_nco, ctx->d_twiddle, d_audio, frame_stride, d_frame_offset, (int)n_frames, s,
-                                   ctx->d_ws_state, ctx->d_ws_fq, seg_tab);
+                                   ctx->d_ws_state, fq_s, seg_tab, 1);
             else
                 hipLaunchKernelGGL(dev::mix_fft_kernel<9>, dim3(grid_fft), dim3(dev::kWave), 0, st, ctx->d_demod,
                                    ctx->d_nco, ctx->d_twiddle, d_audio, frame_stride, d_frame_offset, (int)n_frames, s,
-                                   ctx->d_ws_state, ctx->d_ws_fq, seg_tab);
+                                   ctx->d_ws_state, fq_s, seg_tab, 1);
         }
         const bool training = s < D.n_train;
         const bool last = (s == n_sym - 1);
         if (training) {
             LaunchSpan span(ctx, ULTRA_HIP_K_TRACK);
             hipLaunchKernelGGL(dev::train_kernel, dim3(grid_trk), dim3(dev::kWave), 0, st, ctx->d_demod, (int)n_frames, s,
-                               ctx->d_ws_state, ctx->d_ws_fq);
+                               ctx->d_ws_state, fq_s);
             continue;
         }
         // Data symbols: the pilot half of the channel update runs 4 (<= 16 pilots) or 2 (<= 32: every usable
@@ -217,16 +241,16 @@ int launch_demod(ultra_hip_ctx* ctx, const float* d_audio, size_t frame_stride, 
             if (D.n_pilot <= 16) {
                 const unsigned g = (unsigned)std::min((n_frames + 3) / 4, (size_t)ctx->cu_count * 256);
                 hipLaunchKernelGGL(dev::track_pilot_kernel<16>, dim3(g), dim3(dev::kWave), 0, st, ctx->d_demod, (int)n_frames,
-                                   ctx->d_ws_state, ctx->d_ws_fq);
+                                   ctx->d_ws_state, fq_s);
             } else {
                 const unsigned g = (unsigned)std::min((n_frames + 1) / 2, (size_t)ctx->cu_count * 512);
                 hipLaunchKernelGGL(dev::track_pilot_kernel<32>, dim3(g), dim3(dev::kWave), 0, st, ctx->d_demod, (int)n_frames,
-                                   ctx->d_ws_state, ctx->d_ws_fq);
+                                   ctx->d_ws_state, fq_s);
             }
         }
 #define UH_TRACK(MOD)                                                                                            \
     hipLaunchKernelGGL(dev::track_kernel<MOD>, dim3(grid_trk), dim3(dev::kWave), 0, st, ctx->d_demod, (int)n_frames,  \
-                       s - D.n_train, ctx->d_ws_state, ctx->d_ws_fq, d_llr, llr_stride, last ? d_state : nullptr)
+                       s - D.n_train, ctx->d_ws_state, fq_s, d_llr, llr_stride, last ? d_state : nullptr)
         LaunchSpan span(ctx, ULTRA_HIP_K_TRACK);
         switch (D.modulation) {
             case ULTRA_MOD_DBPSK: UH_TRACK(ULTRA_MOD_DBPSK); break;
@@ -543,6 +567,11 @@ int ultra_hip_reserve(ultra_hip_ctx* ctx, size_t n_frames) {
     if (n_frames == 0) return ULTRA_HIP_OK;
     DeviceGuard guard(ctx->device);
     int rc = ensure_demod_workspace(ctx, n_frames);
+    if (rc == ULTRA_HIP_OK) {          // one row per frame and symbol where launch_demod may transform all symbols at once
+        const DemodConst& D = ctx->h_demod;
+        const size_t syms = (!D.presynced && D.n_pilot == 0) ? (size_t)std::max(1, D.n_train + D.n_data_sym) : 1;
+        rc = ensure_fq_workspace(ctx, n_frames * syms);
+    }
     if (rc == ULTRA_HIP_OK) rc = ensure_llr_workspace(ctx, n_frames);
     return rc;
 }
