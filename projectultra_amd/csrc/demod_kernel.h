@@ -1082,14 +1082,17 @@ __global__ __launch_bounds__(kWave, 4) void train_kernel(const DemodConst* __res
 template <int MOD>
 __global__ __launch_bounds__(kWave, 6) void track_kernel(
     const DemodConst* __restrict__ Dp, int n_frames, int data_sym, float* __restrict__ state,
-    const c32* __restrict__ fq_all, float* __restrict__ llr, size_t llr_stride, float* __restrict__ state_out) {
+    const c32* __restrict__ fq_all, float* __restrict__ llr, size_t llr_stride, float* __restrict__ state_out,
+    int n_sym_batch) {
+    // n_sym_batch > 1 (zero-CFO layouts, whose bins of ALL symbols are already there: launch_demod): the wavefront walks
+    // data symbols data_sym .. data_sym + n_sym_batch - 1 of its frame with the tracker state in registers and LDS —
+    // one record read and one record write per frame instead of one of each per symbol, one launch instead of n_sym.
     __shared__ TrackShared sh;
     const DemodConst& D = *Dp;
     const int lane = threadIdx.x;
     const LaneConst lc = lane_constants(D);
     for (int frame = blockIdx.x; frame < n_frames; frame += gridDim.x) {
         float* st = state + (size_t)frame * kStFloats;
-        const c32* fq = fq_all + (size_t)frame * 128;
         Track tr;
         load_track(st, tr);
         // A layout without pilots leaves the pilot half of updateChannelEstimate three scalar effects (no pilot phase
@@ -1097,15 +1100,19 @@ __global__ __launch_bounds__(kWave, 6) void track_kernel(
         // taken here instead of in a track_pilot_kernel launch of their own (SYNCED entry; the presynced entry without
         // pilots never ran the estimate, demodulator.cpp:936-960).
         const bool scalar_pilot_half = D.n_pilot == 0 && !D.presynced;
-        if (scalar_pilot_half) { tr.ppc = mk(1.0f, 0.0f); tr.has_prev = 0; tr.snr_symbol_count++; }
         const bool compact = compact_pilot_state(D);
         if (!compact) sh.H[lane] = reinterpret_cast<const c32*>(st + kStH)[lane];
         else if (lane < D.n_pilot) sh.H[lc.pilot_slot] = reinterpret_cast<const c32*>(st + kStHp)[lane];   // the rest is interpolated before it is read
         c32 dprev = D.differential ? reinterpret_cast<const c32*>(st + kStDprev)[lane] : mk(1.0f, 0.0f);
         wave_sync();
-        if (!D.presynced || D.n_pilot != 0) finish_channel_estimate(sh, D, lc, tr);
-        equalize_demap<MOD>(sh, D, lc, tr, dprev, fq, llr + (size_t)frame * llr_stride + (size_t)data_sym * D.llrs_per_symbol);
-        wave_sync();
+        for (int ds = 0; ds < n_sym_batch; ++ds) {
+            const c32* fq = fq_all + ((size_t)ds * n_frames + frame) * 128;
+            if (scalar_pilot_half) { tr.ppc = mk(1.0f, 0.0f); tr.has_prev = 0; tr.snr_symbol_count++; }
+            if (!D.presynced || D.n_pilot != 0) finish_channel_estimate(sh, D, lc, tr);
+            equalize_demap<MOD>(sh, D, lc, tr, dprev, fq,
+                                llr + (size_t)frame * llr_stride + (size_t)(data_sym + ds) * D.llrs_per_symbol);
+            wave_sync();
+        }
         // write the record back
         if (!compact) reinterpret_cast<c32*>(st + kStH)[lane] = sh.H[lane];
         else if (lane < ((D.n_pilot + 15) & ~15))               // whole 128-byte lines: no partial-sector writes

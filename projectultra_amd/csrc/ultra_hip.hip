@@ -248,9 +248,12 @@ int launch_demod(ultra_hip_ctx* ctx, const float* d_audio, size_t frame_stride, 
                                    ctx->d_ws_state, fq_s);
             }
         }
+        // zero-CFO layouts: every symbol's bins are there already — one launch walks all data symbols of a frame
+        const int track_batch = all_symbols_at_once ? n_sym : 1;
+        const bool last_launch = last || all_symbols_at_once;
 #define UH_TRACK(MOD)                                                                                            \
     hipLaunchKernelGGL(dev::track_kernel<MOD>, dim3(grid_trk), dim3(dev::kWave), 0, st, ctx->d_demod, (int)n_frames,  \
-                       s - D.n_train, ctx->d_ws_state, fq_s, d_llr, llr_stride, last ? d_state : nullptr)
+                       s - D.n_train, ctx->d_ws_state, fq_s, d_llr, llr_stride, last_launch ? d_state : nullptr, track_batch)
         LaunchSpan span(ctx, ULTRA_HIP_K_TRACK);
         switch (D.modulation) {
             case ULTRA_MOD_DBPSK: UH_TRACK(ULTRA_MOD_DBPSK); break;
@@ -265,6 +268,7 @@ int launch_demod(ultra_hip_ctx* ctx, const float* d_audio, size_t frame_stride, 
             default: return ULTRA_HIP_ERR_UNSUPPORTED;
         }
 #undef UH_TRACK
+        if (all_symbols_at_once) break;          // that launch covered symbols s .. n_sym - 1 (s == 0 here)
     }
     UH_HIP(hipGetLastError());
     return ULTRA_HIP_OK;
