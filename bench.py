@@ -212,6 +212,7 @@ class ModemWorkload:
         n_sym = self.ctx.cfg.n_data_symbols
         self.per_launch = {"cfo_walk_kernel": 0, "mix_fft_kernel": g.symbol_samples * 4, "track_pilot_kernel": 0,
                            "track_kernel": -(-648 * 4 // n_sym), "ldpc_decode_kernel": 648 * 4 + g.decoded_bytes + 4 + 1}
+        self.per_step = {"mix_fft_kernel": self.n * n_sym * g.symbol_samples * 4, "track_kernel": self.n * 648 * 4}
         self.launch_units = self.n
         self.data = (f"synthetic ({self.n} distinct {self.channel} realisations per GPU generated on the device in HBM; "
                      f"random-payload codewords, {self.snr_db:g} dB)")
@@ -455,6 +456,7 @@ class ModeSweepWorkload:
         # per launch and frame: one symbol of audio (1120 samples) into mix_fft; the LLRs out of track_kernel and the
         # decoder's in/out differ from cell to cell (mean over the grid used)
         self.per_launch = {"mix_fft_kernel": 1120 * 4, "ldpc_decode_kernel": 648 * 4 + 50 + 4 + 1}
+        self.per_step = {"mix_fft_kernel": sum(S * n * sh.ctx.cfg.n_data_symbols * 1120 * 4 for sh in self.shards)}
         self.launch_units = n * S
         self.geo = self.shards[0].ctx.geometry
         self.data = (f"synthetic ({P} points x {n} distinct frames per GPU generated on the device in HBM, AWGN; "
@@ -627,6 +629,9 @@ def main():
                 continue
             avg = ms_total / launches
             alg = wl.launch_units * wl.per_launch.get(name, 0)
+            # kernels whose launch may cover one symbol or all symbols of a frame (zero-CFO layouts): bytes per step / launches
+            if name in getattr(wl, "per_step", {}):
+                alg = wl.per_step[name] / (launches / args.steps)
             kernels[name] = {"avg_launch_ms": avg, "launches_per_step": launches / args.steps, "ms_per_step": ms_total / args.steps,
                              "algorithmic_bytes_per_launch": alg, "GBps": alg / (avg * 1e-3) / 1e9,
                              "frac": alg / (avg * 1e-3) / 1e9 / HBM_PEAK_GBPS}
