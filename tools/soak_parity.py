@@ -1,7 +1,8 @@
 """Randomised parity soak (run on the GPU box): many mode / rate / channel / SNR / CFO combinations, a few
 thousand frames each, HIP path vs the oracle on the host cores — LLRs, decoded bytes, iteration counts and the
 tracker state compared BITWISE; presynced cases with the CFO "never set" for a tenth of the frames (training-symbol
-estimate), half of the cases with the channel's own CFO shift on their first rows (device shift vs oracle shift).    python3 tools/soak_parity.py [frames_per_case] [seed]"""
+estimate), half of the cases with the channel's own CFO shift on their first rows (device shift vs oracle shift);
+the layouts without pilots once more without initial offsets (the zero-CFO path of launch_demod).    python3 tools/soak_parity.py [frames_per_case] [seed]"""
 import itertools, sys, time
 import numpy as np, torch
 sys.path.insert(0, "."); sys.path.insert(0, "tests")
@@ -48,6 +49,15 @@ for (fft, mod, rate, kw), (chan, snr) in itertools.product(modes, (("watterson",
         ok = chan_ok and (np.array_equal(r["llr"].cpu().numpy().view(np.uint32), want["llr"].view(np.uint32))
               and np.array_equal(r["bytes"].cpu().numpy(), want["bytes"]) and np.array_equal(r["iters"].cpu().numpy(), want["iters"])
               and np.array_equal(r["ok"].cpu().numpy(), want["ok"]))
+        if entry == 0 and not kw.get("use_pilots") and mod in ("DQPSK", "D8PSK", "DBPSK"):
+            # no pilots, no initial offsets: the zero-CFO path (all symbols in one transform launch and one tracking launch)
+            want0 = o.demod_decode_batch(cfg, audio, n_threads=64)
+            r0 = ctx.demod_decode(audio, want_llr=True)
+            ctx.synchronize()
+            ok = ok and (np.array_equal(r0["llr"].cpu().numpy().view(np.uint32), want0["llr"].view(np.uint32))
+                         and np.array_equal(r0["bytes"].cpu().numpy(), want0["bytes"]) and np.array_equal(r0["iters"].cpu().numpy(), want0["iters"])
+                         and np.array_equal(r0["ok"].cpu().numpy(), want0["ok"]))
+            total += n
         total += n
         if not ok:
             bad += 1
