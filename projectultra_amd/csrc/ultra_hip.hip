@@ -209,7 +209,10 @@ int launch_demod(ultra_hip_ctx* ctx, const float* d_audio, size_t frame_stride, 
     }
     for (int s = 0; s < n_sym; ++s) {
         c32* fq_s = ctx->d_ws_fq + (all_symbols_at_once ? (size_t)s * n_frames * 128 : (size_t)0);
-        if (!cfo_is_zero) {
+        // the first symbol of a SYNCED batch without initial offsets is at CFO 0 in every frame: nothing to walk yet
+        const bool first_at_zero = s == 0 && !D.presynced && d_cfo_hz == nullptr;
+        const unsigned* seg_tab_s = first_at_zero ? nullptr : seg_tab;
+        if (!cfo_is_zero && !first_at_zero) {
             LaunchSpan span(ctx, ULTRA_HIP_K_WALK);
             hipLaunchKernelGGL(dev::cfo_walk_kernel, dim3((unsigned)((n_frames + 255) / 256)), dim3(256), 0, st, ctx->d_demod,
                                (int)n_frames, ctx->d_ws_state, ctx->d_ws_seg);
@@ -219,11 +222,11 @@ int launch_demod(ultra_hip_ctx* ctx, const float* d_audio, size_t frame_stride, 
             if (D.log2_fft == 10)
                 hipLaunchKernelGGL(dev::mix_fft_kernel<10>, dim3(grid_fft), dim3(dev::kWave), 0, st, ctx->d_demod,
                                    ctx->d_nco, ctx->d_twiddle, d_audio, frame_stride, d_frame_offset, (int)n_frames, s,
-                                   ctx->d_ws_state, fq_s, seg_tab, 1);
+                                   ctx->d_ws_state, fq_s, seg_tab_s, 1);
             else
                 hipLaunchKernelGGL(dev::mix_fft_kernel<9>, dim3(grid_fft), dim3(dev::kWave), 0, st, ctx->d_demod,
                                    ctx->d_nco, ctx->d_twiddle, d_audio, frame_stride, d_frame_offset, (int)n_frames, s,
-                                   ctx->d_ws_state, fq_s, seg_tab, 1);
+                                   ctx->d_ws_state, fq_s, seg_tab_s, 1);
         }
         const bool training = s < D.n_train;
         const bool last = (s == n_sym - 1);
