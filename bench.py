@@ -429,19 +429,23 @@ class ModeSweepWorkload:
         t0 = time.time()
         self.shards, self.audio, self.payload, self.outs = [], [], [], []
         resident = 0
+        # The cells are independent receive contexts with batches of S * n frames — too small to fill the chip at the
+        # ramp and the tail of every launch — so they are spread over a few HIP streams (one context per stream).
+        self.streams = [torch.cuda.Stream() for _ in range(int(os.environ.get("ULTRA_BENCH_CELL_STREAMS", "4")))]
         for ci, (m, r) in enumerate(self.cells):
-            sh = HipModemShard(nvis_cell_config(m, r), channel="awgn", batch=n)
-            g = sh.ctx.geometry
-            audio = torch.empty((S * n, g.frame_samples), dtype=torch.float32, device="cuda")
-            payload = torch.empty((S * n, g.ldpc_k // 8), dtype=torch.uint8, device="cuda")
-            for si, snr in enumerate(self.snrs):
-                sh.ctx.make_batch(n, seed=point_seed(0x5EED, ci * S + si), first_frame=lo, channel="awgn", snr_db=snr,
-                                  out=(audio[si * n:(si + 1) * n], payload[si * n:(si + 1) * n]))
-            resident += audio.numel() * 4
-            self.shards.append(sh); self.audio.append(audio); self.payload.append(payload)
-            self.outs.append(dict(bytes=torch.empty((S * n, g.decoded_bytes), dtype=torch.uint8, device="cuda"),
-                                  iters=torch.empty(S * n, dtype=torch.int32, device="cuda"),
-                                  ok=torch.empty(S * n, dtype=torch.uint8, device="cuda")))
+            with torch.cuda.stream(self.streams[ci % len(self.streams)]):
+                sh = HipModemShard(nvis_cell_config(m, r), channel="awgn", batch=n)
+                g = sh.ctx.geometry
+                audio = torch.empty((S * n, g.frame_samples), dtype=torch.float32, device="cuda")
+                payload = torch.empty((S * n, g.ldpc_k // 8), dtype=torch.uint8, device="cuda")
+                for si, snr in enumerate(self.snrs):
+                    sh.ctx.make_batch(n, seed=point_seed(0x5EED, ci * S + si), first_frame=lo, channel="awgn", snr_db=snr,
+                                      out=(audio[si * n:(si + 1) * n], payload[si * n:(si + 1) * n]))
+                resident += audio.numel() * 4
+                self.shards.append(sh); self.audio.append(audio); self.payload.append(payload)
+                self.outs.append(dict(bytes=torch.empty((S * n, g.decoded_bytes), dtype=torch.uint8, device="cuda"),
+                                      iters=torch.empty(S * n, dtype=torch.int32, device="cuda"),
+                                      ok=torch.empty(S * n, dtype=torch.uint8, device="cuda")))
         torch.cuda.synchronize()
         self.t_gen = time.time() - t0
         P = len(self.cells) * S
@@ -464,15 +468,23 @@ class ModeSweepWorkload:
         self.workload = (f"{{DBPSK,DQPSK,D8PSK,16QAM,32QAM}} x {{R1/4,R1/3,R1/2,R2/3,R3/4,R5/6}} on OFDM 1024-FFT / 59 carriers, SNR "
                          f"{self.snrs[0]:g}..{self.snrs[-1]:g} dB in 3 dB steps, post-sync entry, {n} frames per point per GPU per step, "
                          f"the {S} points of a cell in one batch")
-        self.parallelism = f"frames of every point sharded over {world} GPU(s), one all-reduce of the counter block per mode/rate cell"
+        self.parallelism = (f"frames of every point sharded over {world} GPU(s), one all-reduce of the counter block per mode/rate cell; "
+                            f"the cells' contexts spread over {len(self.streams)} HIP streams")
 
     def step(self, allreduce):
+        torch = self.torch
         self.counters.zero_()
         S, n = len(self.snrs), self.n
+        main = torch.cuda.current_stream()
+        for st in self.streams:
+            st.wait_stream(main)                                 # the zeroed counters
         for ci, (sh, audio, payload, out) in enumerate(zip(self.shards, self.audio, self.payload, self.outs)):
-            r = sh.ctx.demod_decode(audio, out=out)
-            sh.ctx.count_errors_points(r, payload, self.counters[ci * S:(ci + 1) * S])
-            allreduce(self.counters[ci * S:(ci + 1) * S])
+            with torch.cuda.stream(self.streams[ci % len(self.streams)]):
+                r = sh.ctx.demod_decode(audio, out=out)
+                sh.ctx.count_errors_points(r, payload, self.counters[ci * S:(ci + 1) * S])
+                allreduce(self.counters[ci * S:(ci + 1) * S])
+        for st in self.streams:
+            main.wait_stream(st)
 
     def contexts(self):
         return [sh.ctx for sh in self.shards]
@@ -502,11 +514,12 @@ class ModeSweepWorkload:
         t_port = t_ref = 0.0
         ok_port = ok_ref = True
         total = 0
-        for (m, r), sh, a_cell in zip(self.cells, self.shards, self.audio):
+        for ci, ((m, r), sh, a_cell) in enumerate(zip(self.cells, self.shards, self.audio)):
             ccfg = make_config(1024, m.name, r.name)
             audio = np.concatenate([a_cell[si * n:si * n + per].cpu().numpy() for si in range(S)])
-            got = sh.ctx.demod_decode(self.torch.from_numpy(audio).cuda())
-            got = {k: v.cpu().numpy() for k, v in got.items()}
+            with self.torch.cuda.stream(self.streams[ci % len(self.streams)]):      # the cell's context lives on this stream
+                got = sh.ctx.demod_decode(self.torch.from_numpy(audio).cuda())
+                got = {k: v.cpu().numpy() for k, v in got.items()}
             t0 = time.perf_counter()
             w = o.demod_decode_batch(ccfg, audio, n_threads=cores, want_llr=False, want_state=False)
             t_port += time.perf_counter() - t0
