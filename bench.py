@@ -15,7 +15,12 @@
 A "step" = one pass of the configuration's hot path over this rank's batch of synthetic input, inputs already resident
 in HBM (generated on the device before the timed region), ending in the configuration's collective: ONE all-reduce of
 the eight uint64 counters per step (cfg2/cfg3/raw) or per sweep point (cfg4/cfg5).  Trials shard embarrassingly; per-GPU
-work is fixed as N grows (weak scaling).
+work is fixed as N grows (weak scaling) for every config but cfg3 (below).
+
+cfg3 (the headline) is STRONG scaling by default: ONE batch of 2^20 frames per step (north_star), rank r takes the
+contiguous shard shard_range(2^20, r, N); --frames n switches to weak scaling with n frames per GPU (configs[2] is
+--frames 262144 on one GPU).  The timed step delivers everything SURVEY.md 8(d) prices: decoded bytes, iteration counts,
+status AND the frame's soft bits in a caller-owned buffer.
 
 Prints ONE JSON line on rank 0 (see the driver contract) with the extra objects
   roofline      dominant kernel: algorithmic bytes per launch / mean launch duration (HIP events), HBM and LDS/VALU view
@@ -64,7 +69,10 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--frames", type=int, default=0, help="trials per GPU per step (per sweep point for cfg4/cfg5); 0 = the config's size")
+    ap.add_argument("--frames", type=int, default=0, help="trials per GPU per step (per sweep point for cfg4/cfg5): WEAK scaling; 0 = the config's size")
+    ap.add_argument("--total-frames", type=int, default=0,
+                    help="cfg2/cfg3: trials per step over ALL GPUs, sharded contiguously (STRONG scaling). cfg3 defaults to "
+                         "2^20 — north_star's batch at 1, 2, 4 and 8 GPUs — unless --frames is given")
     ap.add_argument("--snr-db", type=float, default=None, help="cfg2/cfg3/raw: channel SNR (default 30 dB cfg3/raw, 3 dB cfg2)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample", type=int, default=0, help="trials for the CPU baseline (0 = auto)")
@@ -179,14 +187,14 @@ class ModemWorkload:
         if name == "cfg3":
             mc = presets.nvis_mode().with_mode(Modulation.QAM16, CodeRate.R3_4)
             mc.pilot_spacing = 4                           # tools/test_nvis_mode.cpp:208-212
-            self.n = args.frames or (1 << 18)
+            total = 0 if args.frames else (args.total_frames or (1 << 20))
             self.channel, self.snr_db = "watterson", 30.0 if args.snr_db is None else args.snr_db
             self.metric = "OFDM-1024 16QAM R3/4 frames decoded/sec"
             self.what = "OFDM 1024-FFT 16QAM R3/4, 59 carriers (15 pilots), Watterson good channel (0.5 ms / 0.1 Hz)"
             self.oracle_cfg = (1024, "QAM16", "R3_4")
         else:
             mc = ModemConfig().with_mode(Modulation.DQPSK, CodeRate.R1_2)      # tools/test_mode_snr.cpp:21-31
-            self.n = args.frames or (1 << 16)
+            total = 0 if args.frames else args.total_frames
             self.channel, self.snr_db = "awgn", 3.0 if args.snr_db is None else args.snr_db
             self.metric = "OFDM-512 DQPSK R1/2 frames decoded/sec"
             self.what = "OFDM 512-FFT DQPSK R1/2, 30 carriers (no pilots), AWGN"
@@ -194,15 +202,23 @@ class ModemWorkload:
         self.unit = "frames/s"
         self.ctx = ReceiveContext(mc)
         g = self.geo = self.ctx.geometry
-        lo, _ = shard_range(self.n * world, rank, world)           # global frame ids of this rank
+        if total:                                                  # strong scaling: one batch, contiguous shards
+            lo, hi = shard_range(total, rank, world)
+            self.n, self.scaling, self.total_units = hi - lo, "strong", total
+        else:                                                      # weak scaling: the same batch size on every GPU
+            self.n = args.frames or (1 << 16)
+            lo, _ = shard_range(self.n * world, rank, world)       # global frame ids of this rank
+            self.scaling, self.total_units = "weak", self.n * world
         t0 = time.time()
         self.d_audio, self.d_payload = self.ctx.make_batch(self.n, seed=0x5EED, first_frame=lo, channel=self.channel,
                                                            snr_db=self.snr_db, delay_ms=0.5, doppler_hz=0.1)
         torch.cuda.synchronize()
         self.t_gen = time.time() - t0
+        # everything SURVEY.md 8(d) counts as output is handed to the caller, the soft bits included
         self.out = dict(bytes=torch.empty((self.n, g.decoded_bytes), dtype=torch.uint8, device="cuda"),
                         iters=torch.empty(self.n, dtype=torch.int32, device="cuda"),
-                        ok=torch.empty(self.n, dtype=torch.uint8, device="cuda"))
+                        ok=torch.empty(self.n, dtype=torch.uint8, device="cuda"),
+                        llr=torch.empty((self.n, g.llrs_per_frame), dtype=torch.float32, device="cuda"))
         self.counters = torch.zeros(8, dtype=torch.int64, device="cuda")
         self.units_per_step = self.n
         self.points_per_step = 1
@@ -216,7 +232,12 @@ class ModemWorkload:
         self.launch_units = self.n
         self.data = (f"synthetic ({self.n} distinct {self.channel} realisations per GPU generated on the device in HBM; "
                      f"random-payload codewords, {self.snr_db:g} dB)")
-        self.workload = f"{self.what}, post-sync entry, LDPC min-sum <= 50 iterations, {self.n} frames per GPU per step"
+        if self.scaling == "strong":
+            self.workload = (f"{self.what}, post-sync entry, LDPC min-sum <= 50 iterations, ONE batch of {total} frames per step "
+                             f"sharded over {world} GPU(s) ({self.n} on rank {rank}); soft bits delivered to the caller")
+        else:
+            self.workload = (f"{self.what}, post-sync entry, LDPC min-sum <= 50 iterations, {self.n} frames per GPU per step; "
+                             f"soft bits delivered to the caller")
         self.parallelism = f"frames sharded over {world} GPU(s), one counter all-reduce per step"
 
     def step(self, allreduce):
@@ -630,7 +651,7 @@ def main():
     elapsed = float(t_max.item())
     last = wl.counters.reshape(-1, 8).sum(dim=0).cpu()
     stats = counters_dict(last)
-    expect = wl.units_per_step * world
+    expect = getattr(wl, "total_units", wl.units_per_step * world)
     assert stats["frames"] == expect, f"counted {stats['frames']} trials per step, expected {expect}"
 
     # ---- roofline of the dominant kernel (largest share of the step), rank 0 --------------------------------------
@@ -660,12 +681,24 @@ def main():
         tf = ROOT / "profiles" / "traffic.json"
         if tf.exists():
             try:
+                from projectultra_amd._lib import source_hash
                 t = json.loads(tf.read_text())
-                if t.get("n_frames") == wl.launch_units and t.get("config", "cfg3") == args.config:
+                why = None
+                if t.get("config", "cfg3") != args.config:
+                    why = f"collected for {t.get('config')}, this line is {args.config}"
+                elif t.get("n_frames") != wl.launch_units:
+                    why = f"collected at {t.get('n_frames')} units per launch, this run has {wl.launch_units}"
+                elif t.get("csrc_sha") != source_hash():
+                    why = (f"collected on kernel sources {t.get('csrc_sha')} (commit {t.get('commit')}), the tree holds "
+                           f"{source_hash()}: counters of another kernel are not quoted")
+                if why is None:
                     roofline["traffic"] = t.get("kernels", {}).get(dom, {}).get("hbm_bytes_per_launch")
-                    roofline["traffic_source"] = {"file": "profiles/traffic.json", "commit": t.get("commit"), "collected": t.get("collected")}
-            except Exception:
-                pass
+                    roofline["traffic_source"] = {"file": "profiles/traffic.json", "commit": t.get("commit"),
+                                                  "csrc_sha": t.get("csrc_sha"), "collected": t.get("collected")}
+                else:
+                    roofline["traffic_dropped"] = why
+            except Exception as e:
+                roofline["traffic_dropped"] = f"profiles/traffic.json unreadable: {e}"
         # What actually bounds the decoder: the CU's single LDS pipeline.  One codeword-iteration of the lane-linear
         # instances (R2/3, R3/4, R5/6) issues E gather reads + E scattered stores (check step) and E lane-linear reads +
         # E add-TID stores (variable step), E = information-edge slots of the instance's degree profile; the other
@@ -738,13 +771,14 @@ def main():
                    gpu_matches_cpu_bitwise=head["gpu_matches_bitwise"], legs=res)
 
     if rank == 0:
-        total = wl.units_per_step * world * args.steps
+        total = getattr(wl, "total_units", wl.units_per_step * world) * args.steps
         value = total / elapsed
         line = {
             "metric": wl.metric, "value": value, "unit": wl.unit, "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": getattr(wl, "scaling", "weak"), "vs_baseline": None,
             "dtype": "f32", "data": wl.data,
             "config": {"workload": wl.workload, "name": args.config, "trials_per_gpu_per_step": wl.units_per_step,
+                       "trials_per_step_all_gpus": getattr(wl, "total_units", wl.units_per_step * world),
                        "bytes_per_trial": wl.bytes_per_unit, "parallelism": wl.parallelism},
             "achieved_hbm_GBps": value * wl.bytes_per_unit / 1e9,
             "hbm_frac_of_peak": value * wl.bytes_per_unit / 1e9 / (HBM_PEAK_GBPS * world),

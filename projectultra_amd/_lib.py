@@ -7,11 +7,14 @@ the product path fails loudly instead of silently computing somewhere else.
 from __future__ import annotations
 
 import ctypes as C
+import os
 import subprocess
 from pathlib import Path
 
 PKG_DIR = Path(__file__).resolve().parent
-LIB_PATH = PKG_DIR / "libultra_hip.so"
+# ULTRA_HIP_LIB: a VARIANT build of the same sources (tools/variants_bench.sh, tools/mix_fft_stalls.py) — never a fallback:
+# whatever is named must exist and export the whole ABI
+LIB_PATH = Path(os.environ["ULTRA_HIP_LIB"]).resolve() if os.environ.get("ULTRA_HIP_LIB") else PKG_DIR / "libultra_hip.so"
 CSRC_DIR = PKG_DIR / "csrc"
 
 ULTRA_HIP_ABI_VERSION = 4
@@ -92,6 +95,17 @@ PROTOTYPES = {
 }
 
 _LIB = None
+
+
+def source_hash() -> str:
+    """sha256[:16] over the device/host sources the library is built from (csrc/*, include/ultra_hip.h), in name order.
+    Evidence files that describe the KERNELS (profiles/traffic*.json, SQ counters) carry it, so a reader — bench.py — can
+    tell whether they were collected on the code that is in the tree now; it works on the GPU box, where no .git exists."""
+    import hashlib
+    h = hashlib.sha256()
+    for f in sorted(list(CSRC_DIR.glob("*.h")) + list(CSRC_DIR.glob("*.hip")) + [PKG_DIR.parent / "include" / "ultra_hip.h"]):
+        h.update(f.name.encode()); h.update(b"\0"); h.update(f.read_bytes())
+    return h.hexdigest()[:16]
 
 
 def build(force: bool = False) -> Path:

@@ -224,6 +224,33 @@ template <int A> __device__ __forceinline__ constexpr int bitrev_small(int q) {
     } while (0)
 
 // ---------------------------------------------------------------------------
+// Diagnostic build only (-DUH_MIXFFT_STAMPS, tools/mix_fft_stalls.py): shader-clock stamps at the phase boundaries of
+// every work item of mix_fft_kernel / mix_fft2_kernel, one record of kStampWords 64-bit words per wavefront and item:
+// [0..kStampPhases] clock, then HW_ID (wave slot / SIMD / CU / SE) and XCC_ID.  The product build contains none of it.
+constexpr int kStampPhases = 10, kStampWords = 12;
+#ifdef UH_MIXFFT_STAMPS
+__device__ unsigned long long* g_mix_stamps = nullptr;
+struct Stamps {
+    unsigned long long t[kStampPhases + 1];
+    // s_memtime, followed by a marker comment in the ISA so that the tool can cut the static code into the same phases
+    template <int K> __device__ __forceinline__ void at() { t[K] = __builtin_readcyclecounter(); asm volatile("; UHSTAMP %0" ::"n"(K)); }
+    __device__ __forceinline__ void store(size_t record, int lane) {
+        if (g_mix_stamps == nullptr || lane != 0) return;
+        unsigned hw, xcc;
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+        unsigned long long* r = g_mix_stamps + record * kStampWords;
+        for (int k = 0; k <= kStampPhases; ++k) r[k] = t[k];
+        r[kStampPhases + 1] = ((unsigned long long)xcc << 32) | hw;
+    }
+};
+#define UH_STAMP(k) stamps.template at<k>()
+#else
+struct Stamps { __device__ __forceinline__ void store(size_t, int) {} };
+#define UH_STAMP(k) do {} while (0)
+#endif
+
+// ---------------------------------------------------------------------------
 // Asynchronous HBM -> LDS copy of the FFT window of one symbol (global_load_lds: no VGPRs, the
 // wave keeps computing).  The staging area aliases the FFT exchange buffer X, which is idle
 // between the last FFT stage of one symbol and the first LDS transpose of the next, so the HBM
@@ -244,8 +271,9 @@ template <int LOG2N>
 __device__ __forceinline__ void symbol_to_freq(FftShared<LOG2N>& sh, const DemodConst& D, float freq_offset_hz,
                                                float& cfo_phase, const c32* __restrict__ nco_sym,
                                                const c32* __restrict__ twiddle, c32* __restrict__ fq_out,
-                                               const unsigned* __restrict__ seg_tab) {
+                                               const unsigned* __restrict__ seg_tab, Stamps& stamps) {
     constexpr int N = 1 << LOG2N, P = N / kWave, A = FftShared<LOG2N>::A;
+    UH_STAMP(0);
     const int lane = threadIdx.x;
     const int rl = (int)(__brev((unsigned)lane) >> 26);      // bitrev6(lane)
     const bool cfo_on = fabsf(freq_offset_hz) > 0.01f;
@@ -268,6 +296,8 @@ __device__ __forceinline__ void symbol_to_freq(FftShared<LOG2N>& sh, const Demod
 #pragma unroll
     for (int qp = 0; qp < P; ++qp) xs[qp] = stage[64 * qp + rl];
     wave_sync();                                                                // X may be overwritten from here on
+    UH_STAMP(1);
+    UH_STAMP(2);
 
     // ---- CFO rotation factors (toBaseband: phase recurrence + cos/sin per sample) ----
     // Lane l produces the factors of the P CONSECUTIVE window positions P*l .. P*l+P-1 (they
@@ -352,6 +382,7 @@ __device__ __forceinline__ void symbol_to_freq(FftShared<LOG2N>& sh, const Demod
             pcur = pnext;
         }
         cfo_phase = pcur;
+        UH_STAMP(2);
         if (bounded) {
 #pragma unroll
             for (int j = 0; j < P; ++j) {
@@ -366,6 +397,7 @@ __device__ __forceinline__ void symbol_to_freq(FftShared<LOG2N>& sh, const Demod
         }
         wave_sync();
     }
+    UH_STAMP(3);
     // ---- mix: samples[i] * conj(osc) (* rotation), in two halves to bound live registers ----
 #pragma unroll
     for (int h = 0; h < 2; ++h) {
@@ -381,6 +413,7 @@ __device__ __forceinline__ void symbol_to_freq(FftShared<LOG2N>& sh, const Demod
         }
     }
     if (cfo_on) wave_sync();
+    UH_STAMP(4);
 
     // ---- group A: stages 0..A-1 on the lane's P consecutive (bit-reversed) positions ----
 #pragma unroll
@@ -396,6 +429,7 @@ __device__ __forceinline__ void symbol_to_freq(FftShared<LOG2N>& sh, const Demod
 #pragma unroll
     for (int q = 0; q < P; ++q) { const int i = P * lane + q; sh.X[i + (i >> A)] = v[q]; }
     wave_sync();
+    UH_STAMP(5);
 
     // ---- group B: stages A..2A-1, lane (blk, r) holds X[blk*P*P + r + P*j] ----
     {
@@ -417,6 +451,7 @@ __device__ __forceinline__ void symbol_to_freq(FftShared<LOG2N>& sh, const Demod
         for (int j = 0; j < P; ++j) { const int i = blk * P * P + r + P * j; sh.X[i + (i >> A)] = v[j]; }
     }
     wave_sync();
+    UH_STAMP(6);
 
     // ---- group C: stages 2A..LOG2N-1, lane holds X[lane + 64*t]; only outputs t = 0 and
     //      t = P-1 (bins `lane` and N-64+lane) are used, the rest is dead code ----
@@ -434,10 +469,261 @@ __device__ __forceinline__ void symbol_to_freq(FftShared<LOG2N>& sh, const Demod
                 UH_BUTTERFLY(v[t], v[t + ht], w);
             }
         }
+        UH_STAMP(7);
+        UH_STAMP(8);
         fq_out[lane] = v[0];
         fq_out[64 + lane] = v[P - 1];
     }
     wave_sync();
+    UH_STAMP(9);
+}
+
+// ---------------------------------------------------------------------------
+// TWO WAVEFRONTS PER FRAME (N = 1024).  The radix-2 decimation-in-time network of fft_impl (fft.cpp:89-121) works
+// on the bit-reversed input: positions [0, N/2) hold the EVEN time samples, [N/2, N) the odd ones, and stages
+// 0 .. log2(N)-2 never cross that line — they are two independent N/2-point transforms (with the twiddles
+// W_N^(2k) = twiddle[k << (LOG2N-1-s)], the very table entries the one-wavefront kernel reads).  Only the last
+// stage pairs element k of the even half with element k of the odd half.  So wavefront h of a 128-thread workgroup
+// takes the samples of parity h — 8 points per lane instead of 16: the lane's oscillator values, rotation phases,
+// sincos temporaries and butterfly registers all halve (<= 96 VGPRs instead of 154, five or six wavefronts per SIMD
+// instead of three) — runs mixing, CFO rotation and nine stages on its own, exactly like the 512-point instance, and
+// meets its partner ONCE per frame: the last stage needs E[k] + w O[k] for the bins k < 64 (wavefront 0 computes them
+// from its own E and the partner's O) and E[k] - w O[k] for k >= 448 (bins N-64 .. N-1, wavefront 1).  Same operations
+// on the same operands in the same order as the one-wavefront kernel: bit-identical bins.
+template <int LOG2N>
+struct Fft2Shared {
+    static_assert(LOG2N == 10, "two-wavefront layout: N = 1024");
+    static constexpr int N = 1 << LOG2N, M = N / 2;         // M-point transform per wavefront
+    static constexpr int P = M / kWave;                     // 8 points per lane
+    static constexpr int A = 3;                             // log2(P); 3 groups of 3 stages + the joint last stage
+    c32 X[2][M + M / P];                                    // per-wavefront exchange buffer, 1 pad per P entries
+    static constexpr int kTwB = P * ((1 << A) - 1);
+    c32 twB[kTwB];                                          // twiddles of stages A..2A-1 (as in FftShared)
+    um::PhaseSeg seg[2][kPhaseCap];
+    int seg_start[2][kPhaseCap + 4] __attribute__((aligned(16)));
+    c32 xch[2][2][kWave];                                   // [frame parity][writer][lane]: E_hi from wavefront 0, O_lo from 1
+};
+
+// staging of the samples of parity h of one symbol's FFT window: stage[64 q + l] = window[2 (64 q + l) + h]
+template <int LOG2N>
+__device__ __forceinline__ void prefetch_symbol2(Fft2Shared<LOG2N>& sh, const DemodConst& D, int h, int lane,
+                                                 const float* __restrict__ audio_sym) {
+    constexpr int P = Fft2Shared<LOG2N>::P;
+    float* stage = reinterpret_cast<float*>(sh.X[h]);
+#pragma unroll
+    for (int q = 0; q < P; ++q)
+        __builtin_amdgcn_global_load_lds(audio_sym + D.cp + 2 * (64 * q + lane) + h, stage + 64 * q, 4, 0, 0);
+}
+
+template <int LOG2N>
+__device__ __forceinline__ void symbol_to_freq2(Fft2Shared<LOG2N>& sh, const DemodConst& D, const int h, const int lane,
+                                                float freq_offset_hz, float& cfo_phase, const c32* __restrict__ nco_sym,
+                                                const c32* __restrict__ twiddle, c32* __restrict__ fq_out,
+                                                const unsigned* __restrict__ seg_tab, const int par, Stamps& stamps) {
+    constexpr int P = Fft2Shared<LOG2N>::P, A = Fft2Shared<LOG2N>::A;
+    UH_STAMP(0);
+    const int rl = (int)(__brev((unsigned)lane) >> 26);      // bitrev6(lane)
+    const bool cfo_on = fabsf(freq_offset_hz) > 0.01f;
+    c32* X = sh.X[h];
+    um::PhaseSeg* seg = sh.seg[h];
+    int* seg_start = sh.seg_start[h];
+    c32 v[P];
+    const float* stage = reinterpret_cast<const float*>(X);
+    int tab_ns = 0, tab_covered = 0, tab_start = 0x7fffffff;
+    float tab_pnext = 0.0f, tab_base = 0.0f, tab_step = 0.0f;
+    if (cfo_on && seg_tab) {
+        tab_ns = (int)seg_tab[0]; tab_covered = (int)seg_tab[1]; tab_pnext = __uint_as_float(seg_tab[2]);
+        if (lane < tab_ns) {
+            tab_start = (int)seg_tab[4 + 3 * lane];
+            tab_base = __uint_as_float(seg_tab[5 + 3 * lane]);
+            tab_step = __uint_as_float(seg_tab[6 + 3 * lane]);
+        }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                            // staged audio has landed
+    wave_sync();
+    float xs[P];
+#pragma unroll
+    for (int qp = 0; qp < P; ++qp) xs[qp] = stage[64 * qp + rl];               // window sample 2 (rl + 64 qp) + h
+    wave_sync();                                                                // X may be overwritten from here on
+    UH_STAMP(1);
+    UH_STAMP(2);
+
+    // ---- CFO rotation factors: lane l evaluates the P samples of its parity at local indices m = P l .. P l + P - 1
+    //      (window positions 2 m + h: a run of 2 P positions, almost always inside one segment) ----
+    c32* rot = X;                                          // rot[m + (m >> A)]
+    c32 os_first[P / 2];
+#pragma unroll
+    for (int q2 = 0; q2 < P / 2; ++q2) os_first[q2] = nco_sym[D.cp + 2 * (rl + 64 * q2) + h];
+    if (cfo_on) {
+        const float inc = (float)(((-kTwoPi) * (double)freq_offset_hz) / (double)D.sample_rate);
+        const bool bounded = fabsf(cfo_phase) <= 4.0f && fabsf(inc) <= 1.0f;
+        float ph[P];
+#pragma unroll
+        for (int j = 0; j < P; ++j) ph[j] = 0.0f;
+        int done = 0;
+        float pcur = cfo_phase;
+        while (done < D.sym_len) {                           // one round unless a table overflows
+            int covered;
+            float pnext;
+            int my_start = 0x7fffffff;
+            float my_base = 0.0f, my_step = 0.0f;
+            int ns;
+            if (done == 0 && seg_tab) {
+                ns = tab_ns; covered = tab_covered; pnext = tab_pnext;
+                my_start = tab_start; my_base = tab_base; my_step = tab_step;
+            } else {
+                ns = um::phase_table_walk(pcur, inc, D.sym_len - done, kPhaseCap, &covered, &pnext,
+                                          [&](int k, int start, float base, float step) {
+                                              const bool mine = (lane == k);
+                                              my_start = mine ? start : my_start;
+                                              my_base = mine ? base : my_base;
+                                              my_step = mine ? step : my_step;
+                                          });
+            }
+            if (lane < kPhaseCap) { seg[lane].start = my_start; seg[lane].base = my_base; seg[lane].step = my_step; }
+            if (lane < kPhaseCap + 4) seg_start[lane] = my_start;            // INT_MAX beyond the last segment
+            wave_sync();
+            const int i0 = D.cp + 2 * P * lane + h - done;  // position of the lane's first sample inside this round
+            const int ilast = i0 + 2 * (P - 1);
+            if (ilast >= 0 && i0 < covered) {
+                // first of the lane's positions that lies inside the round (i0 < 0 only behind a table overflow)
+                const int ifirst = (i0 >= 0) ? i0 : (i0 & 1);
+                int cnt = 1;                                 // segments starting at or before ifirst (segment 0 starts at 0)
+                for (int k = 1; k < ns; ++k) cnt += (__builtin_amdgcn_readlane(my_start, k) <= ifirst) ? 1 : 0;
+                int sg = cnt - 1;
+                um::PhaseSeg cur = seg[sg];
+                int nstart = seg_start[sg + 1];
+                if (i0 >= 0 && ilast < covered && ilast < nstart) {          // the usual case: one segment
+#pragma unroll
+                    for (int j = 0; j < P; ++j) ph[j] = um::phase_table_eval(cur, i0 + 2 * j);
+                } else if (i0 >= 0 && ilast < covered && ilast < seg_start[sg + 2]) {
+                    const um::PhaseSeg nxt = seg[sg + 1];                    // one boundary inside the run
+#pragma unroll
+                    for (int j = 0; j < P; ++j) {
+                        const int i = i0 + 2 * j;
+                        const float a = um::phase_table_eval(cur, i), b = um::phase_table_eval(nxt, i);
+                        ph[j] = (i < nstart) ? a : b;
+                    }
+                } else {
+#pragma unroll
+                    for (int j = 0; j < P; ++j) {
+                        const int i = i0 + 2 * j;
+                        if (i >= 0 && i < covered) {
+                            while (i >= nstart) { ++sg; cur = seg[sg]; nstart = seg_start[sg + 1]; }
+                            ph[j] = um::phase_table_eval(cur, i);
+                        }
+                    }
+                }
+            }
+            wave_sync();
+            done += covered;
+            pcur = pnext;
+        }
+        cfo_phase = pcur;
+        UH_STAMP(2);
+        if (bounded) {
+#pragma unroll
+            for (int j = 0; j < P; ++j) {
+                float sn, cs;
+                um::sincosf_bounded_(ph[j], &sn, &cs);
+                const int m = P * lane + j;
+                rot[m + (m >> A)] = mk(cs, sn);
+                // two evaluations at a time: their f64 chains cover each other, more in flight only costs registers
+                if (j & 1) __builtin_amdgcn_sched_barrier(0);
+            }
+        } else {
+#pragma unroll 2
+            for (int j = 0; j < P; ++j) { const int m = P * lane + j; rot[m + (m >> A)] = cexpj(ph[j]); }
+        }
+        wave_sync();
+    }
+    UH_STAMP(3);
+    // ---- mix: samples[i] * conj(osc) (* rotation) ----
+#pragma unroll
+    for (int hh = 0; hh < 2; ++hh) {
+        c32 os[P / 2];
+#pragma unroll
+        for (int q2 = 0; q2 < P / 2; ++q2)
+            os[q2] = (hh == 0) ? os_first[q2] : nco_sym[D.cp + 2 * (rl + 64 * (P / 2 + q2)) + h];
+#pragma unroll
+        for (int q2 = 0; q2 < P / 2; ++q2) {
+            const int qp = hh * (P / 2) + q2;
+            c32 mixed = mk(os[q2].re * xs[qp], (-os[q2].im) * xs[qp]);
+            if (cfo_on) { const int m = rl + 64 * qp; mixed = cmul(mixed, rot[m + (m >> A)]); }
+            v[bitrev_small<A>(qp)] = mixed;
+        }
+    }
+    if (cfo_on) wave_sync();
+    UH_STAMP(4);
+
+    // ---- group A: stages 0..A-1 on the lane's P consecutive (bit-reversed) positions of its half ----
+#pragma unroll
+    for (int s = 0; s < A; ++s) {
+        const int half = 1 << s;
+#pragma unroll
+        for (int q = 0; q < P; ++q) {
+            if (q & half) continue;
+            const c32 w = twiddle[(q & (half - 1)) << (LOG2N - 1 - s)];   // wave-uniform
+            UH_BUTTERFLY(v[q], v[q + half], w);
+        }
+    }
+#pragma unroll
+    for (int q = 0; q < P; ++q) { const int i = P * lane + q; X[i + (i >> A)] = v[q]; }
+    wave_sync();
+    UH_STAMP(5);
+    // ---- group B: stages A..2A-1, lane (blk, r) holds X[blk*P*P + r + P*j] ----
+    {
+        const int blk = lane / P, r = lane % P;
+#pragma unroll
+        for (int j = 0; j < P; ++j) { const int i = blk * P * P + r + P * j; v[j] = X[i + (i >> A)]; }
+#pragma unroll
+        for (int s = A; s < 2 * A; ++s) {
+            const int hj = 1 << (s - A);
+#pragma unroll
+            for (int j = 0; j < P; ++j) {
+                if (j & hj) continue;
+                const int k = r + P * (j & (hj - 1));
+                const c32 w = sh.twB[P * (hj - 1) + k];
+                UH_BUTTERFLY(v[j], v[j + hj], w);
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < P; ++j) { const int i = blk * P * P + r + P * j; X[i + (i >> A)] = v[j]; }
+    }
+    wave_sync();
+    UH_STAMP(6);
+    // ---- group C: stages 2A..3A-1 = LOG2N-2, lane holds X[lane + 64*t]; only t = 0 (elements 0..63 of the half) and
+    //      t = P-1 (elements M-64..M-1) feed bins that are used ----
+    {
+#pragma unroll
+        for (int t = 0; t < P; ++t) { const int i = lane + 64 * t; v[t] = X[i + (i >> A)]; }
+#pragma unroll
+        for (int s = 2 * A; s < 3 * A; ++s) {
+            const int ht = 1 << (s - 6);
+#pragma unroll
+            for (int t = 0; t < P; ++t) {
+                if (t & ht) continue;
+                const int k = lane + 64 * (t & (ht - 1));
+                const c32 w = twiddle[k << (LOG2N - 1 - s)];
+                UH_BUTTERFLY(v[t], v[t + ht], w);
+            }
+        }
+    }
+    UH_STAMP(7);
+    // ---- last stage (LOG2N-1): element k of the even half with element k of the odd half, w = twiddle[k] ----
+    const c32 w_last = twiddle[h ? (Fft2Shared<LOG2N>::M - 64 + lane) : lane];
+    sh.xch[par][h][lane] = h ? v[0] : v[P - 1];              // what the partner needs: O_lo from 1, E_hi from 0
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    UH_STAMP(8);
+    {
+        const c32 other = sh.xch[par][1 - h][lane];
+        c32 a = h ? other : v[0];                             // even half's element
+        c32 b = h ? v[P - 1] : other;                         // odd half's element
+        UH_BUTTERFLY(a, b, w_last);
+        fq_out[64 * h + lane] = h ? b : a;                    // bins `lane` (a + t) / N-64+lane (a - t)
+    }
+    wave_sync();
+    UH_STAMP(9);
 }
 
 // interpolateChannel (channel_equalizer.cpp:601-631): one lane per table entry
@@ -1009,11 +1295,59 @@ __global__ __launch_bounds__(kWave, 2) void mix_fft_kernel(
         float* st = state + (size_t)frame * kStFloats;
         const float cfo = st[st_cfo];
         float phase = st[st_cfo_phase];
+        Stamps stamps;
         symbol_to_freq<LOG2N>(sh, D, cfo, phase, nco + (size_t)(sym + ds) * D.sym_len, twiddle, fq + (size_t)w * 128,
-                              seg_tab ? seg_tab + (size_t)frame * kSegTabWords : nullptr);
+                              seg_tab ? seg_tab + (size_t)frame * kSegTabWords : nullptr, stamps);
         if (lane == 0 && n_sym_batch == 1) st[st_cfo_phase] = phase;
         const int next = w + (int)gridDim.x;
         if (next < total) prefetch_symbol<LOG2N>(sh, D, item_base(next));
+        UH_STAMP(10);
+        stamps.store((size_t)w, lane);
+    }
+}
+
+// The same work items as mix_fft_kernel<10>, two wavefronts per frame (symbol_to_freq2).
+// UH_MIX2_WAVES = wavefronts per SIMD the register allocator is told to reach (tools/build_variants.sh builds the others).
+#ifndef UH_MIX2_WAVES
+#define UH_MIX2_WAVES 5
+#endif
+template <int LOG2N>
+__global__ __launch_bounds__(2 * kWave) __attribute__((amdgpu_waves_per_eu(UH_MIX2_WAVES, 8))) void mix_fft2_kernel(
+    const DemodConst* __restrict__ Dp, const c32* __restrict__ nco, const c32* __restrict__ twiddle,
+    const float* __restrict__ audio, size_t frame_stride, const unsigned* __restrict__ frame_offset, int n_frames,
+    int sym, float* __restrict__ state, c32* __restrict__ fq, const unsigned* __restrict__ seg_tab, int n_sym_batch) {
+    __shared__ Fft2Shared<LOG2N> sh;
+    const DemodConst& D = *Dp;
+    const int h = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6), lane = threadIdx.x & 63;
+    {
+        constexpr int P = Fft2Shared<LOG2N>::P, A = Fft2Shared<LOG2N>::A;
+        for (int idx = threadIdx.x; idx < Fft2Shared<LOG2N>::kTwB; idx += 2 * kWave) {
+            const int sA = 31 - __clz(idx / P + 1);
+            const int k = idx - P * ((1 << sA) - 1);
+            sh.twB[idx] = twiddle[k << (LOG2N - 1 - (A + sA))];
+        }
+    }
+    __syncthreads();
+    auto item_base = [&](int w) {
+        const int f = (n_sym_batch > 1) ? w % n_frames : w, ds = (n_sym_batch > 1) ? w / n_frames : 0;
+        return audio + (size_t)f * frame_stride + (frame_offset ? frame_offset[f] : 0u) + (size_t)(sym + ds) * D.sym_len;
+    };
+    const int total = n_frames * n_sym_batch;
+    if ((int)blockIdx.x < total) prefetch_symbol2<LOG2N>(sh, D, h, lane, item_base((int)blockIdx.x));
+    int par = 0;
+    for (int w = blockIdx.x; w < total; w += gridDim.x, par ^= 1) {
+        const int frame = (n_sym_batch > 1) ? w % n_frames : w, ds = (n_sym_batch > 1) ? w / n_frames : 0;
+        float* st = state + (size_t)frame * kStFloats;
+        const float cfo = st[st_cfo];
+        float phase = st[st_cfo_phase];
+        Stamps stamps;
+        symbol_to_freq2<LOG2N>(sh, D, h, lane, cfo, phase, nco + (size_t)(sym + ds) * D.sym_len, twiddle, fq + (size_t)w * 128,
+                               seg_tab ? seg_tab + (size_t)frame * kSegTabWords : nullptr, par, stamps);
+        if (threadIdx.x == 0 && n_sym_batch == 1) st[st_cfo_phase] = phase;
+        const int next = w + (int)gridDim.x;
+        if (next < total) prefetch_symbol2<LOG2N>(sh, D, h, lane, item_base(next));
+        UH_STAMP(10);
+        stamps.store((size_t)w * 2 + h, lane);
     }
 }
 

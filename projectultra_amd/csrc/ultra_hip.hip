@@ -77,6 +77,7 @@ struct ultra_hip_ctx {
     // per-kernel profiling (ultra_hip_profile_*): recorded (class, start, stop) triples + spare events
     uint32_t deint_step = 1;             // ChannelInterleaver step fused into the LDPC LLR load (1 = off)
     uint16_t* d_deint_table = nullptr;   // general gather table of the fused deinterleave (nullptr = use the step)
+    bool mix_one_wave = false;           // ULTRA_HIP_MIXFFT_ONE_WAVE=1: the one-wavefront-per-frame mix_fft_kernel<10> (A/B runs)
     bool profiling = false;
     struct Span { int kind; hipEvent_t e0, e1; };
     std::vector<Span> spans;
@@ -200,7 +201,10 @@ int launch_demod(ultra_hip_ctx* ctx, const float* d_audio, size_t frame_stride, 
     if (all_symbols_at_once) {
         LaunchSpan span(ctx, ULTRA_HIP_K_MIX_FFT);
         const unsigned g = (unsigned)std::min(n_frames * (size_t)n_sym, (size_t)ctx->cu_count * 128);
-        if (D.log2_fft == 10)
+        if (D.log2_fft == 10 && !ctx->mix_one_wave)
+            hipLaunchKernelGGL(dev::mix_fft2_kernel<10>, dim3(g), dim3(2 * dev::kWave), 0, st, ctx->d_demod, ctx->d_nco, ctx->d_twiddle,
+                               d_audio, frame_stride, d_frame_offset, (int)n_frames, 0, ctx->d_ws_state, ctx->d_ws_fq, seg_tab, n_sym);
+        else if (D.log2_fft == 10)
             hipLaunchKernelGGL(dev::mix_fft_kernel<10>, dim3(g), dim3(dev::kWave), 0, st, ctx->d_demod, ctx->d_nco, ctx->d_twiddle,
                                d_audio, frame_stride, d_frame_offset, (int)n_frames, 0, ctx->d_ws_state, ctx->d_ws_fq, seg_tab, n_sym);
         else
@@ -219,7 +223,11 @@ int launch_demod(ultra_hip_ctx* ctx, const float* d_audio, size_t frame_stride, 
         }
         if (!all_symbols_at_once) {
             LaunchSpan span(ctx, ULTRA_HIP_K_MIX_FFT);
-            if (D.log2_fft == 10)
+            if (D.log2_fft == 10 && !ctx->mix_one_wave)
+                hipLaunchKernelGGL(dev::mix_fft2_kernel<10>, dim3(grid_fft), dim3(2 * dev::kWave), 0, st, ctx->d_demod,
+                                   ctx->d_nco, ctx->d_twiddle, d_audio, frame_stride, d_frame_offset, (int)n_frames, s,
+                                   ctx->d_ws_state, fq_s, seg_tab_s, 1);
+            else if (D.log2_fft == 10)
                 hipLaunchKernelGGL(dev::mix_fft_kernel<10>, dim3(grid_fft), dim3(dev::kWave), 0, st, ctx->d_demod,
                                    ctx->d_nco, ctx->d_twiddle, d_audio, frame_stride, d_frame_offset, (int)n_frames, s,
                                    ctx->d_ws_state, fq_s, seg_tab_s, 1);
@@ -447,6 +455,16 @@ extern "C" {
 
 int ultra_hip_abi_version(void) { return ULTRA_HIP_ABI_VERSION; }
 
+#ifdef UH_MIXFFT_STAMPS
+// diagnostic build only (tools/mix_fft_stalls.py): where mix_fft_kernel / mix_fft2_kernel leave their phase stamps
+int ultra_hip_debug_set_stamps(ultra_hip_ctx* ctx, void* d_buf) {
+    if (!ctx) return ULTRA_HIP_ERR_INVALID_ARG;
+    DeviceGuard guard(ctx->device);
+    unsigned long long* p = static_cast<unsigned long long*>(d_buf);
+    return hipMemcpyToSymbol(HIP_SYMBOL(ultra_hip::dev::g_mix_stamps), &p, sizeof(p)) == hipSuccess ? ULTRA_HIP_OK : ULTRA_HIP_ERR_HIP;
+}
+#endif
+
 const char* ultra_hip_strerror(int status) {
     switch (status) {
         case ULTRA_HIP_OK: return "ok";
@@ -501,6 +519,7 @@ int ultra_hip_create(const ultra_hip_config* cfg, int device, void* stream, ultr
     rc = build_ldpc_plan(ctx->h_ldpc, ctx->h_plan);
     if (rc != ULTRA_HIP_OK) { delete ctx; return rc; }
     // ULTRA_HIP_LDPC_MESSAGES=1 keeps the message-passing kernel for every rate (A/B measurements, parity tests of both)
+    { const char* e = std::getenv("ULTRA_HIP_MIXFFT_ONE_WAVE"); ctx->mix_one_wave = (e && e[0] == '1'); }
     const char* force_messages = std::getenv("ULTRA_HIP_LDPC_MESSAGES");
     if (!(force_messages && force_messages[0] == '1')) (void)build_ldpc_tplan(ctx->h_ldpc, cfg->code_rate, ctx->h_tplan);
     ctx->h_tplan.max_iterations = ctx->h_ldpc.max_iterations;

@@ -133,7 +133,9 @@ class ReceiveContext:
     def _check_stream(self):
         """The context launches on the stream that was current when it was created; torch allocates and frees the
         tensors handed to it on whatever stream is current NOW.  A different current stream would let the caching
-        allocator reuse a temporary before the queued kernels have read it, so it is refused."""
+        allocator reuse a temporary before the queued kernels have read it, so it is refused — by EVERY method that hands
+        tensor pointers to the library (generators and counters included: make_batch(cfo_hz=...) allocates and frees a
+        temporary itself)."""
         torch = _torch()
         with torch.cuda.device(self.device):
             cur = torch.cuda.current_stream().cuda_stream
@@ -192,22 +194,28 @@ class ReceiveContext:
         return (llr, state) if want_state else llr
 
     def demod_decode(self, audio, cfo_hz=None, cfo_phase=None, want_llr: bool = False, out=None):
-        """Fused receive path -> dict(bytes, iters, ok[, llr])."""
+        """Fused receive path -> dict(bytes, iters, ok[, llr]).  `out` may hand in the result tensors (and, under "llr",
+        the [n][llrs_per_frame] destination of the soft bits)."""
         torch = _torch()
         self._check_stream()
         audio = self._frames(audio)
         n = audio.shape[0]
         cfo, cph = self._opt(cfo_hz, n), self._opt(cfo_phase, n)
         g = self.geometry
+        llr = None
+        if out is not None and out.get("llr") is not None:      # the caller's LLR buffer: soft bits are delivered, not workspace
+            llr = out["llr"]
+            self._check_out(llr, (n, g.llrs_per_frame), torch.float32, "llr")
+        elif want_llr:
+            llr = torch.empty((n, g.llrs_per_frame), dtype=torch.float32, device=self.device)
         out = self._result_buffers(n, out)
-        llr = torch.empty((n, g.llrs_per_frame), dtype=torch.float32, device=self.device) if want_llr else None
         check(self.lib.ultra_hip_demod_decode_batch(self._ctx, audio.data_ptr(), self._row_stride(audio),
                                                     cfo.data_ptr() if cfo is not None else None,
                                                     cph.data_ptr() if cph is not None else None, n,
-                                                    llr.data_ptr() if want_llr else None, out["bytes"].data_ptr(),
+                                                    llr.data_ptr() if llr is not None else None, out["bytes"].data_ptr(),
                                                     out["iters"].data_ptr(), out["ok"].data_ptr()),
               "ultra_hip_demod_decode_batch")
-        if want_llr:
+        if llr is not None:
             out["llr"] = llr
         return out
 
@@ -216,6 +224,7 @@ class ReceiveContext:
         SEARCHING state, each stream fed `chunk` samples per call: demodulator.cpp:461-600).
         Returns device tensors dict(found, data_start, cfo_hz, sync_offset, fed_at_sync)."""
         torch = _torch()
+        self._check_stream()
         audio = self._dev(audio, torch.float32, "audio")
         if audio.dim() != 2:
             raise ValueError("audio must be [n_streams][n_samples]")
@@ -236,6 +245,7 @@ class ReceiveContext:
         src/sync/chirp_sync.hpp:349-505).  Returns device tensors dict(detected, start_sample, cfo_hz,
         correlation, up_chirp_start, down_chirp_start)."""
         torch = _torch()
+        self._check_stream()
         audio = self._dev(audio, torch.float32, "audio")
         if audio.dim() != 2:
             raise ValueError("audio must be [n_streams][n_samples]")
@@ -256,6 +266,7 @@ class ReceiveContext:
         start and coarse CFO -> LDPC decode (ultra_hip_receive_batch).  Returns device tensors
         dict(bytes, iters, ok, entry, cfo_hz[, llr]); entry == -1 (0xffffffff) marks streams without a frame."""
         torch = _torch()
+        self._check_stream()
         audio = self._dev(audio, torch.float32, "audio")
         if audio.dim() != 2:
             raise ValueError("audio must be [n_streams][n_samples]")
@@ -280,6 +291,7 @@ class ReceiveContext:
         stream's training start with the chirp CFO and its accumulated phase -> LDPC decode
         (ultra_hip_chirp_receive_batch).  Same result dict as receive()."""
         torch = _torch()
+        self._check_stream()
         audio = self._dev(audio, torch.float32, "audio")
         if audio.dim() != 2:
             raise ValueError("audio must be [n_streams][n_samples]")
@@ -307,6 +319,7 @@ class ReceiveContext:
         success, is_ping, frame_type, codewords_ok, codewords_failed, expected_codewords, frame_len, status;
         frame_data [n][stride] uint8)."""
         torch = _torch()
+        self._check_stream()
         soft = self._dev(soft, torch.float32, "soft")
         if soft.dim() != 2:
             raise ValueError("soft must be [n_frames][n_soft]")
@@ -326,6 +339,7 @@ class ReceiveContext:
         payload [n][k // 8]) device tensors; `out` may hand in that pair (e.g. row slices of a larger batch) to be
         overwritten.  Bit-identical to the oracle's uo_make_batch for channel "none"."""
         torch = _torch()
+        self._check_stream()
         g = self.geometry
         if out is None:
             audio = torch.empty((n_frames, g.frame_samples), dtype=torch.float32, device=self.device)
@@ -355,6 +369,7 @@ class ReceiveContext:
         """The channel's carrier frequency offset (WattersonChannel::applyCFO, hf_channel.hpp:161-232; every row by a fresh
         channel) applied to a batch of audio rows -> new tensor.  Bit-identical to the reference."""
         torch = _torch()
+        self._check_stream()
         audio = self._dev(audio, torch.float32, "audio")
         if audio.dim() != 2:
             raise _lib.UltraHipError(-1, "channel_cfo: audio must be [n_frames][n_samples]")
@@ -369,6 +384,7 @@ class ReceiveContext:
         """Raw-audio streams for receive(): [lead silence][preamble][data symbols][tail silence], 0.5 peak, AWGN on every
         sample (ultra_hip_make_raw_batch).  Returns (audio [n][lead + preamble + frame_samples + tail], payload)."""
         torch = _torch()
+        self._check_stream()
         g = self.geometry
         n_out = lead + 7 * (self.config.fft_size + g.cp_len) + g.frame_samples + tail
         audio = torch.empty((n_streams, n_out), dtype=torch.float32, device=self.device)
@@ -384,6 +400,7 @@ class ReceiveContext:
         (ultra_hip_make_llr_batch; SURVEY.md 8d cfg4).  Returns (llr [n][648] f32, payload [n][k // 8] u8); `out` may
         hand in that pair to be overwritten.  Bit-identical to the oracle's uo_make_llr_batch."""
         torch = _torch()
+        self._check_stream()
         g = self.geometry
         if out is None:
             llr = torch.empty((n_cw, LDPC_BLOCK_SIZE), dtype=torch.float32, device=self.device)
@@ -438,6 +455,7 @@ class ReceiveContext:
     def count_errors(self, result, payload, counters=None):
         """Accumulate the Monte-Carlo counters (device int64[8]) for a decoded batch."""
         torch = _torch()
+        self._check_stream()
         payload = self._dev(payload, torch.uint8, "payload")
         n, pb = payload.shape
         if counters is None:
@@ -451,6 +469,7 @@ class ReceiveContext:
         """The counters of a batch that holds n_points sweep points of equal size back to back: rows
         [p * n, (p + 1) * n) accumulate into counters[p] (device int64 [n_points][8]); one launch."""
         torch = _torch()
+        self._check_stream()
         payload = self._dev(payload, torch.uint8, "payload")
         rows, pb = payload.shape
         self._check_out(counters, (counters.shape[0], 8), torch.int64, "counters")
@@ -464,6 +483,7 @@ class ReceiveContext:
 
     def selftest_math(self, fn: int, a, b=None):
         torch = _torch()
+        self._check_stream()
         a = self._dev(a, torch.float32, "a")
         b = self._dev(b, torch.float32, "b") if b is not None else None
         out = torch.empty_like(a)

@@ -1,7 +1,9 @@
 """HBM bytes per launch of every kernel of the path from rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE CSVs (separate
 passes, counter unit KiB; gfx950: FETCH_SIZE counts 128-B requests at 64 B -> x2, see
 /opt/skills/guides/MI355X_MICROARCH.md, HBM section).  usage: traffic_from_pmc.py <outdir> <config> <units per launch> <commit>"""
-import csv, glob, json, sys, collections, time
+import csv, glob, json, sys, collections, time, pathlib
+sys.path.insert(0, str(pathlib.Path(__file__).resolve().parent.parent))
+from projectultra_amd._lib import source_hash
 out = sys.argv[1]
 config = sys.argv[2] if len(sys.argv) > 2 else "cfg3"
 units = int(sys.argv[3]) if len(sys.argv) > 3 else 262144
@@ -21,7 +23,7 @@ for c in ("FETCH_SIZE", "WRITE_SIZE"):
                 if key in name:
                     acc[ALIASES.get(key, key)][c].append(float(r["Counter_Value"]) * 1024.0)
                     break
-res = {"config": config, "n_frames": units, "commit": commit, "collected": time.strftime("%Y-%m-%dT%H:%M:%SZ", time.gmtime()),
+res = {"config": config, "n_frames": units, "commit": commit, "csrc_sha": source_hash(), "collected": time.strftime("%Y-%m-%dT%H:%M:%SZ", time.gmtime()),
        "method": "rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate passes (bench.py --steps 1 --warmup 0 --no-build), "
                  "counter unit KiB; gfx950 correction of MI355X_MICROARCH.md (HBM section): FETCH_SIZE counts 128-B requests "
                  "at 64 B, so read bytes = 2 x FETCH_SIZE for coalesced streams; WRITE_SIZE taken as is; mean over launches",
