@@ -497,6 +497,7 @@ struct Fft2Shared {
     static constexpr int P = M / kWave;                     // 8 points per lane
     static constexpr int A = 3;                             // log2(P); 3 groups of 3 stages + the joint last stage
     c32 X[2][M + M / P];                                    // per-wavefront exchange buffer, 1 pad per P entries
+    float stage[2][M];                                      // landing zone of the NEXT item's samples (asynchronous copy)
     static constexpr int kTwB = P * ((1 << A) - 1);
     c32 twB[kTwB];                                          // twiddles of stages A..2A-1 (as in FftShared)
     um::PhaseSeg seg[2][kPhaseCap];
@@ -504,73 +505,105 @@ struct Fft2Shared {
     c32 xch[2][2][kWave];                                   // [frame parity][writer][lane]: E_hi from wavefront 0, O_lo from 1
 };
 
+// What an item needs from memory besides its samples: the tracker's CFO and phase and this lane's entry of the frame's
+// phase table.  Requested one item AHEAD (together with the samples), so that no memory round trip is left on the
+// path of an item: the stamps of the first version (profiles/r03_mix_fft_stalls_two_wave_v1.txt) showed 60 % of a
+// wavefront's time in four of them — staged audio, table, oscillator values, last twiddles.
+struct MixItem {
+    // Held as PER-LANE words until the item starts: a uniform value the compiler moves to a scalar register with
+    // v_readfirstlane at once, i.e. it waits for the load — behind the asynchronous copy of the samples that was issued
+    // just before it (loads return in order) — right where the request was meant to be fire-and-forget.
+    float stv;                  // lane 0: CFO, lane 1: start phase
+    unsigned hw;                // lanes 0..3: table header (segments, samples covered, phase after them, start phase)
+    int tab_start;              // lane k: segment k
+    float tab_base, tab_step;
+};
+__device__ __forceinline__ void request_item(MixItem& it, const float* __restrict__ st, const unsigned* __restrict__ tab, int lane) {
+    it.hw = 0u; it.tab_start = 0x7fffffff; it.tab_base = 0.0f; it.tab_step = 0.0f;
+    if (tab) {
+        const float* src = (lane == 1) ? reinterpret_cast<const float*>(tab + 3) : st + st_cfo;   // ONE load, per-lane address
+        it.stv = *src;                                                            // (lanes >= 2: unused)
+        it.hw = tab[lane & 3];
+        const unsigned* e = tab + 4 + 3 * ((lane < kPhaseCap) ? lane : 0);      // entries behind the last segment: stale, masked at use
+        it.tab_start = (int)e[0]; it.tab_base = __uint_as_float(e[1]); it.tab_step = __uint_as_float(e[2]);
+    } else {
+        it.stv = 0.0f;          // no table <=> the CFO is zero for every frame of the launch (launch_demod): nothing to read
+    }
+}
 // staging of the samples of parity h of one symbol's FFT window: stage[64 q + l] = window[2 (64 q + l) + h]
 template <int LOG2N>
 __device__ __forceinline__ void prefetch_symbol2(Fft2Shared<LOG2N>& sh, const DemodConst& D, int h, int lane,
                                                  const float* __restrict__ audio_sym) {
     constexpr int P = Fft2Shared<LOG2N>::P;
-    float* stage = reinterpret_cast<float*>(sh.X[h]);
+    float* stage = sh.stage[h];
 #pragma unroll
     for (int q = 0; q < P; ++q)
         __builtin_amdgcn_global_load_lds(audio_sym + D.cp + 2 * (64 * q + lane) + h, stage + 64 * q, 4, 0, 0);
 }
 
+// per-lane values that do not change from item to item: the oscillator at the lane's 8 samples (for one symbol index)
+// and the twiddles of the last four stages
 template <int LOG2N>
+struct Mix2Lane {
+    static constexpr int P = Fft2Shared<LOG2N>::P;
+    c32 os[P];
+    c32 w6, w7[2], w8[2], w_last;
+    c32 wA[P / 2];              // group A (wave-uniform): twiddle[j << (LOG2N - A)], j < P/2
+};
+
+template <int LOG2N, class NextFn>
 __device__ __forceinline__ void symbol_to_freq2(Fft2Shared<LOG2N>& sh, const DemodConst& D, const int h, const int lane,
-                                                float freq_offset_hz, float& cfo_phase, const c32* __restrict__ nco_sym,
-                                                const c32* __restrict__ twiddle, c32* __restrict__ fq_out,
-                                                const unsigned* __restrict__ seg_tab, const int par, Stamps& stamps) {
+                                                MixItem& it, const Mix2Lane<LOG2N>& lc,
+                                                const c32* __restrict__ twiddle, c32& bin_out, const int par,
+                                                NextFn request_next, Stamps& stamps) {
     constexpr int P = Fft2Shared<LOG2N>::P, A = Fft2Shared<LOG2N>::A;
     UH_STAMP(0);
     const int rl = (int)(__brev((unsigned)lane) >> 26);      // bitrev6(lane)
+    const float freq_offset_hz = lane_f(it.stv, 0);
+    float cfo_phase = lane_f(it.stv, 1);
     const bool cfo_on = fabsf(freq_offset_hz) > 0.01f;
+    const int it_ns = __builtin_amdgcn_readlane((int)it.hw, 0), it_covered = __builtin_amdgcn_readlane((int)it.hw, 1);
+    const float it_pnext = __int_as_float(__builtin_amdgcn_readlane((int)it.hw, 2));
     c32* X = sh.X[h];
     um::PhaseSeg* seg = sh.seg[h];
     int* seg_start = sh.seg_start[h];
     c32 v[P];
-    const float* stage = reinterpret_cast<const float*>(X);
-    int tab_ns = 0, tab_covered = 0, tab_start = 0x7fffffff;
-    float tab_pnext = 0.0f, tab_base = 0.0f, tab_step = 0.0f;
-    if (cfo_on && seg_tab) {
-        tab_ns = (int)seg_tab[0]; tab_covered = (int)seg_tab[1]; tab_pnext = __uint_as_float(seg_tab[2]);
-        if (lane < tab_ns) {
-            tab_start = (int)seg_tab[4 + 3 * lane];
-            tab_base = __uint_as_float(seg_tab[5 + 3 * lane]);
-            tab_step = __uint_as_float(seg_tab[6 + 3 * lane]);
-        }
-    }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                            // staged audio has landed
+    const float* stage = sh.stage[h];
+    const int tab_ns = cfo_on ? it_ns : 0;
+    // This item's samples have landed.  Nothing younger is in flight: the bins of the previous item are stored by
+    // request_next() below, IN FRONT of the requests (a store at the end of the item would be the youngest operation here,
+    // and vector-memory operations complete in order).
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     wave_sync();
     float xs[P];
 #pragma unroll
     for (int qp = 0; qp < P; ++qp) xs[qp] = stage[64 * qp + rl];               // window sample 2 (rl + 64 qp) + h
-    wave_sync();                                                                // X may be overwritten from here on
+    wave_sync();
     UH_STAMP(1);
     UH_STAMP(2);
 
     // ---- CFO rotation factors: lane l evaluates the P samples of its parity at local indices m = P l .. P l + P - 1
     //      (window positions 2 m + h: a run of 2 P positions, almost always inside one segment) ----
     c32* rot = X;                                          // rot[m + (m >> A)]
-    c32 os_first[P / 2];
+    float ph[P];
 #pragma unroll
-    for (int q2 = 0; q2 < P / 2; ++q2) os_first[q2] = nco_sym[D.cp + 2 * (rl + 64 * q2) + h];
+    for (int j = 0; j < P; ++j) ph[j] = 0.0f;
+    bool bounded = true;
     if (cfo_on) {
         const float inc = (float)(((-kTwoPi) * (double)freq_offset_hz) / (double)D.sample_rate);
-        const bool bounded = fabsf(cfo_phase) <= 4.0f && fabsf(inc) <= 1.0f;
-        float ph[P];
-#pragma unroll
-        for (int j = 0; j < P; ++j) ph[j] = 0.0f;
+        bounded = fabsf(cfo_phase) <= 4.0f && fabsf(inc) <= 1.0f;
         int done = 0;
         float pcur = cfo_phase;
+        const bool have_tab = it_covered > 0;
         while (done < D.sym_len) {                           // one round unless a table overflows
             int covered;
             float pnext;
             int my_start = 0x7fffffff;
             float my_base = 0.0f, my_step = 0.0f;
             int ns;
-            if (done == 0 && seg_tab) {
-                ns = tab_ns; covered = tab_covered; pnext = tab_pnext;
-                my_start = tab_start; my_base = tab_base; my_step = tab_step;
+            if (done == 0 && have_tab) {
+                ns = tab_ns; covered = it_covered; pnext = it_pnext;
+                if (lane < tab_ns) { my_start = it.tab_start; my_base = it.tab_base; my_step = it.tab_step; }
             } else {
                 ns = um::phase_table_walk(pcur, inc, D.sym_len - done, kPhaseCap, &covered, &pnext,
                                           [&](int k, int start, float base, float step) {
@@ -620,7 +653,13 @@ __device__ __forceinline__ void symbol_to_freq2(Fft2Shared<LOG2N>& sh, const Dem
             pcur = pnext;
         }
         cfo_phase = pcur;
-        UH_STAMP(2);
+    }
+    // The next item's samples, CFO, start phase and table entry — requested HERE, behind the last use of this item's
+    // request registers (`it` is overwritten in place: no copy at the loop end, which would have to wait for the loads)
+    // and three quarters of an item ahead of their use.  Nothing else is loaded in the rest of the item.
+    request_next();
+    UH_STAMP(2);
+    if (cfo_on) {
         if (bounded) {
 #pragma unroll
             for (int j = 0; j < P; ++j) {
@@ -628,8 +667,6 @@ __device__ __forceinline__ void symbol_to_freq2(Fft2Shared<LOG2N>& sh, const Dem
                 um::sincosf_bounded_(ph[j], &sn, &cs);
                 const int m = P * lane + j;
                 rot[m + (m >> A)] = mk(cs, sn);
-                // two evaluations at a time: their f64 chains cover each other, more in flight only costs registers
-                if (j & 1) __builtin_amdgcn_sched_barrier(0);
             }
         } else {
 #pragma unroll 2
@@ -640,18 +677,10 @@ __device__ __forceinline__ void symbol_to_freq2(Fft2Shared<LOG2N>& sh, const Dem
     UH_STAMP(3);
     // ---- mix: samples[i] * conj(osc) (* rotation) ----
 #pragma unroll
-    for (int hh = 0; hh < 2; ++hh) {
-        c32 os[P / 2];
-#pragma unroll
-        for (int q2 = 0; q2 < P / 2; ++q2)
-            os[q2] = (hh == 0) ? os_first[q2] : nco_sym[D.cp + 2 * (rl + 64 * (P / 2 + q2)) + h];
-#pragma unroll
-        for (int q2 = 0; q2 < P / 2; ++q2) {
-            const int qp = hh * (P / 2) + q2;
-            c32 mixed = mk(os[q2].re * xs[qp], (-os[q2].im) * xs[qp]);
-            if (cfo_on) { const int m = rl + 64 * qp; mixed = cmul(mixed, rot[m + (m >> A)]); }
-            v[bitrev_small<A>(qp)] = mixed;
-        }
+    for (int qp = 0; qp < P; ++qp) {
+        c32 mixed = mk(lc.os[qp].re * xs[qp], (-lc.os[qp].im) * xs[qp]);
+        if (cfo_on) { const int m = rl + 64 * qp; mixed = cmul(mixed, rot[m + (m >> A)]); }
+        v[bitrev_small<A>(qp)] = mixed;
     }
     if (cfo_on) wave_sync();
     UH_STAMP(4);
@@ -663,7 +692,7 @@ __device__ __forceinline__ void symbol_to_freq2(Fft2Shared<LOG2N>& sh, const Dem
 #pragma unroll
         for (int q = 0; q < P; ++q) {
             if (q & half) continue;
-            const c32 w = twiddle[(q & (half - 1)) << (LOG2N - 1 - s)];   // wave-uniform
+            const c32 w = lc.wA[(q & (half - 1)) << (A - 1 - s)];         // twiddle[k << (LOG2N-1-s)], wave-uniform
             UH_BUTTERFLY(v[q], v[q + half], w);
         }
     }
@@ -693,25 +722,23 @@ __device__ __forceinline__ void symbol_to_freq2(Fft2Shared<LOG2N>& sh, const Dem
     wave_sync();
     UH_STAMP(6);
     // ---- group C: stages 2A..3A-1 = LOG2N-2, lane holds X[lane + 64*t]; only t = 0 (elements 0..63 of the half) and
-    //      t = P-1 (elements M-64..M-1) feed bins that are used ----
+    //      t = P-1 (elements M-64..M-1) feed bins that are used, so only their ancestors are computed:
+    //      stage 6 pairs (t, t+1) with w6 = twiddle[lane << 3]; stage 7 pairs (t, t+2) with twiddle[(lane + 64 (t&1)) << 2];
+    //      stage 8 pairs (0, 4) and (3, 7) with twiddle[(lane + 64 (t&3)) << 1], t = 0 and 3 ----
     {
 #pragma unroll
         for (int t = 0; t < P; ++t) { const int i = lane + 64 * t; v[t] = X[i + (i >> A)]; }
 #pragma unroll
-        for (int s = 2 * A; s < 3 * A; ++s) {
-            const int ht = 1 << (s - 6);
-#pragma unroll
-            for (int t = 0; t < P; ++t) {
-                if (t & ht) continue;
-                const int k = lane + 64 * (t & (ht - 1));
-                const c32 w = twiddle[k << (LOG2N - 1 - s)];
-                UH_BUTTERFLY(v[t], v[t + ht], w);
-            }
-        }
+        for (int t = 0; t < P; t += 2) UH_BUTTERFLY(v[t], v[t + 1], lc.w6);
+        UH_BUTTERFLY(v[0], v[2], lc.w7[0]);
+        UH_BUTTERFLY(v[4], v[6], lc.w7[0]);
+        UH_BUTTERFLY(v[1], v[3], lc.w7[1]);
+        UH_BUTTERFLY(v[5], v[7], lc.w7[1]);
+        UH_BUTTERFLY(v[0], v[4], lc.w8[0]);
+        UH_BUTTERFLY(v[3], v[7], lc.w8[1]);
     }
     UH_STAMP(7);
     // ---- last stage (LOG2N-1): element k of the even half with element k of the odd half, w = twiddle[k] ----
-    const c32 w_last = twiddle[h ? (Fft2Shared<LOG2N>::M - 64 + lane) : lane];
     sh.xch[par][h][lane] = h ? v[0] : v[P - 1];              // what the partner needs: O_lo from 1, E_hi from 0
     asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
     UH_STAMP(8);
@@ -719,8 +746,8 @@ __device__ __forceinline__ void symbol_to_freq2(Fft2Shared<LOG2N>& sh, const Dem
         const c32 other = sh.xch[par][1 - h][lane];
         c32 a = h ? other : v[0];                             // even half's element
         c32 b = h ? v[P - 1] : other;                         // odd half's element
-        UH_BUTTERFLY(a, b, w_last);
-        fq_out[64 * h + lane] = h ? b : a;                    // bins `lane` (a + t) / N-64+lane (a - t)
+        UH_BUTTERFLY(a, b, lc.w_last);
+        bin_out = h ? b : a;                                  // bin `lane` (a + t) / N-64+lane (a - t): stored with the next request
     }
     wave_sync();
     UH_STAMP(9);
@@ -1239,13 +1266,16 @@ __global__ __launch_bounds__(256) void train_cfo_kernel(const DemodConst* __rest
 // wavefront of a frame would wait for it: 3.8 k cycles median, 19 k at the 90th percentile of a 27 k-cycle
 // frame).  Reads the tracker's CFO and the phase the previous symbol ended on, writes the frame's table.
 __global__ __launch_bounds__(256) void cfo_walk_kernel(const DemodConst* __restrict__ Dp, int n_frames,
-                                                       const float* __restrict__ state, unsigned* __restrict__ seg_tab) {
+                                                       float* __restrict__ state, unsigned* __restrict__ seg_tab) {
     const DemodConst& D = *Dp;
     const int frame = blockIdx.x * blockDim.x + threadIdx.x;
     if (frame >= n_frames) return;
-    const float* st = state + (size_t)frame * kStFloats;
+    float* st = state + (size_t)frame * kStFloats;
     unsigned* tab = seg_tab + (size_t)frame * kSegTabWords;
     const float cfo = st[st_cfo], phase = st[st_cfo_phase];
+    // word 3: the phase the symbol STARTS with (what mix_fft reads); the record is advanced to the phase the symbol ENDS
+    // with right here — the walk knows it, and the transform kernels then have no store but their bins
+    tab[3] = __float_as_uint(phase);
     if (!(fabsf(cfo) > 0.01f)) { tab[0] = 0u; tab[1] = 0u; tab[2] = __float_as_uint(phase); return; }
     const float inc = (float)(((-kTwoPi) * (double)cfo) / (double)D.sample_rate);
     int covered;
@@ -1257,6 +1287,16 @@ __global__ __launch_bounds__(256) void cfo_walk_kernel(const DemodConst* __restr
                                             tab[6 + 3 * k] = __float_as_uint(step);
                                         });
     tab[0] = (unsigned)ns; tab[1] = (unsigned)covered; tab[2] = __float_as_uint(pnext);
+    // a table overflow (more than kPhaseCap segments in one symbol) leaves the rest to mix_fft; the end phase is
+    // walked on here with the same function
+    for (int done = covered; done < D.sym_len;) {
+        int c2;
+        float p2;
+        um::phase_table_walk(pnext, inc, D.sym_len - done, kPhaseCap, &c2, &p2, [](int, int, float, float) {});
+        done += c2;
+        pnext = p2;
+    }
+    st[st_cfo_phase] = pnext;
 }
 
 // Launch bound 2, occupancy 3: with the bound at 3 the register allocator stops at 168 VGPRs and spills two of
@@ -1294,11 +1334,12 @@ __global__ __launch_bounds__(kWave, 2) void mix_fft_kernel(
         const int frame = (n_sym_batch > 1) ? w % n_frames : w, ds = (n_sym_batch > 1) ? w / n_frames : 0;
         float* st = state + (size_t)frame * kStFloats;
         const float cfo = st[st_cfo];
-        float phase = st[st_cfo_phase];
+        // the phase the symbol starts with: word 3 of the frame's table (cfo_walk_kernel has already advanced the record
+        // to the symbol's END phase); without a table the CFO is zero and the phase does not move (launch_demod)
+        float phase = seg_tab ? __uint_as_float(seg_tab[(size_t)frame * kSegTabWords + 3]) : st[st_cfo_phase];
         Stamps stamps;
         symbol_to_freq<LOG2N>(sh, D, cfo, phase, nco + (size_t)(sym + ds) * D.sym_len, twiddle, fq + (size_t)w * 128,
                               seg_tab ? seg_tab + (size_t)frame * kSegTabWords : nullptr, stamps);
-        if (lane == 0 && n_sym_batch == 1) st[st_cfo_phase] = phase;
         const int next = w + (int)gridDim.x;
         if (next < total) prefetch_symbol<LOG2N>(sh, D, item_base(next));
         UH_STAMP(10);
@@ -1306,10 +1347,11 @@ __global__ __launch_bounds__(kWave, 2) void mix_fft_kernel(
     }
 }
 
-// The same work items as mix_fft_kernel<10>, two wavefronts per frame (symbol_to_freq2).
+// The same work items as mix_fft_kernel<10>, two wavefronts per frame (symbol_to_freq2), software-pipelined: everything
+// item i+1 needs from memory is requested while item i computes.
 // UH_MIX2_WAVES = wavefronts per SIMD the register allocator is told to reach (tools/build_variants.sh builds the others).
 #ifndef UH_MIX2_WAVES
-#define UH_MIX2_WAVES 5
+#define UH_MIX2_WAVES 3
 #endif
 template <int LOG2N>
 __global__ __launch_bounds__(2 * kWave) __attribute__((amdgpu_waves_per_eu(UH_MIX2_WAVES, 8))) void mix_fft2_kernel(
@@ -1318,37 +1360,69 @@ __global__ __launch_bounds__(2 * kWave) __attribute__((amdgpu_waves_per_eu(UH_MI
     int sym, float* __restrict__ state, c32* __restrict__ fq, const unsigned* __restrict__ seg_tab, int n_sym_batch) {
     __shared__ Fft2Shared<LOG2N> sh;
     const DemodConst& D = *Dp;
+    constexpr int P = Fft2Shared<LOG2N>::P, A = Fft2Shared<LOG2N>::A, M = Fft2Shared<LOG2N>::M;
     const int h = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6), lane = threadIdx.x & 63;
-    {
-        constexpr int P = Fft2Shared<LOG2N>::P, A = Fft2Shared<LOG2N>::A;
-        for (int idx = threadIdx.x; idx < Fft2Shared<LOG2N>::kTwB; idx += 2 * kWave) {
-            const int sA = 31 - __clz(idx / P + 1);
-            const int k = idx - P * ((1 << sA) - 1);
-            sh.twB[idx] = twiddle[k << (LOG2N - 1 - (A + sA))];
-        }
+    const int rl = (int)(__brev((unsigned)lane) >> 26);
+    for (int idx = threadIdx.x; idx < Fft2Shared<LOG2N>::kTwB; idx += 2 * kWave) {
+        const int sA = 31 - __clz(idx / P + 1);
+        const int k = idx - P * ((1 << sA) - 1);
+        sh.twB[idx] = twiddle[k << (LOG2N - 1 - (A + sA))];
     }
     __syncthreads();
-    auto item_base = [&](int w) {
-        const int f = (n_sym_batch > 1) ? w % n_frames : w, ds = (n_sym_batch > 1) ? w / n_frames : 0;
-        return audio + (size_t)f * frame_stride + (frame_offset ? frame_offset[f] : 0u) + (size_t)(sym + ds) * D.sym_len;
-    };
     const int total = n_frames * n_sym_batch;
-    if ((int)blockIdx.x < total) prefetch_symbol2<LOG2N>(sh, D, h, lane, item_base((int)blockIdx.x));
-    int par = 0;
-    for (int w = blockIdx.x; w < total; w += gridDim.x, par ^= 1) {
-        const int frame = (n_sym_batch > 1) ? w % n_frames : w, ds = (n_sym_batch > 1) ? w / n_frames : 0;
-        float* st = state + (size_t)frame * kStFloats;
-        const float cfo = st[st_cfo];
-        float phase = st[st_cfo_phase];
-        Stamps stamps;
-        symbol_to_freq2<LOG2N>(sh, D, h, lane, cfo, phase, nco + (size_t)(sym + ds) * D.sym_len, twiddle, fq + (size_t)w * 128,
-                               seg_tab ? seg_tab + (size_t)frame * kSegTabWords : nullptr, par, stamps);
-        if (threadIdx.x == 0 && n_sym_batch == 1) st[st_cfo_phase] = phase;
+    auto frame_of = [&](int w) { return (n_sym_batch > 1) ? w % n_frames : w; };
+    auto ds_of = [&](int w) { return (n_sym_batch > 1) ? w / n_frames : 0; };
+    auto item_base = [&](int w) {
+        const int f = frame_of(w);
+        return audio + (size_t)f * frame_stride + (frame_offset ? frame_offset[f] : 0u) + (size_t)(sym + ds_of(w)) * D.sym_len;
+    };
+    auto request = [&](MixItem& it, int w) {
+        const int f = frame_of(w);
+        prefetch_symbol2<LOG2N>(sh, D, h, lane, item_base(w));
+        request_item(it, state + (size_t)f * kStFloats, seg_tab ? seg_tab + (size_t)f * kSegTabWords : nullptr, lane);
+    };
+    Mix2Lane<LOG2N> lc;
+    lc.w6 = twiddle[lane << 3];
+    lc.w7[0] = twiddle[lane << 2]; lc.w7[1] = twiddle[(lane + 64) << 2];
+    lc.w8[0] = twiddle[lane << 1]; lc.w8[1] = twiddle[(lane + 192) << 1];
+    lc.w_last = twiddle[h ? (M - 64 + lane) : lane];
+#pragma unroll
+    for (int j = 0; j < P / 2; ++j) lc.wA[j] = twiddle[j << (LOG2N - A)];
+    asm volatile("" ::"v"(lc.w6.re), "v"(lc.w6.im), "v"(lc.w7[0].re), "v"(lc.w7[0].im), "v"(lc.w7[1].re), "v"(lc.w7[1].im),
+                 "v"(lc.w8[0].re), "v"(lc.w8[0].im), "v"(lc.w8[1].re), "v"(lc.w8[1].im), "v"(lc.w_last.re), "v"(lc.w_last.im));
+    int os_ds = -1;
+    MixItem cur;
+    c32 pending = mk(0.0f, 0.0f);                          // the previous item's bin of this lane, stored with the next request
+    int w_stored = -1;
+    int w = blockIdx.x;
+    if (w < total) request(cur, w);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // the first item has no bin store in front of it (symbol_to_freq2)
+    for (int par = 0; w < total; w += gridDim.x, par ^= 1) {
+        const int ds = ds_of(w);
+        if (ds != os_ds) {                                   // the oscillator at this lane's samples: once per symbol index
+            const c32* nco_sym = nco + (size_t)(sym + ds) * D.sym_len;
+#pragma unroll
+            for (int qp = 0; qp < P; ++qp) lc.os[qp] = nco_sym[D.cp + 2 * (rl + 64 * qp) + h];
+            os_ds = ds;
+            // the compiler's wait for these loads belongs HERE and not at their first use in the item, where it would
+            // also wait for the requests of the next item issued in between
+#pragma unroll
+            for (int qp = 0; qp < P; ++qp) asm volatile("" ::"v"(lc.os[qp].re), "v"(lc.os[qp].im));
+        }
         const int next = w + (int)gridDim.x;
-        if (next < total) prefetch_symbol2<LOG2N>(sh, D, h, lane, item_base(next));
+        Stamps stamps;
+        c32 bin;
+        symbol_to_freq2<LOG2N>(sh, D, h, lane, cur, lc, twiddle, bin, par,
+                               [&]() {
+                                   if (w_stored >= 0) fq[(size_t)w_stored * 128 + 64 * h + lane] = pending;
+                                   if (next < total) request(cur, next);
+                               }, stamps);
+        pending = bin;
+        w_stored = w;
         UH_STAMP(10);
         stamps.store((size_t)w * 2 + h, lane);
     }
+    if (w_stored >= 0) fq[(size_t)w_stored * 128 + 64 * h + lane] = pending;
 }
 
 // mode 0: data symbol (updateChannelEstimate + equalize + demodulateSymbol)
