@@ -227,11 +227,11 @@ template <int A> __device__ __forceinline__ constexpr int bitrev_small(int q) {
 // Diagnostic build only (-DUH_MIXFFT_STAMPS, tools/mix_fft_stalls.py): shader-clock stamps at the phase boundaries of
 // every work item of mix_fft_kernel / mix_fft2_kernel, one record of kStampWords 64-bit words per wavefront and item:
 // [0..kStampPhases] clock, then HW_ID (wave slot / SIMD / CU / SE) and XCC_ID.  The product build contains none of it.
-constexpr int kStampPhases = 10, kStampWords = 12;
+constexpr int kStampPhases = 10, kStampExtra = 4, kStampWords = 16;   // extra: sub-stamps inside the lookup phase (mix_fft2)
 #ifdef UH_MIXFFT_STAMPS
 __device__ unsigned long long* g_mix_stamps = nullptr;
 struct Stamps {
-    unsigned long long t[kStampPhases + 1];
+    unsigned long long t[kStampPhases + 1 + kStampExtra] = {};
     // s_memtime, followed by a marker comment in the ISA so that the tool can cut the static code into the same phases
     template <int K> __device__ __forceinline__ void at() { t[K] = __builtin_readcyclecounter(); asm volatile("; UHSTAMP %0" ::"n"(K)); }
     __device__ __forceinline__ void store(size_t record, int lane) {
@@ -242,6 +242,7 @@ struct Stamps {
         unsigned long long* r = g_mix_stamps + record * kStampWords;
         for (int k = 0; k <= kStampPhases; ++k) r[k] = t[k];
         r[kStampPhases + 1] = ((unsigned long long)xcc << 32) | hw;
+        for (int k = 0; k < kStampExtra; ++k) r[kStampPhases + 2 + k] = t[kStampPhases + 1 + k];
     }
 };
 #define UH_STAMP(k) stamps.template at<k>()
@@ -500,8 +501,10 @@ struct Fft2Shared {
     float stage[2][M];                                      // landing zone of the NEXT item's samples (asynchronous copy)
     static constexpr int kTwB = P * ((1 << A) - 1);
     c32 twB[kTwB];                                          // twiddles of stages A..2A-1 (as in FftShared)
-    um::PhaseSeg seg[2][kPhaseCap];
+    um::PhaseSeg seg[2][kPhaseCap + 2];                     // two entries behind the last segment: start = INT_MAX
     int seg_start[2][kPhaseCap + 4] __attribute__((aligned(16)));
+    unsigned segmask[2][2];                                 // lanes that a segment starts in (symbol_to_freq2)
+    int segslot[2][kWave];                                  // ... and the last segment that starts there
     c32 xch[2][2][kWave];                                   // [frame parity][writer][lane]: E_hi from wavefront 0, O_lo from 1
 };
 
@@ -613,38 +616,82 @@ __device__ __forceinline__ void symbol_to_freq2(Fft2Shared<LOG2N>& sh, const Dem
                                               my_step = mine ? step : my_step;
                                           });
             }
-            if (lane < kPhaseCap) { seg[lane].start = my_start; seg[lane].base = my_base; seg[lane].step = my_step; }
+            if (lane < kPhaseCap + 2) { seg[lane].start = my_start; seg[lane].base = my_base; seg[lane].step = my_step; }
             if (lane < kPhaseCap + 4) seg_start[lane] = my_start;            // INT_MAX beyond the last segment
+            sh.segslot[h][lane] = 0;
+            if (lane < 2) sh.segmask[h][lane] = 0u;
             wave_sync();
+            UH_STAMP(11);
             const int i0 = D.cp + 2 * P * lane + h - done;  // position of the lane's first sample inside this round
             const int ilast = i0 + 2 * (P - 1);
-            if (ilast >= 0 && i0 < covered) {
-                // first of the lane's positions that lies inside the round (i0 < 0 only behind a table overflow)
+            if (done == 0) {
+                // The table round (positions i0 >= 0): the segment of the lane's first position WITHOUT a search.  Starts
+                // ascend with the segment index k and first positions with the lane, so segment k claims the lanes from
+                // r_k = ceil((start_k - first position of lane 0) / 2P) on, and lane l is in the LAST segment that claimed
+                // a lane <= l: the claims go into a 64-bit mask (ds_or) and slot[r_k] = max k (ds_max: several segments
+                // may start inside one run around a zero crossing); lane l finds the highest mask bit at or below l and
+                // reads that slot.  Its own, the next and the next-but-one segment come straight out of the owners'
+                // registers (ds_bpermute).  A run with at most one boundary is then two evaluations and a select per
+                // sample; lanes whose run holds more boundaries (or leaves the round) walk on through the LDS table.
+                const int first0 = D.cp + h;
+                const bool in_tab = lane < ns;
+                const int rk = (my_start - first0 + 2 * P - 1) >> (A + 1);
+                const bool claims = in_tab && my_start > first0 && rk <= 63;
+                if (claims) {
+                    atomicOr(&sh.segmask[h][rk >> 5], 1u << (rk & 31));
+                    atomicMax(&sh.segslot[h][rk], lane);
+                }
+                const int base = __popcll(__ballot(in_tab && my_start <= first0));     // segment 0 starts at 0: base >= 1
+                wave_sync();
+                const unsigned long long mask = (unsigned long long)sh.segmask[h][0] | ((unsigned long long)sh.segmask[h][1] << 32);
+                const unsigned long long below = mask & ((2ull << lane) - 1ull);
+                int sg = base - 1;
+                if (below) sg = sh.segslot[h][63 - __clzll(below)];
+                UH_STAMP(12);
+                auto from_lane = [&](int v, int src) { return __builtin_amdgcn_ds_bpermute(src << 2, v); };
+                um::PhaseSeg cur, nxt;
+                cur.start = from_lane(my_start, sg); cur.base = __int_as_float(from_lane(__float_as_int(my_base), sg));
+                cur.step = __int_as_float(from_lane(__float_as_int(my_step), sg));
+                nxt.start = from_lane(my_start, sg + 1); nxt.base = __int_as_float(from_lane(__float_as_int(my_base), sg + 1));
+                nxt.step = __int_as_float(from_lane(__float_as_int(my_step), sg + 1));
+                const int n2 = from_lane(my_start, sg + 2);                 // lanes >= ns hold INT_MAX (sg + 2 <= kPhaseCap + 1 < 64)
+#pragma unroll
+                for (int j = 0; j < P; ++j) {
+                    const int i = i0 + 2 * j;
+                    const float a = um::phase_table_eval(cur, i), b = um::phase_table_eval(nxt, i);
+                    ph[j] = (i < nxt.start) ? a : b;
+                }
+                const bool more = !(ilast < n2 && ilast < covered);
+#ifdef UH_MIXFFT_STAMPS
+                stamps.t[kStampPhases + 4] = __any(more) ? 2ull : 1ull;
+#endif
+                if (__any(more)) {
+                    if (more) {
+                        int nstart = nxt.start;
+#pragma unroll
+                        for (int j = 0; j < P; ++j) {
+                            const int i = i0 + 2 * j;
+                            if (i < covered) {
+                                while (i >= nstart) { ++sg; cur = seg[sg]; nstart = seg_start[sg + 1]; }
+                                ph[j] = um::phase_table_eval(cur, i);
+                            }
+                        }
+                    }
+                }
+            } else if (ilast >= 0 && i0 < covered) {
+                // a round behind a table overflow (more than kPhaseCap segments in one symbol): the search
                 const int ifirst = (i0 >= 0) ? i0 : (i0 & 1);
                 int cnt = 1;                                 // segments starting at or before ifirst (segment 0 starts at 0)
                 for (int k = 1; k < ns; ++k) cnt += (__builtin_amdgcn_readlane(my_start, k) <= ifirst) ? 1 : 0;
                 int sg = cnt - 1;
                 um::PhaseSeg cur = seg[sg];
                 int nstart = seg_start[sg + 1];
-                if (i0 >= 0 && ilast < covered && ilast < nstart) {          // the usual case: one segment
 #pragma unroll
-                    for (int j = 0; j < P; ++j) ph[j] = um::phase_table_eval(cur, i0 + 2 * j);
-                } else if (i0 >= 0 && ilast < covered && ilast < seg_start[sg + 2]) {
-                    const um::PhaseSeg nxt = seg[sg + 1];                    // one boundary inside the run
-#pragma unroll
-                    for (int j = 0; j < P; ++j) {
-                        const int i = i0 + 2 * j;
-                        const float a = um::phase_table_eval(cur, i), b = um::phase_table_eval(nxt, i);
-                        ph[j] = (i < nstart) ? a : b;
-                    }
-                } else {
-#pragma unroll
-                    for (int j = 0; j < P; ++j) {
-                        const int i = i0 + 2 * j;
-                        if (i >= 0 && i < covered) {
-                            while (i >= nstart) { ++sg; cur = seg[sg]; nstart = seg_start[sg + 1]; }
-                            ph[j] = um::phase_table_eval(cur, i);
-                        }
+                for (int j = 0; j < P; ++j) {
+                    const int i = i0 + 2 * j;
+                    if (i >= 0 && i < covered) {
+                        while (i >= nstart) { ++sg; cur = seg[sg]; nstart = seg_start[sg + 1]; }
+                        ph[j] = um::phase_table_eval(cur, i);
                     }
                 }
             }
@@ -657,6 +704,7 @@ __device__ __forceinline__ void symbol_to_freq2(Fft2Shared<LOG2N>& sh, const Dem
     // The next item's samples, CFO, start phase and table entry — requested HERE, behind the last use of this item's
     // request registers (`it` is overwritten in place: no copy at the loop end, which would have to wait for the loads)
     // and three quarters of an item ahead of their use.  Nothing else is loaded in the rest of the item.
+    UH_STAMP(13);
     request_next();
     UH_STAMP(2);
     if (cfo_on) {

@@ -17,4 +17,4 @@ print('%-28s step %.3f ms  %.2f M/s | ' % ('$label', d['ms_per_step'], d['value'
 python3 bench.py --config cfg3 --frames 1024 --steps 1 --warmup 0 --no-cpu-baseline > /dev/null 2>&1   # builds the checker libraries once
 run in-tree ULTRA_X=0
 for e in $ENVS; do run "in-tree $e" $e; done
-for v in build/v_*.so; do [ -f "$v" ] && run "$v" ULTRA_HIP_LIB=$v; done
+for v in build/v_*.so; do if [ -f "$v" ]; then run "$v" ULTRA_HIP_LIB=$v; fi; done

@@ -41,9 +41,22 @@ def static_phases(one_wave):
     key = "mix_fft_kernelILi10E" if one_wave else "mix_fft2_kernelILi10E"
     body = next(v for k, v in fns.items() if key in k)
     cuts = [i for i, l in enumerate(body) if "UHSTAMP" in l]
-    parts = [body[a:b] for a, b in zip(cuts, cuts[1:])]
-    # stamps in program order: 0, 1, 2 (outer), 2 (inside `if (cfo_on)`), 3 .. 10  ->  11 partitions
-    return [im.mix(p, costs) for p in parts], costs, len(cuts)
+    ids = [int(re.search(r"UHSTAMP (\d+)", body[i]).group(1)) for i in cuts]
+    # dynamic phase k = stamps k -> k + 1.  Markers in program order: 0, 1, 2 (outer), [11, 12, 13: sub-stamps of the
+    # lookup, two-wave kernel], 2 (inside `if (cfo_on)`), 3 .. 10; the code behind marker m belongs to phase m, the lookup
+    # phase (1) also owns the code behind the outer 2 and the sub-stamps
+    phases = [dict(valu=0, valu_cycles=0.0, salu=0, lds=0, lds_cycles=0.0) for _ in range(10)]
+    seen2 = 0
+    for a, b, m in zip(cuts, cuts[1:] + [len(body)], ids):
+        if m == 2:
+            seen2 += 1
+        k = 0 if m == 0 else 1 if (m in (1, 11, 12, 13) or (m == 2 and seen2 == 1)) else m
+        if k > 9:
+            continue
+        x = im.mix(body[a:b], costs)
+        for f in phases[k]:
+            phases[k][f] += x[f]
+    return phases, costs, len(cuts)
 
 
 def main():
@@ -71,7 +84,7 @@ def main():
         ctx.demod(audio)
     torch.cuda.synchronize()
     waves = 1 if args.one_wave else 2
-    WORDS = 12
+    WORDS = 16
     buf = torch.zeros(n * waves * WORDS, dtype=torch.int64, device="cuda")
     fn = ctx.lib.ultra_hip_debug_set_stamps
     fn.restype, fn.argtypes = C.c_int, [C.c_void_p, C.c_void_p]
@@ -85,6 +98,7 @@ def main():
     hw = (r[:, 11] & np.uint64(0xffffffff)).astype(np.int64); xcc = (r[:, 11] >> np.uint64(32)).astype(np.int64) & 0xf
     simd = (xcc << 20) | (((hw >> 13) & 7) << 16) | (((hw >> 12) & 1) << 12) | (((hw >> 8) & 0xf) << 4) | ((hw >> 4) & 3)
     d = np.diff(t, axis=1)                       # [records][10]
+    ex = r[:, 12:16].astype(np.int64)            # sub-stamps 11, 12, 13 inside the lookup phase (two-wave kernel)
     total = t[:, 10] - t[:, 0]
     print(f"# {'mix_fft_kernel<10> (one wavefront per frame)' if args.one_wave else 'mix_fft2_kernel<10> (two wavefronts per frame)'}, "
           f"{n} frames, stamps of the last data symbol's launch; demodulation of the batch with stamps on: {e0.elapsed_time(e1):.3f} ms")
@@ -105,17 +119,13 @@ def main():
     parts = None
     if stat:
         parts, costs, ncuts = stat
-        # partitions: [0-1] [1-2o] [2o-2i] [2i-3] [3-4] ... [9-10]; fold [1-2o] (empty) into the lookup phase
-        assert ncuts == 12, f"expected 12 stamps in the ISA, found {ncuts}"
-        parts = [parts[0], parts[1], parts[2]] + parts[3:]
     tot_issue = 0.0
     for k in range(10):
         name = PHASES[k if k < 1 else k + 1] if k >= 1 else PHASES[0]
         col = d[:, k]
         line = f"{name:58s} {col.mean():7.0f} {np.median(col):7.0f} {np.percentile(col, 90):7.0f} {100 * col.mean() / total.mean():5.1f}%"
         if parts:
-            # dynamic phase k = stamps k -> k+1; ISA partitions: 0 -> [0-1]; 1 -> [1-2o] + [2o-2i]; k >= 2 -> index k + 1
-            ps = [parts[0]] if k == 0 else ([parts[1], parts[2]] if k == 1 else [parts[k + 1]])
+            ps = [parts[k]]
             valu = sum(p["valu"] for p in ps); vc = sum(p["valu_cycles"] for p in ps); salu = sum(p["salu"] for p in ps)
             lds = sum(p["lds"] for p in ps); lc = sum(p["lds_cycles"] for p in ps)
             tot_issue += vc
@@ -124,7 +134,13 @@ def main():
     if parts:
         print(f"# static VALU issue cycles per wavefront-item {tot_issue:.0f} (loops counted once: the segment count loop runs n_segments times); "
               f"elapsed / issue overall {total.mean() / tot_issue:.2f} at {W:.2f} working wavefronts per SIMD -> VALU issue busy about {100 * W * tot_issue / total.mean():.0f} %")
-    gap = []
+    if not args.one_wave and ex[:, 0].any():
+        cfo = ex[:, 0] > 0
+        a = (ex[cfo, 0] - t[cfo, 1]); b = (ex[cfo, 1] - ex[cfo, 0]); c = (ex[cfo, 2] - ex[cfo, 1]); dd = (t[cfo, 2] - ex[cfo, 2])
+        print(f"# inside the lookup phase ({cfo.mean() * 100:.0f} % of the items rotate): header readlanes + table entries into LDS {a.mean():.0f}, "
+              f"segment mask + entries back {b.mean():.0f}, phase evaluation (+ search when needed) {c.mean():.0f}, "
+              f"bin store + request of the next item {dd.mean():.0f} cycles (mean); search-free lookup taken by "
+              f"{100.0 * (ex[cfo, 3] == 1).mean():.1f} % of the rotating items")
     return 0
 
 
