@@ -203,9 +203,16 @@ constexpr int kStHp = 16 + 512 + 16;                    // c32 Hp[32] at byte 21
 constexpr int kStFloats = kStHp + 64;                   // 2432 bytes = 19 lines
 enum { st_cfo = 0, st_cfo_filt, st_cfo_phase, st_noise, st_snr, st_timing, st_ppc_re, st_ppc_im, st_cpc_re, st_cpc_im,
        st_flags, st_count, st_since };
+// deferred carrier half (track_all_kernel): per (symbol, frame) record from track_pilot_kernel
+constexpr int kPwPilots = 32;                               // pilots per frame the record holds
+constexpr int kTrkRecFloats = 96;                           // three cache lines: 8 scalars (below), then c32 Hp_derotated[<= 32]
+constexpr int kTrkRecHp = 8;                                // (<= 12 pilots touch one line, the headline's 15 two)
+enum { tk_noise = 0, tk_timing, tk_cfo, tk_snr, tk_phase, tk_count };
 constexpr int kFqFloats = 256;      // c32 Fq[128] per frame: bins [0,64) and [N-64,N)
-// Per-frame phase table of the next symbol's CFO rotation (cfo_walk_kernel -> mix_fft_kernel), 32-bit words:
-// number of segments, samples covered, phase after them (float bits), reserved; then {start, base, step} each.
+// Per-frame phase table of the next symbol's CFO rotation (cfo_walk_kernel / pilot_walk_kernel -> mix_fft kernels),
+// 32-bit words: [0] number of segments | samples covered << 8, [1] the tracker's CFO in Hz (float bits), [2] phase after
+// the covered samples (float bits), [3] phase the symbol starts with; then {start, base, step} per segment.  It carries
+// everything the transform needs to know about the frame: mix_fft never reads the tracker record.
 constexpr int kSegTabWords = 4 + 3 * kPhaseCap;
 
 __device__ __forceinline__ bool compact_pilot_state(const DemodConst& D) { return !D.differential && D.n_pilot > 0; }
@@ -284,7 +291,7 @@ __device__ __forceinline__ void symbol_to_freq(FftShared<LOG2N>& sh, const Demod
     int tab_ns = 0, tab_covered = 0, tab_start = 0x7fffffff;
     float tab_pnext = 0.0f, tab_base = 0.0f, tab_step = 0.0f;
     if (cfo_on && seg_tab) {
-        tab_ns = (int)seg_tab[0]; tab_covered = (int)seg_tab[1]; tab_pnext = __uint_as_float(seg_tab[2]);
+        tab_ns = (int)(seg_tab[0] & 0xffu); tab_covered = (int)(seg_tab[0] >> 8); tab_pnext = __uint_as_float(seg_tab[2]);
         if (lane < tab_ns) {
             tab_start = (int)seg_tab[4 + 3 * lane];
             tab_base = __uint_as_float(seg_tab[5 + 3 * lane]);
@@ -516,23 +523,19 @@ struct MixItem {
     // Held as PER-LANE words until the item starts: a uniform value the compiler moves to a scalar register with
     // v_readfirstlane at once, i.e. it waits for the load — behind the asynchronous copy of the samples that was issued
     // just before it (loads return in order) — right where the request was meant to be fire-and-forget.
-    float stv;                  // lane 0: CFO, lane 1: start phase
-    unsigned hw;                // lanes 0..3: table header (segments, samples covered, phase after them, start phase)
+    unsigned hw;                // lanes 0..3: table header (segments | covered << 8, CFO, phase after them, start phase)
     int tab_start;              // lane k: segment k
     float tab_base, tab_step;
 };
-__device__ __forceinline__ void request_item(MixItem& it, const float* __restrict__ st, const unsigned* __restrict__ tab, int lane) {
+__device__ __forceinline__ void request_item(MixItem& it, const unsigned* __restrict__ tab, int lane) {
     it.hw = 0u; it.tab_start = 0x7fffffff; it.tab_base = 0.0f; it.tab_step = 0.0f;
-    if (tab) {
-        const float* src = (lane == 1) ? reinterpret_cast<const float*>(tab + 3) : st + st_cfo;   // ONE load, per-lane address
-        it.stv = *src;                                                            // (lanes >= 2: unused)
+    if (tab) {                  // no table <=> the CFO is zero for every frame of the launch (launch_demod): nothing to read
         it.hw = tab[lane & 3];
         const unsigned* e = tab + 4 + 3 * ((lane < kPhaseCap) ? lane : 0);      // entries behind the last segment: stale, masked at use
         it.tab_start = (int)e[0]; it.tab_base = __uint_as_float(e[1]); it.tab_step = __uint_as_float(e[2]);
-    } else {
-        it.stv = 0.0f;          // no table <=> the CFO is zero for every frame of the launch (launch_demod): nothing to read
     }
 }
+
 // staging of the samples of parity h of one symbol's FFT window: stage[64 q + l] = window[2 (64 q + l) + h]
 template <int LOG2N>
 __device__ __forceinline__ void prefetch_symbol2(Fft2Shared<LOG2N>& sh, const DemodConst& D, int h, int lane,
@@ -562,10 +565,11 @@ __device__ __forceinline__ void symbol_to_freq2(Fft2Shared<LOG2N>& sh, const Dem
     constexpr int P = Fft2Shared<LOG2N>::P, A = Fft2Shared<LOG2N>::A;
     UH_STAMP(0);
     const int rl = (int)(__brev((unsigned)lane) >> 26);      // bitrev6(lane)
-    const float freq_offset_hz = lane_f(it.stv, 0);
-    float cfo_phase = lane_f(it.stv, 1);
+    const unsigned hw0 = (unsigned)__builtin_amdgcn_readlane((int)it.hw, 0);
+    const float freq_offset_hz = __int_as_float(__builtin_amdgcn_readlane((int)it.hw, 1));
+    float cfo_phase = __int_as_float(__builtin_amdgcn_readlane((int)it.hw, 3));
     const bool cfo_on = fabsf(freq_offset_hz) > 0.01f;
-    const int it_ns = __builtin_amdgcn_readlane((int)it.hw, 0), it_covered = __builtin_amdgcn_readlane((int)it.hw, 1);
+    const int it_ns = (int)(hw0 & 0xffu), it_covered = (int)(hw0 >> 8);
     const float it_pnext = __int_as_float(__builtin_amdgcn_readlane((int)it.hw, 2));
     c32* X = sh.X[h];
     um::PhaseSeg* seg = sh.seg[h];
@@ -843,7 +847,8 @@ __device__ __forceinline__ void finish_channel_estimate(TrackShared& sh, const D
 // interpolates, equalises and demaps.
 template <int G>
 __global__ __launch_bounds__(kWave, 5) void track_pilot_kernel(const DemodConst* __restrict__ Dp, int n_frames,
-                                                               float* __restrict__ state, const c32* __restrict__ fq_all) {
+                                                               float* __restrict__ state, const c32* __restrict__ fq_all,
+                                                               float* __restrict__ trk_rec) {
     constexpr int FPW = kWave / G;
     constexpr int kRow = G * 8 + 8;                            // floats per group: 8 terms per pilot, padded (banks)
     __shared__ __attribute__((aligned(16))) float s_terms[FPW][kRow];   // also the staging of the carrier-phase sum
@@ -986,6 +991,10 @@ __global__ __launch_bounds__(kWave, 5) void track_pilot_kernel(const DemodConst*
         // coherent timing fix: the pilots are de-rotated before the interpolation (:514-530)
         const bool fix = !D.differential && fabsf(tr.timing) > 0.1f;
         if (fix && is_pilot) h_new = cmul(h_new, cexpj_bounded(-timing_phase_of(pilot_k, tr.timing, D.log2_fft)));
+        // deferred carrier half (track_all_kernel): it gets the de-rotated estimate in its own record, and the rotation back
+        // that it would have applied to the pilots after the interpolation (:561-567) happens here
+        const c32 h_derot = h_new;
+        if (trk_rec && fix && is_pilot) h_new = cmul(h_new, cexpj_bounded(timing_phase_of(pilot_k, tr.timing, D.log2_fft)));
         if (noise_count > 1 && noise_power_sum > 0.0f) {            // (:583-592)
             float nv = noise_power_sum / (float)(noise_count - 1);
             if (nv < 1e-6f) nv = 1e-6f;
@@ -1021,6 +1030,17 @@ __global__ __launch_bounds__(kWave, 5) void track_pilot_kernel(const DemodConst*
             mine = (sub == st_count) ? (float)tr.snr_symbol_count : mine;
             mine = (sub == st_since) ? (float)tr.symbols_since_sync : mine;
             if (sub <= st_since && sub != st_cfo_phase) st[sub] = mine;
+            if (trk_rec) {
+                float* rec = trk_rec + (size_t)frame * kTrkRecFloats;
+                if (is_pilot) reinterpret_cast<c32*>(rec + kTrkRecHp)[sub] = h_derot;
+                float v = tr.noise_variance;                    // lane sub stores scalar sub of the record's tail
+                v = (sub == tk_timing - tk_noise) ? tr.timing : v;
+                v = (sub == tk_cfo - tk_noise) ? tr.freq_offset_hz : v;
+                v = (sub == tk_snr - tk_noise) ? tr.snr_linear : v;
+                v = (sub == tk_phase - tk_noise) ? tr.cfo_phase : v;
+                v = (sub == tk_count - tk_noise) ? (float)tr.snr_symbol_count : v;
+                if (sub < 8) rec[tk_noise + sub] = (sub <= tk_count - tk_noise) ? v : 0.0f;
+            }
         }
     }
 }
@@ -1313,18 +1333,12 @@ __global__ __launch_bounds__(256) void train_cfo_kernel(const DemodConst* __rest
 // symbol (phase_table.h) — is scalar work per frame: here one LANE per frame (in mix_fft_kernel the whole
 // wavefront of a frame would wait for it: 3.8 k cycles median, 19 k at the 90th percentile of a 27 k-cycle
 // frame).  Reads the tracker's CFO and the phase the previous symbol ended on, writes the frame's table.
-__global__ __launch_bounds__(256) void cfo_walk_kernel(const DemodConst* __restrict__ Dp, int n_frames,
-                                                       float* __restrict__ state, unsigned* __restrict__ seg_tab) {
-    const DemodConst& D = *Dp;
-    const int frame = blockIdx.x * blockDim.x + threadIdx.x;
-    if (frame >= n_frames) return;
-    float* st = state + (size_t)frame * kStFloats;
-    unsigned* tab = seg_tab + (size_t)frame * kSegTabWords;
-    const float cfo = st[st_cfo], phase = st[st_cfo_phase];
-    // word 3: the phase the symbol STARTS with (what mix_fft reads); the record is advanced to the phase the symbol ENDS
-    // with right here — the walk knows it, and the transform kernels then have no store but their bins
+// Phase table of one frame's coming symbol (layout: kSegTabWords above) from the tracker's CFO and the phase the symbol
+// starts with; returns the phase it ends with.
+__device__ __forceinline__ float walk_to_table(const DemodConst& D, float cfo, float phase, unsigned* __restrict__ tab) {
     tab[3] = __float_as_uint(phase);
-    if (!(fabsf(cfo) > 0.01f)) { tab[0] = 0u; tab[1] = 0u; tab[2] = __float_as_uint(phase); return; }
+    tab[1] = __float_as_uint(cfo);
+    if (!(fabsf(cfo) > 0.01f)) { tab[0] = 0u; tab[2] = __float_as_uint(phase); return phase; }
     const float inc = (float)(((-kTwoPi) * (double)cfo) / (double)D.sample_rate);
     int covered;
     float pnext;
@@ -1334,7 +1348,7 @@ __global__ __launch_bounds__(256) void cfo_walk_kernel(const DemodConst* __restr
                                             tab[5 + 3 * k] = __float_as_uint(base);
                                             tab[6 + 3 * k] = __float_as_uint(step);
                                         });
-    tab[0] = (unsigned)ns; tab[1] = (unsigned)covered; tab[2] = __float_as_uint(pnext);
+    tab[0] = (unsigned)ns | ((unsigned)covered << 8); tab[2] = __float_as_uint(pnext);
     // a table overflow (more than kPhaseCap segments in one symbol) leaves the rest to mix_fft; the end phase is
     // walked on here with the same function
     for (int done = covered; done < D.sym_len;) {
@@ -1344,7 +1358,18 @@ __global__ __launch_bounds__(256) void cfo_walk_kernel(const DemodConst* __restr
         done += c2;
         pnext = p2;
     }
-    st[st_cfo_phase] = pnext;
+    return pnext;
+}
+
+__global__ __launch_bounds__(256) void cfo_walk_kernel(const DemodConst* __restrict__ Dp, int n_frames,
+                                                       float* __restrict__ state, unsigned* __restrict__ seg_tab) {
+    const DemodConst& D = *Dp;
+    const int frame = blockIdx.x * blockDim.x + threadIdx.x;
+    if (frame >= n_frames) return;
+    float* st = state + (size_t)frame * kStFloats;
+    // word 3: the phase the symbol STARTS with (what mix_fft reads); the record is advanced to the phase the symbol ENDS
+    // with right here — the walk knows it, and the transform kernels then have no store but their bins
+    st[st_cfo_phase] = walk_to_table(D, st[st_cfo], st[st_cfo_phase], seg_tab + (size_t)frame * kSegTabWords);
 }
 
 // Launch bound 2, occupancy 3: with the bound at 3 the register allocator stops at 168 VGPRs and spills two of
@@ -1354,7 +1379,7 @@ template <int LOG2N>
 __global__ __launch_bounds__(kWave, 2) void mix_fft_kernel(
     const DemodConst* __restrict__ Dp, const c32* __restrict__ nco, const c32* __restrict__ twiddle,
     const float* __restrict__ audio, size_t frame_stride, const unsigned* __restrict__ frame_offset, int n_frames,
-    int sym, float* __restrict__ state, c32* __restrict__ fq, const unsigned* __restrict__ seg_tab, int n_sym_batch) {
+    int sym, c32* __restrict__ fq, const unsigned* __restrict__ seg_tab, int n_sym_batch) {
     __shared__ FftShared<LOG2N> sh;
     const DemodConst& D = *Dp;
     const int lane = threadIdx.x;
@@ -1380,11 +1405,12 @@ __global__ __launch_bounds__(kWave, 2) void mix_fft_kernel(
     if ((int)blockIdx.x < total) prefetch_symbol<LOG2N>(sh, D, item_base((int)blockIdx.x));
     for (int w = blockIdx.x; w < total; w += gridDim.x) {
         const int frame = (n_sym_batch > 1) ? w % n_frames : w, ds = (n_sym_batch > 1) ? w / n_frames : 0;
-        float* st = state + (size_t)frame * kStFloats;
-        const float cfo = st[st_cfo];
-        // the phase the symbol starts with: word 3 of the frame's table (cfo_walk_kernel has already advanced the record
-        // to the symbol's END phase); without a table the CFO is zero and the phase does not move (launch_demod)
-        float phase = seg_tab ? __uint_as_float(seg_tab[(size_t)frame * kSegTabWords + 3]) : st[st_cfo_phase];
+        // CFO and the phase the symbol starts with: words 1 and 3 of the frame's table (cfo_walk_kernel / pilot_walk_kernel,
+        // which have already advanced the tracker to the symbol's END phase); without a table the CFO of every frame of
+        // the launch is zero and the phase does not move (launch_demod)
+        const unsigned* tab = seg_tab ? seg_tab + (size_t)frame * kSegTabWords : nullptr;
+        const float cfo = tab ? __uint_as_float(tab[1]) : 0.0f;
+        float phase = tab ? __uint_as_float(tab[3]) : 0.0f;
         Stamps stamps;
         symbol_to_freq<LOG2N>(sh, D, cfo, phase, nco + (size_t)(sym + ds) * D.sym_len, twiddle, fq + (size_t)w * 128,
                               seg_tab ? seg_tab + (size_t)frame * kSegTabWords : nullptr, stamps);
@@ -1405,7 +1431,7 @@ template <int LOG2N>
 __global__ __launch_bounds__(2 * kWave) __attribute__((amdgpu_waves_per_eu(UH_MIX2_WAVES, 8))) void mix_fft2_kernel(
     const DemodConst* __restrict__ Dp, const c32* __restrict__ nco, const c32* __restrict__ twiddle,
     const float* __restrict__ audio, size_t frame_stride, const unsigned* __restrict__ frame_offset, int n_frames,
-    int sym, float* __restrict__ state, c32* __restrict__ fq, const unsigned* __restrict__ seg_tab, int n_sym_batch) {
+    int sym, c32* __restrict__ fq, const unsigned* __restrict__ seg_tab, int n_sym_batch) {
     __shared__ Fft2Shared<LOG2N> sh;
     const DemodConst& D = *Dp;
     constexpr int P = Fft2Shared<LOG2N>::P, A = Fft2Shared<LOG2N>::A, M = Fft2Shared<LOG2N>::M;
@@ -1427,7 +1453,7 @@ __global__ __launch_bounds__(2 * kWave) __attribute__((amdgpu_waves_per_eu(UH_MI
     auto request = [&](MixItem& it, int w) {
         const int f = frame_of(w);
         prefetch_symbol2<LOG2N>(sh, D, h, lane, item_base(w));
-        request_item(it, state + (size_t)f * kStFloats, seg_tab ? seg_tab + (size_t)f * kSegTabWords : nullptr, lane);
+        request_item(it, seg_tab ? seg_tab + (size_t)f * kSegTabWords : nullptr, lane);
     };
     Mix2Lane<LOG2N> lc;
     lc.w6 = twiddle[lane << 3];
@@ -1592,6 +1618,58 @@ __global__ __launch_bounds__(kWave, 6) void track_kernel(
                 so[ULTRA_HIP_STATE_SYMBOLS] = (float)tr.snr_symbol_count;
                 so[ULTRA_HIP_STATE_RESERVED] = 0.0f;
             }
+        }
+        wave_sync();
+    }
+}
+
+// ---------------------------------------------------------------------------
+// The DEFERRED carrier half of the coherent layouts with pilots (SYNCED entry: the headline configuration).
+//
+// For these layouts the carrier half of a symbol (interpolate, equalise, demap) does not feed back into the tracker: no
+// decision-directed block, and channel_estimate at the data carriers is rebuilt from the pilots every symbol.  The only
+// thing it used to hand back is the pilots' estimates re-rotated by the timing phase (:561-567) — per-pilot work that
+// track_pilot_kernel now does itself.  So the per-symbol chain is  cfo_walk -> mix_fft -> track_pilot  and the carrier
+// half of ALL symbols runs afterwards in ONE launch over (symbol, frame) items (track_all_kernel), from the bins of every
+// symbol and a 256-byte record per item that track_pilot_kernel leaves behind: the de-rotated pilots' estimates and the
+// scalars the carrier half reads.  (Measured and not kept, profiles/r03_lane_per_frame_pilot.txt: the whole pilot half
+// + the walk as ONE LANE per frame — sums as plain loops, nothing replicated, 16 x fewer wavefronts — is 0.14-0.19 ms
+// per launch against 0.084 + 0.03: the per-pilot terms (hypot, two divisions, atan2f) dominate and were already spread
+// over 16 lanes; one lane per frame turns them into a serial chain that four wavefronts per SIMD cannot cover.)
+// The carrier half of every data symbol of every frame in ONE launch (coherent layouts of the lean chain): item
+// w = s * n_frames + f reads the bins Fq[w] and the record trk_rec[w] and writes the LLRs of symbol sym0 + s of frame f.
+template <int MOD>
+__global__ __launch_bounds__(kWave, 6) void track_all_kernel(const DemodConst* __restrict__ Dp, int n_frames, int sym0, int n_sym_batch,
+                                                             const float* __restrict__ trk_rec, const c32* __restrict__ fq_all,
+                                                             float* __restrict__ llr, size_t llr_stride, float* __restrict__ state_out) {
+    __shared__ TrackShared sh;
+    const DemodConst& D = *Dp;
+    const int lane = threadIdx.x;
+    const LaneConst lc = lane_constants(D);
+    const int total = n_frames * n_sym_batch;
+    for (int w = blockIdx.x; w < total; w += gridDim.x) {
+        const int frame = w % n_frames, ds = w / n_frames;
+        const float* rec = trk_rec + (size_t)w * kTrkRecFloats;
+        Track tr;
+        tr.noise_variance = rec[tk_noise]; tr.timing = rec[tk_timing];
+        tr.ppc = mk(1.0f, 0.0f); tr.cpc = mk(1.0f, 0.0f);
+        tr.cpc_init = 1; tr.has_prev = 1; tr.has_dprev = 0; tr.snr_symbol_count = 0; tr.symbols_since_sync = 0;
+        if (lane < D.n_pilot) sh.H[lc.pilot_slot] = reinterpret_cast<const c32*>(rec + kTrkRecHp)[lane];   // the rest is interpolated before it is read
+        c32 dprev = mk(1.0f, 0.0f);
+        wave_sync();
+        finish_channel_estimate(sh, D, lc, tr);
+        equalize_demap<MOD>(sh, D, lc, tr, dprev, fq_all + (size_t)w * 128,
+                            llr + (size_t)frame * llr_stride + (size_t)(sym0 + ds) * D.llrs_per_symbol);
+        if (state_out && lane == 0 && sym0 + ds == D.n_data_sym - 1) {
+            float* so = state_out + (size_t)frame * ULTRA_HIP_STATE_FLOATS;
+            so[ULTRA_HIP_STATE_FREQ_OFFSET_HZ] = rec[tk_cfo];
+            so[ULTRA_HIP_STATE_NOISE_VARIANCE] = rec[tk_noise];
+            so[ULTRA_HIP_STATE_SNR_LINEAR] = rec[tk_snr];
+            so[ULTRA_HIP_STATE_TIMING_OFFSET] = rec[tk_timing];
+            so[ULTRA_HIP_STATE_CFO_PHASE] = rec[tk_phase];
+            so[ULTRA_HIP_STATE_MIXER_PHASE] = D.mixer_phase_end;
+            so[ULTRA_HIP_STATE_SYMBOLS] = rec[tk_count];
+            so[ULTRA_HIP_STATE_RESERVED] = 0.0f;
         }
         wave_sync();
     }

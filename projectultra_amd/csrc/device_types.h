@@ -38,6 +38,8 @@ struct DemodConst {
     int16_t interp_lo[kMaxCarriers];  // slot of lower pilot or -1
     int16_t interp_hi[kMaxCarriers];
     float interp_alpha[kMaxCarriers];
+    int16_t pilot_fq[kMaxCarriers];   // pilot i -> entry of the frame's Fq row (bins [0,64) then [fft-64, fft)); pilot_walk_kernel
+    int16_t pilot_k[kMaxCarriers];    // pilot i -> signed carrier number
     c32 pilot_seq[kMaxCarriers];      // +-1 + 0j
     c32 sync_seq[kMaxCarriers];       // Zadoff-Chu
 };

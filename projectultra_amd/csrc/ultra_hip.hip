@@ -78,6 +78,9 @@ struct ultra_hip_ctx {
     uint32_t deint_step = 1;             // ChannelInterleaver step fused into the LDPC LLR load (1 = off)
     uint16_t* d_deint_table = nullptr;   // general gather table of the fused deinterleave (nullptr = use the step)
     bool mix_one_wave = false;           // ULTRA_HIP_MIXFFT_ONE_WAVE=1: the one-wavefront-per-frame mix_fft_kernel<10> (A/B runs)
+    bool old_chain = false;              // ULTRA_HIP_OLD_CHAIN=1: track_pilot_kernel + track_kernel per symbol for every layout (A/B runs)
+    float* d_ws_trk = nullptr;           // deferred carrier half: one record per (symbol, frame) from track_pilot_kernel to track_all_kernel
+    size_t ws_trk_rows = 0;
     bool profiling = false;
     struct Span { int kind; hipEvent_t e0, e1; };
     std::vector<Span> spans;
@@ -152,6 +155,15 @@ int ensure_fq_workspace(ultra_hip_ctx* ctx, size_t rows) {
     ctx->ws_fq_rows = rows;
     return ULTRA_HIP_OK;
 }
+int ensure_trk_workspace(ultra_hip_ctx* ctx, size_t rows) {
+    if (ctx->ws_trk_rows >= rows) return ULTRA_HIP_OK;
+    UH_HIP(hipStreamSynchronize(ctx->stream));
+    if (ctx->d_ws_trk) { (void)hipFree(ctx->d_ws_trk); ctx->d_ws_trk = nullptr; }
+    ctx->ws_trk_rows = 0;
+    UH_HIP(hipMalloc(&ctx->d_ws_trk, rows * (size_t)dev::kTrkRecFloats * sizeof(float)));
+    ctx->ws_trk_rows = rows;
+    return ULTRA_HIP_OK;
+}
 int ensure_llr_workspace(ultra_hip_ctx* ctx, size_t n_frames) {
     if (ctx->ws_llr_frames >= n_frames) return ULTRA_HIP_OK;
     if (ctx->d_ws_llr) { UH_HIP(hipStreamSynchronize(ctx->stream)); (void)hipFree(ctx->d_ws_llr); ctx->d_ws_llr = nullptr; }
@@ -176,6 +188,7 @@ int launch_demod(ultra_hip_ctx* ctx, const float* d_audio, size_t frame_stride, 
     const unsigned grid_fft = (unsigned)std::min(n_frames, (size_t)ctx->cu_count * 128);
     const unsigned grid_trk = (unsigned)std::min(n_frames, (size_t)ctx->cu_count * 128);
     hipStream_t st = ctx->stream;
+    if (D.log2_fft != 10 && D.log2_fft != 9) return ULTRA_HIP_ERR_UNSUPPORTED;
     {
         LaunchSpan span(ctx, ULTRA_HIP_K_INIT_STATE);
         // compact pilot state (demod_kernel.h, kStHp) and no training symbols that read the full H array first
@@ -193,26 +206,37 @@ int launch_demod(ultra_hip_ctx* ctx, const float* d_audio, size_t frame_stride, 
     // it is 0 for every frame and every symbol, mix_fft_kernel never rotates — no phase tables to walk.
     const bool cfo_is_zero = !D.presynced && D.n_pilot == 0 && d_cfo_hz == nullptr;
     const unsigned* seg_tab = cfo_is_zero ? nullptr : ctx->d_ws_seg;
-    if (D.log2_fft != 10 && D.log2_fft != 9) return ULTRA_HIP_ERR_UNSUPPORTED;
     // ... and no symbol's transform depends on the symbol before it: ALL symbols of all frames in one launch (a grid of
     // n_frames * n_sym items instead of n_sym launches that each ramp up and drain), bins to one Fq row per frame and symbol
-    const bool all_symbols_at_once = cfo_is_zero && n_sym > 1 && n_frames * (size_t)n_sym < 0x7fffffffull;
-    { const int rc_fq = ensure_fq_workspace(ctx, all_symbols_at_once ? n_frames * (size_t)n_sym : n_frames); if (rc_fq != ULTRA_HIP_OK) return rc_fq; }
+    bool all_symbols_at_once = cfo_is_zero && n_sym > 1 && n_frames * (size_t)n_sym < 0x7fffffffull;
+    // Coherent layouts with pilots entered SYNCED: the carrier half does not feed back into the tracker, so it runs once,
+    // behind the last symbol, over every (symbol, frame) — track_all_kernel, demod_kernel.h; per symbol only
+    // cfo_walk -> mix_fft -> track_pilot remain.  Needs every symbol's bins and a record per (symbol, frame).
+    bool deferred = !ctx->old_chain && !D.differential && D.n_pilot > 0 && D.n_pilot <= dev::kPwPilots && D.n_train == 0 &&
+                    !D.presynced && n_frames * (size_t)n_sym < 0x7fffffffull;
+    // n_sym rows of workspace per frame instead of one: if that cannot be had, fall back to the per-symbol launches
+    if ((all_symbols_at_once || deferred) && ensure_fq_workspace(ctx, n_frames * (size_t)n_sym) != ULTRA_HIP_OK) {
+        (void)hipGetLastError();
+        all_symbols_at_once = false; deferred = false;
+    }
+    if (deferred && ensure_trk_workspace(ctx, n_frames * (size_t)n_sym) != ULTRA_HIP_OK) { (void)hipGetLastError(); deferred = false; }
+    { const int rc_fq = ensure_fq_workspace(ctx, n_frames); if (rc_fq != ULTRA_HIP_OK) return rc_fq; }
     if (all_symbols_at_once) {
         LaunchSpan span(ctx, ULTRA_HIP_K_MIX_FFT);
         const unsigned g = (unsigned)std::min(n_frames * (size_t)n_sym, (size_t)ctx->cu_count * 128);
         if (D.log2_fft == 10 && !ctx->mix_one_wave)
             hipLaunchKernelGGL(dev::mix_fft2_kernel<10>, dim3(g), dim3(2 * dev::kWave), 0, st, ctx->d_demod, ctx->d_nco, ctx->d_twiddle,
-                               d_audio, frame_stride, d_frame_offset, (int)n_frames, 0, ctx->d_ws_state, ctx->d_ws_fq, seg_tab, n_sym);
+                               d_audio, frame_stride, d_frame_offset, (int)n_frames, 0, ctx->d_ws_fq, seg_tab, n_sym);
         else if (D.log2_fft == 10)
             hipLaunchKernelGGL(dev::mix_fft_kernel<10>, dim3(g), dim3(dev::kWave), 0, st, ctx->d_demod, ctx->d_nco, ctx->d_twiddle,
-                               d_audio, frame_stride, d_frame_offset, (int)n_frames, 0, ctx->d_ws_state, ctx->d_ws_fq, seg_tab, n_sym);
+                               d_audio, frame_stride, d_frame_offset, (int)n_frames, 0, ctx->d_ws_fq, seg_tab, n_sym);
         else
             hipLaunchKernelGGL(dev::mix_fft_kernel<9>, dim3(g), dim3(dev::kWave), 0, st, ctx->d_demod, ctx->d_nco, ctx->d_twiddle,
-                               d_audio, frame_stride, d_frame_offset, (int)n_frames, 0, ctx->d_ws_state, ctx->d_ws_fq, seg_tab, n_sym);
+                               d_audio, frame_stride, d_frame_offset, (int)n_frames, 0, ctx->d_ws_fq, seg_tab, n_sym);
     }
     for (int s = 0; s < n_sym; ++s) {
-        c32* fq_s = ctx->d_ws_fq + (all_symbols_at_once ? (size_t)s * n_frames * 128 : (size_t)0);
+        c32* fq_s = ctx->d_ws_fq + ((all_symbols_at_once || deferred) ? (size_t)s * n_frames * 128 : (size_t)0);
+        float* rec_s = deferred ? ctx->d_ws_trk + (size_t)s * n_frames * dev::kTrkRecFloats : nullptr;
         // the first symbol of a SYNCED batch without initial offsets is at CFO 0 in every frame: nothing to walk yet
         const bool first_at_zero = s == 0 && !D.presynced && d_cfo_hz == nullptr;
         const unsigned* seg_tab_s = first_at_zero ? nullptr : seg_tab;
@@ -226,15 +250,15 @@ int launch_demod(ultra_hip_ctx* ctx, const float* d_audio, size_t frame_stride, 
             if (D.log2_fft == 10 && !ctx->mix_one_wave)
                 hipLaunchKernelGGL(dev::mix_fft2_kernel<10>, dim3(grid_fft), dim3(2 * dev::kWave), 0, st, ctx->d_demod,
                                    ctx->d_nco, ctx->d_twiddle, d_audio, frame_stride, d_frame_offset, (int)n_frames, s,
-                                   ctx->d_ws_state, fq_s, seg_tab_s, 1);
+                                   fq_s, seg_tab_s, 1);
             else if (D.log2_fft == 10)
                 hipLaunchKernelGGL(dev::mix_fft_kernel<10>, dim3(grid_fft), dim3(dev::kWave), 0, st, ctx->d_demod,
                                    ctx->d_nco, ctx->d_twiddle, d_audio, frame_stride, d_frame_offset, (int)n_frames, s,
-                                   ctx->d_ws_state, fq_s, seg_tab_s, 1);
+                                   fq_s, seg_tab_s, 1);
             else
                 hipLaunchKernelGGL(dev::mix_fft_kernel<9>, dim3(grid_fft), dim3(dev::kWave), 0, st, ctx->d_demod,
                                    ctx->d_nco, ctx->d_twiddle, d_audio, frame_stride, d_frame_offset, (int)n_frames, s,
-                                   ctx->d_ws_state, fq_s, seg_tab_s, 1);
+                                   fq_s, seg_tab_s, 1);
         }
         const bool training = s < D.n_train;
         const bool last = (s == n_sym - 1);
@@ -252,15 +276,35 @@ int launch_demod(ultra_hip_ctx* ctx, const float* d_audio, size_t frame_stride, 
             if (D.n_pilot <= 16) {
                 const unsigned g = (unsigned)std::min((n_frames + 3) / 4, (size_t)ctx->cu_count * 256);
                 hipLaunchKernelGGL(dev::track_pilot_kernel<16>, dim3(g), dim3(dev::kWave), 0, st, ctx->d_demod, (int)n_frames,
-                                   ctx->d_ws_state, fq_s);
+                                   ctx->d_ws_state, fq_s, rec_s);
             } else {
                 const unsigned g = (unsigned)std::min((n_frames + 1) / 2, (size_t)ctx->cu_count * 512);
                 hipLaunchKernelGGL(dev::track_pilot_kernel<32>, dim3(g), dim3(dev::kWave), 0, st, ctx->d_demod, (int)n_frames,
-                                   ctx->d_ws_state, fq_s);
+                                   ctx->d_ws_state, fq_s, rec_s);
             }
         }
+        if (deferred) {
+            if (!last) continue;
+            LaunchSpan span(ctx, ULTRA_HIP_K_TRACK);
+            const unsigned g = (unsigned)std::min(n_frames * (size_t)n_sym, (size_t)ctx->cu_count * 128);
+#define UH_TRACK_ALL(MOD)                                                                                                  \
+    hipLaunchKernelGGL(dev::track_all_kernel<MOD>, dim3(g), dim3(dev::kWave), 0, st, ctx->d_demod, (int)n_frames, 0, n_sym, \
+                       ctx->d_ws_trk, ctx->d_ws_fq, d_llr, llr_stride, d_state)
+            switch (D.modulation) {
+                case ULTRA_MOD_BPSK: UH_TRACK_ALL(ULTRA_MOD_BPSK); break;
+                case ULTRA_MOD_QPSK: UH_TRACK_ALL(ULTRA_MOD_QPSK); break;
+                case ULTRA_MOD_QAM16: UH_TRACK_ALL(ULTRA_MOD_QAM16); break;
+                case ULTRA_MOD_QAM32: UH_TRACK_ALL(ULTRA_MOD_QAM32); break;
+                case ULTRA_MOD_QAM64: UH_TRACK_ALL(ULTRA_MOD_QAM64); break;
+                case ULTRA_MOD_QAM256: UH_TRACK_ALL(ULTRA_MOD_QAM256); break;
+                default: return ULTRA_HIP_ERR_UNSUPPORTED;
+            }
+#undef UH_TRACK_ALL
+            break;
+        }
         // zero-CFO layouts: every symbol's bins are there already — one launch walks all data symbols of a frame
-        const int track_batch = all_symbols_at_once ? n_sym : 1;
+        // (n_train == 0 for the SYNCED entry, so s == 0 here and the launch covers symbols 0 .. n_sym - 1)
+        const int track_batch = all_symbols_at_once ? n_sym - s : 1;
         const bool last_launch = last || all_symbols_at_once;
 #define UH_TRACK(MOD)                                                                                            \
     hipLaunchKernelGGL(dev::track_kernel<MOD>, dim3(grid_trk), dim3(dev::kWave), 0, st, ctx->d_demod, (int)n_frames,  \
@@ -520,6 +564,7 @@ int ultra_hip_create(const ultra_hip_config* cfg, int device, void* stream, ultr
     if (rc != ULTRA_HIP_OK) { delete ctx; return rc; }
     // ULTRA_HIP_LDPC_MESSAGES=1 keeps the message-passing kernel for every rate (A/B measurements, parity tests of both)
     { const char* e = std::getenv("ULTRA_HIP_MIXFFT_ONE_WAVE"); ctx->mix_one_wave = (e && e[0] == '1'); }
+    { const char* e = std::getenv("ULTRA_HIP_OLD_CHAIN"); ctx->old_chain = (e && e[0] == '1'); }
     const char* force_messages = std::getenv("ULTRA_HIP_LDPC_MESSAGES");
     if (!(force_messages && force_messages[0] == '1')) (void)build_ldpc_tplan(ctx->h_ldpc, cfg->code_rate, ctx->h_tplan);
     ctx->h_tplan.max_iterations = ctx->h_ldpc.max_iterations;
@@ -581,6 +626,7 @@ void ultra_hip_destroy(ultra_hip_ctx* ctx) {
     if (ctx->d_ws_cfo) (void)hipFree(ctx->d_ws_cfo);
     if (ctx->d_ws_llr) (void)hipFree(ctx->d_ws_llr);
     if (ctx->d_ws_state) (void)hipFree(ctx->d_ws_state);
+    if (ctx->d_ws_trk) (void)hipFree(ctx->d_ws_trk);
     if (ctx->d_ws_fq) (void)hipFree(ctx->d_ws_fq);
     if (ctx->d_ws_seg) (void)hipFree(ctx->d_ws_seg);
     if (ctx->ev_begin) (void)hipEventDestroy(ctx->ev_begin);
