@@ -197,7 +197,8 @@ int ultra_hip_ldpc_decode_batch(ultra_hip_ctx* ctx, const float* d_llr, size_t n
  *              means "the frequency offset was never set on this demodulator" — processPresynced then takes it
  *              from the two training symbols (Impl::estimateCFOFromTraining, src/ofdm/ofdm_sync.cpp:278-380,
  *              demodulator.cpp:920-925) and starts the correction phase at 0; NULL or a number is a preset,
- *              trusted offset (:918-919)
+ *              trusted offset (:918-919).  ULTRA_ENTRY_SYNCED has no such convention: a NaN there is the caller's
+ *              error and travels through the tracker as NaN (the reference would do the same with a NaN offset)
  *   d_cfo_phase[n_frames] f32 or NULL (=0): initial freq_correction_phase
  *              (OFDMDemodulator::setFrequencyOffsetWithPhase)
  *   d_llr      [n_frames][llrs_per_frame] f32: soft bits in the order

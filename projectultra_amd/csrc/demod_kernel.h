@@ -1601,9 +1601,8 @@ __global__ __launch_bounds__(kWave, 6) void track_kernel(
             reinterpret_cast<c32*>(st + kStHp)[lane] = (lane < D.n_pilot) ? sh.H[lc.pilot_slot] : mk(0.0f, 0.0f);
         if (D.differential) reinterpret_cast<c32*>(st + kStDprev)[lane] = dprev;
         if (lane == 0) {
-            // only what the carrier half owns (equalize_demap: pilot_phase_correction, has_dprev) — the rest of the
-            // record's scalars belong to the pilot half and to mix_fft_kernel, which may already be working on the
-            // next symbol of this frame on the main stream (launch_demod)
+            // only what the carrier half owns (equalize_demap: pilot_phase_correction, has_dprev); the rest of the
+            // record's scalars belong to the pilot half and to cfo_walk_kernel — one partial store instead of the line
             st[st_ppc_re] = tr.ppc.re; st[st_ppc_im] = tr.ppc.im;
             st[st_flags] = (float)(tr.cpc_init | (tr.has_prev << 1) | (tr.has_dprev << 2));
             if (scalar_pilot_half) st[st_count] = (float)tr.snr_symbol_count;

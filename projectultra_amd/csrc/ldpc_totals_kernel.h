@@ -31,6 +31,15 @@ namespace dev {
 
 // RR row rounds, VR variable rounds, D = largest variable degree (LdpcTPlan).  WAVES: wavefronts per SIMD the register
 // budget is sized for.  WANT_TOTAL: also write the final a-posteriori LLRs (parity tests).
+// The totals kernel names its LDS planes by immediate offsets behind M0 = 0 (ds_write_addtid_b32), i.e. it assumes that a
+// kernel whose only LDS is the dynamic allocation sees it at LDS address 0.  ultra_hip_create checks that ONCE with this
+// probe (same declaration, same launch shape) and keeps the message-passing kernel for the context if it ever fails —
+// a synchronous, loud decision instead of a guard inside the decoder that nobody could see.
+__global__ void ldpc_lds_base_probe_kernel(unsigned* __restrict__ out) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
+    if (threadIdx.x == 0) { lds_raw[0] = 1; out[0] = (unsigned)(size_t)lds_raw; }
+}
+
 template <int RR, int VR, int D, bool WANT_TOTAL, int WAVES>
 __global__ __launch_bounds__(kLdpcThreads, WAVES) void ldpc_totals_kernel(
     const LdpcTPlan* __restrict__ Pp, const float* __restrict__ llr, size_t llr_stride, int n_cw,

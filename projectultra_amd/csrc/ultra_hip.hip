@@ -198,6 +198,7 @@ int launch_demod(ultra_hip_ctx* ctx, const float* d_audio, size_t frame_stride, 
     }
     if (D.presynced && d_cfo_hz) {
         // frames whose initial CFO is NaN ("never set"): estimateCFOFromTraining, demodulator.cpp:920-925
+        LaunchSpan span(ctx, ULTRA_HIP_K_INIT_STATE);
         hipLaunchKernelGGL(dev::train_cfo_kernel, dim3((unsigned)((n_frames + 255) / 256)), dim3(256), 0, st, ctx->d_demod, ctx->d_nco,
                            d_audio, frame_stride, d_frame_offset, d_cfo_hz, (int)n_frames, ctx->d_ws_state);
     }
@@ -582,6 +583,18 @@ int ultra_hip_create(const ultra_hip_config* cfg, int device, void* stream, ultr
     if (hipMalloc(&ctx->d_work, 16 * dev::kLdpcQueueWords * sizeof(unsigned int)) != hipSuccess) return fail(ULTRA_HIP_ERR_OOM);
     if (hipMalloc(&ctx->d_nco, nco.size() * sizeof(c32)) != hipSuccess) return fail(ULTRA_HIP_ERR_OOM);
     if (hipMalloc(&ctx->d_twiddle, tw.size() * sizeof(c32)) != hipSuccess) return fail(ULTRA_HIP_ERR_OOM);
+    if (ctx->h_tplan.valid) {
+        // ldpc_totals_kernel.h: dynamic LDS must start at LDS address 0 for the totals kernel; d_work doubles as the probe's word
+        unsigned base = 1u;
+        hipLaunchKernelGGL(dev::ldpc_lds_base_probe_kernel, dim3(1), dim3(dev::kLdpcThreads), (size_t)ctx->h_tplan.lds_bytes, ctx->stream, ctx->d_work);
+        if (hipGetLastError() != hipSuccess || hipStreamSynchronize(ctx->stream) != hipSuccess ||
+            hipMemcpy(&base, ctx->d_work, sizeof(base), hipMemcpyDeviceToHost) != hipSuccess)
+            return fail(ULTRA_HIP_ERR_HIP);
+        if (base != 0u) {
+            std::fprintf(stderr, "ultra_hip: dynamic LDS starts at %u, not 0: this context decodes with the message-passing kernel\n", base);
+            ctx->h_tplan.valid = 0;
+        }
+    }
     if (hipMemcpy(ctx->d_demod, &ctx->h_demod, sizeof(DemodConst), hipMemcpyHostToDevice) != hipSuccess ||
         hipMemcpy(ctx->d_plan, &ctx->h_plan, sizeof(LdpcPlan), hipMemcpyHostToDevice) != hipSuccess ||
         hipMemcpy(ctx->d_tplan, &ctx->h_tplan, sizeof(LdpcTPlan), hipMemcpyHostToDevice) != hipSuccess ||
@@ -639,10 +652,19 @@ int ultra_hip_reserve(ultra_hip_ctx* ctx, size_t n_frames) {
     if (n_frames == 0) return ULTRA_HIP_OK;
     DeviceGuard guard(ctx->device);
     int rc = ensure_demod_workspace(ctx, n_frames);
-    if (rc == ULTRA_HIP_OK) {          // one row per frame and symbol where launch_demod may transform all symbols at once
+    if (rc == ULTRA_HIP_OK) {
+        // One row per frame always; one per frame AND symbol where launch_demod keeps every symbol's bins (layouts without
+        // pilots at CFO 0, and the deferred carrier half of the coherent layouts) — that multiple is best effort: without
+        // it launch_demod runs the per-symbol launches on single-symbol buffers instead of failing.
         const DemodConst& D = ctx->h_demod;
-        const size_t syms = (!D.presynced && D.n_pilot == 0) ? (size_t)std::max(1, D.n_train + D.n_data_sym) : 1;
-        rc = ensure_fq_workspace(ctx, n_frames * syms);
+        const size_t syms = (size_t)std::max(1, D.n_train + D.n_data_sym);
+        const bool zero_cfo_layout = !D.presynced && D.n_pilot == 0;
+        const bool deferred_layout = !ctx->old_chain && !D.differential && D.n_pilot > 0 && D.n_train == 0 && !D.presynced;
+        if ((zero_cfo_layout || deferred_layout) && syms > 1) {
+            if (ensure_fq_workspace(ctx, n_frames * syms) != ULTRA_HIP_OK) (void)hipGetLastError();
+            else if (deferred_layout && ensure_trk_workspace(ctx, n_frames * syms) != ULTRA_HIP_OK) (void)hipGetLastError();
+        }
+        rc = ensure_fq_workspace(ctx, n_frames);
     }
     if (rc == ULTRA_HIP_OK) rc = ensure_llr_workspace(ctx, n_frames);
     return rc;
