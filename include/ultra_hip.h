@@ -33,7 +33,7 @@
 extern "C" {
 #endif
 
-#define ULTRA_HIP_ABI_VERSION 4
+#define ULTRA_HIP_ABI_VERSION 5
 
 /* ultra::Modulation (include/ultra/types.hpp:27-39) — same numeric values. */
 enum ultra_hip_modulation {
@@ -215,6 +215,23 @@ int ultra_hip_demod_batch(ultra_hip_ctx* ctx, const float* d_audio, size_t frame
                           const float* d_cfo_hz, const float* d_cfo_phase, size_t n_frames,
                           float* d_llr, float* d_state);
 
+/* The SYNCED symbol loop of OFDMDemodulator::process (src/ofdm/demodulator.cpp:672-697) as it runs on a live stream:
+ * symbols are demodulated when they arrive.  Symbols [first_symbol, first_symbol + n_symbols) of every frame, the
+ * tracker continuing from where the previous call on this context left it (first_symbol == 0 starts a fresh
+ * demodulator from d_cfo_hz / d_cfo_phase, which are ignored otherwise).  Same results as one
+ * ultra_hip_demod_batch call over all symbols: the chain is causal.
+ *   d_audio   [n_frames] rows of frame_stride floats, row f starting at symbol first_symbol of frame f
+ *   d_llr     [n_frames][n_data * llrs_per_symbol] f32, n_data = the data symbols among those of this call
+ *   d_state   [n_frames][ULTRA_HIP_STATE_FLOATS] or NULL: the tracker after the last symbol of this call
+ * The context must have been created with n_data_symbols >= the frame's length (<= 251: process() gives up after
+ * MAX_SYMBOLS_BEFORE_TIMEOUT + 1 symbols) and must not run another batch in between. */
+int ultra_hip_demod_stream_batch(ultra_hip_ctx* ctx, const float* d_audio, size_t frame_stride, const float* d_cfo_hz,
+                                 const float* d_cfo_phase, size_t n_frames, uint32_t first_symbol, uint32_t n_symbols,
+                                 float* d_llr, float* d_state);
+/* OFDMDemodulator::setFrequencyOffset (demodulator.cpp:805-815) between two ultra_hip_demod_stream_batch calls:
+ * freq_offset_hz = freq_offset_filtered = cfo_hz, correction phase 0, for frame `frame` of the stream in flight. */
+int ultra_hip_demod_stream_set_cfo(ultra_hip_ctx* ctx, size_t frame, float cfo_hz);
+
 #define ULTRA_HIP_STATE_FLOATS 8
 #define ULTRA_HIP_STATE_FREQ_OFFSET_HZ 0   /* OFDMDemodulator::getFrequencyOffset     */
 #define ULTRA_HIP_STATE_NOISE_VARIANCE 1   /* Impl::noise_variance                    */
@@ -288,6 +305,19 @@ int ultra_hip_timer_end(ultra_hip_ctx* ctx, float* ms);
 int ultra_hip_acquire_batch(ultra_hip_ctx* ctx, const float* d_audio, size_t stream_stride, uint32_t n_samples,
                             uint32_t chunk, size_t n_streams, uint32_t* d_found, uint32_t* d_data_start,
                             float* d_cfo_hz, uint32_t* d_sync_offset, uint32_t* d_fed_at_sync);
+
+/* The same search for LIVE streams, one OFDMDemodulator::process() call per launch (the streaming adapters,
+ * include/ultra_hip_waveform.hpp: HipOfdmCoxWaveform).  Everything fed since the previous launch is this call's chunk.
+ *   origin        sample index i of stream s lives at d_audio[s * stream_stride + i - origin]: the caller keeps only
+ *                 what the search can still look at (at least everything from d_resume[4 s] on)
+ *   n_samples     samples fed so far, this call's included (absolute, as are all sample indices below)
+ *   d_resume      [n_streams][4] u32, in/out: {start of rx_buffer, samples fed, noise floor of the energy gate (float
+ *                 bits), reserved} — what Impl carries between process() calls while SEARCHING; zero it for a fresh
+ *                 demodulator, keep the noise floor across frames (OFDMDemodulator::reset does not clear it)
+ *   outputs as in ultra_hip_acquire_batch; on d_found[s] = 1 the stream enters SYNCED at d_data_start[s]. */
+int ultra_hip_acquire_stream_batch(ultra_hip_ctx* ctx, const float* d_audio, size_t stream_stride, uint32_t origin,
+                                   uint32_t n_samples, size_t n_streams, uint32_t* d_resume, uint32_t* d_found,
+                                   uint32_t* d_data_start, float* d_cfo_hz, uint32_t* d_sync_offset);
 
 /* Chirp synchronisation: OFDMChirpWaveform::detectSync
  * (src/waveform/ofdm_chirp_waveform.cpp:129-172) = sync::ChirpSync::detectDualChirp

@@ -102,6 +102,15 @@ struct DevBuf {                            // device allocation tied to a contex
     DevBuf(const DevBuf&) = delete;
     DevBuf& operator=(const DevBuf&) = delete;
 };
+// a device buffer that lives with its owner and only ever grows (the adapters' per-call scratch)
+struct GrowBuf {
+    std::unique_ptr<DevBuf> b; size_t cap = 0; ultra_hip_ctx* owner = nullptr;
+    void* get(ultra_hip_ctx* ctx, size_t bytes) {
+        if (!b || owner != ctx || bytes > cap) { b.reset(); cap = std::max<size_t>(bytes, 2 * cap); b = std::make_unique<DevBuf>(ctx, cap); owner = ctx; }
+        return b->d;
+    }
+    void drop() { b.reset(); cap = 0; owner = nullptr; }
+};
 inline void check(int rc, const char* what) {
     if (rc != ULTRA_HIP_OK) throw std::runtime_error(std::string(what) + ": " + ultra_hip_strerror(rc));
 }
@@ -153,15 +162,17 @@ public:
     // n_cw independent codewords, host buffers: llr [n_cw][648] -> bytes [n_cw][ceil(k/8)], iters, ok
     void decodeBatch(const float* llr, size_t n_cw, uint8_t* bytes, int32_t* iters, uint8_t* ok) {
         ultra_hip_geometry g; detail::check(ultra_hip_get_geometry(ctx_.p, &g), "geometry");
-        detail::DevBuf d_llr(ctx_.p, n_cw * 648 * sizeof(float)), d_b(ctx_.p, n_cw * g.decoded_bytes),
-            d_i(ctx_.p, n_cw * sizeof(int32_t)), d_o(ctx_.p, n_cw);
-        detail::check(ultra_hip_memcpy_h2d(ctx_.p, d_llr.d, llr, n_cw * 648 * sizeof(float)), "h2d");
-        detail::check(ultra_hip_ldpc_decode_batch(ctx_.p, static_cast<const float*>(d_llr.d), n_cw,
-                                                  static_cast<uint8_t*>(d_b.d), static_cast<int32_t*>(d_i.d),
-                                                  static_cast<uint8_t*>(d_o.d), nullptr), "ldpc_decode_batch");
-        detail::check(ultra_hip_memcpy_d2h(ctx_.p, bytes, d_b.d, n_cw * g.decoded_bytes), "d2h");
-        detail::check(ultra_hip_memcpy_d2h(ctx_.p, iters, d_i.d, n_cw * sizeof(int32_t)), "d2h");
-        detail::check(ultra_hip_memcpy_d2h(ctx_.p, ok, d_o.d, n_cw), "d2h");
+        void* d_llr = s_llr_.get(ctx_.p, n_cw * 648 * sizeof(float));
+        void* d_b = s_bytes_.get(ctx_.p, n_cw * g.decoded_bytes);
+        void* d_i = s_iters_.get(ctx_.p, n_cw * sizeof(int32_t));
+        void* d_o = s_ok_.get(ctx_.p, n_cw);
+        detail::check(ultra_hip_memcpy_h2d(ctx_.p, d_llr, llr, n_cw * 648 * sizeof(float)), "h2d");
+        detail::check(ultra_hip_ldpc_decode_batch(ctx_.p, static_cast<const float*>(d_llr), n_cw,
+                                                  static_cast<uint8_t*>(d_b), static_cast<int32_t*>(d_i),
+                                                  static_cast<uint8_t*>(d_o), nullptr), "ldpc_decode_batch");
+        detail::check(ultra_hip_memcpy_d2h(ctx_.p, bytes, d_b, n_cw * g.decoded_bytes), "d2h");
+        detail::check(ultra_hip_memcpy_d2h(ctx_.p, iters, d_i, n_cw * sizeof(int32_t)), "d2h");
+        detail::check(ultra_hip_memcpy_d2h(ctx_.p, ok, d_o, n_cw), "d2h");
     }
     bool lastDecodeSuccess() const { return last_success_; }
     int lastIterations() const { return last_iters_; }
@@ -171,13 +182,17 @@ public:
 
 private:
     void rebuild() {
+        s_llr_.drop(); s_bytes_.drop(); s_iters_.drop(); s_ok_.drop();   // they belong to the context that goes away
         ModemConfig c; c.code_rate = rate_;
         ctx_ = detail::Ctx(to_c_config(c, ULTRA_ENTRY_SYNCED, 44, 0, static_cast<uint32_t>(max_iter_)), device_);
         if (deinterleave_) detail::check(ultra_hip_set_deinterleave(ctx_.p, deinterleave_), "ultra_hip_set_deinterleave");
     }
     CodeRate rate_; int device_; int max_iter_ = 50; bool last_success_ = false; int last_iters_ = 0;
     uint32_t deinterleave_ = 0;
+    detail::GrowBuf s_llr_, s_bytes_, s_iters_, s_ok_;   // declared before ctx_: destroyed after... see ~HipLDPCDecoder
     detail::Ctx ctx_;
+public:
+    ~HipLDPCDecoder() { s_llr_.drop(); s_bytes_.drop(); s_iters_.drop(); s_ok_.drop(); }   // buffers first, then the context
 };
 
 // ---------------------------------------------------------------------------------------------
@@ -194,6 +209,7 @@ public:
     void configure(Modulation mod, CodeRate rate) {                     // as OFDMNvisWaveform::configure
         config_.modulation = mod; config_.code_rate = rate;
         config_.use_pilots = !(mod == Modulation::DBPSK || mod == Modulation::DQPSK || mod == Modulation::D8PSK);
+        s_audio_.drop(); s_cp_.drop(); s_llr_.drop(); s_state_.drop();
         ctx_.reset();
     }
     void setFrequencyOffset(float cfo_hz) { cfo_hz_ = cfo_hz; }
@@ -206,15 +222,16 @@ public:
     // device (scope row f4, ultra_hip_chirp_sync_batch); start_sample = where the two training symbols start.
     bool detectSync(SampleSpan samples, SyncResult& result, float threshold = 0.3f) {
         if (!sync_ctx_.p) sync_ctx_ = detail::Ctx(to_c_config(config_, ULTRA_ENTRY_PRESYNCED, 1, 2), device_);
-        detail::DevBuf d_a(sync_ctx_.p, std::max<size_t>(samples.size(), 1) * sizeof(float)), d_o(sync_ctx_.p, 4 * sizeof(uint32_t));
-        detail::check(ultra_hip_memcpy_h2d(sync_ctx_.p, d_a.d, samples.data(), samples.size() * sizeof(float)), "h2d");
-        uint32_t* o = static_cast<uint32_t*>(d_o.d);
-        detail::check(ultra_hip_chirp_sync_batch(sync_ctx_.p, static_cast<const float*>(d_a.d), samples.size(),
+        void* d_a = s_sync_audio_.get(sync_ctx_.p, std::max<size_t>(samples.size(), 1) * sizeof(float));
+        void* d_o = s_sync_out_.get(sync_ctx_.p, 4 * sizeof(uint32_t));
+        detail::check(ultra_hip_memcpy_h2d(sync_ctx_.p, d_a, samples.data(), samples.size() * sizeof(float)), "h2d");
+        uint32_t* o = static_cast<uint32_t*>(d_o);
+        detail::check(ultra_hip_chirp_sync_batch(sync_ctx_.p, static_cast<const float*>(d_a), samples.size(),
                                                  static_cast<uint32_t>(samples.size()), 1, threshold, o,
                                                  reinterpret_cast<int32_t*>(o + 1), reinterpret_cast<float*>(o + 2),
                                                  reinterpret_cast<float*>(o + 3), nullptr, nullptr), "chirp_sync_batch");
         uint32_t h[4];
-        detail::check(ultra_hip_memcpy_d2h(sync_ctx_.p, h, d_o.d, sizeof(h)), "d2h");
+        detail::check(ultra_hip_memcpy_d2h(sync_ctx_.p, h, d_o, sizeof(h)), "d2h");
         result.detected = h[0] != 0;
         std::memcpy(&result.cfo_hz, &h[2], sizeof(float));
         std::memcpy(&result.correlation, &h[3], sizeof(float));
@@ -238,6 +255,7 @@ public:
         if (samples.size() < size_t(3) * sym) return false;
         const uint32_t n_data = static_cast<uint32_t>(samples.size() / sym) - 2;
         if (!ctx_.p || n_data != n_data_) {
+            s_audio_.drop(); s_cp_.drop(); s_llr_.drop(); s_state_.drop();
             ctx_ = detail::Ctx(to_c_config(config_, ULTRA_ENTRY_PRESYNCED, n_data, 2), device_);
             n_data_ = n_data;
         }
@@ -247,21 +265,26 @@ public:
                                          double(config_.sample_rate));
         while (double(phase) > M_PI) phase = static_cast<float>(double(phase) - 2.0 * M_PI);
         while (double(phase) < -M_PI) phase = static_cast<float>(double(phase) + 2.0 * M_PI);
-        detail::DevBuf d_a(ctx_.p, g.frame_samples * sizeof(float)), d_c(ctx_.p, 2 * sizeof(float)),
-            d_l(ctx_.p, g.llrs_per_frame * sizeof(float)), d_s(ctx_.p, ULTRA_HIP_STATE_FLOATS * sizeof(float));
+        void* d_a = s_audio_.get(ctx_.p, g.frame_samples * sizeof(float));
+        void* d_c = s_cp_.get(ctx_.p, 2 * sizeof(float));
+        void* d_l = s_llr_.get(ctx_.p, g.llrs_per_frame * sizeof(float));
+        void* d_s = s_state_.get(ctx_.p, ULTRA_HIP_STATE_FLOATS * sizeof(float));
         const float cp[2] = {cfo_hz_, phase};
-        detail::check(ultra_hip_memcpy_h2d(ctx_.p, d_a.d, samples.data(), g.frame_samples * sizeof(float)), "h2d");
-        detail::check(ultra_hip_memcpy_h2d(ctx_.p, d_c.d, cp, sizeof(cp)), "h2d");
-        detail::check(ultra_hip_demod_batch(ctx_.p, static_cast<const float*>(d_a.d), g.frame_samples,
-                                            static_cast<const float*>(d_c.d), static_cast<const float*>(d_c.d) + 1, 1,
-                                            static_cast<float*>(d_l.d), static_cast<float*>(d_s.d)), "demod_batch");
+        detail::check(ultra_hip_memcpy_h2d(ctx_.p, d_a, samples.data(), g.frame_samples * sizeof(float)), "h2d");
+        detail::check(ultra_hip_memcpy_h2d(ctx_.p, d_c, cp, sizeof(cp)), "h2d");
+        detail::check(ultra_hip_demod_batch(ctx_.p, static_cast<const float*>(d_a), g.frame_samples,
+                                            static_cast<const float*>(d_c), static_cast<const float*>(d_c) + 1, 1,
+                                            static_cast<float*>(d_l), static_cast<float*>(d_s)), "demod_batch");
         soft_bits_.resize(g.llrs_per_frame);
-        detail::check(ultra_hip_memcpy_d2h(ctx_.p, soft_bits_.data(), d_l.d, g.llrs_per_frame * sizeof(float)), "d2h");
-        detail::check(ultra_hip_memcpy_d2h(ctx_.p, state_, d_s.d, sizeof(state_)), "d2h");
+        detail::check(ultra_hip_memcpy_d2h(ctx_.p, soft_bits_.data(), d_l, g.llrs_per_frame * sizeof(float)), "d2h");
+        detail::check(ultra_hip_memcpy_d2h(ctx_.p, state_, d_s, sizeof(state_)), "d2h");
         return soft_bits_.size() >= 648;
     }
     std::vector<float> getSoftBits() { return std::move(soft_bits_); }
     void reset() { soft_bits_.clear(); synced_ = false; }
+    ~HipOfdmWaveform() {                                                  // buffers before the contexts they came from
+        s_audio_.drop(); s_cp_.drop(); s_llr_.drop(); s_state_.drop(); s_sync_audio_.drop(); s_sync_out_.drop();
+    }
     bool isSynced() const { return synced_; }
     bool hasData() const { return !soft_bits_.empty(); }
     float estimatedSNR() const { return 10.0f * std::log10(state_[ULTRA_HIP_STATE_SNR_LINEAR]); }
@@ -312,6 +335,7 @@ private:
     ModemConfig config_;
     int device_;
     detail::Ctx ctx_, sync_ctx_;
+    detail::GrowBuf s_audio_, s_cp_, s_llr_, s_state_, s_sync_audio_, s_sync_out_;   // persistent per-call scratch
     float last_cfo_ = 0.0f;
     uint32_t n_data_ = 0;
     float cfo_hz_ = 0.0f;
@@ -332,10 +356,10 @@ struct HipRxFrameResult {                      // gui::RxFrameResult
 class HipRxFrameDecoder {
 public:
     explicit HipRxFrameDecoder(int device = 0) : device_(device) {}
-    void setDataMode(CodeRate rate, bool connected) { rate_ = rate; connected_ = connected; ctx_.reset(); }
-    void setInterleavingEnabled(bool enabled) { interleaving_ = enabled; ctx_.reset(); }
+    void setDataMode(CodeRate rate, bool connected) { rate_ = rate; connected_ = connected; dropScratch(); ctx_.reset(); }
+    void setInterleavingEnabled(bool enabled) { interleaving_ = enabled; dropScratch(); ctx_.reset(); }
     void setInterleaverConfig(size_t bits_per_symbol) {            // rx_pipeline.cpp:24-31
-        if (bits_per_symbol != bits_per_symbol_) { bits_per_symbol_ = bits_per_symbol; ctx_.reset(); }
+        if (bits_per_symbol != bits_per_symbol_) { bits_per_symbol_ = bits_per_symbol; dropScratch(); ctx_.reset(); }
     }
     int getExpectedCodewords() const { return expected_; }
     bool isAccumulating() const { return expected_ > 0; }
@@ -351,96 +375,302 @@ public:
         }
         ultra_hip_geometry g; detail::check(ultra_hip_get_geometry(ctx_.p, &g), "geometry");
         const size_t n = soft_bits.size(), stride = std::max<size_t>((n / 648) * (g.ldpc_k / 8), 1);
-        detail::DevBuf d_s(ctx_.p, n * sizeof(float)), d_r(ctx_.p, sizeof(ultra_hip_frame_result)), d_d(ctx_.p, stride);
-        detail::check(ultra_hip_memcpy_h2d(ctx_.p, d_s.d, soft_bits.data(), n * sizeof(float)), "h2d");
-        detail::check(ultra_hip_decode_frames_batch(ctx_.p, static_cast<const float*>(d_s.d), n, static_cast<uint32_t>(n), 1,
-                                                    static_cast<ultra_hip_frame_result*>(d_r.d),
-                                                    static_cast<uint8_t*>(d_d.d), stride), "decode_frames_batch");
+        void* d_s = s_soft_.get(ctx_.p, n * sizeof(float));
+        void* d_r = s_res_.get(ctx_.p, sizeof(ultra_hip_frame_result));
+        void* d_d = s_data_.get(ctx_.p, stride);
+        detail::check(ultra_hip_memcpy_h2d(ctx_.p, d_s, soft_bits.data(), n * sizeof(float)), "h2d");
+        detail::check(ultra_hip_decode_frames_batch(ctx_.p, static_cast<const float*>(d_s), n, static_cast<uint32_t>(n), 1,
+                                                    static_cast<ultra_hip_frame_result*>(d_r),
+                                                    static_cast<uint8_t*>(d_d), stride), "decode_frames_batch");
         ultra_hip_frame_result h;
-        detail::check(ultra_hip_memcpy_d2h(ctx_.p, &h, d_r.d, sizeof(h)), "d2h");
+        detail::check(ultra_hip_memcpy_d2h(ctx_.p, &h, d_r, sizeof(h)), "d2h");
         r.success = h.success != 0; r.is_ping = h.is_ping != 0; r.frame_type = h.frame_type;
         r.codewords_ok = h.codewords_ok; r.codewords_failed = h.codewords_failed; expected_ = h.expected_codewords;
         r.frame_data.resize(size_t(h.frame_len));
-        if (h.frame_len > 0) detail::check(ultra_hip_memcpy_d2h(ctx_.p, r.frame_data.data(), d_d.d, size_t(h.frame_len)), "d2h");
+        if (h.frame_len > 0) detail::check(ultra_hip_memcpy_d2h(ctx_.p, r.frame_data.data(), d_d, size_t(h.frame_len)), "d2h");
         return r;
     }
 private:
     int device_; CodeRate rate_ = CodeRate::R1_4; bool connected_ = false, interleaving_ = true;
     size_t bits_per_symbol_ = 60;           // the constructor's ChannelInterleaver(60, 648): rx_pipeline.cpp:13-18
     int expected_ = 0;
+    detail::GrowBuf s_soft_, s_res_, s_data_;
     detail::Ctx ctx_;
+    void dropScratch() { s_soft_.drop(); s_res_.drop(); s_data_.drop(); }
+public:
+    ~HipRxFrameDecoder() { dropScratch(); }
 };
 
 // ---------------------------------------------------------------------------------------------
-// Schmidl-Cox flavour: mirrors ultra::OFDMNvisWaveform's receive half (src/waveform/ofdm_cox_waveform.cpp:
-// 98-138), whose detectSync/process simply feed OFDMDemodulator::process — the chunk-fed search
-// (scope row f1, ultra_hip_acquire_batch) followed by the SYNCED symbol loop.  Feed it equal-sized
-// chunks (the harnesses use 960 samples: the search result depends on the chunking).
-class HipOfdmCoxReceiver {
+// Schmidl-Cox flavour: ultra::OFDMNvisWaveform (src/waveform/ofdm_cox_waveform.cpp) — what
+// WaveformFactory::create(WaveformMode::OFDM_COX) returns (src/waveform/waveform_factory.cpp:16-17,52-53) and the waveform
+// the headline configuration runs on.  Its receive half is OFDMDemodulator::process (src/ofdm/demodulator.cpp:461-741)
+// behind detectSync / process / getSoftBits; this class is that state machine on the device, as a LIVE stream:
+//   SEARCHING  every process() call is ONE launch of the chunk-fed Schmidl-Cox search that continues from the state the
+//              previous call left (ultra_hip_acquire_stream_batch: start of rx_buffer, samples fed, the energy gate's
+//              noise floor) — only the new samples are uploaded, nothing is searched twice;
+//   SYNCED     whole symbols are demodulated as they arrive, the tracker continuing on the device
+//              (ultra_hip_demod_stream_batch); no frame length is needed up front; the three ways out of SYNCED are
+//              the reference's: more than MAX_SYMBOLS_BEFORE_TIMEOUT symbols (:683-691), more than
+//              MAX_IDLE_CALLS_BEFORE_RESET calls without a new soft bit (:704-716), an empty call with nothing left
+//              to demodulate and less than a codeword buffered ("frame complete", :720-731).
+// Device buffers live as long as the object.  Not reproduced: the mid-frame preamble re-detection of :605-657 (a second
+// Schmidl-Cox search inside SYNCED after two idle calls) — frames end through the three exits above.
+// Inside the reference tree (-DULTRA_HIP_WITH_REFERENCE) it derives from ultra::IWaveform and the transmit half is the
+// reference's own OFDMModulator, so it can stand wherever an OFDMNvisWaveform stands.
+#ifdef ULTRA_HIP_WITH_REFERENCE
+}  // namespace ultra_hip
+#include "ultra/ofdm.hpp"
+namespace ultra_hip {
+#endif
+class HipOfdmCoxWaveform
+#ifdef ULTRA_HIP_WITH_REFERENCE
+    : public ultra::IWaveform
+#endif
+{
 public:
-    explicit HipOfdmCoxReceiver(const ModemConfig& config, uint32_t n_data_symbols, int device = 0)
-        : config_(config), ctx_(to_c_config(config, ULTRA_ENTRY_SYNCED, n_data_symbols, 0), device) {
-        detail::check(ultra_hip_get_geometry(ctx_.p, &geo_), "geometry");
+    static constexpr int kMaxSymbolsBeforeTimeout = 250, kMaxIdleCallsBeforeReset = 10;   // demodulator_constants.hpp:37-38
+    explicit HipOfdmCoxWaveform(const ModemConfig& config = defaultConfig(), int device = 0) : config_(config), device_(device) {
+        initComponents();
     }
-    void reset() { rx_.clear(); soft_bits_.clear(); chunk_ = 0; synced_ = false; found_ = false; }
-    bool isSynced() const { return synced_; }
-    size_t getLastSyncOffset() const { return sync_offset_; }
-    float getFrequencyOffset() const { return synced_ ? state_[ULTRA_HIP_STATE_FREQ_OFFSET_HZ] : cfo_hz_; }
-    float coarseCFO() const { return cfo_hz_; }
-    bool detectSync(SampleSpan samples, SyncResult& result, float = 0.8f) {        // ofdm_cox_waveform.cpp:98-120
-        process(samples);
-        if (!found_) return false;
-        result.detected = true;
-        result.start_sample = static_cast<int>(sync_offset_);
-        result.cfo_hz = getFrequencyOffset();
-        return true;
-    }
-    // OFDMDemodulator::process: true when at least 648 soft bits are buffered
-    bool process(SampleSpan samples) {
-        if (chunk_ == 0) chunk_ = static_cast<uint32_t>(samples.size());
-        rx_.insert(rx_.end(), samples.begin(), samples.end());
-        if (synced_) return soft_bits_.size() >= 648;
-        if (!found_) {
-            detail::DevBuf d_a(ctx_.p, rx_.size() * sizeof(float)), d_o(ctx_.p, 5 * sizeof(uint32_t));
-            detail::check(ultra_hip_memcpy_h2d(ctx_.p, d_a.d, rx_.data(), rx_.size() * sizeof(float)), "h2d");
-            uint32_t* o = static_cast<uint32_t*>(d_o.d);
-            detail::check(ultra_hip_acquire_batch(ctx_.p, static_cast<const float*>(d_a.d), rx_.size(),
-                                                  static_cast<uint32_t>(rx_.size()), chunk_, 1, o, o + 1,
-                                                  reinterpret_cast<float*>(o + 2), o + 3, o + 4), "acquire_batch");
-            uint32_t h[5];
-            detail::check(ultra_hip_memcpy_d2h(ctx_.p, h, d_o.d, sizeof(h)), "d2h");
-            if (!h[0]) return false;
-            found_ = true; data_start_ = h[1]; std::memcpy(&cfo_hz_, &h[2], sizeof(float)); sync_offset_ = h[3];
-        }
-        if (rx_.size() < size_t(data_start_) + geo_.frame_samples) return false;
-        detail::DevBuf d_a(ctx_.p, geo_.frame_samples * sizeof(float)), d_c(ctx_.p, sizeof(float)),
-            d_l(ctx_.p, geo_.llrs_per_frame * sizeof(float)), d_s(ctx_.p, ULTRA_HIP_STATE_FLOATS * sizeof(float));
-        detail::check(ultra_hip_memcpy_h2d(ctx_.p, d_a.d, rx_.data() + data_start_, geo_.frame_samples * sizeof(float)), "h2d");
-        detail::check(ultra_hip_memcpy_h2d(ctx_.p, d_c.d, &cfo_hz_, sizeof(float)), "h2d");
-        detail::check(ultra_hip_demod_batch(ctx_.p, static_cast<const float*>(d_a.d), geo_.frame_samples,
-                                            static_cast<const float*>(d_c.d), nullptr, 1, static_cast<float*>(d_l.d),
-                                            static_cast<float*>(d_s.d)), "demod_batch");
-        soft_bits_.resize(geo_.llrs_per_frame);
-        detail::check(ultra_hip_memcpy_d2h(ctx_.p, soft_bits_.data(), d_l.d, geo_.llrs_per_frame * sizeof(float)), "d2h");
-        detail::check(ultra_hip_memcpy_d2h(ctx_.p, state_, d_s.d, sizeof(state_)), "d2h");
-        synced_ = true;
-        return soft_bits_.size() >= 648;
-    }
-    std::vector<float> getSoftBits() {                                    // 648 at a time (demodulator.cpp:766-791)
-        if (soft_bits_.size() <= 648) return std::move(soft_bits_);
-        std::vector<float> out(soft_bits_.begin(), soft_bits_.begin() + 648);
-        soft_bits_.erase(soft_bits_.begin(), soft_bits_.begin() + 648);
-        return out;
+    static ModemConfig defaultConfig() {                                // OFDMNvisWaveform::OFDMNvisWaveform()
+        ModemConfig c; c.fft_size = 512; c.num_carriers = 30; c.modulation = Modulation::QPSK; c.code_rate = CodeRate::R1_2;
+        c.use_pilots = true; return c;
     }
 
+    std::string getName() const { return "OFDM-COX-HIP"; }
+    void configure(Modulation mod, CodeRate rate) {                     // ofdm_cox_waveform.cpp:52-68
+        config_.modulation = mod; config_.code_rate = rate;
+        config_.use_pilots = !(mod == Modulation::DBPSK || mod == Modulation::DQPSK || mod == Modulation::D8PSK);
+        initComponents();
+    }
+    void setFrequencyOffset(float cfo_hz) {                             // :70-75 -> OFDMDemodulator::setFrequencyOffset
+        cfo_hz_ = cfo_hz; freq_offset_hz_ = cfo_hz;
+        if (synced_ && synced_symbols_ > 0) detail::check(ultra_hip_demod_stream_set_cfo(ctx_.p, 0, cfo_hz), "stream_set_cfo");
+        else pending_cfo_ = true;                                       // the next symbol 0 starts from it
+    }
+    Modulation getModulation() const { return config_.modulation; }
+    CodeRate getCodeRate() const { return config_.code_rate; }
+    float getFrequencyOffset() const { return cfo_hz_; }
+
+    // OFDMNvisWaveform::detectSync (:98-120): feed the demodulator, report whether it is synced
+    bool detectSync(SampleSpan samples, SyncResult& result, float /*threshold*/ = 0.3f) {
+        demodProcess(samples);
+        if (!synced_) return false;
+        result.detected = true;
+        result.start_sample = static_cast<int>(last_sync_offset_);
+        result.cfo_hz = freq_offset_hz_;
+        result.snr_estimate = estimatedSNR();
+        result.has_training = true;
+        return true;
+    }
+    bool process(SampleSpan samples) {                                  // :122-134
+        const bool ready = demodProcess(samples);
+        if (ready) soft_bits_ = demodGetSoftBits();
+        return ready;
+    }
+    std::vector<float> getSoftBits() { return std::move(soft_bits_); }
+    void reset() {                                                      // :140-147 -> OFDMDemodulator::reset (:987-1017)
+        synced_ = false; synced_symbols_ = 0; idle_calls_ = 0;
+        rx_.clear(); origin_ = fed_; d_origin_ = fed_; demod_soft_.clear(); soft_bits_.clear();
+        freq_offset_hz_ = 0.0f; pending_cfo_ = false;
+        state_[ULTRA_HIP_STATE_SNR_LINEAR] = 1.0f; state_[ULTRA_HIP_STATE_FREQ_OFFSET_HZ] = 0.0f;
+        restartSearch();
+    }
+    bool isSynced() const { return synced_; }
+    bool hasData() const {                                              // :153-155, OFDMDemodulator::hasPendingData
+        return !soft_bits_.empty() || (synced_ && (!demod_soft_.empty() || fed_ - origin_ >= symbolSamples()));
+    }
+    float estimatedSNR() const { return 10.0f * std::log10(state_[ULTRA_HIP_STATE_SNR_LINEAR]); }
+    float estimatedCFO() const { return freq_offset_hz_; }
+    float coarseCFO() const { return coarse_cfo_; }                     // Impl::estimateCoarseCFO at the last sync
+    size_t getLastSyncOffset() const { return last_sync_offset_; }
+    std::vector<std::complex<float>> getConstellationSymbols() const { return {}; }   // GUI ring: not produced
+
+    std::string getStatusString() const {
+        return "OFDM-COX " + std::to_string(config_.num_carriers) + " carriers (HIP)" + (config_.use_pilots ? " (pilots)" : "");
+    }
+    int getCarrierCount() const { return static_cast<int>(config_.num_carriers); }
+    int getSamplesPerSymbol() const { return static_cast<int>(symbolSamples()); }
+    int getPreambleSamples() const { return 2 * getSamplesPerSymbol(); }
+    int getMinSamplesForFrame() const {                                   // ofdm_cox_waveform.cpp:231-258
+        const int bits_per_symbol = dataCarriers() * bitsPerCarrier();
+        return (2 + (648 + bits_per_symbol - 1) / bits_per_symbol) * getSamplesPerSymbol();
+    }
+    float getThroughput(CodeRate rate) const {                            // :184-220
+        static const float ratio[] = {0.25f, 0.333f, 0.5f, 0.667f, 0.75f, 0.833f, 0.5f};
+        return float(config_.sample_rate) / float(getSamplesPerSymbol()) * float(dataCarriers()) * float(bitsPerCarrier()) *
+               ratio[static_cast<int>(rate) <= 6 ? static_cast<int>(rate) : 2];
+    }
+
+#ifdef ULTRA_HIP_WITH_REFERENCE
+    ultra::protocol::WaveformMode getMode() const override { return ultra::protocol::WaveformMode::OFDM_COX; }
+    WaveformCapabilities getCapabilities() const override {               // :33-50
+        WaveformCapabilities c;
+        c.supports_cfo_correction = true; c.supports_doppler_correction = true; c.requires_pilots = config_.use_pilots;
+        c.supports_differential = true;
+        c.min_snr_db = config_.use_pilots ? 17.0f : 12.0f; c.max_snr_db = 35.0f;
+        c.max_throughput_bps = getThroughput(CodeRate::R3_4);
+        c.preamble_duration_ms = 2.0f * getSamplesPerSymbol() * 1000.0f / config_.sample_rate;
+        return c;
+    }
+    void setTxFrequencyOffset(float cfo_hz) override { config_.tx_cfo_hz = cfo_hz; modulator_ = std::make_unique<ultra::OFDMModulator>(config_); }
+    // the transmit half is not on the hot path: the reference's own modulator (:85-96)
+    Samples generatePreamble() override { return modulator_->generatePreamble(); }
+    Samples modulate(const Bytes& encoded) override {
+        return modulator_->modulate(ultra::ByteSpan(encoded.data(), encoded.size()), config_.modulation);
+    }
+#else
+    void setTxFrequencyOffset(float) {}
+#endif
+
 private:
+    void initComponents() {
+#ifdef ULTRA_HIP_WITH_REFERENCE
+        modulator_ = std::make_unique<ultra::OFDMModulator>(config_);
+#endif
+        d_small_.reset(); d_rx_.reset(); d_llr_.reset();               // they belong to the context that goes away
+        // the longest frame process() will ever see: MAX_SYMBOLS_BEFORE_TIMEOUT + 1 symbols
+        ctx_ = detail::Ctx(to_c_config(config_, ULTRA_ENTRY_SYNCED, kMaxSymbolsBeforeTimeout + 1, 0), device_);
+        detail::check(ultra_hip_get_geometry(ctx_.p, &geo_), "geometry");
+        d_small_ = std::make_unique<detail::DevBuf>(ctx_.p, 32 * sizeof(uint32_t));   // resume[4], found, data_start, cfo, sync offset, state[8], cfo in
+        rx_cap_ = 1u << 16; d_rx_ = std::make_unique<detail::DevBuf>(ctx_.p, rx_cap_ * sizeof(float));
+        d_llr_.reset(); llr_cap_ = 0;
+        synced_ = false; synced_symbols_ = 0; idle_calls_ = 0;
+        rx_.clear(); origin_ = fed_ = d_origin_ = 0; demod_soft_.clear(); soft_bits_.clear(); noise_floor_bits_ = 0;
+        restartSearch();
+    }
+    uint32_t* small() const { return static_cast<uint32_t*>(d_small_->d); }
+    // the search restarts on whatever is still buffered: rx_buffer = [origin_, fed_)
+    void restartSearch() {
+        const uint32_t r[4] = {origin_, fed_, noise_floor_bits_, 0u};
+        detail::check(ultra_hip_memcpy_h2d(ctx_.p, small(), r, sizeof(r)), "h2d");
+    }
+    // sample indices are 32-bit and absolute: long before they run out (6 h of audio) the origin moves to rx_buffer's start
+    void rebase() {
+        uint32_t r[4];
+        detail::check(ultra_hip_memcpy_d2h(ctx_.p, r, small(), sizeof(r)), "d2h");
+        const uint32_t shift = origin_;
+        r[0] -= shift; r[1] -= shift;
+        detail::check(ultra_hip_memcpy_h2d(ctx_.p, small(), r, sizeof(r)), "h2d");
+        fed_ -= shift; origin_ = 0; d_origin_ = 0;
+        if (!rx_.empty()) detail::check(ultra_hip_memcpy_h2d(ctx_.p, d_rx_->d, rx_.data(), rx_.size() * sizeof(float)), "h2d");
+    }
+    void appendSamples(SampleSpan samples) {
+        if (!synced_ && fed_ > (1u << 29)) rebase();
+        rx_.insert(rx_.end(), samples.begin(), samples.end());
+        const size_t need = size_t(fed_ - d_origin_) + samples.size();
+        if (need > rx_cap_ || (d_origin_ < origin_ && size_t(origin_ - d_origin_) > rx_cap_ / 2)) {
+            // grow, or drop the consumed front: the device window restarts at origin_ from the host's copy
+            const size_t live = rx_.size();
+            if (live > rx_cap_ || !d_rx_) { rx_cap_ = std::max<size_t>(2 * live, 1u << 16); d_rx_ = std::make_unique<detail::DevBuf>(ctx_.p, rx_cap_ * sizeof(float)); }
+            d_origin_ = origin_;
+            if (live) detail::check(ultra_hip_memcpy_h2d(ctx_.p, d_rx_->d, rx_.data(), live * sizeof(float)), "h2d");
+        } else if (!samples.empty()) {
+            detail::check(ultra_hip_memcpy_h2d(ctx_.p, static_cast<float*>(d_rx_->d) + (fed_ - d_origin_), samples.data(),
+                                               samples.size() * sizeof(float)), "h2d");
+        }
+        fed_ += static_cast<uint32_t>(samples.size());
+    }
+    void consumeTo(uint32_t abs_index) {                                 // rx_buffer.erase(begin, begin + n)
+        rx_.erase(rx_.begin(), rx_.begin() + (abs_index - origin_));
+        origin_ = abs_index;
+    }
+    void toSearching() { synced_ = false; synced_symbols_ = 0; idle_calls_ = 0; restartSearch(); }
+
+    // OFDMDemodulator::process
+    bool demodProcess(SampleSpan samples) {
+        appendSamples(samples);
+        if (!synced_) {
+            uint32_t* w = small();
+            detail::check(ultra_hip_acquire_stream_batch(ctx_.p, static_cast<const float*>(d_rx_->d), rx_cap_, d_origin_, fed_, 1,
+                                                         w, w + 4, w + 5, reinterpret_cast<float*>(w + 6), w + 7), "acquire_stream");
+            uint32_t h[8];
+            detail::check(ultra_hip_memcpy_d2h(ctx_.p, h, w, sizeof(h)), "d2h");
+            noise_floor_bits_ = h[2];
+            if (h[4]) {                                                  // SEARCHING -> SYNCED (:533-591)
+                std::memcpy(&coarse_cfo_, &h[6], sizeof(float));
+                freq_offset_hz_ = coarse_cfo_; last_sync_offset_ = h[7];
+                consumeTo(h[5]);
+                synced_ = true; synced_symbols_ = 0; pending_cfo_ = false;
+            } else if (h[0] > origin_) {
+                consumeTo(h[0]);                                         // what the search trimmed off the buffer
+            }
+        }
+        if (!synced_) return false;
+        const uint32_t sym = symbolSamples();
+        uint32_t n_new = (fed_ - origin_) / sym;
+        const uint32_t room = uint32_t(kMaxSymbolsBeforeTimeout + 1) - synced_symbols_;
+        if (n_new > room) n_new = room;
+        const size_t soft_before = demod_soft_.size();
+        if (n_new > 0) {
+            const size_t n_llr = size_t(n_new) * geo_.llrs_per_symbol;
+            if (n_llr > llr_cap_) { llr_cap_ = std::max<size_t>(2 * n_llr, 4096); d_llr_ = std::make_unique<detail::DevBuf>(ctx_.p, llr_cap_ * sizeof(float)); }
+            float* d_state = reinterpret_cast<float*>(small() + 8);
+            float* d_cfo = reinterpret_cast<float*>(small() + 16);
+            const float cfo0 = pending_cfo_ ? cfo_hz_ : coarse_cfo_;
+            if (synced_symbols_ == 0) detail::check(ultra_hip_memcpy_h2d(ctx_.p, d_cfo, &cfo0, sizeof(float)), "h2d");
+            detail::check(ultra_hip_demod_stream_batch(ctx_.p, static_cast<const float*>(d_rx_->d) + (origin_ - d_origin_),
+                                                       size_t(n_new) * sym, d_cfo, nullptr, 1, synced_symbols_, n_new,
+                                                       static_cast<float*>(d_llr_->d), d_state), "demod_stream");
+            const size_t at = demod_soft_.size();
+            demod_soft_.resize(at + n_llr);
+            detail::check(ultra_hip_memcpy_d2h(ctx_.p, demod_soft_.data() + at, d_llr_->d, n_llr * sizeof(float)), "d2h");
+            detail::check(ultra_hip_memcpy_d2h(ctx_.p, state_, d_state, sizeof(state_)), "d2h");
+            freq_offset_hz_ = state_[ULTRA_HIP_STATE_FREQ_OFFSET_HZ];
+            consumeTo(origin_ + n_new * sym);
+            synced_symbols_ += n_new; pending_cfo_ = false;
+            if (synced_symbols_ > uint32_t(kMaxSymbolsBeforeTimeout)) {   // sync timeout (:683-691)
+                toSearching();
+                return demod_soft_.size() >= 648;
+            }
+        }
+        if (demod_soft_.size() == soft_before) {                         // idle calls (:704-716)
+            if (++idle_calls_ > kMaxIdleCallsBeforeReset) { toSearching(); return demod_soft_.size() >= 648; }
+        } else {
+            idle_calls_ = 0;
+        }
+        const bool has_codeword = demod_soft_.size() >= 648;
+        if (!has_codeword && synced_symbols_ > 0 && samples.empty() && n_new == 0) {   // frame complete (:720-731)
+            toSearching();
+            demod_soft_.clear();
+        }
+        return has_codeword;
+    }
+    std::vector<float> demodGetSoftBits() {                              // 648 at a time (demodulator.cpp:766-791)
+        if (demod_soft_.size() <= 648) { std::vector<float> out = std::move(demod_soft_); demod_soft_.clear(); return out; }
+        std::vector<float> out(demod_soft_.begin(), demod_soft_.begin() + 648);
+        demod_soft_.erase(demod_soft_.begin(), demod_soft_.begin() + 648);
+        return out;
+    }
+    uint32_t symbolSamples() const { return geo_.symbol_samples; }
+    int dataCarriers() const {
+        int d = static_cast<int>(config_.num_carriers);
+        if (config_.use_pilots && config_.pilot_spacing > 0) d -= config_.num_carriers / config_.pilot_spacing;
+        return d;
+    }
+    int bitsPerCarrier() const {
+        static const int bpc[] = {1, 1, 2, 2, 3, 3, 4, 5, 6, 2, 2};
+        const int m = static_cast<int>(config_.modulation);
+        return bpc[m <= 10 ? m : 3];
+    }
+
     ModemConfig config_;
+    int device_;
     detail::Ctx ctx_;
     ultra_hip_geometry geo_{};
-    std::vector<float> rx_, soft_bits_;
-    uint32_t chunk_ = 0, data_start_ = 0, sync_offset_ = 0;
-    float cfo_hz_ = 0.0f;
-    bool synced_ = false, found_ = false;
+#ifdef ULTRA_HIP_WITH_REFERENCE
+    std::unique_ptr<ultra::OFDMModulator> modulator_;
+#endif
+    std::unique_ptr<detail::DevBuf> d_small_, d_rx_, d_llr_;
+    size_t rx_cap_ = 0, llr_cap_ = 0;
+    std::vector<float> rx_;                  // rx_buffer = samples [origin_, fed_)
+    uint32_t origin_ = 0, fed_ = 0, d_origin_ = 0;   // d_rx_[0] holds sample d_origin_ <= origin_
+    uint32_t noise_floor_bits_ = 0, last_sync_offset_ = 0, synced_symbols_ = 0;
+    int idle_calls_ = 0;
+    bool synced_ = false, pending_cfo_ = false;
+    float cfo_hz_ = 0.0f, coarse_cfo_ = 0.0f, freq_offset_hz_ = 0.0f;
+    std::vector<float> demod_soft_, soft_bits_;
     float state_[ULTRA_HIP_STATE_FLOATS] = {0, 0, 1, 0, 0, 0, 0, 0};
 };
 

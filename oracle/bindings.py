@@ -461,6 +461,21 @@ class Ref(_Base):
                                               C.byref(fs))
         return llr[:n].copy(), so.value, cc.value, fc.value, fs.value
 
+    def demod_stream(self, cfg, audio, chunks):
+        """A live stream through OFDMDemodulator::process + getSoftBits, one call per entry of `chunks` (sample counts,
+        0 = an empty call) → (ready [n_calls] u8, synced [n_calls] u8, drained [n_calls] u32, soft bits concatenated)."""
+        audio = _f32(audio)
+        chunks = np.ascontiguousarray(chunks, np.uint32)
+        assert int(chunks.sum()) <= audio.size
+        n = chunks.size
+        ready = np.zeros(n, np.uint8); synced = np.zeros(n, np.uint8); drained = np.zeros(n, np.uint32)
+        cap = 1 << 18
+        soft = np.zeros(cap, np.float32)
+        total = self.lib.ref_demod_stream(C.byref(cfg), _ptr(audio), _ptr(chunks, C.c_uint32), C.c_uint32(n), _ptr(ready, C.c_uint8),
+                                          _ptr(synced, C.c_uint8), _ptr(drained, C.c_uint32), _ptr(soft), C.c_uint32(cap))
+        assert 0 <= total <= cap
+        return ready, synced, drained, soft[:total].copy()
+
     def demod_decode_batch(self, cfg, audio, cfo_hz=None):
         """The reference's own classes over SYNCED-entry frames, one thread → dict(bytes, iters, ok)."""
         audio = _f32(audio)

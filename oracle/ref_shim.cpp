@@ -304,6 +304,33 @@ int ref_demod_process_coarse(const ultra_hip_config* c, const float* audio, uint
     return (int)sb.size();
 }
 
+// A LIVE stream through the reference's Schmidl-Cox waveform, call by call: what OFDMNvisWaveform::process
+// (src/waveform/ofdm_cox_waveform.cpp:122-134) does — demodulator.process(chunk); when it reports a codeword,
+// getSoftBits() hands out 648 soft bits — for a list of chunk lengths (0 = an empty call).  Records per call the
+// return value, isSynced() afterwards and how many soft bits were handed out; the soft bits are concatenated.
+// Exercises the ways out of SYNCED (timeout, idle calls, frame complete: demodulator.cpp:683-732) and re-acquisition.
+int ref_demod_stream(const ultra_hip_config* c, const float* audio, const uint32_t* chunks, uint32_t n_calls,
+                     uint8_t* ready_out, uint8_t* synced_out, uint32_t* drained_out, float* soft_out, uint32_t cap) {
+    StderrMute mute;
+    ModemConfig cfg = to_cfg(c);
+    OFDMDemodulator demod(cfg);
+    size_t pos = 0, total = 0;
+    for (uint32_t i = 0; i < n_calls; ++i) {
+        const bool ready = demod.process(SampleSpan(audio + pos, chunks[i]));
+        pos += chunks[i];
+        uint32_t drained = 0;
+        if (ready) {
+            std::vector<float> sb = demod.getSoftBits();
+            drained = (uint32_t)sb.size();
+            for (float v : sb) { if (total < cap) soft_out[total] = v; ++total; }
+        }
+        ready_out[i] = ready ? 1 : 0;
+        synced_out[i] = demod.isSynced() ? 1 : 0;
+        drained_out[i] = drained;
+    }
+    return (int)total;
+}
+
 // Acquisition (scope row f1): OFDMDemodulator::process in the SEARCHING state, fed in `chunk`-sample
 // calls (src/ofdm/demodulator.cpp:461-600).  Reports, per stream: whether sync was declared, after how
 // many fed samples, the Schmidl-Cox offset (last_sync_offset, relative to the buffer at that call), the

@@ -17,7 +17,7 @@ PKG_DIR = Path(__file__).resolve().parent
 LIB_PATH = Path(os.environ["ULTRA_HIP_LIB"]).resolve() if os.environ.get("ULTRA_HIP_LIB") else PKG_DIR / "libultra_hip.so"
 CSRC_DIR = PKG_DIR / "csrc"
 
-ULTRA_HIP_ABI_VERSION = 4
+ULTRA_HIP_ABI_VERSION = 5
 STATE_FLOATS = 8
 
 
@@ -65,6 +65,9 @@ PROTOTYPES = {
     "ultra_hip_get_tanner_graph": (_i, [_vp, _u32p, _u32p]),
     "ultra_hip_ldpc_decode_batch": (_i, [_vp, _vp, _sz, _vp, _vp, _vp, _vp]),
     "ultra_hip_demod_batch": (_i, [_vp, _vp, _sz, _vp, _vp, _sz, _vp, _vp]),
+    "ultra_hip_demod_stream_batch": (_i, [_vp, _vp, _sz, _vp, _vp, _sz, C.c_uint32, C.c_uint32, _vp, _vp]),
+    "ultra_hip_demod_stream_set_cfo": (_i, [_vp, _sz, C.c_float]),
+    "ultra_hip_acquire_stream_batch": (_i, [_vp, _vp, _sz, C.c_uint32, C.c_uint32, _sz, _vp, _vp, _vp, _vp, _vp]),
     "ultra_hip_demod_decode_batch": (_i, [_vp, _vp, _sz, _vp, _vp, _sz, _vp, _vp, _vp, _vp]),
     "ultra_hip_count_errors": (_i, [_vp, _vp, _vp, _vp, _vp, _sz, _sz, _vp]),
     "ultra_hip_reserve": (_i, [_vp, _sz]),

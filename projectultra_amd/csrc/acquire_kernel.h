@@ -407,7 +407,12 @@ __global__ __launch_bounds__(kWave, (LOG2N == 10) ? 3 : 4) void acquire_kernel(
     const float* __restrict__ lts_Q, float energy_ref, float sync_threshold, const float* __restrict__ audio,
     size_t stream_stride, unsigned n_samples, unsigned chunk, int n_streams, unsigned* __restrict__ found_out,
     unsigned* __restrict__ data_start_out, float* __restrict__ cfo_out, unsigned* __restrict__ sync_offset_out,
-    unsigned* __restrict__ fed_out) {
+    unsigned* __restrict__ fed_out, unsigned origin, unsigned* __restrict__ resume) {
+    // origin / resume (ultra_hip_acquire_stream_batch): the search of a LIVE stream, one process() call per launch.
+    // Sample index i of stream s lives at audio[s * stream_stride + i - origin] (the caller keeps only the part the
+    // search can still look at), and resume[s] = {base, fed, noise floor, -} is what OFDMDemodulator::Impl carries
+    // from one process() call to the next in the SEARCHING state: where rx_buffer starts, how much was fed, and the
+    // energy gate's noise floor — the only state of the search (everything else is recomputed from the samples).
     constexpr int N = 1 << LOG2N;
     constexpr bool kCalls = (LOG2N == 10);                   // phases as out-of-line functions, see above
     __shared__ AcqShared<LOG2N> sh;
@@ -431,9 +436,10 @@ __global__ __launch_bounds__(kWave, (LOG2N == 10) ? 3 : 4) void acquire_kernel(
     const unsigned psl = (unsigned)(N + D.cp), preamble_total = psl * 6u, corr_win = psl * 2u;
     const int gate_count = (int)((corr_win + 15u) / 16u);    // i = 0, 16, .. < window_len
     for (int stream = blockIdx.x; stream < n_streams; stream += gridDim.x) {
-        const float* all = audio + (size_t)stream * stream_stride;
+        const float* all = audio + (size_t)stream * stream_stride - origin;
         unsigned base = 0, fed = 0, found = 0, so_out = 0, ds_out = 0, fed_at = 0;
         float cfo = 0.0f, noise_floor = 0.0f;
+        if (resume) { base = resume[4 * stream]; fed = resume[4 * stream + 1]; noise_floor = __uint_as_float(resume[4 * stream + 2]); }
         unsigned gate_first = 0xffffffffu;                    // window start of lane 0 of the current energy-gate group
         float gate_sum = 0.0f;                                // lane g: sum of squares of the gate window at gate_first + 8 g
         unsigned grp_first = 0xffffffffu;                     // window start of lane 0 of the current DC group
@@ -555,6 +561,7 @@ __global__ __launch_bounds__(kWave, (LOG2N == 10) ? 3 : 4) void acquire_kernel(
                 base += size - kAcqOverlap;
             }
         }
+        if (lane == 0 && resume) { resume[4 * stream] = base; resume[4 * stream + 1] = fed; resume[4 * stream + 2] = __float_as_uint(noise_floor); }
         if (lane == 0) {
             found_out[stream] = found;
             data_start_out[stream] = ds_out;

@@ -1659,7 +1659,7 @@ __global__ __launch_bounds__(kWave, 6) void track_all_kernel(const DemodConst* _
         finish_channel_estimate(sh, D, lc, tr);
         equalize_demap<MOD>(sh, D, lc, tr, dprev, fq_all + (size_t)w * 128,
                             llr + (size_t)frame * llr_stride + (size_t)(sym0 + ds) * D.llrs_per_symbol);
-        if (state_out && lane == 0 && sym0 + ds == D.n_data_sym - 1) {
+        if (state_out && lane == 0 && ds == n_sym_batch - 1) {   // the tracker after the last symbol of the launch
             float* so = state_out + (size_t)frame * ULTRA_HIP_STATE_FLOATS;
             so[ULTRA_HIP_STATE_FREQ_OFFSET_HZ] = rec[tk_cfo];
             so[ULTRA_HIP_STATE_NOISE_VARIANCE] = rec[tk_noise];

@@ -94,7 +94,8 @@ inline int validate_config(const ultra_hip_config& c) {
     if (c.fft_size + 64 * (c.fft_size / 512) + c.symbol_guard > 1280) return ULTRA_HIP_ERR_UNSUPPORTED;
     if (c.code_rate > ULTRA_RATE_R5_6) return ULTRA_HIP_ERR_UNSUPPORTED;  // R7/8 has no code in the reference either
     if (c.entry > ULTRA_ENTRY_PRESYNCED) return ULTRA_HIP_ERR_INVALID_ARG;
-    if (c.n_data_symbols == 0 || c.n_data_symbols > 250) return ULTRA_HIP_ERR_INVALID_ARG;  // MAX_SYMBOLS_BEFORE_TIMEOUT
+    // MAX_SYMBOLS_BEFORE_TIMEOUT = 250: process() gives up after the 251st symbol of a frame (demodulator.cpp:683-691)
+    if (c.n_data_symbols == 0 || c.n_data_symbols > 251) return ULTRA_HIP_ERR_INVALID_ARG;
     if (c.entry == ULTRA_ENTRY_PRESYNCED && c.training_symbols > 8) return ULTRA_HIP_ERR_INVALID_ARG;
     if (c.max_iterations > 1000) return ULTRA_HIP_ERR_INVALID_ARG;
     return ULTRA_HIP_OK;

@@ -78,6 +78,7 @@ struct ultra_hip_ctx {
     uint32_t deint_step = 1;             // ChannelInterleaver step fused into the LDPC LLR load (1 = off)
     uint16_t* d_deint_table = nullptr;   // general gather table of the fused deinterleave (nullptr = use the step)
     bool mix_one_wave = false;           // ULTRA_HIP_MIXFFT_ONE_WAVE=1: the one-wavefront-per-frame mix_fft_kernel<10> (A/B runs)
+    bool stream_cfo_given = false;       // launch_demod: whether the frame in flight started with caller-supplied offsets
     bool old_chain = false;              // ULTRA_HIP_OLD_CHAIN=1: track_pilot_kernel + track_kernel per symbol for every layout (A/B runs)
     float* d_ws_trk = nullptr;           // deferred carrier half: one record per (symbol, frame) from track_pilot_kernel to track_all_kernel
     size_t ws_trk_rows = 0;
@@ -175,9 +176,17 @@ int ensure_llr_workspace(ultra_hip_ctx* ctx, size_t n_frames) {
 
 int launch_demod(ultra_hip_ctx* ctx, const float* d_audio, size_t frame_stride, const float* d_cfo_hz,
                  const float* d_cfo_phase, size_t n_frames, float* d_llr, size_t llr_stride, float* d_state,
-                 const unsigned* d_frame_offset = nullptr) {
+                 const unsigned* d_frame_offset = nullptr, int sym_begin = 0, int sym_count = -1) {
+    // sym_begin / sym_count (ultra_hip_demod_stream_batch): symbols [sym_begin, sym_begin + sym_count) of every frame,
+    // continuing from the tracker records the previous call left in the context's workspace (sym_begin > 0: no
+    // initialisation; d_audio and d_llr then address the frame as if it were complete — the caller shifts its pointers)
     if (n_frames == 0) return ULTRA_HIP_OK;
     const DemodConst& D = ctx->h_demod;
+    const int s_begin = sym_begin, s_end = (sym_count < 0) ? D.n_train + D.n_data_sym : sym_begin + sym_count;
+    if (s_begin < 0 || s_end > D.n_train + D.n_data_sym || s_end <= s_begin) return ULTRA_HIP_ERR_INVALID_ARG;
+    if (s_begin > 0 && ctx->ws_demod_frames < n_frames) return ULTRA_HIP_ERR_INVALID_ARG;      // nothing to continue from
+    const bool cfo_given = (s_begin == 0) ? d_cfo_hz != nullptr : ctx->stream_cfo_given;
+    if (s_begin == 0) ctx->stream_cfo_given = cfo_given;
     { const int rc_ws = ensure_demod_workspace(ctx, n_frames); if (rc_ws != ULTRA_HIP_OK) return rc_ws; }
     // one wavefront per frame in every kernel; grids are capped (grid-stride over frames) so a huge
     // batch stays one launch per stage and per-workgroup constants are loaded once
@@ -189,23 +198,23 @@ int launch_demod(ultra_hip_ctx* ctx, const float* d_audio, size_t frame_stride, 
     const unsigned grid_trk = (unsigned)std::min(n_frames, (size_t)ctx->cu_count * 128);
     hipStream_t st = ctx->stream;
     if (D.log2_fft != 10 && D.log2_fft != 9) return ULTRA_HIP_ERR_UNSUPPORTED;
-    {
+    if (s_begin == 0) {
         LaunchSpan span(ctx, ULTRA_HIP_K_INIT_STATE);
         // compact pilot state (demod_kernel.h, kStHp) and no training symbols that read the full H array first
         const int compact = (!D.differential && D.n_pilot > 0 && D.n_train == 0) ? 1 : 0;
         hipLaunchKernelGGL(dev::init_state_kernel, dim3(grid_trk), dim3(dev::kWave), 0, st, d_cfo_hz, d_cfo_phase,
                            (int)n_frames, ctx->d_ws_state, compact);
     }
-    if (D.presynced && d_cfo_hz) {
+    if (s_begin == 0 && D.presynced && d_cfo_hz) {
         // frames whose initial CFO is NaN ("never set"): estimateCFOFromTraining, demodulator.cpp:920-925
         LaunchSpan span(ctx, ULTRA_HIP_K_INIT_STATE);
         hipLaunchKernelGGL(dev::train_cfo_kernel, dim3((unsigned)((n_frames + 255) / 256)), dim3(256), 0, st, ctx->d_demod, ctx->d_nco,
                            d_audio, frame_stride, d_frame_offset, d_cfo_hz, (int)n_frames, ctx->d_ws_state);
     }
-    const int n_sym = D.n_train + D.n_data_sym;
+    const int n_sym = s_end - s_begin;
     // No pilots, SYNCED entry, no initial offsets: nothing on the path ever estimates a CFO (that is the pilot half's job),
     // it is 0 for every frame and every symbol, mix_fft_kernel never rotates — no phase tables to walk.
-    const bool cfo_is_zero = !D.presynced && D.n_pilot == 0 && d_cfo_hz == nullptr;
+    const bool cfo_is_zero = !D.presynced && D.n_pilot == 0 && !cfo_given;
     const unsigned* seg_tab = cfo_is_zero ? nullptr : ctx->d_ws_seg;
     // ... and no symbol's transform depends on the symbol before it: ALL symbols of all frames in one launch (a grid of
     // n_frames * n_sym items instead of n_sym launches that each ramp up and drain), bins to one Fq row per frame and symbol
@@ -227,19 +236,19 @@ int launch_demod(ultra_hip_ctx* ctx, const float* d_audio, size_t frame_stride, 
         const unsigned g = (unsigned)std::min(n_frames * (size_t)n_sym, (size_t)ctx->cu_count * 128);
         if (D.log2_fft == 10 && !ctx->mix_one_wave)
             hipLaunchKernelGGL(dev::mix_fft2_kernel<10>, dim3(g), dim3(2 * dev::kWave), 0, st, ctx->d_demod, ctx->d_nco, ctx->d_twiddle,
-                               d_audio, frame_stride, d_frame_offset, (int)n_frames, 0, ctx->d_ws_fq, seg_tab, n_sym);
+                               d_audio, frame_stride, d_frame_offset, (int)n_frames, s_begin, ctx->d_ws_fq, seg_tab, n_sym);
         else if (D.log2_fft == 10)
             hipLaunchKernelGGL(dev::mix_fft_kernel<10>, dim3(g), dim3(dev::kWave), 0, st, ctx->d_demod, ctx->d_nco, ctx->d_twiddle,
-                               d_audio, frame_stride, d_frame_offset, (int)n_frames, 0, ctx->d_ws_fq, seg_tab, n_sym);
+                               d_audio, frame_stride, d_frame_offset, (int)n_frames, s_begin, ctx->d_ws_fq, seg_tab, n_sym);
         else
             hipLaunchKernelGGL(dev::mix_fft_kernel<9>, dim3(g), dim3(dev::kWave), 0, st, ctx->d_demod, ctx->d_nco, ctx->d_twiddle,
-                               d_audio, frame_stride, d_frame_offset, (int)n_frames, 0, ctx->d_ws_fq, seg_tab, n_sym);
+                               d_audio, frame_stride, d_frame_offset, (int)n_frames, s_begin, ctx->d_ws_fq, seg_tab, n_sym);
     }
-    for (int s = 0; s < n_sym; ++s) {
-        c32* fq_s = ctx->d_ws_fq + ((all_symbols_at_once || deferred) ? (size_t)s * n_frames * 128 : (size_t)0);
-        float* rec_s = deferred ? ctx->d_ws_trk + (size_t)s * n_frames * dev::kTrkRecFloats : nullptr;
+    for (int s = s_begin; s < s_end; ++s) {
+        c32* fq_s = ctx->d_ws_fq + ((all_symbols_at_once || deferred) ? (size_t)(s - s_begin) * n_frames * 128 : (size_t)0);
+        float* rec_s = deferred ? ctx->d_ws_trk + (size_t)(s - s_begin) * n_frames * dev::kTrkRecFloats : nullptr;
         // the first symbol of a SYNCED batch without initial offsets is at CFO 0 in every frame: nothing to walk yet
-        const bool first_at_zero = s == 0 && !D.presynced && d_cfo_hz == nullptr;
+        const bool first_at_zero = s == 0 && !D.presynced && !cfo_given;
         const unsigned* seg_tab_s = first_at_zero ? nullptr : seg_tab;
         if (!cfo_is_zero && !first_at_zero) {
             LaunchSpan span(ctx, ULTRA_HIP_K_WALK);
@@ -262,7 +271,7 @@ int launch_demod(ultra_hip_ctx* ctx, const float* d_audio, size_t frame_stride, 
                                    fq_s, seg_tab_s, 1);
         }
         const bool training = s < D.n_train;
-        const bool last = (s == n_sym - 1);
+        const bool last = (s == s_end - 1);
         if (training) {
             LaunchSpan span(ctx, ULTRA_HIP_K_TRACK);
             hipLaunchKernelGGL(dev::train_kernel, dim3(grid_trk), dim3(dev::kWave), 0, st, ctx->d_demod, (int)n_frames, s,
@@ -289,7 +298,7 @@ int launch_demod(ultra_hip_ctx* ctx, const float* d_audio, size_t frame_stride, 
             LaunchSpan span(ctx, ULTRA_HIP_K_TRACK);
             const unsigned g = (unsigned)std::min(n_frames * (size_t)n_sym, (size_t)ctx->cu_count * 128);
 #define UH_TRACK_ALL(MOD)                                                                                                  \
-    hipLaunchKernelGGL(dev::track_all_kernel<MOD>, dim3(g), dim3(dev::kWave), 0, st, ctx->d_demod, (int)n_frames, 0, n_sym, \
+    hipLaunchKernelGGL(dev::track_all_kernel<MOD>, dim3(g), dim3(dev::kWave), 0, st, ctx->d_demod, (int)n_frames, s_begin, n_sym, \
                        ctx->d_ws_trk, ctx->d_ws_fq, d_llr, llr_stride, d_state)
             switch (D.modulation) {
                 case ULTRA_MOD_BPSK: UH_TRACK_ALL(ULTRA_MOD_BPSK); break;
@@ -305,7 +314,7 @@ int launch_demod(ultra_hip_ctx* ctx, const float* d_audio, size_t frame_stride, 
         }
         // zero-CFO layouts: every symbol's bins are there already — one launch walks all data symbols of a frame
         // (n_train == 0 for the SYNCED entry, so s == 0 here and the launch covers symbols 0 .. n_sym - 1)
-        const int track_batch = all_symbols_at_once ? n_sym - s : 1;
+        const int track_batch = all_symbols_at_once ? s_end - s : 1;
         const bool last_launch = last || all_symbols_at_once;
 #define UH_TRACK(MOD)                                                                                            \
     hipLaunchKernelGGL(dev::track_kernel<MOD>, dim3(grid_trk), dim3(dev::kWave), 0, st, ctx->d_demod, (int)n_frames,  \
@@ -703,6 +712,38 @@ int ultra_hip_demod_batch(ultra_hip_ctx* ctx, const float* d_audio, size_t frame
                         ctx->geo.llrs_per_frame, d_state);
 }
 
+int ultra_hip_demod_stream_batch(ultra_hip_ctx* ctx, const float* d_audio, size_t frame_stride, const float* d_cfo_hz,
+                                 const float* d_cfo_phase, size_t n_frames, uint32_t first_symbol, uint32_t n_symbols,
+                                 float* d_llr, float* d_state) {
+    if (!ctx) return ULTRA_HIP_ERR_INVALID_ARG;
+    if (n_frames == 0 || n_symbols == 0) return ULTRA_HIP_OK;
+    const DemodConst& D = ctx->h_demod;
+    const uint32_t total = (uint32_t)(D.n_train + D.n_data_sym);
+    if (!d_audio || !d_llr || n_frames > 0x7fffffffull || first_symbol >= total || n_symbols > total - first_symbol ||
+        frame_stride < (size_t)n_symbols * (size_t)D.sym_len)
+        return ULTRA_HIP_ERR_INVALID_ARG;
+    if (D.n_train != 0 && first_symbol != 0 && first_symbol < (uint32_t)D.n_train) return ULTRA_HIP_ERR_INVALID_ARG;
+    DeviceGuard guard(ctx->device);
+    // the kernels address symbol s of a frame at row + s * sym_len and its LLRs at row + (s - n_train) * llrs_per_symbol
+    const uint32_t first_data = first_symbol > (uint32_t)D.n_train ? first_symbol - (uint32_t)D.n_train : 0u;
+    const uint32_t data_in_call = first_symbol + n_symbols > (uint32_t)D.n_train ? first_symbol + n_symbols - (uint32_t)D.n_train - first_data : 0u;
+    const float* audio0 = d_audio - (size_t)first_symbol * (size_t)D.sym_len;
+    float* llr0 = d_llr - (size_t)first_data * (size_t)D.llrs_per_symbol;
+    return launch_demod(ctx, audio0, frame_stride, d_cfo_hz, d_cfo_phase, n_frames, llr0,
+                        (size_t)data_in_call * (size_t)D.llrs_per_symbol, d_state, nullptr, (int)first_symbol, (int)n_symbols);
+}
+
+int ultra_hip_demod_stream_set_cfo(ultra_hip_ctx* ctx, size_t frame, float cfo_hz) {
+    if (!ctx || frame >= ctx->ws_demod_frames) return ULTRA_HIP_ERR_INVALID_ARG;
+    DeviceGuard guard(ctx->device);
+    // OFDMDemodulator::setFrequencyOffset (demodulator.cpp:805-815): freq_offset_hz = filtered = cfo, correction phase 0
+    const float v[3] = {cfo_hz, cfo_hz, 0.0f};
+    static_assert(dev::st_cfo == 0 && dev::st_cfo_filt == 1 && dev::st_cfo_phase == 2, "record layout");
+    UH_HIP(hipMemcpyAsync(ctx->d_ws_state + frame * (size_t)dev::kStFloats, v, sizeof(v), hipMemcpyHostToDevice, ctx->stream));
+    UH_HIP(hipStreamSynchronize(ctx->stream));
+    return ULTRA_HIP_OK;
+}
+
 int ultra_hip_demod_decode_batch(ultra_hip_ctx* ctx, const float* d_audio, size_t frame_stride,
                                  const float* d_cfo_hz, const float* d_cfo_phase, size_t n_frames, float* d_llr,
                                  uint8_t* d_bytes, int32_t* d_iters, uint8_t* d_ok) {
@@ -726,15 +767,10 @@ int ultra_hip_demod_decode_batch(ultra_hip_ctx* ctx, const float* d_audio, size_
     return launch_ldpc(ctx, llr, ctx->geo.llrs_per_frame, n_frames, d_bytes, d_iters, d_ok, nullptr);
 }
 
-int ultra_hip_acquire_batch(ultra_hip_ctx* ctx, const float* d_audio, size_t stream_stride, uint32_t n_samples,
-                            uint32_t chunk, size_t n_streams, uint32_t* d_found, uint32_t* d_data_start,
-                            float* d_cfo_hz, uint32_t* d_sync_offset, uint32_t* d_fed_at_sync) {
-    if (!ctx) return ULTRA_HIP_ERR_INVALID_ARG;
-    if (n_streams == 0) return ULTRA_HIP_OK;
-    if (!d_audio || !d_found || !d_data_start || !d_cfo_hz || chunk == 0 || stream_stride < n_samples ||
-        n_streams > 0x7fffffffull || n_samples > 0x3fffffffu)
-        return ULTRA_HIP_ERR_INVALID_ARG;
-    DeviceGuard guard(ctx->device);
+namespace {
+int launch_acquire(ultra_hip_ctx* ctx, const float* d_audio, size_t stream_stride, uint32_t n_samples, uint32_t chunk,
+                   size_t n_streams, uint32_t* d_found, uint32_t* d_data_start, float* d_cfo_hz, uint32_t* d_sync_offset,
+                   uint32_t* d_fed_at_sync, uint32_t origin, uint32_t* d_resume) {
     const unsigned grid = (unsigned)std::min(n_streams, (size_t)ctx->cu_count * 64);
     LaunchSpan span(ctx, ULTRA_HIP_K_ACQUIRE);
     const float* lts_I = ctx->d_lts;
@@ -744,16 +780,44 @@ int ultra_hip_acquire_batch(ultra_hip_ctx* ctx, const float* d_audio, size_t str
         hipLaunchKernelGGL(dev::acquire_kernel<10>, dim3(grid), dim3(dev::kWave), 0, ctx->stream, ctx->d_demod,
                            ctx->d_twiddle, lts_I, lts_Q, ctx->lts_energy_ref, sync_threshold, d_audio, stream_stride,
                            n_samples, chunk, (int)n_streams, d_found, d_data_start, d_cfo_hz, d_sync_offset,
-                           d_fed_at_sync);
+                           d_fed_at_sync, origin, d_resume);
     else if (ctx->h_demod.log2_fft == 9)
         hipLaunchKernelGGL(dev::acquire_kernel<9>, dim3(grid), dim3(dev::kWave), 0, ctx->stream, ctx->d_demod,
                            ctx->d_twiddle, lts_I, lts_Q, ctx->lts_energy_ref, sync_threshold, d_audio, stream_stride,
                            n_samples, chunk, (int)n_streams, d_found, d_data_start, d_cfo_hz, d_sync_offset,
-                           d_fed_at_sync);
+                           d_fed_at_sync, origin, d_resume);
     else
         return ULTRA_HIP_ERR_UNSUPPORTED;
     UH_HIP(hipGetLastError());
     return ULTRA_HIP_OK;
+}
+}  // namespace
+
+int ultra_hip_acquire_batch(ultra_hip_ctx* ctx, const float* d_audio, size_t stream_stride, uint32_t n_samples,
+                            uint32_t chunk, size_t n_streams, uint32_t* d_found, uint32_t* d_data_start,
+                            float* d_cfo_hz, uint32_t* d_sync_offset, uint32_t* d_fed_at_sync) {
+    if (!ctx) return ULTRA_HIP_ERR_INVALID_ARG;
+    if (n_streams == 0) return ULTRA_HIP_OK;
+    if (!d_audio || !d_found || !d_data_start || !d_cfo_hz || chunk == 0 || stream_stride < n_samples ||
+        n_streams > 0x7fffffffull || n_samples > 0x3fffffffu)
+        return ULTRA_HIP_ERR_INVALID_ARG;
+    DeviceGuard guard(ctx->device);
+    return launch_acquire(ctx, d_audio, stream_stride, n_samples, chunk, n_streams, d_found, d_data_start, d_cfo_hz,
+                          d_sync_offset, d_fed_at_sync, 0u, nullptr);
+}
+
+int ultra_hip_acquire_stream_batch(ultra_hip_ctx* ctx, const float* d_audio, size_t stream_stride, uint32_t origin,
+                                   uint32_t n_samples, size_t n_streams, uint32_t* d_resume, uint32_t* d_found,
+                                   uint32_t* d_data_start, float* d_cfo_hz, uint32_t* d_sync_offset) {
+    if (!ctx) return ULTRA_HIP_ERR_INVALID_ARG;
+    if (n_streams == 0) return ULTRA_HIP_OK;
+    if (!d_audio || !d_resume || !d_found || !d_data_start || !d_cfo_hz || n_samples < origin ||
+        stream_stride < (size_t)(n_samples - origin) || n_streams > 0x7fffffffull || n_samples > 0x3fffffffu)
+        return ULTRA_HIP_ERR_INVALID_ARG;
+    DeviceGuard guard(ctx->device);
+    // one process() call: everything fed since the last launch is one chunk
+    return launch_acquire(ctx, d_audio, stream_stride, n_samples, 0xffffffffu, n_streams, d_found, d_data_start, d_cfo_hz,
+                          d_sync_offset, nullptr, origin, d_resume);
 }
 
 int ultra_hip_receive_batch(ultra_hip_ctx* ctx, const float* d_audio, size_t stream_stride, uint32_t n_samples,

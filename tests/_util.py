@@ -195,3 +195,39 @@ def valid_special_codewords(rng, oracle, rate, n=48):
             j = int(rng.integers(0, 648))
             llr[i, j] = np.float32(-3.0) if bits[j] == 0 else np.float32(3.0)
     return llr
+
+
+def build_stream(frames, recipe):
+    """Audio + chunk list of a live-stream scenario (tests/golden/stream.npz) from a few stored whole frames:
+    recipe = list of (kind, *args): ("frame", i) frame i; ("zeros", n); ("tile", i, first, length, count): `count` copies of
+    samples [first, first + length) of frame i (the data symbols of a frame, to keep a demodulator SYNCED for hundreds of
+    symbols).  Chunks are given per segment as ("feed", size, n_empty): the audio so far is fed in `size`-sample calls (the
+    last one shorter), followed by n_empty empty calls."""
+    audio, chunks, pending = [], [], 0
+    for item in recipe:
+        if item[0] == "frame":
+            audio.append(frames[item[1]]); pending += frames[item[1]].size
+        elif item[0] == "zeros":
+            audio.append(np.zeros(item[1], np.float32)); pending += item[1]
+        elif item[0] == "tile":
+            _, i, first, length, count = item
+            audio.append(np.tile(frames[i][first:first + length], count)); pending += length * count
+        elif item[0] == "feed":
+            _, size, n_empty = item
+            while pending > 0:
+                chunks.append(min(size, pending)); pending -= chunks[-1]
+            chunks += [0] * n_empty
+    assert pending == 0
+    return np.concatenate(audio).astype(np.float32), np.array(chunks, np.uint32)
+
+
+STREAM_SCENARIOS = {
+    # two frames in one stream: the first ends through "frame complete" (an empty call with nothing left), the search
+    # starts again on what is still buffered and finds the second; then ten empty calls
+    "two_frames": lambda sym, pre: [("zeros", 1500), ("frame", 0), ("feed", 960, 2), ("zeros", 3000), ("frame", 1), ("feed", 960, 3)],
+    # idle exit: after the frame the stream dribbles in 100 samples at a time — more than ten calls in a row without a new
+    # soft bit — then a second frame
+    "idle_reset": lambda sym, pre: [("frame", 0), ("feed", 960, 0), ("zeros", 3 * sym), ("feed", sym // 12, 0), ("frame", 2), ("feed", 960, 2)],
+    # timeout: the demodulator is kept busy for more than MAX_SYMBOLS_BEFORE_TIMEOUT = 250 symbols
+    "timeout": lambda sym, pre: [("frame", 1), ("tile", 1, pre, sym, 262), ("feed", 960, 1)],
+}

@@ -17,6 +17,8 @@ Fixtures
                refined LTS / data start) and chirp synchronisation (detectDualChirp + detectSync's start sample)
                of whole transmissions
   frames.npz   v2 wire format: soft bits of frames in, RxPipeline::processFrame's result out
+  stream.npz   live streams call by call (OFDMDemodulator::process + getSoftBits): the three exits of the SYNCED state
+               (frame complete, idle calls, timeout) and re-acquisition; audio rebuilt from fullsync.npz's frames
   fullsync.npz full Schmidl-Cox receive of whole frames (OFDMDemodulator::process fed in 960-sample
                chunks): sync offset, coarse CFO, LLRs, and the data-start offset at which the
                SYNCED-entry loop reproduces those LLRs bit for bit
@@ -197,6 +199,29 @@ def fullsync():
     np.savez_compressed(OUT / "fullsync.npz", **d)
 
 
+def stream():
+    """Live streams through OFDMDemodulator::process + getSoftBits, call by call (ref_demod_stream): the exits of the
+    SYNCED state and re-acquisition.  The audio is rebuilt from fullsync.npz's frames by tests/_util.build_stream; only
+    the per-call outputs are stored."""
+    sys.path.insert(0, str(ROOT / "tests"))
+    from _util import STREAM_SCENARIOS, build_stream, cfg_from_array
+    g = np.load(OUT / "fullsync.npz")
+    d = {}
+    for name in ("cfg3_qam16_r34", "cfg2_dqpsk_r12"):
+        cfg = cfg_from_array(g[f"{name}__cfg"])
+        geo = geometry(cfg)
+        frames = g[f"{name}__audio"]
+        pre = int(g[f"{name}__meta"][0][0])
+        for sc, recipe in STREAM_SCENARIOS.items():
+            audio, chunks = build_stream(frames, recipe(geo.symbol_samples, pre))
+            ready, synced, drained, soft = r.demod_stream(cfg, audio, chunks)
+            d[f"{name}__{sc}__ready"] = ready; d[f"{name}__{sc}__synced"] = synced
+            d[f"{name}__{sc}__drained"] = drained; d[f"{name}__{sc}__soft"] = soft
+            print(name, sc, "calls", chunks.size, "samples", audio.size, "ready calls", int(ready.sum()), "soft bits", soft.size,
+                  "synced transitions", int(np.abs(np.diff(synced.astype(int))).sum()))
+    np.savez_compressed(OUT / "stream.npz", **d)
+
+
 def sync():
     sys.path.insert(0, str(ROOT / "tests"))
     from _util import chirp_streams, long_acquisition_streams
@@ -255,7 +280,7 @@ def frames():
 
 
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["ldpc", "tables", "demod", "presynced", "fullsync", "sync", "frames"]
+    which = sys.argv[1:] or ["ldpc", "tables", "demod", "presynced", "fullsync", "sync", "frames", "stream"]
     for name in which:
         globals()[name]()
     for f in sorted(OUT.glob("*.npz")):

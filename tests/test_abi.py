@@ -24,7 +24,7 @@ def test_every_declared_symbol_is_exported_and_bound(hiplib):
     for n in names:
         assert hasattr(hiplib, n), f"{n} declared in include/ultra_hip.h but not exported"
     assert set(names) == set(_lib.PROTOTYPES), "ctypes prototypes out of sync with the header"
-    assert hiplib.ultra_hip_abi_version() == _lib.ULTRA_HIP_ABI_VERSION == 4
+    assert hiplib.ultra_hip_abi_version() == _lib.ULTRA_HIP_ABI_VERSION == 5
     assert hiplib.ultra_hip_strerror(-2).decode().startswith("configuration not supported")
 
 
@@ -66,7 +66,7 @@ def test_invalid_configs_are_rejected(hiplib):
     assert rc(fft_size=1000) == -2 and rc(fft_size=2048) == -2      # FFT sizes outside the built path
     assert rc(num_carriers=0) == -2 and rc(num_carriers=65) == -2
     assert rc(pilot_spacing=0) == -1 and rc(modulation=9) == -1 and rc(modulation=5) == -2
-    assert rc(code_rate=6) == -2 and rc(n_data_symbols=0) == -1 and rc(n_data_symbols=251) == -1
+    assert rc(code_rate=6) == -2 and rc(n_data_symbols=0) == -1 and rc(n_data_symbols=252) == -1
     assert rc(entry=2) == -1 and rc(cp_mode=3) == -1
     assert hiplib.ultra_hip_geometry_for(None, C.byref(g)) == -1
 

@@ -8,6 +8,7 @@ import pytest
 ROOT = Path(__file__).resolve().parent.parent
 SRC = r'''
 #include "ultra_hip_waveform.hpp"
+#include <type_traits>
 int main() {
     ultra_hip::ModemConfig c;
     ultra_hip::HipOfdmWaveform w(c);
@@ -18,6 +19,10 @@ int main() {
 #ifdef ULTRA_HIP_WITH_REFERENCE
     ultra::WaveformPtr p = std::make_unique<ultra_hip::HipOfdmWaveform>(c);   // through the plugin pointer type
     (void)p;
+    // the Schmidl-Cox flavour — what WaveformFactory::create(OFDM_COX) returns — as a complete ultra::IWaveform
+    auto make_cox = [](const ultra::ModemConfig& cfg) -> ultra::WaveformPtr { return std::make_unique<ultra_hip::HipOfdmCoxWaveform>(cfg); };
+    (void)make_cox;
+    static_assert(std::is_base_of_v<ultra::IWaveform, ultra_hip::HipOfdmCoxWaveform> && !std::is_abstract_v<ultra_hip::HipOfdmCoxWaveform>);
 #endif
     return (w.getSamplesPerSymbol() == 564 && w.getMinSamplesForFrame() == 13 * 564 && w.getCarrierCount() == 30) ? 0 : 1;
 }

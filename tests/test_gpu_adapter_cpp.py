@@ -31,7 +31,7 @@ int main(int argc, char** argv) {
     c.cp_mode = static_cast<decltype(c.cp_mode)>(std::stoi(argv[7])); c.symbol_guard = std::stoul(argv[8]);
     c.pilot_spacing = std::stoul(argv[9]); c.use_pilots = std::stoi(argv[10]) != 0;
     c.modulation = static_cast<Modulation>(std::stoi(argv[11])); c.code_rate = static_cast<CodeRate>(std::stoi(argv[12]));
-    HipOfdmCoxReceiver rx(c, std::stoul(argv[13]));
+    HipOfdmCoxWaveform rx(c);                                   // no frame length: symbols are demodulated as they arrive
     bool ready = false;
     for (size_t i = 0; i < n; i += 960) {                       // tools/test_nvis_mode.cpp:88-99
         const size_t len = std::min<size_t>(960, n - i);
@@ -264,3 +264,74 @@ def test_cpp_sweep_harness_equals_python_driver(tmp_path):
     for row, p in zip(rows, want):
         assert row[0] == p.label.replace(" ", "_") and [int(v) for v in row[2:]] == [p.counters[k] for k in keys], (row, p.counters)
 
+
+
+SRC_STREAM = r'''
+#include "ultra_hip_waveform.hpp"
+#include <cstdio>
+#include <vector>
+using namespace ultra_hip;
+int main(int argc, char** argv) {
+    // argv: in.f32 n_samples chunks.u32 n_calls out.bin fft carriers cp_mode guard pilot_spacing use_pilots mod rate
+    const size_t n = std::stoul(argv[2]), n_calls = std::stoul(argv[4]);
+    std::vector<float> audio(n);
+    std::vector<uint32_t> chunks(n_calls);
+    FILE* f = std::fopen(argv[1], "rb"); if (std::fread(audio.data(), 4, n, f) != n) return 2; std::fclose(f);
+    f = std::fopen(argv[3], "rb"); if (std::fread(chunks.data(), 4, n_calls, f) != n_calls) return 2; std::fclose(f);
+    ModemConfig c;
+    c.fft_size = std::stoul(argv[6]); c.num_carriers = std::stoul(argv[7]);
+    c.cp_mode = static_cast<decltype(c.cp_mode)>(std::stoi(argv[8])); c.symbol_guard = std::stoul(argv[9]);
+    c.pilot_spacing = std::stoul(argv[10]); c.use_pilots = std::stoi(argv[11]) != 0;
+    c.modulation = static_cast<Modulation>(std::stoi(argv[12])); c.code_rate = static_cast<CodeRate>(std::stoi(argv[13]));
+    HipOfdmCoxWaveform w(c);                                    // what WaveformFactory::create(OFDM_COX, config) would hand out
+    std::vector<uint32_t> trace;                                // per call: ready, synced, soft bits handed out
+    std::vector<float> soft;
+    size_t pos = 0;
+    for (size_t i = 0; i < n_calls; ++i) {
+        const bool ready = w.process(SampleSpan(audio.data() + pos, chunks[i]));
+        pos += chunks[i];
+        uint32_t drained = 0;
+        if (ready) { std::vector<float> sb = w.getSoftBits(); drained = (uint32_t)sb.size(); soft.insert(soft.end(), sb.begin(), sb.end()); }
+        trace.push_back(ready ? 1u : 0u); trace.push_back(w.isSynced() ? 1u : 0u); trace.push_back(drained);
+    }
+    FILE* g = std::fopen(argv[5], "wb");
+    std::fwrite(trace.data(), 4, trace.size(), g); std::fwrite(soft.data(), 4, soft.size(), g); std::fclose(g);
+    return 0;
+}
+'''
+
+
+@pytest.mark.parametrize("name", ["cfg3_qam16_r34", "cfg2_dqpsk_r12"])
+def test_cox_waveform_live_stream(tmp_path, name):
+    """HipOfdmCoxWaveform as a LIVE stream, call by call against the compiled reference's OFDMDemodulator::process +
+    getSoftBits (tests/golden/stream.npz): two frames in one stream (frame-complete exit, re-acquisition on the
+    leftover buffer), the idle-call exit, the 250-symbol timeout; return values, isSynced() and every soft bit."""
+    from _util import STREAM_SCENARIOS, build_stream
+    from oracle.bindings import geometry
+    g = np.load(GOLDEN / "fullsync.npz")
+    want = np.load(GOLDEN / "stream.npz")
+    cfg = cfg_from_array(g[f"{name}__cfg"])
+    geo = geometry(cfg)
+    src = tmp_path / "st.cpp"
+    src.write_text(SRC_STREAM)
+    exe = tmp_path / "st"
+    lib = ROOT / "projectultra_amd"
+    subprocess.check_call(["g++", "-O1", "-std=c++20", f"-I{ROOT / 'include'}", str(src), f"-L{lib}", "-lultra_hip",
+                           f"-Wl,-rpath,{lib}", "-o", str(exe)])
+    pre = int(g[f"{name}__meta"][0][0])
+    for sc, recipe in STREAM_SCENARIOS.items():
+        audio, chunks = build_stream(g[f"{name}__audio"], recipe(geo.symbol_samples, pre))
+        fin, fc, fo = tmp_path / f"{sc}.f32", tmp_path / f"{sc}.u32", tmp_path / f"{sc}.out"
+        audio.tofile(fin); chunks.tofile(fc)
+        args = [str(exe), str(fin), str(audio.size), str(fc), str(chunks.size), str(fo)] + [str(int(x)) for x in (
+            cfg.fft_size, cfg.num_carriers, cfg.cp_mode, cfg.symbol_guard, cfg.pilot_spacing, cfg.use_pilots,
+            cfg.modulation, cfg.code_rate)]
+        r = subprocess.run(args, capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0, (sc, r.returncode, r.stderr[-400:])
+        raw = np.fromfile(fo, np.uint32)
+        trace = raw[:3 * chunks.size].reshape(-1, 3)
+        soft = raw[3 * chunks.size:].view(np.float32)
+        assert np.array_equal(trace[:, 0], want[f"{name}__{sc}__ready"]), (name, sc, "ready")
+        assert np.array_equal(trace[:, 1], want[f"{name}__{sc}__synced"]), (name, sc, "synced")
+        assert np.array_equal(trace[:, 2], want[f"{name}__{sc}__drained"]), (name, sc, "drained")
+        assert beq(soft, want[f"{name}__{sc}__soft"]), (name, sc, "soft bits")

@@ -323,3 +323,22 @@ def test_v2_default_pipeline_deinterleaves(oracle, ref):
     assert ref.v2_decode_frame(0, soft, 0)["success"] == 1
     assert ref.v2_decode_frame(0, soft, AS_CONSTRUCTED)["success"] == 0
 
+
+
+def test_stream_fixture_is_the_reference(ref):
+    """tests/golden/stream.npz (the live-stream traces the GPU adapter is held to) regenerated from the compiled reference:
+    the committed fixture is what OFDMDemodulator::process + getSoftBits do call by call."""
+    from _util import STREAM_SCENARIOS, build_stream, cfg_from_array
+    from conftest import GOLDEN
+    g = np.load(GOLDEN / "fullsync.npz")
+    want = np.load(GOLDEN / "stream.npz")
+    name = "cfg2_dqpsk_r12"
+    cfg = cfg_from_array(g[f"{name}__cfg"])
+    geo = geometry(cfg)
+    pre = int(g[f"{name}__meta"][0][0])
+    for sc in ("two_frames", "idle_reset"):
+        audio, chunks = build_stream(g[f"{name}__audio"], STREAM_SCENARIOS[sc](geo.symbol_samples, pre))
+        ready, synced, drained, soft = ref.demod_stream(cfg, audio, chunks)
+        assert np.array_equal(ready, want[f"{name}__{sc}__ready"]) and np.array_equal(synced, want[f"{name}__{sc}__synced"])
+        assert np.array_equal(drained, want[f"{name}__{sc}__drained"]) and beq(soft, want[f"{name}__{sc}__soft"])
+        assert synced.any() and not synced[-1]              # it did sync, and it did leave SYNCED again
