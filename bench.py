@@ -433,14 +433,14 @@ class LdpcSweepWorkload:
 
 
 class ModeSweepWorkload:
-    """cfg5: the 5 x 6 mode/rate grid x 11 SNR points per step — one receive context per cell, n frames per point per
-    GPU, audio of every point resident in HBM.  The 11 points of a cell go through demodulate + decode as ONE batch (the
-    receive path does not depend on the SNR, frames are independent; with ~2 k frames per point the path is otherwise
-    bound by launch latency), are counted per point, and the cell's [11][8] counter block is all-reduced once."""
+    """cfg5: the 5 x 6 mode/rate grid x 11 SNR points per step, n frames per point per GPU, audio of every point resident
+    in HBM.  The launches are shared ACROSS cells (projectultra_amd.sweep.HipModeGrid): one demodulation per modulation
+    over the frames of its six rates and eleven points, one LDPC launch per code rate over the soft bits of all five
+    modulations, one counting launch per rate; the [30 x 11][8] counter block is all-reduced once per step."""
 
     def __init__(self, args, rank, world, torch):
         from projectultra_amd.montecarlo import shard_range
-        from projectultra_amd.sweep import CFG5_MODULATIONS, CFG5_RATES, CFG5_SNR_POINTS, HipModemShard, nvis_cell_config, point_seed
+        from projectultra_amd.sweep import CFG5_MODULATIONS, CFG5_RATES, CFG5_SNR_POINTS, HipModeGrid
         self.name, self.torch = "cfg5", torch
         self.n = args.frames or 1920
         self.snrs = list(CFG5_SNR_POINTS)
@@ -448,67 +448,40 @@ class ModeSweepWorkload:
         S, n = len(self.snrs), self.n
         lo, _ = shard_range(n * world, rank, world)
         t0 = time.time()
-        self.shards, self.audio, self.payload, self.outs = [], [], [], []
-        resident = 0
-        # The cells are independent receive contexts with batches of S * n frames — too small to fill the chip at the
-        # ramp and the tail of every launch — so they are spread over a few HIP streams (one context per stream).
-        self.streams = [torch.cuda.Stream() for _ in range(int(os.environ.get("ULTRA_BENCH_CELL_STREAMS", "4")))]
-        for ci, (m, r) in enumerate(self.cells):
-            with torch.cuda.stream(self.streams[ci % len(self.streams)]):
-                sh = HipModemShard(nvis_cell_config(m, r), channel="awgn", batch=n)
-                g = sh.ctx.geometry
-                audio = torch.empty((S * n, g.frame_samples), dtype=torch.float32, device="cuda")
-                payload = torch.empty((S * n, g.ldpc_k // 8), dtype=torch.uint8, device="cuda")
-                for si, snr in enumerate(self.snrs):
-                    sh.ctx.make_batch(n, seed=point_seed(0x5EED, ci * S + si), first_frame=lo, channel="awgn", snr_db=snr,
-                                      out=(audio[si * n:(si + 1) * n], payload[si * n:(si + 1) * n]))
-                resident += audio.numel() * 4
-                self.shards.append(sh); self.audio.append(audio); self.payload.append(payload)
-                self.outs.append(dict(bytes=torch.empty((S * n, g.decoded_bytes), dtype=torch.uint8, device="cuda"),
-                                      iters=torch.empty(S * n, dtype=torch.int32, device="cuda"),
-                                      ok=torch.empty(S * n, dtype=torch.uint8, device="cuda")))
+        self.grid = HipModeGrid(CFG5_MODULATIONS, CFG5_RATES, self.snrs, frames_per_point=n)
+        self.grid.generate(lo, seed=0x5EED)
         torch.cuda.synchronize()
         self.t_gen = time.time() - t0
+        resident = self.grid.audio_bytes
         P = len(self.cells) * S
         self.counters = torch.zeros((P, 8), dtype=torch.int64, device="cuda")
         self.units_per_step = n * P
         self.points_per_step = P
-        self.collectives_per_step = len(self.cells)
-        self.collective_op = f"all_reduce(SUM) of {S} x 8 x int64 (the points of one mode/rate cell)"
+        self.collectives_per_step = 1
+        self.collective_op = f"all_reduce(SUM) of {P} x 8 x int64 (every point of the grid)"
         self.metric = "adaptive-mode Monte-Carlo frames decoded/sec (5 modulations x 6 code rates x 11 SNR points)"
         self.unit = "frames/s"
         self.bytes_per_unit = resident / (n * P) + 4 + 648 * 4 + 60 + 4      # mean over the grid
         # per launch and frame: one symbol of audio (1120 samples) into mix_fft; the LLRs out of track_kernel and the
         # decoder's in/out differ from cell to cell (mean over the grid used)
         self.per_launch = {"mix_fft_kernel": 1120 * 4, "ldpc_decode_kernel": 648 * 4 + 50 + 4 + 1}
-        self.per_step = {"mix_fft_kernel": sum(S * n * sh.ctx.cfg.n_data_symbols * 1120 * 4 for sh in self.shards)}
-        self.launch_units = n * S
-        self.geo = self.shards[0].ctx.geometry
+        self.per_step = {"mix_fft_kernel": sum(S * n * self.grid.ctx[c].cfg.n_data_symbols * 1120 * 4 for c in self.cells)}
+        self.launch_units = n * S * len(CFG5_RATES)
+        self.geo = self.grid.demod_ctx[0].geometry
         self.data = (f"synthetic ({P} points x {n} distinct frames per GPU generated on the device in HBM, AWGN; "
                      f"{resident / 1e9:.1f} GB of audio resident)")
         self.workload = (f"{{DBPSK,DQPSK,D8PSK,16QAM,32QAM}} x {{R1/4,R1/3,R1/2,R2/3,R3/4,R5/6}} on OFDM 1024-FFT / 59 carriers, SNR "
-                         f"{self.snrs[0]:g}..{self.snrs[-1]:g} dB in 3 dB steps, post-sync entry, {n} frames per point per GPU per step, "
-                         f"the {S} points of a cell in one batch")
-        self.parallelism = (f"frames of every point sharded over {world} GPU(s), one all-reduce of the counter block per mode/rate cell; "
-                            f"the cells' contexts spread over {len(self.streams)} HIP streams")
+                         f"{self.snrs[0]:g}..{self.snrs[-1]:g} dB in 3 dB steps, post-sync entry, {n} frames per point per GPU per step; "
+                         f"one demodulation per modulation, one LDPC launch per code rate")
+        self.parallelism = (f"frames of every point sharded over {world} GPU(s), one all-reduce of the grid's counter block per step")
 
     def step(self, allreduce):
-        torch = self.torch
-        self.counters.zero_()
-        S, n = len(self.snrs), self.n
-        main = torch.cuda.current_stream()
-        for st in self.streams:
-            st.wait_stream(main)                                 # the zeroed counters
-        for ci, (sh, audio, payload, out) in enumerate(zip(self.shards, self.audio, self.payload, self.outs)):
-            with torch.cuda.stream(self.streams[ci % len(self.streams)]):
-                r = sh.ctx.demod_decode(audio, out=out)
-                sh.ctx.count_errors_points(r, payload, self.counters[ci * S:(ci + 1) * S])
-                allreduce(self.counters[ci * S:(ci + 1) * S])
-        for st in self.streams:
-            main.wait_stream(st)
+        c = self.grid.receive()                                   # [modulation][rate][point][8]
+        self.counters.copy_(c.reshape(-1, 8))
+        allreduce(self.counters)
 
     def contexts(self):
-        return [sh.ctx for sh in self.shards]
+        return self.grid.contexts()
 
     def curves(self):
         from projectultra_amd.montecarlo import counters_dict
@@ -519,12 +492,14 @@ class ModeSweepWorkload:
 
     def cpu_baseline(self, cores, sample):
         from oracle.bindings import have_ref, make_config, oracle, Ref
+        from projectultra_amd.sweep import CFG5_MODULATIONS, CFG5_RATES
         o = oracle()
         ref = Ref() if have_ref() else None
         ccfg0 = make_config(1024, "QAM16", "R3_4")
-        S, n = len(self.snrs), self.n
-        c16 = next(i for i, (m, r) in enumerate(self.cells) if (m.name, r.name) == ("QAM16", "R3_4"))
-        probe = self.audio[c16][8 * n:8 * n + min(512, n)].cpu().numpy()     # the 16QAM R3/4 cell, 15 dB
+        S, n, R = len(self.snrs), self.n, len(CFG5_RATES)
+        mi16, ri34 = [m.name for m in CFG5_MODULATIONS].index("QAM16"), [r.name for r in CFG5_RATES].index("R3_4")
+        cell_audio = lambda mi, ri: self.grid.audio[mi][ri * S * n:(ri + 1) * S * n]          # [S * n][frame_samples]
+        probe = cell_audio(mi16, ri34)[8 * n:8 * n + min(512, n)].cpu().numpy()             # the 16QAM R3/4 cell, 15 dB
 
         def rate(t):
             t0 = time.perf_counter()
@@ -535,12 +510,13 @@ class ModeSweepWorkload:
         t_port = t_ref = 0.0
         ok_port = ok_ref = True
         total = 0
-        for ci, ((m, r), sh, a_cell) in enumerate(zip(self.cells, self.shards, self.audio)):
+        for ci, (m, r) in enumerate(self.cells):
+            mi, ri = ci // R, ci % R
             ccfg = make_config(1024, m.name, r.name)
+            a_cell = cell_audio(mi, ri)
             audio = np.concatenate([a_cell[si * n:si * n + per].cpu().numpy() for si in range(S)])
-            with self.torch.cuda.stream(self.streams[ci % len(self.streams)]):      # the cell's context lives on this stream
-                got = sh.ctx.demod_decode(self.torch.from_numpy(audio).cuda())
-                got = {k: v.cpu().numpy() for k, v in got.items()}
+            got = self.grid.ctx[(m, r)].demod_decode(self.torch.from_numpy(audio).cuda())
+            got = {k: v.cpu().numpy() for k, v in got.items()}
             t0 = time.perf_counter()
             w = o.demod_decode_batch(ccfg, audio, n_threads=cores, want_llr=False, want_state=False)
             t_port += time.perf_counter() - t0

@@ -215,6 +215,19 @@ int ultra_hip_demod_batch(ultra_hip_ctx* ctx, const float* d_audio, size_t frame
                           const float* d_cfo_hz, const float* d_cfo_phase, size_t n_frames,
                           float* d_llr, float* d_state);
 
+/* ultra_hip_demod_batch with a caller-chosen row stride of the LLR array (>= llrs_per_frame): several configurations
+ * can then share one LLR array (the mode grid of BASELINE configs[4]: one demodulation per MODULATION over the frames of
+ * all its code rates, rows of 768 soft bits whatever the modulation). */
+int ultra_hip_demod_batch_strided(ultra_hip_ctx* ctx, const float* d_audio, size_t frame_stride, const float* d_cfo_hz,
+                                  const float* d_cfo_phase, size_t n_frames, float* d_llr, size_t llr_stride, float* d_state);
+
+/* ultra_hip_ldpc_decode_batch over n_blocks runs of block_len codewords inside a larger LLR array of rows of llr_stride
+ * floats (the first 648 of a row are the codeword): codeword c = row (c / block_len) * block_stride + c % block_len.
+ * One launch per CODE RATE over the soft bits of every modulation of a mode grid (decoding does not depend on the
+ * modulation).  Results are dense: d_bytes [n_blocks * block_len][ceil(k/8)], d_iters, d_ok. */
+int ultra_hip_ldpc_decode_blocks(ultra_hip_ctx* ctx, const float* d_llr, size_t llr_stride, size_t block_len, size_t block_stride,
+                                 size_t n_blocks, uint8_t* d_bytes, int32_t* d_iters, uint8_t* d_ok);
+
 /* The SYNCED symbol loop of OFDMDemodulator::process (src/ofdm/demodulator.cpp:672-697) as it runs on a live stream:
  * symbols are demodulated when they arrive.  Symbols [first_symbol, first_symbol + n_symbols) of every frame, the
  * tracker continuing from where the previous call on this context left it (first_symbol == 0 starts a fresh

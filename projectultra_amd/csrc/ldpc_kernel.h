@@ -167,7 +167,13 @@ __global__ __launch_bounds__(kLdpcThreads, WAVES) void ldpc_decode_kernel(
     const LdpcPlan* __restrict__ Pp, const float* __restrict__ llr, size_t llr_stride, int n_cw,
     uint8_t* __restrict__ bytes, int32_t* __restrict__ iters, uint8_t* __restrict__ okv,
     float* __restrict__ llr_total, unsigned int* __restrict__ work_counter, int llr_step,
-    const uint16_t* __restrict__ llr_perm) {
+    const uint16_t* __restrict__ llr_perm, int block_len, int block_stride) {
+    // block_len > 0 (ultra_hip_ldpc_decode_blocks): codeword c is row (c / block_len) * block_stride + c % block_len of the
+    // LLR array — several equally long runs of rows inside a larger array (one code rate's share of a mode grid) decoded
+    // by ONE launch; results stay dense (row c).
+    auto llr_row = [&](int c) -> size_t {
+        return block_len > 0 ? (size_t)(c / block_len) * (size_t)block_stride + (size_t)(c % block_len) : (size_t)c;
+    };
     constexpr int DMAX = ldpc_prof_max(VMAX, VR);
     extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
     const LdpcPlan& P = *Pp;
@@ -253,7 +259,7 @@ __global__ __launch_bounds__(kLdpcThreads, WAVES) void ldpc_decode_kernel(
     // The table case is a separate loop behind ONE uniform branch: with the choice made per load, every asynchronous
     // copy sat behind a conditional index load and its wait (measured on the R1/4 sweep: 10 ms of 73 per 5.5 M codewords).
     auto fetch = [&](int c) {
-        const float* src = llr + (size_t)c * llr_stride;
+        const float* src = llr + llr_row(c) * llr_stride;
         if (llr_perm) {
             for (int j0 = 0; j0 < n; j0 += kLdpcThreads)
                 if (j0 + lane < n) __builtin_amdgcn_global_load_lds(src + (unsigned)llr_perm[j0 + lane], llr_s + j0, 4, 0, 0);

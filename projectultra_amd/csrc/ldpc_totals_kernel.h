@@ -45,7 +45,13 @@ __global__ __launch_bounds__(kLdpcThreads, WAVES) void ldpc_totals_kernel(
     const LdpcTPlan* __restrict__ Pp, const float* __restrict__ llr, size_t llr_stride, int n_cw,
     uint8_t* __restrict__ bytes, int32_t* __restrict__ iters, uint8_t* __restrict__ okv,
     float* __restrict__ llr_total, unsigned int* __restrict__ work_counter, int llr_step,
-    const uint16_t* __restrict__ llr_perm) {
+    const uint16_t* __restrict__ llr_perm, int block_len, int block_stride) {
+    // block_len > 0 (ultra_hip_ldpc_decode_blocks): codeword c is row (c / block_len) * block_stride + c % block_len of the
+    // LLR array — several equally long runs of rows inside a larger array (one code rate's share of a mode grid) decoded
+    // by ONE launch; results stay dense (row c).
+    auto llr_row = [&](int c) -> size_t {
+        return block_len > 0 ? (size_t)(c / block_len) * (size_t)block_stride + (size_t)(c % block_len) : (size_t)c;
+    };
     extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
     const LdpcTPlan& P = *Pp;
     const int lane = threadIdx.x;
@@ -110,7 +116,7 @@ __global__ __launch_bounds__(kLdpcThreads, WAVES) void ldpc_totals_kernel(
         src_p[r] = (i != 0xFFFFu) ? (unsigned short)src_index(k + (int)i) : (unsigned short)0xFFFFu;
     }
     auto fetch = [&](int c) {
-        const float* src = llr + (size_t)c * llr_stride;
+        const float* src = llr + llr_row(c) * llr_stride;
         float* stage_v = reinterpret_cast<float*>(lds_raw + STAGE_V);
         float* stage_p = reinterpret_cast<float*>(lds_raw + STAGE_P);
 #pragma unroll
@@ -257,7 +263,7 @@ __global__ __launch_bounds__(kLdpcThreads, WAVES) void ldpc_totals_kernel(
         // ---- outputs: hard decisions of the k information bits packed MSB-first (:238-258) ----
         // Totals of the checked variables are in T (those of the last completed iteration — the row phase does not
         // touch T); an unchecked variable's total is its channel LLR, read again from memory.
-        const float* src = llr + (size_t)cw * llr_stride;
+        const float* src = llr + llr_row(cw) * llr_stride;
         uint8_t* ob = bytes + (size_t)cw * decoded_bytes;
         for (int b = lane; b < decoded_bytes; b += kLdpcThreads) {
             unsigned v = 0;

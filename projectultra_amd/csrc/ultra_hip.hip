@@ -340,7 +340,7 @@ int launch_demod(ultra_hip_ctx* ctx, const float* d_audio, size_t frame_stride, 
 }
 
 int launch_ldpc(ultra_hip_ctx* ctx, const float* d_llr, size_t llr_stride, size_t n_cw, uint8_t* d_bytes,
-                int32_t* d_iters, uint8_t* d_ok, float* d_llr_total) {
+                int32_t* d_iters, uint8_t* d_ok, float* d_llr_total, int block_len = 0, int block_stride = 0) {
     if (n_cw == 0) return ULTRA_HIP_OK;
     // persistent workgroups (one wavefront each) pull codewords from an atomic counter; every
     // launch uses its own counter word, zeroed on the stream just before the launch
@@ -364,11 +364,11 @@ int launch_ldpc(ultra_hip_ctx* ctx, const float* d_llr, size_t llr_stride, size_
         if (d_llr_total)                                                                                          \
             hipLaunchKernelGGL((dev::ldpc_totals_kernel<RR, VR, D, true, WV>), dim3(grid), dim3(dev::kLdpcThreads), tlds, \
                                ctx->stream, ctx->d_tplan, d_llr, llr_stride, (int)n_cw, d_bytes, d_iters, d_ok,   \
-                               d_llr_total, counter, (int)ctx->deint_step, ctx->d_deint_table);                                       \
+                               d_llr_total, counter, (int)ctx->deint_step, ctx->d_deint_table, block_len, block_stride);                                       \
         else                                                                                                      \
             hipLaunchKernelGGL((dev::ldpc_totals_kernel<RR, VR, D, false, WV>), dim3(grid), dim3(dev::kLdpcThreads), tlds, \
                                ctx->stream, ctx->d_tplan, d_llr, llr_stride, (int)n_cw, d_bytes, d_iters, d_ok,   \
-                               d_llr_total, counter, (int)ctx->deint_step, ctx->d_deint_table);                                       \
+                               d_llr_total, counter, (int)ctx->deint_step, ctx->d_deint_table, block_len, block_stride);                                       \
     } while (0)
         bool launched = true;
         if (T.row_rounds == 3 && T.var_rounds == 6 && T.dmax == 3) UH_TOTALS_LAUNCH(3, 6, 3, 5);                  // R3/4
@@ -391,12 +391,12 @@ int launch_ldpc(ultra_hip_ctx* ctx, const float* d_llr, size_t llr_stride, size_
             hipLaunchKernelGGL((dev::ldpc_decode_kernel<RR, VR, RMAX, RMIN, VMAX, VMIN, RID, LIN, true, WV>),        \
                                dim3(grid), dim3(dev::kLdpcThreads), lds, ctx->stream, ctx->d_plan, d_llr,       \
                                llr_stride, (int)n_cw, d_bytes, d_iters, d_ok, d_llr_total, counter,             \
-                               (int)ctx->deint_step, ctx->d_deint_table);                                                           \
+                               (int)ctx->deint_step, ctx->d_deint_table, block_len, block_stride);                                                           \
         else                                                                                                    \
             hipLaunchKernelGGL((dev::ldpc_decode_kernel<RR, VR, RMAX, RMIN, VMAX, VMIN, RID, LIN, false, WV>),       \
                                dim3(grid), dim3(dev::kLdpcThreads), lds, ctx->stream, ctx->d_plan, d_llr,       \
                                llr_stride, (int)n_cw, d_bytes, d_iters, d_ok, d_llr_total, counter,             \
-                               (int)ctx->deint_step, ctx->d_deint_table);                                                           \
+                               (int)ctx->deint_step, ctx->d_deint_table, block_len, block_stride);                                                           \
     } while (0)
     // One instance per degree profile of the reference's six codes (LdpcPlan::prof_*, four bits per round, round 0
     // lowest; tools/ldpc_plan_check.cpp prints them): the kernel touches exactly the edge slots a round has.  The
@@ -710,6 +710,27 @@ int ultra_hip_demod_batch(ultra_hip_ctx* ctx, const float* d_audio, size_t frame
     DeviceGuard guard(ctx->device);
     return launch_demod(ctx, d_audio, frame_stride, d_cfo_hz, d_cfo_phase, n_frames, d_llr,
                         ctx->geo.llrs_per_frame, d_state);
+}
+
+int ultra_hip_demod_batch_strided(ultra_hip_ctx* ctx, const float* d_audio, size_t frame_stride, const float* d_cfo_hz,
+                                  const float* d_cfo_phase, size_t n_frames, float* d_llr, size_t llr_stride, float* d_state) {
+    if (!ctx) return ULTRA_HIP_ERR_INVALID_ARG;
+    if (n_frames == 0) return ULTRA_HIP_OK;
+    if (!d_audio || !d_llr || frame_stride < ctx->geo.frame_samples || llr_stride < ctx->geo.llrs_per_frame || n_frames > 0x7fffffffull)
+        return ULTRA_HIP_ERR_INVALID_ARG;
+    DeviceGuard guard(ctx->device);
+    return launch_demod(ctx, d_audio, frame_stride, d_cfo_hz, d_cfo_phase, n_frames, d_llr, llr_stride, d_state);
+}
+
+int ultra_hip_ldpc_decode_blocks(ultra_hip_ctx* ctx, const float* d_llr, size_t llr_stride, size_t block_len, size_t block_stride,
+                                 size_t n_blocks, uint8_t* d_bytes, int32_t* d_iters, uint8_t* d_ok) {
+    if (!ctx) return ULTRA_HIP_ERR_INVALID_ARG;
+    if (n_blocks == 0 || block_len == 0) return ULTRA_HIP_OK;
+    if (!d_llr || !d_bytes || !d_iters || !d_ok || llr_stride < (size_t)kLdpcN || block_stride < block_len ||
+        block_len > 0x7fffffffull || block_stride > 0x7fffffffull || n_blocks * block_len > 0x7fffffffull)
+        return ULTRA_HIP_ERR_INVALID_ARG;
+    DeviceGuard guard(ctx->device);
+    return launch_ldpc(ctx, d_llr, llr_stride, n_blocks * block_len, d_bytes, d_iters, d_ok, nullptr, (int)block_len, (int)block_stride);
 }
 
 int ultra_hip_demod_stream_batch(ultra_hip_ctx* ctx, const float* d_audio, size_t frame_stride, const float* d_cfo_hz,

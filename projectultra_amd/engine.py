@@ -193,6 +193,41 @@ class ReceiveContext:
                                              state.data_ptr() if want_state else None), "ultra_hip_demod_batch")
         return (llr, state) if want_state else llr
 
+    def demod_into(self, audio, llr, cfo_hz=None, cfo_phase=None):
+        """Demodulate into the rows of a caller-owned LLR array whose row stride may exceed llrs_per_frame
+        (ultra_hip_demod_batch_strided): llr = a [n][>= llrs_per_frame] f32 view with unit column stride — e.g. a row
+        range of the [.][768] array the modulations of a mode grid share."""
+        torch = _torch()
+        self._check_stream()
+        audio = self._frames(audio)
+        n = audio.shape[0]
+        g = self.geometry
+        if (not isinstance(llr, torch.Tensor) or llr.dtype != torch.float32 or llr.device != self.device or llr.dim() != 2
+                or llr.shape[0] != n or llr.shape[1] < g.llrs_per_frame or llr.stride(1) != 1):
+            raise _lib.UltraHipError(-1, "demod_into: llr must be a [n][>= llrs_per_frame] f32 view with unit column stride")
+        cfo, cph = self._opt(cfo_hz, n), self._opt(cfo_phase, n)
+        check(self.lib.ultra_hip_demod_batch_strided(self._ctx, audio.data_ptr(), self._row_stride(audio),
+                                                     cfo.data_ptr() if cfo is not None else None,
+                                                     cph.data_ptr() if cph is not None else None, n, llr.data_ptr(),
+                                                     self._row_stride(llr), None), "ultra_hip_demod_batch_strided")
+        return llr
+
+    def ldpc_decode_blocks(self, llr, block_len: int, block_stride: int, n_blocks: int, out=None):
+        """Decode n_blocks runs of block_len codewords that lie block_stride rows apart in a [rows][stride >= 648] f32
+        array (ultra_hip_ldpc_decode_blocks) -> dense dict(bytes, iters, ok) of n_blocks * block_len rows."""
+        torch = _torch()
+        self._check_stream()
+        if (not isinstance(llr, torch.Tensor) or llr.dtype != torch.float32 or llr.device != self.device or llr.dim() != 2
+                or llr.shape[1] < LDPC_BLOCK_SIZE or llr.stride(1) != 1
+                or (n_blocks - 1) * block_stride + block_len > llr.shape[0] or block_stride < block_len):
+            raise _lib.UltraHipError(-1, "ldpc_decode_blocks: llr must hold every block as rows of >= 648 f32")
+        n = n_blocks * block_len
+        out = self._result_buffers(n, out)
+        check(self.lib.ultra_hip_ldpc_decode_blocks(self._ctx, llr.data_ptr(), self._row_stride(llr), block_len, block_stride,
+                                                    n_blocks, out["bytes"].data_ptr(), out["iters"].data_ptr(),
+                                                    out["ok"].data_ptr()), "ultra_hip_ldpc_decode_blocks")
+        return out
+
     def demod_decode(self, audio, cfo_hz=None, cfo_phase=None, want_llr: bool = False, out=None):
         """Fused receive path -> dict(bytes, iters, ok[, llr]).  `out` may hand in the result tensors (and, under "llr",
         the [n][llrs_per_frame] destination of the soft bits)."""

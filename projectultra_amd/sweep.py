@@ -166,6 +166,75 @@ class HipModemShard:
         return counters
 
 
+class HipModeGrid:
+    """The whole mode x rate grid of configs[4] with SHARED launches across cells.  Demodulation does not depend on the
+    code rate and decoding does not depend on the modulation (every cell: 648-bit codewords; the data symbols of a frame
+    depend on the modulation only), so a pass over the grid is
+        one demodulation per MODULATION over the frames of all its rates and SNR points   (5 launch chains, not 30)
+        one LDPC launch per CODE RATE over the soft bits of all modulations                (6 launches, not 30)
+        one counting launch per code rate, counters per (modulation, SNR point)
+    through ONE soft-bit array [modulation][rate][point * frame][768] (ultra_hip_demod_batch_strided writes its rows,
+    ultra_hip_ldpc_decode_blocks reads one rate's runs out of it).  Same counters as HipModemShard.run_points cell by
+    cell (tests/test_gpu_sweep.py); tools/test_mode_snr.cpp:126-160 is the loop being batched."""
+    LLR_STRIDE = 768
+
+    def __init__(self, mods=CFG5_MODULATIONS, rates=CFG5_RATES, snr_points=CFG5_SNR_POINTS, frames_per_point: int = 1920,
+                 channel: str = "awgn", delay_ms: float = 0.5, doppler_hz: float = 0.1, max_iterations: int = 50,
+                 device: Optional[int] = None):
+        import torch
+        from .engine import ReceiveContext
+        self._torch = torch
+        self.mods, self.rates, self.snrs = [Modulation(m) for m in mods], [CodeRate(r) for r in rates], [float(x) for x in snr_points]
+        self.n, self.channel, self.delay_ms, self.doppler_hz = int(frames_per_point), channel, float(delay_ms), float(doppler_hz)
+        M, R, S, n = len(self.mods), len(self.rates), len(self.snrs), self.n
+        # one context per cell for the stimulus (payload -> encoder of the rate -> modulator of the modulation); the
+        # receive side uses one of them per modulation (demodulation) and one per rate (decoding, counting)
+        self.ctx = {(m, r): ReceiveContext(nvis_cell_config(m, r), max_iterations=max_iterations, device=device)
+                    for m in self.mods for r in self.rates}
+        dev = next(iter(self.ctx.values())).device
+        self.demod_ctx = [self.ctx[(m, self.rates[0])] for m in self.mods]
+        self.ldpc_ctx = [self.ctx[(self.mods[0], r)] for r in self.rates]
+        if any(c.geometry.llrs_per_frame > self.LLR_STRIDE or c.geometry.llrs_per_frame < 648 for c in self.demod_ctx):
+            raise ValueError("HipModeGrid: a frame must carry between 648 and 768 soft bits")
+        rows = S * n
+        self.audio = [torch.empty((R * rows, c.geometry.frame_samples), dtype=torch.float32, device=dev) for c in self.demod_ctx]
+        self.llr = torch.empty((M * R * rows, self.LLR_STRIDE), dtype=torch.float32, device=dev)
+        self.payload = [torch.empty((M * rows, c.geometry.ldpc_k // 8), dtype=torch.uint8, device=dev) for c in self.ldpc_ctx]
+        self.out = [dict(bytes=torch.empty((M * rows, c.geometry.decoded_bytes), dtype=torch.uint8, device=dev),
+                         iters=torch.empty(M * rows, dtype=torch.int32, device=dev),
+                         ok=torch.empty(M * rows, dtype=torch.uint8, device=dev)) for c in self.ldpc_ctx]
+        self.counters = torch.zeros((R, M * S, 8), dtype=torch.int64, device=dev)
+        self.audio_bytes = sum(a.numel() * 4 for a in self.audio)
+
+    def generate(self, lo: int, seed: int = 0x5EED):
+        """Stimulus of frames [lo, lo + n) of every point of every cell; the point index of (cell ci, SNR si) is
+        ci * len(snrs) + si with ci = modulation-major, as in mode_sweep."""
+        M, R, S, n = len(self.mods), len(self.rates), len(self.snrs), self.n
+        for mi, m in enumerate(self.mods):
+            for ri, r in enumerate(self.rates):
+                c = self.ctx[(m, r)]
+                for si, snr in enumerate(self.snrs):
+                    a0, p0 = (ri * S + si) * n, (mi * S + si) * n
+                    c.make_batch(n, seed=point_seed(seed, (mi * R + ri) * S + si), first_frame=lo, channel=self.channel, snr_db=snr,
+                                 delay_ms=self.delay_ms, doppler_hz=self.doppler_hz,
+                                 out=(self.audio[mi][a0:a0 + n], self.payload[ri][p0:p0 + n]))
+
+    def receive(self):
+        """One pass over the grid -> device int64 counters [modulation][rate][point][8]."""
+        M, R, S, n = len(self.mods), len(self.rates), len(self.snrs), self.n
+        rows = S * n
+        self.counters.zero_()
+        for mi, c in enumerate(self.demod_ctx):
+            c.demod_into(self.audio[mi], self.llr[mi * R * rows:(mi + 1) * R * rows])
+        for ri, c in enumerate(self.ldpc_ctx):
+            r = c.ldpc_decode_blocks(self.llr[ri * rows:], rows, R * rows, M, out=self.out[ri])
+            c.count_errors_points(r, self.payload[ri], self.counters[ri])
+        return self.counters.reshape(R, M, S, 8).permute(1, 0, 2, 3)
+
+    def contexts(self):
+        return list(self.ctx.values())
+
+
 # --------------------------------------------------------------------------------------------------------------
 # the loops
 # --------------------------------------------------------------------------------------------------------------
@@ -246,6 +315,48 @@ def mode_sweep(cells=None, snr_points: Iterable[float] = CFG5_SNR_POINTS, frames
         out += sweep(f"{Modulation(mod).name} {CodeRate(rate).name}", shard, snr_points, frames_per_point, seed, rank, world,
                      group, ci * len(snr_points), on_point)
         del shard
+    return out
+
+
+def mode_sweep_grid(snr_points: Iterable[float] = CFG5_SNR_POINTS, frames_per_point: int = 1 << 14, channel: str = "awgn",
+                    delay_ms: float = 0.5, doppler_hz: float = 0.1, seed: int = 0x5EED, rank: int = 0, world: int = 1, group=None,
+                    grid_frames: int = 1920, on_point=None) -> List[SweepPoint]:
+    """BASELINE configs[4] with launches shared across cells (HipModeGrid): this rank's shard of every point goes
+    through the grid grid_frames frames at a time, the counters of all 30 x len(snr_points) points accumulate on the
+    device and meet in ONE all-reduce.  Same counters as mode_sweep (same point seeds, same trials)."""
+    import torch
+    snr_points = [float(x) for x in snr_points]
+    lo, hi = shard_range(frames_per_point, rank, world)
+    t0 = time.perf_counter()
+    total = None
+    grid = None
+    f0 = lo
+    while f0 < hi or total is None:
+        n = min(grid_frames, max(hi - f0, 0))
+        if n == 0:                                                  # an empty shard still takes part in the all-reduce
+            M, R, S = len(CFG5_MODULATIONS), len(CFG5_RATES), len(snr_points)
+            total = torch.zeros((M, R, S, 8), dtype=torch.int64, device="cuda")
+            break
+        if grid is None or grid.n != n:
+            grid = HipModeGrid(CFG5_MODULATIONS, CFG5_RATES, snr_points, frames_per_point=n, channel=channel, delay_ms=delay_ms,
+                               doppler_hz=doppler_hz)
+        grid.generate(f0, seed=seed)
+        c = grid.receive().contiguous()
+        total = c.clone() if total is None else total + c
+        f0 += n
+    block = allreduce_counters(total.reshape(-1, 8), group=group).cpu()
+    dt = (time.perf_counter() - t0) / max(block.shape[0], 1)
+    out = []
+    S = len(snr_points)
+    for ci, (mod, rate) in enumerate((m, r) for m in CFG5_MODULATIONS for r in CFG5_RATES):
+        for si, snr in enumerate(snr_points):
+            p = SweepPoint(label=f"{Modulation(mod).name} {CodeRate(rate).name}", snr_db=snr, trials=int(frames_per_point),
+                           seed=point_seed(seed, ci * S + si), counters=counters_dict(block[ci * S + si]), seconds=dt)
+            if p.counters["frames"] != frames_per_point:
+                raise RuntimeError(f"grid point {p.label} @ {snr} dB counted {p.counters['frames']} of {frames_per_point} trials")
+            out.append(p)
+            if on_point is not None:
+                on_point(p)
     return out
 
 

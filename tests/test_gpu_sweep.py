@@ -120,6 +120,32 @@ def test_run_points_equals_run_per_point():
         assert shard.run_points(5, 5, snrs, seeds).sum().item() == 0
 
 
+def test_mode_grid_shares_launches_across_cells():
+    """HipModeGrid — one demodulation per modulation over the frames of all its rates, one LDPC launch per rate over the
+    soft bits of all modulations (ultra_hip_demod_batch_strided + ultra_hip_ldpc_decode_blocks) — gives every cell and
+    every SNR point exactly the counters of that cell's own HipModemShard.run_points."""
+    from projectultra_amd import CodeRate, Modulation
+    from projectultra_amd.sweep import HipModeGrid, HipModemShard, nvis_cell_config, point_seed
+    mods = [Modulation.DBPSK, Modulation.D8PSK, Modulation.QAM16, Modulation.QAM32]
+    rates = [CodeRate.R1_4, CodeRate.R2_3, CodeRate.R5_6]
+    snrs = [0.0, 6.0, 12.0]
+    n, lo = 384, 64
+    grid = HipModeGrid(mods, rates, snrs, frames_per_point=n)
+    grid.generate(lo, seed=11)
+    got = grid.receive().cpu().numpy()
+    assert got.shape == (len(mods), len(rates), len(snrs), 8)
+    for mi, m in enumerate(mods):
+        for ri, r in enumerate(rates):
+            shard = HipModemShard(nvis_cell_config(m, r), channel="awgn")
+            seeds = [point_seed(11, (mi * len(rates) + ri) * len(snrs) + si) for si in range(len(snrs))]
+            want = shard.run_points(lo, lo + n, snrs, seeds).cpu().numpy()
+            assert np.array_equal(got[mi, ri], want), (m, r)
+            assert (want[:, 0] == n).all()
+    assert got[..., 1].min() == 0 and got[..., 1].max() == n      # the grid spans clean and hopeless cells
+    again = grid.receive().cpu().numpy()                          # buffers are reused pass after pass
+    assert np.array_equal(again, got)
+
+
 def test_round2_entries_refuse_bad_arguments():
     """The C-ABI entries added this round check what they are handed before any kernel is launched (a faulting kernel can
     take the whole host down): aliasing / short strides for the channel CFO shift, a point count the grid cannot hold or

@@ -34,6 +34,7 @@ def main():
     ap.add_argument("--snr", type=float, nargs="*", default=None, help="SNR points in dB (default: the config's axis)")
     ap.add_argument("--seed", type=lambda s: int(s, 0), default=0x5EED)
     ap.add_argument("--batch", type=int, default=0)
+    ap.add_argument("--per-cell", action="store_true", help="cfg5: one receive chain per cell (mode_sweep) instead of the shared grid")
     ap.add_argument("--out", default="")
     args = ap.parse_args()
 
@@ -67,8 +68,12 @@ def main():
     else:
         trials = args.trials or 12800
         snrs = args.snr if args.snr else sw.CFG5_SNR_POINTS
-        pts = sw.mode_sweep(None, snrs, frames_per_point=trials, channel=args.channel, seed=args.seed, rank=rank, world=world,
-                            batch=args.batch or (1 << 16), on_point=show)
+        if args.per_cell:
+            pts = sw.mode_sweep(None, snrs, frames_per_point=trials, channel=args.channel, seed=args.seed, rank=rank, world=world,
+                                batch=args.batch or (1 << 16), on_point=show)
+        else:                                        # launches shared across cells (HipModeGrid): same counters
+            pts = sw.mode_sweep_grid(snrs, frames_per_point=trials, channel=args.channel, seed=args.seed, rank=rank, world=world,
+                                     grid_frames=args.batch or 1920, on_point=show)
         meta = dict(config="BASELINE.json configs[4]", geometry="1024-FFT, 59 carriers, CP 96 (presets::nvis_mode)", channel=args.channel,
                     snr_axis="SNR dB over the audio band (tools/test_nvis_mode.cpp:78-86)", trials_per_point=trials)
     torch.cuda.synchronize()
