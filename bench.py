@@ -755,6 +755,7 @@ def main():
             "dtype": "f32", "data": wl.data,
             "config": {"workload": wl.workload, "name": args.config, "trials_per_gpu_per_step": wl.units_per_step,
                        "trials_per_step_all_gpus": getattr(wl, "total_units", wl.units_per_step * world),
+                       "launch_units": wl.launch_units,
                        "bytes_per_trial": wl.bytes_per_unit, "parallelism": wl.parallelism},
             "achieved_hbm_GBps": value * wl.bytes_per_unit / 1e9,
             "hbm_frac_of_peak": value * wl.bytes_per_unit / 1e9 / (HBM_PEAK_GBPS * world),

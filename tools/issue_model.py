@@ -132,8 +132,8 @@ def parse_pmc(path):
 
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument("--pmc", nargs="*", default=[str(ROOT / "profiles" / f) for f in ("r02_sq_counters.txt", "r02_sq_counters_cfg4.txt",
-                                                                                     "r02_sq_counters_raw.txt", "r02_sq_counters_chirp.txt")],
+    ap.add_argument("--pmc", nargs="*", default=[str(ROOT / "profiles" / f) for f in ("r03_sq_counters.txt", "r03_sq_counters_cfg2.txt", "r03_sq_counters_cfg4.txt",
+                                                                                     "r03_sq_counters_cfg5.txt", "r03_sq_counters_raw.txt", "r02_sq_counters_chirp.txt")],
                     help="pmc_sweep.sh summaries (kernels of later files do not replace those of earlier ones)")
     ap.add_argument("--asm", default="")
     ap.add_argument("--cus", type=int, default=256)
@@ -158,7 +158,9 @@ def main():
     want = [("ldpc_totals_kernelILi3ELi6ELi3ELb0", "ldpc_totals_kernel<3, 6, 3, false", True),
             ("ldpc_decode_kernelILi3ELi6E", "ldpc_decode_kernel<3, 6", True),
             ("ldpc_decode_kernelILi8ELi3E", "ldpc_decode_kernel<8, 3", True),
-            ("mix_fft_kernelILi10E", "mix_fft_kernel<10>", False), ("track_kernelILi6E", "track_kernel<6>", False),
+            ("mix_fft2_kernelILi10E", "mix_fft2_kernel<10>", False), ("mix_fft_kernelILi10E", "mix_fft_kernel<10>", False),
+            ("mix_fft_kernelILi9E", "mix_fft_kernel<9>", False), ("track_all_kernelILi6E", "track_all_kernel<6>", False),
+            ("track_kernelILi6E", "track_kernel<6>", False), ("track_kernelILi2E", "track_kernel<2>", False),
             ("track_pilot_kernelILi16E", "track_pilot_kernel<16>", False), ("cfo_walk_kernel", "cfo_walk_kernel", False),
             ("acquire_kernelILi10E", "acquire_kernel<10>", False), ("chirp_sync_kernel", "chirp_sync_kernel", False)]
     for key, pmc_key, is_ldpc in want:

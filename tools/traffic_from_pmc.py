@@ -10,8 +10,8 @@ units = int(sys.argv[3]) if len(sys.argv) > 3 else 262144
 commit = sys.argv[4] if len(sys.argv) > 4 else None
 # (substring of the kernel name, key in the output) — the key is the kernel CLASS bench.py reports (ultra_hip_kernel_class):
 # both decoders (ldpc_totals_kernel for R2/3 .. R5/6, ldpc_decode_kernel otherwise) are "ldpc_decode_kernel" there
-ALIASES = {"ldpc_totals_kernel": "ldpc_decode_kernel"}
-KEYS = ("ldpc_totals_kernel", "ldpc_decode_kernel", "mix_fft_kernel", "track_pilot_kernel", "track_kernel", "cfo_walk_kernel", "init_state_kernel",
+ALIASES = {"ldpc_totals_kernel": "ldpc_decode_kernel", "mix_fft2_kernel": "mix_fft_kernel", "track_all_kernel": "track_kernel"}
+KEYS = ("ldpc_totals_kernel", "ldpc_decode_kernel", "mix_fft2_kernel", "mix_fft_kernel", "track_all_kernel", "track_pilot_kernel", "track_kernel", "cfo_walk_kernel", "init_state_kernel",
         "count_errors_kernel", "acquire_kernel", "train_kernel")
 acc = collections.defaultdict(lambda: collections.defaultdict(list))
 for c in ("FETCH_SIZE", "WRITE_SIZE"):
