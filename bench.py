@@ -49,16 +49,18 @@ CLOCK_HZ = 2.4e9                # MI355X peak engine clock (MI355X_MICROARCH.md)
 # LDS-pipeline cycles per wave-instruction (MI355X_MICROARCH.md, LDS table; re-measured in profiles/r02_issue_table.txt)
 LDS_CYC = dict(read_b32=2, write_b32=4, write_addtid_b32=2)
 # Compute-side roofline: issue cycles per unit of work and kernel, = (dynamic instruction counts per unit from rocprofv3
-# --pmc SQ_INSTS_VALU / _SALU / _LDS, profiles/r02_sq_counters.txt) x (measured cost per instruction of the kernel's own
-# opcode mix, profiles/r02_issue_table.txt), as tools/issue_model.py derives them into profiles/r02_issue_model.txt.
+# --pmc SQ_INSTS_VALU / _SALU / _LDS, profiles/r03_sq_counters.txt) x (measured cost per instruction of the kernel's own
+# opcode mix, profiles/r02_issue_table.txt), as tools/issue_model.py derives them into profiles/r03_issue_model.txt.
 #   valu / salu: cycles of ONE SIMD per unit (a CU has 4 SIMDs); lds: cycles of the CU's single LDS pipeline per unit.
 #   unit: "cw_iteration" = one executed BP iteration of one codeword; "frame" = one frame of one launch.
 ISSUE_CYCLES = {
     "ldpc_totals R3/4": dict(unit="cw_iteration", valu=162.5 * 3.38, salu=80.4 * 4.19, lds=61.5 * 2.13),
-    "mix_fft_kernel": dict(unit="frame", valu=1120 * 3.44, salu=136 * 4.19, lds=81.4 * 3.54),
-    "track_kernel": dict(unit="frame", valu=198.5 * 3.30, salu=118 * 4.19, lds=20.9 * 3.94),
-    "track_pilot_kernel": dict(unit="frame", valu=151 * 3.48, salu=61.8 * 4.19, lds=4.75 * 5.08),
-    # per raw stream of 14,400 samples at 30 dB (profiles/r02_sq_counters_raw.txt: 65,536 streams per launch)
+    # round 3 (profiles/r03_sq_counters.txt -> profiles/r03_issue_model.txt): the two-wavefront transform, the deferred
+    # carrier half (unit: one symbol of one frame), the pilot half with its record for the carrier half
+    "mix_fft_kernel": dict(unit="frame", valu=1261.5 * 3.47, salu=268.6 * 4.19, lds=104.4 * 3.28),
+    "track_kernel": dict(unit="frame_symbol", valu=182.3 * 3.29, salu=116.2 * 4.19, lds=19.9 * 4.01),
+    "track_pilot_kernel": dict(unit="frame", valu=163.5 * 3.54, salu=63.9 * 4.19, lds=4.75 * 5.08),
+    # per raw stream of 14,400 samples at 30 dB (profiles/r03_sq_counters_raw.txt: 65,536 streams per launch)
     "acquire_kernel": dict(unit="stream", valu=952.8e3 * 3.35, salu=134.7e3 * 4.19, lds=166.4e3 * 3.33),
 }
 
@@ -688,14 +690,17 @@ def main():
             cu = props.multi_processor_count
             u = dict(valu=m["valu"] * units / (4 * cu * t), salu=m["salu"] * units / (4 * cu * t), lds=m["lds"] * units / (cu * t))
             kernels[name]["issue"] = dict(unit=m["unit"], units_per_step=units, cycles_per_unit={k: m[k] for k in ("valu", "salu", "lds")},
-                                          busy_frac=u, clock_hz=CLOCK_HZ, source="profiles/r02_issue_model.txt")
+                                          busy_frac=u, clock_hz=CLOCK_HZ, source="profiles/r03_issue_model.txt")
             return u
         if wl.name == "cfg3":
             executed = stats["iters_sum"] / world + (stats["frames"] - stats["ldpc_fail"]) / world
             views = {"ldpc_decode_kernel": issue_view("ldpc_decode_kernel", "ldpc_totals R3/4", executed, kernels["ldpc_decode_kernel"]["ms_per_step"])}
             for kname in ("mix_fft_kernel", "track_kernel", "track_pilot_kernel"):
                 if kname in kernels:
-                    views[kname] = issue_view(kname, kname, wl.launch_units * kernels[kname]["launches_per_step"], kernels[kname]["ms_per_step"])
+                    # the carrier half is ONE launch over every (symbol, frame): its unit is a frame-symbol
+                    units = (wl.launch_units * wl.ctx.cfg.n_data_symbols if kname == "track_kernel"
+                             else wl.launch_units * kernels[kname]["launches_per_step"])
+                    views[kname] = issue_view(kname, kname, units, kernels[kname]["ms_per_step"])
             if dom in views:
                 res = max(views[dom], key=views[dom].get)
                 roofline.update({"bound": res, "compute": {"resource": {"valu": "vector issue (4 SIMDs per CU)", "salu": "scalar issue",
@@ -728,7 +733,7 @@ def main():
         roofline["note"] = ("achieved/peak/frac = HBM view: algorithmic bytes per launch / mean launch duration (HIP events around every "
                             "launch of a repeat of the timed steps) against 8 TB/s. bound = the busiest unit of the dominant kernel where an "
                             "issue model exists (compute.frac: issue cycles from PMC instruction counts x measured per-opcode costs, "
-                            "profiles/r02_issue_model.txt, over the cycles the launch had; kernels.*.issue for the others); 'lds' with the "
+                            "profiles/r03_issue_model.txt, over the cycles the launch had; kernels.*.issue for the others); 'lds' with the "
                             "cycle model of DESIGN.md 4.2 for the message-passing decoder (cfg4); 'hbm' otherwise")
 
     # ---- CPU baseline: the compiled reference on the host's physical cores, bounded sample (rank 0, N=1 only) ----
