@@ -208,7 +208,8 @@ constexpr int kPwPilots = 32;                               // pilots per frame 
 constexpr int kTrkRecFloats = 96;                           // three cache lines: 8 scalars (below), then c32 Hp_derotated[<= 32]
 constexpr int kTrkRecHp = 8;                                // (<= 12 pilots touch one line, the headline's 15 two)
 enum { tk_noise = 0, tk_timing, tk_cfo, tk_snr, tk_phase, tk_count };
-constexpr int kFqFloats = 256;      // c32 Fq[128] per frame: bins [0,64) and [N-64,N)
+// Fq row of a frame (and symbol): c32[2 * D.fq_half] = bins [0, fq_half) then [N - fq_half, N), fq_half = 32 or 64
+__device__ __forceinline__ int fq_index(const DemodConst& D, int bin) { return (bin < D.fq_half) ? bin : D.fq_half + (bin - (D.fft - D.fq_half)); }
 // Per-frame phase table of the next symbol's CFO rotation (cfo_walk_kernel / pilot_walk_kernel -> mix_fft kernels),
 // 32-bit words: [0] number of segments | samples covered << 8, [1] the tracker's CFO in Hz (float bits), [2] phase after
 // the covered samples (float bits), [3] phase the symbol starts with; then {start, base, step} per segment.  It carries
@@ -479,8 +480,10 @@ __device__ __forceinline__ void symbol_to_freq(FftShared<LOG2N>& sh, const Demod
         }
         UH_STAMP(7);
         UH_STAMP(8);
-        fq_out[lane] = v[0];
-        fq_out[64 + lane] = v[P - 1];
+        // bins `lane` and N - 64 + lane: the row keeps the fq_half of each side that lie next to DC
+        const int fh = D.fq_half;
+        if (lane < fh) fq_out[lane] = v[0];
+        if (lane >= 64 - fh) fq_out[fh + lane - (64 - fh)] = v[P - 1];
     }
     wave_sync();
     UH_STAMP(9);
@@ -855,9 +858,9 @@ __global__ __launch_bounds__(kWave, 5) void track_pilot_kernel(const DemodConst*
     __shared__ __attribute__((aligned(16))) float s_sums[FPW][8];
     const DemodConst& D = *Dp;
     const int lane = threadIdx.x, sub = lane % G, grp = lane / G;
-    const int N = D.fft, np = D.n_pilot;
+    const int np = D.n_pilot;
     const bool is_pilot = sub < np;
-    auto fq_of = [&](int bin) { return (bin < 64) ? bin : 64 + (bin - (N - 64)); };
+    auto fq_of = [&](int bin) { return fq_index(D, bin); };
     const int ps = is_pilot ? D.pilot_slot[sub] : 0;
     const int pilot_fq = fq_of(D.bin[ps]), pilot_k = D.k_of[ps];
     const c32 pilot_seq = is_pilot ? D.pilot_seq[sub] : mk(1.0f, 0.0f);
@@ -866,7 +869,7 @@ __global__ __launch_bounds__(kWave, 5) void track_pilot_kernel(const DemodConst*
         const bool act = base + grp < n_frames;
         const int frame = act ? base + grp : n_frames - 1;     // idle groups shadow the last frame, stores masked
         float* st = state + (size_t)frame * kStFloats;
-        const c32* fq = fq_all + (size_t)frame * 128;
+        const c32* fq = fq_all + (size_t)frame * (2 * D.fq_half);
         Track tr;
         tr.freq_offset_hz = st[st_cfo]; tr.freq_offset_filtered = st[st_cfo_filt]; tr.cfo_phase = st[st_cfo_phase];
         tr.noise_variance = st[st_noise]; tr.snr_linear = st[st_snr]; tr.timing = st[st_timing];
@@ -1260,7 +1263,7 @@ __device__ __forceinline__ void lts_finish(TrackShared& sh, const DemodConst& D,
 // ---------------------------------------------------------------------------
 // Kernels.  All three use one 64-lane workgroup per frame with a grid-stride loop over frames.
 //   state   [n_frames][kStFloats] f32 workspace records
-//   fq      [n_frames][128] c32 workspace: the used FFT bins of the symbol in flight
+//   fq      [n_frames][2 * fq_half] c32 workspace: the used FFT bins of the symbol in flight
 
 // Fresh demodulator per frame (demodulator.cpp:26-43 + SYNCED transition :533-591, or the reset
 // block of processPresynced :868-905).
@@ -1412,7 +1415,7 @@ __global__ __launch_bounds__(kWave, 2) void mix_fft_kernel(
         const float cfo = tab ? __uint_as_float(tab[1]) : 0.0f;
         float phase = tab ? __uint_as_float(tab[3]) : 0.0f;
         Stamps stamps;
-        symbol_to_freq<LOG2N>(sh, D, cfo, phase, nco + (size_t)(sym + ds) * D.sym_len, twiddle, fq + (size_t)w * 128,
+        symbol_to_freq<LOG2N>(sh, D, cfo, phase, nco + (size_t)(sym + ds) * D.sym_len, twiddle, fq + (size_t)w * (2 * D.fq_half),
                               seg_tab ? seg_tab + (size_t)frame * kSegTabWords : nullptr, stamps);
         const int next = w + (int)gridDim.x;
         if (next < total) prefetch_symbol<LOG2N>(sh, D, item_base(next));
@@ -1467,6 +1470,10 @@ __global__ __launch_bounds__(2 * kWave) __attribute__((amdgpu_waves_per_eu(UH_MI
     int os_ds = -1;
     MixItem cur;
     c32 pending = mk(0.0f, 0.0f);                          // the previous item's bin of this lane, stored with the next request
+    // wavefront 0 holds bins `lane`, wavefront 1 bins N - 64 + lane; the row keeps the fq_half of each side next to DC
+    const int fh = D.fq_half;
+    const bool fq_mine = h ? (lane >= 64 - fh) : (lane < fh);
+    const int fq_slot = h ? fh + lane - (64 - fh) : lane;
     int w_stored = -1;
     int w = blockIdx.x;
     if (w < total) request(cur, w);
@@ -1488,7 +1495,7 @@ __global__ __launch_bounds__(2 * kWave) __attribute__((amdgpu_waves_per_eu(UH_MI
         c32 bin;
         symbol_to_freq2<LOG2N>(sh, D, h, lane, cur, lc, twiddle, bin, par,
                                [&]() {
-                                   if (w_stored >= 0) fq[(size_t)w_stored * 128 + 64 * h + lane] = pending;
+                                   if (w_stored >= 0 && fq_mine) fq[(size_t)w_stored * (2 * fh) + fq_slot] = pending;
                                    if (next < total) request(cur, next);
                                }, stamps);
         pending = bin;
@@ -1496,7 +1503,7 @@ __global__ __launch_bounds__(2 * kWave) __attribute__((amdgpu_waves_per_eu(UH_MI
         UH_STAMP(10);
         stamps.store((size_t)w * 2 + h, lane);
     }
-    if (w_stored >= 0) fq[(size_t)w_stored * 128 + 64 * h + lane] = pending;
+    if (w_stored >= 0 && fq_mine) fq[(size_t)w_stored * (2 * fh) + fq_slot] = pending;
 }
 
 // mode 0: data symbol (updateChannelEstimate + equalize + demodulateSymbol)
@@ -1517,9 +1524,9 @@ __device__ __forceinline__ void store_track(float* __restrict__ st, const Track&
     st[st_count] = (float)tr.snr_symbol_count; st[st_since] = (float)tr.symbols_since_sync;
 }
 __device__ __forceinline__ LaneConst lane_constants(const DemodConst& D) {
-    const int lane = threadIdx.x, N = D.fft;
+    const int lane = threadIdx.x;
     LaneConst lc;
-    auto fq_of = [&](int bin) { return (bin < 64) ? bin : 64 + (bin - (N - 64)); };
+    auto fq_of = [&](int bin) { return fq_index(D, bin); };
     const int ps = (lane < D.n_pilot) ? D.pilot_slot[lane] : 0;
     lc.pilot_slot = ps; lc.pilot_fq = fq_of(D.bin[ps]); lc.pilot_k = D.k_of[ps];
     lc.pilot_seq = (lane < D.n_pilot) ? D.pilot_seq[lane] : mk(1.0f, 0.0f);
@@ -1541,7 +1548,7 @@ __global__ __launch_bounds__(kWave, 4) void train_kernel(const DemodConst* __res
     const LaneConst lc = lane_constants(D);
     for (int frame = blockIdx.x; frame < n_frames; frame += gridDim.x) {
         float* st = state + (size_t)frame * kStFloats;
-        const c32* fq = fq_all + (size_t)frame * 128;
+        const c32* fq = fq_all + (size_t)frame * (2 * D.fq_half);
         Track tr;
         load_track(st, tr);
         sh.H[lane] = reinterpret_cast<const c32*>(st + kStH)[lane];
@@ -1588,7 +1595,7 @@ __global__ __launch_bounds__(kWave, 6) void track_kernel(
         c32 dprev = D.differential ? reinterpret_cast<const c32*>(st + kStDprev)[lane] : mk(1.0f, 0.0f);
         wave_sync();
         for (int ds = 0; ds < n_sym_batch; ++ds) {
-            const c32* fq = fq_all + ((size_t)ds * n_frames + frame) * 128;
+            const c32* fq = fq_all + ((size_t)ds * n_frames + frame) * (2 * D.fq_half);
             if (scalar_pilot_half) { tr.ppc = mk(1.0f, 0.0f); tr.has_prev = 0; tr.snr_symbol_count++; }
             if (!D.presynced || D.n_pilot != 0) finish_channel_estimate(sh, D, lc, tr);
             equalize_demap<MOD>(sh, D, lc, tr, dprev, fq,
@@ -1657,7 +1664,7 @@ __global__ __launch_bounds__(kWave, 6) void track_all_kernel(const DemodConst* _
         c32 dprev = mk(1.0f, 0.0f);
         wave_sync();
         finish_channel_estimate(sh, D, lc, tr);
-        equalize_demap<MOD>(sh, D, lc, tr, dprev, fq_all + (size_t)w * 128,
+        equalize_demap<MOD>(sh, D, lc, tr, dprev, fq_all + (size_t)w * (2 * D.fq_half),
                             llr + (size_t)frame * llr_stride + (size_t)(sym0 + ds) * D.llrs_per_symbol);
         if (state_out && lane == 0 && ds == n_sym_batch - 1) {   // the tracker after the last symbol of the launch
             float* so = state_out + (size_t)frame * ULTRA_HIP_STATE_FLOATS;

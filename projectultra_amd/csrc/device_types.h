@@ -22,7 +22,8 @@ struct DemodConst {
     int32_t fft, log2_fft, cp, sym_len;
     int32_t n_train, n_data_sym, n_carriers, n_data, n_pilot, n_interp;
     int32_t modulation, bits, differential, presynced;
-    int32_t llrs_per_symbol, llrs_per_frame, frame_samples, _pad0;
+    int32_t llrs_per_symbol, llrs_per_frame, frame_samples;
+    int32_t fq_half;            // 32 or 64: a frame's Fq row holds bins [0, fq_half) and [fft - fq_half, fft) (every used carrier)
     float ce_margin;            // soft_demap::getCEErrorMargin(mod)
     float sample_rate;          // (float) config.sample_rate
     float symbol_duration;      // (float)getSymbolDuration() / (float)sample_rate
@@ -38,8 +39,6 @@ struct DemodConst {
     int16_t interp_lo[kMaxCarriers];  // slot of lower pilot or -1
     int16_t interp_hi[kMaxCarriers];
     float interp_alpha[kMaxCarriers];
-    int16_t pilot_fq[kMaxCarriers];   // pilot i -> entry of the frame's Fq row (bins [0,64) then [fft-64, fft)); pilot_walk_kernel
-    int16_t pilot_k[kMaxCarriers];    // pilot i -> signed carrier number
     c32 pilot_seq[kMaxCarriers];      // +-1 + 0j
     c32 sync_seq[kMaxCarriers];       // Zadoff-Chu
 };

@@ -655,11 +655,9 @@ inline int build_demod(const ultra_hip_config& c, DemodConst& D, std::vector<c32
     }
     D.llrs_per_symbol = D.n_data * D.bits;
     D.llrs_per_frame = D.llrs_per_symbol * D.n_data_sym;
-    for (int i = 0; i < D.n_pilot; ++i) {
-        const int bin = D.bin[D.pilot_slot[i]];
-        D.pilot_fq[i] = (int16_t)((bin < 64) ? bin : 64 + (bin - ((int)c.fft_size - 64)));
-        D.pilot_k[i] = D.k_of[D.pilot_slot[i]];
-    }
+    // the transform keeps bins [0, fq_half) and [fft - fq_half, fft): 32 each when every carrier lies within +-31 (30 and 59
+    // carriers do), 64 each otherwise — half the row, half the traffic of three kernels
+    D.fq_half = (neg_limit <= 31 && pos_limit <= 31) ? 32 : 64;
 
     // Zadoff-Chu (u = 1) and BPSK pilots
     const size_t N = c.num_carriers, u = 1;

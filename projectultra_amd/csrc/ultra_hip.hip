@@ -146,13 +146,13 @@ int ensure_demod_workspace(ultra_hip_ctx* ctx, size_t n_frames) {
     ctx->ws_demod_frames = n_frames;
     return ULTRA_HIP_OK;
 }
-// used FFT bins: one row of 128 per frame — per frame AND symbol where all symbols are transformed in one launch
+// used FFT bins: one row of 2 * fq_half (64 or 128) per frame — per frame AND symbol where all symbols are transformed in one launch
 int ensure_fq_workspace(ultra_hip_ctx* ctx, size_t rows) {
     if (ctx->ws_fq_rows >= rows) return ULTRA_HIP_OK;
     UH_HIP(hipStreamSynchronize(ctx->stream));
     if (ctx->d_ws_fq) { (void)hipFree(ctx->d_ws_fq); ctx->d_ws_fq = nullptr; }
     ctx->ws_fq_rows = 0;
-    UH_HIP(hipMalloc(&ctx->d_ws_fq, rows * (size_t)128 * sizeof(c32)));
+    UH_HIP(hipMalloc(&ctx->d_ws_fq, rows * (size_t)(2 * ctx->h_demod.fq_half) * sizeof(c32)));
     ctx->ws_fq_rows = rows;
     return ULTRA_HIP_OK;
 }
@@ -245,7 +245,7 @@ int launch_demod(ultra_hip_ctx* ctx, const float* d_audio, size_t frame_stride, 
                                d_audio, frame_stride, d_frame_offset, (int)n_frames, s_begin, ctx->d_ws_fq, seg_tab, n_sym);
     }
     for (int s = s_begin; s < s_end; ++s) {
-        c32* fq_s = ctx->d_ws_fq + ((all_symbols_at_once || deferred) ? (size_t)(s - s_begin) * n_frames * 128 : (size_t)0);
+        c32* fq_s = ctx->d_ws_fq + ((all_symbols_at_once || deferred) ? (size_t)(s - s_begin) * n_frames * (size_t)(2 * D.fq_half) : (size_t)0);
         float* rec_s = deferred ? ctx->d_ws_trk + (size_t)(s - s_begin) * n_frames * dev::kTrkRecFloats : nullptr;
         // the first symbol of a SYNCED batch without initial offsets is at CFO 0 in every frame: nothing to walk yet
         const bool first_at_zero = s == 0 && !D.presynced && !cfo_given;
