@@ -22,5 +22,5 @@ for c in FETCH_SIZE WRITE_SIZE; do
 done
 UNITS=$(python3 -c "import json;print(json.load(open('$OUT/bench_$CFG$SUF.json'))['config']['launch_units'])")
 python3 tools/traffic_from_pmc.py "$OUT" $CFG $UNITS $COMMIT > "$OUT/traffic_$CFG$SUF.json"
-rm -rf "$OUT/ks" "$OUT"/pmc_*/ 2>/dev/null
+rm -rf "$OUT/ks" "$OUT"/pmc_FETCH_SIZE "$OUT"/pmc_WRITE_SIZE 2>/dev/null
 head -c 600 "$OUT/bench_$CFG$SUF.json"; echo; head -12 "$OUT/kernel_stats_$CFG$SUF.csv" | cut -c1-170; cat "$OUT/traffic_$CFG$SUF.json"
