@@ -236,6 +236,7 @@ int ultra_hip_ldpc_decode_blocks(ultra_hip_ctx* ctx, const float* d_llr, size_t 
  *   d_audio   [n_frames] rows of frame_stride floats, row f starting at symbol first_symbol of frame f
  *   d_llr     [n_frames][n_data * llrs_per_symbol] f32, n_data = the data symbols among those of this call
  *   d_state   [n_frames][ULTRA_HIP_STATE_FLOATS] or NULL: the tracker after the last symbol of this call
+ * ULTRA_ENTRY_PRESYNCED: the first call takes all training symbols (n_symbols >= training_symbols), later calls start behind them.
  * The context must have been created with n_data_symbols >= the frame's length (<= 251: process() gives up after
  * MAX_SYMBOLS_BEFORE_TIMEOUT + 1 symbols) and must not run another batch in between. */
 int ultra_hip_demod_stream_batch(ultra_hip_ctx* ctx, const float* d_audio, size_t frame_stride, const float* d_cfo_hz,

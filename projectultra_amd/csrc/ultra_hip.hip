@@ -743,7 +743,9 @@ int ultra_hip_demod_stream_batch(ultra_hip_ctx* ctx, const float* d_audio, size_
     if (!d_audio || !d_llr || n_frames > 0x7fffffffull || first_symbol >= total || n_symbols > total - first_symbol ||
         frame_stride < (size_t)n_symbols * (size_t)D.sym_len)
         return ULTRA_HIP_ERR_INVALID_ARG;
-    if (D.n_train != 0 && first_symbol != 0 && first_symbol < (uint32_t)D.n_train) return ULTRA_HIP_ERR_INVALID_ARG;
+    // the presynced entry's training symbols are one unit (estimateCFOFromTraining reads both): the first call takes them all
+    if (D.n_train != 0 && ((first_symbol == 0 && n_symbols < (uint32_t)D.n_train) || (first_symbol != 0 && first_symbol < (uint32_t)D.n_train)))
+        return ULTRA_HIP_ERR_INVALID_ARG;
     DeviceGuard guard(ctx->device);
     // the kernels address symbol s of a frame at row + s * sym_len and its LLRs at row + (s - n_train) * llrs_per_symbol
     const uint32_t first_data = first_symbol > (uint32_t)D.n_train ? first_symbol - (uint32_t)D.n_train : 0u;

@@ -193,6 +193,34 @@ class ReceiveContext:
                                              state.data_ptr() if want_state else None), "ultra_hip_demod_batch")
         return (llr, state) if want_state else llr
 
+    def demod_stream(self, audio, first_symbol: int, n_symbols: int, cfo_hz=None, cfo_phase=None, want_state: bool = False):
+        """Symbols [first_symbol, first_symbol + n_symbols) of every frame, continuing from the tracker the previous call on
+        this context left behind (ultra_hip_demod_stream_batch; first_symbol == 0 starts afresh from cfo_hz / cfo_phase).
+        audio rows start AT symbol first_symbol.  Returns the LLRs of the data symbols among them [n][n_data * llrs_per_symbol]
+        (+ the tracker after the last symbol [n][8])."""
+        torch = _torch()
+        self._check_stream()
+        audio = self._dev(audio, torch.float32, "audio")
+        if audio.dim() == 1:
+            audio = audio.reshape(1, -1)
+        g = self.geometry
+        n = audio.shape[0]
+        if audio.shape[1] < n_symbols * g.symbol_samples:
+            raise _lib.UltraHipError(-1, "demod_stream: audio rows must hold n_symbols symbols")
+        n_train = int(self.cfg.training_symbols)
+        first_data = max(first_symbol - n_train, 0)
+        n_data = max(first_symbol + n_symbols - n_train, 0) - first_data
+        cfo, cph = self._opt(cfo_hz, n), self._opt(cfo_phase, n)
+        llr = torch.empty((n, max(n_data, 1) * g.llrs_per_symbol), dtype=torch.float32, device=self.device)
+        state = torch.empty((n, _lib.STATE_FLOATS), dtype=torch.float32, device=self.device) if want_state else None
+        check(self.lib.ultra_hip_demod_stream_batch(self._ctx, audio.data_ptr(), self._row_stride(audio),
+                                                    cfo.data_ptr() if cfo is not None else None,
+                                                    cph.data_ptr() if cph is not None else None, n, int(first_symbol), int(n_symbols),
+                                                    llr.data_ptr(), state.data_ptr() if want_state else None),
+              "ultra_hip_demod_stream_batch")
+        llr = llr[:, :n_data * g.llrs_per_symbol]
+        return (llr, state) if want_state else llr
+
     def demod_into(self, audio, llr, cfo_hz=None, cfo_phase=None):
         """Demodulate into the rows of a caller-owned LLR array whose row stride may exceed llrs_per_frame
         (ultra_hip_demod_batch_strided): llr = a [n][>= llrs_per_frame] f32 view with unit column stride — e.g. a row

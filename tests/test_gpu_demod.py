@@ -506,3 +506,63 @@ def test_sync_golden_reference():
         assert [int(q["detected"]), int(q["up_chirp_start"]), int(q["down_chirp_start"]), int(q["start_sample"])] == list(ints)
         assert np.float32(q["cfo_hz"]).tobytes() == fl[0].tobytes()
         assert np.float32(q["correlation"]).tobytes() == max(fl[1], fl[2]).tobytes()
+
+
+@pytest.mark.parametrize("fft,mod,rate,kw", [(1024, "QAM16", "R3_4", {}), (512, "DQPSK", "R1_2", {}), (1024, "DQPSK", "R1_4", dict(pilot_spacing=2, use_pilots=1)),
+                                             (512, "QPSK", "R2_3", {}), (1024, "QAM32", "R1_2", dict(entry=1))])
+def test_streamed_symbols_equal_the_batch(oracle, fft, mod, rate, kw):
+    """ultra_hip_demod_stream_batch: the symbols of a frame demodulated as they arrive — in any split — give the LLRs and the
+    final tracker of one batch call (and of the oracle): deferred and per-symbol carrier halves, zero-CFO and rotating
+    layouts, the presynced entry with its training symbols, with and without initial offsets."""
+    cfg = make_config(fft, mod, rate, n_data_symbols=9, **kw)
+    g = geometry(cfg)
+    n = 96
+    audio, _ = oracle.make_batch(cfg, n, seed=77, channel="watterson", snr_db=24.0)
+    rng = np.random.default_rng(5)
+    n_train = int(cfg.training_symbols)
+    total = n_train + 9
+    for with_cfo in (False, True):
+        cfo = rng.normal(0, 6.0, n).astype(np.float32) if with_cfo else None
+        ph = rng.uniform(-3, 3, n).astype(np.float32) if (with_cfo and n_train) else None
+        want = oracle.demod_decode_batch(cfg, audio, cfo_hz=cfo, cfo_phase=ph, n_threads=16)
+        ctx = context_for(cfg)
+        whole, st_whole = ctx.demod(audio, cfo_hz=cfo, cfo_phase=ph, want_state=True)
+        assert beq(whole.cpu().numpy(), want["llr"])
+        first = max(n_train, 1)                                       # the training symbols of the presynced entry go in one call
+        for split in ([total], [first] + [1] * (total - first), [first, 3, total - first - 3], [total - 1, 1]):
+            ctx2 = context_for(cfg)
+            parts, s0 = [], 0
+            for k in split:
+                a = audio[:, s0 * g.symbol_samples:(s0 + k) * g.symbol_samples]
+                llr, st = ctx2.demod_stream(np.ascontiguousarray(a), s0, k, cfo_hz=cfo if s0 == 0 else None,
+                                            cfo_phase=ph if s0 == 0 else None, want_state=True)
+                parts.append(llr.cpu().numpy()); s0 += k
+            got = np.concatenate([p for p in parts if p.shape[1]], axis=1)
+            assert beq(got, want["llr"]), (mod, with_cfo, split)
+            assert beq(st.cpu().numpy(), st_whole.cpu().numpy()), (mod, with_cfo, split)
+
+
+def test_stream_and_block_entries_refuse_bad_arguments():
+    """The round-3 entries validate before they launch: a resume without a previous call, symbol ranges outside the frame,
+    rows too short for the symbols, block runs that overlap or leave the LLR array."""
+    import torch
+    from projectultra_amd import UltraHipError
+    cfg = make_config(1024, "QAM16", "R3_4")
+    g = geometry(cfg)
+    ctx = context_for(cfg)
+    a = torch.zeros((4, g.frame_samples), dtype=torch.float32, device="cuda")
+    with pytest.raises(UltraHipError):
+        ctx.demod_stream(a[:, :g.symbol_samples], 2, 1)                   # nothing to continue from
+    with pytest.raises(UltraHipError):
+        ctx.demod_stream(a, 3, 2)                                         # symbols 3, 4 of a 4-symbol frame
+    with pytest.raises(UltraHipError):
+        ctx.demod_stream(a[:, :g.symbol_samples], 0, 2)                   # rows hold one symbol
+    llr = torch.zeros((64, 768), dtype=torch.float32, device="cuda")
+    with pytest.raises(UltraHipError):
+        ctx.ldpc_decode_blocks(llr, 16, 8, 4)                             # runs overlap
+    with pytest.raises(UltraHipError):
+        ctx.ldpc_decode_blocks(llr, 16, 32, 3)                            # the third run leaves the array
+    with pytest.raises(UltraHipError):
+        ctx.demod_into(a, llr[:4, :600])                                  # rows shorter than llrs_per_frame
+    r = ctx.ldpc_decode_blocks(llr, 16, 32, 2)
+    assert r["ok"].shape[0] == 32
