@@ -2,8 +2,8 @@
 for the part of its surface that is the hot path: the post-sync symbol loop and the
 presynced entry, batched on the GPU.
 
-`process()` is the chunk-fed receive of the reference: Schmidl-Cox search (scope row f1, on the GPU:
-ultra_hip_acquire_batch) -> SYNCED symbol loop.  `process_synced()` / `processPresynced()` enter past the
+`process()` is the chunk-fed receive of the reference as a live stream: incremental Schmidl-Cox search (scope row f1:
+ultra_hip_acquire_stream_batch) -> SYNCED symbol loop as the symbols arrive (ultra_hip_demod_stream_batch) -> the exits of SYNCED.  `process_synced()` / `processPresynced()` enter past the
 search with the timing and CFO a sync stage produced.
 """
 from __future__ import annotations
@@ -38,6 +38,9 @@ class OFDMDemodulator:
         self._chunk = None                   # samples per process() call
         self._last_sync_offset = 0
         self._data_start = None
+        self._resume = None                  # live-stream state of process(): built on first use
+        self._synced_symbols = self._idle_calls = 0
+        self._origin = self._fed = 0
 
     def setFrequencyOffset(self, cfo_hz: float) -> None:            # demodulator.cpp:805-814
         self._cfo_hz, self._cfo_phase, self._chirp_cfo = float(cfo_hz), 0.0, True
@@ -90,32 +93,78 @@ class OFDMDemodulator:
         ctx = self._context(Entry.SYNCED, n_sym, 0)
         return self._run(ctx, samples)
 
+    MAX_SYMBOLS_BEFORE_TIMEOUT, MAX_IDLE_CALLS_BEFORE_RESET = 250, 10       # demodulator_constants.hpp:37-38
+
     def process(self, samples) -> bool:
-        """OFDMDemodulator::process (demodulator.cpp:461-700) for a stream fed in equal-sized calls (the
-        harnesses feed 960 samples; the search result depends on the chunking): SEARCHING
-        state on the GPU (ultra_hip_acquire_batch over everything fed so far), then the SYNCED symbol loop
-        once the frame's samples have arrived.  True when at least 648 soft bits are buffered."""
+        """OFDMDemodulator::process (demodulator.cpp:461-741) on a LIVE stream, call by call — the Python twin of
+        ultra_hip::HipOfdmCoxWaveform: while SEARCHING one launch of the chunk-fed Schmidl-Cox search per call, resumed
+        from the previous call's state (ultra_hip_acquire_stream_batch); once SYNCED whole symbols are demodulated as
+        they arrive, the tracker continuing on the device (ultra_hip_demod_stream_batch); SYNCED is left after more than
+        250 symbols, more than 10 calls without a new soft bit, or an empty call with nothing left (frame complete), and
+        the search restarts on what is still buffered.  True when at least 648 soft bits are buffered.  Not reproduced:
+        the mid-frame preamble re-detection of :605-657."""
+        import torch
         samples = np.ascontiguousarray(samples, np.float32).reshape(-1)
-        if self._chunk is None:
-            self._chunk = samples.size
-        elif samples.size > self._chunk:
-            raise ValueError("process(): calls must not grow (the chunk-fed search is emulated with a fixed call size)")
+        ctx = self._context(Entry.SYNCED, self.MAX_SYMBOLS_BEFORE_TIMEOUT + 1, 0)
+        if getattr(self, "_resume", None) is None:
+            self._origin = self._fed = 0
+            self._resume = torch.zeros((1, 4), dtype=torch.int32, device=ctx.device)
+            self._synced_symbols = self._idle_calls = 0
         self._rx = np.concatenate([self._rx, samples])
-        ctx = self._context(Entry.SYNCED, None, 0)
+        self._fed += samples.size
         if not self._synced:
-            if self._data_start is None:
-                r = ctx.acquire(self._rx.reshape(1, -1), self._chunk)
-                ctx.synchronize()
-                if not int(r["found"][0]):
-                    return False
-                self._data_start = int(r["data_start"][0])
+            window = torch.from_numpy(self._rx if self._rx.size else np.zeros(1, np.float32)).reshape(1, -1)
+            r = ctx.acquire_stream(window, self._origin, self._fed, self._resume)
+            ctx.synchronize()
+            base = int(self._resume[0, 0].item()) & 0xffffffff
+            if int(r["found"][0]):
                 self._cfo_hz, self._cfo_phase = float(r["cfo_hz"][0]), 0.0
+                self._coarse_cfo = self._cfo_hz
                 self._last_sync_offset = int(r["sync_offset"][0])
-            fs = ctx.geometry.frame_samples
-            if self._rx.size < self._data_start + fs:
-                return False                 # the reference would have demodulated the symbols that are complete
-            return self._run(ctx, self._rx[self._data_start:])
-        return self._soft_bits.size >= LDPC_BLOCK_SIZE
+                self._consume_to(int(r["data_start"][0]))
+                self._synced, self._synced_symbols, self._state = True, 0, None
+            elif base > self._origin:
+                self._consume_to(base)                    # what the search trimmed off rx_buffer
+        if not self._synced:
+            return False
+        sym = ctx.geometry.symbol_samples
+        n_new = min(self._rx.size // sym, self.MAX_SYMBOLS_BEFORE_TIMEOUT + 1 - self._synced_symbols)
+        before = self._soft_bits.size
+        if n_new > 0:
+            llr, state = ctx.demod_stream(self._rx[:n_new * sym].reshape(1, -1), self._synced_symbols, n_new,
+                                          cfo_hz=np.array([self._cfo_hz], np.float32) if self._synced_symbols == 0 else None,
+                                          want_state=True)
+            ctx.synchronize()
+            self._soft_bits = np.concatenate([self._soft_bits, llr[0].cpu().numpy()])
+            self._state = state[0].cpu().numpy()
+            self._consume_to(self._origin + n_new * sym)
+            self._synced_symbols += n_new
+            if self._synced_symbols > self.MAX_SYMBOLS_BEFORE_TIMEOUT:            # :683-691
+                self._to_searching()
+                return self._soft_bits.size >= LDPC_BLOCK_SIZE
+        if self._soft_bits.size == before:                                        # :704-716
+            self._idle_calls += 1
+            if self._idle_calls > self.MAX_IDLE_CALLS_BEFORE_RESET:
+                self._to_searching()
+                return self._soft_bits.size >= LDPC_BLOCK_SIZE
+        else:
+            self._idle_calls = 0
+        has_codeword = self._soft_bits.size >= LDPC_BLOCK_SIZE
+        if not has_codeword and self._synced_symbols > 0 and samples.size == 0 and n_new == 0:   # frame complete (:720-731)
+            self._to_searching()
+            self._soft_bits = np.zeros(0, np.float32)
+        return has_codeword
+
+    def _consume_to(self, abs_index: int) -> None:        # rx_buffer.erase(begin, begin + n)
+        self._rx = self._rx[abs_index - self._origin:]
+        self._origin = abs_index
+
+    def _to_searching(self) -> None:
+        """Back to SEARCHING on whatever is still buffered; the energy gate's noise floor survives (Impl member)."""
+        import torch
+        self._synced, self._synced_symbols, self._idle_calls = False, 0, 0
+        noise = int(self._resume[0, 2].item())
+        self._resume.copy_(torch.tensor([[_i32(self._origin), _i32(self._fed), noise, 0]], dtype=torch.int32))
 
     def getLastSyncOffset(self) -> int:      # demodulator.cpp:846-848
         return self._last_sync_offset
@@ -143,6 +192,11 @@ class OFDMDemodulator:
         self._state = state[0].cpu().numpy()
         self._synced = True
         return self._soft_bits.size >= LDPC_BLOCK_SIZE
+
+
+def _i32(u: int) -> int:
+    u &= 0xffffffff
+    return u - (1 << 32) if u >= (1 << 31) else u
 
 
 def _lib_state(name: str) -> int:

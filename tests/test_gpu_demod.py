@@ -566,3 +566,29 @@ def test_stream_and_block_entries_refuse_bad_arguments():
         ctx.demod_into(a, llr[:4, :600])                                  # rows shorter than llrs_per_frame
     r = ctx.ldpc_decode_blocks(llr, 16, 32, 2)
     assert r["ok"].shape[0] == 32
+
+
+@pytest.mark.parametrize("name", ["cfg3_qam16_r34", "cfg2_dqpsk_r12"])
+def test_demodulator_mirror_live_stream(name):
+    """projectultra_amd.OFDMDemodulator.process() as a live stream (the Python twin of HipOfdmCoxWaveform) against the compiled
+    reference call by call (tests/golden/stream.npz): frame-complete exit and re-acquisition, idle exit, 250-symbol timeout."""
+    from projectultra_amd import OFDMDemodulator
+    from _util import STREAM_SCENARIOS, build_stream, modem_config_from_c
+    g = np.load(GOLDEN / "fullsync.npz")
+    want = np.load(GOLDEN / "stream.npz")
+    cfg = cfg_from_array(g[f"{name}__cfg"])
+    mc, _ = modem_config_from_c(cfg)
+    geo = geometry(cfg)
+    pre = int(g[f"{name}__meta"][0][0])
+    for sc, recipe in STREAM_SCENARIOS.items():
+        audio, chunks = build_stream(g[f"{name}__audio"], recipe(geo.symbol_samples, pre))
+        d = OFDMDemodulator(mc)
+        pos, ready, synced, drained, soft = 0, [], [], [], []
+        for c in chunks:
+            r = d.process(audio[pos:pos + int(c)]); pos += int(c)
+            sb = d.getSoftBits() if r else np.zeros(0, np.float32)      # OFDMNvisWaveform::process
+            ready.append(int(r)); synced.append(int(d.isSynced())); drained.append(sb.size); soft.append(sb)
+        assert ready == want[f"{name}__{sc}__ready"].tolist(), (name, sc)
+        assert synced == want[f"{name}__{sc}__synced"].tolist(), (name, sc)
+        assert drained == want[f"{name}__{sc}__drained"].tolist(), (name, sc)
+        assert beq(np.concatenate(soft).astype(np.float32), want[f"{name}__{sc}__soft"]), (name, sc)
