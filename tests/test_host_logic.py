@@ -125,3 +125,62 @@ def test_row_column_interleaver_mirror_matches_oracle(oracle):
         assert np.array_equal(il.deinterleave(il.interleave(x)), x)
         assert sorted(il.permutation.tolist()) == list(range(648))
 
+
+
+def test_evidence_is_tied_to_the_kernel_sources(tmp_path):
+    """profiles/traffic.json is quoted by bench.py only for the kernels it was collected on: _lib.source_hash() covers every
+    file the library is built from and changes with any of them."""
+    import shutil
+    from projectultra_amd import _lib
+    h = _lib.source_hash()
+    assert len(h) == 16 and h == _lib.source_hash()
+    pkg = tmp_path / "projectultra_amd"
+    shutil.copytree(_lib.CSRC_DIR, pkg / "csrc")
+    (tmp_path / "include").mkdir()
+    shutil.copy(_lib.PKG_DIR.parent / "include" / "ultra_hip.h", tmp_path / "include" / "ultra_hip.h")
+    old = (_lib.CSRC_DIR, _lib.PKG_DIR)
+    try:
+        _lib.CSRC_DIR, _lib.PKG_DIR = pkg / "csrc", pkg
+        assert _lib.source_hash() == h                       # same sources elsewhere: same hash
+        with open(pkg / "csrc" / "demod_kernel.h", "a") as f:
+            f.write("\n// touched\n")
+        assert _lib.source_hash() != h
+    finally:
+        _lib.CSRC_DIR, _lib.PKG_DIR = old
+
+
+def test_bench_headline_is_one_sharded_batch():
+    """bench.py's default for the headline: ONE 2^20-frame batch per step, rank r takes shard_range(2^20, r, N) (strong
+    scaling, north_star); --frames switches to the same batch size on every GPU (weak)."""
+    import argparse
+    sys.path.insert(0, str(ROOT))
+    import bench
+    from projectultra_amd.montecarlo import shard_range
+    argv = sys.argv
+    try:
+        sys.argv = ["bench.py"]
+        a = bench.parse()
+        assert a.config == "cfg3" and a.frames == 0 and a.total_frames == 0 and a.gpus == 1
+        sys.argv = ["bench.py", "--frames", "262144", "--gpus", "8"]
+        b = bench.parse()
+        assert b.frames == 262144
+    finally:
+        sys.argv = argv
+    total = 1 << 20
+    for world in (1, 2, 4, 8):
+        spans = [shard_range(total, r, world) for r in range(world)]
+        assert sum(hi - lo for lo, hi in spans) == total and all(hi - lo == total // world for lo, hi in spans)
+
+
+def test_stream_scenarios_rebuild_deterministically():
+    """tests/golden/stream.npz stores only the reference's outputs: the audio is rebuilt from fullsync.npz's frames."""
+    from _util import STREAM_SCENARIOS, build_stream
+    from conftest import GOLDEN
+    g = np.load(GOLDEN / "fullsync.npz")
+    want = np.load(GOLDEN / "stream.npz")
+    frames = g["cfg2_dqpsk_r12__audio"]
+    for sc, recipe in STREAM_SCENARIOS.items():
+        a1, c1 = build_stream(frames, recipe(564, int(g["cfg2_dqpsk_r12__meta"][0][0])))
+        a2, c2 = build_stream(frames, recipe(564, int(g["cfg2_dqpsk_r12__meta"][0][0])))
+        assert np.array_equal(a1, a2) and np.array_equal(c1, c2) and int(c1.sum()) == a1.size
+        assert c1.size == want[f"cfg2_dqpsk_r12__{sc}__ready"].size
