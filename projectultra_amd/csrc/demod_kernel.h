@@ -560,7 +560,9 @@ struct Mix2Lane {
     c32 wA[P / 2];              // group A (wave-uniform): twiddle[j << (LOG2N - A)], j < P/2
 };
 
-template <int LOG2N, class NextFn>
+// ROT = false: the launch has no phase table, i.e. the CFO of every frame is zero (launch_demod) — the rotation, its
+// lookup and the sixteen sincosf per frame-lane are compiled out, and with them most of the kernel's registers.
+template <int LOG2N, bool ROT, class NextFn>
 __device__ __forceinline__ void symbol_to_freq2(Fft2Shared<LOG2N>& sh, const DemodConst& D, const int h, const int lane,
                                                 MixItem& it, const Mix2Lane<LOG2N>& lc,
                                                 const c32* __restrict__ twiddle, c32& bin_out, const int par,
@@ -571,7 +573,7 @@ __device__ __forceinline__ void symbol_to_freq2(Fft2Shared<LOG2N>& sh, const Dem
     const unsigned hw0 = (unsigned)__builtin_amdgcn_readlane((int)it.hw, 0);
     const float freq_offset_hz = __int_as_float(__builtin_amdgcn_readlane((int)it.hw, 1));
     float cfo_phase = __int_as_float(__builtin_amdgcn_readlane((int)it.hw, 3));
-    const bool cfo_on = fabsf(freq_offset_hz) > 0.01f;
+    const bool cfo_on = ROT && fabsf(freq_offset_hz) > 0.01f;
     const int it_ns = (int)(hw0 & 0xffu), it_covered = (int)(hw0 >> 8);
     const float it_pnext = __int_as_float(__builtin_amdgcn_readlane((int)it.hw, 2));
     c32* X = sh.X[h];
@@ -1430,8 +1432,11 @@ __global__ __launch_bounds__(kWave, 2) void mix_fft_kernel(
 #ifndef UH_MIX2_WAVES
 #define UH_MIX2_WAVES 3
 #endif
-template <int LOG2N>
-__global__ __launch_bounds__(2 * kWave) __attribute__((amdgpu_waves_per_eu(UH_MIX2_WAVES, 8))) void mix_fft2_kernel(
+#ifndef UH_MIX2_WAVES_NOROT
+#define UH_MIX2_WAVES_NOROT 4
+#endif
+template <int LOG2N, bool ROT>
+__global__ __launch_bounds__(2 * kWave) __attribute__((amdgpu_waves_per_eu(ROT ? UH_MIX2_WAVES : UH_MIX2_WAVES_NOROT, 8))) void mix_fft2_kernel(
     const DemodConst* __restrict__ Dp, const c32* __restrict__ nco, const c32* __restrict__ twiddle,
     const float* __restrict__ audio, size_t frame_stride, const unsigned* __restrict__ frame_offset, int n_frames,
     int sym, c32* __restrict__ fq, const unsigned* __restrict__ seg_tab, int n_sym_batch) {
@@ -1456,7 +1461,7 @@ __global__ __launch_bounds__(2 * kWave) __attribute__((amdgpu_waves_per_eu(UH_MI
     auto request = [&](MixItem& it, int w) {
         const int f = frame_of(w);
         prefetch_symbol2<LOG2N>(sh, D, h, lane, item_base(w));
-        request_item(it, seg_tab ? seg_tab + (size_t)f * kSegTabWords : nullptr, lane);
+        request_item(it, (ROT && seg_tab) ? seg_tab + (size_t)f * kSegTabWords : nullptr, lane);
     };
     Mix2Lane<LOG2N> lc;
     lc.w6 = twiddle[lane << 3];
@@ -1493,7 +1498,7 @@ __global__ __launch_bounds__(2 * kWave) __attribute__((amdgpu_waves_per_eu(UH_MI
         const int next = w + (int)gridDim.x;
         Stamps stamps;
         c32 bin;
-        symbol_to_freq2<LOG2N>(sh, D, h, lane, cur, lc, twiddle, bin, par,
+        symbol_to_freq2<LOG2N, ROT>(sh, D, h, lane, cur, lc, twiddle, bin, par,
                                [&]() {
                                    if (w_stored >= 0 && fq_mine) fq[(size_t)w_stored * (2 * fh) + fq_slot] = pending;
                                    if (next < total) request(cur, next);

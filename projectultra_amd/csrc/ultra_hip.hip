@@ -234,9 +234,9 @@ int launch_demod(ultra_hip_ctx* ctx, const float* d_audio, size_t frame_stride, 
     if (all_symbols_at_once) {
         LaunchSpan span(ctx, ULTRA_HIP_K_MIX_FFT);
         const unsigned g = (unsigned)std::min(n_frames * (size_t)n_sym, (size_t)ctx->cu_count * 128);
-        if (D.log2_fft == 10 && !ctx->mix_one_wave)
-            hipLaunchKernelGGL(dev::mix_fft2_kernel<10>, dim3(g), dim3(2 * dev::kWave), 0, st, ctx->d_demod, ctx->d_nco, ctx->d_twiddle,
-                               d_audio, frame_stride, d_frame_offset, (int)n_frames, s_begin, ctx->d_ws_fq, seg_tab, n_sym);
+        if (D.log2_fft == 10 && !ctx->mix_one_wave)          // cfo_is_zero: no table, the instance without the rotation
+            hipLaunchKernelGGL((dev::mix_fft2_kernel<10, false>), dim3(g), dim3(2 * dev::kWave), 0, st, ctx->d_demod, ctx->d_nco, ctx->d_twiddle,
+                               d_audio, frame_stride, d_frame_offset, (int)n_frames, s_begin, ctx->d_ws_fq, nullptr, n_sym);
         else if (D.log2_fft == 10)
             hipLaunchKernelGGL(dev::mix_fft_kernel<10>, dim3(g), dim3(dev::kWave), 0, st, ctx->d_demod, ctx->d_nco, ctx->d_twiddle,
                                d_audio, frame_stride, d_frame_offset, (int)n_frames, s_begin, ctx->d_ws_fq, seg_tab, n_sym);
@@ -247,8 +247,11 @@ int launch_demod(ultra_hip_ctx* ctx, const float* d_audio, size_t frame_stride, 
     for (int s = s_begin; s < s_end; ++s) {
         c32* fq_s = ctx->d_ws_fq + ((all_symbols_at_once || deferred) ? (size_t)(s - s_begin) * n_frames * (size_t)(2 * D.fq_half) : (size_t)0);
         float* rec_s = deferred ? ctx->d_ws_trk + (size_t)(s - s_begin) * n_frames * dev::kTrkRecFloats : nullptr;
-        // the first symbol of a SYNCED batch without initial offsets is at CFO 0 in every frame: nothing to walk yet
-        const bool first_at_zero = s == 0 && !D.presynced && !cfo_given;
+        // The first TWO symbols of a SYNCED batch without initial offsets are at CFO 0 in every frame: the tracker estimates
+        // a CFO from the phase differences of the pilots between two symbols (channel_equalizer.cpp:421-470: only with
+        // prev_pilot_phases from an earlier symbol), so the first estimate exists after the second symbol.  No table to
+        // walk, no rotation: the transform's instance without it.
+        const bool first_at_zero = s <= 1 && !D.presynced && !cfo_given;
         const unsigned* seg_tab_s = first_at_zero ? nullptr : seg_tab;
         if (!cfo_is_zero && !first_at_zero) {
             LaunchSpan span(ctx, ULTRA_HIP_K_WALK);
@@ -257,10 +260,14 @@ int launch_demod(ultra_hip_ctx* ctx, const float* d_audio, size_t frame_stride, 
         }
         if (!all_symbols_at_once) {
             LaunchSpan span(ctx, ULTRA_HIP_K_MIX_FFT);
-            if (D.log2_fft == 10 && !ctx->mix_one_wave)
-                hipLaunchKernelGGL(dev::mix_fft2_kernel<10>, dim3(grid_fft), dim3(2 * dev::kWave), 0, st, ctx->d_demod,
+            if (D.log2_fft == 10 && !ctx->mix_one_wave && seg_tab_s)
+                hipLaunchKernelGGL((dev::mix_fft2_kernel<10, true>), dim3(grid_fft), dim3(2 * dev::kWave), 0, st, ctx->d_demod,
                                    ctx->d_nco, ctx->d_twiddle, d_audio, frame_stride, d_frame_offset, (int)n_frames, s,
                                    fq_s, seg_tab_s, 1);
+            else if (D.log2_fft == 10 && !ctx->mix_one_wave)   // no table: CFO 0 in every frame, the instance without the rotation
+                hipLaunchKernelGGL((dev::mix_fft2_kernel<10, false>), dim3(grid_fft), dim3(2 * dev::kWave), 0, st, ctx->d_demod,
+                                   ctx->d_nco, ctx->d_twiddle, d_audio, frame_stride, d_frame_offset, (int)n_frames, s,
+                                   fq_s, nullptr, 1);
             else if (D.log2_fft == 10)
                 hipLaunchKernelGGL(dev::mix_fft_kernel<10>, dim3(grid_fft), dim3(dev::kWave), 0, st, ctx->d_demod,
                                    ctx->d_nco, ctx->d_twiddle, d_audio, frame_stride, d_frame_offset, (int)n_frames, s,
