@@ -292,7 +292,7 @@ __device__ __forceinline__ void symbol_to_freq(FftShared<LOG2N>& sh, const Demod
     int tab_ns = 0, tab_covered = 0, tab_start = 0x7fffffff;
     float tab_pnext = 0.0f, tab_base = 0.0f, tab_step = 0.0f;
     if (cfo_on && seg_tab) {
-        tab_ns = (int)(seg_tab[0] & 0xffu); tab_covered = (int)(seg_tab[0] >> 8); tab_pnext = __uint_as_float(seg_tab[2]);
+        tab_ns = (int)(seg_tab[0] & 0xffu); tab_covered = (int)((seg_tab[0] >> 8) & 0x7fffffu); tab_pnext = __uint_as_float(seg_tab[2]);
         if (lane < tab_ns) {
             tab_start = (int)seg_tab[4 + 3 * lane];
             tab_base = __uint_as_float(seg_tab[5 + 3 * lane]);
@@ -501,7 +501,7 @@ __device__ __forceinline__ void symbol_to_freq(FftShared<LOG2N>& sh, const Demod
 // meets its partner ONCE per frame: the last stage needs E[k] + w O[k] for the bins k < 64 (wavefront 0 computes them
 // from its own E and the partner's O) and E[k] - w O[k] for k >= 448 (bins N-64 .. N-1, wavefront 1).  Same operations
 // on the same operands in the same order as the one-wavefront kernel: bit-identical bins.
-template <int LOG2N>
+template <int LOG2N, bool ROT = true>
 struct Fft2Shared {
     static_assert(LOG2N == 10, "two-wavefront layout: N = 1024");
     static constexpr int N = 1 << LOG2N, M = N / 2;         // M-point transform per wavefront
@@ -511,10 +511,9 @@ struct Fft2Shared {
     float stage[2][M];                                      // landing zone of the NEXT item's samples (asynchronous copy)
     static constexpr int kTwB = P * ((1 << A) - 1);
     c32 twB[kTwB];                                          // twiddles of stages A..2A-1 (as in FftShared)
-    um::PhaseSeg seg[2][kPhaseCap + 2];                     // two entries behind the last segment: start = INT_MAX
-    int seg_start[2][kPhaseCap + 4] __attribute__((aligned(16)));
-    unsigned segmask[2][2];                                 // lanes that a segment starts in (symbol_to_freq2)
-    int segslot[2][kWave];                                  // ... and the last segment that starts there
+    // the rotation's lookup tables: not in the instance without it (15.8 KB instead of 17.9: ten workgroups per CU)
+    um::PhaseSeg seg[2][ROT ? kPhaseCap + 2 : 1];           // two entries behind the last segment: start = INT_MAX
+    int seg_start[2][ROT ? kPhaseCap + 4 : 4] __attribute__((aligned(16)));
     c32 xch[2][2][kWave];                                   // [frame parity][writer][lane]: E_hi from wavefront 0, O_lo from 1
 };
 
@@ -540,14 +539,14 @@ __device__ __forceinline__ void request_item(MixItem& it, const unsigned* __rest
 }
 
 // staging of the samples of parity h of one symbol's FFT window: stage[64 q + l] = window[2 (64 q + l) + h]
-template <int LOG2N>
-__device__ __forceinline__ void prefetch_symbol2(Fft2Shared<LOG2N>& sh, const DemodConst& D, int h, int lane,
+template <int LOG2N, bool ROT>
+__device__ __forceinline__ void prefetch_symbol2(Fft2Shared<LOG2N, ROT>& sh, const int cp, int h, int lane,
                                                  const float* __restrict__ audio_sym) {
     constexpr int P = Fft2Shared<LOG2N>::P;
     float* stage = sh.stage[h];
 #pragma unroll
     for (int q = 0; q < P; ++q)
-        __builtin_amdgcn_global_load_lds(audio_sym + D.cp + 2 * (64 * q + lane) + h, stage + 64 * q, 4, 0, 0);
+        __builtin_amdgcn_global_load_lds(audio_sym + cp + 2 * (64 * q + lane) + h, stage + 64 * q, 4, 0, 0);
 }
 
 // per-lane values that do not change from item to item: the oscillator at the lane's 8 samples (for one symbol index)
@@ -563,10 +562,10 @@ struct Mix2Lane {
 // ROT = false: the launch has no phase table, i.e. the CFO of every frame is zero (launch_demod) — the rotation, its
 // lookup and the sixteen sincosf per frame-lane are compiled out, and with them most of the kernel's registers.
 template <int LOG2N, bool ROT, class NextFn>
-__device__ __forceinline__ void symbol_to_freq2(Fft2Shared<LOG2N>& sh, const DemodConst& D, const int h, const int lane,
+__device__ __forceinline__ void symbol_to_freq2(Fft2Shared<LOG2N, ROT>& sh, const DemodConst& D, const int h, const int lane,
                                                 MixItem& it, const Mix2Lane<LOG2N>& lc,
                                                 const c32* __restrict__ twiddle, c32& bin_out, const int par,
-                                                NextFn request_next, Stamps& stamps) {
+                                                const int cp, const int sym_len, NextFn request_next, Stamps& stamps) {
     constexpr int P = Fft2Shared<LOG2N>::P, A = Fft2Shared<LOG2N>::A;
     UH_STAMP(0);
     const int rl = (int)(__brev((unsigned)lane) >> 26);      // bitrev6(lane)
@@ -574,7 +573,7 @@ __device__ __forceinline__ void symbol_to_freq2(Fft2Shared<LOG2N>& sh, const Dem
     const float freq_offset_hz = __int_as_float(__builtin_amdgcn_readlane((int)it.hw, 1));
     float cfo_phase = __int_as_float(__builtin_amdgcn_readlane((int)it.hw, 3));
     const bool cfo_on = ROT && fabsf(freq_offset_hz) > 0.01f;
-    const int it_ns = (int)(hw0 & 0xffu), it_covered = (int)(hw0 >> 8);
+    const int it_ns = (int)(hw0 & 0xffu), it_covered = (int)((hw0 >> 8) & 0x7fffffu);
     const float it_pnext = __int_as_float(__builtin_amdgcn_readlane((int)it.hw, 2));
     c32* X = sh.X[h];
     um::PhaseSeg* seg = sh.seg[h];
@@ -602,12 +601,11 @@ __device__ __forceinline__ void symbol_to_freq2(Fft2Shared<LOG2N>& sh, const Dem
     for (int j = 0; j < P; ++j) ph[j] = 0.0f;
     bool bounded = true;
     if (cfo_on) {
-        const float inc = (float)(((-kTwoPi) * (double)freq_offset_hz) / (double)D.sample_rate);
-        bounded = fabsf(cfo_phase) <= 4.0f && fabsf(inc) <= 1.0f;
+        bounded = (hw0 >> 31) != 0u;                         // walk_to_table: |start phase| <= 4 and |increment| <= 1
         int done = 0;
         float pcur = cfo_phase;
         const bool have_tab = it_covered > 0;
-        while (done < D.sym_len) {                           // one round unless a table overflows
+        while (done < sym_len) {                           // one round unless a table overflows
             int covered;
             float pnext;
             int my_start = 0x7fffffff;
@@ -617,7 +615,8 @@ __device__ __forceinline__ void symbol_to_freq2(Fft2Shared<LOG2N>& sh, const Dem
                 ns = tab_ns; covered = it_covered; pnext = it_pnext;
                 if (lane < tab_ns) { my_start = it.tab_start; my_base = it.tab_base; my_step = it.tab_step; }
             } else {
-                ns = um::phase_table_walk(pcur, inc, D.sym_len - done, kPhaseCap, &covered, &pnext,
+                const float inc = (float)(((-kTwoPi) * (double)freq_offset_hz) / (double)D.sample_rate);
+                ns = um::phase_table_walk(pcur, inc, sym_len - done, kPhaseCap, &covered, &pnext,
                                           [&](int k, int start, float base, float step) {
                                               const bool mine = (lane == k);
                                               my_start = mine ? start : my_start;
@@ -627,35 +626,32 @@ __device__ __forceinline__ void symbol_to_freq2(Fft2Shared<LOG2N>& sh, const Dem
             }
             if (lane < kPhaseCap + 2) { seg[lane].start = my_start; seg[lane].base = my_base; seg[lane].step = my_step; }
             if (lane < kPhaseCap + 4) seg_start[lane] = my_start;            // INT_MAX beyond the last segment
-            sh.segslot[h][lane] = 0;
-            if (lane < 2) sh.segmask[h][lane] = 0u;
             wave_sync();
             UH_STAMP(11);
-            const int i0 = D.cp + 2 * P * lane + h - done;  // position of the lane's first sample inside this round
+            const int i0 = cp + 2 * P * lane + h - done;  // position of the lane's first sample inside this round
             const int ilast = i0 + 2 * (P - 1);
             if (done == 0) {
                 // The table round (positions i0 >= 0): the segment of the lane's first position WITHOUT a search.  Starts
                 // ascend with the segment index k and first positions with the lane, so segment k claims the lanes from
                 // r_k = ceil((start_k - first position of lane 0) / 2P) on, and lane l is in the LAST segment that claimed
-                // a lane <= l: the claims go into a 64-bit mask (ds_or) and slot[r_k] = max k (ds_max: several segments
-                // may start inside one run around a zero crossing); lane l finds the highest mask bit at or below l and
-                // reads that slot.  Its own, the next and the next-but-one segment come straight out of the owners'
+                // a lane <= l: segment k pushes k + 1 to lane r_k (several segments may start inside one run around a
+                // zero crossing: the largest arrives), lane l finds the highest claimed lane at or below l in the ballot
+                // of the arrivals and fetches that lane's word.  Its own, the next and the next-but-one segment come straight out of the owners'
                 // registers (ds_bpermute).  A run with at most one boundary is then two evaluations and a select per
                 // sample; lanes whose run holds more boundaries (or leaves the round) walk on through the LDS table.
-                const int first0 = D.cp + h;
+                const int first0 = cp + h;
                 const bool in_tab = lane < ns;
                 const int rk = (my_start - first0 + 2 * P - 1) >> (A + 1);
                 const bool claims = in_tab && my_start > first0 && rk <= 63;
-                if (claims) {
-                    atomicOr(&sh.segmask[h][rk >> 5], 1u << (rk & 31));
-                    atomicMax(&sh.segslot[h][rk], lane);
-                }
+                // ds_permute: every lane PUSHES one word to a lane of its choice and, of several pushes to one lane, the
+                // highest pushing lane's arrives — the largest k, as wanted.  Lanes without a claim push a zero to lane 0,
+                // which no segment claims (rk >= 1).  No LDS memory, no atomics, no fence.
+                const int slot = __builtin_amdgcn_ds_permute((claims ? rk : 0) << 2, claims ? lane + 1 : 0);
                 const int base = __popcll(__ballot(in_tab && my_start <= first0));     // segment 0 starts at 0: base >= 1
-                wave_sync();
-                const unsigned long long mask = (unsigned long long)sh.segmask[h][0] | ((unsigned long long)sh.segmask[h][1] << 32);
-                const unsigned long long below = mask & ((2ull << lane) - 1ull);
-                int sg = base - 1;
-                if (below) sg = sh.segslot[h][63 - __clzll(below)];
+                const unsigned long long below = __ballot(slot != 0) & ((2ull << lane) - 1ull);
+                const int from = below ? 63 - __clzll(below) : lane;
+                const int got = __builtin_amdgcn_ds_bpermute(from << 2, slot);
+                int sg = below ? got - 1 : base - 1;
                 UH_STAMP(12);
                 auto from_lane = [&](int v, int src) { return __builtin_amdgcn_ds_bpermute(src << 2, v); };
                 um::PhaseSeg cur, nxt;
@@ -1353,7 +1349,10 @@ __device__ __forceinline__ float walk_to_table(const DemodConst& D, float cfo, f
                                             tab[5 + 3 * k] = __float_as_uint(base);
                                             tab[6 + 3 * k] = __float_as_uint(step);
                                         });
-    tab[0] = (unsigned)ns | ((unsigned)covered << 8); tab[2] = __float_as_uint(pnext);
+    // bit 31: start phase and increment are inside the range of the bounded sincosf (symbol_to_freq2 then has no use for
+    // the increment — a double-precision division per item — unless a table overflows)
+    const unsigned bounded = (fabsf(phase) <= 4.0f && fabsf(inc) <= 1.0f) ? 0x80000000u : 0u;
+    tab[0] = (unsigned)ns | ((unsigned)covered << 8) | bounded; tab[2] = __float_as_uint(pnext);
     // a table overflow (more than kPhaseCap segments in one symbol) leaves the rest to mix_fft; the end phase is
     // walked on here with the same function
     for (int done = covered; done < D.sym_len;) {
@@ -1440,7 +1439,7 @@ __global__ __launch_bounds__(2 * kWave) __attribute__((amdgpu_waves_per_eu(ROT ?
     const DemodConst* __restrict__ Dp, const c32* __restrict__ nco, const c32* __restrict__ twiddle,
     const float* __restrict__ audio, size_t frame_stride, const unsigned* __restrict__ frame_offset, int n_frames,
     int sym, c32* __restrict__ fq, const unsigned* __restrict__ seg_tab, int n_sym_batch) {
-    __shared__ Fft2Shared<LOG2N> sh;
+    __shared__ Fft2Shared<LOG2N, ROT> sh;
     const DemodConst& D = *Dp;
     constexpr int P = Fft2Shared<LOG2N>::P, A = Fft2Shared<LOG2N>::A, M = Fft2Shared<LOG2N>::M;
     const int h = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6), lane = threadIdx.x & 63;
@@ -1452,15 +1451,16 @@ __global__ __launch_bounds__(2 * kWave) __attribute__((amdgpu_waves_per_eu(ROT ?
     }
     __syncthreads();
     const int total = n_frames * n_sym_batch;
-    auto frame_of = [&](int w) { return (n_sym_batch > 1) ? w % n_frames : w; };
+    // What every item needs of the layout and of the launch, read ONCE and made opaque: left to itself the compiler
+    // re-reads D.sym_len, D.cp and the grid size from memory inside every request (scalar registers are short here, a
+    // load looks cheaper to it than a spill) and waits for them, ~1000 cycles per item in the stamps of that version.
+    int sym_len = D.sym_len, cp = D.cp, grid_step = (int)gridDim.x;
+    asm volatile("" : "+s"(sym_len), "+s"(cp), "+s"(grid_step));
     auto ds_of = [&](int w) { return (n_sym_batch > 1) ? w / n_frames : 0; };
-    auto item_base = [&](int w) {
-        const int f = frame_of(w);
-        return audio + (size_t)f * frame_stride + (frame_offset ? frame_offset[f] : 0u) + (size_t)(sym + ds_of(w)) * D.sym_len;
-    };
     auto request = [&](MixItem& it, int w) {
-        const int f = frame_of(w);
-        prefetch_symbol2<LOG2N>(sh, D, h, lane, item_base(w));
+        const int ds = ds_of(w), f = w - ds * n_frames;
+        const float* audio_sym = audio + (size_t)f * frame_stride + (frame_offset ? frame_offset[f] : 0u) + (size_t)(sym + ds) * sym_len;
+        prefetch_symbol2<LOG2N, ROT>(sh, cp, h, lane, audio_sym);
         request_item(it, (ROT && seg_tab) ? seg_tab + (size_t)f * kSegTabWords : nullptr, lane);
     };
     Mix2Lane<LOG2N> lc;
@@ -1483,22 +1483,22 @@ __global__ __launch_bounds__(2 * kWave) __attribute__((amdgpu_waves_per_eu(ROT ?
     int w = blockIdx.x;
     if (w < total) request(cur, w);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // the first item has no bin store in front of it (symbol_to_freq2)
-    for (int par = 0; w < total; w += gridDim.x, par ^= 1) {
+    for (int par = 0; w < total; w += grid_step, par ^= 1) {
         const int ds = ds_of(w);
         if (ds != os_ds) {                                   // the oscillator at this lane's samples: once per symbol index
-            const c32* nco_sym = nco + (size_t)(sym + ds) * D.sym_len;
+            const c32* nco_sym = nco + (size_t)(sym + ds) * sym_len;
 #pragma unroll
-            for (int qp = 0; qp < P; ++qp) lc.os[qp] = nco_sym[D.cp + 2 * (rl + 64 * qp) + h];
+            for (int qp = 0; qp < P; ++qp) lc.os[qp] = nco_sym[cp + 2 * (rl + 64 * qp) + h];
             os_ds = ds;
             // the compiler's wait for these loads belongs HERE and not at their first use in the item, where it would
             // also wait for the requests of the next item issued in between
 #pragma unroll
             for (int qp = 0; qp < P; ++qp) asm volatile("" ::"v"(lc.os[qp].re), "v"(lc.os[qp].im));
         }
-        const int next = w + (int)gridDim.x;
+        const int next = w + grid_step;
         Stamps stamps;
         c32 bin;
-        symbol_to_freq2<LOG2N, ROT>(sh, D, h, lane, cur, lc, twiddle, bin, par,
+        symbol_to_freq2<LOG2N, ROT>(sh, D, h, lane, cur, lc, twiddle, bin, par, cp, sym_len,
                                [&]() {
                                    if (w_stored >= 0 && fq_mine) fq[(size_t)w_stored * (2 * fh) + fq_slot] = pending;
                                    if (next < total) request(cur, next);
