@@ -333,6 +333,21 @@ int ultra_hip_acquire_stream_batch(ultra_hip_ctx* ctx, const float* d_audio, siz
                                    uint32_t n_samples, size_t n_streams, uint32_t* d_resume, uint32_t* d_found,
                                    uint32_t* d_data_start, float* d_cfo_hz, uint32_t* d_sync_offset);
 
+/* The preamble check of the SYNCED state (src/ofdm/demodulator.cpp:605-657: a new frame arriving while the demodulator
+ * still waits for the rest of the old one).  process() runs it when symbols have been demodulated since the sync and the
+ * last two calls or more brought no new soft bit; the caller keeps those two counters (HipOfdmCoxWaveform does) and calls
+ * this entry instead of re-implementing the scan: Schmidl-Cox metric at offsets 0, 8, .. <= min(size - 6 preamble symbols,
+ * 2 data symbols) of rx_buffer = samples [d_resume[4 s], n_samples) of stream s — no energy gate, no plateau test; the first
+ * offset above sync_threshold whose LTS confirmation (refineLTSTiming) holds wins, a failed confirmation continues the
+ * scan.  d_resume is only read (word 0 of each record: where rx_buffer starts); origin, n_samples and the outputs are those
+ * of ultra_hip_acquire_stream_batch.  On d_found[s] = 1 the caller drops its soft bits and restarts the stream's
+ * demodulation at d_data_start[s] with d_cfo_hz[s] (ultra_hip_demod_stream_batch, first_symbol 0 — the reference resets
+ * the tracker to the constructor's state there, :640-655); d_found[s] = 0 (also when fewer than 6 preamble symbols are
+ * buffered) leaves everything as it was. */
+int ultra_hip_resync_stream_batch(ultra_hip_ctx* ctx, const float* d_audio, size_t stream_stride, uint32_t origin,
+                                  uint32_t n_samples, size_t n_streams, const uint32_t* d_resume, uint32_t* d_found,
+                                  uint32_t* d_data_start, float* d_cfo_hz, uint32_t* d_sync_offset);
+
 /* Chirp synchronisation: OFDMChirpWaveform::detectSync
  * (src/waveform/ofdm_chirp_waveform.cpp:129-172) = sync::ChirpSync::detectDualChirp
  * (src/sync/chirp_sync.hpp:349-505; 300 -> 2700 Hz up chirp, 100 ms gap, down chirp, 500 ms each) for a

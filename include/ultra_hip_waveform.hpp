@@ -414,8 +414,10 @@ public:
 //              the reference's: more than MAX_SYMBOLS_BEFORE_TIMEOUT symbols (:683-691), more than
 //              MAX_IDLE_CALLS_BEFORE_RESET calls without a new soft bit (:704-716), an empty call with nothing left
 //              to demodulate and less than a codeword buffered ("frame complete", :720-731).
-// Device buffers live as long as the object.  Not reproduced: the mid-frame preamble re-detection of :605-657 (a second
-// Schmidl-Cox search inside SYNCED after two idle calls) — frames end through the three exits above.
+//              A new preamble arriving while SYNCED (:605-657: symbols demodulated, two calls or more without a soft
+//              bit, six preamble symbols buffered) abandons the old frame: ultra_hip_resync_stream_batch scans the
+//              buffer's first two symbols, and on a hit the demodulation restarts at the new data start.
+// Device buffers live as long as the object.
 // Inside the reference tree (-DULTRA_HIP_WITH_REFERENCE) it derives from ultra::IWaveform and the transmit half is the
 // reference's own OFDMModulator, so it can stand wherever an OFDMNvisWaveform stands.
 #ifdef ULTRA_HIP_WITH_REFERENCE
@@ -598,6 +600,24 @@ private:
             }
         }
         if (!synced_) return false;
+        // a new preamble while SYNCED (:605-657): symbols were demodulated, the last two calls or more brought no soft bit,
+        // and six preamble symbols are buffered — the scan runs on the device, the two counters live here
+        const uint32_t preamble_total = 6u * (static_cast<uint32_t>(config_.fft_size) + geo_.cp_len);
+        if (synced_symbols_ > 0 && idle_calls_ >= 2 && fed_ - origin_ >= preamble_total) {
+            restartSearch();                                             // word 0 of the record: where rx_buffer starts
+            uint32_t* w = small();
+            detail::check(ultra_hip_resync_stream_batch(ctx_.p, static_cast<const float*>(d_rx_->d), rx_cap_, d_origin_, fed_, 1,
+                                                        w, w + 4, w + 5, reinterpret_cast<float*>(w + 6), w + 7), "resync_stream");
+            uint32_t h[8];
+            detail::check(ultra_hip_memcpy_d2h(ctx_.p, h, w, sizeof(h)), "d2h");
+            if (h[4]) {                                                  // the old frame is abandoned, the tracker starts afresh
+                std::memcpy(&coarse_cfo_, &h[6], sizeof(float));
+                freq_offset_hz_ = coarse_cfo_;
+                consumeTo(h[5]);
+                demod_soft_.clear();
+                synced_symbols_ = 0; idle_calls_ = 0; pending_cfo_ = false;
+            }
+        }
         const uint32_t sym = symbolSamples();
         uint32_t n_new = (fed_ - origin_) / sym;
         const uint32_t room = uint32_t(kMaxSymbolsBeforeTimeout + 1) - synced_symbols_;

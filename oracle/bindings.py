@@ -178,6 +178,17 @@ class _Base:
         return dict(found=u[0].value, fed_at_sync=u[1].value, sync_offset=u[2].value, coarse_cfo=cfo.value,
                     refined_lts=u[3].value, data_start=u[4].value, noise_floor=nf.value)
 
+    def midframe_search(self, cfg, audio):
+        """The preamble check of the SYNCED state (demodulator.cpp:605-657) on rx_buffer = audio ->
+        dict(found, sts_start, refined_lts, consume, coarse_cfo)."""
+        audio = _f32(audio)
+        u = [C.c_uint32(0) for _ in range(4)]
+        cfo = C.c_float(0)
+        rc = self._fn("midframe_search")(C.byref(cfg), _ptr(audio), C.c_uint32(audio.size), C.byref(u[0]), C.byref(u[1]),
+                                         C.byref(u[2]), C.byref(u[3]), C.byref(cfo))
+        assert rc == 0, rc
+        return dict(found=u[0].value, sts_start=u[1].value, refined_lts=u[2].value, consume=u[3].value, coarse_cfo=cfo.value)
+
     def sc_metric(self, cfg, audio, offset, noise_floor=0.0):
         """One Schmidl-Cox metric + energy gate -> (corr, P.re, P.im, energy, noise_floor_after, has_energy)."""
         audio = _f32(audio)

@@ -331,6 +331,41 @@ int ref_demod_stream(const ultra_hip_config* c, const float* audio, const uint32
     return (int)total;
 }
 
+// The preamble check of the SYNCED state (src/ofdm/demodulator.cpp:605-657) on rx_buffer = audio[0, n): a demodulator is
+// put into the state that arms it (SYNCED, symbols demodulated, two idle calls) and process() is called ONCE with the
+// whole buffer.  found / consume are read off what process() did: a detection resets synced_symbol_count (set to 100
+// beforehand) and erases `consume` samples before the symbol loop takes whole symbols.  The Schmidl-Cox offset and the
+// coarse CFO it was declared with are re-derived on a probe demodulator holding the same buffer with the reference's own
+// Impl::measureCorrelation / refineLTSTiming / estimateCoarseCFO (the symbol loop has moved freq_offset_hz on by then).
+int ref_midframe_search(const ultra_hip_config* c, const float* audio, uint32_t n, uint32_t* found, uint32_t* sts_start,
+                        uint32_t* refined_lts, uint32_t* consume, float* coarse_cfo) {
+    StderrMute mute;
+    ModemConfig cfg = to_cfg(c);
+    *found = 0; *sts_start = 0; *refined_lts = 0; *consume = 0; *coarse_cfo = 0;
+    OFDMDemodulator demod(cfg);
+    demod.impl_->state.store(OFDMDemodulator::Impl::State::SYNCED);
+    demod.impl_->synced_symbol_count.store(100);
+    demod.impl_->idle_call_count.store(2);
+    demod.process(SampleSpan(audio, n));
+    const int count = demod.impl_->synced_symbol_count.load();
+    const size_t sym = demod.impl_->symbol_samples, psl = cfg.fft_size + cfg.getCyclicPrefix();
+    if (count >= 100) return 0;                                       // no detection: the loop went on counting
+    *found = 1;
+    *consume = (uint32_t)(n - demod.impl_->rx_buffer.size() - (size_t)count * sym);
+    *refined_lts = *consume - (uint32_t)(2 * psl);
+    OFDMDemodulator probe(cfg);
+    probe.impl_->rx_buffer.assign(audio, audio + n);
+    for (size_t offset = 0; offset + 6 * psl <= n; offset += 8) {
+        if (probe.impl_->measureCorrelation(offset) > probe.impl_->sync_threshold &&
+            probe.impl_->refineLTSTiming(offset) == (size_t)*refined_lts) {
+            *sts_start = (uint32_t)offset;
+            *coarse_cfo = probe.impl_->estimateCoarseCFO(offset);
+            break;
+        }
+    }
+    return 0;
+}
+
 // Acquisition (scope row f1): OFDMDemodulator::process in the SEARCHING state, fed in `chunk`-sample
 // calls (src/ofdm/demodulator.cpp:461-600).  Reports, per stream: whether sync was declared, after how
 // many fed samples, the Schmidl-Cox offset (last_sync_offset, relative to the buffer at that call), the

@@ -1616,6 +1616,38 @@ int uo_acquire(const ultra_hip_config* c, const float* audio, uint32_t n, uint32
     return 0;
 }
 
+/* The preamble check of the SYNCED state, src/ofdm/demodulator.cpp:605-657, on rx_buffer = audio[0, n): the first offset
+ * 0, 8, .. <= min(n - 6 preamble symbols, 2 data symbols) whose Schmidl-Cox metric exceeds the threshold AND whose LTS
+ * confirmation holds (a failed confirmation continues the scan).  consume = what process() erases (:629).  The counters
+ * that arm the check (synced_symbol_count > 0, idle_call_count >= 2) are the caller's. */
+int uo_midframe_search(const ultra_hip_config* c, const float* audio, uint32_t n, uint32_t* found, uint32_t* sts_start,
+                       uint32_t* refined_lts, uint32_t* consume, float* coarse_cfo) {
+    acq* a = (acq*)malloc(sizeof(acq));
+    if (!a) return -1;
+    if (acq_init(a, c) != 0) { free(a); return -1; }
+    *found = 0; *sts_start = 0; *refined_lts = 0; *consume = 0; *coarse_cfo = 0;
+    const size_t psl = c->fft_size + a->d.cp, preamble_total = psl * 6;
+    const size_t symbol_samples = c->fft_size + a->d.cp + c->symbol_guard;
+    if (n >= preamble_total) {
+        size_t search_limit = n - preamble_total;
+        if (symbol_samples * 2 < search_limit) search_limit = symbol_samples * 2;
+        for (size_t offset = 0; offset <= search_limit; offset += 8) {
+            float corr = acq_sc(a, audio, n, offset, NULL, NULL);
+            if (corr > a->sync_threshold) {
+                size_t refined = acq_refine_lts(a, audio, n, offset);
+                if (refined == (size_t)-1) continue;
+                *found = 1; *sts_start = (uint32_t)offset; *refined_lts = (uint32_t)refined;
+                *consume = (uint32_t)(refined + 2 * psl);
+                *coarse_cfo = acq_coarse_cfo(a, audio, n, offset);
+                break;
+            }
+        }
+    }
+    demod_free(&a->d);
+    free(a);
+    return 0;
+}
+
 /* Stage probes for the tests (same outputs as ref_sc_metric / ref_lts_templates in oracle/ref_shim.cpp) */
 int uo_sc_metric(const ultra_hip_config* c, const float* audio, uint32_t n, uint32_t offset,
                  float* corr, float* p_re, float* p_im, float* energy, float* noise_floor_io, uint32_t* has_energy) {

@@ -64,6 +64,10 @@ int uo_nco(float freq, float fs, uint32_t n, float* out_ri);
 int uo_acquire(const ultra_hip_config* c, const float* audio, uint32_t n, uint32_t chunk,
                uint32_t* found, uint32_t* fed_at_sync, uint32_t* sync_offset, float* coarse_cfo,
                uint32_t* refined_lts, uint32_t* data_start, float* noise_floor);
+/* the preamble check of the SYNCED state (demodulator.cpp:605-657) on rx_buffer = audio[0, n); same outputs as
+ * ref_midframe_search */
+int uo_midframe_search(const ultra_hip_config* c, const float* audio, uint32_t n, uint32_t* found, uint32_t* sts_start,
+                       uint32_t* refined_lts, uint32_t* consume, float* coarse_cfo);
 int uo_sc_metric(const ultra_hip_config* c, const float* audio, uint32_t n, uint32_t offset,
                  float* corr, float* p_re, float* p_im, float* energy, float* noise_floor_io, uint32_t* has_energy);
 int uo_lts_templates(const ultra_hip_config* c, float* I, float* Q, uint32_t cap);

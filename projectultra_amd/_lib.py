@@ -70,6 +70,7 @@ PROTOTYPES = {
     "ultra_hip_demod_stream_batch": (_i, [_vp, _vp, _sz, _vp, _vp, _sz, C.c_uint32, C.c_uint32, _vp, _vp]),
     "ultra_hip_demod_stream_set_cfo": (_i, [_vp, _sz, C.c_float]),
     "ultra_hip_acquire_stream_batch": (_i, [_vp, _vp, _sz, C.c_uint32, C.c_uint32, _sz, _vp, _vp, _vp, _vp, _vp]),
+    "ultra_hip_resync_stream_batch": (_i, [_vp, _vp, _sz, C.c_uint32, C.c_uint32, _sz, _vp, _vp, _vp, _vp, _vp]),
     "ultra_hip_demod_decode_batch": (_i, [_vp, _vp, _sz, _vp, _vp, _sz, _vp, _vp, _vp, _vp]),
     "ultra_hip_count_errors": (_i, [_vp, _vp, _vp, _vp, _vp, _sz, _sz, _vp]),
     "ultra_hip_reserve": (_i, [_vp, _sz]),

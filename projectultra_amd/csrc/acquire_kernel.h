@@ -401,7 +401,7 @@ __device__ __attribute__((noinline)) void acq_window_metric_call(AcqShared<LOG2N
                                                                  float* R1, float* R2) {
     acq_window_metric<LOG2N>(sh, ltw, win, dc_sum, P_out, R1, R2);
 }
-template <int LOG2N>
+template <int LOG2N, bool MIDFRAME>
 __global__ __launch_bounds__(kWave, (LOG2N == 10) ? 3 : 4) void acquire_kernel(
     const DemodConst* __restrict__ Dp, const c32* __restrict__ twiddle, const float* __restrict__ lts_I,
     const float* __restrict__ lts_Q, float energy_ref, float sync_threshold, const float* __restrict__ audio,
@@ -413,7 +413,11 @@ __global__ __launch_bounds__(kWave, (LOG2N == 10) ? 3 : 4) void acquire_kernel(
     // search can still look at), and resume[s] = {base, fed, noise floor, -} is what OFDMDemodulator::Impl carries
     // from one process() call to the next in the SEARCHING state: where rx_buffer starts, how much was fed, and the
     // energy gate's noise floor — the only state of the search (everything else is recomputed from the samples).
+    // MIDFRAME (an instance of its own, ultra_hip_resync_stream_batch): the preamble check of the SYNCED state (demodulator.cpp:605-657) on the
+    // buffer [resume[4 s], n_samples): offsets 0, 8, .. <= min(size - 6 preamble symbols, 2 data symbols), no energy gate,
+    // no plateau test — the first offset above the threshold whose LTS confirmation holds wins; resume is only read.
     constexpr int N = 1 << LOG2N;
+    constexpr bool midframe = MIDFRAME;
     constexpr bool kCalls = (LOG2N == 10);                   // phases as out-of-line functions, see above
     __shared__ AcqShared<LOG2N> sh;
     const DemodConst& D = *Dp;
@@ -446,11 +450,16 @@ __global__ __launch_bounds__(kWave, (LOG2N == 10) ? 3 : 4) void acquire_kernel(
         float grp_dc = 0.0f;                                  // lane g: dc sum of the window at grp_first + 8 g
         for (int c = lane; c < kAcqCache; c += kWave) sh.ctag[c] = 0xffffffffu;
         wave_sync();
+        if (midframe) fed = base;                             // one call over everything buffered
         while (fed < n_samples && !found) {
-            fed += (n_samples - fed < chunk) ? (n_samples - fed) : chunk;
+            fed += (midframe || n_samples - fed < chunk) ? (n_samples - fed) : chunk;
             unsigned size = fed - base;
-            if (size < kAcqMinSearch) continue;
-            if (size > kAcqMaxBuffer) { base = fed - kAcqOverlap; size = kAcqOverlap; }
+            if (midframe) {
+                if (size < preamble_total) break;
+            } else {
+                if (size < kAcqMinSearch) continue;
+                if (size > kAcqMaxBuffer) { base = fed - kAcqOverlap; size = kAcqOverlap; }
+            }
             const float* buf = all + base;
             // The search (demodulator.cpp:497-531) as a state machine with ONE metric evaluation per turn:
             //   SEARCH   candidate i passes the energy gate -> metric at i; above threshold -> PLATEAU
@@ -459,17 +468,23 @@ __global__ __launch_bounds__(kWave, (LOG2N == 10) ? 3 : 4) void acquire_kernel(
             bool found_sync = false;
             unsigned so = 0;
             float c0 = 0.0f;
-            const unsigned search_end = (size > preamble_total + corr_win) ? size - preamble_total - corr_win : 0u;
+            unsigned search_end = (size > preamble_total + corr_win) ? size - preamble_total - corr_win : 0u;
+            if (midframe) {                                           // offset <= search_limit (:611-615)
+                const unsigned a = size - preamble_total, b = 2u * (unsigned)D.sym_len;
+                search_end = ((a < b) ? a : b) + 1u;
+            }
             enum { kSearch, kPlateau, kCfo };
             int mode = kSearch;
             unsigned i = 0, j = 0, plateau = 0, peak_pos = 0;
             float peak = 0.0f;
+          rescan:
+            found_sync = false;
             for (;;) {
                 unsigned off;
                 if (mode == kSearch) {
                     if (i >= search_end) break;
-                    bool energetic = false;
-                    if (i + corr_win <= size) {                      // hasMinimumEnergy: window inside the buffer
+                    bool energetic = midframe;
+                    if (!midframe && i + corr_win <= size) {         // hasMinimumEnergy: window inside the buffer
                         const unsigned gabs = base + i, d = gabs - gate_first;
                         if (gabs < gate_first || (d & 7u) != 0u || d >= 8u * kWave) {
                             gate_first = gabs;
@@ -535,8 +550,10 @@ __global__ __launch_bounds__(kWave, (LOG2N == 10) ? 3 : 4) void acquire_kernel(
                     wave_sync();
                 }
                 if (mode == kSearch) {
-                    if (corr > sync_threshold) { mode = kPlateau; j = 0; plateau = 0; peak = corr; peak_pos = i; }
-                    else i += kAcqStep;
+                    if (corr > sync_threshold) {
+                        if (midframe) { so = i; mode = kCfo; }
+                        else { mode = kPlateau; j = 0; plateau = 0; peak = corr; peak_pos = i; }
+                    } else i += kAcqStep;
                 } else {
                     if (corr >= 0.90f) plateau++;
                     if (corr > peak) { peak = corr; peak_pos = i + j; }
@@ -548,6 +565,7 @@ __global__ __launch_bounds__(kWave, (LOG2N == 10) ? 3 : 4) void acquire_kernel(
                 // line they are per-lane flat loads the loop waits for at every tap (22.2 against 20.1 ms)
                 const unsigned refined = acq_refine_lts<LOG2N>(sh, D, lts_I, lts_Q, energy_ref, buf, size, so);
                 if (refined == 0xffffffffu) {
+                    if (midframe) { i = so + kAcqStep; mode = kSearch; goto rescan; }     // "continue" of :621-624
                     if (size > kAcqOverlap * 2u) {
                         unsigned trim = so + psl;
                         if (trim > size - kAcqOverlap) trim = size - kAcqOverlap;
@@ -557,11 +575,11 @@ __global__ __launch_bounds__(kWave, (LOG2N == 10) ? 3 : 4) void acquire_kernel(
                     found = 1; fed_at = fed; so_out = so; cfo = c0;
                     ds_out = base + refined + 2u * psl;
                 }
-            } else if (size > kAcqOverlap * 2u) {
+            } else if (!midframe && size > kAcqOverlap * 2u) {
                 base += size - kAcqOverlap;
             }
         }
-        if (lane == 0 && resume) { resume[4 * stream] = base; resume[4 * stream + 1] = fed; resume[4 * stream + 2] = __float_as_uint(noise_floor); }
+        if (lane == 0 && resume && !midframe) { resume[4 * stream] = base; resume[4 * stream + 1] = fed; resume[4 * stream + 2] = __float_as_uint(noise_floor); }
         if (lane == 0) {
             found_out[stream] = found;
             data_start_out[stream] = ds_out;

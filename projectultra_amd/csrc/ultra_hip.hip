@@ -800,22 +800,19 @@ int ultra_hip_demod_decode_batch(ultra_hip_ctx* ctx, const float* d_audio, size_
 namespace {
 int launch_acquire(ultra_hip_ctx* ctx, const float* d_audio, size_t stream_stride, uint32_t n_samples, uint32_t chunk,
                    size_t n_streams, uint32_t* d_found, uint32_t* d_data_start, float* d_cfo_hz, uint32_t* d_sync_offset,
-                   uint32_t* d_fed_at_sync, uint32_t origin, uint32_t* d_resume) {
+                   uint32_t* d_fed_at_sync, uint32_t origin, uint32_t* d_resume, uint32_t midframe = 0u) {
     const unsigned grid = (unsigned)std::min(n_streams, (size_t)ctx->cu_count * 64);
     LaunchSpan span(ctx, ULTRA_HIP_K_ACQUIRE);
     const float* lts_I = ctx->d_lts;
     const float* lts_Q = ctx->d_lts + ctx->lts_len;
     const float sync_threshold = 0.80f;          // ModemConfig::sync_threshold default (types.hpp:188)
-    if (ctx->h_demod.log2_fft == 10)
-        hipLaunchKernelGGL(dev::acquire_kernel<10>, dim3(grid), dim3(dev::kWave), 0, ctx->stream, ctx->d_demod,
-                           ctx->d_twiddle, lts_I, lts_Q, ctx->lts_energy_ref, sync_threshold, d_audio, stream_stride,
-                           n_samples, chunk, (int)n_streams, d_found, d_data_start, d_cfo_hz, d_sync_offset,
-                           d_fed_at_sync, origin, d_resume);
-    else if (ctx->h_demod.log2_fft == 9)
-        hipLaunchKernelGGL(dev::acquire_kernel<9>, dim3(grid), dim3(dev::kWave), 0, ctx->stream, ctx->d_demod,
-                           ctx->d_twiddle, lts_I, lts_Q, ctx->lts_energy_ref, sync_threshold, d_audio, stream_stride,
-                           n_samples, chunk, (int)n_streams, d_found, d_data_start, d_cfo_hz, d_sync_offset,
-                           d_fed_at_sync, origin, d_resume);
+    auto launch = [&](auto kernel) {
+        hipLaunchKernelGGL(kernel, dim3(grid), dim3(dev::kWave), 0, ctx->stream, ctx->d_demod, ctx->d_twiddle, lts_I, lts_Q,
+                           ctx->lts_energy_ref, sync_threshold, d_audio, stream_stride, n_samples, chunk, (int)n_streams, d_found,
+                           d_data_start, d_cfo_hz, d_sync_offset, d_fed_at_sync, origin, d_resume);
+    };
+    if (ctx->h_demod.log2_fft == 10) { if (midframe) launch(dev::acquire_kernel<10, true>); else launch(dev::acquire_kernel<10, false>); }
+    else if (ctx->h_demod.log2_fft == 9) { if (midframe) launch(dev::acquire_kernel<9, true>); else launch(dev::acquire_kernel<9, false>); }
     else
         return ULTRA_HIP_ERR_UNSUPPORTED;
     UH_HIP(hipGetLastError());
@@ -848,6 +845,20 @@ int ultra_hip_acquire_stream_batch(ultra_hip_ctx* ctx, const float* d_audio, siz
     // one process() call: everything fed since the last launch is one chunk
     return launch_acquire(ctx, d_audio, stream_stride, n_samples, 0xffffffffu, n_streams, d_found, d_data_start, d_cfo_hz,
                           d_sync_offset, nullptr, origin, d_resume);
+}
+
+int ultra_hip_resync_stream_batch(ultra_hip_ctx* ctx, const float* d_audio, size_t stream_stride, uint32_t origin,
+                                  uint32_t n_samples, size_t n_streams, const uint32_t* d_resume, uint32_t* d_found,
+                                  uint32_t* d_data_start, float* d_cfo_hz, uint32_t* d_sync_offset) {
+    if (!ctx) return ULTRA_HIP_ERR_INVALID_ARG;
+    if (n_streams == 0) return ULTRA_HIP_OK;
+    if (!d_audio || !d_resume || !d_found || !d_data_start || !d_cfo_hz || n_samples < origin ||
+        stream_stride < (size_t)(n_samples - origin) || n_streams > 0x7fffffffull || n_samples > 0x3fffffffu)
+        return ULTRA_HIP_ERR_INVALID_ARG;
+    DeviceGuard guard(ctx->device);
+    // the kernel only reads the records in this mode
+    return launch_acquire(ctx, d_audio, stream_stride, n_samples, 0xffffffffu, n_streams, d_found, d_data_start, d_cfo_hz,
+                          d_sync_offset, nullptr, origin, const_cast<uint32_t*>(d_resume), 1u);
 }
 
 int ultra_hip_receive_batch(ultra_hip_ctx* ctx, const float* d_audio, size_t stream_stride, uint32_t n_samples,

@@ -303,10 +303,11 @@ class ReceiveContext:
                                                out["fed_at_sync"].data_ptr()), "ultra_hip_acquire_batch")
         return out
 
-    def acquire_stream(self, audio, origin: int, n_samples: int, resume):
+    def acquire_stream(self, audio, origin: int, n_samples: int, resume, midframe: bool = False):
         """ONE process() call of the SEARCHING state for live streams (ultra_hip_acquire_stream_batch): audio [n][>= n_samples
         - origin] holds samples [origin, n_samples) of every stream, resume = device int32 [n][4] in/out ({start of rx_buffer,
-        fed, noise floor bits, -}).  Returns device tensors dict(found, data_start, cfo_hz, sync_offset)."""
+        fed, noise floor bits, -}).  Returns device tensors dict(found, data_start, cfo_hz, sync_offset).
+        midframe=True: the preamble check of the SYNCED state instead (ultra_hip_resync_stream_batch; resume is only read)."""
         torch = _torch()
         self._check_stream()
         audio = self._dev(audio, torch.float32, "audio")
@@ -318,9 +319,10 @@ class ReceiveContext:
                    data_start=torch.zeros(n, dtype=torch.int32, device=self.device),
                    cfo_hz=torch.zeros(n, dtype=torch.float32, device=self.device),
                    sync_offset=torch.zeros(n, dtype=torch.int32, device=self.device))
-        check(self.lib.ultra_hip_acquire_stream_batch(self._ctx, audio.data_ptr(), self._row_stride(audio), int(origin), int(n_samples), n,
-                                                      resume.data_ptr(), out["found"].data_ptr(), out["data_start"].data_ptr(),
-                                                      out["cfo_hz"].data_ptr(), out["sync_offset"].data_ptr()), "ultra_hip_acquire_stream_batch")
+        entry = "ultra_hip_resync_stream_batch" if midframe else "ultra_hip_acquire_stream_batch"
+        check(getattr(self.lib, entry)(self._ctx, audio.data_ptr(), self._row_stride(audio), int(origin), int(n_samples), n,
+                                       resume.data_ptr(), out["found"].data_ptr(), out["data_start"].data_ptr(),
+                                       out["cfo_hz"].data_ptr(), out["sync_offset"].data_ptr()), entry)
         return out
 
     def chirp_sync(self, audio, threshold: float = 0.15):

@@ -101,8 +101,9 @@ class OFDMDemodulator:
         from the previous call's state (ultra_hip_acquire_stream_batch); once SYNCED whole symbols are demodulated as
         they arrive, the tracker continuing on the device (ultra_hip_demod_stream_batch); SYNCED is left after more than
         250 symbols, more than 10 calls without a new soft bit, or an empty call with nothing left (frame complete), and
-        the search restarts on what is still buffered.  True when at least 648 soft bits are buffered.  Not reproduced:
-        the mid-frame preamble re-detection of :605-657."""
+        the search restarts on what is still buffered; a new preamble arriving while SYNCED (symbols demodulated, two calls
+        or more without a soft bit, six preamble symbols buffered: :605-657) restarts the demodulation on the new frame
+        (ultra_hip_resync_stream_batch).  True when at least 648 soft bits are buffered."""
         import torch
         samples = np.ascontiguousarray(samples, np.float32).reshape(-1)
         ctx = self._context(Entry.SYNCED, self.MAX_SYMBOLS_BEFORE_TIMEOUT + 1, 0)
@@ -128,6 +129,17 @@ class OFDMDemodulator:
         if not self._synced:
             return False
         sym = ctx.geometry.symbol_samples
+        preamble_total = 6 * (self.config.fft_size + ctx.geometry.cp_len)
+        if self._synced_symbols > 0 and self._idle_calls >= 2 and self._rx.size >= preamble_total:       # :605-657
+            here = torch.tensor([[_i32(self._origin), _i32(self._fed), 0, 0]], dtype=torch.int32, device=ctx.device)
+            r = ctx.acquire_stream(torch.from_numpy(self._rx).reshape(1, -1), self._origin, self._fed, here, midframe=True)
+            ctx.synchronize()
+            if int(r["found"][0]):
+                self._cfo_hz, self._cfo_phase = float(r["cfo_hz"][0]), 0.0
+                self._coarse_cfo = self._cfo_hz
+                self._consume_to(int(r["data_start"][0]))
+                self._soft_bits = np.zeros(0, np.float32)
+                self._synced_symbols, self._idle_calls, self._state = 0, 0, None
         n_new = min(self._rx.size // sym, self.MAX_SYMBOLS_BEFORE_TIMEOUT + 1 - self._synced_symbols)
         before = self._soft_bits.size
         if n_new > 0:

@@ -230,4 +230,27 @@ STREAM_SCENARIOS = {
     "idle_reset": lambda sym, pre: [("frame", 0), ("feed", 960, 0), ("zeros", 3 * sym), ("feed", sym // 12, 0), ("frame", 2), ("feed", 960, 2)],
     # timeout: the demodulator is kept busy for more than MAX_SYMBOLS_BEFORE_TIMEOUT = 250 symbols
     "timeout": lambda sym, pre: [("frame", 1), ("tile", 1, pre, sym, 262), ("feed", 960, 1)],
+    # a new preamble while SYNCED (demodulator.cpp:605-657): the first frame stops after two and a half data symbols, two
+    # 30-sample calls bring no soft bit, then the second frame arrives in ONE call — the demodulator abandons the old frame
+    "midframe": lambda sym, pre: [("tile", 0, 0, pre + 2 * sym + sym // 2, 1), ("feed", 960, 0), ("zeros", 60), ("feed", 30, 0),
+                                  ("zeros", 200), ("frame", 1), ("zeros", 960), ("feed", 1 << 20, 2)],
 }
+
+
+def midframe_buffers(frames, pre, sym, lead_in, seed=7, n=12):
+    """rx_buffer contents for the preamble check of the SYNCED state (uo_/ref_midframe_search, ultra_hip_resync_stream_batch):
+    the rest of an interrupted data symbol of frame 0, a gap, then frame 1 or 2 with most of its own lead-in cut off, light
+    noise over everything; the last cases are cut short (fewer than six preamble symbols: no search) or start too late (the
+    preamble lies behind the two symbols the check looks at)."""
+    rng = np.random.default_rng(seed)
+    out = []
+    for t in range(n):
+        gap = int(rng.integers(0, sym))
+        tail_old = frames[0][pre + 2 * sym: pre + 2 * sym + int(rng.integers(0, sym // 2))]
+        if t % 6 == 5:
+            gap += 2 * sym                                                  # too late for the check
+        buf = np.concatenate([tail_old, np.zeros(gap, np.float32), frames[1 + t % 2][lead_in * 3 // 4:]])
+        if t % 6 == 4:
+            buf = buf[:int(rng.integers(5 * sym, 7 * sym))]                 # around the six-symbol minimum
+        out.append((buf + rng.normal(0, 0.003, buf.size)).astype(np.float32))
+    return out

@@ -204,7 +204,7 @@ def stream():
     SYNCED state and re-acquisition.  The audio is rebuilt from fullsync.npz's frames by tests/_util.build_stream; only
     the per-call outputs are stored."""
     sys.path.insert(0, str(ROOT / "tests"))
-    from _util import STREAM_SCENARIOS, build_stream, cfg_from_array
+    from _util import STREAM_SCENARIOS, build_stream, cfg_from_array, midframe_buffers
     g = np.load(OUT / "fullsync.npz")
     d = {}
     for name in ("cfg3_qam16_r34", "cfg2_dqpsk_r12"):
@@ -212,6 +212,11 @@ def stream():
         geo = geometry(cfg)
         frames = g[f"{name}__audio"]
         pre = int(g[f"{name}__meta"][0][0])
+        # the preamble check of the SYNCED state on its own (ref_midframe_search: process() armed and called once)
+        res = [r.midframe_search(cfg, b) for b in midframe_buffers(frames, pre, geo.symbol_samples, int(g[f"{name}__meta"][0][1]))]
+        d[f"{name}__midframe_ints"] = np.array([[q["found"], q["sts_start"], q["refined_lts"], q["consume"]] for q in res], np.int64)
+        d[f"{name}__midframe_cfo"] = np.array([q["coarse_cfo"] for q in res], np.float32)
+        print(name, "midframe probes", [(q["found"], q["consume"]) for q in res])
         for sc, recipe in STREAM_SCENARIOS.items():
             audio, chunks = build_stream(frames, recipe(geo.symbol_samples, pre))
             ready, synced, drained, soft = r.demod_stream(cfg, audio, chunks)

@@ -569,6 +569,48 @@ def test_stream_and_block_entries_refuse_bad_arguments():
 
 
 @pytest.mark.parametrize("name", ["cfg3_qam16_r34", "cfg2_dqpsk_r12"])
+def test_midframe_preamble_check_equals_oracle(oracle, name):
+    """ultra_hip_resync_stream_batch — the preamble check of the SYNCED state (demodulator.cpp:605-657) — for a batch of
+    streams whose buffers start at different absolute positions, against uo_midframe_search (pinned to process() itself in
+    tests/test_oracle_vs_ref.py::test_midframe_search and by tests/golden/stream.npz): found, data start, Schmidl-Cox
+    offset exactly, coarse CFO bitwise; records are not written."""
+    import torch
+    from _util import midframe_buffers, modem_config_from_c
+    from projectultra_amd import ReceiveContext
+    g = np.load(GOLDEN / "fullsync.npz")
+    cfg = cfg_from_array(g[f"{name}__cfg"])
+    mc, _ = modem_config_from_c(cfg)
+    geo = geometry(cfg)
+    meta = g[f"{name}__meta"][0]
+    bufs = midframe_buffers(g[f"{name}__audio"], int(meta[0]), geo.symbol_samples, int(meta[1]), seed=21, n=18)
+    ctx = ReceiveContext(mc)
+    origin = 5000                                              # the window starts here; every stream's buffer a bit later
+    base = [origin + 37 * i for i in range(len(bufs))]
+    n_samples = max(b + x.size for b, x in zip(base, bufs))
+    audio = np.zeros((len(bufs), n_samples - origin), np.float32)
+    for i, (b, x) in enumerate(zip(base, bufs)):
+        audio[i, :b - origin] = 0.25                           # before rx_buffer: must not be looked at
+        x = x[:n_samples - b] if i % 5 else x                  # all buffers end at n_samples (rows are padded by repeating)
+        audio[i, b - origin: b - origin + x.size] = x
+        bufs[i] = audio[i, b - origin:].copy()                 # what the stream's rx_buffer really holds
+    resume = torch.tensor([[b, n_samples, 0x3f000000, 0] for b in base], dtype=torch.int32, device=ctx.device)
+    keep = resume.clone()
+    r = ctx.acquire_stream(audio, origin, n_samples, resume, midframe=True)
+    ctx.synchronize()
+    assert torch.equal(resume, keep)
+    r = {k: v.cpu().numpy() for k, v in r.items()}
+    hits = 0
+    for i, (b, x) in enumerate(zip(base, bufs)):
+        o = oracle.midframe_search(cfg, x)
+        assert r["found"][i] == o["found"], (i, o)
+        if o["found"]:
+            hits += 1
+            assert r["data_start"][i] == b + o["consume"] and r["sync_offset"][i] == o["sts_start"], (i, o, r["data_start"][i])
+            assert np.float32(r["cfo_hz"][i]).tobytes() == np.float32(o["coarse_cfo"]).tobytes(), (i, o)
+    assert 6 <= hits < len(bufs)
+
+
+@pytest.mark.parametrize("name", ["cfg3_qam16_r34", "cfg2_dqpsk_r12"])
 def test_demodulator_mirror_live_stream(name):
     """projectultra_amd.OFDMDemodulator.process() as a live stream (the Python twin of HipOfdmCoxWaveform) against the compiled
     reference call by call (tests/golden/stream.npz): frame-complete exit and re-acquisition, idle exit, 250-symbol timeout."""

@@ -336,9 +336,29 @@ def test_stream_fixture_is_the_reference(ref):
     cfg = cfg_from_array(g[f"{name}__cfg"])
     geo = geometry(cfg)
     pre = int(g[f"{name}__meta"][0][0])
-    for sc in ("two_frames", "idle_reset"):
+    for sc in ("two_frames", "idle_reset", "midframe"):
         audio, chunks = build_stream(g[f"{name}__audio"], STREAM_SCENARIOS[sc](geo.symbol_samples, pre))
         ready, synced, drained, soft = ref.demod_stream(cfg, audio, chunks)
         assert np.array_equal(ready, want[f"{name}__{sc}__ready"]) and np.array_equal(synced, want[f"{name}__{sc}__synced"])
         assert np.array_equal(drained, want[f"{name}__{sc}__drained"]) and beq(soft, want[f"{name}__{sc}__soft"])
         assert synced.any() and not synced[-1]              # it did sync, and it did leave SYNCED again
+
+
+@pytest.mark.parametrize("name", ["cfg3_qam16_r34", "cfg2_dqpsk_r12"])
+def test_midframe_search(oracle, ref, name):
+    """The preamble check of the SYNCED state (demodulator.cpp:605-657): the restatement against process() itself (armed and
+    called once, oracle/ref_shim.cpp) on buffers with the new preamble inside, outside and across the limits of the scan."""
+    from _util import cfg_from_array, midframe_buffers
+    from conftest import GOLDEN
+    g = np.load(GOLDEN / "fullsync.npz")
+    cfg = cfg_from_array(g[f"{name}__cfg"])
+    geo = geometry(cfg)
+    meta = g[f"{name}__meta"][0]
+    hits = 0
+    for seed in (7, 8):
+        for buf in midframe_buffers(g[f"{name}__audio"], int(meta[0]), geo.symbol_samples, int(meta[1]), seed=seed):
+            a, b = ref.midframe_search(cfg, buf), oracle.midframe_search(cfg, buf)
+            assert {k: v for k, v in a.items() if k != "coarse_cfo"} == {k: v for k, v in b.items() if k != "coarse_cfo"}, (a, b)
+            assert np.float32(a["coarse_cfo"]).tobytes() == np.float32(b["coarse_cfo"]).tobytes(), (a, b)
+            hits += a["found"]
+    assert 8 <= hits < 24

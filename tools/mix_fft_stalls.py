@@ -38,7 +38,7 @@ def static_phases(one_wave):
                                    "-fhip-fp32-correctly-rounded-divide-sqrt", "-DUH_MIXFFT_STAMPS"] + os.environ.get("STAMP_FLAGS", "").split() + ["-S", "--cuda-device-only", "-o", "-", str(src)],
                                   stderr=subprocess.DEVNULL, cwd=src.parent).decode()
     fns = im.functions(asm)
-    key = "mix_fft_kernelILi10E" if one_wave else "mix_fft2_kernelILi10E"
+    key = "mix_fft_kernelILi10E" if one_wave else "mix_fft2_kernelILi10ELb1E"
     body = next(v for k, v in fns.items() if key in k)
     cuts = [i for i, l in enumerate(body) if "UHSTAMP" in l]
     ids = [int(re.search(r"UHSTAMP (\d+)", body[i]).group(1)) for i in cuts]
