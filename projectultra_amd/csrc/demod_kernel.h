@@ -503,18 +503,19 @@ __device__ __forceinline__ void symbol_to_freq(FftShared<LOG2N>& sh, const Demod
 // on the same operands in the same order as the one-wavefront kernel: bit-identical bins.
 template <int LOG2N, bool ROT = true>
 struct Fft2Shared {
-    static_assert(LOG2N == 10, "two-wavefront layout: N = 1024");
-    static constexpr int N = 1 << LOG2N, M = N / 2;         // M-point transform per wavefront
+    static_assert(LOG2N == 10 || LOG2N == 9, "512 points per wavefront: N = 1024 on two wavefronts, N = 512 on one");
+    static constexpr int W = (LOG2N == 10) ? 2 : 1;         // wavefronts per work item; W = 1: the same code on all N points
+    static constexpr int N = 1 << LOG2N, M = N / W;         // M-point transform per wavefront
     static constexpr int P = M / kWave;                     // 8 points per lane
     static constexpr int A = 3;                             // log2(P); 3 groups of 3 stages + the joint last stage
-    c32 X[2][M + M / P];                                    // per-wavefront exchange buffer, 1 pad per P entries
-    float stage[2][M];                                      // landing zone of the NEXT item's samples (asynchronous copy)
+    c32 X[W][M + M / P];                                    // per-wavefront exchange buffer, 1 pad per P entries
+    float stage[W][M];                                      // landing zone of the NEXT item's samples (asynchronous copy)
     static constexpr int kTwB = P * ((1 << A) - 1);
     c32 twB[kTwB];                                          // twiddles of stages A..2A-1 (as in FftShared)
     // the rotation's lookup tables: not in the instance without it (15.8 KB instead of 17.9: ten workgroups per CU)
-    um::PhaseSeg seg[2][ROT ? kPhaseCap + 2 : 1];           // two entries behind the last segment: start = INT_MAX
-    int seg_start[2][ROT ? kPhaseCap + 4 : 4] __attribute__((aligned(16)));
-    c32 xch[2][2][kWave];                                   // [frame parity][writer][lane]: E_hi from wavefront 0, O_lo from 1
+    um::PhaseSeg seg[W][ROT ? kPhaseCap + 2 : 1];           // two entries behind the last segment: start = INT_MAX
+    int seg_start[W][ROT ? kPhaseCap + 4 : 4] __attribute__((aligned(16)));
+    c32 xch[W == 2 ? 2 : 1][2][W == 2 ? kWave : 1];         // [frame parity][writer][lane]: E_hi from wavefront 0, O_lo from 1
 };
 
 // What an item needs from memory besides its samples: the tracker's CFO and phase and this lane's entry of the frame's
@@ -538,15 +539,16 @@ __device__ __forceinline__ void request_item(MixItem& it, const unsigned* __rest
     }
 }
 
-// staging of the samples of parity h of one symbol's FFT window: stage[64 q + l] = window[2 (64 q + l) + h]
+// staging of the samples of parity h of one symbol's FFT window: stage[64 q + l] = window[2 (64 q + l) + h] (W = 1: all
+// samples, window[64 q + l])
 template <int LOG2N, bool ROT>
 __device__ __forceinline__ void prefetch_symbol2(Fft2Shared<LOG2N, ROT>& sh, const int cp, int h, int lane,
                                                  const float* __restrict__ audio_sym) {
-    constexpr int P = Fft2Shared<LOG2N>::P;
+    constexpr int P = Fft2Shared<LOG2N>::P, W = Fft2Shared<LOG2N>::W;
     float* stage = sh.stage[h];
 #pragma unroll
     for (int q = 0; q < P; ++q)
-        __builtin_amdgcn_global_load_lds(audio_sym + cp + 2 * (64 * q + lane) + h, stage + 64 * q, 4, 0, 0);
+        __builtin_amdgcn_global_load_lds(audio_sym + cp + W * (64 * q + lane) + h, stage + 64 * q, 4, 0, 0);
 }
 
 // per-lane values that do not change from item to item: the oscillator at the lane's 8 samples (for one symbol index)
@@ -564,9 +566,10 @@ struct Mix2Lane {
 template <int LOG2N, bool ROT, class NextFn>
 __device__ __forceinline__ void symbol_to_freq2(Fft2Shared<LOG2N, ROT>& sh, const DemodConst& D, const int h, const int lane,
                                                 MixItem& it, const Mix2Lane<LOG2N>& lc,
-                                                const c32* __restrict__ twiddle, c32& bin_out, const int par,
+                                                const c32* __restrict__ twiddle, c32& bin_out, c32& bin_hi, const int par,
                                                 const int cp, const int sym_len, NextFn request_next, Stamps& stamps) {
-    constexpr int P = Fft2Shared<LOG2N>::P, A = Fft2Shared<LOG2N>::A;
+    // W = 2: the lane's bin (of its wavefront's side) in bin_out.  W = 1: bin `lane` in bin_out, bin N - 64 + lane in bin_hi.
+    constexpr int P = Fft2Shared<LOG2N>::P, A = Fft2Shared<LOG2N>::A, W = Fft2Shared<LOG2N>::W;
     UH_STAMP(0);
     const int rl = (int)(__brev((unsigned)lane) >> 26);      // bitrev6(lane)
     const unsigned hw0 = (unsigned)__builtin_amdgcn_readlane((int)it.hw, 0);
@@ -588,7 +591,7 @@ __device__ __forceinline__ void symbol_to_freq2(Fft2Shared<LOG2N, ROT>& sh, cons
     wave_sync();
     float xs[P];
 #pragma unroll
-    for (int qp = 0; qp < P; ++qp) xs[qp] = stage[64 * qp + rl];               // window sample 2 (rl + 64 qp) + h
+    for (int qp = 0; qp < P; ++qp) xs[qp] = stage[64 * qp + rl];               // window sample W (rl + 64 qp) + h
     wave_sync();
     UH_STAMP(1);
     UH_STAMP(2);
@@ -628,8 +631,8 @@ __device__ __forceinline__ void symbol_to_freq2(Fft2Shared<LOG2N, ROT>& sh, cons
             if (lane < kPhaseCap + 4) seg_start[lane] = my_start;            // INT_MAX beyond the last segment
             wave_sync();
             UH_STAMP(11);
-            const int i0 = cp + 2 * P * lane + h - done;  // position of the lane's first sample inside this round
-            const int ilast = i0 + 2 * (P - 1);
+            const int i0 = cp + W * P * lane + h - done;  // position of the lane's first sample inside this round
+            const int ilast = i0 + W * (P - 1);
             if (done == 0) {
                 // The table round (positions i0 >= 0): the segment of the lane's first position WITHOUT a search.  Starts
                 // ascend with the segment index k and first positions with the lane, so segment k claims the lanes from
@@ -641,7 +644,7 @@ __device__ __forceinline__ void symbol_to_freq2(Fft2Shared<LOG2N, ROT>& sh, cons
                 // sample; lanes whose run holds more boundaries (or leaves the round) walk on through the LDS table.
                 const int first0 = cp + h;
                 const bool in_tab = lane < ns;
-                const int rk = (my_start - first0 + 2 * P - 1) >> (A + 1);
+                const int rk = (my_start - first0 + W * P - 1) >> (A + W - 1);
                 const bool claims = in_tab && my_start > first0 && rk <= 63;
                 // ds_permute: every lane PUSHES one word to a lane of its choice and, of several pushes to one lane, the
                 // highest pushing lane's arrives — the largest k, as wanted.  Lanes without a claim push a zero to lane 0,
@@ -662,7 +665,7 @@ __device__ __forceinline__ void symbol_to_freq2(Fft2Shared<LOG2N, ROT>& sh, cons
                 const int n2 = from_lane(my_start, sg + 2);                 // lanes >= ns hold INT_MAX (sg + 2 <= kPhaseCap + 1 < 64)
 #pragma unroll
                 for (int j = 0; j < P; ++j) {
-                    const int i = i0 + 2 * j;
+                    const int i = i0 + W * j;
                     const float a = um::phase_table_eval(cur, i), b = um::phase_table_eval(nxt, i);
                     ph[j] = (i < nxt.start) ? a : b;
                 }
@@ -675,7 +678,7 @@ __device__ __forceinline__ void symbol_to_freq2(Fft2Shared<LOG2N, ROT>& sh, cons
                         int nstart = nxt.start;
 #pragma unroll
                         for (int j = 0; j < P; ++j) {
-                            const int i = i0 + 2 * j;
+                            const int i = i0 + W * j;
                             if (i < covered) {
                                 while (i >= nstart) { ++sg; cur = seg[sg]; nstart = seg_start[sg + 1]; }
                                 ph[j] = um::phase_table_eval(cur, i);
@@ -685,7 +688,7 @@ __device__ __forceinline__ void symbol_to_freq2(Fft2Shared<LOG2N, ROT>& sh, cons
                 }
             } else if (ilast >= 0 && i0 < covered) {
                 // a round behind a table overflow (more than kPhaseCap segments in one symbol): the search
-                const int ifirst = (i0 >= 0) ? i0 : (i0 & 1);
+                const int ifirst = (i0 >= 0) ? i0 : (W == 2 ? (i0 & 1) : 0);
                 int cnt = 1;                                 // segments starting at or before ifirst (segment 0 starts at 0)
                 for (int k = 1; k < ns; ++k) cnt += (__builtin_amdgcn_readlane(my_start, k) <= ifirst) ? 1 : 0;
                 int sg = cnt - 1;
@@ -693,7 +696,7 @@ __device__ __forceinline__ void symbol_to_freq2(Fft2Shared<LOG2N, ROT>& sh, cons
                 int nstart = seg_start[sg + 1];
 #pragma unroll
                 for (int j = 0; j < P; ++j) {
-                    const int i = i0 + 2 * j;
+                    const int i = i0 + W * j;
                     if (i >= 0 && i < covered) {
                         while (i >= nstart) { ++sg; cur = seg[sg]; nstart = seg_start[sg + 1]; }
                         ph[j] = um::phase_table_eval(cur, i);
@@ -791,16 +794,21 @@ __device__ __forceinline__ void symbol_to_freq2(Fft2Shared<LOG2N, ROT>& sh, cons
         UH_BUTTERFLY(v[3], v[7], lc.w8[1]);
     }
     UH_STAMP(7);
-    // ---- last stage (LOG2N-1): element k of the even half with element k of the odd half, w = twiddle[k] ----
-    sh.xch[par][h][lane] = h ? v[0] : v[P - 1];              // what the partner needs: O_lo from 1, E_hi from 0
-    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
-    UH_STAMP(8);
-    {
+    if constexpr (W == 2) {
+        // ---- last stage (LOG2N-1): element k of the even half with element k of the odd half, w = twiddle[k] ----
+        sh.xch[par][h][lane] = h ? v[0] : v[P - 1];          // what the partner needs: O_lo from 1, E_hi from 0
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+        UH_STAMP(8);
         const c32 other = sh.xch[par][1 - h][lane];
         c32 a = h ? other : v[0];                             // even half's element
         c32 b = h ? v[P - 1] : other;                         // odd half's element
         UH_BUTTERFLY(a, b, lc.w_last);
         bin_out = h ? b : a;                                  // bin `lane` (a + t) / N-64+lane (a - t): stored with the next request
+        bin_hi = bin_out;
+    } else {
+        UH_STAMP(8);
+        bin_out = v[0];                                       // the transform is complete: bins `lane` and N - 64 + lane
+        bin_hi = v[P - 1];
     }
     wave_sync();
     UH_STAMP(9);
@@ -1425,8 +1433,9 @@ __global__ __launch_bounds__(kWave, 2) void mix_fft_kernel(
     }
 }
 
-// The same work items as mix_fft_kernel<10>, two wavefronts per frame (symbol_to_freq2), software-pipelined: everything
-// item i+1 needs from memory is requested while item i computes.
+// The same work items as mix_fft_kernel<LOG2N>, 512 points per wavefront (symbol_to_freq2: two wavefronts per frame for
+// N = 1024, one for N = 512 — the same code minus the joint last stage), software-pipelined: everything item i+1 needs
+// from memory is requested while item i computes.
 // UH_MIX2_WAVES = wavefronts per SIMD the register allocator is told to reach (tools/build_variants.sh builds the others).
 #ifndef UH_MIX2_WAVES
 #define UH_MIX2_WAVES 3
@@ -1435,16 +1444,16 @@ __global__ __launch_bounds__(kWave, 2) void mix_fft_kernel(
 #define UH_MIX2_WAVES_NOROT 4
 #endif
 template <int LOG2N, bool ROT>
-__global__ __launch_bounds__(2 * kWave) __attribute__((amdgpu_waves_per_eu(ROT ? UH_MIX2_WAVES : UH_MIX2_WAVES_NOROT, 8))) void mix_fft2_kernel(
+__global__ __launch_bounds__(Fft2Shared<LOG2N>::W * kWave) __attribute__((amdgpu_waves_per_eu(ROT ? UH_MIX2_WAVES : UH_MIX2_WAVES_NOROT, 8))) void mix_fft2_kernel(
     const DemodConst* __restrict__ Dp, const c32* __restrict__ nco, const c32* __restrict__ twiddle,
     const float* __restrict__ audio, size_t frame_stride, const unsigned* __restrict__ frame_offset, int n_frames,
     int sym, c32* __restrict__ fq, const unsigned* __restrict__ seg_tab, int n_sym_batch) {
     __shared__ Fft2Shared<LOG2N, ROT> sh;
     const DemodConst& D = *Dp;
-    constexpr int P = Fft2Shared<LOG2N>::P, A = Fft2Shared<LOG2N>::A, M = Fft2Shared<LOG2N>::M;
-    const int h = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6), lane = threadIdx.x & 63;
+    constexpr int P = Fft2Shared<LOG2N>::P, A = Fft2Shared<LOG2N>::A, M = Fft2Shared<LOG2N>::M, W = Fft2Shared<LOG2N>::W;
+    const int h = (W == 2) ? __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6) : 0, lane = threadIdx.x & 63;
     const int rl = (int)(__brev((unsigned)lane) >> 26);
-    for (int idx = threadIdx.x; idx < Fft2Shared<LOG2N>::kTwB; idx += 2 * kWave) {
+    for (int idx = threadIdx.x; idx < Fft2Shared<LOG2N>::kTwB; idx += W * kWave) {
         const int sA = 31 - __clz(idx / P + 1);
         const int k = idx - P * ((1 << sA) - 1);
         sh.twB[idx] = twiddle[k << (LOG2N - 1 - (A + sA))];
@@ -1464,21 +1473,27 @@ __global__ __launch_bounds__(2 * kWave) __attribute__((amdgpu_waves_per_eu(ROT ?
         request_item(it, (ROT && seg_tab) ? seg_tab + (size_t)f * kSegTabWords : nullptr, lane);
     };
     Mix2Lane<LOG2N> lc;
-    lc.w6 = twiddle[lane << 3];
-    lc.w7[0] = twiddle[lane << 2]; lc.w7[1] = twiddle[(lane + 64) << 2];
-    lc.w8[0] = twiddle[lane << 1]; lc.w8[1] = twiddle[(lane + 192) << 1];
-    lc.w_last = twiddle[h ? (M - 64 + lane) : lane];
+    lc.w6 = twiddle[lane << (LOG2N - 7)];                  // stage s of the M-point transform: twiddle[k << (LOG2N - 1 - s)]
+    lc.w7[0] = twiddle[lane << (LOG2N - 8)]; lc.w7[1] = twiddle[(lane + 64) << (LOG2N - 8)];
+    lc.w8[0] = twiddle[lane << (LOG2N - 9)]; lc.w8[1] = twiddle[(lane + 192) << (LOG2N - 9)];
+    lc.w_last = (W == 2) ? twiddle[h ? (M - 64 + lane) : lane] : mk(0.0f, 0.0f);
 #pragma unroll
     for (int j = 0; j < P / 2; ++j) lc.wA[j] = twiddle[j << (LOG2N - A)];
     asm volatile("" ::"v"(lc.w6.re), "v"(lc.w6.im), "v"(lc.w7[0].re), "v"(lc.w7[0].im), "v"(lc.w7[1].re), "v"(lc.w7[1].im),
                  "v"(lc.w8[0].re), "v"(lc.w8[0].im), "v"(lc.w8[1].re), "v"(lc.w8[1].im), "v"(lc.w_last.re), "v"(lc.w_last.im));
     int os_ds = -1;
     MixItem cur;
-    c32 pending = mk(0.0f, 0.0f);                          // the previous item's bin of this lane, stored with the next request
-    // wavefront 0 holds bins `lane`, wavefront 1 bins N - 64 + lane; the row keeps the fq_half of each side next to DC
+    c32 pending = mk(0.0f, 0.0f), pending_hi = mk(0.0f, 0.0f);   // the previous item's bin(s) of this lane, stored with the next request
+    // wavefront 0 holds bins `lane`, wavefront 1 bins N - 64 + lane (W = 1: the one wavefront holds both); the row keeps
+    // the fq_half of each side next to DC
     const int fh = D.fq_half;
     const bool fq_mine = h ? (lane >= 64 - fh) : (lane < fh);
     const int fq_slot = h ? fh + lane - (64 - fh) : lane;
+    auto store_bins = [&](int w_item) {
+        c32* row = fq + (size_t)w_item * (2 * fh);
+        if (fq_mine) row[fq_slot] = pending;
+        if (W == 1 && lane >= 64 - fh) row[fh + lane - (64 - fh)] = pending_hi;
+    };
     int w_stored = -1;
     int w = blockIdx.x;
     if (w < total) request(cur, w);
@@ -1488,7 +1503,7 @@ __global__ __launch_bounds__(2 * kWave) __attribute__((amdgpu_waves_per_eu(ROT ?
         if (ds != os_ds) {                                   // the oscillator at this lane's samples: once per symbol index
             const c32* nco_sym = nco + (size_t)(sym + ds) * sym_len;
 #pragma unroll
-            for (int qp = 0; qp < P; ++qp) lc.os[qp] = nco_sym[cp + 2 * (rl + 64 * qp) + h];
+            for (int qp = 0; qp < P; ++qp) lc.os[qp] = nco_sym[cp + W * (rl + 64 * qp) + h];
             os_ds = ds;
             // the compiler's wait for these loads belongs HERE and not at their first use in the item, where it would
             // also wait for the requests of the next item issued in between
@@ -1497,18 +1512,18 @@ __global__ __launch_bounds__(2 * kWave) __attribute__((amdgpu_waves_per_eu(ROT ?
         }
         const int next = w + grid_step;
         Stamps stamps;
-        c32 bin;
-        symbol_to_freq2<LOG2N, ROT>(sh, D, h, lane, cur, lc, twiddle, bin, par, cp, sym_len,
+        c32 bin, bin_hi;
+        symbol_to_freq2<LOG2N, ROT>(sh, D, h, lane, cur, lc, twiddle, bin, bin_hi, par, cp, sym_len,
                                [&]() {
-                                   if (w_stored >= 0 && fq_mine) fq[(size_t)w_stored * (2 * fh) + fq_slot] = pending;
+                                   if (w_stored >= 0) store_bins(w_stored);
                                    if (next < total) request(cur, next);
                                }, stamps);
-        pending = bin;
+        pending = bin; pending_hi = bin_hi;
         w_stored = w;
         UH_STAMP(10);
-        stamps.store((size_t)w * 2 + h, lane);
+        stamps.store((size_t)w * W + h, lane);
     }
-    if (w_stored >= 0 && fq_mine) fq[(size_t)w_stored * (2 * fh) + fq_slot] = pending;
+    if (w_stored >= 0) store_bins(w_stored);
 }
 
 // mode 0: data symbol (updateChannelEstimate + equalize + demodulateSymbol)

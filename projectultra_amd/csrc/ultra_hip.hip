@@ -231,18 +231,28 @@ int launch_demod(ultra_hip_ctx* ctx, const float* d_audio, size_t frame_stride, 
     }
     if (deferred && ensure_trk_workspace(ctx, n_frames * (size_t)n_sym) != ULTRA_HIP_OK) { (void)hipGetLastError(); deferred = false; }
     { const int rc_fq = ensure_fq_workspace(ctx, n_frames); if (rc_fq != ULTRA_HIP_OK) return rc_fq; }
+    // The transform of symbol `sym` (n_sym_batch symbols from it on) of every frame: 512 points per wavefront, software-
+    // pipelined (mix_fft2_kernel: two wavefronts per frame at N = 1024, one at N = 512), with or without the CFO rotation;
+    // ULTRA_HIP_MIXFFT_ONE_WAVE=1 selects round 2's kernel for A/B runs.
+    auto launch_mix = [&](unsigned g, int sym, c32* fq, const unsigned* tab, int n_sym_batch) {
+        auto go = [&](auto kernel, unsigned threads) {
+            hipLaunchKernelGGL(kernel, dim3(g), dim3(threads), 0, st, ctx->d_demod, ctx->d_nco, ctx->d_twiddle, d_audio, frame_stride,
+                               d_frame_offset, (int)n_frames, sym, fq, tab, n_sym_batch);
+        };
+        if (D.log2_fft == 10) {
+            if (ctx->mix_one_wave) go(dev::mix_fft_kernel<10>, dev::kWave);
+            else if (tab) go(dev::mix_fft2_kernel<10, true>, 2 * dev::kWave);
+            else go(dev::mix_fft2_kernel<10, false>, 2 * dev::kWave);
+        } else {
+            if (ctx->mix_one_wave) go(dev::mix_fft_kernel<9>, dev::kWave);
+            else if (tab) go(dev::mix_fft2_kernel<9, true>, dev::kWave);
+            else go(dev::mix_fft2_kernel<9, false>, dev::kWave);
+        }
+    };
     if (all_symbols_at_once) {
         LaunchSpan span(ctx, ULTRA_HIP_K_MIX_FFT);
         const unsigned g = (unsigned)std::min(n_frames * (size_t)n_sym, (size_t)ctx->cu_count * 128);
-        if (D.log2_fft == 10 && !ctx->mix_one_wave)          // cfo_is_zero: no table, the instance without the rotation
-            hipLaunchKernelGGL((dev::mix_fft2_kernel<10, false>), dim3(g), dim3(2 * dev::kWave), 0, st, ctx->d_demod, ctx->d_nco, ctx->d_twiddle,
-                               d_audio, frame_stride, d_frame_offset, (int)n_frames, s_begin, ctx->d_ws_fq, nullptr, n_sym);
-        else if (D.log2_fft == 10)
-            hipLaunchKernelGGL(dev::mix_fft_kernel<10>, dim3(g), dim3(dev::kWave), 0, st, ctx->d_demod, ctx->d_nco, ctx->d_twiddle,
-                               d_audio, frame_stride, d_frame_offset, (int)n_frames, s_begin, ctx->d_ws_fq, seg_tab, n_sym);
-        else
-            hipLaunchKernelGGL(dev::mix_fft_kernel<9>, dim3(g), dim3(dev::kWave), 0, st, ctx->d_demod, ctx->d_nco, ctx->d_twiddle,
-                               d_audio, frame_stride, d_frame_offset, (int)n_frames, s_begin, ctx->d_ws_fq, seg_tab, n_sym);
+        launch_mix(g, s_begin, ctx->d_ws_fq, nullptr, n_sym);       // cfo_is_zero: no table, the instance without the rotation
     }
     for (int s = s_begin; s < s_end; ++s) {
         c32* fq_s = ctx->d_ws_fq + ((all_symbols_at_once || deferred) ? (size_t)(s - s_begin) * n_frames * (size_t)(2 * D.fq_half) : (size_t)0);
@@ -260,22 +270,7 @@ int launch_demod(ultra_hip_ctx* ctx, const float* d_audio, size_t frame_stride, 
         }
         if (!all_symbols_at_once) {
             LaunchSpan span(ctx, ULTRA_HIP_K_MIX_FFT);
-            if (D.log2_fft == 10 && !ctx->mix_one_wave && seg_tab_s)
-                hipLaunchKernelGGL((dev::mix_fft2_kernel<10, true>), dim3(grid_fft), dim3(2 * dev::kWave), 0, st, ctx->d_demod,
-                                   ctx->d_nco, ctx->d_twiddle, d_audio, frame_stride, d_frame_offset, (int)n_frames, s,
-                                   fq_s, seg_tab_s, 1);
-            else if (D.log2_fft == 10 && !ctx->mix_one_wave)   // no table: CFO 0 in every frame, the instance without the rotation
-                hipLaunchKernelGGL((dev::mix_fft2_kernel<10, false>), dim3(grid_fft), dim3(2 * dev::kWave), 0, st, ctx->d_demod,
-                                   ctx->d_nco, ctx->d_twiddle, d_audio, frame_stride, d_frame_offset, (int)n_frames, s,
-                                   fq_s, nullptr, 1);
-            else if (D.log2_fft == 10)
-                hipLaunchKernelGGL(dev::mix_fft_kernel<10>, dim3(grid_fft), dim3(dev::kWave), 0, st, ctx->d_demod,
-                                   ctx->d_nco, ctx->d_twiddle, d_audio, frame_stride, d_frame_offset, (int)n_frames, s,
-                                   fq_s, seg_tab_s, 1);
-            else
-                hipLaunchKernelGGL(dev::mix_fft_kernel<9>, dim3(grid_fft), dim3(dev::kWave), 0, st, ctx->d_demod,
-                                   ctx->d_nco, ctx->d_twiddle, d_audio, frame_stride, d_frame_offset, (int)n_frames, s,
-                                   fq_s, seg_tab_s, 1);
+            launch_mix(grid_fft, s, fq_s, seg_tab_s, 1);        // no table: CFO 0 in every frame, the instance without the rotation
         }
         const bool training = s < D.n_train;
         const bool last = (s == s_end - 1);
