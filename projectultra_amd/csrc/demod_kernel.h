@@ -1650,6 +1650,111 @@ __global__ __launch_bounds__(kWave, 6) void track_kernel(
 }
 
 // ---------------------------------------------------------------------------
+// Differential layouts without pilots, SYNCED entry, at most 32 carriers (the 512-point presets carry 30): TWO frames per
+// wavefront.  What track_kernel does for such a layout is per-carrier work only — equalise against the lane's own
+// channel_estimate entry (never updated without pilots, but for the sign of its zeros in the decision-directed block),
+// the demapper's atan2f / hypotf / sinf / cosf, the lane's differential reference — plus three scalars per frame; with
+// one frame per wavefront 34 of 64 lanes idle through all of it (track_kernel<DQPSK>: 93 % of the vector issue slots
+// busy, profiles/r03_issue_model.txt).  Lane l works on carrier l % 32 of frame 2 p + l / 32; everything per frame that
+// track_kernel keeps wave-uniform is per lane here, the one ballot (strong carriers, demodulator.cpp:362-434) is masked
+// to the lane's half.  Same operations on the same operands: bit-identical records and soft bits.
+template <int MOD>
+__global__ __launch_bounds__(kWave, 6) void track_diff_pair_kernel(
+    const DemodConst* __restrict__ Dp, int n_frames, int data_sym, float* __restrict__ state,
+    const c32* __restrict__ fq_all, float* __restrict__ llr, size_t llr_stride, float* __restrict__ state_out,
+    int n_sym_batch) {
+    static_assert(MOD == ULTRA_MOD_DBPSK || MOD == ULTRA_MOD_DQPSK || MOD == ULTRA_MOD_D8PSK, "differential layouts");
+    constexpr int kBits = (MOD == ULTRA_MOD_DBPSK) ? 1 : (MOD == ULTRA_MOD_DQPSK) ? 2 : 3;
+    const DemodConst& D = *Dp;
+    const int lane = threadIdx.x, g = lane >> 5, sub = lane & 31;
+    const bool is_data = sub < D.n_data;
+    const int dsl = is_data ? D.data_slot[sub] : 0;
+    const int data_fq = fq_index(D, D.bin[dsl]), data_k = D.k_of[dsl];
+    const unsigned long long half_mask = g ? 0xffffffff00000000ull : 0x00000000ffffffffull;
+    const int n_pairs = (n_frames + 1) / 2;
+    for (int pair = blockIdx.x; pair < n_pairs; pair += gridDim.x) {
+        // an odd frame count: the upper half of the last wavefront repeats the last frame and stores nothing
+        const bool live = 2 * pair + g < n_frames;
+        const int frame = live ? 2 * pair + g : n_frames - 1;
+        float* st = state + (size_t)frame * kStFloats;
+        Track tr;
+        load_track(st, tr);
+        c32 H = reinterpret_cast<const c32*>(st + kStH)[dsl];
+        c32 dprev = reinterpret_cast<const c32*>(st + kStDprev)[sub];
+        for (int ds = 0; ds < n_sym_batch; ++ds) {
+            const c32* fq = fq_all + ((size_t)ds * n_frames + frame) * (2 * D.fq_half);
+            // the pilot half of a layout without pilots (track_kernel: scalar_pilot_half)
+            tr.ppc = mk(1.0f, 0.0f); tr.has_prev = 0; tr.snr_symbol_count++;
+            // equalize, differential branch (equalize_demap)
+            c32 eq = mk(0.0f, 0.0f);
+            float nv = 100.0f;
+            if (is_data) {
+                const c32 received = fq[data_fq];
+                const float h_power = cnorm(H);
+                const c32 tc = cexpj_bounded(timing_phase_of(data_k, tr.timing, D.log2_fft));
+                if (h_power > 1e-6f) {
+                    const c32 t = cdivf(cmul(received, cconj(H)), h_power);
+                    eq = cmul(cmul(t, tr.ppc), tc);
+                    nv = tr.noise_variance / h_power;
+                } else {
+                    eq = cmul(cmul(received, tr.ppc), tc);
+                    nv = 100.0f;
+                }
+                nv = fmax_std(1e-6f, fmin_std(100.0f, nv));
+            }
+            if (!tr.has_dprev) dprev = mk(1.0f, 0.0f);
+            if (is_data) {
+                float out[kBits];
+                demap_carrier<MOD>(eq, dprev, nv * D.ce_margin, out);
+                if (live) {
+                    float* dst = llr + (size_t)frame * llr_stride + (size_t)(data_sym + ds) * D.llrs_per_symbol + sub * kBits;
+#pragma unroll
+                    for (int b = 0; b < kBits; ++b) dst[b] = out[b];
+                }
+                dprev = eq;
+            }
+            if ((MOD == ULTRA_MOD_DQPSK || MOD == ULTRA_MOD_D8PSK) && tr.snr_symbol_count >= 1) {
+                // decision-directed block: see equalize_demap (the multiplies only touch the sign of exact zeros)
+                bool strong = false;
+                if (is_data) {
+                    const float a = cabs_(eq);
+                    strong = (a * a) > 0.1f;
+                    if (strong) H = cmul(H, mk(1.0f, -0.0f));
+                }
+                const int valid = __popcll(__ballot(strong) & half_mask);
+                if (valid >= 5) {
+                    c32 p = cmul(cscale(tr.ppc, 1.0f), mk(1.0f, -0.0f));
+                    const float mag = cabs_(p);
+                    if (mag > 0.01f) p = cdivf(p, mag);
+                    tr.ppc = p;
+                }
+            }
+            tr.has_dprev = 1;
+        }
+        if (live && is_data) {
+            reinterpret_cast<c32*>(st + kStH)[dsl] = H;
+            reinterpret_cast<c32*>(st + kStDprev)[sub] = dprev;
+        }
+        if (live && sub == 0) {
+            st[st_ppc_re] = tr.ppc.re; st[st_ppc_im] = tr.ppc.im;
+            st[st_flags] = (float)(tr.cpc_init | (tr.has_prev << 1) | (tr.has_dprev << 2));
+            st[st_count] = (float)tr.snr_symbol_count;
+            if (state_out) {
+                float* so = state_out + (size_t)frame * ULTRA_HIP_STATE_FLOATS;
+                so[ULTRA_HIP_STATE_FREQ_OFFSET_HZ] = tr.freq_offset_hz;
+                so[ULTRA_HIP_STATE_NOISE_VARIANCE] = tr.noise_variance;
+                so[ULTRA_HIP_STATE_SNR_LINEAR] = tr.snr_linear;
+                so[ULTRA_HIP_STATE_TIMING_OFFSET] = tr.timing;
+                so[ULTRA_HIP_STATE_CFO_PHASE] = tr.cfo_phase;
+                so[ULTRA_HIP_STATE_MIXER_PHASE] = D.mixer_phase_end;
+                so[ULTRA_HIP_STATE_SYMBOLS] = (float)tr.snr_symbol_count;
+                so[ULTRA_HIP_STATE_RESERVED] = 0.0f;
+            }
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------
 // The DEFERRED carrier half of the coherent layouts with pilots (SYNCED entry: the headline configuration).
 //
 // For these layouts the carrier half of a symbol (interpolate, equalise, demap) does not feed back into the tracker: no

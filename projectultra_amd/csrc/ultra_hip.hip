@@ -322,6 +322,18 @@ int launch_demod(ultra_hip_ctx* ctx, const float* d_audio, size_t frame_stride, 
     hipLaunchKernelGGL(dev::track_kernel<MOD>, dim3(grid_trk), dim3(dev::kWave), 0, st, ctx->d_demod, (int)n_frames,  \
                        s - D.n_train, ctx->d_ws_state, fq_s, d_llr, llr_stride, last_launch ? d_state : nullptr, track_batch)
         LaunchSpan span(ctx, ULTRA_HIP_K_TRACK);
+        // differential layouts without pilots on at most 32 carriers (the 512-point presets): two frames per wavefront
+        const bool pair_frames = !ctx->old_chain && D.differential && D.n_pilot == 0 && !D.presynced && D.n_carriers <= 32 &&
+                                 D.n_train == 0;      // (without pilots every interpolation entry is empty: nothing to interpolate)
+#define UH_TRACK_PAIR(MOD)                                                                                                         \
+    hipLaunchKernelGGL(dev::track_diff_pair_kernel<MOD>, dim3((unsigned)std::min((n_frames + 1) / 2, (size_t)ctx->cu_count * 128)),  \
+                       dim3(dev::kWave), 0, st, ctx->d_demod, (int)n_frames, s - D.n_train, ctx->d_ws_state, fq_s, d_llr, llr_stride, \
+                       last_launch ? d_state : nullptr, track_batch)
+        if (pair_frames && D.modulation == ULTRA_MOD_DBPSK) UH_TRACK_PAIR(ULTRA_MOD_DBPSK);
+        else if (pair_frames && D.modulation == ULTRA_MOD_DQPSK) UH_TRACK_PAIR(ULTRA_MOD_DQPSK);
+        else if (pair_frames && D.modulation == ULTRA_MOD_D8PSK) UH_TRACK_PAIR(ULTRA_MOD_D8PSK);
+        else
+#undef UH_TRACK_PAIR
         switch (D.modulation) {
             case ULTRA_MOD_DBPSK: UH_TRACK(ULTRA_MOD_DBPSK); break;
             case ULTRA_MOD_BPSK: UH_TRACK(ULTRA_MOD_BPSK); break;

@@ -152,6 +152,26 @@ def test_synthetic_presynced_vs_oracle(oracle, mod, rate, fft, kw):
     assert np.array_equal(r["iters"].cpu().numpy(), want["iters"])
 
 
+@pytest.mark.parametrize("mod,rate", [("DBPSK", "R1_4"), ("DQPSK", "R1_2"), ("D8PSK", "R2_3")])
+def test_pair_tracker_odd_batches(oracle, mod, rate):
+    """Differential 512-point layouts without pilots run two frames per wavefront (track_diff_pair_kernel): odd batch
+    sizes (the last wavefront's upper half has no frame), the all-symbols-at-once path (no initial CFO) and the
+    per-symbol path (with one), soft bits and tracker state against the oracle."""
+    cfg = make_config(512, mod, rate)
+    audio, _ = oracle.make_batch(cfg, 7, seed=0x51, channel="awgn", snr_db=9.0)
+    ctx = context_for(cfg)
+    rng = np.random.default_rng(3)
+    for n in (1, 3, 7):
+        for cfo in (None, rng.normal(0, 3.0, n).astype(np.float32)):
+            want = oracle.demod_decode_batch(cfg, audio[:n], cfo_hz=cfo, n_threads=2)
+            llr, state = ctx.demod(audio[:n], cfo_hz=cfo, want_state=True)
+            ctx.synchronize()
+            assert beq(llr.cpu().numpy(), want["llr"]), (mod, n, cfo is None)
+            st = state.cpu().numpy()
+            for idx in (0, 1, 2, 3, 4, 5):
+                assert beq(st[:, idx], want["state"][:, idx]), ("state", idx, mod, n)
+
+
 def test_ragged_and_strided_inputs(oracle):
     """Rows longer than a frame (stride > frame_samples), one-frame batches, empty batches."""
     import torch
