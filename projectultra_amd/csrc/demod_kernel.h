@@ -1055,20 +1055,24 @@ __global__ __launch_bounds__(kWave, 5) void track_pilot_kernel(const DemodConst*
 }
 
 // one carrier's LLRs (soft_demap.hpp), stored to out[0..bits)
+// sym_abs / prev_abs: cabs_(sym) and cabs_(prev) where the caller has them already (the differential demappers multiply
+// them: the reference calls std::abs on both, the previous symbol's |sym| is this symbol's |prev|); negative = not known
 template <int MOD>
-__device__ __forceinline__ void demap_carrier(c32 sym, c32 prev, float nv, float* __restrict__ out) {
+__device__ __forceinline__ void demap_carrier(c32 sym, c32 prev, float nv, float* __restrict__ out, float sym_abs = -1.0f,
+                                              float prev_abs = -1.0f) {
+    const bool known = sym_abs >= 0.0f && prev_abs >= 0.0f;
     switch (MOD) {
         case ULTRA_MOD_DBPSK: {
             const c32 diff = cmul(sym, cconj(prev));
             const float pd = um::atan2f_(diff.im, diff.re);
-            const float sp = cabs_(sym) * cabs_(prev);
+            const float sp = known ? sym_abs * prev_abs : cabs_(sym) * cabs_(prev);
             out[0] = (sp < 1e-6f) ? 0.0f : clip_llr(2.0f * sp * um::cosf_(pd) / nv);
             break;
         }
         case ULTRA_MOD_DQPSK: {
             const c32 diff = cmul(sym, cconj(prev));
             const float phase = um::atan2f_(diff.im, diff.re);
-            const float sp = cabs_(sym) * cabs_(prev);
+            const float sp = known ? sym_abs * prev_abs : cabs_(sym) * cabs_(prev);
             if (sp < 1e-6f) { out[0] = 0.0f; out[1] = 0.0f; break; }
             const float scale = 2.0f * sp / nv;
             const float pi = 3.14159265358979f;
@@ -1079,7 +1083,7 @@ __device__ __forceinline__ void demap_carrier(c32 sym, c32 prev, float nv, float
         case ULTRA_MOD_D8PSK: {
             const c32 diff = cmul(sym, cconj(prev));
             const float pd = um::atan2f_(diff.im, diff.re);
-            const float sp = cabs_(sym) * cabs_(prev);
+            const float sp = known ? sym_abs * prev_abs : cabs_(sym) * cabs_(prev);
             if (sp < 1e-6f) { out[0] = 0.0f; out[1] = 0.0f; out[2] = 0.0f; break; }
             const float conf = sp / nv;
             out[0] = clip_llr(conf * um::sinf_(pd));
@@ -1158,7 +1162,11 @@ __device__ __forceinline__ void demap_carrier(c32 sym, c32 prev, float nv, float
 // (demodulator.cpp:199-435) for one symbol; dprev = dbpsk_prev_equalized[lane]
 template <int MOD>
 __device__ __forceinline__ void equalize_demap(TrackShared& sh, const DemodConst& D, const LaneConst& lc, Track& tr,
-                                               c32& dprev, const c32* __restrict__ fq, float* __restrict__ llr_sym) {
+                                               c32& dprev, const c32* __restrict__ fq, float* __restrict__ llr_sym,
+                                               float* dprev_abs = nullptr, const c32* tc_fixed = nullptr) {
+    // dprev_abs (differential layouts, nullable): |dprev| carried from symbol to symbol by the caller (negative: not known)
+    // — the previous symbol's |sym| is this symbol's |prev|.  tc_fixed (nullable): the timing-phase factor of this lane
+    // where the timing estimate cannot move between symbols (no pilots).  Both only skip repeated evaluations.
     constexpr bool kDiff = (MOD == ULTRA_MOD_DBPSK || MOD == ULTRA_MOD_DQPSK || MOD == ULTRA_MOD_D8PSK);
     constexpr int kBits = (MOD == ULTRA_MOD_DBPSK || MOD == ULTRA_MOD_BPSK) ? 1 : (MOD == ULTRA_MOD_DQPSK || MOD == ULTRA_MOD_QPSK) ? 2
                         : (MOD == ULTRA_MOD_D8PSK) ? 3 : (MOD == ULTRA_MOD_QAM16) ? 4 : (MOD == ULTRA_MOD_QAM32) ? 5
@@ -1172,7 +1180,7 @@ __device__ __forceinline__ void equalize_demap(TrackShared& sh, const DemodConst
         if (is_data) {
             const c32 received = fq[lc.data_fq], h = sh.H[lc.data_slot];
             const float h_power = cnorm(h);
-            const c32 tc = cexpj_bounded(timing_phase_of(lc.data_k, tr.timing, D.log2_fft));
+            const c32 tc = tc_fixed ? *tc_fixed : cexpj_bounded(timing_phase_of(lc.data_k, tr.timing, D.log2_fft));
             if (h_power > 1e-6f) {
                 const c32 t = cdivf(cmul(received, cconj(h)), h_power);
                 eq = cmul(cmul(t, tr.ppc), tc);
@@ -1203,10 +1211,18 @@ __device__ __forceinline__ void equalize_demap(TrackShared& sh, const DemodConst
         if (is_data && h_power < 0.1f * avg) nv = 100.0f;
     }
 
-    if (kDiff && !tr.has_dprev) dprev = mk(1.0f, 0.0f);   // (1,0) reference on every path
+    if (kDiff && !tr.has_dprev) { dprev = mk(1.0f, 0.0f); if (dprev_abs) *dprev_abs = -1.0f; }   // (1,0) reference on every path
+    float eq_abs = -1.0f;
     if (is_data) {
-        demap_carrier<MOD>(eq, dprev, nv * D.ce_margin, llr_sym + lane * kBits);
-        if (kDiff) dprev = eq;
+        if (kDiff) {
+            eq_abs = cabs_(eq);
+            const float pa = (dprev_abs && *dprev_abs >= 0.0f) ? *dprev_abs : cabs_(dprev);
+            demap_carrier<MOD>(eq, dprev, nv * D.ce_margin, llr_sym + lane * kBits, eq_abs, pa);
+            dprev = eq;
+            if (dprev_abs) *dprev_abs = eq_abs;
+        } else {
+            demap_carrier<MOD>(eq, dprev, nv * D.ce_margin, llr_sym + lane * kBits);
+        }
     }
     if ((MOD == ULTRA_MOD_DQPSK || MOD == ULTRA_MOD_D8PSK) && tr.snr_symbol_count >= 1) {
         // Decision-directed block (demodulator.cpp:362-434).  dbpsk_prev_equalized[i] was just
@@ -1217,7 +1233,7 @@ __device__ __forceinline__ void equalize_demap(TrackShared& sh, const DemodConst
         // the oracle runs the block with the libm calls and the parity tests compare.
         bool strong = false;
         if (is_data) {
-            const float a = cabs_(eq);
+            const float a = eq_abs;                            // cabs_(eq), taken above
             strong = (a * a) > 0.1f;
             if (strong) sh.H[lc.data_slot] = cmul(sh.H[lc.data_slot], mk(1.0f, -0.0f));
         }
@@ -1614,12 +1630,19 @@ __global__ __launch_bounds__(kWave, 6) void track_kernel(
         else if (lane < D.n_pilot) sh.H[lc.pilot_slot] = reinterpret_cast<const c32*>(st + kStHp)[lane];   // the rest is interpolated before it is read
         c32 dprev = D.differential ? reinterpret_cast<const c32*>(st + kStDprev)[lane] : mk(1.0f, 0.0f);
         wave_sync();
+        // differential layouts: |dprev| travels with dprev through the symbols of this launch; without pilots the timing
+        // estimate never moves, so its phase factor is evaluated once per frame (equalize_demap)
+        float dprev_abs = -1.0f;
+        const bool tc_is_fixed = D.differential && D.n_pilot == 0 && n_sym_batch > 1;
+        c32 tc0 = mk(1.0f, 0.0f);
+        if (tc_is_fixed) tc0 = cexpj_bounded(timing_phase_of(lc.data_k, tr.timing, D.log2_fft));
         for (int ds = 0; ds < n_sym_batch; ++ds) {
             const c32* fq = fq_all + ((size_t)ds * n_frames + frame) * (2 * D.fq_half);
             if (scalar_pilot_half) { tr.ppc = mk(1.0f, 0.0f); tr.has_prev = 0; tr.snr_symbol_count++; }
             if (!D.presynced || D.n_pilot != 0) finish_channel_estimate(sh, D, lc, tr);
             equalize_demap<MOD>(sh, D, lc, tr, dprev, fq,
-                                llr + (size_t)frame * llr_stride + (size_t)(data_sym + ds) * D.llrs_per_symbol);
+                                llr + (size_t)frame * llr_stride + (size_t)(data_sym + ds) * D.llrs_per_symbol,
+                                &dprev_abs, tc_is_fixed ? &tc0 : nullptr);
             wave_sync();
         }
         // write the record back
@@ -1681,6 +1704,12 @@ __global__ __launch_bounds__(kWave, 6) void track_diff_pair_kernel(
         load_track(st, tr);
         c32 H = reinterpret_cast<const c32*>(st + kStH)[dsl];
         c32 dprev = reinterpret_cast<const c32*>(st + kStDprev)[sub];
+        if (!tr.has_dprev) dprev = mk(1.0f, 0.0f);             // (1,0) reference before the first symbol
+        // Two of the three hypotf per carrier and symbol are repeats: |prev| is the |sym| of the symbol before, and the
+        // decision-directed block takes |sym| again; and the timing phase does not move without pilots.  Each is evaluated
+        // once — the same function on the same operand.
+        float prev_abs = cabs_(dprev);
+        const c32 tc = cexpj_bounded(timing_phase_of(data_k, tr.timing, D.log2_fft));
         for (int ds = 0; ds < n_sym_batch; ++ds) {
             const c32* fq = fq_all + ((size_t)ds * n_frames + frame) * (2 * D.fq_half);
             // the pilot half of a layout without pilots (track_kernel: scalar_pilot_half)
@@ -1691,7 +1720,6 @@ __global__ __launch_bounds__(kWave, 6) void track_diff_pair_kernel(
             if (is_data) {
                 const c32 received = fq[data_fq];
                 const float h_power = cnorm(H);
-                const c32 tc = cexpj_bounded(timing_phase_of(data_k, tr.timing, D.log2_fft));
                 if (h_power > 1e-6f) {
                     const c32 t = cdivf(cmul(received, cconj(H)), h_power);
                     eq = cmul(cmul(t, tr.ppc), tc);
@@ -1702,22 +1730,23 @@ __global__ __launch_bounds__(kWave, 6) void track_diff_pair_kernel(
                 }
                 nv = fmax_std(1e-6f, fmin_std(100.0f, nv));
             }
-            if (!tr.has_dprev) dprev = mk(1.0f, 0.0f);
+            const float eq_abs = cabs_(eq);
             if (is_data) {
                 float out[kBits];
-                demap_carrier<MOD>(eq, dprev, nv * D.ce_margin, out);
+                demap_carrier<MOD>(eq, dprev, nv * D.ce_margin, out, eq_abs, prev_abs);
                 if (live) {
                     float* dst = llr + (size_t)frame * llr_stride + (size_t)(data_sym + ds) * D.llrs_per_symbol + sub * kBits;
 #pragma unroll
                     for (int b = 0; b < kBits; ++b) dst[b] = out[b];
                 }
                 dprev = eq;
+                prev_abs = eq_abs;
             }
             if ((MOD == ULTRA_MOD_DQPSK || MOD == ULTRA_MOD_D8PSK) && tr.snr_symbol_count >= 1) {
                 // decision-directed block: see equalize_demap (the multiplies only touch the sign of exact zeros)
                 bool strong = false;
                 if (is_data) {
-                    const float a = cabs_(eq);
+                    const float a = eq_abs;
                     strong = (a * a) > 0.1f;
                     if (strong) H = cmul(H, mk(1.0f, -0.0f));
                 }
