@@ -159,7 +159,8 @@ def main():
             ("ldpc_decode_kernelILi3ELi6E", "ldpc_decode_kernel<3, 6", True),
             ("ldpc_decode_kernelILi8ELi3E", "ldpc_decode_kernel<8, 3", True),
             ("mix_fft2_kernelILi10ELb1E", "mix_fft2_kernel<10, true>", False), ("mix_fft2_kernelILi10ELb0E", "mix_fft2_kernel<10, false>", False), ("mix_fft_kernelILi10E", "mix_fft_kernel<10>", False),
-            ("mix_fft_kernelILi9E", "mix_fft_kernel<9>", False), ("track_all_kernelILi6E", "track_all_kernel<6>", False),
+            ("mix_fft2_kernelILi9ELb0E", "mix_fft2_kernel<9, false>", False), ("mix_fft2_kernelILi9ELb1E", "mix_fft2_kernel<9, true>", False),
+            ("track_diff_pair_kernelILi2E", "track_diff_pair_kernel<2>", False), ("mix_fft_kernelILi9E", "mix_fft_kernel<9>", False), ("track_all_kernelILi6E", "track_all_kernel<6>", False),
             ("track_kernelILi6E", "track_kernel<6>", False), ("track_kernelILi2E", "track_kernel<2>", False),
             ("track_pilot_kernelILi16E", "track_pilot_kernel<16>", False), ("cfo_walk_kernel", "cfo_walk_kernel", False),
             ("acquire_kernelILi10ELb0E", "acquire_kernel<10>", False), ("chirp_sync_kernel", "chirp_sync_kernel", False)]
