@@ -385,17 +385,19 @@ __device__ __forceinline__ unsigned acq_refine_lts(AcqShared<LOG2N>& sh, const D
 // functions every phase gets its own register allocation (a handful spilled) and the calls — a few hundred per
 // stream, each worth thousands of cycles — cost nothing measurable: 27.5 -> 25.0 ms per 16384 cfg3 streams.
 // The 512-point instance fits inlined and is faster that way (6.8 against 7.7 ms).
-template <int LOG2N>
+// (TAG: one copy per kernel instance — with two kernels calling ONE copy the callee is compiled for an unknown caller and
+// the search kernel lost 9 %: 128.7 -> 140.4 ms per 65,536 streams)
+template <int LOG2N, int TAG>
 __device__ __attribute__((noinline)) float acq_group_energy_call(AcqShared<LOG2N>& sh, const float* __restrict__ all,
                                                                  unsigned first, int count, unsigned n_samples) {
     return acq_group_energy<LOG2N>(sh, all, first, count, n_samples);
 }
-template <int LOG2N>
+template <int LOG2N, int TAG>
 __device__ __attribute__((noinline)) float acq_group_dc_call(AcqShared<LOG2N>& sh, const float* __restrict__ all,
                                                              unsigned first, unsigned n_samples) {
     return acq_group_dc<LOG2N>(sh, all, first, n_samples);
 }
-template <int LOG2N>
+template <int LOG2N, int TAG>
 __device__ __attribute__((noinline)) void acq_window_metric_call(AcqShared<LOG2N>& sh, const AcqLaneTw<LOG2N>& ltw,
                                                                  const float* __restrict__ win, float dc_sum, c32* P_out,
                                                                  float* R1, float* R2) {
@@ -488,7 +490,7 @@ __global__ __launch_bounds__(kWave, (LOG2N == 10) ? 3 : 4) void acquire_kernel(
                         const unsigned gabs = base + i, d = gabs - gate_first;
                         if (gabs < gate_first || (d & 7u) != 0u || d >= 8u * kWave) {
                             gate_first = gabs;
-                            if constexpr (kCalls) gate_sum = acq_group_energy_call<LOG2N>(sh, all, gabs, gate_count, n_samples);
+                            if constexpr (kCalls) gate_sum = acq_group_energy_call<LOG2N, MIDFRAME>(sh, all, gabs, gate_count, n_samples);
                             else gate_sum = acq_group_energy<LOG2N>(sh, all, gabs, gate_count, n_samples);
                         }
                         energetic = acq_energy_gate(lane_f(gate_sum, (int)((gabs - gate_first) >> 3)), gate_count, noise_floor);
@@ -523,12 +525,12 @@ __global__ __launch_bounds__(kWave, (LOG2N == 10) ? 3 : 4) void acquire_kernel(
                         const unsigned d = wabs - grp_first;              // candidate (d / 8) of the current group?
                         if (wabs < grp_first || (d & 7u) != 0u || d >= 8u * kWave) {
                             grp_first = wabs;
-                            if constexpr (kCalls) grp_dc = acq_group_dc_call<LOG2N>(sh, all, wabs, n_samples);
+                            if constexpr (kCalls) grp_dc = acq_group_dc_call<LOG2N, MIDFRAME>(sh, all, wabs, n_samples);
                             else grp_dc = acq_group_dc<LOG2N>(sh, all, wabs, n_samples);
                         }
                         dc_sum = lane_f(grp_dc, (int)((wabs - grp_first) >> 3));
                     }
-                    if constexpr (kCalls) acq_window_metric_call<LOG2N>(sh, ltw, all + wabs, dc_sum, &Pm, &R1, &R2);
+                    if constexpr (kCalls) acq_window_metric_call<LOG2N, MIDFRAME>(sh, ltw, all + wabs, dc_sum, &Pm, &R1, &R2);
                     else acq_window_metric<LOG2N>(sh, ltw, all + wabs, dc_sum, &Pm, &R1, &R2);
                 }
                 if (mode == kCfo) {

@@ -1,0 +1,28 @@
+#!/bin/bash
+# Everything under profiles/<tag>_* in one go, on the GPU box (three or four gpurun calls: stages a, b, c, d):
+#   bash tools/collect_round.sh <tag> <commit> a|b|c|d
+# a: cfg3 at 2^20 (default) and 2^18 + SQ counters;  b: cfg2, cfg5;  c: cfg4, raw;  d: stall tables (needs build/stamps.so
+# of the SAME sources: STAMP_FLAGS="" bash tools/build_variants.sh), parity soaks, the torchrun line, LDPC rates, sweeps.
+# tools/install_profiles.sh <tag> then copies the results from gpurun_out/ into profiles/.
+set -u
+TAG=${1:-r03}; C=${2:-unknown}; STAGE=${3:-a}
+O=gpurun_out/$TAG; SQ=gpurun_out/${TAG}sq
+mkdir -p $O $SQ
+sq() { bash tools/pmc_sweep.sh $SQ/$1 --config "${@:2}" --no-cpu-baseline > $O/sq_$1.log 2>&1; rm -rf $SQ/$1/p?; grep -c '==' $SQ/$1/summary.txt; }
+case $STAGE in
+a) bash tools/collect_profiles.sh $TAG cfg3 $C > $O/c_cfg3.log 2>&1; head -4 $O/c_cfg3.log
+   bash tools/collect_profiles.sh $TAG cfg3 $C '--frames 262144' _2e18 > $O/c_cfg3_2e18.log 2>&1; head -4 $O/c_cfg3_2e18.log
+   sq cfg3 cfg3 --frames 262144 --steps 2 --warmup 1 ;;
+b) for c in cfg2 cfg5; do bash tools/collect_profiles.sh $TAG $c $C > $O/c_$c.log 2>&1; head -4 $O/c_$c.log; done
+   sq cfg2 cfg2 --steps 2 --warmup 1; sq cfg5 cfg5 --steps 1 --warmup 1 ;;
+c) for c in cfg4 raw; do bash tools/collect_profiles.sh $TAG $c $C > $O/c_$c.log 2>&1; head -4 $O/c_$c.log; done
+   sq cfg4 cfg4 --steps 1 --warmup 1; sq raw raw --steps 1 --warmup 1 ;;
+d) timeout -k 10 300 python3 tools/mix_fft_stalls.py > $O/mix_fft_stalls_two_wave.txt 2> $O/stalls_two.err
+   timeout -k 10 300 python3 tools/mix_fft_stalls.py --one-wave > $O/mix_fft_stalls_one_wave.txt 2> $O/stalls_one.err
+   timeout -k 10 900 python3 tools/soak_parity.py 16384 7 > $O/soak_parity.txt 2>&1; tail -n 2 $O/soak_parity.txt
+   timeout -k 10 600 python3 tools/soak_sync.py 4096 128 3 > $O/soak_sync.txt 2>&1; tail -n 2 $O/soak_sync.txt
+   timeout -k 10 300 python3 -m torch.distributed.run --nnodes=1 --nproc-per-node 1 --master-addr 127.0.0.1 --master-port 29511 \
+       bench.py --gpus 1 --steps 5 --warmup 2 > $O/bench_cfg3_torchrun1.json 2> $O/torchrun.err; head -c 200 $O/bench_cfg3_torchrun1.json; echo
+   timeout -k 10 200 python3 tools/ldpc_bench.py > $O/ldpc_bench.txt 2>&1; tail -n 6 $O/ldpc_bench.txt
+   for c in cfg4 cfg5; do timeout -k 10 600 python3 tools/sweep.py --config $c --out $O/sweep_$c.json > $O/sweep_$c.txt 2>&1; tail -n 1 $O/sweep_$c.txt; done ;;
+esac

@@ -163,7 +163,7 @@ def main():
             ("track_diff_pair_kernelILi2E", "track_diff_pair_kernel<2>", False), ("mix_fft_kernelILi9E", "mix_fft_kernel<9>", False), ("track_all_kernelILi6E", "track_all_kernel<6>", False),
             ("track_kernelILi6E", "track_kernel<6>", False), ("track_kernelILi2E", "track_kernel<2>", False),
             ("track_pilot_kernelILi16E", "track_pilot_kernel<16>", False), ("cfo_walk_kernel", "cfo_walk_kernel", False),
-            ("acquire_kernelILi10ELb0E", "acquire_kernel<10>", False), ("chirp_sync_kernel", "chirp_sync_kernel", False)]
+            ("acquire_kernelILi10ELb0E", "acquire_kernel<10, false>", False), ("chirp_sync_kernel", "chirp_sync_kernel", False)]
     for key, pmc_key, is_ldpc in want:
         names = [n for n in fns if key in n and ("Lb0ELi" in n or not is_ldpc or "totals" in n)]
         if is_ldpc and "decode_kernel" in key:
