@@ -57,11 +57,11 @@ ISSUE_CYCLES = {
     "ldpc_totals R3/4": dict(unit="cw_iteration", valu=162.5 * 3.38, salu=80.4 * 4.19, lds=61.5 * 2.13),
     # round 3 (profiles/r03_sq_counters.txt -> profiles/r03_issue_model.txt): the two-wavefront transform, the deferred
     # carrier half (unit: one symbol of one frame), the pilot half with its record for the carrier half
-    "mix_fft_kernel": dict(unit="frame", valu=1261.5 * 3.47, salu=268.6 * 4.19, lds=104.4 * 3.28),
-    "track_kernel": dict(unit="frame_symbol", valu=182.3 * 3.29, salu=116.2 * 4.19, lds=19.9 * 4.01),
-    "track_pilot_kernel": dict(unit="frame", valu=163.5 * 3.54, salu=63.9 * 4.19, lds=4.75 * 5.08),
+    "mix_fft_kernel": dict(unit="frame", valu=1199.9 * 3.43, salu=242.4 * 4.19, lds=104.8 * 3.41),    # mean of the rotating (1691 VALU) and the no-rotation instance (709): two launches each per step
+    "track_kernel": dict(unit="frame_symbol", valu=182.4 * 3.29, salu=118.3 * 4.19, lds=19.9 * 4.01),
+    "track_pilot_kernel": dict(unit="frame", valu=164.7 * 3.54, salu=64.1 * 4.19, lds=4.75 * 5.08),
     # per raw stream of 14,400 samples at 30 dB (profiles/r03_sq_counters_raw.txt: 65,536 streams per launch)
-    "acquire_kernel": dict(unit="stream", valu=952.8e3 * 3.35, salu=134.7e3 * 4.19, lds=166.4e3 * 3.33),
+    "acquire_kernel": dict(unit="stream", valu=936.6e3 * 3.38, salu=135.3e3 * 4.19, lds=161.4e3 * 3.33),
 }
 
 
