@@ -209,7 +209,8 @@ constexpr int kTrkRecFloats = 96;                           // three cache lines
 constexpr int kTrkRecHp = 8;                                // (<= 12 pilots touch one line, the headline's 15 two)
 enum { tk_noise = 0, tk_timing, tk_cfo, tk_snr, tk_phase, tk_count };
 // Fq row of a frame (and symbol): c32[2 * D.fq_half] = bins [0, fq_half) then [N - fq_half, N), fq_half = 32 or 64
-__device__ __forceinline__ int fq_index(const DemodConst& D, int bin) { return (bin < D.fq_half) ? bin : D.fq_half + (bin - (D.fft - D.fq_half)); }
+__device__ __forceinline__ int fq_natural(const DemodConst& D, int bin) { return (bin < D.fq_half) ? bin : D.fq_half + (bin - (D.fft - D.fq_half)); }
+__device__ __forceinline__ int fq_index(const DemodConst& D, int bin) { return D.fq_pos[fq_natural(D, bin)]; }      // pilots first: DemodConst::fq_pos
 // Per-frame phase table of the next symbol's CFO rotation (cfo_walk_kernel / pilot_walk_kernel -> mix_fft kernels),
 // 32-bit words: [0] number of segments | samples covered << 8, [1] the tracker's CFO in Hz (float bits), [2] phase after
 // the covered samples (float bits), [3] phase the symbol starts with; then {start, base, step} per segment.  It carries
@@ -482,8 +483,8 @@ __device__ __forceinline__ void symbol_to_freq(FftShared<LOG2N>& sh, const Demod
         UH_STAMP(8);
         // bins `lane` and N - 64 + lane: the row keeps the fq_half of each side that lie next to DC
         const int fh = D.fq_half;
-        if (lane < fh) fq_out[lane] = v[0];
-        if (lane >= 64 - fh) fq_out[fh + lane - (64 - fh)] = v[P - 1];
+        if (lane < fh) fq_out[D.fq_pos[lane]] = v[0];
+        if (lane >= 64 - fh) fq_out[D.fq_pos[fh + lane - (64 - fh)]] = v[P - 1];
     }
     wave_sync();
     UH_STAMP(9);
@@ -1504,11 +1505,14 @@ __global__ __launch_bounds__(Fft2Shared<LOG2N>::W * kWave) __attribute__((amdgpu
     // the fq_half of each side next to DC
     const int fh = D.fq_half;
     const bool fq_mine = h ? (lane >= 64 - fh) : (lane < fh);
-    const int fq_slot = h ? fh + lane - (64 - fh) : lane;
+    const bool fq_mine_hi = W == 1 && lane >= 64 - fh;
+    // positions inside the row: the pilots' bins first (DemodConst::fq_pos)
+    const int fq_slot = fq_mine ? (int)D.fq_pos[h ? fh + lane - (64 - fh) : lane] : 0;
+    const int fq_slot_hi = fq_mine_hi ? (int)D.fq_pos[fh + lane - (64 - fh)] : 0;
     auto store_bins = [&](int w_item) {
         c32* row = fq + (size_t)w_item * (2 * fh);
         if (fq_mine) row[fq_slot] = pending;
-        if (W == 1 && lane >= 64 - fh) row[fh + lane - (64 - fh)] = pending_hi;
+        if (fq_mine_hi) row[fq_slot_hi] = pending_hi;
     };
     int w_stored = -1;
     int w = blockIdx.x;

@@ -41,6 +41,11 @@ struct DemodConst {
     float interp_alpha[kMaxCarriers];
     c32 pilot_seq[kMaxCarriers];      // +-1 + 0j
     c32 sync_seq[kMaxCarriers];       // Zadoff-Chu
+    // Where the transform puts a kept bin inside the frame's Fq row: natural slot s (bin s for s < fq_half, bin
+    // fft - fq_half + (s - fq_half) above) -> position.  The PILOTS come first, in pilot order, then the data carriers in
+    // data order, then the bins nobody reads: the pilot half (track_pilot_kernel) then touches one 128-byte line of the
+    // row (15 pilots; two lines for up to 32) instead of all four — it runs at the memory system's ceiling.
+    uint8_t fq_pos[2 * kMaxCarriers];
 };
 
 // Per-rate Tanner graph, CSR by check (row-major edge order of H_rows) and CSR

@@ -658,6 +658,17 @@ inline int build_demod(const ultra_hip_config& c, DemodConst& D, std::vector<c32
     // the transform keeps bins [0, fq_half) and [fft - fq_half, fft): 32 each when every carrier lies within +-31 (30 and 59
     // carriers do), 64 each otherwise — half the row, half the traffic of three kernels
     D.fq_half = (neg_limit <= 31 && pos_limit <= 31) ? 32 : 64;
+    {
+        // row positions: pilots, then data carriers, then the unused bins (DemodConst::fq_pos)
+        const int rows = 2 * D.fq_half;
+        auto natural = [&](int bin) { return (bin < D.fq_half) ? bin : D.fq_half + (bin - (D.fft - D.fq_half)); };
+        std::vector<int> pos(rows, -1);
+        int next = 0;
+        for (int i = 0; i < D.n_pilot; ++i) pos[natural(D.bin[D.pilot_slot[i]])] = next++;
+        for (int i = 0; i < D.n_data; ++i) pos[natural(D.bin[D.data_slot[i]])] = next++;
+        for (int s = 0; s < rows; ++s) if (pos[s] < 0) pos[s] = next++;
+        for (int s = 0; s < 2 * kMaxCarriers; ++s) D.fq_pos[s] = (uint8_t)((s < rows) ? pos[s] : 0);
+    }
 
     // Zadoff-Chu (u = 1) and BPSK pilots
     const size_t N = c.num_carriers, u = 1;

@@ -586,6 +586,16 @@ def test_stream_and_block_entries_refuse_bad_arguments():
         ctx.demod_into(a, llr[:4, :600])                                  # rows shorter than llrs_per_frame
     r = ctx.ldpc_decode_blocks(llr, 16, 32, 2)
     assert r["ok"].shape[0] == 32
+    # the mid-frame check: a window that does not reach n_samples, samples fed before the window's origin; a buffer shorter
+    # than six preamble symbols is not an error — nothing is found
+    resume = torch.tensor([[100, 9000, 0, 0]] * 4, dtype=torch.int32, device="cuda")
+    with pytest.raises(UltraHipError):
+        ctx.acquire_stream(a[:, :1000], 100, 9000, resume, midframe=True)   # 8900 samples claimed, rows hold 1000
+    with pytest.raises(UltraHipError):
+        ctx.acquire_stream(a, 500, 400, resume, midframe=True)              # n_samples < origin
+    short = ctx.acquire_stream(a[:, :3000], 100, 3100, resume, midframe=True)
+    ctx.synchronize()
+    assert not short["found"].cpu().numpy().any()
 
 
 @pytest.mark.parametrize("name", ["cfg3_qam16_r34", "cfg2_dqpsk_r12"])
