@@ -510,8 +510,17 @@ __global__ __launch_bounds__(256) void count_errors_kernel(
     for (int f = blockIdx.x * blockDim.x + threadIdx.x; f < n_frames; f += gridDim.x * blockDim.x) {
         const uint8_t* d = bytes + (size_t)f * bytes_stride;
         const uint8_t* p = payload + (size_t)f * payload_bytes;
+        // four bytes at a time (rows start at any byte: unaligned dword loads, which the memory system splits itself —
+        // a quarter of the load instructions of the byte loop, each of which touched 31 cache lines per wavefront)
         unsigned biterr = 0;
-        for (int b = 0; b < payload_bytes; ++b) biterr += __popc((unsigned)(d[b] ^ p[b]));
+        int b = 0;
+        for (; b + 4 <= payload_bytes; b += 4) {
+            unsigned x, y;
+            __builtin_memcpy(&x, d + b, 4);
+            __builtin_memcpy(&y, p + b, 4);
+            biterr += __popc(x ^ y);
+        }
+        for (; b < payload_bytes; ++b) biterr += __popc((unsigned)(d[b] ^ p[b]));
         const int ok = okv[f];
         c[0] += 1;
         c[1] += (!ok || biterr) ? 1 : 0;
