@@ -172,6 +172,37 @@ def test_pair_tracker_odd_batches(oracle, mod, rate):
                 assert beq(st[:, idx], want["state"][:, idx]), ("state", idx, mod, n)
 
 
+@pytest.mark.parametrize("fft,mod,rate,kw", [
+    (1024, "QAM16", "R3_4", dict(carriers=64, pilot_spacing=2)),      # 128-position rows, 32 pilots (two frames per wavefront in the pilot half)
+    (1024, "QPSK", "R1_2", dict(carriers=63, pilot_spacing=3)),
+    (512, "QAM64", "R2_3", dict(carriers=64, pilot_spacing=4)),
+    (1024, "DQPSK", "R1_2", dict(carriers=24)),                       # 1024 points, two frames per wavefront in the tracker
+    (512, "D8PSK", "R3_4", dict(carriers=12)),
+    (512, "DQPSK", "R1_2", dict(carriers=33)),                        # one carrier too many for the pair tracker
+    (1024, "DBPSK", "R1_4", dict(carriers=64)),
+])
+def test_carrier_counts(oracle, fft, mod, rate, kw):
+    """Layouts other than the presets' 30 / 59 carriers: rows of 128 bins (carriers beyond +-31), the pilots-first row order
+    with 16 to 32 pilots, the two-frames-per-wavefront tracker at and around its 32-carrier limit — soft bits, decoded bytes,
+    iteration counts and tracker state against the oracle, with and without an initial CFO."""
+    cfg = make_config(fft, mod, rate, **kw)
+    n = 45
+    audio, _ = oracle.make_batch(cfg, n, seed=0xC0 + fft // 512, channel="awgn", snr_db=14.0)
+    rng = np.random.default_rng(17)
+    ctx = context_for(cfg)
+    for cfo in (None, rng.normal(0, 3.0, n).astype(np.float32)):
+        want = oracle.demod_decode_batch(cfg, audio, cfo_hz=cfo, n_threads=8)
+        r = ctx.demod_decode(audio, cfo_hz=cfo, want_llr=True)
+        llr2, state = ctx.demod(audio, cfo_hz=cfo, want_state=True)
+        ctx.synchronize()
+        assert beq(r["llr"].cpu().numpy(), want["llr"]), (fft, mod, kw, cfo is None)
+        assert beq(llr2.cpu().numpy(), want["llr"])
+        assert np.array_equal(r["bytes"].cpu().numpy(), want["bytes"]) and np.array_equal(r["iters"].cpu().numpy(), want["iters"])
+        st = state.cpu().numpy()
+        for idx in (0, 1, 2, 3, 4, 5):
+            assert beq(st[:, idx], want["state"][:, idx]), ("state", idx, fft, mod, kw)
+
+
 def test_ragged_and_strided_inputs(oracle):
     """Rows longer than a frame (stride > frame_samples), one-frame batches, empty batches."""
     import torch
