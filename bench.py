@@ -31,6 +31,7 @@ Prints ONE JSON line on rank 0 (see the driver contract) with the extra objects
 from __future__ import annotations
 
 import argparse
+import math
 import fcntl
 import json
 import os
@@ -597,6 +598,21 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    # Steady state before anything is counted: the first ten or so steps after set-up run up to 30 % slower than the rest
+    # (clocks ramp up, workspaces are allocated and touched for the first time; tools/step_times.py shows the decay over
+    # ~35 ms), which W warm-up steps do not cover when a step is 3 ms — a rank's share of the strong-scaling batch at N = 8.
+    # ~0.15 s of untimed steps first, the same number on every rank (the step holds the collective).
+    barrier()
+    t_p = time.perf_counter()
+    for _ in range(2):
+        wl.step(allreduce)
+    barrier()
+    t_step = torch.tensor([(time.perf_counter() - t_p) / 2], dtype=torch.float64, device="cuda")
+    if distributed:
+        dist.all_reduce(t_step, op=dist.ReduceOp.MAX)
+    n_prime = int(min(64, max(0, math.ceil(0.15 / max(float(t_step.item()), 1e-4)) - 2)))
+    for _ in range(n_prime):
+        wl.step(allreduce)
     for _ in range(args.warmup):
         wl.step(allreduce)
     barrier()
@@ -755,7 +771,7 @@ def main():
         total = getattr(wl, "total_units", wl.units_per_step * world) * args.steps
         value = total / elapsed
         line = {
-            "metric": wl.metric, "value": value, "unit": wl.unit, "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "metric": wl.metric, "value": value, "unit": wl.unit, "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "untimed_priming_steps": n_prime + 2,
             "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": getattr(wl, "scaling", "weak"), "vs_baseline": None,
             "dtype": "f32", "data": wl.data,
             "config": {"workload": wl.workload, "name": args.config, "trials_per_gpu_per_step": wl.units_per_step,
