@@ -77,6 +77,7 @@ struct ultra_hip_ctx {
     // per-kernel profiling (ultra_hip_profile_*): recorded (class, start, stop) triples + spare events
     uint32_t deint_step = 1;             // ChannelInterleaver step fused into the LDPC LLR load (1 = off)
     uint16_t* d_deint_table = nullptr;   // general gather table of the fused deinterleave (nullptr = use the step)
+    int mix_wg_per_cu = 0;               // ULTRA_HIP_MIX_WG_PER_CU: workgroups per CU of the transform's grid (sweeps; 0 = by batch size)
     bool mix_one_wave = false;           // ULTRA_HIP_MIXFFT_ONE_WAVE=1: the one-wavefront-per-frame mix_fft_kernel<10> (A/B runs)
     bool stream_cfo_given = false;       // launch_demod: whether the frame in flight started with caller-supplied offsets
     bool old_chain = false;              // ULTRA_HIP_OLD_CHAIN=1: track_pilot_kernel + track_kernel per symbol for every layout (A/B runs)
@@ -194,7 +195,17 @@ int launch_demod(ultra_hip_ctx* ctx, const float* d_audio, size_t frame_stride, 
     // the hardware dispatcher rebalances CUs/XCDs that run slower (measured 7.19 -> 6.49 ms for the
     // demodulator stage at 2^18 frames; sweep in profiles/README.md; re-swept after the walk moved out of
     // mix_fft_kernel: 96..192 workgroups per CU are level, 384 is 2.5 % slower).
-    const unsigned grid_fft = (unsigned)std::min(n_frames, (size_t)ctx->cu_count * 128);
+    // The pipelined transform wants a couple of dozen items per workgroup (its prologue — twiddles, the oscillator at the
+    // lane's samples, the first item's unhidden requests — is paid once per workgroup) and enough workgroups for the
+    // dispatcher to rebalance: 24 items each, between 24 and 128 workgroups per CU (sweep at 2^17 and 2^20 frames:
+    // profiles/r03_variants/r03_ab_transform_grid.txt — 2^17: 0.325 ms at 128 per CU, 0.312 at 24-48; 2^20: 2.46 at 128-256,
+    // 2.56 at 24).
+    auto mix_grid = [&](size_t items) {
+        size_t per_cu = ctx->mix_wg_per_cu > 0 ? (size_t)ctx->mix_wg_per_cu
+                                               : std::min<size_t>(128, std::max<size_t>(24, items / ((size_t)ctx->cu_count * 24)));
+        return (unsigned)std::min(items, (size_t)ctx->cu_count * per_cu);
+    };
+    const unsigned grid_fft = mix_grid(n_frames);
     const unsigned grid_trk = (unsigned)std::min(n_frames, (size_t)ctx->cu_count * 128);
     hipStream_t st = ctx->stream;
     if (D.log2_fft != 10 && D.log2_fft != 9) return ULTRA_HIP_ERR_UNSUPPORTED;
@@ -251,7 +262,7 @@ int launch_demod(ultra_hip_ctx* ctx, const float* d_audio, size_t frame_stride, 
     };
     if (all_symbols_at_once) {
         LaunchSpan span(ctx, ULTRA_HIP_K_MIX_FFT);
-        const unsigned g = (unsigned)std::min(n_frames * (size_t)n_sym, (size_t)ctx->cu_count * 128);
+        const unsigned g = mix_grid(n_frames * (size_t)n_sym);
         launch_mix(g, s_begin, ctx->d_ws_fq, nullptr, n_sym);       // cfo_is_zero: no table, the instance without the rotation
     }
     for (int s = s_begin; s < s_end; ++s) {
@@ -588,6 +599,7 @@ int ultra_hip_create(const ultra_hip_config* cfg, int device, void* stream, ultr
     if (rc != ULTRA_HIP_OK) { delete ctx; return rc; }
     // ULTRA_HIP_LDPC_MESSAGES=1 keeps the message-passing kernel for every rate (A/B measurements, parity tests of both)
     { const char* e = std::getenv("ULTRA_HIP_MIXFFT_ONE_WAVE"); ctx->mix_one_wave = (e && e[0] == '1'); }
+    { const char* e = std::getenv("ULTRA_HIP_MIX_WG_PER_CU"); if (e && std::atoi(e) > 0) ctx->mix_wg_per_cu = std::atoi(e); }
     { const char* e = std::getenv("ULTRA_HIP_OLD_CHAIN"); ctx->old_chain = (e && e[0] == '1'); }
     const char* force_messages = std::getenv("ULTRA_HIP_LDPC_MESSAGES");
     if (!(force_messages && force_messages[0] == '1')) (void)build_ldpc_tplan(ctx->h_ldpc, cfg->code_rate, ctx->h_tplan);

@@ -24,5 +24,8 @@ d) timeout -k 10 300 python3 tools/mix_fft_stalls.py > $O/mix_fft_stalls_two_wav
    timeout -k 10 300 python3 -m torch.distributed.run --nnodes=1 --nproc-per-node 1 --master-addr 127.0.0.1 --master-port 29511 \
        bench.py --gpus 1 --steps 5 --warmup 2 > $O/bench_cfg3_torchrun1.json 2> $O/torchrun.err; head -c 200 $O/bench_cfg3_torchrun1.json; echo
    timeout -k 10 200 python3 tools/ldpc_bench.py > $O/ldpc_bench.txt 2>&1; tail -n 6 $O/ldpc_bench.txt
+   # what a rank of the strong-scaling run sees: the default batch of 2^20 frames cut into 1, 2, 4, 8 shares
+   for n in 1048576 524288 262144 131072; do timeout -k 10 300 python3 bench.py --frames $n --no-cpu-baseline --no-build 2>/dev/null | python3 -c "
+import json,sys; d=json.loads(sys.stdin.readline()); print('%8d frames per GPU per step: %.3f ms, %.2f M frames/s per GPU (%d timed steps after %d untimed)' % (d['config']['launch_units'], d['ms_per_step'], d['value']/1e6, d['steps'], d['warmup'] + d['untimed_priming_steps']))"; done > $O/batch_size_series.txt; cat $O/batch_size_series.txt
    for c in cfg4 cfg5; do timeout -k 10 600 python3 tools/sweep.py --config $c --out $O/sweep_$c.json > $O/sweep_$c.txt 2>&1; tail -n 1 $O/sweep_$c.txt; done ;;
 esac

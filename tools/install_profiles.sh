@@ -14,6 +14,7 @@ for c in cfg2 cfg4 cfg5 raw; do cp $SQ/$c/summary.txt $P/${TAG}_sq_counters_$c.t
 cp $O/mix_fft_stalls_two_wave.txt $P/${TAG}_mix_fft_stalls_two_wave.txt; cp $O/mix_fft_stalls_one_wave.txt $P/${TAG}_mix_fft_stalls_one_wave.txt
 cat $O/soak_parity.txt $O/soak_sync.txt > $P/${TAG}_soak_parity.txt
 cp $O/ldpc_bench.txt $P/${TAG}_ldpc_bench.txt
+cp $O/batch_size_series.txt $P/${TAG}_batch_size_series.txt
 for c in cfg4 cfg5; do cp $O/sweep_$c.json $P/${TAG}_sweep_$c.json; cp $O/sweep_$c.txt $P/${TAG}_sweep_$c.txt; done
 python3 tools/issue_model.py > $P/${TAG}_issue_model.txt
 grep -l csrc_sha $P/${TAG}_traffic_*.json $P/traffic.json | xargs grep -h '"csrc_sha"' | sort | uniq -c
