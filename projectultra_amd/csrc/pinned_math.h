@@ -226,6 +226,45 @@ UM_FN void sincosf_bounded_(float y, float* sp, float* cp) {
     *cp = cosine;
 }
 
+// sincosf_bounded_ for a caller that KNOWS the quadrant: n = the n reduce_fast gives for y (the caller's y values share it:
+// reduce_fast is monotone in y, so n(min) == n(max) settles a whole set), and y is not -0.0.  With n wave-uniform every
+// per-lane select of sincosf_bounded_ becomes a scalar choice:
+//   * x = fma(-n, hpi, y), then xs = +-x by the quadrant:  fma(-n s, hpi, s y) with s = +-1 is that value exactly (negating
+//     product and addend negates the exact sum, rounding to nearest is symmetric; s y is exact);
+//   * the cosine's sign for n & 2 is a multiplication by +-1.0f (exact), the swap for n & 1 is the caller's choice of
+//     which result goes where (SWAP);
+//   * glibc's |y| < 2^-12 shortcut (y, 1.0f) is what the polynomials round to anyway (|y^3 / 6| and y^2 / 2 are below half
+//     an ulp of y and of 1) — for every such y but -0.0, whose sine the polynomial turns into +0.0: the caller keeps -0.0 out.
+// The same fused operations on the same operands in the same order otherwise.  tools/pinned_math_check.cpp ("quadrant")
+// compares it with sincosf_bounded_ and glibc over every float of the range.
+template <bool SWAP>
+UM_FN void sincosf_quadrant_(float y, double neg_n_signed, float y_sign, float cos_sign, float* sp, float* cp) {
+    const SinCosTab p = UM_TAB0;
+    const double xs = fma(neg_n_signed, 0x1.921FB54442D18p0, (double)(y * y_sign));
+    const double x2 = xs * xs;
+    const double x3 = xs * x2;
+    const double s1 = fma(x2, p.s3, p.s2);
+    const double x7 = x3 * x2;
+    const double sa = fma(x3, p.s1, xs);
+    const float sine = (float)fma(x7, s1, sa);
+    const double x4 = x2 * x2;
+    const double c2 = fma(x2, p.c4, p.c3);
+    const double c1 = fma(x2, p.c1, p.c0);
+    const double x6 = x4 * x2;
+    const double ca = fma(x4, p.c2, c1);
+    const float cosine = (float)fma(x6, c2, ca) * cos_sign;
+    *sp = SWAP ? cosine : sine;
+    *cp = SWAP ? sine : cosine;
+}
+// the scalars of sincosf_quadrant_ for quadrant n
+UM_FN void sincosf_quadrant_setup(int n, double* neg_n_signed, float* y_sign, float* cos_sign, bool* swap) {
+    const bool flip = ((n + 1) & 2) != 0;
+    *y_sign = flip ? -1.0f : 1.0f;
+    *neg_n_signed = flip ? (double)n : -(double)n;
+    *cos_sign = (n & 2) ? -1.0f : 1.0f;
+    *swap = (n & 1) != 0;
+}
+
 // fdlibm atanf (s_atanf.c)
 UM_FN float atanf_(float x) {
     // atanhi / atanlo as selects (a dynamically indexed local array would live in memory on the GPU)

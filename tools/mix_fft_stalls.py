@@ -100,6 +100,13 @@ def main():
     d = np.diff(t, axis=1)                       # [records][10]
     ex = r[:, 12:16].astype(np.int64)            # sub-stamps 11, 12, 13 inside the lookup phase (two-wave kernel)
     total = t[:, 10] - t[:, 0]
+    if os.environ.get("UH_STAMP_FLAGS_HIST"):
+        vals, cnts = np.unique(r[:, 15], return_counts=True)
+        print("# flag word histogram:", dict(zip(vals.tolist(), cnts.tolist())), file=sys.stderr)
+        for fl in (16, 32):
+            m = (r[:, 15] & np.uint64(fl)) != 0
+            if m.any():
+                print(f"# flag {fl}: {m.mean():.3f} of items, sincos phase mean {d[m, 3].mean():.0f} cycles, item mean {total[m].mean():.0f}", file=sys.stderr)
     print(f"# {'mix_fft_kernel<10> (one wavefront per frame)' if args.one_wave else 'mix_fft2_kernel<10> (two wavefronts per frame)'}, "
           f"{n} frames, stamps of the last data symbol's launch; demodulation of the batch with stamps on: {e0.elapsed_time(e1):.3f} ms")
     # residency: wavefronts working at a time per SIMD

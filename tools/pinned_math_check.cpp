@@ -30,11 +30,11 @@ int main(int argc, char** argv) {
     const unsigned T = std::max(1u, std::thread::hardware_concurrency());
     const uint64_t stride = full ? 1 : 1021;            // prime stride for the quick subset
     const uint64_t pairs = (full || pairs_only) ? (1ull << 31) : (1ull << 24);
-    std::atomic<uint64_t> bad[9]; for (auto& b : bad) b = 0;
-    std::atomic<uint64_t> cnt[9]; for (auto& c : cnt) c = 0;
+    std::atomic<uint64_t> bad[10]; for (auto& b : bad) b = 0;
+    std::atomic<uint64_t> cnt[10]; for (auto& c : cnt) c = 0;
     std::vector<std::thread> th;
     for (unsigned t = 0; t < T; ++t) th.emplace_back([&, t] {
-        uint64_t lb[9] = {0}, lc[9] = {0};
+        uint64_t lb[10] = {0}, lc[10] = {0};
         for (uint64_t u = t * stride; !pairs_only && u < (1ull << 32); u += (uint64_t)T * stride) {
             float x = um::as_f32((uint32_t)u);
             float s, c; sincosf(x, &s, &c);
@@ -42,6 +42,13 @@ int main(int argc, char** argv) {
             lc[1]++; if (!same(um::cosf_(x), cosf(x))) { if (lb[1]++ < 3) fprintf(stderr, "cosf %08x\n", (unsigned)u); }
             float ms, mc; um::sincosf_(x, &ms, &mc);
             lc[2]++; if (!same(ms, s) || !same(mc, c)) { if (lb[2]++ < 3) fprintf(stderr, "sincosf %08x\n", (unsigned)u); }
+            if (um::abstop12(x) < 0x42f && (uint32_t)u != 0x80000000u) {   // the quadrant variant: |x| < 120, every float but -0.0 (its sine comes out +0.0)
+                int n; (void)um::reduce_fast((double)x, &n);
+                double m; float ys, csn; bool sw; um::sincosf_quadrant_setup(n, &m, &ys, &csn, &sw);
+                float qs, qc;
+                if (sw) um::sincosf_quadrant_<true>(x, m, ys, csn, &qs, &qc); else um::sincosf_quadrant_<false>(x, m, ys, csn, &qs, &qc);
+                lc[9]++; if (!same(qs, s) || !same(qc, c)) { if (lb[9]++ < 3) fprintf(stderr, "sincosf_quadrant %08x\n", (unsigned)u); }
+            }
             if (um::abstop12(x) < 0x42f) {            // the branch-free variant's domain: |x| < 120
                 float bs, bc; um::sincosf_bounded_(x, &bs, &bc);
                 lc[6]++; if (!same(bs, s) || !same(bc, c)) { if (lb[6]++ < 3) fprintf(stderr, "sincosf_bounded %08x\n", (unsigned)u); }
@@ -76,12 +83,12 @@ int main(int argc, char** argv) {
                 lc[7]++; if (um::atan2f_beyond_right_angle(y, x) != (fabsf(atan2f(y, x)) > 1.5708f)) lb[7]++;
             }
         }
-        for (int k = 0; k < 9; ++k) { bad[k] += lb[k]; cnt[k] += lc[k]; }
+        for (int k = 0; k < 10; ++k) { bad[k] += lb[k]; cnt[k] += lc[k]; }
     });
     for (auto& x : th) x.join();
-    const char* names[9] = {"sinf", "cosf", "sincosf", "atanf", "atan2f", "hypotf", "sincosf_bounded", "right_angle_test", "logf"};
+    const char* names[10] = {"sinf", "cosf", "sincosf", "atanf", "atan2f", "hypotf", "sincosf_bounded", "right_angle_test", "logf", "sincosf_quadrant"};
     int rc = 0;
-    for (int k = 0; k < 9; ++k) {
+    for (int k = 0; k < 10; ++k) {
         printf("%s checked=%llu mismatches=%llu\n", names[k], (unsigned long long)cnt[k].load(), (unsigned long long)bad[k].load());
         if (bad[k].load()) rc = 1;
     }
