@@ -686,7 +686,7 @@ __device__ __forceinline__ void symbol_to_freq2(Fft2Shared<LOG2N, ROT>& sh, cons
 #ifdef UH_MIXFFT_STAMPS
                 stamps.t[kStampPhases + 4] = __any(more) ? 2ull : 1ull;
 #endif
-                if (__any(more)) {
+                if (__builtin_expect(__any(more), 0)) {
                     if (more) {
                         int nstart = nxt.start;
 #pragma unroll
@@ -756,7 +756,7 @@ __device__ __forceinline__ void symbol_to_freq2(Fft2Shared<LOG2N, ROT>& sh, cons
 #ifdef UH_MIXFFT_STAMPS
             stamps.t[kStampPhases + 4] |= one_quadrant ? 16ull : 32ull;
 #endif
-            if (one_quadrant) {
+            if (__builtin_expect(one_quadrant, 1)) {
                 double m_n; float y_sign, cos_sign; bool swap;
                 um::sincosf_quadrant_setup(n_lo, &m_n, &y_sign, &cos_sign, &swap);
                 if (swap) {
