@@ -58,7 +58,7 @@ ISSUE_CYCLES = {
     "ldpc_totals R3/4": dict(unit="cw_iteration", valu=162.5 * 3.38, salu=80.4 * 4.19, lds=61.5 * 2.13),
     # round 3 (profiles/r03_sq_counters.txt -> profiles/r03_issue_model.txt): the two-wavefront transform, the deferred
     # carrier half (unit: one symbol of one frame), the pilot half with its record for the carrier half
-    "mix_fft_kernel": dict(unit="frame", valu=1199.9 * 3.43, salu=242.4 * 4.19, lds=104.8 * 3.41),    # mean of the rotating (1691 VALU) and the no-rotation instance (709): two launches each per step
+    "mix_fft_kernel": dict(unit="frame", valu=1095.7 * 3.47, salu=236.4 * 4.19, lds=106.7 * 3.48),    # mean of the rotating (1505 VALU) and the no-rotation instance (686): two launches each per step
     "track_kernel": dict(unit="frame_symbol", valu=182.4 * 3.29, salu=118.3 * 4.19, lds=19.9 * 4.01),
     "track_pilot_kernel": dict(unit="frame", valu=164.7 * 3.54, salu=64.1 * 4.19, lds=4.75 * 5.08),
     # per raw stream of 14,400 samples at 30 dB (profiles/r03_sq_counters_raw.txt: 65,536 streams per launch)
