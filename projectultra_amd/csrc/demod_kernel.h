@@ -1224,7 +1224,9 @@ __device__ __forceinline__ void demap_carrier(c32 sym, c32 prev, float nv, float
 template <int MOD>
 __device__ __forceinline__ void equalize_demap(TrackShared& sh, const DemodConst& D, const LaneConst& lc, Track& tr,
                                                c32& dprev, const c32* __restrict__ fq, float* __restrict__ llr_sym,
-                                               float* dprev_abs = nullptr, const c32* tc_fixed = nullptr) {
+                                               float* dprev_abs = nullptr, const c32* tc_fixed = nullptr,
+                                               const c32* received_in = nullptr) {
+    // received_in (nullable): this lane's bin, where the caller has requested it ahead of time (track_all_kernel)
     // dprev_abs (differential layouts, nullable): |dprev| carried from symbol to symbol by the caller (negative: not known)
     // — the previous symbol's |sym| is this symbol's |prev|.  tc_fixed (nullable): the timing-phase factor of this lane
     // where the timing estimate cannot move between symbols (no pilots).  Both only skip repeated evaluations.
@@ -1255,7 +1257,7 @@ __device__ __forceinline__ void equalize_demap(TrackShared& sh, const DemodConst
     } else {
         float h_power = 0.0f;
         if (is_data) {
-            const c32 received = fq[lc.data_fq], h = sh.H[lc.data_slot];
+            const c32 received = received_in ? *received_in : fq[lc.data_fq], h = sh.H[lc.data_slot];
             h_power = cnorm(h);
             const float mmse_denom = h_power + tr.noise_variance;
             if (mmse_denom < 1e-10f) {
@@ -1871,19 +1873,34 @@ __global__ __launch_bounds__(kWave, 6) void track_all_kernel(const DemodConst* _
     const int lane = threadIdx.x;
     const LaneConst lc = lane_constants(D);
     const int total = n_frames * n_sym_batch;
+    // What an item reads — the record's scalars, the pilots' estimates, this lane's bin — is requested one item ahead, as
+    // per-lane words (a uniform load would be waited for on the spot): the item then starts on data that has arrived.
+    float nx_rec = 0.0f;
+    c32 nx_hp = mk(0.0f, 0.0f), nx_fq = mk(0.0f, 0.0f);
+    auto request = [&](int w) {
+        const float* rec = trk_rec + (size_t)w * kTrkRecFloats;
+        nx_rec = rec[lane & 7];
+        if (lane < D.n_pilot) nx_hp = reinterpret_cast<const c32*>(rec + kTrkRecHp)[lane];
+        if (lane < D.n_data) nx_fq = fq_all[(size_t)w * (2 * D.fq_half) + lc.data_fq];
+    };
+    if ((int)blockIdx.x < total) request((int)blockIdx.x);
     for (int w = blockIdx.x; w < total; w += gridDim.x) {
         const int frame = w % n_frames, ds = w / n_frames;
         const float* rec = trk_rec + (size_t)w * kTrkRecFloats;
         Track tr;
-        tr.noise_variance = rec[tk_noise]; tr.timing = rec[tk_timing];
+        const float my_rec = nx_rec;
+        const c32 my_hp = nx_hp, my_fq = nx_fq;
+        if (w + (int)gridDim.x < total) request(w + (int)gridDim.x);
+        tr.noise_variance = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(my_rec), tk_noise));
+        tr.timing = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(my_rec), tk_timing));
         tr.ppc = mk(1.0f, 0.0f); tr.cpc = mk(1.0f, 0.0f);
         tr.cpc_init = 1; tr.has_prev = 1; tr.has_dprev = 0; tr.snr_symbol_count = 0; tr.symbols_since_sync = 0;
-        if (lane < D.n_pilot) sh.H[lc.pilot_slot] = reinterpret_cast<const c32*>(rec + kTrkRecHp)[lane];   // the rest is interpolated before it is read
+        if (lane < D.n_pilot) sh.H[lc.pilot_slot] = my_hp;      // the rest is interpolated before it is read
         c32 dprev = mk(1.0f, 0.0f);
         wave_sync();
         finish_channel_estimate(sh, D, lc, tr);
         equalize_demap<MOD>(sh, D, lc, tr, dprev, fq_all + (size_t)w * (2 * D.fq_half),
-                            llr + (size_t)frame * llr_stride + (size_t)(sym0 + ds) * D.llrs_per_symbol);
+                            llr + (size_t)frame * llr_stride + (size_t)(sym0 + ds) * D.llrs_per_symbol, nullptr, nullptr, &my_fq);
         if (state_out && lane == 0 && ds == n_sym_batch - 1) {   // the tracker after the last symbol of the launch
             float* so = state_out + (size_t)frame * ULTRA_HIP_STATE_FLOATS;
             so[ULTRA_HIP_STATE_FREQ_OFFSET_HZ] = rec[tk_cfo];
