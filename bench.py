@@ -79,6 +79,10 @@ def parse():
     ap.add_argument("--snr-db", type=float, default=None, help="cfg2/cfg3/raw: channel SNR (default 30 dB cfg3/raw, 3 dB cfg2)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample", type=int, default=0, help="trials for the CPU baseline (0 = auto)")
+    ap.add_argument("--backend", choices=("nccl", "gloo"), default="nccl",
+                    help="process-group backend of the counter all-reduce: nccl (= RCCL over xGMI, one GPU per rank) or gloo "
+                         "(counters reduced through host memory; ranks may then SHARE a card, rank r on device r %% device_count: "
+                         "the many-ranks-one-card rehearsal of tests/test_gpu_multirank.py)")
     ap.add_argument("--no-build", action="store_true",
                     help="do not (re)build the checker libraries; REQUIRED under rocprofv3, whose preloaded library "
                          "initialises the GPU before main() — the compiler must never be started from such a process")
@@ -165,6 +169,22 @@ def pick_threads(cores, run):
     cands = sorted({c for c in (cores, cores // 2, cores // 4, cores // 8, 32, 16) if 1 <= c <= cores}, reverse=True)
     rates = {c: run(c) for c in cands}
     return max(rates, key=rates.get), rates
+
+
+def stratified_frames(n, frame_bytes, block=4096, seed=0x5712A7):
+    """Indices of the frames the CPU legs check beside the timed prefix: first / middle / last `block`, `block` drawn
+    uniformly over the batch, and block/2 around the frame whose audio crosses byte offset 2^32 of the buffer (32-bit
+    offset arithmetic in a kernel would fail exactly there).  Sorted, unique."""
+    block = min(block, n)
+    rng = np.random.default_rng(seed)
+    parts = [np.arange(0, block), np.arange((n - block) // 2, (n - block) // 2 + block), np.arange(n - block, n),
+             rng.choice(n, size=block, replace=False)]
+    strata = f"first, middle and last {block}, {block} drawn uniformly"
+    edge = (1 << 32) // frame_bytes
+    if edge + block // 4 < n:
+        parts.append(np.arange(edge - block // 4, edge + block // 4))
+        strata += f", {block // 2} around frame {edge} (byte offset 2^32 of the audio)"
+    return np.unique(np.concatenate(parts)).astype(np.int64), strata
 
 
 def best_of(fn, runs=3):
@@ -270,13 +290,34 @@ class ModemWorkload:
         t_port, want = best_of(lambda: o.demod_decode_batch(ccfg, audio, n_threads=cores, want_llr=False, want_state=False))
         res["port"] = dict(value=sample / t_port, unit="frames/s", cores=cores, kind="port", seconds=t_port,
                            gpu_matches_bitwise=bool(all(np.array_equal(got[k], want[k]) for k in ("bytes", "iters", "ok"))))
-        if have_ref():
-            ref = Ref()
+        ref = Ref() if have_ref() else None
+        if ref is not None:
             t_ref, rr = best_of(lambda: ref.demod_decode_batch_mt(ccfg, audio, cores))
             res["reference"] = dict(value=sample / t_ref, unit="frames/s", cores=cores, kind="reference", seconds=t_ref,
                                     gpu_matches_bitwise=bool(all(np.array_equal(got[k], rr[k]) for k in ("bytes", "iters", "ok"))))
+        # The WHOLE batch is what the step decoded, so the comparison is stratified over the whole batch (untimed): the first,
+        # middle and last 4,096 frames, the 2,048 frames around the 4 GiB byte offset of the audio buffer where the batch
+        # reaches it, and 4,096 frames drawn over all of it — soft bits bitwise against the oracle port, bytes / iterations /
+        # status against the compiled reference as well.
+        idx, strata = stratified_frames(self.n, self.bytes_audio)
+        t_idx = self.torch.from_numpy(idx).cuda()
+        a = self.d_audio[t_idx].cpu().numpy()
+        g_s = {k: v[t_idx].cpu().numpy() for k, v in self.out.items()}
+        w = o.demod_decode_batch(ccfg, a, n_threads=cores, want_llr=True, want_state=False)
+        n_llr = min(g_s["llr"].shape[1], w["llr"].shape[1])
+        ver = dict(frames=int(idx.size), strata=strata,
+                   llr_bitwise_vs_port=bool(np.array_equal(g_s["llr"][:, :n_llr].view(np.uint32), w["llr"][:, :n_llr].view(np.uint32))),
+                   decode_vs_port=bool(all(np.array_equal(g_s[k], w[k]) for k in ("bytes", "iters", "ok"))))
+        if ref is not None:
+            rr = ref.demod_decode_batch_mt(ccfg, a, cores)
+            ver["decode_vs_reference"] = bool(all(np.array_equal(g_s[k], rr[k]) for k in ("bytes", "iters", "ok")))
+        ver["all_equal"] = all(v for k, v in ver.items() if k not in ("frames", "strata"))
+        for leg in res.values():
+            leg["gpu_matches_bitwise"] = bool(leg["gpu_matches_bitwise"] and ver["all_equal"])
+        self.verified = ver
         self.cores_used = cores
-        return res, f"first {sample} frames of the same batch (copied from the device), post-sync demodulate + decode"
+        return res, (f"timed: first {sample} frames of the same batch (copied from the device), post-sync demodulate + decode; "
+                     f"compared: those and {idx.size} frames stratified over the whole batch ({strata})")
 
 
 class RawWorkload(ModemWorkload):
@@ -538,10 +579,31 @@ class ModeSweepWorkload:
         return res, f"first {per} frames of each of the {len(self.cells) * len(self.snrs)} points (same audio, copied from the device)"
 
 
+def self_launch(args) -> int:
+    """`python bench.py --gpus N` with no launcher around it: start the N ranks ourselves, as a CHILD
+    `python -m torch.distributed.run --nproc-per-node N bench.py ...` (never an exec, and before anything in this process has
+    touched the GPU).  The child's rank 0 prints the JSON line on the stdout it inherits; the exit code is the child's, so a
+    rank that fails fails the run."""
+    import socket
+    with socket.socket() as s:                      # a free rendezvous port on the loopback interface
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), str(Path(__file__).resolve())] + sys.argv[1:] + ["--no-build"]
+    print(f"bench.py: --gpus {args.gpus} and no RANK in the environment: starting {args.gpus} ranks ({' '.join(cmd[1:8])} ...)",
+          file=sys.stderr, flush=True)
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+    return subprocess.call(cmd, env=env)
+
+
 # ------------------------------------------------------------------------------------------------------------------
 def main():
     args = parse()
     ensure_built(args.no_build)                     # before anything initialises the GPU
+    if args.gpus < 1:
+        raise SystemExit("bench.py: --gpus must be >= 1")
+    if "RANK" not in os.environ and args.gpus > 1:
+        raise SystemExit(self_launch(args))
     # stdout carries exactly ONE line (the JSON): whatever libraries print there meanwhile (RCCL's version banner at
     # communicator creation) goes to stderr instead
     sys.stdout.flush()
@@ -553,20 +615,25 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    if world != args.gpus:
-        if rank == 0:
-            print(f"bench.py: WORLD_SIZE={world} but --gpus {args.gpus}", file=sys.stderr)
-        args.gpus = world
+    if world != args.gpus:                          # never a silent fall-back to another number of GPUs
+        raise SystemExit(f"bench.py: the launcher started WORLD_SIZE={world} ranks but --gpus {args.gpus} was asked for: refusing "
+                         f"to report a line for another number of GPUs than the one named")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the receive path has no CPU fallback")
-    torch.cuda.set_device(local_rank)
+    n_dev = torch.cuda.device_count()
+    if args.backend == "nccl" and local_rank >= n_dev:
+        raise SystemExit(f"bench.py: rank {rank} has no GPU of its own ({n_dev} visible, {world} ranks): RCCL needs one device per "
+                         f"rank (--backend gloo lets ranks share a card for a rehearsal)")
+    device_index = local_rank % n_dev
+    torch.cuda.set_device(device_index)
     distributed = "RANK" in os.environ and "WORLD_SIZE" in os.environ      # launched by torch.distributed.run (also for N = 1)
     backend = None
     if distributed:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29500")
-        dist.init_process_group(backend="nccl", rank=rank, world_size=world)   # "nccl" IS RCCL on ROCm
+        dist.init_process_group(backend=args.backend, rank=rank, world_size=world)   # "nccl" IS RCCL on ROCm
         backend = dist.get_backend()
+    via_host = distributed and args.backend == "gloo"    # gloo: the 64 bytes go through host memory
 
     from projectultra_amd.montecarlo import counters_dict
 
@@ -580,10 +647,26 @@ def main():
         wl = ModeSweepWorkload(args, rank, world, torch)
 
     # the single collective of the path; timed with HIP events on the launch stream when profiling
-    ar_events = []
+    ar_events, ar_host = [], []
+
+    def reduce_max(x: float) -> float:
+        """max over the ranks of one host scalar (through the device for RCCL, through host memory for gloo)"""
+        if not distributed:
+            return x
+        t = torch.tensor([x], dtype=torch.float64, device="cpu" if via_host else "cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        return float(t.item())
 
     def allreduce(t):
         if not distributed:
+            return
+        if via_host:
+            t0 = time.perf_counter()
+            h = t.cpu()
+            dist.all_reduce(h, op=dist.ReduceOp.SUM)
+            t.copy_(h)
+            if allreduce.timed:
+                ar_host.append(time.perf_counter() - t0)
             return
         if ar_events is not None and allreduce.timed:
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -607,10 +690,8 @@ def main():
     for _ in range(2):
         wl.step(allreduce)
     barrier()
-    t_step = torch.tensor([(time.perf_counter() - t_p) / 2], dtype=torch.float64, device="cuda")
-    if distributed:
-        dist.all_reduce(t_step, op=dist.ReduceOp.MAX)
-    n_prime = int(min(64, max(0, math.ceil(0.15 / max(float(t_step.item()), 1e-4)) - 2)))
+    t_step = reduce_max((time.perf_counter() - t_p) / 2)
+    n_prime = int(min(64, max(0, math.ceil(0.15 / max(t_step, 1e-4)) - 2)))
     for _ in range(n_prime):
         wl.step(allreduce)
     for _ in range(args.warmup):
@@ -639,10 +720,9 @@ def main():
             for k, (ms, cnt) in c.profile_read().items():
                 a = prof.setdefault(k, [0.0, 0]); a[0] += ms; a[1] += cnt
     ar_us = float(np.mean([a.elapsed_time(b) for a, b in ar_events]) * 1e3) if ar_events else None
-    t_max = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
-    if distributed:
-        dist.all_reduce(t_max, op=dist.ReduceOp.MAX)
-    elapsed = float(t_max.item())
+    if ar_host:
+        ar_us = float(np.mean(ar_host) * 1e6)
+    elapsed = reduce_max(elapsed)
     last = wl.counters.reshape(-1, 8).sum(dim=0).cpu()
     stats = counters_dict(last)
     expect = getattr(wl, "total_units", wl.units_per_step * world)
@@ -664,7 +744,7 @@ def main():
                              "algorithmic_bytes_per_launch": alg, "GBps": alg / (avg * 1e-3) / 1e9,
                              "frac": alg / (avg * 1e-3) / 1e9 / HBM_PEAK_GBPS}
         dom = max(kernels, key=lambda k: kernels[k]["ms_per_step"])
-        props = torch.cuda.get_device_properties(0)
+        props = torch.cuda.get_device_properties(device_index)
         roofline = {"bound": "hbm", "kernel": dom, "achieved": kernels[dom]["GBps"], "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                     "frac": kernels[dom]["frac"], "traffic": None, "launch_ms": kernels[dom]["avg_launch_ms"],
                     "algorithmic_bytes_per_launch": kernels[dom]["algorithmic_bytes_per_launch"],
@@ -765,7 +845,7 @@ def main():
                    threads="one worker thread per usable core: the physical cores, capped by the affinity mask and the container's "
                            "CPU quota where visible, then the fastest of {all, 1/2, 1/4, 1/8, 32, 16} on a probe sample "
                            "(thread_probe_trials_per_s); disjoint trial ranges, best of 3",
-                   gpu_matches_cpu_bitwise=head["gpu_matches_bitwise"], legs=res)
+                   gpu_matches_cpu_bitwise=head["gpu_matches_bitwise"], verified=getattr(wl, "verified", None), legs=res)
 
     if rank == 0:
         total = getattr(wl, "total_units", wl.units_per_step * world) * args.steps
@@ -781,8 +861,11 @@ def main():
             "achieved_hbm_GBps": value * wl.bytes_per_unit / 1e9,
             "hbm_frac_of_peak": value * wl.bytes_per_unit / 1e9 / (HBM_PEAK_GBPS * world),
             "fer": stats["fer"], "ber": stats["ber"], "mean_bp_iterations": stats["mean_iters"], "trials_counted": stats["frames"],
+            "counters": [int(v) for v in last.tolist()],           # the eight counters of the last step, summed over ranks (and points)
+            "counters_per_point": wl.counters.reshape(-1, 8).cpu().tolist() if wl.points_per_step > 1 else None,
             "stimulus_seconds": wl.t_gen,
             "collective": {"backend": backend or "none (single process, no process group)", "world_size": dist.get_world_size() if distributed else 1,
+                           "ranks_per_device": -(-world // n_dev) if distributed else 1,
                            "op": getattr(wl, "collective_op", "all_reduce(SUM) of 8 x int64"),
                            "per_step": getattr(wl, "collectives_per_step", wl.points_per_step), "allreduce_us": ar_us},
             "roofline": roofline, "cpu_baseline": cpu,

@@ -243,7 +243,9 @@ int ultra_hip_demod_stream_batch(ultra_hip_ctx* ctx, const float* d_audio, size_
                                  const float* d_cfo_phase, size_t n_frames, uint32_t first_symbol, uint32_t n_symbols,
                                  float* d_llr, float* d_state);
 /* OFDMDemodulator::setFrequencyOffset (demodulator.cpp:805-815) between two ultra_hip_demod_stream_batch calls:
- * freq_offset_hz = freq_offset_filtered = cfo_hz, correction phase 0, for frame `frame` of the stream in flight. */
+ * freq_offset_hz = freq_offset_filtered = cfo_hz, correction phase 0, for frame `frame` of the stream in flight, applied
+ * from the next symbol on — also when the frame started without offsets (d_cfo_hz == NULL at first_symbol 0): the batch
+ * then leaves the zero-offset fast paths for the rest of the frame (tests/golden/setcfo.npz). */
 int ultra_hip_demod_stream_set_cfo(ultra_hip_ctx* ctx, size_t frame, float cfo_hz);
 
 #define ULTRA_HIP_STATE_FLOATS 8

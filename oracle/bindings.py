@@ -527,6 +527,19 @@ class Ref(_Base):
         assert n == cap
         return llr
 
+    def demod_synced_setcfo(self, cfg, audio, set_at, cfo_new_hz, cfo0_hz=None):
+        """SYNCED-entry frame whose offset is replaced by setFrequencyOffset before symbol `set_at` -> LLRs."""
+        audio = _f32(audio)
+        g = geometry(cfg)
+        nsym = audio.size // g.symbol_samples
+        cap = nsym * g.llrs_per_symbol
+        llr = np.zeros(cap, np.float32)
+        n = self.lib.ref_demod_synced_setcfo(C.byref(cfg), _ptr(audio), C.c_uint32(nsym), C.c_int(cfo0_hz is not None),
+                                             C.c_float(cfo0_hz or 0.0), C.c_uint32(set_at), C.c_float(cfo_new_hz),
+                                             _ptr(llr), C.c_uint32(cap))
+        assert n == cap, (n, cap)
+        return llr
+
     def harness_awgn(self, cfg, payload: bytes, snr_db, noise_seed):
         cap = 1 << 20
         out = np.zeros(cap, np.float32)

@@ -675,6 +675,28 @@ int ref_demod_synced_public(const ultra_hip_config* c, const float* audio, uint3
     return (int)sb.size();
 }
 
+// OFDMDemodulator::setFrequencyOffset (src/ofdm/demodulator.cpp:805-814) BETWEEN two process() calls of a frame in the
+// SYNCED state: symbols [0, set_at) with the offset the frame started with (none when has_cfo0 == 0), then the new offset
+// from symbol set_at on (correction phase restarts at 0).
+int ref_demod_synced_setcfo(const ultra_hip_config* c, const float* audio, uint32_t n_symbols, int has_cfo0, float cfo0_hz,
+                            uint32_t set_at, float cfo_new_hz, float* llr_out, uint32_t llr_cap) {
+    StderrMute mute;
+    ModemConfig cfg = to_cfg(c);
+    OFDMDemodulator demod(cfg);
+    auto* im = demod.impl_.get();
+    if (has_cfo0) { im->freq_offset_hz = cfo0_hz; im->freq_offset_filtered = cfo0_hz; }
+    im->state.store(OFDMDemodulator::Impl::State::SYNCED);
+    if (set_at > n_symbols) set_at = n_symbols;
+    if (set_at > 0) demod.process(SampleSpan(audio, (size_t)set_at * im->symbol_samples));
+    demod.setFrequencyOffset(cfo_new_hz);
+    if (n_symbols > set_at)
+        demod.process(SampleSpan(audio + (size_t)set_at * im->symbol_samples, (size_t)(n_symbols - set_at) * im->symbol_samples));
+    auto& sb = im->soft_bits;
+    uint32_t m = (uint32_t)std::min<size_t>(sb.size(), llr_cap);
+    std::memcpy(llr_out, sb.data(), m * sizeof(float));
+    return (int)sb.size();
+}
+
 // OFDMDemodulator::processPresynced (src/ofdm/demodulator.cpp:854-985) after
 // setFrequencyOffsetWithPhase (:816-825) when has_cfo != 0.
 int ref_demod_presynced(const ultra_hip_config* c, const float* audio, uint32_t n_samples,

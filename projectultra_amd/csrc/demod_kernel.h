@@ -164,21 +164,6 @@ struct LaneConst {
     c32 zc;                               // sync_sequence[lane % n_carriers] for data carrier `lane`
 };
 
-template <int LOG2N>
-struct FftShared {                                          // mix_fft_kernel
-    static constexpr int N = 1 << LOG2N;
-    static constexpr int P = N / kWave;                     // points per lane: 8 / 16
-    static constexpr int A = (P == 16) ? 4 : 3;             // log2(P)
-    c32 X[N + N / P];                                       // FFT exchange buffer, 1 pad per P entries
-    // Twiddles of stages A..2A-1, one contiguous run per stage: stage s uses k = 0 .. P*2^(s-A)-1
-    // (w = twiddle[k << (LOG2N-1-s)]), stored at twB[P*(2^(s-A)-1) + k].  Lanes of a 32-lane group
-    // then read consecutive slots (or the same one): no bank conflicts, unlike a strided view of
-    // the global table (8-way at stage A).
-    static constexpr int kTwB = P * ((1 << A) - 1);
-    c32 twB[kTwB];
-    um::PhaseSeg seg[kPhaseCap];
-    int seg_start[kPhaseCap + 4] __attribute__((aligned(16)));   // segment starts, INT_MAX beyond the last one
-};
 struct TrackShared {                                        // track_kernel
     c32 H[kMaxCarriers];                                    // channel_estimate by slot
     union {
@@ -211,7 +196,7 @@ enum { tk_noise = 0, tk_timing, tk_cfo, tk_snr, tk_phase, tk_count };
 // Fq row of a frame (and symbol): c32[2 * D.fq_half] = bins [0, fq_half) then [N - fq_half, N), fq_half = 32 or 64
 __device__ __forceinline__ int fq_natural(const DemodConst& D, int bin) { return (bin < D.fq_half) ? bin : D.fq_half + (bin - (D.fft - D.fq_half)); }
 __device__ __forceinline__ int fq_index(const DemodConst& D, int bin) { return D.fq_pos[fq_natural(D, bin)]; }      // pilots first: DemodConst::fq_pos
-// Per-frame phase table of the next symbol's CFO rotation (cfo_walk_kernel / pilot_walk_kernel -> mix_fft kernels),
+// Per-frame phase table of the next symbol's CFO rotation (cfo_walk_kernel -> mix_fft2_kernel),
 // 32-bit words: [0] number of segments | samples covered << 8, [1] the tracker's CFO in Hz (float bits), [2] phase after
 // the covered samples (float bits), [3] phase the symbol starts with; then {start, base, step} per segment.  It carries
 // everything the transform needs to know about the frame: mix_fft never reads the tracker record.
@@ -234,7 +219,7 @@ template <int A> __device__ __forceinline__ constexpr int bitrev_small(int q) {
 
 // ---------------------------------------------------------------------------
 // Diagnostic build only (-DUH_MIXFFT_STAMPS, tools/mix_fft_stalls.py): shader-clock stamps at the phase boundaries of
-// every work item of mix_fft_kernel / mix_fft2_kernel, one record of kStampWords 64-bit words per wavefront and item:
+// every work item of mix_fft2_kernel, one record of kStampWords 64-bit words per wavefront and item:
 // [0..kStampPhases] clock, then HW_ID (wave slot / SIMD / CU / SE) and XCC_ID.  The product build contains none of it.
 constexpr int kStampPhases = 10, kStampExtra = 4, kStampWords = 16;   // extra: sub-stamps inside the lookup phase (mix_fft2)
 #ifdef UH_MIXFFT_STAMPS
@@ -260,236 +245,6 @@ struct Stamps { __device__ __forceinline__ void store(size_t, int) {} };
 #define UH_STAMP(k) do {} while (0)
 #endif
 
-// ---------------------------------------------------------------------------
-// Asynchronous HBM -> LDS copy of the FFT window of one symbol (global_load_lds: no VGPRs, the
-// wave keeps computing).  The staging area aliases the FFT exchange buffer X, which is idle
-// between the last FFT stage of one symbol and the first LDS transpose of the next, so the HBM
-// latency of symbol s+1 hides behind the tracking / demapping of symbol s.
-template <int LOG2N>
-__device__ __forceinline__ void prefetch_symbol(FftShared<LOG2N>& sh, const DemodConst& D,
-                                                const float* __restrict__ audio_sym) {
-    constexpr int P = (1 << LOG2N) / kWave;
-    float* stage = reinterpret_cast<float*>(sh.X);
-#pragma unroll
-    for (int q = 0; q < P; ++q)
-        __builtin_amdgcn_global_load_lds(audio_sym + D.cp + 64 * q + (int)threadIdx.x, stage + 64 * q, 4, 0, 0);
-}
-
-// mix one symbol to baseband (with CFO rotation), FFT it, leave the used bins in sh.Fq.
-// The symbol's FFT window must have been requested with prefetch_symbol().
-template <int LOG2N>
-__device__ __forceinline__ void symbol_to_freq(FftShared<LOG2N>& sh, const DemodConst& D, float freq_offset_hz,
-                                               float& cfo_phase, const c32* __restrict__ nco_sym,
-                                               const c32* __restrict__ twiddle, c32* __restrict__ fq_out,
-                                               const unsigned* __restrict__ seg_tab, Stamps& stamps) {
-    constexpr int N = 1 << LOG2N, P = N / kWave, A = FftShared<LOG2N>::A;
-    UH_STAMP(0);
-    const int lane = threadIdx.x;
-    const int rl = (int)(__brev((unsigned)lane) >> 26);      // bitrev6(lane)
-    const bool cfo_on = fabsf(freq_offset_hz) > 0.01f;
-    c32 v[P];
-    const float* stage = reinterpret_cast<const float*>(sh.X);
-    // this frame's phase table (cfo_walk_kernel): requested before the wait for the audio, which covers both
-    int tab_ns = 0, tab_covered = 0, tab_start = 0x7fffffff;
-    float tab_pnext = 0.0f, tab_base = 0.0f, tab_step = 0.0f;
-    if (cfo_on && seg_tab) {
-        tab_ns = (int)(seg_tab[0] & 0xffu); tab_covered = (int)((seg_tab[0] >> 8) & 0x7fffffu); tab_pnext = __uint_as_float(seg_tab[2]);
-        if (lane < tab_ns) {
-            tab_start = (int)seg_tab[4 + 3 * lane];
-            tab_base = __uint_as_float(seg_tab[5 + 3 * lane]);
-            tab_step = __uint_as_float(seg_tab[6 + 3 * lane]);
-        }
-    }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                            // staged audio has landed
-    wave_sync();
-    float xs[P];
-#pragma unroll
-    for (int qp = 0; qp < P; ++qp) xs[qp] = stage[64 * qp + rl];
-    wave_sync();                                                                // X may be overwritten from here on
-    UH_STAMP(1);
-    UH_STAMP(2);
-
-    // ---- CFO rotation factors (toBaseband: phase recurrence + cos/sin per sample) ----
-    // Lane l produces the factors of the P CONSECUTIVE window positions P*l .. P*l+P-1 (they
-    // almost always lie in one segment of the phase table: one lookup, then straight-line code)
-    // and parks them in the idle exchange buffer; the mixing stage below picks up the positions
-    // rl + 64*q it needs.  The P phases are computed first and the P sincos evaluations follow as
-    // one branch-free block, so their dependent double-precision chains overlap.
-    c32* rot = sh.X;                                       // rot[w + (w >> A)], w = window position
-    // The first half of the symbol's oscillator values (L2-resident table) is requested HERE, ahead of the phase / sincos
-    // block that covers its latency; the mixing stage asks for the second half while it consumes the first.  Measured:
-    // 2.93 -> 2.85 ms per step; all sixteen early 2.92 ms (168 VGPRs), twelve 2.88 ms.  The register allocation settles at
-    // 152 VGPRs with these eight values live across the block, against 168 without them.
-    c32 os_first[P / 2];
-#pragma unroll
-    for (int q2 = 0; q2 < P / 2; ++q2) os_first[q2] = nco_sym[D.cp + rl + 64 * q2];
-    if (cfo_on) {
-        const float inc = (float)(((-kTwoPi) * (double)freq_offset_hz) / (double)D.sample_rate);
-        // every phase of the symbol stays below 120 in magnitude (domain of the branch-free sincos)
-        const bool bounded = fabsf(cfo_phase) <= 4.0f && fabsf(inc) <= 1.0f;
-        float ph[P];
-#pragma unroll
-        for (int j = 0; j < P; ++j) ph[j] = 0.0f;
-        int done = 0;
-        float pcur = cfo_phase;
-        while (done < D.sym_len) {                           // one round unless a table overflows
-            int covered;
-            float pnext;
-            // lane k keeps segment k in registers (a further round — table overflow — is walked here, by every lane)
-            int my_start = 0x7fffffff;
-            float my_base = 0.0f, my_step = 0.0f;
-            int ns;
-            if (done == 0 && seg_tab) {
-                // the first round (almost always the only one) was walked by cfo_walk_kernel, one lane per frame
-                ns = tab_ns; covered = tab_covered; pnext = tab_pnext;
-                my_start = tab_start; my_base = tab_base; my_step = tab_step;
-            } else {
-                ns = um::phase_table_walk(pcur, inc, D.sym_len - done, kPhaseCap, &covered, &pnext,
-                                          [&](int k, int start, float base, float step) {
-                                              const bool mine = (lane == k);
-                                              my_start = mine ? start : my_start;
-                                              my_base = mine ? base : my_base;
-                                              my_step = mine ? step : my_step;
-                                          });
-            }
-            if (lane < kPhaseCap) { sh.seg[lane].start = my_start; sh.seg[lane].base = my_base; sh.seg[lane].step = my_step; }
-            if (lane < kPhaseCap + 4) sh.seg_start[lane] = my_start;         // INT_MAX beyond the last segment
-            wave_sync();
-            const int i0 = D.cp + P * lane - done;          // this lane's first position inside this round
-            if (i0 + P > 0 && i0 < covered) {
-                const int ifirst = (i0 > 0) ? i0 : 0;
-                int cnt = 1;                                 // segments starting at or before ifirst (segment 0 starts at 0)
-                for (int k = 1; k < ns; ++k) cnt += (__builtin_amdgcn_readlane(my_start, k) <= ifirst) ? 1 : 0;
-                int sg = cnt - 1;
-                um::PhaseSeg cur = sh.seg[sg];
-                int nstart = sh.seg_start[sg + 1];
-                const int ilast = i0 + P - 1;
-                if (i0 >= 0 && ilast < covered && ilast < nstart) {          // the usual case: one segment
-#pragma unroll
-                    for (int j = 0; j < P; ++j) ph[j] = um::phase_table_eval(cur, i0 + j);
-                } else if (i0 >= 0 && ilast < covered && ilast < sh.seg_start[sg + 2]) {
-                    // one boundary inside the window (every frame has a few such lanes): both segments, select
-                    const um::PhaseSeg nxt = sh.seg[sg + 1];
-#pragma unroll
-                    for (int j = 0; j < P; ++j) {
-                        const int i = i0 + j;
-                        const float a = um::phase_table_eval(cur, i), b = um::phase_table_eval(nxt, i);
-                        ph[j] = (i < nstart) ? a : b;
-                    }
-                } else {
-#pragma unroll
-                    for (int j = 0; j < P; ++j) {
-                        const int i = i0 + j;
-                        if (i >= 0 && i < covered) {
-                            while (i >= nstart) { ++sg; cur = sh.seg[sg]; nstart = sh.seg_start[sg + 1]; }
-                            ph[j] = um::phase_table_eval(cur, i);
-                        }
-                    }
-                }
-            }
-            wave_sync();
-            done += covered;
-            pcur = pnext;
-        }
-        cfo_phase = pcur;
-        UH_STAMP(2);
-        if (bounded) {
-#pragma unroll
-            for (int j = 0; j < P; ++j) {
-                float sn, cs;
-                um::sincosf_bounded_(ph[j], &sn, &cs);
-                const int w = P * lane + j;
-                rot[w + (w >> A)] = mk(cs, sn);
-            }
-        } else {
-#pragma unroll 2
-            for (int j = 0; j < P; ++j) { const int w = P * lane + j; rot[w + (w >> A)] = cexpj(ph[j]); }
-        }
-        wave_sync();
-    }
-    UH_STAMP(3);
-    // ---- mix: samples[i] * conj(osc) (* rotation), in two halves to bound live registers ----
-#pragma unroll
-    for (int h = 0; h < 2; ++h) {
-        c32 os[P / 2];
-#pragma unroll
-        for (int q2 = 0; q2 < P / 2; ++q2) os[q2] = (h == 0) ? os_first[q2] : nco_sym[D.cp + rl + 64 * (P / 2 + q2)];
-#pragma unroll
-        for (int q2 = 0; q2 < P / 2; ++q2) {
-            const int qp = h * (P / 2) + q2;
-            c32 mixed = mk(os[q2].re * xs[qp], (-os[q2].im) * xs[qp]);
-            if (cfo_on) { const int w = rl + 64 * qp; mixed = cmul(mixed, rot[w + (w >> A)]); }
-            v[bitrev_small<A>(qp)] = mixed;
-        }
-    }
-    if (cfo_on) wave_sync();
-    UH_STAMP(4);
-
-    // ---- group A: stages 0..A-1 on the lane's P consecutive (bit-reversed) positions ----
-#pragma unroll
-    for (int s = 0; s < A; ++s) {
-        const int half = 1 << s;
-#pragma unroll
-        for (int q = 0; q < P; ++q) {
-            if (q & half) continue;
-            const c32 w = twiddle[(q & (half - 1)) << (LOG2N - 1 - s)];   // wave-uniform
-            UH_BUTTERFLY(v[q], v[q + half], w);
-        }
-    }
-#pragma unroll
-    for (int q = 0; q < P; ++q) { const int i = P * lane + q; sh.X[i + (i >> A)] = v[q]; }
-    wave_sync();
-    UH_STAMP(5);
-
-    // ---- group B: stages A..2A-1, lane (blk, r) holds X[blk*P*P + r + P*j] ----
-    {
-        const int blk = lane / P, r = lane % P;
-#pragma unroll
-        for (int j = 0; j < P; ++j) { const int i = blk * P * P + r + P * j; v[j] = sh.X[i + (i >> A)]; }
-#pragma unroll
-        for (int s = A; s < 2 * A; ++s) {
-            const int hj = 1 << (s - A);                     // pair distance in j
-#pragma unroll
-            for (int j = 0; j < P; ++j) {
-                if (j & hj) continue;
-                const int k = r + P * (j & (hj - 1));
-                const c32 w = sh.twB[P * (hj - 1) + k];
-                UH_BUTTERFLY(v[j], v[j + hj], w);
-            }
-        }
-#pragma unroll
-        for (int j = 0; j < P; ++j) { const int i = blk * P * P + r + P * j; sh.X[i + (i >> A)] = v[j]; }
-    }
-    wave_sync();
-    UH_STAMP(6);
-
-    // ---- group C: stages 2A..LOG2N-1, lane holds X[lane + 64*t]; only outputs t = 0 and
-    //      t = P-1 (bins `lane` and N-64+lane) are used, the rest is dead code ----
-    {
-#pragma unroll
-        for (int t = 0; t < P; ++t) { const int i = lane + 64 * t; v[t] = sh.X[i + (i >> A)]; }
-#pragma unroll
-        for (int s = 2 * A; s < LOG2N; ++s) {
-            const int ht = 1 << (s - 6);                     // pair distance in t (half = 64 * ht)
-#pragma unroll
-            for (int t = 0; t < P; ++t) {
-                if (t & ht) continue;
-                const int k = lane + 64 * (t & (ht - 1));
-                const c32 w = twiddle[k << (LOG2N - 1 - s)];
-                UH_BUTTERFLY(v[t], v[t + ht], w);
-            }
-        }
-        UH_STAMP(7);
-        UH_STAMP(8);
-        // bins `lane` and N - 64 + lane: the row keeps the fq_half of each side that lie next to DC
-        const int fh = D.fq_half;
-        if (lane < fh) fq_out[D.fq_pos[lane]] = v[0];
-        if (lane >= 64 - fh) fq_out[D.fq_pos[fh + lane - (64 - fh)]] = v[P - 1];
-    }
-    wave_sync();
-    UH_STAMP(9);
-}
-
 // minimum / maximum over the 64 lanes, wave-uniform result: DPP operands inside the 16-lane rows, then four readlanes
 __device__ __forceinline__ float wave_fmin(float v) {
     v = fminf(v, __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0xB1, 0xF, 0xF, true)));    // quad_perm [1,0,3,2]
@@ -506,14 +261,14 @@ __device__ __forceinline__ float wave_fmax(float v) { return -wave_fmin(-v); }
 // TWO WAVEFRONTS PER FRAME (N = 1024).  The radix-2 decimation-in-time network of fft_impl (fft.cpp:89-121) works
 // on the bit-reversed input: positions [0, N/2) hold the EVEN time samples, [N/2, N) the odd ones, and stages
 // 0 .. log2(N)-2 never cross that line — they are two independent N/2-point transforms (with the twiddles
-// W_N^(2k) = twiddle[k << (LOG2N-1-s)], the very table entries the one-wavefront kernel reads).  Only the last
+// W_N^(2k) = twiddle[k << (LOG2N-1-s)], the table entries a one-wavefront transform of all N points reads).  Only the last
 // stage pairs element k of the even half with element k of the odd half.  So wavefront h of a 128-thread workgroup
 // takes the samples of parity h — 8 points per lane instead of 16: the lane's oscillator values, rotation phases,
 // sincos temporaries and butterfly registers all halve (<= 96 VGPRs instead of 154, five or six wavefronts per SIMD
 // instead of three) — runs mixing, CFO rotation and nine stages on its own, exactly like the 512-point instance, and
 // meets its partner ONCE per frame: the last stage needs E[k] + w O[k] for the bins k < 64 (wavefront 0 computes them
 // from its own E and the partner's O) and E[k] - w O[k] for k >= 448 (bins N-64 .. N-1, wavefront 1).  Same operations
-// on the same operands in the same order as the one-wavefront kernel: bit-identical bins.
+// on the same operands in the same order as a transform of all N points on one wavefront (round 2's kernel, removed in round 4): bit-identical bins.
 template <int LOG2N, bool ROT = true>
 struct Fft2Shared {
     static_assert(LOG2N == 10 || LOG2N == 9, "512 points per wavefront: N = 1024 on two wavefronts, N = 512 on one");
@@ -1085,7 +840,7 @@ __global__ __launch_bounds__(kWave, 5) void track_pilot_kernel(const DemodConst*
             }
             // Every lane of the group carries the frame's scalars: lane `sub` stores scalar `sub` — one store
             // instruction per wavefront writing 52 contiguous bytes per record, where lane 0 storing all twelve was
-            // twelve instructions of four 4-byte writes each.  st_cfo_phase belongs to mix_fft_kernel.
+            // twelve instructions of four 4-byte writes each.  st_cfo_phase belongs to cfo_walk_kernel.
             static_assert(st_since == 12 && st_cfo_phase == 2 && G >= 13, "scalar block layout");
             float mine = tr.freq_offset_hz;
             mine = (sub == st_cfo_filt) ? tr.freq_offset_filtered : mine;
@@ -1463,56 +1218,7 @@ __global__ __launch_bounds__(256) void cfo_walk_kernel(const DemodConst* __restr
     st[st_cfo_phase] = walk_to_table(D, st[st_cfo], st[st_cfo_phase], seg_tab + (size_t)frame * kSegTabWords);
 }
 
-// Launch bound 2, occupancy 3: with the bound at 3 the register allocator stops at 168 VGPRs and spills two of
-// them (12 B of scratch, reloaded per frame); with the looser bound it still settles on 168 — three wavefronts
-// per SIMD — and spills nothing (0.767 -> 0.743 ms per 2^18-frame launch).  LDS caps the CU at 14 workgroups anyway.
-template <int LOG2N>
-__global__ __launch_bounds__(kWave, 2) void mix_fft_kernel(
-    const DemodConst* __restrict__ Dp, const c32* __restrict__ nco, const c32* __restrict__ twiddle,
-    const float* __restrict__ audio, size_t frame_stride, const unsigned* __restrict__ frame_offset, int n_frames,
-    int sym, c32* __restrict__ fq, const unsigned* __restrict__ seg_tab, int n_sym_batch) {
-    __shared__ FftShared<LOG2N> sh;
-    const DemodConst& D = *Dp;
-    const int lane = threadIdx.x;
-    {
-        constexpr int P = FftShared<LOG2N>::P, A = FftShared<LOG2N>::A;
-        for (int idx = lane; idx < FftShared<LOG2N>::kTwB; idx += kWave) {
-            const int sA = 31 - __clz(idx / P + 1);          // stage - A: runs start at P*(2^sA - 1)
-            const int k = idx - P * ((1 << sA) - 1);
-            sh.twB[idx] = twiddle[k << (LOG2N - 1 - (A + sA))];
-        }
-    }
-    wave_sync();
-    // n_sym_batch == 1: symbol `sym` of every frame (the tracker's CFO of symbol s comes out of symbol s - 1).
-    // n_sym_batch > 1: symbols sym .. sym + n_sym_batch - 1 of every frame in ONE launch, work item w = s * n_frames + frame,
-    // bins to fq[w] — for the layouts where the CFO is identically zero (no pilots, SYNCED entry, no initial offsets:
-    // launch_demod), whose symbols do not depend on each other here; the CFO phase is then not touched.
-    // frame f starts at audio + f * frame_stride (+ frame_offset[f]: per-stream data start from the acquisition)
-    auto item_base = [&](int w) {
-        const int f = (n_sym_batch > 1) ? w % n_frames : w, ds = (n_sym_batch > 1) ? w / n_frames : 0;
-        return audio + (size_t)f * frame_stride + (frame_offset ? frame_offset[f] : 0u) + (size_t)(sym + ds) * D.sym_len;
-    };
-    const int total = n_frames * n_sym_batch;
-    if ((int)blockIdx.x < total) prefetch_symbol<LOG2N>(sh, D, item_base((int)blockIdx.x));
-    for (int w = blockIdx.x; w < total; w += gridDim.x) {
-        const int frame = (n_sym_batch > 1) ? w % n_frames : w, ds = (n_sym_batch > 1) ? w / n_frames : 0;
-        // CFO and the phase the symbol starts with: words 1 and 3 of the frame's table (cfo_walk_kernel / pilot_walk_kernel,
-        // which have already advanced the tracker to the symbol's END phase); without a table the CFO of every frame of
-        // the launch is zero and the phase does not move (launch_demod)
-        const unsigned* tab = seg_tab ? seg_tab + (size_t)frame * kSegTabWords : nullptr;
-        const float cfo = tab ? __uint_as_float(tab[1]) : 0.0f;
-        float phase = tab ? __uint_as_float(tab[3]) : 0.0f;
-        Stamps stamps;
-        symbol_to_freq<LOG2N>(sh, D, cfo, phase, nco + (size_t)(sym + ds) * D.sym_len, twiddle, fq + (size_t)w * (2 * D.fq_half),
-                              seg_tab ? seg_tab + (size_t)frame * kSegTabWords : nullptr, stamps);
-        const int next = w + (int)gridDim.x;
-        if (next < total) prefetch_symbol<LOG2N>(sh, D, item_base(next));
-        UH_STAMP(10);
-        stamps.store((size_t)w, lane);
-    }
-}
-
-// The same work items as mix_fft_kernel<LOG2N>, 512 points per wavefront (symbol_to_freq2: two wavefronts per frame for
+// One work item = one symbol of one frame, 512 points per wavefront (symbol_to_freq2: two wavefronts per frame for
 // N = 1024, one for N = 512 — the same code minus the joint last stage), software-pipelined: everything item i+1 needs
 // from memory is requested while item i computes.
 // UH_MIX2_WAVES = wavefronts per SIMD the register allocator is told to reach (tools/build_variants.sh builds the others).

@@ -77,10 +77,14 @@ struct ultra_hip_ctx {
     // per-kernel profiling (ultra_hip_profile_*): recorded (class, start, stop) triples + spare events
     uint32_t deint_step = 1;             // ChannelInterleaver step fused into the LDPC LLR load (1 = off)
     uint16_t* d_deint_table = nullptr;   // general gather table of the fused deinterleave (nullptr = use the step)
-    int mix_wg_per_cu = 0;               // ULTRA_HIP_MIX_WG_PER_CU: workgroups per CU of the transform's grid (sweeps; 0 = by batch size)
-    bool mix_one_wave = false;           // ULTRA_HIP_MIXFFT_ONE_WAVE=1: the one-wavefront-per-frame mix_fft_kernel<10> (A/B runs)
+    int mix_wg_per_cu = 0;               // variant builds only (-DUH_AB_SWITCHES, ULTRA_HIP_MIX_WG_PER_CU): workgroups per CU of the transform's grid
     bool stream_cfo_given = false;       // launch_demod: whether the frame in flight started with caller-supplied offsets
-    bool old_chain = false;              // ULTRA_HIP_OLD_CHAIN=1: track_pilot_kernel + track_kernel per symbol for every layout (A/B runs)
+    // ULTRA_HIP_FALLBACK_CHAIN=1: the fall-back kernels for every layout — track_pilot_kernel + track_kernel per symbol instead
+    // of the deferred carrier half and the pair tracker (what launch_demod drops to when the n_sym-fold workspace cannot be
+    // had), and with ULTRA_HIP_LDPC_MESSAGES=1 the message-passing decoder for every rate (what the totals decoder drops to
+    // when its LDS placement is refused).  Both are product paths, so both are held to the same parity tests
+    // (tests/test_gpu_fallbacks.py).
+    bool old_chain = false;
     float* d_ws_trk = nullptr;           // deferred carrier half: one record per (symbol, frame) from track_pilot_kernel to track_all_kernel
     size_t ws_trk_rows = 0;
     bool profiling = false;
@@ -243,20 +247,17 @@ int launch_demod(ultra_hip_ctx* ctx, const float* d_audio, size_t frame_stride, 
     if (deferred && ensure_trk_workspace(ctx, n_frames * (size_t)n_sym) != ULTRA_HIP_OK) { (void)hipGetLastError(); deferred = false; }
     { const int rc_fq = ensure_fq_workspace(ctx, n_frames); if (rc_fq != ULTRA_HIP_OK) return rc_fq; }
     // The transform of symbol `sym` (n_sym_batch symbols from it on) of every frame: 512 points per wavefront, software-
-    // pipelined (mix_fft2_kernel: two wavefronts per frame at N = 1024, one at N = 512), with or without the CFO rotation;
-    // ULTRA_HIP_MIXFFT_ONE_WAVE=1 selects round 2's kernel for A/B runs.
+    // pipelined (mix_fft2_kernel: two wavefronts per frame at N = 1024, one at N = 512), with or without the CFO rotation.
     auto launch_mix = [&](unsigned g, int sym, c32* fq, const unsigned* tab, int n_sym_batch) {
         auto go = [&](auto kernel, unsigned threads) {
             hipLaunchKernelGGL(kernel, dim3(g), dim3(threads), 0, st, ctx->d_demod, ctx->d_nco, ctx->d_twiddle, d_audio, frame_stride,
                                d_frame_offset, (int)n_frames, sym, fq, tab, n_sym_batch);
         };
         if (D.log2_fft == 10) {
-            if (ctx->mix_one_wave) go(dev::mix_fft_kernel<10>, dev::kWave);
-            else if (tab) go(dev::mix_fft2_kernel<10, true>, 2 * dev::kWave);
+            if (tab) go(dev::mix_fft2_kernel<10, true>, 2 * dev::kWave);
             else go(dev::mix_fft2_kernel<10, false>, 2 * dev::kWave);
         } else {
-            if (ctx->mix_one_wave) go(dev::mix_fft_kernel<9>, dev::kWave);
-            else if (tab) go(dev::mix_fft2_kernel<9, true>, dev::kWave);
+            if (tab) go(dev::mix_fft2_kernel<9, true>, dev::kWave);
             else go(dev::mix_fft2_kernel<9, false>, dev::kWave);
         }
     };
@@ -597,10 +598,12 @@ int ultra_hip_create(const ultra_hip_config* cfg, int device, void* stream, ultr
     if (ctx->h_ldpc.edges > kLdpcMaxEdges || ctx->h_ldpc.m > kLdpcMaxChecks) { delete ctx; return ULTRA_HIP_ERR_UNSUPPORTED; }
     rc = build_ldpc_plan(ctx->h_ldpc, ctx->h_plan);
     if (rc != ULTRA_HIP_OK) { delete ctx; return rc; }
-    // ULTRA_HIP_LDPC_MESSAGES=1 keeps the message-passing kernel for every rate (A/B measurements, parity tests of both)
-    { const char* e = std::getenv("ULTRA_HIP_MIXFFT_ONE_WAVE"); ctx->mix_one_wave = (e && e[0] == '1'); }
+    // The two switches the product reads select its own FALL-BACK kernels (see ultra_hip_ctx::old_chain); grid-size sweeps
+    // exist only in variant builds (tools/build_variants.sh).
+#ifdef UH_AB_SWITCHES
     { const char* e = std::getenv("ULTRA_HIP_MIX_WG_PER_CU"); if (e && std::atoi(e) > 0) ctx->mix_wg_per_cu = std::atoi(e); }
-    { const char* e = std::getenv("ULTRA_HIP_OLD_CHAIN"); ctx->old_chain = (e && e[0] == '1'); }
+#endif
+    { const char* e = std::getenv("ULTRA_HIP_FALLBACK_CHAIN"); ctx->old_chain = (e && e[0] == '1'); }
     const char* force_messages = std::getenv("ULTRA_HIP_LDPC_MESSAGES");
     if (!(force_messages && force_messages[0] == '1')) (void)build_ldpc_tplan(ctx->h_ldpc, cfg->code_rate, ctx->h_tplan);
     ctx->h_tplan.max_iterations = ctx->h_ldpc.max_iterations;
@@ -790,6 +793,10 @@ int ultra_hip_demod_stream_set_cfo(ultra_hip_ctx* ctx, size_t frame, float cfo_h
     static_assert(dev::st_cfo == 0 && dev::st_cfo_filt == 1 && dev::st_cfo_phase == 2, "record layout");
     UH_HIP(hipMemcpyAsync(ctx->d_ws_state + frame * (size_t)dev::kStFloats, v, sizeof(v), hipMemcpyHostToDevice, ctx->stream));
     UH_HIP(hipStreamSynchronize(ctx->stream));
+    // From the next symbol on some frame of the batch carries an offset nothing on the path estimated: the short cuts
+    // launch_demod takes for frames that started without one (no phase table on layouts without pilots, the first two
+    // symbols at CFO 0 on layouts with them) no longer hold for the rest of this frame.
+    ctx->stream_cfo_given = true;
     return ULTRA_HIP_OK;
 }
 

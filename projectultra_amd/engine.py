@@ -256,6 +256,11 @@ class ReceiveContext:
                                                     out["ok"].data_ptr()), "ultra_hip_ldpc_decode_blocks")
         return out
 
+    def demod_stream_set_cfo(self, frame: int, cfo_hz: float):
+        """OFDMDemodulator::setFrequencyOffset (demodulator.cpp:805-814) for one frame of the batch in flight, between two
+        demod_stream calls: CFO and filtered CFO = cfo_hz, correction phase 0, from the next symbol on."""
+        check(self.lib.ultra_hip_demod_stream_set_cfo(self._ctx, int(frame), float(cfo_hz)), "ultra_hip_demod_stream_set_cfo")
+
     def demod_decode(self, audio, cfo_hz=None, cfo_phase=None, want_llr: bool = False, out=None):
         """Fused receive path -> dict(bytes, iters, ok[, llr]).  `out` may hand in the result tensors (and, under "llr",
         the [n][llrs_per_frame] destination of the soft bits)."""

@@ -19,6 +19,7 @@ Fixtures
   frames.npz   v2 wire format: soft bits of frames in, RxPipeline::processFrame's result out
   stream.npz   live streams call by call (OFDMDemodulator::process + getSoftBits): the three exits of the SYNCED state
                (frame complete, idle calls, timeout) and re-acquisition; audio rebuilt from fullsync.npz's frames
+  setcfo.npz   SYNCED-entry frames whose offset is replaced by setFrequencyOffset between two process() calls
   fullsync.npz full Schmidl-Cox receive of whole frames (OFDMDemodulator::process fed in 960-sample
                chunks): sync offset, coarse CFO, LLRs, and the data-start offset at which the
                SYNCED-entry loop reproduces those LLRs bit for bit
@@ -284,8 +285,44 @@ def frames():
     np.savez_compressed(OUT / "frames.npz", **d)
 
 
+def setcfo():
+    """OFDMDemodulator::setFrequencyOffset between two process() calls of a SYNCED frame (demodulator.cpp:805-814): frames
+    that started WITHOUT an offset (the case the advisor found unhandled) and with one, on a layout without pilots and on the
+    headline's layout with pilots; the new offset arrives before symbol 1, 2 or 5."""
+    d = {}
+    rs = np.random.default_rng(4242)
+    cases = []
+    for name, fft, mod, rate, kw in (("cfg2_dqpsk_r12", 512, "DQPSK", "R1_2", {}), ("cfg3_qam16_r34", 1024, "QAM16", "R3_4", dict(n_data_symbols=8))):
+        cfg = make_config(fft, mod, rate, **kw)
+        g = geometry(cfg)
+        d[f"{name}__cfg"] = cfg_array(cfg)
+        nsym = g.frame_samples // g.symbol_samples
+        for set_at in (1, 2, 5):
+            for has0 in (0, 1):
+                audio, cfo0, cfon, llrs = [], [], [], []
+                for t in range(3):
+                    nbytes = (g.llrs_per_frame // 648 + 1) * (INFO_BITS[cfg.code_rate] // 8)
+                    payload = bytes(rs.integers(0, 256, nbytes, dtype=np.uint8))
+                    a, pre = r.harness_awgn(cfg, payload, 24, 7000 + t)
+                    shift = float(rs.normal(0, 3.0))
+                    a = r.channel_apply_cfo(a, shift)
+                    x = a[pre: pre + g.frame_samples]
+                    c0 = float(np.float32(shift + rs.normal(0, 1.0)))
+                    cn = float(np.float32(shift + rs.normal(0, 0.3)))
+                    l = r.demod_synced_setcfo(cfg, x, set_at, cn, c0 if has0 else None)
+                    audio.append(x); cfo0.append(c0); cfon.append(cn); llrs.append(l)
+                key = f"{name}__at{set_at}_has{has0}"
+                cases.append(key)
+                d[f"{key}__audio"] = np.stack(audio).astype(np.float32)
+                d[f"{key}__cfo0"] = np.array(cfo0, np.float32)
+                d[f"{key}__cfo_new"] = np.array(cfon, np.float32)
+                d[f"{key}__llr"] = np.stack(llrs)
+    d["cases"] = np.array(cases)
+    np.savez_compressed(OUT / "setcfo.npz", **d)
+
+
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["ldpc", "tables", "demod", "presynced", "fullsync", "sync", "frames", "stream"]
+    which = sys.argv[1:] or ["ldpc", "tables", "demod", "presynced", "fullsync", "sync", "frames", "stream", "setcfo"]
     for name in which:
         globals()[name]()
     for f in sorted(OUT.glob("*.npz")):

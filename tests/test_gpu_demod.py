@@ -695,3 +695,77 @@ def test_demodulator_mirror_live_stream(name):
         assert synced == want[f"{name}__{sc}__synced"].tolist(), (name, sc)
         assert drained == want[f"{name}__{sc}__drained"].tolist(), (name, sc)
         assert beq(np.concatenate(soft).astype(np.float32), want[f"{name}__{sc}__soft"]), (name, sc)
+
+
+def test_headline_batch_whole(oracle):
+    """north_star's 2^20-frame cfg3 batch (Watterson good channel, 30 dB), checked where one launch over a million frames
+    can go wrong and a 16,384-frame prefix cannot show it: the LAST 2,048 frames (tail workgroups of every kernel), 2,048
+    frames straddling byte offset 2^32 of the audio buffer (frame 239,674: 32-bit offset arithmetic fails there), 2,048 drawn
+    over all of it — soft bits bitwise, bytes, iterations, status against the oracle — and the batch's eight counters equal to
+    the sum over four 2^18-frame batches generated separately with first_frame offsets (generators keyed on the global frame
+    index; what a rank's shard of the strong-scaling run computes)."""
+    import torch
+    from projectultra_amd import CodeRate, Modulation, ReceiveContext, presets
+    cfg = make_config(1024, "QAM16", "R3_4")
+    mc = presets.nvis_mode().with_mode(Modulation.QAM16, CodeRate.R3_4)
+    mc.pilot_spacing = 4
+    ctx = ReceiveContext(mc)
+    n = 1 << 20
+    chan = dict(seed=0x5EED, channel="watterson", snr_db=30.0, delay_ms=0.5, doppler_hz=0.1)
+    audio, payload = ctx.make_batch(n, first_frame=0, **chan)
+    assert audio.numel() * 4 > (1 << 32)
+    r = ctx.demod_decode(audio, want_llr=True)
+    counters = ctx.count_errors(r, payload).cpu().numpy()
+    ctx.synchronize()
+    assert counters[0] == n and 0 < counters[1] < n
+
+    edge = (1 << 32) // (audio.shape[1] * 4)
+    rng = np.random.default_rng(20)
+    idx = np.unique(np.concatenate([np.arange(n - 2048, n), np.arange(edge - 1024, edge + 1024), rng.choice(n, 2048, replace=False)]))
+    t_idx = torch.from_numpy(idx).cuda()
+    a = audio[t_idx].cpu().numpy()
+    want = oracle.demod_decode_batch(cfg, a, n_threads=16)
+    _check_llr(r["llr"][t_idx].cpu().numpy(), want["llr"], "2^20 batch, stratified frames")
+    for k in ("bytes", "iters", "ok"):
+        assert np.array_equal(r[k][t_idx].cpu().numpy(), want[k]), k
+    # the device generator's frames at those global indices are the frames a separate call with first_frame makes
+    a2, p2 = ctx.make_batch(2048, first_frame=n - 2048, **chan)
+    assert torch.equal(a2, audio[n - 2048:]) and torch.equal(p2, payload[n - 2048:])
+    del a2, p2
+
+    total = np.zeros(8, np.int64)
+    q = n // 4
+    for part in range(4):
+        pa, pp = ctx.make_batch(q, first_frame=part * q, **chan)
+        assert torch.equal(pa[-64:], audio[(part + 1) * q - 64:(part + 1) * q])
+        pr = ctx.demod_decode(pa)
+        total += ctx.count_errors(pr, pp).cpu().numpy()
+        for k in ("bytes", "iters", "ok"):
+            assert torch.equal(pr[k], r[k][part * q:(part + 1) * q]), (part, k)
+        del pa, pp, pr
+    assert np.array_equal(total, counters), (total, counters)
+
+
+def test_set_cfo_between_stream_calls_golden():
+    """ultra_hip_demod_stream_set_cfo = OFDMDemodulator::setFrequencyOffset between two process() calls
+    (/root/reference/src/ofdm/demodulator.cpp:805-814): the compiled reference's LLRs (tests/golden/setcfo.npz) for frames that
+    started WITHOUT an offset — where the batch runs its zero-offset short cuts until the call — and with one, on a layout
+    without pilots (cfg2) and with pilots (cfg3 layout, 8 symbols), the new offset arriving before symbol 1, 2 or 5."""
+    g = np.load(GOLDEN / "setcfo.npz")
+    for key in g["cases"]:
+        key = str(key)
+        name = key.split("__")[0]
+        cfg = cfg_from_array(g[f"{name}__cfg"])
+        geo = geometry(cfg)
+        set_at = int(key.split("__at")[1].split("_")[0])
+        has0 = key.endswith("has1")
+        audio, cfo0, cfon, want = g[f"{key}__audio"], g[f"{key}__cfo0"], g[f"{key}__cfo_new"], g[f"{key}__llr"]
+        nsym = geo.frame_samples // geo.symbol_samples
+        ctx = context_for(cfg)
+        n = audio.shape[0]
+        first = ctx.demod_stream(np.ascontiguousarray(audio[:, :set_at * geo.symbol_samples]), 0, set_at, cfo_hz=cfo0 if has0 else None)
+        for f in range(n):
+            ctx.demod_stream_set_cfo(f, float(cfon[f]))
+        rest = ctx.demod_stream(np.ascontiguousarray(audio[:, set_at * geo.symbol_samples:]), set_at, nsym - set_at)
+        got = np.concatenate([first.cpu().numpy(), rest.cpu().numpy()], axis=1)
+        _check_llr(got, want, key)

@@ -184,3 +184,22 @@ def test_stream_scenarios_rebuild_deterministically():
         a2, c2 = build_stream(frames, recipe(564, int(g["cfg2_dqpsk_r12__meta"][0][0])))
         assert np.array_equal(a1, a2) and np.array_equal(c1, c2) and int(c1.sum()) == a1.size
         assert c1.size == want[f"cfg2_dqpsk_r12__{sc}__ready"].size
+
+
+def test_bench_starts_its_own_ranks_and_a_failing_rank_fails_the_run():
+    """`python bench.py --gpus 2` without a launcher starts two ranks itself (a child torch.distributed.run, before anything
+    touches the GPU); here no GPU exists, so every rank refuses ("no CPU fallback") — and the run must report that as a
+    failure with nothing on stdout, never as a result for fewer GPUs.  A launcher whose WORLD_SIZE differs from --gpus is
+    refused outright."""
+    import os, subprocess, sys
+    from conftest import ROOT
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    env["HIP_VISIBLE_DEVICES"] = ""            # also on a GPU box this test sees no device
+    p = subprocess.run([sys.executable, str(ROOT / "bench.py"), "--gpus", "2", "--backend", "gloo", "--steps", "1", "--warmup", "0",
+                        "--no-cpu-baseline", "--no-build"], capture_output=True, text=True, timeout=600, env=env)
+    assert p.returncode != 0
+    assert "starting 2 ranks" in p.stderr and "needs a GPU" in p.stderr, p.stderr[-2000:]
+    assert not p.stdout.strip()
+    env.update(RANK="0", LOCAL_RANK="0", WORLD_SIZE="1", MASTER_ADDR="127.0.0.1", MASTER_PORT="29533")
+    p = subprocess.run([sys.executable, str(ROOT / "bench.py"), "--gpus", "4", "--no-build"], capture_output=True, text=True, timeout=600, env=env)
+    assert p.returncode != 0 and "refusing" in p.stderr and not p.stdout.strip()

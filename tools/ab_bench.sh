@@ -2,7 +2,7 @@
 # A/B of library variants on the GPU box: every build/v_*.so (tools/build_variants.sh) and the in-tree library go through
 #   python3 bench.py <bench args> --no-cpu-baseline --no-build      (default args: --config cfg3 --frames 262144)
 # and one line per variant with the step time and the per-kernel mean launch times is printed (and kept in $OUT).
-#   OUT=gpurun_out/ab/x.txt ENVS="ULTRA_HIP_MIXFFT_ONE_WAVE=1" bash tools/ab_bench.sh [bench args]
+#   OUT=gpurun_out/ab/x.txt ENVS="ULTRA_HIP_FALLBACK_CHAIN=1" bash tools/ab_bench.sh [bench args]
 OUT=${OUT:-gpurun_out/ab/ab_$(date +%H%M%S).txt}
 mkdir -p "$(dirname "$OUT")"
 ARGS=${@:---config cfg3 --frames 262144}

@@ -62,13 +62,13 @@ def static_phases(one_wave):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--frames", type=int, default=1 << 17)
-    ap.add_argument("--one-wave", action="store_true")
+    ap.add_argument("--one-wave", action="store_true", help=argparse.SUPPRESS)   # round 2's kernel: removed from the product in round 4
     ap.add_argument("--lib", default=str(ROOT / "build" / "stamps.so"))
     ap.add_argument("--no-static", action="store_true")
     args = ap.parse_args()
     os.environ["ULTRA_HIP_LIB"] = args.lib
     if args.one_wave:
-        os.environ["ULTRA_HIP_MIXFFT_ONE_WAVE"] = "1"
+        raise SystemExit("the one-wavefront transform left the product in round 4 (its stall table: profiles/r03_mix_fft_stalls_one_wave.txt)")
     stat = None
     if not args.no_static:
         stat = static_phases(args.one_wave)              # before anything touches the GPU (starts the compiler)
