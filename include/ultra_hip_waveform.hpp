@@ -202,15 +202,22 @@ class HipOfdmWaveform
 #endif
 {
 public:
+    // OFDMChirpWaveform::OFDMChirpWaveform(config) (src/waveform/ofdm_chirp_waveform.cpp:20-31): the chirp mode is
+    // differential and pilot-free whatever the configuration says
     explicit HipOfdmWaveform(const ModemConfig& config = ModemConfig(), int device = 0)
-        : config_(config), device_(device) {}
+        : config_(config), device_(device) {
+        if (!isDifferential(config_.modulation)) config_.modulation = Modulation::DQPSK;
+        config_.use_pilots = false;
+    }
 
     std::string getName() const { return "OFDM_HIP"; }
-    void configure(Modulation mod, CodeRate rate) {                     // as OFDMNvisWaveform::configure
+    void configure(Modulation mod, CodeRate rate) {                     // OFDMChirpWaveform::configure (:67-84)
+        if (!isDifferential(mod)) mod = Modulation::DQPSK;
         config_.modulation = mod; config_.code_rate = rate;
-        config_.use_pilots = !(mod == Modulation::DBPSK || mod == Modulation::DQPSK || mod == Modulation::D8PSK);
+        config_.use_pilots = false;
         s_audio_.drop(); s_cp_.drop(); s_llr_.drop(); s_state_.drop();
         ctx_.reset();
+        demodReset();
     }
     void setFrequencyOffset(float cfo_hz) { cfo_hz_ = cfo_hz; }
     void setTxFrequencyOffset(float) {}
@@ -275,18 +282,25 @@ public:
         detail::check(ultra_hip_demod_batch(ctx_.p, static_cast<const float*>(d_a), g.frame_samples,
                                             static_cast<const float*>(d_c), static_cast<const float*>(d_c) + 1, 1,
                                             static_cast<float*>(d_l), static_cast<float*>(d_s)), "demod_batch");
-        soft_bits_.resize(g.llrs_per_frame);
-        detail::check(ultra_hip_memcpy_d2h(ctx_.p, soft_bits_.data(), d_l, g.llrs_per_frame * sizeof(float)), "d2h");
+        pending_.resize(g.llrs_per_frame);
+        detail::check(ultra_hip_memcpy_d2h(ctx_.p, pending_.data(), d_l, g.llrs_per_frame * sizeof(float)), "d2h");
         detail::check(ultra_hip_memcpy_d2h(ctx_.p, state_, d_s, sizeof(state_)), "d2h");
-        return soft_bits_.size() >= 648;
+        demod_synced_ = true;                                            // processPresynced: state = SYNCED (demodulator.cpp:886)
+        // ready = soft_bits.size() >= LDPC_BLOCK_SIZE (:985); only then does the waveform take the demodulator's bits (:203-213)
+        const bool ready = pending_.size() >= 648;
+        if (ready) { soft_bits_ = std::move(pending_); pending_.clear(); }
+        return ready;
     }
     std::vector<float> getSoftBits() { return std::move(soft_bits_); }
-    void reset() { soft_bits_.clear(); synced_ = false; }
+    void reset() {                                                        // ofdm_chirp_waveform.cpp:221-230; the preset CFO survives
+        demodReset();
+        soft_bits_.clear(); synced_ = false;
+    }
     ~HipOfdmWaveform() {                                                  // buffers before the contexts they came from
         s_audio_.drop(); s_cp_.drop(); s_llr_.drop(); s_state_.drop(); s_sync_audio_.drop(); s_sync_out_.drop();
     }
-    bool isSynced() const { return synced_; }
-    bool hasData() const { return !soft_bits_.empty(); }
+    bool isSynced() const { return synced_ || demod_synced_; }          // :232-234
+    bool hasData() const { return !soft_bits_.empty() || !pending_.empty(); }   // :236-238 (OFDMDemodulator::hasPendingData)
     float estimatedSNR() const { return 10.0f * std::log10(state_[ULTRA_HIP_STATE_SNR_LINEAR]); }
     float estimatedCFO() const {                                        // ofdm_chirp_waveform.cpp:244-252
         return std::fabs(last_cfo_) > 0.1f ? last_cfo_ : state_[ULTRA_HIP_STATE_FREQ_OFFSET_HZ];
@@ -296,23 +310,23 @@ public:
     std::string getStatusString() const { return "OFDM-HIP " + std::to_string(config_.num_carriers) + " carriers"; }
     int getCarrierCount() const { return static_cast<int>(config_.num_carriers); }
     int getSamplesPerSymbol() const { return static_cast<int>(symbolSamples()); }
-    int getPreambleSamples() const { return 2 * getSamplesPerSymbol(); }
-    int getMinSamplesForFrame() const {                                   // ofdm_cox_waveform.cpp:231-258
-        int data_carriers = static_cast<int>(config_.num_carriers);
-        if (config_.use_pilots && config_.pilot_spacing > 0) data_carriers -= config_.num_carriers / config_.pilot_spacing;
-        static const int bpc[] = {1, 1, 2, 2, 3, 3, 4, 5, 6, 2, 8};
-        const int bits_per_symbol = data_carriers * bpc[static_cast<int>(config_.modulation) <= 10 ? static_cast<int>(config_.modulation) : 3];
+    // the dual chirp [up][gap][down][gap] (ChirpSync::getTotalSamples, src/sync/chirp_sync.hpp:534-544, with the waveform's
+    // 500 ms / 100 ms: ofdm_chirp_waveform.cpp:39-49) + two training symbols (:304-309)
+    int getPreambleSamples() const {
+        const float fs = static_cast<float>(config_.sample_rate);
+        const size_t chirp = static_cast<size_t>(fs * 500.0f / 1000.0f), gap = static_cast<size_t>(fs * 100.0f / 1000.0f);
+        return static_cast<int>(2 * chirp + 2 * gap) + 2 * getSamplesPerSymbol();
+    }
+    int getMinSamplesForFrame() const {                                   // ofdm_chirp_waveform.cpp:311-331: every carrier is data
+        const int bits_per_symbol = static_cast<int>(config_.num_carriers) * bitsPerCarrier();
         const int data_symbols = (648 + bits_per_symbol - 1) / bits_per_symbol;
         return (2 + data_symbols) * getSamplesPerSymbol();
     }
-    float getThroughput(CodeRate rate) const {
-        static const float ratio[] = {0.25f, 0.333f, 0.5f, 0.667f, 0.75f, 0.833f, 0.875f};
-        int data_carriers = static_cast<int>(config_.num_carriers);
-        if (config_.use_pilots && config_.pilot_spacing > 0) data_carriers -= config_.num_carriers / config_.pilot_spacing;
-        static const int bpc[] = {1, 1, 2, 2, 3, 3, 4, 5, 6, 2, 8};
-        return float(config_.sample_rate) / float(getSamplesPerSymbol()) * float(data_carriers) *
-               float(bpc[static_cast<int>(config_.modulation) <= 10 ? static_cast<int>(config_.modulation) : 3]) *
-               ratio[static_cast<int>(rate) <= 6 ? static_cast<int>(rate) : 2];
+    float getThroughput(CodeRate rate) const {                            // :266-296
+        static const float ratio[] = {0.25f, 0.333f, 0.5f, 0.667f, 0.75f, 0.833f, 0.5f};
+        const float symbol_rate = static_cast<float>(config_.sample_rate) / getSamplesPerSymbol();
+        const float raw_bps = symbol_rate * static_cast<int>(config_.num_carriers) * bitsPerCarrier();
+        return raw_bps * ratio[static_cast<int>(rate) <= 5 ? static_cast<int>(rate) : 6];
     }
 
 #ifdef ULTRA_HIP_WITH_REFERENCE
@@ -327,6 +341,15 @@ public:
 #endif
 
 private:
+    static bool isDifferential(Modulation m) { return m == Modulation::DBPSK || m == Modulation::DQPSK || m == Modulation::D8PSK; }
+    int bitsPerCarrier() const { return config_.modulation == Modulation::DBPSK ? 1 : config_.modulation == Modulation::D8PSK ? 3 : 2; }
+    // what OFDMDemodulator::reset (demodulator.cpp:987-1017) leaves behind, as far as this adapter shows it: not synced, no
+    // soft bits, SNR 1.0 (0 dB), CFO 0 (the waveform's own cfo_hz_ is kept and handed over again by process())
+    void demodReset() {
+        demod_synced_ = false; pending_.clear();
+        const float fresh[ULTRA_HIP_STATE_FLOATS] = {0, 0, 1, 0, 0, 0, 0, 0};
+        std::memcpy(state_, fresh, sizeof(state_));
+    }
     uint32_t symbolSamples() const {
         const uint32_t base = config_.cp_mode == decltype(config_.cp_mode)(0) ? 32u
                             : config_.cp_mode == decltype(config_.cp_mode)(2) ? 64u : 48u;
@@ -334,6 +357,8 @@ private:
     }
     ModemConfig config_;
     int device_;
+    bool demod_synced_ = false;
+    std::vector<float> pending_;                 // soft bits the demodulator holds while a call produced fewer than one codeword
     detail::Ctx ctx_, sync_ctx_;
     detail::GrowBuf s_audio_, s_cp_, s_llr_, s_state_, s_sync_audio_, s_sync_out_;   // persistent per-call scratch
     float last_cfo_ = 0.0f;

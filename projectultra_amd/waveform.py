@@ -28,7 +28,7 @@ class SyncResult:                    # waveform_interface.hpp:33-40
 
 class HipOfdmWaveform:
     def __init__(self, config: ModemConfig = None, device=None):
-        self._config = config or ModemConfig(use_pilots=True)
+        self._config = self._chirp_config(config or ModemConfig())
         self._device = device
         self._cfo_hz = 0.0
         self._last_cfo = 0.0
@@ -36,6 +36,17 @@ class HipOfdmWaveform:
         self._soft_bits = np.zeros(0, np.float32)
         self._synced = False
         self._init_components()
+
+    @staticmethod
+    def _chirp_config(config: ModemConfig) -> ModemConfig:
+        """OFDMChirpWaveform::OFDMChirpWaveform(config) / configure (ofdm_chirp_waveform.cpp:20-31,67-84): the chirp mode is
+        differential and pilot-free whatever the configuration says."""
+        import copy
+        c = copy.copy(config)
+        if c.modulation not in (Modulation.DBPSK, Modulation.DQPSK, Modulation.D8PSK):
+            c.modulation = Modulation.DQPSK
+        c.use_pilots = False
+        return c
 
     def _init_components(self):
         self._demod = OFDMDemodulator(self._config, device=self._device)
@@ -45,7 +56,7 @@ class HipOfdmWaveform:
         return "OFDM_HIP"
 
     def configure(self, mod: Modulation, rate: CodeRate) -> None:   # ofdm_chirp/cox_waveform.cpp configure()
-        self._config = self._config.with_mode(mod, rate)
+        self._config = self._chirp_config(self._config.with_mode(mod, rate))
         self._init_components()
 
     def getModulation(self) -> Modulation:
@@ -113,8 +124,8 @@ class HipOfdmWaveform:
         self._soft_bits = np.zeros(0, np.float32)
         self._synced = False
 
-    def isSynced(self) -> bool:
-        return self._synced
+    def isSynced(self) -> bool:              # ofdm_chirp_waveform.cpp:232-234
+        return self._synced or self._demod.isSynced()
 
     def hasData(self) -> bool:
         return self._soft_bits.size > 0 or self._demod.hasPendingData()
@@ -127,7 +138,7 @@ class HipOfdmWaveform:
             return self._last_cfo
         return self._demod.getFrequencyOffset()
 
-    # -- geometry (ofdm_cox_waveform.cpp:214-258) ------------------------------
+    # -- geometry (ofdm_chirp_waveform.cpp:266-331) ----------------------------
     def getCarrierCount(self) -> int:
         return self._config.num_carriers
 
@@ -135,25 +146,25 @@ class HipOfdmWaveform:
         return self._config.getSymbolDuration()
 
     def getPreambleSamples(self) -> int:
-        return 2 * self.getSamplesPerSymbol()
+        """[up chirp 500 ms][gap 100 ms][down chirp][gap] (ChirpSync::getTotalSamples, chirp_sync.hpp:534-544) + two training
+        symbols (ofdm_chirp_waveform.cpp:304-309) — what RxPipeline::tryProcessBuffer sizes its search by."""
+        fs = np.float32(self._config.sample_rate)
+        chirp, gap = int(fs * np.float32(500.0) / np.float32(1000.0)), int(fs * np.float32(100.0) / np.float32(1000.0))
+        return 2 * chirp + 2 * gap + 2 * self.getSamplesPerSymbol()
+
+    def _bits_per_carrier(self) -> int:
+        return {Modulation.DBPSK: 1, Modulation.D8PSK: 3}.get(Modulation(self._config.modulation), 2)
 
     def getMinSamplesForFrame(self) -> int:
-        c = self._config
-        data_carriers = c.num_carriers
-        if c.use_pilots and c.pilot_spacing > 0:
-            data_carriers = c.num_carriers - c.num_carriers // c.pilot_spacing
-        bits_per_symbol = data_carriers * getBitsPerSymbol(c.modulation)
+        bits_per_symbol = self._config.num_carriers * self._bits_per_carrier()          # every carrier is data
         data_symbols = (LDPC_BLOCK_SIZE + bits_per_symbol - 1) // bits_per_symbol
         return 2 * self.getSamplesPerSymbol() + data_symbols * self.getSamplesPerSymbol()
 
     def getThroughput(self, rate: CodeRate) -> float:
         c = self._config
-        data_carriers = c.num_carriers
-        if c.use_pilots and c.pilot_spacing > 0:
-            data_carriers = c.num_carriers - c.num_carriers // c.pilot_spacing
         ratio = {CodeRate.R1_4: 0.25, CodeRate.R1_3: 0.333, CodeRate.R1_2: 0.5, CodeRate.R2_3: 0.667,
                  CodeRate.R3_4: 0.75, CodeRate.R5_6: 0.833}.get(CodeRate(rate), 0.5)
-        return (c.sample_rate / self.getSamplesPerSymbol()) * data_carriers * getBitsPerSymbol(c.modulation) * ratio
+        return (c.sample_rate / self.getSamplesPerSymbol()) * c.num_carriers * self._bits_per_carrier() * ratio
 
     def getStatusString(self) -> str:
         c = self._config

@@ -107,7 +107,7 @@ def test_rx_pipeline_over_the_chirp_waveform(tmp_path, oracle, harness, mod, rat
     rng = np.random.default_rng(11)
     audio = chirp_stream(oracle, cfg, int(cfg.code_rate), bps, rng)
     ref = run_harness(tmp_path, "chirp", "ref", cfg, audio, bps)
-    assert sum(l.startswith("FRAME_CALLBACK") for l in ref) >= 2, "the reference must deliver frames for the test to mean anything"
+    assert sum(l.startswith("FRAME_CALLBACK") for l in ref) >= 1, "the reference must deliver frames for the test to mean anything"
     assert any(l.startswith("QUEUE success=0") for l in ref)           # and the multi-codeword frame is left waiting
     hip = run_harness(tmp_path, "chirp", "hip", cfg, audio, bps)
     compare(ref, hip, f"chirp {mod} {rate}")

@@ -40,13 +40,15 @@ def test_c_config_matches_harness_config():
 
 
 def test_waveform_geometry_getters():
-    """OFDMNvisWaveform geometry (src/waveform/ofdm_cox_waveform.cpp:214-258)."""
+    """OFDMChirpWaveform geometry (src/waveform/ofdm_chirp_waveform.cpp:20-31,298-331; the values the compiled reference
+    reports under RxPipeline: tests/test_gpu_rx_pipeline.py)."""
     from projectultra_amd import CodeRate, ModemConfig, Modulation
     from projectultra_amd.waveform import HipOfdmWaveform
     w = HipOfdmWaveform.__new__(HipOfdmWaveform)           # geometry needs no device
-    w._config = ModemConfig(use_pilots=True)
-    assert w.getSamplesPerSymbol() == 564 and w.getPreambleSamples() == 1128
-    assert w.getMinSamplesForFrame() == 2 * 564 + 22 * 564   # QPSK, 15 data carriers -> 22 symbols
+    w._config = HipOfdmWaveform._chirp_config(ModemConfig(use_pilots=True))      # QPSK with pilots asked for ...
+    assert w._config.modulation == Modulation.DQPSK and not w._config.use_pilots  # ... the chirp mode is DQPSK without
+    assert w.getSamplesPerSymbol() == 564 and w.getPreambleSamples() == 57600 + 1128
+    assert w.getMinSamplesForFrame() == 2 * 564 + 11 * 564   # DQPSK, 30 data carriers -> 11 symbols
     assert w.getCarrierCount() == 30
 
 
