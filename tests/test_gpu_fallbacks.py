@@ -77,3 +77,27 @@ def test_message_decoder_for_the_high_rates(oracle, switch, rate):
     r = d.decode_batch(g[f"dec_llr_r{rate}"])
     assert np.array_equal(r["bytes"], g[f"dec_bytes_r{rate}"]) and np.array_equal(r["ok"], g[f"dec_ok_r{rate}"])
     assert np.array_equal(r["iters"], g[f"dec_iters_r{rate}"])
+
+
+def test_unaligned_rows_and_odd_strides(oracle):
+    """The C-ABI takes any float pointer and any row stride >= the frame: the same frames at row offsets of 0, 1, 2, 3 floats
+    and odd row strides give the same bits (nothing in the transform's asynchronous copies may assume 16-byte alignment)."""
+    import torch
+    from _util import geometry
+    for fft, mod, rate in ((1024, "QAM16", "R3_4"), (512, "DQPSK", "R1_2")):
+        cfg = make_config(fft, mod, rate)
+        g = geometry(cfg)
+        n = 67
+        audio, _ = oracle.make_batch(cfg, n, seed=0xA11C, channel="watterson", snr_db=20.0)
+        want = oracle.demod_decode_batch(cfg, audio, n_threads=8)
+        ctx = context_for(cfg)
+        for shift, pad in ((0, 0), (1, 0), (2, 3), (3, 1), (0, 2), (4, 4)):
+            stride = g.frame_samples + pad
+            big = torch.zeros(n * stride + 8, dtype=torch.float32, device="cuda")
+            rows = big[shift:shift + n * stride].view(n, stride)      # contiguous rows of `stride` floats that start `shift` floats in
+            rows[:, :g.frame_samples].copy_(torch.from_numpy(audio))
+            assert rows.is_contiguous() and rows.data_ptr() == big.data_ptr() + 4 * shift
+            r = ctx.demod_decode(rows, want_llr=True)
+            assert beq(r["llr"].cpu().numpy(), want["llr"]), (mod, shift, pad)
+            for k in ("bytes", "iters", "ok"):
+                assert np.array_equal(r[k].cpu().numpy(), want[k]), (mod, shift, pad, k)

@@ -30,7 +30,7 @@ PHASES = ["table header, wait for the staged audio, read samples", "(stamp pair)
           "last stage + bin store", "phase store + next prefetch issue"]
 
 
-def static_phases(one_wave):
+def static_phases(one_wave, norot=False):
     import issue_model as im
     costs, _ = im.parse_issue_table(ROOT / "profiles" / "r02_issue_table.txt")
     src = ROOT / "projectultra_amd" / "csrc" / "ultra_hip.hip"
@@ -38,7 +38,7 @@ def static_phases(one_wave):
                                    "-fhip-fp32-correctly-rounded-divide-sqrt", "-DUH_MIXFFT_STAMPS"] + os.environ.get("STAMP_FLAGS", "").split() + ["-S", "--cuda-device-only", "-o", "-", str(src)],
                                   stderr=subprocess.DEVNULL, cwd=src.parent).decode()
     fns = im.functions(asm)
-    key = "mix_fft_kernelILi10E" if one_wave else "mix_fft2_kernelILi10ELb1E"
+    key = "mix_fft_kernelILi10E" if one_wave else ("mix_fft2_kernelILi10ELb0E" if norot else "mix_fft2_kernelILi10ELb1E")
     body = next(v for k, v in fns.items() if key in k)
     cuts = [i for i, l in enumerate(body) if "UHSTAMP" in l]
     ids = [int(re.search(r"UHSTAMP (\d+)", body[i]).group(1)) for i in cuts]
@@ -63,6 +63,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--frames", type=int, default=1 << 17)
     ap.add_argument("--one-wave", action="store_true", help=argparse.SUPPRESS)   # round 2's kernel: removed from the product in round 4
+    ap.add_argument("--norot", action="store_true", help="the instance WITHOUT the rotation: stamps of symbol 1's launch (CFO 0 in every frame)")
     ap.add_argument("--lib", default=str(ROOT / "build" / "stamps.so"))
     ap.add_argument("--no-static", action="store_true")
     args = ap.parse_args()
@@ -71,7 +72,7 @@ def main():
         raise SystemExit("the one-wavefront transform left the product in round 4 (its stall table: profiles/r03_mix_fft_stalls_one_wave.txt)")
     stat = None
     if not args.no_static:
-        stat = static_phases(args.one_wave)              # before anything touches the GPU (starts the compiler)
+        stat = static_phases(args.one_wave, args.norot)  # before anything touches the GPU (starts the compiler)
     import numpy as np
     import torch
     from projectultra_amd import CodeRate, Modulation, ReceiveContext, presets, _lib
@@ -90,7 +91,12 @@ def main():
     fn.restype, fn.argtypes = C.c_int, [C.c_void_p, C.c_void_p]
     assert fn(ctx._ctx, buf.data_ptr()) == 0
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    e0.record(); ctx.demod(audio); e1.record()
+    if args.norot:                                   # symbols 0 and 1 only: both launches are the instance without the rotation
+        g = ctx.geometry
+        two = audio[:, :2 * g.symbol_samples].contiguous()
+        e0.record(); ctx.demod_stream(two, 0, 2); e1.record()
+    else:
+        e0.record(); ctx.demod(audio); e1.record()
     torch.cuda.synchronize()
     assert fn(ctx._ctx, None) == 0
     r = buf.cpu().numpy().reshape(n * waves, WORDS).astype(np.uint64)
@@ -107,7 +113,7 @@ def main():
             m = (r[:, 15] & np.uint64(fl)) != 0
             if m.any():
                 print(f"# flag {fl}: {m.mean():.3f} of items, sincos phase mean {d[m, 3].mean():.0f} cycles, item mean {total[m].mean():.0f}", file=sys.stderr)
-    print(f"# {'mix_fft_kernel<10> (one wavefront per frame)' if args.one_wave else 'mix_fft2_kernel<10> (two wavefronts per frame)'}, "
+    print(f"# {'mix_fft_kernel<10> (one wavefront per frame)' if args.one_wave else ('mix_fft2_kernel<10, false> (no rotation; symbols 0 and 1 only)' if args.norot else 'mix_fft2_kernel<10> (two wavefronts per frame)')}, "
           f"{n} frames, stamps of the last data symbol's launch; demodulation of the batch with stamps on: {e0.elapsed_time(e1):.3f} ms")
     # residency: wavefronts working at a time per SIMD
     res, spans = [], []
