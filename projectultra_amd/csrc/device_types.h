@@ -113,7 +113,9 @@ struct LdpcPlan {
 constexpr int kTPlanRowRounds = 4, kTPlanVarRounds = 7, kTPlanDmax = 4;
 struct LdpcTPlan {
     int32_t valid, k, m, n, max_iterations, decoded_bytes, row_rounds, var_rounds, dmax;
-    int32_t t_pad, r_base, r_pad, stage_v, stage_p, lds_bytes, extra_cycles, _pad[2];
+    int32_t t_pad, r_base, r_pad, stage_v, stage_p, lds_bytes, extra_cycles;
+    int32_t n_checked;                                    // variables j < n_checked have checks, n_checked <= j < k have none (validated)
+    int32_t _pad[1];
     uint16_t row_check[kTPlanRowRounds * 64];             // slot -> check index i (parity bit = variable k + i); 0xFFFF: empty
     uint16_t row_taddr[kTPlanRowRounds * 64 * 6];         // byte offset of the T word gathered by edge slot t (t_pad: none)
     uint16_t var_id[kTPlanVarRounds * 64];                // slot -> variable index; 0xFFFF: empty

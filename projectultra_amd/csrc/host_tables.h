@@ -431,6 +431,11 @@ inline int build_ldpc_tplan(const LdpcConst& L, uint32_t rate, LdpcTPlan& P) {
     for (auto& x : P.var_slot_of) x = 0xFFFF;
     for (auto& x : P.row_taddr) x = (uint16_t)P.t_pad;
     for (auto& x : P.var_caddr) x = (uint16_t)P.r_pad;
+    // the information bits without any check are the LAST ones of every code the reference builds (buildMatrix connects the
+    // first 3 m / ... variables): the decoder's output step relies on that split (ldpc_totals_kernel.h), so it is checked
+    P.n_checked = L.k;
+    for (int j = L.k - 1; j >= 0 && L.var_ptr[j + 1] - L.var_ptr[j] == 0; --j) P.n_checked = j;
+    for (int j = 0; j < P.n_checked; ++j) if (L.var_ptr[j + 1] - L.var_ptr[j] == 0) return ULTRA_HIP_ERR_UNSUPPORTED;
     for (int j = 0; j < L.k; ++j) {
         const int d = L.var_ptr[j + 1] - L.var_ptr[j];
         if ((d > 0) != (vs[j] != 0xFFFF)) return ULTRA_HIP_ERR_UNSUPPORTED;

@@ -269,8 +269,22 @@ __global__ __launch_bounds__(kLdpcThreads, WAVES) void ldpc_decode_kernel(
                     __builtin_amdgcn_global_load_lds(src + (unsigned)((j0 + lane) * llr_step) % (unsigned)kLdpcN, llr_s + j0, 4, 0, 0);
         }
     };
+    // Tickets are drawn one codeword ahead of their use (see ldpc_totals_kernel.h): the atomic's round trip runs under a
+    // decode; a ticket beyond the queue's end (the launch's tail) falls back to the synchronous claim().
+    int ticket_v = 0, ticket_queue = queue;
+    auto draw = [&]() {
+        ticket_queue = queue;
+        ticket_v = 0;
+        if (lane == 0) ticket_v = (int)atomicAdd(work_counter + queue * kLdpcQueueStride, 1u);
+    };
+    auto take = [&]() -> int {
+        const int c = __builtin_amdgcn_readfirstlane(ticket_v) * kLdpcQueues + ticket_queue;
+        if (c < n_cw) return c;
+        if (dry >= kLdpcQueues) return -1;
+        return claim();
+    };
     int cw = claim();
-    if (cw >= 0) fetch(cw);
+    if (cw >= 0) { fetch(cw); draw(); }
     while (cw >= 0) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // staged LLRs have landed
         __syncthreads();
@@ -309,8 +323,8 @@ __global__ __launch_bounds__(kLdpcThreads, WAVES) void ldpc_decode_kernel(
             tpar[r] = 0.0f;
         }
         __syncthreads();
-        const int cw_next = claim();                       // llr_s is free from here on
-        if (cw_next >= 0) fetch(cw_next);
+        const int cw_next = take();                        // llr_s is free from here on
+        if (cw_next >= 0) { fetch(cw_next); draw(); }
 
         int it = 0, ok = 0;
         unsigned F = 1u;                                                       // syndrome filter of iteration it-1

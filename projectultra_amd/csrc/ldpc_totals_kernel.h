@@ -29,6 +29,22 @@
 namespace ultra_hip {
 namespace dev {
 
+// Diagnostic build only (-DUH_LDPC_STAMPS, tools/ldpc_stalls.py): shader-clock time of one codeword split over the phases of
+// the loop below, summed over its iterations — record of kLdpcStampWords 64-bit words per codeword: [0] start, [1] end,
+// [2] LLRs landed + staged (wait for the asynchronous copy, first totals), [3] row phases (gathers of totals, parity
+// verdict, check step, c2v stores issued), [4] drain behind the row phase, [5] variable phases (gathers of c2v, sums,
+// totals stored), [6] drain behind the variable phase, [7] outputs, [8] iterations executed, [9] HW_ID | XCC_ID << 32.
+// Every stamp is an s_memtime whose result is waited for (lgkmcnt), i.e. each phase ends with its LDS operations
+// complete; the product build contains none of this.
+constexpr int kLdpcStampWords = 10;
+#ifdef UH_LDPC_STAMPS
+__device__ unsigned long long* g_ldpc_stamps = nullptr;
+#define UH_LD_NOW() __builtin_readcyclecounter()
+#define UH_LD_ACC(k) do { const unsigned long long now_ = UH_LD_NOW(); ld_acc[k] += now_ - ld_t; ld_t = now_; asm volatile("; UHLDSTAMP %0" ::"n"(k)); } while (0)
+#else
+#define UH_LD_ACC(k) do {} while (0)
+#endif
+
 // RR row rounds, VR variable rounds, D = largest variable degree (LdpcTPlan).  WAVES: wavefronts per SIMD the register
 // budget is sized for.  WANT_TOTAL: also write the final a-posteriori LLRs (parity tests).
 // The totals kernel names its LDS planes by immediate offsets behind M0 = 0 (ds_write_addtid_b32), i.e. it assumes that a
@@ -60,7 +76,7 @@ __global__ __launch_bounds__(kLdpcThreads, WAVES) void ldpc_totals_kernel(
     // otherwise make the compiler reload them from the plan inside the iteration loop.
     constexpr unsigned T_PAD = VR * 256, R_BASE = T_PAD + 128, R_PAD = R_BASE + RR * 6 * 256, STAGE_V = R_PAD + 128,
                        STAGE_P = STAGE_V + VR * 256;
-    const int k = P.k, max_iterations = P.max_iterations, decoded_bytes = P.decoded_bytes;
+    const int k = P.k, max_iterations = P.max_iterations, decoded_bytes = P.decoded_bytes, n_checked = P.n_checked;
     auto ldsf = [&](unsigned byte_off) -> float& { return *reinterpret_cast<float*>(lds_raw + byte_off); };
     const unsigned lds_base = (unsigned)(size_t)lds_raw;
     // lane-linear store: word (plane_byte_off / 4 + lane) <- x, no address register (ds_write_addtid_b32: 2 LDS cycles)
@@ -140,9 +156,31 @@ __global__ __launch_bounds__(kLdpcThreads, WAVES) void ldpc_totals_kernel(
     // it elsewhere, refuse to run rather than store to the wrong words.
     if (lds_base != 0u) { if (blockIdx.x == 0 && lane == 0 && n_cw > 0) { iters[0] = -1; okv[0] = 0; } return; }
 
+    // Tickets are drawn ONE CODEWORD AHEAD of their use: the atomic's round trip (~2,000 cycles at the head of every codeword
+    // in profiles/r04_ldpc_stalls_before.txt) then runs under a decode instead of in front of one.  draw() leaves the ticket
+    // in lane 0's register without waiting for it; take() turns it into a codeword of the queue it was drawn from, or — the
+    // queue has run dry: the launch's tail — falls back to the synchronous claim(), which moves on to the other queues.
+    int ticket_v = 0, ticket_queue = queue;
+    auto draw = [&]() {
+        ticket_queue = queue;
+        ticket_v = 0;
+        if (lane == 0) ticket_v = (int)atomicAdd(work_counter + queue * kLdpcQueueStride, 1u);
+    };
+    auto take = [&]() -> int {
+        const int c = __builtin_amdgcn_readfirstlane(ticket_v) * kLdpcQueues + ticket_queue;
+        if (c < n_cw) return c;
+        if (dry >= kLdpcQueues) return -1;
+        return claim();             // counts the dry queue again at worst: `dry` only has to reach kLdpcQueues eventually
+    };
     int cw = claim();
-    if (cw >= 0) fetch(cw);
+    if (cw >= 0) { fetch(cw); draw(); }
     while (cw >= 0) {
+#ifdef UH_LDPC_STAMPS
+        unsigned long long ld_acc[8] = {};
+        unsigned long long ld_t = UH_LD_NOW();
+        const unsigned long long ld_t0 = ld_t;
+        int ld_iters = 0;
+#endif
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // staged LLRs have landed
         __syncthreads();
         float llr_v[VR], llr_p[RR], c2v[RR][7];
@@ -158,11 +196,12 @@ __global__ __launch_bounds__(kLdpcThreads, WAVES) void ldpc_totals_kernel(
             for (int t = 0; t < 7; ++t) c2v[r][t] = 0.0f;                      // check_to_var starts at 0 (:175)
         }
         __syncthreads();
-        const int cw_next = claim();                                          // the staging planes are free from here on
-        if (cw_next >= 0) fetch(cw_next);
+        const int cw_next = take();                                           // the staging planes are free from here on
+        if (cw_next >= 0) { fetch(cw_next); draw(); }
 
         int it = 0, ok = 0;
         float tpar[RR];                                                        // total of the row's parity bit (WANT_TOTAL)
+        UH_LD_ACC(2);
         for (;;) {
             // ---- row phase: gather totals; parity equations of the previous iteration; check step ----
             const float cap = (it == 0) ? kFltMax : 50.0f;                    // clamp deferred to the reader, see ldpc_kernel.h
@@ -210,9 +249,14 @@ __global__ __launch_bounds__(kLdpcThreads, WAVES) void ldpc_totals_kernel(
                                 "n"(R_BASE + (r * 6 + 3) * 256), "n"(R_BASE + (r * 6 + 4) * 256), "n"(R_BASE + (r * 6 + 5) * 256)
                              : "m0", "memory");
             });
+            UH_LD_ACC(3);
+#ifdef UH_LDPC_STAMPS
+            ++ld_iters;
+#endif
             if (all_hold) { ok = 1; if (it > 0) --it; break; }                 // checkParity passed after iteration it - 1 (or holds at 0)
             if (it >= max_iterations) break;
             __syncthreads();                  // one wavefront per workgroup: an LDS drain (measured: no cost against leaving it out)
+            UH_LD_ACC(4);
             // ---- variable phase: total = llr_in + sum of the check messages in ascending check order (:206-213) ----
             float tots[VR];
             {
@@ -254,29 +298,53 @@ __global__ __launch_bounds__(kLdpcThreads, WAVES) void ldpc_totals_kernel(
                                  :: "v"(tots[0]), "v"(tots[1]), "v"(tots[2]), "v"(tots[3]), "v"(tots[VR > 4 ? 4 : 0]), "v"(tots[VR > 5 ? 5 : 0]),
                                     "v"(tots[VR > 6 ? 6 : 0]) : "m0", "memory");
             }
+            UH_LD_ACC(5);
             __syncthreads();
+            UH_LD_ACC(6);
             ++it;
         }
         const int iters_out = ok ? it : max_iterations;
         __syncthreads();
 
         // ---- outputs: hard decisions of the k information bits packed MSB-first (:238-258) ----
-        // Totals of the checked variables are in T (those of the last completed iteration — the row phase does not
-        // touch T); an unchecked variable's total is its channel LLR, read again from memory.
+        // Totals of the checked variables (j < n_checked) are in T (those of the last completed iteration — the row phase does
+        // not touch T); an unchecked variable's total is its channel LLR, read again from memory.  ONE memory round trip: the
+        // eight slot words of the lane's byte and the channel values of its unchecked bits are independent loads issued
+        // together (which bits are unchecked is a property of the index, LdpcTPlan::n_checked), then the eight LDS reads.
+        // (Round 3's loop took the bits one at a time — slot word, wait, LDS or memory read, wait — 9,300 cycles per codeword
+        // in the stamps of profiles/r04_ldpc_stalls_before.txt, as long as thirteen iterations.)
         const float* src = llr + llr_row(cw) * llr_stride;
         uint8_t* ob = bytes + (size_t)cw * decoded_bytes;
         for (int b = lane; b < decoded_bytes; b += kLdpcThreads) {
+            unsigned sl[8];
+            float ch[8];
+            // every load unconditional, at an address that is valid for every lane (a load under a lane mask ends in a wait of
+            // its own): bits that are not of the kind read word 0 of the table / element `lane` of the row and drop the value
+#pragma unroll
+            for (int t = 0; t < 8; ++t) {
+                const int j = 8 * b + t;
+                sl[t] = (unsigned)P.var_slot_of[(j < n_checked) ? j : 0];
+            }
+            unsigned idx[8];
+            if (llr_perm) {                                                       // wave-uniform: one branch around all eight
+#pragma unroll
+                for (int t = 0; t < 8; ++t) idx[t] = (unsigned)llr_perm[min(8 * b + t, kLdpcN - 1)];
+            } else {
+#pragma unroll
+                for (int t = 0; t < 8; ++t) idx[t] = (unsigned)(min(8 * b + t, kLdpcN - 1) * llr_step) % (unsigned)kLdpcN;
+            }
+#pragma unroll
+            for (int t = 0; t < 8; ++t) {
+                const int j = 8 * b + t;
+                ch[t] = src[(j >= n_checked && j < k) ? idx[t] : (unsigned)lane];
+            }
             unsigned v = 0;
 #pragma unroll
             for (int t = 0; t < 8; ++t) {
                 const int j = 8 * b + t;
-                unsigned bit = 0;
-                if (j < k) {
-                    const unsigned sl = P.var_slot_of[j];
-                    const float tot = (sl != 0xFFFFu) ? ldsf(sl * 4u) : src[src_index(j)];
-                    bit = (tot < 0) ? 1u : 0u;
-                }
-                v = (v << 1) | bit;
+                const float in_t = ldsf(((j < n_checked) ? sl[t] : 0u) * 4u);
+                const float tot = (j < n_checked) ? in_t : ((j < k) ? ch[t] : 0.0f);      // beyond k: bit 0
+                v = (v << 1) | ((tot < 0) ? 1u : 0u);
             }
             ob[b] = (uint8_t)v;
         }
@@ -294,6 +362,18 @@ __global__ __launch_bounds__(kLdpcThreads, WAVES) void ldpc_totals_kernel(
             }
         }
         if (lane == 0) { iters[cw] = iters_out; okv[cw] = (uint8_t)ok; }
+#ifdef UH_LDPC_STAMPS
+        UH_LD_ACC(7);
+        if (g_ldpc_stamps != nullptr && lane == 0) {
+            unsigned hw, xcc;
+            asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
+            asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+            unsigned long long* r = g_ldpc_stamps + (size_t)cw * kLdpcStampWords;
+            r[0] = ld_t0; r[1] = ld_t;
+            for (int q = 2; q < 8; ++q) r[q] = ld_acc[q];
+            r[8] = (unsigned long long)ld_iters; r[9] = ((unsigned long long)xcc << 32) | hw;
+        }
+#endif
         __syncthreads();                                                       // T is rewritten by the next codeword
         cw = cw_next;
     }

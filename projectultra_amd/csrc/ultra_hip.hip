@@ -545,6 +545,16 @@ int ultra_hip_debug_set_stamps(ultra_hip_ctx* ctx, void* d_buf) {
 }
 #endif
 
+#ifdef UH_LDPC_STAMPS
+// diagnostic build only (tools/ldpc_stalls.py): where ldpc_totals_kernel leaves its per-codeword phase times
+int ultra_hip_debug_set_ldpc_stamps(ultra_hip_ctx* ctx, void* d_buf) {
+    if (!ctx) return ULTRA_HIP_ERR_INVALID_ARG;
+    DeviceGuard guard(ctx->device);
+    unsigned long long* p = static_cast<unsigned long long*>(d_buf);
+    return hipMemcpyToSymbol(HIP_SYMBOL(ultra_hip::dev::g_ldpc_stamps), &p, sizeof(p)) == hipSuccess ? ULTRA_HIP_OK : ULTRA_HIP_ERR_HIP;
+}
+#endif
+
 const char* ultra_hip_strerror(int status) {
     switch (status) {
         case ULTRA_HIP_OK: return "ok";
