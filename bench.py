@@ -77,6 +77,9 @@ def parse():
                     help="cfg2/cfg3: trials per step over ALL GPUs, sharded contiguously (STRONG scaling). cfg3 defaults to "
                          "2^20 — north_star's batch at 1, 2, 4 and 8 GPUs — unless --frames is given")
     ap.add_argument("--snr-db", type=float, default=None, help="cfg2/cfg3/raw: channel SNR (default 30 dB cfg3/raw, 3 dB cfg2)")
+    ap.add_argument("--raw-channel", choices=("awgn", "watterson"), default="awgn",
+                    help="raw: channel of the streams — AWGN (the decoder has nothing to do at 30 dB) or the headline's Watterson "
+                         "good channel (0.5 ms / 0.1 Hz) over the transmission")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample", type=int, default=0, help="trials for the CPU baseline (0 = auto)")
     ap.add_argument("--backend", choices=("nccl", "gloo"), default="nccl",
@@ -331,7 +334,7 @@ class RawWorkload(ModemWorkload):
         mc = presets.nvis_mode().with_mode(Modulation.QAM16, CodeRate.R3_4)
         mc.pilot_spacing = 4
         self.n = args.frames or (1 << 16)
-        self.channel, self.snr_db = "awgn", 30.0 if args.snr_db is None else args.snr_db
+        self.channel, self.snr_db = args.raw_channel, 30.0 if args.snr_db is None else args.snr_db
         self.metric = "OFDM-1024 16QAM R3/4 raw-audio streams received/sec (acquisition + demodulation + decode)"
         self.unit = "streams/s"
         self.oracle_cfg = (1024, "QAM16", "R3_4")
@@ -357,7 +360,8 @@ class RawWorkload(ModemWorkload):
                            "ldpc_decode_kernel": 648 * 4 + g.decoded_bytes + 4 + 1}
         self.launch_units = self.n
         self.data = (f"synthetic ({self.n} distinct raw streams per GPU generated on the device in HBM: {self.lead} samples of "
-                     f"noise, preamble, 4 data symbols, {self.tail} samples of noise; AWGN {self.snr_db:g} dB)")
+                     f"noise, preamble, 4 data symbols, {self.tail} samples of noise; "
+                     f"{'AWGN' if self.channel == 'awgn' else 'Watterson good channel (0.5 ms / 0.1 Hz) over the transmission,'} {self.snr_db:g} dB)")
         self.workload = (f"OFDM 1024-FFT 16QAM R3/4 from raw audio ({self.n_samples} samples per stream, fed in 960-sample "
                          f"chunks): Schmidl-Cox acquisition + demodulation + LDPC decode, {self.n} streams per GPU per step")
         self.parallelism = f"streams sharded over {world} GPU(s), one counter all-reduce per step"
@@ -369,28 +373,38 @@ class RawWorkload(ModemWorkload):
         allreduce(self.counters)
 
     def cpu_baseline(self, cores, sample):
-        from oracle.bindings import make_config, oracle
+        """The whole receive of a raw stream on the host: the compiled reference's OFDMDemodulator::process fed 960 samples per
+        call (search, sync, SYNCED demodulation) + LDPCDecoder::decodeSoft of the first 648 soft bits, one stream per worker
+        thread at a time (kind "reference"); beside it the oracle port's acquisition alone (98 % of the reference's time on
+        this path).  Best of three; every stream of the sample compared with the device's result."""
+        import concurrent.futures as cf
+        from oracle.bindings import have_ref, make_config, oracle, Ref
         ccfg = make_config(*self.oracle_cfg)
         cores = min(cores, 32)                   # see pick_threads: more runnable threads than the container's share thrash
         self.cores_used = cores
-        sample = sample or min(self.n, 16 * cores)
+        sample = sample or min(self.n, 64 * cores)
         audio = self.d_audio[:sample].cpu().numpy()
         o = oracle()
-        import concurrent.futures as cf
+        got = {k: v[:sample].cpu().numpy() for k, v in self.out.items()}
 
-        def one(a):
-            acq = o.acquire(ccfg, a, chunk=960)
-            return acq
-        def run():
+        def run_port():
             with cf.ThreadPoolExecutor(cores) as ex:
-                return list(ex.map(one, audio))
-        t, acq = best_of(run, runs=1)
-        got = self.out["entry"][:sample].cpu().numpy()
+                return list(ex.map(lambda a: o.acquire(ccfg, a, chunk=960), audio))
+        t, acq = best_of(run_port, runs=3)
         want = np.array([a["data_start"] if a["found"] else -1 for a in acq], np.int64)
         res = {"port": dict(value=sample / t, unit="streams/s", cores=cores, kind="port", seconds=t,
                             note="acquisition only (98 % of the reference's CPU time on this path); the post-sync part is the cfg3 line",
-                            gpu_matches_bitwise=bool(np.array_equal(np.where(got < 0, -1, got), want)))}
-        return res, f"first {sample} raw streams of the same batch, Schmidl-Cox acquisition"
+                            gpu_matches_bitwise=bool(np.array_equal(np.where(got["entry"] < 0, -1, got["entry"]), want)))}
+        if have_ref():
+            ref = Ref()
+            t, rr = best_of(lambda: ref.receive_batch_mt(ccfg, audio, cores, chunk=960), runs=3)
+            lost = got["entry"] < 0
+            same = bool(np.array_equal(lost, rr["found"] == 0) and all(np.array_equal(got[k][~lost], rr[k][~lost]) for k in ("bytes", "iters", "ok")))
+            res["reference"] = dict(value=sample / t, unit="streams/s", cores=cores, kind="reference", seconds=t,
+                                    note="OFDMDemodulator::process in 960-sample chunks + LDPCDecoder::decodeSoft per stream",
+                                    gpu_matches_bitwise=bool(same))
+        return res, (f"first {sample} raw streams of the same batch (copied from the device): the compiled reference's whole receive, "
+                     f"best of 3; the oracle port's acquisition beside it")
 
 
 class LdpcSweepWorkload:

@@ -33,7 +33,7 @@
 extern "C" {
 #endif
 
-#define ULTRA_HIP_ABI_VERSION 5
+#define ULTRA_HIP_ABI_VERSION 6
 
 /* ultra::Modulation (include/ultra/types.hpp:27-39) — same numeric values. */
 enum ultra_hip_modulation {
@@ -464,6 +464,13 @@ int ultra_hip_channel_cfo_batch(ultra_hip_ctx* ctx, const float* d_in, size_t in
 int ultra_hip_make_raw_batch(ultra_hip_ctx* ctx, uint64_t seed, uint64_t first_frame, size_t n_streams, int channel_kind,
                              float snr_db, uint32_t lead, uint32_t tail, float* d_audio, size_t stream_stride,
                              uint8_t* d_payload);
+/* ... through a channel with parameters: channel_kind 2 = WattersonChannel::process (src/sim/hf_channel.hpp:106-168,258-275;
+ * delay_ms / doppler_hz as in ultra_hip_make_batch: two paths, gains 0.707 / 0.707, fading restarted per stream) over the
+ * TRANSMISSION (preamble + data symbols: the channel sees what ultra_hip_make_batch's sees, so a stream's frame fades like
+ * that batch's frame), its noise on every sample of the stream; kinds 0 and 1 as above (delay_ms, doppler_hz unused). */
+int ultra_hip_make_raw_batch_channel(ultra_hip_ctx* ctx, uint64_t seed, uint64_t first_frame, size_t n_streams, int channel_kind,
+                                     float snr_db, float delay_ms, float doppler_hz, uint32_t lead, uint32_t tail, float* d_audio,
+                                     size_t stream_stride, uint8_t* d_payload);
 
 /* LDPC-only stimulus on the device (BASELINE.json configs[3]: "LDPC R1/4 ... SNR sweep -11..+30 dB"):
  * codewords first_cw .. first_cw + n_cw - 1 of the context's code rate as BPSK over AWGN, handed to the decoder as

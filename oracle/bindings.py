@@ -516,6 +516,20 @@ class Ref(_Base):
         assert rc == 0
         return dict(bytes=by, iters=it, ok=ok)
 
+    def receive_batch_mt(self, cfg, audio, n_threads, chunk=960):
+        """Raw streams [n][n_samples] -> the reference's whole receive per stream (fresh demodulator, `chunk` samples per
+        process() call, decodeSoft of the first 648 soft bits) -> dict(bytes, iters, ok, found, sync_offset)."""
+        audio = _f32(audio)
+        g = geometry(cfg)
+        n, stride = audio.shape
+        by = np.zeros((n, g.decoded_bytes), np.uint8); it = np.zeros(n, np.int32); ok = np.zeros(n, np.uint8)
+        found = np.zeros(n, np.uint8); so = np.zeros(n, np.uint32)
+        rc = self.lib.ref_receive_batch_mt(C.byref(cfg), _ptr(audio), C.c_size_t(stride), C.c_uint32(stride), C.c_uint32(chunk),
+                                           C.c_uint32(n), C.c_int(n_threads), _ptr(by, C.c_uint8), C.c_uint32(g.decoded_bytes),
+                                           _ptr(it, C.c_int32), _ptr(ok, C.c_uint8), _ptr(found, C.c_uint8), _ptr(so, C.c_uint32))
+        assert rc == 0
+        return dict(bytes=by, iters=it, ok=ok, found=found, sync_offset=so)
+
     def demod_synced_public(self, cfg, audio, cfo_hz=0.0):
         audio = _f32(audio)
         g = geometry(cfg)

@@ -270,6 +270,51 @@ int ref_demod_process(const ultra_hip_config* c, const float* audio, uint32_t n,
     return (int)sb.size();
 }
 
+// The whole receive of a batch of raw streams on worker threads: per stream a FRESH OFDMDemodulator fed `chunk` samples per
+// process() call (search, sync, SYNCED demodulation: src/ofdm/demodulator.cpp:461-760) and LDPCDecoder::decodeSoft of the
+// first 648 soft bits — the reference's CPU path for bench.py's raw-audio line.  found[f] = 0 (and cleared results) where
+// the stream produced fewer than 648 soft bits.
+int ref_receive_batch_mt(const ultra_hip_config* c, const float* audio, size_t stream_stride, uint32_t n_samples, uint32_t chunk,
+                         uint32_t n_streams, int n_threads, uint8_t* bytes_out, uint32_t bytes_per_frame, int32_t* iters_out,
+                         uint8_t* ok_out, uint8_t* found_out, uint32_t* sync_offset_out) {
+    StderrMute mute;                                   // once, around all threads (it redirects the process's fd 2)
+    const LogLevel saved_level = g_log_level;
+    setLogLevel(LogLevel::WARN);                       // as the reference's harnesses do before they run trials
+    if (n_threads < 1) n_threads = 1;
+    std::vector<std::thread> th;
+    std::vector<int> rc((size_t)n_threads, 0);
+    for (int t = 0; t < n_threads; ++t) {
+        const uint32_t n0 = (uint32_t)((uint64_t)n_streams * t / n_threads), n1 = (uint32_t)((uint64_t)n_streams * (t + 1) / n_threads);
+        th.emplace_back([=, &rc] {
+            ModemConfig cfg = to_cfg(c);
+            LDPCDecoder dec(cfg.code_rate);
+            dec.setMaxIterations((int)c->max_iterations);
+            for (uint32_t f = n0; f < n1; ++f) {
+                const float* a = audio + (size_t)f * stream_stride;
+                OFDMDemodulator demod(cfg);
+                for (uint32_t i = 0; i < n_samples; i += chunk) demod.process(SampleSpan(a + i, std::min(chunk, n_samples - i)));
+                auto& sb = demod.impl_->soft_bits;
+                if (sync_offset_out) sync_offset_out[f] = (uint32_t)demod.getLastSyncOffset();
+                if (sb.size() < 648) {
+                    found_out[f] = 0; ok_out[f] = 0; iters_out[f] = 0;
+                    std::memset(bytes_out + (size_t)f * bytes_per_frame, 0, bytes_per_frame);
+                    continue;
+                }
+                Bytes r = dec.decodeSoft(std::span<const float>(sb.data(), 648));
+                if (r.size() != bytes_per_frame) { rc[(size_t)t] = -1; return; }
+                std::memcpy(bytes_out + (size_t)f * bytes_per_frame, r.data(), r.size());
+                iters_out[f] = dec.lastIterations();
+                ok_out[f] = dec.lastDecodeSuccess() ? 1 : 0;
+                found_out[f] = 1;
+            }
+        });
+    }
+    for (auto& x : th) x.join();
+    setLogLevel(saved_level);
+    for (int v : rc) if (v) return v;
+    return 0;
+}
+
 // As ref_demod_process, and additionally recovers the COARSE CFO the search stage set on
 // the sync transition (demodulator.cpp:533-537).  getFrequencyOffset() after the run is the
 // tracked value; the coarse one is a pure function of the buffered audio at the moment of

@@ -17,7 +17,7 @@ PKG_DIR = Path(__file__).resolve().parent
 LIB_PATH = Path(os.environ["ULTRA_HIP_LIB"]).resolve() if os.environ.get("ULTRA_HIP_LIB") else PKG_DIR / "libultra_hip.so"
 CSRC_DIR = PKG_DIR / "csrc"
 
-ULTRA_HIP_ABI_VERSION = 5
+ULTRA_HIP_ABI_VERSION = 6
 STATE_FLOATS = 8
 
 
@@ -87,6 +87,8 @@ PROTOTYPES = {
     "ultra_hip_receive_batch": (_i, [_vp, _vp, _sz, C.c_uint32, C.c_uint32, _sz, _vp, _vp, _vp, _vp, _vp, _vp]),
     "ultra_hip_make_batch": (_i, [_vp, C.c_uint64, C.c_uint64, _sz, _i, C.c_float, C.c_float, C.c_float, _vp, _sz, _vp]),
     "ultra_hip_make_raw_batch": (_i, [_vp, C.c_uint64, C.c_uint64, _sz, _i, C.c_float, C.c_uint32, C.c_uint32, _vp, _sz, _vp]),
+    "ultra_hip_make_raw_batch_channel": (_i, [_vp, C.c_uint64, C.c_uint64, _sz, _i, C.c_float, C.c_float, C.c_float, C.c_uint32, C.c_uint32,
+                                              _vp, _sz, _vp]),
     "ultra_hip_make_llr_batch": (_i, [_vp, C.c_uint64, C.c_uint64, _sz, C.c_float, _vp, _vp]),
     "ultra_hip_set_deinterleave": (_i, [_vp, C.c_uint32]),
     "ultra_hip_set_deinterleave_table": (_i, [_vp, _vp, C.c_uint32]),

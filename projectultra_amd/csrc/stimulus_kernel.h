@@ -402,10 +402,14 @@ __global__ __launch_bounds__(kWave) void channel_kernel(
 // The whole signal is scaled to a 0.5 peak and AWGN at snr_db relative to the mean power of preamble + modulator
 // output is added to EVERY sample of the stream (kind 1; kind 0: scaling only) — the harness of
 // tools/test_nvis_mode.cpp:62-86 with silence around the transmission.
+// kind 2: the Watterson channel of channel_kernel over the transmission (same keys, same chunk-parallel fading filters: the
+// frame of stream f fades exactly like frame f of ultra_hip_make_batch), its noise on every sample of the stream.
 __global__ __launch_bounds__(kWave) void raw_stream_kernel(
-    const DemodConst* __restrict__ Dp, int kind, float snr_db, unsigned long long seed, unsigned long long f0, int n_frames,
+    const DemodConst* __restrict__ Dp, int kind, float snr_db, int delay_samples, float fading_alpha, float g1, float g2,
+    unsigned long long seed, unsigned long long f0, int n_frames,
     int lead, int pre_len, int tail, int total_len, const float* __restrict__ preamble, const float* __restrict__ pre_stats,
     const float* __restrict__ fstats, float* __restrict__ audio, size_t stream_stride) {
+    extern __shared__ float s_tx[];                           // kind 2: the scaled transmission (the delayed tap reads it)
     const DemodConst& D = *Dp;
     const int lane = threadIdx.x;
     const int frame_len = D.frame_samples;
@@ -417,6 +421,56 @@ __global__ __launch_bounds__(kWave) void raw_stream_kernel(
         const float mx = fmaxf(pre_stats[0], fstats[2 * (size_t)frame]);
         const float scale = 0.5f / mx;
         const float power = (pre_stats[1] + fstats[2 * (size_t)frame + 1]) * scale * scale / (float)total_len;
+        if (kind == 2) {
+            const int T = pre_len + frame_len;
+            for (int i = lane; i < T; i += kWave) s_tx[i] = ((i < pre_len) ? preamble[i] : a[lead + i]) * scale;
+            wave_sync();
+            const int C = (T + kWave - 1) / kWave;
+            const float al = fading_alpha, dec = 1.0f - al, gain = al * sqrtf(1.0f / al);
+            const int lo = lane * C, hi = (lo + C < T) ? lo + C : T;
+            c32 p1 = mk(0.0f, 0.0f), p2 = mk(0.0f, 0.0f);
+            float decay = 1.0f;
+            for (int i = lo; i < hi; ++i) {
+                float a0, a1, b0, b1;
+                gauss_pair(key ^ 0x1111ull, (unsigned long long)i, &a0, &a1);
+                gauss_pair(key ^ 0x2222ull, (unsigned long long)i, &b0, &b1);
+                p1 = mk(dec * p1.re + gain * a0, dec * p1.im + gain * a1);
+                p2 = mk(dec * p2.re + gain * b0, dec * p2.im + gain * b1);
+                decay *= dec;
+            }
+            c32 s1 = mk(1.0f, 0.0f), s2 = mk(1.0f, 0.0f);
+            c32 my1 = s1, my2 = s2;
+            for (int l = 0; l < kWave; ++l) {
+                if (lane == l) { my1 = s1; my2 = s2; }
+                const float dl = lane_f(decay, l);
+                const c32 q1 = mk(lane_f(p1.re, l), lane_f(p1.im, l)), q2 = mk(lane_f(p2.re, l), lane_f(p2.im, l));
+                s1 = mk(dl * s1.re + q1.re, dl * s1.im + q1.im);
+                s2 = mk(dl * s2.re + q2.re, dl * s2.im + q2.im);
+            }
+            const float eff_noise = sqrtf(power) * powf(10.0f, -snr_db / 20.0f);
+            c32 c1 = my1, c2 = my2;
+            for (int i = lo; i < hi; ++i) {
+                float a0, a1, b0, b1;
+                gauss_pair(key ^ 0x1111ull, (unsigned long long)i, &a0, &a1);
+                gauss_pair(key ^ 0x2222ull, (unsigned long long)i, &b0, &b1);
+                c1 = mk(dec * c1.re + gain * a0, dec * c1.im + gain * a1);
+                c2 = mk(dec * c2.re + gain * b0, dec * c2.im + gain * b1);
+                const float h1 = sqrtf(c1.re * c1.re + c1.im * c1.im), h2 = sqrtf(c2.re * c2.re + c2.im * c2.im);
+                const int d = i - delay_samples - 1;
+                float o = (delay_samples > 0) ? s_tx[i] * g1 * h1 + ((d >= 0) ? s_tx[d] : 0.0f) * g2 * h2 : s_tx[i] * h1;
+                float n0, n1;
+                gauss_pair(key ^ 0x3333ull, (unsigned long long)i, &n0, &n1);
+                a[lead + i] = o + eff_noise * n0;
+            }
+            // the silence around the transmission carries the channel's noise alone
+            for (int i = lane; i < lead + tail; i += kWave) {
+                float n0, n1;
+                gauss_pair(key ^ 0x4444ull, (unsigned long long)i, &n0, &n1);
+                a[(i < lead) ? i : T + i] = eff_noise * n0;
+            }
+            wave_sync();
+            continue;
+        }
         const float nstd = (kind == 1) ? sqrtf(power / powf(10.0f, snr_db / 10.0f)) : 0.0f;
         for (int i = lane; i < n_out; i += 2 * kWave) {
             float n0 = 0.0f, n1 = 0.0f;

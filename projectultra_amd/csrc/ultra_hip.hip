@@ -1098,15 +1098,26 @@ int ultra_hip_channel_cfo_batch(ultra_hip_ctx* ctx, const float* d_in, size_t in
 int ultra_hip_make_raw_batch(ultra_hip_ctx* ctx, uint64_t seed, uint64_t first_frame, size_t n_streams, int channel_kind,
                              float snr_db, uint32_t lead, uint32_t tail, float* d_audio, size_t stream_stride,
                              uint8_t* d_payload) {
+    if (channel_kind < 0 || channel_kind > 1) return ULTRA_HIP_ERR_INVALID_ARG;
+    return ultra_hip_make_raw_batch_channel(ctx, seed, first_frame, n_streams, channel_kind, snr_db, 0.0f, 0.0f, lead, tail, d_audio,
+                                            stream_stride, d_payload);
+}
+
+int ultra_hip_make_raw_batch_channel(ultra_hip_ctx* ctx, uint64_t seed, uint64_t first_frame, size_t n_streams, int channel_kind,
+                                     float snr_db, float delay_ms, float doppler_hz, uint32_t lead, uint32_t tail, float* d_audio,
+                                     size_t stream_stride, uint8_t* d_payload) {
     if (!ctx) return ULTRA_HIP_ERR_INVALID_ARG;
     if (n_streams == 0) return ULTRA_HIP_OK;
     if (ctx->cfg.entry != ULTRA_ENTRY_SYNCED) return ULTRA_HIP_ERR_UNSUPPORTED;
     const DemodConst& D = ctx->h_demod;
     const int psl = D.fft + D.cp;
     const size_t n_out = (size_t)lead + (size_t)7 * psl + ctx->geo.frame_samples + tail;
-    if (!d_audio || !d_payload || stream_stride < n_out || channel_kind < 0 || channel_kind > 1 || n_streams > 0x7fffffffull ||
+    if (!d_audio || !d_payload || stream_stride < n_out || channel_kind < 0 || channel_kind > 2 || n_streams > 0x7fffffffull ||
         n_out > 0x3fffffffull)
         return ULTRA_HIP_ERR_INVALID_ARG;
+    // Watterson: the scaled transmission (preamble + data symbols) sits in LDS for the delayed tap
+    const size_t raw_lds = (channel_kind == 2) ? ((size_t)7 * psl + ctx->geo.frame_samples) * sizeof(float) : 0;
+    if (raw_lds > 64 * 1024 || (channel_kind == 2 && !(doppler_hz > 0.0f && delay_ms >= 0.0f))) return ULTRA_HIP_ERR_UNSUPPORTED;
     DeviceGuard guard(ctx->device);
     { const int rc = stimulus_tables(ctx); if (rc != ULTRA_HIP_OK) return rc; }
     // the modulator's data symbols land where the stream has them: behind the lead and the preamble
@@ -1114,7 +1125,11 @@ int ultra_hip_make_raw_batch(ultra_hip_ctx* ctx, uint64_t seed, uint64_t first_f
       if (rc != ULTRA_HIP_OK) return rc; }
     const unsigned grid = (unsigned)std::min(n_streams, (size_t)ctx->cu_count * 32);
     const int total_len = ctx->stim_pre_len + ctx->stim_tx_symbols * D.sym_len;
-    hipLaunchKernelGGL(dev::raw_stream_kernel, dim3(grid), dim3(dev::kWave), 0, ctx->stream, ctx->d_demod, channel_kind, snr_db,
+    const float fs = (float)ctx->cfg.sample_rate;                           // the channel's constants as in ultra_hip_make_batch
+    const int delay_samples = (int)(size_t)(delay_ms * fs / 1000.0f);
+    const float fading_alpha = (float)(1.0 - std::exp((double)-2.0f * M_PI * (double)(doppler_hz / fs)));
+    hipLaunchKernelGGL(dev::raw_stream_kernel, dim3(grid), dim3(dev::kWave), raw_lds, ctx->stream, ctx->d_demod, channel_kind, snr_db,
+                       delay_samples, fading_alpha, 0.707f, 0.707f,
                        (unsigned long long)seed, (unsigned long long)first_frame, (int)n_streams, (int)lead, ctx->stim_pre_len,
                        (int)tail, total_len, ctx->d_preamble, ctx->d_preamble + 7 * psl, ctx->d_ws_fstats, d_audio, stream_stride);
     UH_HIP(hipGetLastError());

@@ -470,19 +470,21 @@ class ReceiveContext:
         return out
 
     def make_raw_batch(self, n_streams: int, seed: int = 0x5EED, first_frame: int = 0, channel: str = "awgn",
-                       snr_db: float = 30.0, lead: int = 1120, tail: int = 960):
+                       snr_db: float = 30.0, lead: int = 1120, tail: int = 960, delay_ms: float = 0.5, doppler_hz: float = 0.1):
         """Raw-audio streams for receive(): [lead silence][preamble][data symbols][tail silence], 0.5 peak, AWGN on every
-        sample (ultra_hip_make_raw_batch).  Returns (audio [n][lead + preamble + frame_samples + tail], payload)."""
+        sample or ("watterson") the transmission through the two-path fading channel of make_batch with its noise on every
+        sample (ultra_hip_make_raw_batch_channel).  Returns (audio [n][lead + preamble + frame_samples + tail], payload)."""
         torch = _torch()
         self._check_stream()
         g = self.geometry
         n_out = lead + 7 * (self.config.fft_size + g.cp_len) + g.frame_samples + tail
         audio = torch.empty((n_streams, n_out), dtype=torch.float32, device=self.device)
         payload = torch.empty((n_streams, g.ldpc_k // 8), dtype=torch.uint8, device=self.device)
-        kind = dict(none=0, awgn=1)[channel]
-        check(self.lib.ultra_hip_make_raw_batch(self._ctx, int(seed), int(first_frame), n_streams, kind, float(snr_db), int(lead),
-                                                int(tail), audio.data_ptr(), self._row_stride(audio), payload.data_ptr()),
-              "ultra_hip_make_raw_batch")
+        kind = dict(none=0, awgn=1, watterson=2)[channel]
+        check(self.lib.ultra_hip_make_raw_batch_channel(self._ctx, int(seed), int(first_frame), n_streams, kind, float(snr_db),
+                                                        float(delay_ms), float(doppler_hz), int(lead), int(tail), audio.data_ptr(),
+                                                        self._row_stride(audio), payload.data_ptr()),
+              "ultra_hip_make_raw_batch_channel")
         return audio, payload
 
     def make_llr_batch(self, n_cw: int, esn0_db: float, seed: int = 0x5EED, first_cw: int = 0, out=None):

@@ -194,3 +194,36 @@ def test_channel_cfo_is_bit_identical_to_the_reference_model(oracle, cfo_hz):
         ctx.synchronize()
         w = oracle.demod_decode_batch(cfg, want, n_threads=8, want_llr=True, want_state=True, decode=False)
         assert beq(llr.cpu().numpy(), w["llr"]) and beq(state.cpu().numpy(), w["state"])
+
+
+def test_raw_watterson_streams_carry_the_batch_generators_frames():
+    """ultra_hip_make_raw_batch_channel(kind 2): the transmission of stream f goes through the SAME channel realisation as
+    frame f of ultra_hip_make_batch (same keys, same filters), so the frame part of the raw stream equals that batch's frame
+    bit for bit; lead and tail hold noise of the channel's level only; and the whole receive (acquisition -> demodulation ->
+    decode) of those streams equals the oracle's on the same samples."""
+    import torch
+    from _util import context_for, make_config
+    from oracle.bindings import oracle as get_oracle
+    cfg = make_config(1024, "QAM16", "R3_4")
+    ctx = context_for(cfg)
+    g = ctx.geometry
+    n, lead, tail = 96, 1120, 960
+    raw, pay_raw = ctx.make_raw_batch(n, seed=0xFADE, first_frame=40, channel="watterson", snr_db=24.0, lead=lead, tail=tail)
+    frames, pay = ctx.make_batch(n, seed=0xFADE, first_frame=40, channel="watterson", snr_db=24.0, delay_ms=0.5, doppler_hz=0.1)
+    pre = raw.shape[1] - lead - tail - g.frame_samples
+    assert torch.equal(pay_raw, pay)
+    assert torch.equal(raw[:, lead + pre:lead + pre + g.frame_samples], frames)
+    silence = torch.cat([raw[:, :lead], raw[:, lead + pre + g.frame_samples:]], dim=1)
+    tx = raw[:, lead:lead + pre + g.frame_samples]
+    ratio = (tx.pow(2).mean() / silence.pow(2).mean()).item()
+    assert 10 ** 2.0 < ratio < 10 ** 2.8, ratio                  # 24 dB below the transmission's power, give or take the fading
+    r = ctx.receive(raw, chunk=960, want_llr=True)
+    o = get_oracle()
+    a = raw.cpu().numpy()
+    entry = r["entry"].cpu().numpy()
+    assert (entry >= 0).mean() > 0.9
+    for f in range(0, n, 7):
+        acq = o.acquire(cfg, a[f], chunk=960)
+        assert (entry[f] >= 0) == bool(acq["found"])
+        if acq["found"]:
+            assert entry[f] == acq["data_start"]
