@@ -110,11 +110,17 @@ struct LdpcPlan {
 //   R words      [r_base, r_base + row_rounds * 6 * 256)   word ((round * 6 + t) * 64 + lane) = edge slot t of the row
 //   R pad words  32 at r_pad (one per bank): -0.0f (the neutral addend of a variable with fewer than dmax edges)
 //   staging      stage_v [var_rounds][64], stage_p [row_rounds][64]: channel LLRs of the NEXT codeword, slot-indexed
-constexpr int kTPlanRowRounds = 4, kTPlanVarRounds = 7, kTPlanDmax = 4;
+constexpr int kTPlanRowRounds = 8, kTPlanVarRounds = 7, kTPlanDmax = 13;
 struct LdpcTPlan {
     int32_t valid, k, m, n, max_iterations, decoded_bytes, row_rounds, var_rounds, dmax;
     int32_t t_pad, r_base, r_pad, stage_v, stage_p, lds_bytes, extra_cycles;
     int32_t n_checked;                                    // variables j < n_checked have checks, n_checked <= j < k have none (validated)
+    int32_t n_planes;                                     // R planes: sum of the row profile
+    // Degree profiles, four bits per round (ldpc_prof): row_prof round r = S_r, the information-edge slots of its rows (the
+    // R planes of round r are plane_base[r] .. plane_base[r] + S_r - 1); var_prof round r = D_r, the edges of its variables.
+    // The regular codes (R2/3, R3/4, R5/6: ldpc_totals_kernel.h) have S_r = 6 and D_r = dmax throughout.
+    uint64_t row_prof, var_prof;
+    int32_t plane_base[kTPlanRowRounds + 1];
     int32_t _pad[1];
     uint16_t row_check[kTPlanRowRounds * 64];             // slot -> check index i (parity bit = variable k + i); 0xFFFF: empty
     uint16_t row_taddr[kTPlanRowRounds * 64 * 6];         // byte offset of the T word gathered by edge slot t (t_pad: none)

@@ -21,8 +21,12 @@
 #include "device_types.h"
 #ifndef ULTRA_LDPC_NO_PLACEMENT
 #include "ldpc_placement.h"
+#include "ldpc_placement_low.h"
 #else       // tools/ldpc_place.cpp, which GENERATES that header, compiles without it
-namespace ultra_hip { inline bool ldpc_placement(uint32_t, const uint16_t**, int*, const uint16_t**, int*) { return false; } }
+namespace ultra_hip {
+inline bool ldpc_placement(uint32_t, const uint16_t**, int*, const uint16_t**, int*) { return false; }
+inline bool ldpc_placement_low(uint32_t, const uint16_t**, int*, const uint16_t**, int*, unsigned long long*, unsigned long long*) { return false; }
+}
 #endif
 
 namespace ultra_hip {
@@ -415,7 +419,10 @@ inline int build_ldpc_tplan(const LdpcConst& L, uint32_t rate, LdpcTPlan& P) {
     P = LdpcTPlan{};
     const uint16_t *vs = nullptr, *rs = nullptr;
     int nv = 0, nr = 0;
-    if (!ldpc_placement(rate, &vs, &nv, &rs, &nr) || nv != L.k || nr != L.m) return ULTRA_HIP_ERR_UNSUPPORTED;
+    unsigned long long want_rprof = 0, want_vprof = 0;       // low-rate codes: the profiles the placement (and the kernel instance) was made for
+    if (!(ldpc_placement(rate, &vs, &nv, &rs, &nr) || ldpc_placement_low(rate, &vs, &nv, &rs, &nr, &want_rprof, &want_vprof)) || nv != L.k ||
+        nr != L.m)
+        return ULTRA_HIP_ERR_UNSUPPORTED;
     int na = 0, dmax = 0;
     for (int j = 0; j < L.k; ++j) { const int d = L.var_ptr[j + 1] - L.var_ptr[j]; if (d > 0) ++na; dmax = std::max(dmax, d); }
     const int VR = (na + 63) / 64, RR = (L.m + 63) / 64;
@@ -423,8 +430,23 @@ inline int build_ldpc_tplan(const LdpcConst& L, uint32_t rate, LdpcTPlan& P) {
     for (int j = L.k; j < L.n; ++j) if (L.var_ptr[j + 1] - L.var_ptr[j] != 1) return ULTRA_HIP_ERR_UNSUPPORTED;
     P.k = L.k; P.m = L.m; P.n = L.n; P.max_iterations = L.max_iterations; P.decoded_bytes = L.decoded_bytes;
     P.row_rounds = RR; P.var_rounds = VR; P.dmax = dmax;
+    // Degree profiles of the placement: S[r] = the most information edges a row of round r has, D[r] = the most edges a
+    // variable of round r has.  The regular codes' kernel (ldpc_totals_kernel.h) runs six slots in every row round whatever
+    // the rows hold, so their S is 6 by definition (R2/3 has one row of four).
+    int S[kTPlanRowRounds] = {0}, Dv[kTPlanVarRounds] = {0};
+    for (int i = 0; i < L.m; ++i) { if (rs[i] >= RR * 64) return ULTRA_HIP_ERR_UNSUPPORTED; S[rs[i] / 64] = std::max(S[rs[i] / 64], L.row_ptr[i + 1] - L.row_ptr[i] - 1); }
+    for (int j = 0; j < L.k; ++j) { if (vs[j] == 0xFFFF) continue; if (vs[j] >= VR * 64) return ULTRA_HIP_ERR_UNSUPPORTED; Dv[vs[j] / 64] = std::max(Dv[vs[j] / 64], L.var_ptr[j + 1] - L.var_ptr[j]); }
+    if (want_rprof == 0) { for (int r = 0; r < RR; ++r) S[r] = 6; for (int r = 0; r < VR; ++r) Dv[r] = dmax; }
+    else {      // the instance's profile must cover what the placement put into each round (it may have slack)
+        for (int r = 0; r < RR; ++r) { const int w = (int)((want_rprof >> (4 * r)) & 15ull); if (w < S[r]) return ULTRA_HIP_ERR_UNSUPPORTED; S[r] = w; }
+        for (int r = 0; r < VR; ++r) { const int w = (int)((want_vprof >> (4 * r)) & 15ull); if (w < Dv[r]) return ULTRA_HIP_ERR_UNSUPPORTED; Dv[r] = w; }
+    }
+    P.row_prof = 0; P.var_prof = 0; P.plane_base[0] = 0;
+    for (int r = 0; r < RR; ++r) { if (S[r] < 1 || S[r] > 6) return ULTRA_HIP_ERR_UNSUPPORTED; P.row_prof |= (uint64_t)S[r] << (4 * r); P.plane_base[r + 1] = P.plane_base[r] + S[r]; }
+    for (int r = 0; r < VR; ++r) { if (Dv[r] < 1 || Dv[r] > 15) return ULTRA_HIP_ERR_UNSUPPORTED; P.var_prof |= (uint64_t)Dv[r] << (4 * r); }
+    P.n_planes = P.plane_base[RR];
     // pads: 32 words each (one per bank), so that a pad read can sit in a bank the instruction's real reads leave free
-    P.t_pad = VR * 256; P.r_base = P.t_pad + 128; P.r_pad = P.r_base + RR * 6 * 256; P.stage_v = P.r_pad + 128;
+    P.t_pad = VR * 256; P.r_base = P.t_pad + 128; P.r_pad = P.r_base + P.n_planes * 256; P.stage_v = P.r_pad + 128;
     P.stage_p = P.stage_v + VR * 256; P.lds_bytes = P.stage_p + RR * 256;
     for (auto& x : P.row_check) x = 0xFFFF;
     for (auto& x : P.var_id) x = 0xFFFF;
@@ -446,7 +468,7 @@ inline int build_ldpc_tplan(const LdpcConst& L, uint32_t rate, LdpcTPlan& P) {
     for (int i = 0; i < L.m; ++i) {
         const int d = L.row_ptr[i + 1] - L.row_ptr[i];
         if (d < 2 || d > 7 || L.col[L.row_ptr[i + 1] - 1] != L.k + i) return ULTRA_HIP_ERR_UNSUPPORTED;
-        if (rs[i] >= RR * 64 || P.row_check[rs[i]] != 0xFFFF) return ULTRA_HIP_ERR_UNSUPPORTED;
+        if (rs[i] >= RR * 64 || P.row_check[rs[i]] != 0xFFFF || d - 1 > S[rs[i] / 64]) return ULTRA_HIP_ERR_UNSUPPORTED;
         P.row_check[rs[i]] = (uint16_t)i;
     }
     // row side: per half-wave a six-edge-colouring of rows x variable banks
@@ -458,12 +480,12 @@ inline int build_ldpc_tplan(const LdpcConst& L, uint32_t rate, LdpcTPlan& P) {
         for (size_t li = 0; li < rows_g.size(); ++li)
             for (int e = L.row_ptr[rows_g[li]]; e + 1 < L.row_ptr[rows_g[li] + 1]; ++e) {
                 const int b = vs[L.col[e]] % 32;
-                if (++cell[b] > 6) return ULTRA_HIP_ERR_UNSUPPORTED;
+                if (++cell[b] > S[g / 2]) return ULTRA_HIP_ERR_UNSUPPORTED;
                 ed.push_back({(int)li, b}); eid.push_back(e);
             }
         std::vector<int> colour;
-        bipartite_edge_colouring((int)rows_g.size(), 32, ed, 6, colour);
-        for (size_t x = 0; x < ed.size(); ++x) { if (colour[x] < 0 || colour[x] >= 6) return ULTRA_HIP_ERR_UNSUPPORTED; slot_t[eid[x]] = colour[x]; }
+        bipartite_edge_colouring((int)rows_g.size(), 32, ed, S[g / 2], colour);
+        for (size_t x = 0; x < ed.size(); ++x) { if (colour[x] < 0 || colour[x] >= S[g / 2]) return ULTRA_HIP_ERR_UNSUPPORTED; slot_t[eid[x]] = colour[x]; }
     }
     std::vector<int> layer(2 * VR * dmax * 32, 0);
     for (int i = 0; i < L.m; ++i)
@@ -473,7 +495,8 @@ inline int build_ldpc_tplan(const LdpcConst& L, uint32_t rate, LdpcTPlan& P) {
             for (int x = L.var_ptr[j]; x < L.var_ptr[j + 1]; ++x) if (L.var_edge[x] == e) q = x - L.var_ptr[j];
             if (q < 0 || t < 0) return ULTRA_HIP_ERR_UNSUPPORTED;
             P.row_taddr[rsl * 6 + t] = (uint16_t)(vsl * 4);
-            P.var_caddr[vsl * kTPlanDmax + q] = (uint16_t)(P.r_base + (((rsl / 64) * 6 + t) * 64 + rsl % 64) * 4);
+            if (q >= Dv[vsl / 64]) return ULTRA_HIP_ERR_UNSUPPORTED;
+            P.var_caddr[vsl * kTPlanDmax + q] = (uint16_t)(P.r_base + ((P.plane_base[rsl / 64] + t) * 64 + rsl % 64) * 4);
             layer[((vsl / 32) * dmax + q) * 32 + rsl % 32]++;
         }
     for (int hq = 0; hq < 2 * VR * dmax; ++hq) { int mx = 1; for (int u = 0; u < 32; ++u) mx = std::max(mx, layer[hq * 32 + u]); P.extra_cycles += mx - 1; }

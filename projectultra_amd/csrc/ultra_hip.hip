@@ -21,6 +21,7 @@
 #include "demod_kernel.h"
 #include "ldpc_kernel.h"
 #include "ldpc_totals_kernel.h"
+#include "ldpc_totals_prof_kernel.h"
 #include "acquire_kernel.h"
 #include "stimulus_kernel.h"
 #include "chirp_kernel.h"
@@ -379,7 +380,7 @@ int launch_ldpc(ultra_hip_ctx* ctx, const float* d_llr, size_t llr_stride, size_
         const LdpcTPlan& T = ctx->h_tplan;
         const size_t tlds = (size_t)T.lds_bytes;
         // the kernel derives its LDS offsets from its template arguments with the builder's formulas
-        if (T.t_pad != T.var_rounds * 256 || T.r_base != T.t_pad + 128 || T.r_pad != T.r_base + T.row_rounds * 6 * 256 ||
+        if (T.t_pad != T.var_rounds * 256 || T.r_base != T.t_pad + 128 || T.r_pad != T.r_base + T.n_planes * 256 ||
             T.stage_v != T.r_pad + 128 || T.stage_p != T.stage_v + T.var_rounds * 256 || T.lds_bytes != T.stage_p + T.row_rounds * 256)
             return ULTRA_HIP_ERR_UNSUPPORTED;
 #define UH_TOTALS_LAUNCH(RR, VR, D, WV)                                                                           \
@@ -396,13 +397,35 @@ int launch_ldpc(ultra_hip_ctx* ctx, const float* d_llr, size_t llr_stride, size_
                                ctx->stream, ctx->d_tplan, d_llr, llr_stride, (int)n_cw, d_bytes, d_iters, d_ok,   \
                                d_llr_total, counter, (int)ctx->deint_step, ctx->d_deint_table, block_len, block_stride);                                       \
     } while (0)
+        // the codes with irregular rows: the profile-templated twin (ldpc_totals_prof_kernel.h), one instance per placement
+#define UH_TOTALS_PROF_LAUNCH(RR, VR, RP, VP, WV)                                                                 \
+    do {                                                                                                          \
+        LaunchSpan span(ctx, ULTRA_HIP_K_LDPC);                                                                   \
+        const size_t per_cu = std::max<size_t>(1, std::min<size_t>(4 * (WV), (size_t)(160 * 1024) / tlds));       \
+        const unsigned grid = (unsigned)std::min(n_cw, (size_t)ctx->cu_count * per_cu);                           \
+        if (d_llr_total)                                                                                          \
+            hipLaunchKernelGGL((dev::ldpc_totals_prof_kernel<RR, VR, RP, VP, true, WV>), dim3(grid), dim3(dev::kLdpcThreads), tlds, \
+                               ctx->stream, ctx->d_tplan, d_llr, llr_stride, (int)n_cw, d_bytes, d_iters, d_ok,   \
+                               d_llr_total, counter, (int)ctx->deint_step, ctx->d_deint_table, block_len, block_stride); \
+        else                                                                                                      \
+            hipLaunchKernelGGL((dev::ldpc_totals_prof_kernel<RR, VR, RP, VP, false, WV>), dim3(grid), dim3(dev::kLdpcThreads), tlds, \
+                               ctx->stream, ctx->d_tplan, d_llr, llr_stride, (int)n_cw, d_bytes, d_iters, d_ok,   \
+                               d_llr_total, counter, (int)ctx->deint_step, ctx->d_deint_table, block_len, block_stride); \
+    } while (0)
         bool launched = true;
-        if (T.row_rounds == 3 && T.var_rounds == 6 && T.dmax == 3) UH_TOTALS_LAUNCH(3, 6, 3, 5);                  // R3/4
+        if (T.row_rounds == 8 && T.var_rounds == 3 && T.row_prof == kPlaceRowProf_R1_4 && T.var_prof == kPlaceVarProf_R1_4)
+            UH_TOTALS_PROF_LAUNCH(8, 3, kPlaceRowProf_R1_4, kPlaceVarProf_R1_4, 3);                                // R1/4
+        else if (T.row_rounds == 6 && T.var_rounds == 6 && T.row_prof == kPlaceRowProf_R1_3 && T.var_prof == kPlaceVarProf_R1_3)
+            UH_TOTALS_PROF_LAUNCH(6, 6, kPlaceRowProf_R1_3, kPlaceVarProf_R1_3, 4);                                // R1/3
+        else if (T.row_rounds == 6 && T.var_rounds == 6 && T.row_prof == kPlaceRowProf_R1_2 && T.var_prof == kPlaceVarProf_R1_2)
+            UH_TOTALS_PROF_LAUNCH(6, 6, kPlaceRowProf_R1_2, kPlaceVarProf_R1_2, 4);                                // R1/2
+        else if (T.row_rounds == 3 && T.var_rounds == 6 && T.dmax == 3) UH_TOTALS_LAUNCH(3, 6, 3, 5);             // R3/4
         else if (T.row_rounds == 2 && T.var_rounds == 4 && T.dmax == 3) UH_TOTALS_LAUNCH(2, 4, 3, 6);             // R5/6
         else if (T.row_rounds == 4 && T.var_rounds == 7 && T.dmax == 3) UH_TOTALS_LAUNCH(4, 7, 3, 4);             // R2/3
         else if (T.row_rounds == 4 && T.var_rounds == 7 && T.dmax == 4) UH_TOTALS_LAUNCH(4, 7, 4, 4);
         else launched = false;
 #undef UH_TOTALS_LAUNCH
+#undef UH_TOTALS_PROF_LAUNCH
         if (launched) { UH_HIP(hipGetLastError()); return ULTRA_HIP_OK; }
     }
     const size_t lds = dev::ldpc_lds_bytes(P.msg_words);

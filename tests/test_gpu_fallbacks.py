@@ -3,8 +3,8 @@
 libultra_hip.so reads two environment switches at ultra_hip_create (ultra_hip.hip, ultra_hip_ctx::old_chain):
   ULTRA_HIP_FALLBACK_CHAIN=1   per-symbol track_pilot_kernel + track_kernel for every layout — what launch_demod drops to
                                when the n_sym-fold workspace of the deferred carrier half cannot be had — and no pair tracker
-  ULTRA_HIP_LDPC_MESSAGES=1    the message-passing decoder for every rate — what the totals decoder drops to when its LDS
-                               placement is refused (R2/3, R3/4, R5/6 otherwise never run it)
+  ULTRA_HIP_LDPC_MESSAGES=1    the message-passing decoder for every rate — what the totals decoders drop to when their LDS
+                               placement is refused (no code runs it otherwise since round 4)
 Each is a second product path; nothing else in tests/ reaches them for the layouts the fast kernels cover."""
 import os
 
@@ -58,11 +58,13 @@ def test_fallback_chain_golden_and_synthetic(oracle, switch):
 
 
 @pytest.mark.parametrize("switch", ["ULTRA_HIP_LDPC_MESSAGES"], indirect=True)
-@pytest.mark.parametrize("rate", [3, 4, 5])
-def test_message_decoder_for_the_high_rates(oracle, switch, rate):
-    """R2/3, R3/4, R5/6 on the message-passing kernel: waterfall mix, non-finite inputs, the golden reference cases."""
+@pytest.mark.parametrize("rate", [0, 1, 2, 3, 4, 5])
+def test_message_decoder_for_every_rate(oracle, switch, rate):
+    """All six codes on the message-passing kernel (since round 4 every code normally runs a totals kernel, so this switch is
+    the only way to it): waterfall mix, non-finite inputs, the golden reference cases."""
     from projectultra_amd import CodeRate, LDPCDecoder
-    sig = {3: [0.45, 0.6, 0.75, 0.9], 4: [0.4, 0.5, 0.6, 0.75], 5: [0.3, 0.4, 0.5, 0.6]}[rate]
+    sig = {0: [0.9, 1.3, 1.7, 2.2], 1: [0.6, 0.8, 1.0, 1.3], 2: [0.6, 0.8, 1.0, 1.3], 3: [0.45, 0.6, 0.75, 0.9], 4: [0.4, 0.5, 0.6, 0.75],
+           5: [0.3, 0.4, 0.5, 0.6]}[rate]
     llr, _ = noisy_codewords(oracle, rate, 768, sig, seed=300 + rate)
     d = LDPCDecoder(CodeRate(rate))
     r = d.decode_batch(llr, want_total=True)

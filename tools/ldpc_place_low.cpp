@@ -1,0 +1,164 @@
+// tools/ldpc_place_low.cpp — offline placement solver for the totals LDPC kernel on the three LOW-RATE codes (R1/4, R1/3,
+// R1/2): tools/ldpc_place.cpp generalised to irregular rows and variables (csrc/ldpc_totals_prof_kernel.h).
+//
+// Rows have 1..6 information edges and variables 4..13 (src/fec/ldpc_decoder.cpp:64-137 builds H = [H_data | I] with a fixed
+// column weight per code and whatever row weights the mt19937 draws give).  The kernel runs round r of its row phase with
+// S_r edge slots and round r of its variable phase with D_r, compile-time profiles; so
+//   * rows are sorted by degree into rounds (S_r = the largest degree of round r), variables likewise (D_r), and a move may
+//     only put a row / variable into a round whose profile covers its degree;
+//   C1  for every row half-wave G of round r and every LDS bank b at most S_r edges lead from G's rows to variables of bank
+//       b (then the rows x banks multigraph of G has maximum degree S_r and an S_r-edge-colouring assigns the gather slots);
+//   C2  for every variable half-wave H and every edge rank q (ascending check order) the q-th rows of H's variables sit at
+//       32 distinct positions (row lane mod 32).
+// Simulated annealing over both sides, as in ldpc_place.cpp; C1 must reach 0, residual C2 collisions cost LDS cycles.
+//
+//   g++ -O2 -std=c++17 -Iprojectultra_amd/csrc tools/ldpc_place_low.cpp -o /tmp/ldpc_place_low && /tmp/ldpc_place_low > projectultra_amd/csrc/ldpc_placement_low.h
+#define ULTRA_LDPC_NO_PLACEMENT 1
+#include "host_tables.h"
+#include <algorithm>
+#include <cstdio>
+#include <numeric>
+#include <random>
+using namespace ultra_hip;
+
+struct Placement { std::vector<uint16_t> var_slot, row_slot; long c2 = 0; int extra = 0; std::vector<int> S, D; };
+
+// Row profiles with slack.  The sorted profile is exactly full in its top rounds (every row of a six-slot round has six
+// edges, so every (half-wave, bank) cell must hold exactly six), and with only five variables per bank (R1/4: 162 variables
+// on 32 banks) the annealing does not get C1 to zero there; one more slot in some rounds buys the slack (0: sorted profile).
+static int g_row_profile[6][8] = {{0}};
+
+static bool place(uint32_t rate, uint32_t seed, long iters, Placement& out) {
+    LdpcConst L; build_ldpc(rate, 50, L);
+    std::vector<int> act;
+    for (int j = 0; j < L.k; ++j) if (L.var_ptr[j + 1] - L.var_ptr[j] > 0) act.push_back(j);
+    const int VR = ((int)act.size() + 63) / 64, RR = (L.m + 63) / 64, NH = 2 * VR, NG = 2 * RR;
+    std::vector<int> rdeg(L.m), vdeg(L.k, 0);
+    for (int i = 0; i < L.m; ++i) {
+        rdeg[i] = L.row_ptr[i + 1] - L.row_ptr[i] - 1;                    // information edges (the last edge is the parity bit)
+        if (rdeg[i] < 1 || rdeg[i] > 6 || L.col[L.row_ptr[i + 1] - 1] != L.k + i) return false;
+    }
+    std::vector<std::vector<int>> vrow(L.k);
+    std::vector<std::vector<std::pair<int, int>>> rvar(L.m);
+    for (int i = 0; i < L.m; ++i)
+        for (int e = L.row_ptr[i]; e + 1 < L.row_ptr[i + 1]; ++e) vrow[L.col[e]].push_back(i);     // ascending check order
+    for (int j = 0; j < L.k; ++j) { vdeg[j] = (int)vrow[j].size(); for (int q = 0; q < vdeg[j]; ++q) rvar[vrow[j][q]].push_back({j, q}); }
+    // profiles: sorted by degree, descending, 64 per round
+    std::vector<int> rows(L.m), vars = act;
+    std::iota(rows.begin(), rows.end(), 0);
+    std::stable_sort(rows.begin(), rows.end(), [&](int a, int b) { return rdeg[a] > rdeg[b]; });
+    std::stable_sort(vars.begin(), vars.end(), [&](int a, int b) { return vdeg[a] > vdeg[b]; });
+    std::vector<int> S(RR, 0), Dr(VR, 0);
+    for (int p = 0; p < L.m; ++p) S[p / 64] = std::max(S[p / 64], rdeg[rows[p]]);
+    if (g_row_profile[rate][0]) for (int r = 0; r < RR; ++r) { if (g_row_profile[rate][r] < S[r]) return false; S[r] = g_row_profile[rate][r]; }
+    for (int p = 0; p < (int)vars.size(); ++p) Dr[p / 64] = std::max(Dr[p / 64], vdeg[vars[p]]);
+    const int D = *std::max_element(Dr.begin(), Dr.end());
+    std::mt19937 rng(seed);
+    std::vector<int> bank(L.k, -1), H(L.k, -1), grp(L.m, -1), U(L.m, -1);
+    std::vector<int> occV(32 * NH, -1), occR(NG * 32, -1);
+    for (int p = 0; p < (int)vars.size(); ++p) { const int j = vars[p]; H[j] = p / 32; bank[j] = p % 32; occV[bank[j] * NH + H[j]] = j; }
+    for (int p = 0; p < L.m; ++p) { const int i = rows[p]; grp[i] = p / 32; U[i] = p % 32; occR[grp[i] * 32 + U[i]] = i; }
+    std::vector<int> c2(NH * D * 32, 0), c1(NG * 32, 0);
+    auto pen2 = [](int c) { return c > 1 ? c - 1 : 0; };
+    auto a2 = [&](int h, int q, int u, int s) { int& c = c2[(h * D + q) * 32 + u]; const int b = pen2(c); c += s; return pen2(c) - b; };
+    auto a1 = [&](int g, int b, int s) {
+        const int lim = S[g / 2];
+        int& c = c1[g * 32 + b]; const int bf = c > lim ? 50 * (c - lim) : 0; c += s; return (c > lim ? 50 * (c - lim) : 0) - bf;
+    };
+    long cost = 0;
+    for (int j : act) for (int q = 0; q < vdeg[j]; ++q) { cost += a2(H[j], q, U[vrow[j][q]], 1); cost += a1(grp[vrow[j][q]], bank[j], 1); }
+    auto var_at = [&](int j, int b, int h, int s) { long d = 0; for (int q = 0; q < vdeg[j]; ++q) { const int i = vrow[j][q]; d += a2(h, q, U[i], s); d += a1(grp[i], b, s); } return d; };
+    auto row_at = [&](int i, int g, int u, int s) { long d = 0; for (auto [j, q] : rvar[i]) { d += a2(H[j], q, u, s); d += a1(g, bank[j], s); } return d; };
+    std::uniform_real_distribution<double> R01(0, 1);
+    double T = 0.7;
+    std::vector<int> bestV, bestB, bestG, bestU; long best = 1L << 60;
+    auto snapshot = [&] { bestV = H; bestB = bank; bestG = grp; bestU = U; best = cost; };
+    for (long it = 0; cost > 0 && it < iters; ++it) {
+        long d = 0;
+        if (rng() % 3) {
+            const int j = act[rng() % act.size()], b0 = bank[j], h0 = H[j];
+            const int b1 = (rng() % 4 == 0) ? (int)(rng() % 32) : b0, h1 = rng() % NH;
+            if (b1 == b0 && h1 == h0) continue;
+            const int k = occV[b1 * NH + h1];
+            if (vdeg[j] > Dr[h1 / 2] || (k >= 0 && vdeg[k] > Dr[h0 / 2])) continue;           // the round's profile must cover the degree
+            d += var_at(j, b0, h0, -1); if (k >= 0) d += var_at(k, b1, h1, -1);
+            d += var_at(j, b1, h1, +1); if (k >= 0) d += var_at(k, b0, h0, +1);
+            if (d <= 0 || R01(rng) < std::exp(-(double)d / T)) { bank[j] = b1; H[j] = h1; occV[b1 * NH + h1] = j; if (k >= 0) { bank[k] = b0; H[k] = h0; } occV[b0 * NH + h0] = k; cost += d; }
+            else { var_at(j, b1, h1, -1); if (k >= 0) var_at(k, b0, h0, -1); var_at(j, b0, h0, +1); if (k >= 0) var_at(k, b1, h1, +1); }
+        } else {
+            const int i = rng() % L.m, g0 = grp[i], u0 = U[i];
+            const int g1 = (rng() % 4 == 0) ? (int)(rng() % NG) : g0, u1 = rng() % 32;
+            if (g1 == g0 && u1 == u0) continue;
+            const int k = occR[g1 * 32 + u1];
+            if (rdeg[i] > S[g1 / 2] || (k >= 0 && rdeg[k] > S[g0 / 2])) continue;
+            d += row_at(i, g0, u0, -1); if (k >= 0) d += row_at(k, g1, u1, -1);
+            grp[i] = g1; U[i] = u1; if (k >= 0) { grp[k] = g0; U[k] = u0; }
+            d += row_at(i, g1, u1, +1); if (k >= 0) d += row_at(k, g0, u0, +1);
+            if (d <= 0 || R01(rng) < std::exp(-(double)d / T)) { occR[g1 * 32 + u1] = i; occR[g0 * 32 + u0] = k; cost += d; }
+            else { row_at(i, g1, u1, -1); if (k >= 0) row_at(k, g0, u0, -1); grp[i] = g0; U[i] = u0; if (k >= 0) { grp[k] = g1; U[k] = u1; } row_at(i, g0, u0, +1); if (k >= 0) row_at(k, g1, u1, +1); }
+        }
+        T = std::max(0.10, T * 0.9999998);
+        if (cost < best && T < 0.3) snapshot();
+    }
+    if (cost < best) snapshot();
+    std::vector<int> e2(NH * D * 32, 0), e1(NG * 32, 0);
+    for (int j : act) for (int q = 0; q < vdeg[j]; ++q) { e2[(bestV[j] * D + q) * 32 + bestU[vrow[j][q]]]++; e1[bestG[vrow[j][q]] * 32 + bestB[j]]++; }
+    for (int g = 0; g < NG; ++g) for (int b = 0; b < 32; ++b) if (e1[g * 32 + b] > S[g / 2]) return false;
+    out.c2 = 0; out.extra = 0;
+    for (int h = 0; h < NH; ++h) for (int q = 0; q < Dr[h / 2]; ++q) { int mx = 0; for (int u = 0; u < 32; ++u) { const int c = e2[(h * D + q) * 32 + u]; mx = std::max(mx, c); out.c2 += c > 1 ? c - 1 : 0; } out.extra += std::max(0, mx - 1); }
+    out.var_slot.assign(L.k, 0xFFFF); out.row_slot.assign(L.m, 0xFFFF);
+    for (int j : act) out.var_slot[j] = (uint16_t)((bestV[j] / 2) * 64 + (bestV[j] % 2) * 32 + bestB[j]);
+    for (int i = 0; i < L.m; ++i) out.row_slot[i] = (uint16_t)((bestG[i] / 2) * 64 + (bestG[i] % 2) * 32 + bestU[i]);
+    out.S = S; out.D = Dr;
+    return true;
+}
+
+int main(int argc, char** argv) {
+    // ldpc_place_low [iterations [rate S0 S1 ...]]: with a rate, only that code, with the given row profile
+    const long iters = argc > 1 ? atol(argv[1]) : 120000000;
+    const int only = argc > 2 ? atoi(argv[2]) : -1;
+    if (only >= 0) for (int r = 0; r < 8 && 3 + r < argc; ++r) g_row_profile[only][r] = atoi(argv[3 + r]);
+    else { const int p0[8] = {6, 6, 6, 5, 5, 4, 3, 2}; for (int r = 0; r < 8; ++r) g_row_profile[0][r] = p0[r]; }
+    const char* names[6] = {"R1_4", "R1_3", "R1_2", "R2_3", "R3_4", "R5_6"};
+    std::printf("// ldpc_placement_low.h — GENERATED by tools/ldpc_place_low.cpp (simulated annealing, fixed seeds); do not edit.\n"
+                "// Slots of the variables and rows of the profile-templated totals LDPC kernel (csrc/ldpc_totals_prof_kernel.h) for the\n"
+                "// codes with irregular rows: var slot = round * 64 + lane, row slot = round * 64 + lane; rows and variables sit in rounds\n"
+                "// whose profile (S_r information-edge slots / D_r edges) covers their degree.  Validated against the code's Tanner graph\n"
+                "// by build_ldpc_tplan (csrc/host_tables.h) at context creation.\n"
+                "#ifndef ULTRA_LDPC_PLACEMENT_LOW_H\n#define ULTRA_LDPC_PLACEMENT_LOW_H\n#include <stdint.h>\nnamespace ultra_hip {\n");
+    for (uint32_t rate : {0u, 1u, 2u}) {
+        if (only >= 0 && (int)rate != only) continue;
+        Placement best; bool have = false;
+        for (uint32_t seed = 1; seed <= 3; ++seed) {
+            Placement p;
+            if (!place(rate, 2000 * (rate + 1) + seed, iters, p)) { std::fprintf(stderr, "rate %s seed %u: C1 not met\n", names[rate], seed); continue; }
+            std::fprintf(stderr, "rate %s seed %u: residual C2 collisions %ld, extra LDS cycles per iteration %d\n", names[rate], seed, p.c2, p.extra);
+            if (!have || p.extra < best.extra) { best = p; have = true; }
+            if (best.extra == 0) break;
+        }
+        if (!have) { std::fprintf(stderr, "rate %s: no placement\n", names[rate]); return 1; }
+        std::printf("// %s: row profile S =", names[rate]);
+        for (int s : best.S) std::printf(" %d", s);
+        std::printf(", variable profile D =");
+        for (int d : best.D) std::printf(" %d", d);
+        std::printf("; %d extra LDS cycles per iteration from residual gather collisions of the variable step\n", best.extra);
+        std::printf("static const uint16_t kPlaceVar_%s[%zu] = {", names[rate], best.var_slot.size());
+        for (size_t i = 0; i < best.var_slot.size(); ++i) std::printf("%s%u", i ? "," : "", best.var_slot[i]);
+        std::printf("};\nstatic const uint16_t kPlaceRow_%s[%zu] = {", names[rate], best.row_slot.size());
+        for (size_t i = 0; i < best.row_slot.size(); ++i) std::printf("%s%u", i ? "," : "", best.row_slot[i]);
+        unsigned long long rp = 0, vp = 0;
+        for (size_t r = 0; r < best.S.size(); ++r) rp |= (unsigned long long)best.S[r] << (4 * r);
+        for (size_t r = 0; r < best.D.size(); ++r) vp |= (unsigned long long)best.D[r] << (4 * r);
+        std::printf("};\nstatic const unsigned long long kPlaceRowProf_%s = 0x%llxull, kPlaceVarProf_%s = 0x%llxull;\n", names[rate], rp, names[rate], vp);
+    }
+    if (only >= 0) return 0;
+    std::printf("// row_prof / var_prof: the profiles the placement was made for (four bits per round), the template arguments of the kernel\n"
+                "inline bool ldpc_placement_low(uint32_t rate, const uint16_t** var_slot, int* n_var, const uint16_t** row_slot, int* n_row,\n"
+                "                               unsigned long long* row_prof, unsigned long long* var_prof) {\n"
+                "    switch (rate) {\n"
+                "        case 0: *var_slot = kPlaceVar_R1_4; *n_var = (int)(sizeof(kPlaceVar_R1_4) / 2); *row_slot = kPlaceRow_R1_4; *n_row = (int)(sizeof(kPlaceRow_R1_4) / 2); *row_prof = kPlaceRowProf_R1_4; *var_prof = kPlaceVarProf_R1_4; return true;\n"
+                "        case 1: *var_slot = kPlaceVar_R1_3; *n_var = (int)(sizeof(kPlaceVar_R1_3) / 2); *row_slot = kPlaceRow_R1_3; *n_row = (int)(sizeof(kPlaceRow_R1_3) / 2); *row_prof = kPlaceRowProf_R1_3; *var_prof = kPlaceVarProf_R1_3; return true;\n"
+                "        case 2: *var_slot = kPlaceVar_R1_2; *n_var = (int)(sizeof(kPlaceVar_R1_2) / 2); *row_slot = kPlaceRow_R1_2; *n_row = (int)(sizeof(kPlaceRow_R1_2) / 2); *row_prof = kPlaceRowProf_R1_2; *var_prof = kPlaceVarProf_R1_2; return true;\n"
+                "        default: return false;\n    }\n}\n}  // namespace ultra_hip\n#endif\n");
+    return 0;
+}
