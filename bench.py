@@ -823,14 +823,14 @@ def main():
             roofline.update({"bound": res, "compute": {"resource": {"valu": "vector issue (4 SIMDs per CU)", "salu": "scalar issue",
                                                                     "lds": "LDS pipeline"}[res], "frac": v[res], "all": v},
                              "hbm_frac": kernels[dom]["frac"]})
-        if dom == "ldpc_decode_kernel" and wl.name == "cfg4":       # the message-passing kernel (R1/4 has no totals placement)
-            rate = int(wl.ctx.cfg.code_rate)
-            # (LDS read/store pairs per iteration over both steps, lane-linear layout?) per code
-            pairs, linear = {0: (70, False), 1: (49, False), 2: (49, False), 3: (48, True), 4: (36, True), 5: (24, True)}[rate]
-            if linear:      # half of the stores are the variable step's add-TID stores
-                cyc = pairs * LDS_CYC["read_b32"] + pairs // 2 * LDS_CYC["write_b32"] + pairs // 2 * LDS_CYC["write_addtid_b32"]
-            else:
-                cyc = pairs * (LDS_CYC["read_b32"] + LDS_CYC["write_b32"])
+        if dom == "ldpc_decode_kernel" and wl.name == "cfg4":
+            # R1/4 on the profile-templated totals kernel (round 4; ldpc_totals_prof_kernel.h): per codeword-iteration the row
+            # phase issues one gather and one lane-linear store per R plane (37: row profile 6 6 6 5 5 4 3 2), the variable
+            # phase one gather per edge slot of its profile (13 + 12 + 12) and one lane-linear store per round (3); the
+            # placement's residual gather collisions add 44 cycles (csrc/ldpc_placement_low.h).  Cycles per wave-instruction:
+            # MI355X_MICROARCH.md's LDS table, re-measured in profiles/r02_issue_table.txt.
+            planes, var_slots, var_rounds, extra = 37, 37, 3, 44
+            cyc = (planes + var_slots) * LDS_CYC["read_b32"] + (planes + var_rounds) * LDS_CYC["write_addtid_b32"] + extra
             executed = stats["iters_sum"] / world + (stats["frames"] - stats["ldpc_fail"]) / world
             avail = kernels[dom]["ms_per_step"] * 1e-3 * CLOCK_HZ * props.multi_processor_count
             frac = cyc * executed / avail
@@ -844,7 +844,7 @@ def main():
                             "launch of a repeat of the timed steps) against 8 TB/s. bound = the busiest unit of the dominant kernel where an "
                             "issue model exists (compute.frac: issue cycles from PMC instruction counts x measured per-opcode costs, "
                             "profiles/r03_issue_model.txt, over the cycles the launch had; kernels.*.issue for the others); 'lds' with the "
-                            "cycle model of DESIGN.md 4.2 for the message-passing decoder (cfg4); 'hbm' otherwise")
+                            "instruction count of the totals decoder's profile for R1/4 (cfg4); 'hbm' otherwise")
 
     # ---- CPU baseline: the compiled reference on the host's physical cores, bounded sample (rank 0, N=1 only) ----
     cpu = None
