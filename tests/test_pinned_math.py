@@ -78,16 +78,18 @@ def test_ldpc_kernel_instances_cover_the_six_profiles(tmp_path):
 
 
 def test_ldpc_totals_plan_and_emulation(tmp_path):
-    """The totals LDPC kernel's plan (embedded placement, csrc/ldpc_placement.h -> build_ldpc_tplan): valid for R2/3, R3/4,
-    R5/6, absent for the irregular codes, and a lane-by-lane CPU emulation of the kernel over the plan decodes 200 noisy
-    codewords per rate exactly as the reference's decodeBP (iterations, success, every bit)."""
+    """The totals LDPC kernels' plans (embedded placements, csrc/ldpc_placement.h and — round 4, the codes with irregular
+    rows — csrc/ldpc_placement_low.h -> build_ldpc_tplan): valid for all six codes, and a lane-by-lane CPU emulation of the
+    kernel over the plan (per-round degree profiles, plane bases, pad words) decodes 200 noisy codewords per rate exactly as the
+    reference's decodeBP (iterations, success, every bit)."""
     import re
     exe = tmp_path / "tpc"
     subprocess.check_call(["g++", "-O2", "-std=c++17", "-ffp-contract=off", "-I" + str(ROOT / "projectultra_amd" / "csrc"),
                            str(ROOT / "tools" / "ldpc_tplan_check.cpp"), "-o", str(exe)])
     out = subprocess.run([str(exe)], capture_output=True, text=True, timeout=600)
     assert out.returncode == 0, out.stdout + out.stderr
-    assert out.stdout.count("plan valid") == 3 and out.stdout.count(": 0 mismatches of 200") == 3, out.stdout
+    assert out.stdout.count("plan valid") == 6 and out.stdout.count(": 0 mismatches of 200") == 6, out.stdout
     extra = {int(r): int(c) for r, c in re.findall(r"rate (\d): plan valid.*cost (\d+) cycles", out.stdout)}
     assert extra[4] <= 4 and extra[5] <= 4, extra          # R3/4 and R5/6: (nearly) conflict-free gathers
+    assert extra[1] <= 4 and extra[2] <= 4 and extra[0] <= 48, extra      # R1/3, R1/2 likewise; R1/4 (13 edges per variable) keeps 44
 
