@@ -224,7 +224,10 @@ int ultra_hip_demod_batch_strided(ultra_hip_ctx* ctx, const float* d_audio, size
 /* ultra_hip_ldpc_decode_batch over n_blocks runs of block_len codewords inside a larger LLR array of rows of llr_stride
  * floats (the first 648 of a row are the codeword): codeword c = row (c / block_len) * block_stride + c % block_len.
  * One launch per CODE RATE over the soft bits of every modulation of a mode grid (decoding does not depend on the
- * modulation).  Results are dense: d_bytes [n_blocks * block_len][ceil(k/8)], d_iters, d_ok. */
+ * modulation).  Results are dense: d_bytes [n_blocks * block_len][ceil(k/8)], d_iters, d_ok.
+ * The context's channel deinterleaver (ultra_hip_set_deinterleave[_table]) applies to EVERY run alike: a step that depends on
+ * the modulation's bits per symbol must not be set on a context that decodes several modulations' runs (the mode grid sets
+ * none). */
 int ultra_hip_ldpc_decode_blocks(ultra_hip_ctx* ctx, const float* d_llr, size_t llr_stride, size_t block_len, size_t block_stride,
                                  size_t n_blocks, uint8_t* d_bytes, int32_t* d_iters, uint8_t* d_ok);
 

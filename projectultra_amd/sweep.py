@@ -338,6 +338,7 @@ def mode_sweep_grid(snr_points: Iterable[float] = CFG5_SNR_POINTS, frames_per_po
             total = torch.zeros((M, R, S, 8), dtype=torch.int64, device="cuda")
             break
         if grid is None or grid.n != n:
+            grid = None                                             # the ragged tail: free the 30 contexts and their buffers first
             grid = HipModeGrid(CFG5_MODULATIONS, CFG5_RATES, snr_points, frames_per_point=n, channel=channel, delay_ms=delay_ms,
                                doppler_hz=doppler_hz)
         grid.generate(f0, seed=seed)

@@ -18,7 +18,12 @@ b) for c in cfg2 cfg5; do bash tools/collect_profiles.sh $TAG $c $C > $O/c_$c.lo
 c) for c in cfg4 raw; do bash tools/collect_profiles.sh $TAG $c $C > $O/c_$c.log 2>&1; head -4 $O/c_$c.log; done
    sq cfg4 cfg4 --steps 1 --warmup 1; sq raw raw --steps 1 --warmup 1 ;;
 d) timeout -k 10 300 python3 tools/mix_fft_stalls.py > $O/mix_fft_stalls_two_wave.txt 2> $O/stalls_two.err
-   timeout -k 10 300 python3 tools/mix_fft_stalls.py --one-wave > $O/mix_fft_stalls_one_wave.txt 2> $O/stalls_one.err
+   timeout -k 10 300 python3 tools/mix_fft_stalls.py --norot > $O/mix_fft_stalls_norot.txt 2> $O/stalls_norot.err
+   timeout -k 10 300 python3 tools/ldpc_stalls.py > $O/ldpc_stalls.txt 2> $O/ldpc_stalls.err      # needs build/v_ldstamps.so (build_variants.sh ldstamps="-DUH_LDPC_STAMPS")
+   timeout -k 10 400 python3 bench.py --config raw --raw-channel watterson > $O/bench_raw_watterson.json 2> $O/bench_raw_watterson.err
+   # the N > 1 path on the one card (gloo): strong-scaling cfg3 at 2 and 4 ranks next to 1
+   for n in 1 2 4; do timeout -k 10 400 python3 bench.py --gpus $n --backend gloo --total-frames 131072 --steps 5 --warmup 2 --no-cpu-baseline 2>/dev/null | python3 -c "
+import json,sys; d=json.loads(sys.stdin.readline()); print('ranks %d on one card (gloo): %.3f ms per 2^17-frame step, counters %s, collective world %d' % (d['n_gpus'], d['ms_per_step'], d['counters'], d['collective']['world_size']))"; done > $O/multirank_one_card.txt; cat $O/multirank_one_card.txt
    timeout -k 10 900 python3 tools/soak_parity.py 16384 7 > $O/soak_parity.txt 2>&1; tail -n 2 $O/soak_parity.txt
    timeout -k 10 600 python3 tools/soak_sync.py 4096 128 3 > $O/soak_sync.txt 2>&1; tail -n 2 $O/soak_sync.txt
    timeout -k 10 300 python3 -m torch.distributed.run --nnodes=1 --nproc-per-node 1 --master-addr 127.0.0.1 --master-port 29511 \

@@ -11,7 +11,8 @@ cp $O/traffic_cfg3.json $P/traffic.json
 cp $O/bench_cfg3_torchrun1.json $P/${TAG}_bench_cfg3_torchrun1.json
 cp $SQ/cfg3/summary.txt $P/${TAG}_sq_counters.txt
 for c in cfg2 cfg4 cfg5 raw; do cp $SQ/$c/summary.txt $P/${TAG}_sq_counters_$c.txt; done
-cp $O/mix_fft_stalls_two_wave.txt $P/${TAG}_mix_fft_stalls_two_wave.txt; cp $O/mix_fft_stalls_one_wave.txt $P/${TAG}_mix_fft_stalls_one_wave.txt
+cp $O/mix_fft_stalls_two_wave.txt $P/${TAG}_mix_fft_stalls_rot.txt; cp $O/mix_fft_stalls_norot.txt $P/${TAG}_mix_fft_stalls_norot.txt
+cp $O/ldpc_stalls.txt $P/${TAG}_ldpc_stalls.txt; cp $O/bench_raw_watterson.json $P/${TAG}_bench_raw_watterson.json; cp $O/multirank_one_card.txt $P/${TAG}_multirank_one_card.txt
 cat $O/soak_parity.txt $O/soak_sync.txt > $P/${TAG}_soak_parity.txt
 cp $O/ldpc_bench.txt $P/${TAG}_ldpc_bench.txt
 cp $O/batch_size_series.txt $P/${TAG}_batch_size_series.txt
