@@ -51,12 +51,12 @@ CLOCK_HZ = 2.4e9                # MI355X peak engine clock (MI355X_MICROARCH.md)
 LDS_CYC = dict(read_b32=2, write_b32=4, write_addtid_b32=2)
 # Compute-side roofline: issue cycles per unit of work and kernel, = (dynamic instruction counts per unit from rocprofv3
 # --pmc SQ_INSTS_VALU / _SALU / _LDS, profiles/r03_sq_counters.txt) x (measured cost per instruction of the kernel's own
-# opcode mix, profiles/r02_issue_table.txt), as tools/issue_model.py derives them into profiles/r03_issue_model.txt.
+# opcode mix, profiles/r02_issue_table.txt), as tools/issue_model.py derives them into profiles/r04_issue_model.txt.
 #   valu / salu: cycles of ONE SIMD per unit (a CU has 4 SIMDs); lds: cycles of the CU's single LDS pipeline per unit.
 #   unit: "cw_iteration" = one executed BP iteration of one codeword; "frame" = one frame of one launch.
 ISSUE_CYCLES = {
     "ldpc_totals R3/4": dict(unit="cw_iteration", valu=162.5 * 3.38, salu=80.4 * 4.19, lds=61.5 * 2.13),
-    # round 3 (profiles/r03_sq_counters.txt -> profiles/r03_issue_model.txt): the two-wavefront transform, the deferred
+    # round 3 (profiles/r03_sq_counters.txt -> profiles/r04_issue_model.txt): the two-wavefront transform, the deferred
     # carrier half (unit: one symbol of one frame), the pilot half with its record for the carrier half
     "mix_fft_kernel": dict(unit="frame", valu=1095.7 * 3.47, salu=236.4 * 4.19, lds=106.7 * 3.48),    # mean of the rotating (1505 VALU) and the no-rotation instance (686): two launches each per step
     "track_kernel": dict(unit="frame_symbol", valu=182.4 * 3.29, salu=118.3 * 4.19, lds=19.9 * 4.01),
@@ -800,7 +800,7 @@ def main():
             cu = props.multi_processor_count
             u = dict(valu=m["valu"] * units / (4 * cu * t), salu=m["salu"] * units / (4 * cu * t), lds=m["lds"] * units / (cu * t))
             kernels[name]["issue"] = dict(unit=m["unit"], units_per_step=units, cycles_per_unit={k: m[k] for k in ("valu", "salu", "lds")},
-                                          busy_frac=u, clock_hz=CLOCK_HZ, source="profiles/r03_issue_model.txt")
+                                          busy_frac=u, clock_hz=CLOCK_HZ, source="profiles/r04_issue_model.txt")
             return u
         if wl.name == "cfg3":
             executed = stats["iters_sum"] / world + (stats["frames"] - stats["ldpc_fail"]) / world
@@ -843,7 +843,7 @@ def main():
         roofline["note"] = ("achieved/peak/frac = HBM view: algorithmic bytes per launch / mean launch duration (HIP events around every "
                             "launch of a repeat of the timed steps) against 8 TB/s. bound = the busiest unit of the dominant kernel where an "
                             "issue model exists (compute.frac: issue cycles from PMC instruction counts x measured per-opcode costs, "
-                            "profiles/r03_issue_model.txt, over the cycles the launch had; kernels.*.issue for the others); 'lds' with the "
+                            "profiles/r04_issue_model.txt, over the cycles the launch had; kernels.*.issue for the others); 'lds' with the "
                             "instruction count of the totals decoder's profile for R1/4 (cfg4); 'hbm' otherwise")
 
     # ---- CPU baseline: the compiled reference on the host's physical cores, bounded sample (rank 0, N=1 only) ----
