@@ -2,10 +2,13 @@
 """bench.py — benchmarks of the batched OFDM-demodulate + LDPC-decode receive path, one line per BASELINE config.
 
     python bench.py [--config cfg3] --gpus N --steps K --warmup W
-    (N > 1: python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...)
+    N > 1 with no launcher around it: bench.py starts its own N ranks (a child `python -m torch.distributed.run --nnodes=1
+    --nproc-per-node N ... bench.py --gpus N ...`, before anything touches the GPU).  Under a launcher (RANK / WORLD_SIZE in the
+    environment) it is one rank of it and refuses a WORLD_SIZE other than --gpus.  --backend gloo reduces the counters through
+    host memory, so ranks may share a card (rehearsal of the N > 1 path on a one-GPU box).
 
 --config (default cfg3 = BASELINE.json's headline metric and configs[2]):
-  cfg3  OFDM-1024 16QAM R3/4, 59 carriers (15 pilots), Watterson "good" 30 dB, post-sync entry, 2^18 frames per GPU
+  cfg3  OFDM-1024 16QAM R3/4, 59 carriers (15 pilots), Watterson "good" 30 dB, post-sync entry, ONE 2^20-frame batch per step
   cfg2  OFDM-512 DQPSK R1/2, 30 carriers, AWGN, 65,536 frames per GPU                       (configs[1])
   cfg4  LDPC R1/4 Es/N0 sweep -11..+30 dB, BPSK/AWGN LLRs, 2^17 codewords per point per GPU  (configs[3]: 2^20 on 8 GPUs)
   cfg5  {DBPSK,DQPSK,D8PSK,16QAM,32QAM} x {R1/4..R5/6} x 11 SNR points, 1,920 frames per point per GPU
