@@ -72,14 +72,22 @@ def test_random_noisy_codewords_bit_exact(oracle, rate):
 
 
 @pytest.mark.parametrize("max_iter", [0, 1, 3, 200])
-def test_iteration_limits(oracle, max_iter):
-    rate = 4
-    llr, _ = noisy_codewords(oracle, rate, 96, [0.55, 0.7], seed=7)
+@pytest.mark.parametrize("rate", [0, 2, 4])
+def test_iteration_limits(oracle, rate, max_iter):
+    """setMaxIterations 0 / 1 / 3 / 200 on the three kernel families' codes (R1/4: profile kernel with 13-edge variables, R1/2:
+    profile kernel, R3/4: regular totals kernel), through BOTH instances of each: with the a-posteriori LLRs (no iteration-0
+    short cut) and without (the production instance)."""
+    sig = {0: [1.3, 1.9], 2: [0.8, 1.1], 4: [0.55, 0.7]}[rate]
+    llr, _ = noisy_codewords(oracle, rate, 96, sig, seed=7)
+    valid = np.where(np.unpackbits(np.frombuffer(oracle.ldpc_encode(rate, bytes(INFO_BITS[rate] // 8)), np.uint8))[:648] > 0, -3.0, 3.0)
+    llr[0] = valid.astype(np.float32)                                      # converges at iteration 0
     d = _decoder(rate, max_iter=max_iter)
     r = d.decode_batch(llr, want_total=True)
     ob, oi, ook, ototal = oracle.ldpc_decode_batch(rate, llr, max_iters=max_iter, want_total=True)
     assert np.array_equal(r["iters"], oi) and np.array_equal(r["ok"], ook) and np.array_equal(r["bytes"], ob)
     assert beq(r["llr_total"], ototal)
+    p = d.decode_batch(llr)
+    assert np.array_equal(p["iters"], oi) and np.array_equal(p["ok"], ook) and np.array_equal(p["bytes"], ob)
 
 
 def test_edge_llrs(oracle):
