@@ -122,6 +122,8 @@ def test_nonfinite_llrs(oracle, rate):
     both_nan = np.isnan(got) & np.isnan(ototal)          # a fresh NaN's sign bit differs between x86 and gfx950
     assert np.array_equal(np.isnan(got), np.isnan(ototal))
     assert beq(np.where(both_nan, np.float32(0), got), np.where(both_nan, np.float32(0), ototal))
+    p = d.decode_batch(cases)                       # the production instance (no a-posteriori LLRs: iteration-0 short cut, other registers)
+    assert np.array_equal(p["iters"], oi) and np.array_equal(p["ok"], ook) and np.array_equal(p["bytes"], ob)
 
 
 @pytest.mark.parametrize("bps", [60, 116, 176])
