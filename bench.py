@@ -827,7 +827,7 @@ def main():
                                                                     "lds": "LDS pipeline"}[res], "frac": v[res], "all": v},
                              "hbm_frac": kernels[dom]["frac"]})
         if dom == "ldpc_decode_kernel" and wl.name == "cfg4":
-            # R1/4 on the profile-templated totals kernel (round 4; ldpc_totals_prof_kernel.h): per codeword-iteration the row
+            # R1/4 on the totals kernel with its degree profile (round 4; ldpc_totals_kernel.h): per codeword-iteration the row
             # phase issues one gather and one lane-linear store per R plane (37: row profile 6 6 6 5 5 4 3 2), the variable
             # phase one gather per edge slot of its profile (13 + 12 + 12) and one lane-linear store per round (3); the
             # placement's residual gather collisions add 44 cycles (csrc/ldpc_placement_low.h).  Cycles per wave-instruction:

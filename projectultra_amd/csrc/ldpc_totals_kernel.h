@@ -1,24 +1,34 @@
-// ldpc_totals_kernel.h — LDPC(648) scaled-min-sum decode for gfx950, "totals" formulation: one wavefront per codeword,
-// HALF the LDS traffic of the message-passing kernel (ldpc_kernel.h) for the codes it covers (R2/3, R3/4, R5/6).
+// ldpc_totals_kernel.h — LDPC(648) scaled-min-sum decode for gfx950, "totals" formulation: one wavefront per codeword, all six
+// codes of the reference (round 2: R2/3, R3/4, R5/6; round 4: R1/4, R1/3, R1/2 through per-round degree profiles).
 //
 // Same arithmetic as LDPCDecoder::Impl::decodeBP (src/fec/ldpc_decoder.cpp:153-259) — see ldpc_kernel.h's header for
 // the value-identical reformulations shared with it (minima with |.| modifiers and minNum semantics, signs as lane
 // masks, the +-50 clamp deferred to the reader, parity bits in the registers of their row's lane, unchecked variables
-// untouched).  What differs is WHO computes the variable-to-check message and what travels through LDS:
+// untouched).  What differs from the message-passing kernel there is WHO computes the variable-to-check message and what
+// travels through LDS:
 //
 //   reference / message kernel   variable step:  v2c[e] = clamp(total[j] - c2v[e])  per EDGE, stored, read by the row
 //   here                          the variable publishes ONE number, total[j]; the ROW computes total[j] - c2v[e] with
 //                                 its own previous c2v[e], which it kept in a register.  Same operands, same operation.
 //
-// LDS per codeword-iteration (R3/4: 3 row rounds, 6 variable rounds, 18 edge slots):
+// DEGREE PROFILES are template arguments (four bits per round, ldpc_prof): round r of the row phase gathers, computes and
+// stores S_r information-edge slots plus the parity edge (a leave-one-out network of S_r + 1 magnitudes), round r of the
+// variable phase gathers and adds D_r messages; the R planes of round r are plane_base[r] .. plane_base[r] + S_r - 1.  The
+// regular codes (every row six information edges, every variable three) have S = 6 and D = 3 throughout; the low-rate codes'
+// rows hold 1..6 edges and their variables 4..13, and rows / variables sit in rounds whose profile covers their degree
+// (tools/ldpc_place_low.cpp -> ldpc_placement_low.h).  A shorter row's spare slots gather the T pad word FLT_MAX (positive,
+// never a minimum), a variable's spare edges the R pad word -0.0f (the exact neutral addend).
+//
+// LDS per codeword-iteration (R3/4: 3 row rounds x 6 slots, 6 variable rounds x 3 edges):
 //   row side       18 gathers of totals (ds_read_b32, 2 cycles)      18 lane-linear stores of c2v (ds_write_addtid_b32, 2)
 //   variable side  18 gathers of c2v   (ds_read_b32, 2 cycles)        6 lane-linear stores of totals (add-TID, 2)
 //   = 120 LDS-pipeline cycles (+ the plan's residual gather collisions, P.extra_cycles) against 180 of the message kernel,
-//   whose check step stores through address registers (ds_write_b32: 4 cycles each).
-// Both gathers are made conflict-free by WHERE variables and rows sit (tools/ldpc_place.cpp -> ldpc_placement.h ->
-// build_ldpc_tplan).  The stopping test needs no extra pass: a row that has gathered the totals of its variables
-// evaluates its own parity equation on them — the exact checkParity (:139-151) of the PREVIOUS iteration, decided at
-// the top of the next one from the very gathers the check step needs anyway.
+//   whose check step stores through address registers (ds_write_b32: 4 cycles each); R1/4: 114 instructions against 70
+//   read / four-cycle-write pairs.
+// Both gathers are made conflict-free by WHERE variables and rows sit (tools/ldpc_place.cpp, tools/ldpc_place_low.cpp ->
+// ldpc_placement.h, ldpc_placement_low.h -> build_ldpc_tplan).  The stopping test needs no extra pass: a row that has
+// gathered the totals of its variables evaluates its own parity equation on them — the exact checkParity (:139-151) of the
+// PREVIOUS iteration, decided at the top of the next one from the very gathers the check step needs anyway.
 #ifndef ULTRA_LDPC_TOTALS_KERNEL_H
 #define ULTRA_LDPC_TOTALS_KERNEL_H
 
@@ -45,8 +55,74 @@ __device__ unsigned long long* g_ldpc_stamps = nullptr;
 #define UH_LD_ACC(k) do {} while (0)
 #endif
 
-// RR row rounds, VR variable rounds, D = largest variable degree (LdpcTPlan).  WAVES: wavefronts per SIMD the register
-// budget is sized for.  WANT_TOTAL: also write the final a-posteriori LLRs (parity tests).
+__host__ __device__ constexpr int tprof_planes_before(unsigned long long p, int r) {
+    int s = 0;
+    for (int i = 0; i < r; ++i) s += ldpc_prof(p, i);
+    return s;
+}
+
+// S lane-linear stores of c[0..S-1] to the planes at byte offsets BASE, BASE + 256, ...: ONE asm statement (M0 must not change
+// between its write and the stores)
+template <int S, unsigned BASE>
+__device__ __forceinline__ void tprof_store_planes(const float (&c)[7]) {
+    static_assert(S >= 1 && S <= 6, "information-edge slots per row round");
+    if constexpr (S == 1)
+        asm volatile("s_mov_b32 m0, 0\n\ts_nop 0\n\tds_write_addtid_b32 %0 offset:%1" :: "v"(c[0]), "n"(BASE) : "m0", "memory");
+    else if constexpr (S == 2)
+        asm volatile("s_mov_b32 m0, 0\n\ts_nop 0\n\tds_write_addtid_b32 %0 offset:%2\n\tds_write_addtid_b32 %1 offset:%3"
+                     :: "v"(c[0]), "v"(c[1]), "n"(BASE), "n"(BASE + 256) : "m0", "memory");
+    else if constexpr (S == 3)
+        asm volatile("s_mov_b32 m0, 0\n\ts_nop 0\n\tds_write_addtid_b32 %0 offset:%3\n\tds_write_addtid_b32 %1 offset:%4\n\t"
+                     "ds_write_addtid_b32 %2 offset:%5"
+                     :: "v"(c[0]), "v"(c[1]), "v"(c[2]), "n"(BASE), "n"(BASE + 256), "n"(BASE + 512) : "m0", "memory");
+    else if constexpr (S == 4)
+        asm volatile("s_mov_b32 m0, 0\n\ts_nop 0\n\tds_write_addtid_b32 %0 offset:%4\n\tds_write_addtid_b32 %1 offset:%5\n\t"
+                     "ds_write_addtid_b32 %2 offset:%6\n\tds_write_addtid_b32 %3 offset:%7"
+                     :: "v"(c[0]), "v"(c[1]), "v"(c[2]), "v"(c[3]), "n"(BASE), "n"(BASE + 256), "n"(BASE + 512), "n"(BASE + 768) : "m0", "memory");
+    else if constexpr (S == 5)
+        asm volatile("s_mov_b32 m0, 0\n\ts_nop 0\n\tds_write_addtid_b32 %0 offset:%5\n\tds_write_addtid_b32 %1 offset:%6\n\t"
+                     "ds_write_addtid_b32 %2 offset:%7\n\tds_write_addtid_b32 %3 offset:%8\n\tds_write_addtid_b32 %4 offset:%9"
+                     :: "v"(c[0]), "v"(c[1]), "v"(c[2]), "v"(c[3]), "v"(c[4]), "n"(BASE), "n"(BASE + 256), "n"(BASE + 512), "n"(BASE + 768),
+                        "n"(BASE + 1024) : "m0", "memory");
+    else
+        asm volatile("s_mov_b32 m0, 0\n\ts_nop 0\n\t"
+                     "ds_write_addtid_b32 %0 offset:%6\n\tds_write_addtid_b32 %1 offset:%7\n\t"
+                     "ds_write_addtid_b32 %2 offset:%8\n\tds_write_addtid_b32 %3 offset:%9\n\t"
+                     "ds_write_addtid_b32 %4 offset:%10\n\tds_write_addtid_b32 %5 offset:%11"
+                     :: "v"(c[0]), "v"(c[1]), "v"(c[2]), "v"(c[3]), "v"(c[4]), "v"(c[5]), "n"(BASE), "n"(BASE + 256), "n"(BASE + 512),
+                        "n"(BASE + 768), "n"(BASE + 1024), "n"(BASE + 1280) : "m0", "memory");
+}
+
+// the variable phase's lane-linear stores of the VR totals to the T planes (byte offsets 0, 256, ...), one asm statement
+template <int VR>
+__device__ __forceinline__ void tprof_store_totals(const float (&t)[VR]) {
+    static_assert(VR >= 3 && VR <= 7, "variable rounds of the six codes");
+    if constexpr (VR == 3)
+        asm volatile("s_mov_b32 m0, 0\n\ts_nop 0\n\tds_write_addtid_b32 %0\n\tds_write_addtid_b32 %1 offset:256\n\tds_write_addtid_b32 %2 offset:512"
+                     :: "v"(t[0]), "v"(t[1]), "v"(t[2]) : "m0", "memory");
+    else if constexpr (VR == 4)
+        asm volatile("s_mov_b32 m0, 0\n\ts_nop 0\n\tds_write_addtid_b32 %0\n\tds_write_addtid_b32 %1 offset:256\n\t"
+                     "ds_write_addtid_b32 %2 offset:512\n\tds_write_addtid_b32 %3 offset:768"
+                     :: "v"(t[0]), "v"(t[1]), "v"(t[2]), "v"(t[VR > 3 ? 3 : 0]) : "m0", "memory");
+    else if constexpr (VR == 5)
+        asm volatile("s_mov_b32 m0, 0\n\ts_nop 0\n\tds_write_addtid_b32 %0\n\tds_write_addtid_b32 %1 offset:256\n\t"
+                     "ds_write_addtid_b32 %2 offset:512\n\tds_write_addtid_b32 %3 offset:768\n\tds_write_addtid_b32 %4 offset:1024"
+                     :: "v"(t[0]), "v"(t[1]), "v"(t[2]), "v"(t[VR > 3 ? 3 : 0]), "v"(t[VR > 4 ? 4 : 0]) : "m0", "memory");
+    else if constexpr (VR == 6)
+        asm volatile("s_mov_b32 m0, 0\n\ts_nop 0\n\tds_write_addtid_b32 %0\n\tds_write_addtid_b32 %1 offset:256\n\t"
+                     "ds_write_addtid_b32 %2 offset:512\n\tds_write_addtid_b32 %3 offset:768\n\tds_write_addtid_b32 %4 offset:1024\n\t"
+                     "ds_write_addtid_b32 %5 offset:1280"
+                     :: "v"(t[0]), "v"(t[1]), "v"(t[2]), "v"(t[VR > 3 ? 3 : 0]), "v"(t[VR > 4 ? 4 : 0]), "v"(t[VR > 5 ? 5 : 0]) : "m0", "memory");
+    else
+        asm volatile("s_mov_b32 m0, 0\n\ts_nop 0\n\tds_write_addtid_b32 %0\n\tds_write_addtid_b32 %1 offset:256\n\t"
+                     "ds_write_addtid_b32 %2 offset:512\n\tds_write_addtid_b32 %3 offset:768\n\tds_write_addtid_b32 %4 offset:1024\n\t"
+                     "ds_write_addtid_b32 %5 offset:1280\n\tds_write_addtid_b32 %6 offset:1536"
+                     :: "v"(t[0]), "v"(t[1]), "v"(t[2]), "v"(t[VR > 3 ? 3 : 0]), "v"(t[VR > 4 ? 4 : 0]), "v"(t[VR > 5 ? 5 : 0]),
+                        "v"(t[VR > 6 ? 6 : 0]) : "m0", "memory");
+}
+
+// RR row rounds, VR variable rounds; RPROF / VPROF: S_r / D_r, four bits per round (LdpcTPlan::row_prof / var_prof).  WAVES:
+// wavefronts per SIMD the register budget is sized for.  WANT_TOTAL: also write the final a-posteriori LLRs (parity tests).
 // The totals kernel names its LDS planes by immediate offsets behind M0 = 0 (ds_write_addtid_b32), i.e. it assumes that a
 // kernel whose only LDS is the dynamic allocation sees it at LDS address 0.  ultra_hip_create checks that ONCE with this
 // probe (same declaration, same launch shape) and keeps the message-passing kernel for the context if it ever fails —
@@ -56,7 +132,7 @@ __global__ void ldpc_lds_base_probe_kernel(unsigned* __restrict__ out) {
     if (threadIdx.x == 0) { lds_raw[0] = 1; out[0] = (unsigned)(size_t)lds_raw; }
 }
 
-template <int RR, int VR, int D, bool WANT_TOTAL, int WAVES>
+template <int RR, int VR, unsigned long long RPROF, unsigned long long VPROF, bool WANT_TOTAL, int WAVES>
 __global__ __launch_bounds__(kLdpcThreads, WAVES) void ldpc_totals_kernel(
     const LdpcTPlan* __restrict__ Pp, const float* __restrict__ llr, size_t llr_stride, int n_cw,
     uint8_t* __restrict__ bytes, int32_t* __restrict__ iters, uint8_t* __restrict__ okv,
@@ -74,7 +150,8 @@ __global__ __launch_bounds__(kLdpcThreads, WAVES) void ldpc_totals_kernel(
     // The LDS layout is a function of the instance (build_ldpc_tplan uses the same formulas and ultra_hip.hip checks
     // them): compile-time offsets, and the plan's scalars in locals — the "memory" clobber of the store asm would
     // otherwise make the compiler reload them from the plan inside the iteration loop.
-    constexpr unsigned T_PAD = VR * 256, R_BASE = T_PAD + 128, R_PAD = R_BASE + RR * 6 * 256, STAGE_V = R_PAD + 128,
+    constexpr int NPLANES = tprof_planes_before(RPROF, RR), D = ldpc_prof_max(VPROF, VR);
+    constexpr unsigned T_PAD = VR * 256, R_BASE = T_PAD + 128, R_PAD = R_BASE + NPLANES * 256, STAGE_V = R_PAD + 128,
                        STAGE_P = STAGE_V + VR * 256;
     const int k = P.k, max_iterations = P.max_iterations, decoded_bytes = P.decoded_bytes, n_checked = P.n_checked;
     auto ldsf = [&](unsigned byte_off) -> float& { return *reinterpret_cast<float*>(lds_raw + byte_off); };
@@ -91,13 +168,13 @@ __global__ __launch_bounds__(kLdpcThreads, WAVES) void ldpc_totals_kernel(
     for (int r = 0; r < RR; ++r) {
         row_on[r] = P.row_check[r * 64 + lane] != 0xFFFFu;
 #pragma unroll
-        for (int t = 0; t < 6; ++t) taddr[r][t] = P.row_taddr[(r * 64 + lane) * 6 + t];
+        for (int t = 0; t < 6; ++t) if (t < ldpc_prof(RPROF, r)) taddr[r][t] = P.row_taddr[(r * 64 + lane) * 6 + t];
     }
 #pragma unroll
     for (int r = 0; r < VR; ++r) {
         var_on[r] = P.var_id[r * 64 + lane] != 0xFFFFu;
 #pragma unroll
-        for (int q = 0; q < D; ++q) caddr[r][q] = P.var_caddr[(r * 64 + lane) * kTPlanDmax + q];
+        for (int q = 0; q < D; ++q) if (q < ldpc_prof(VPROF, r)) caddr[r][q] = P.var_caddr[(r * 64 + lane) * kTPlanDmax + q];
     }
     if (lane < 32) { ldsf(T_PAD + 4u * lane) = kFltMax; ldsf(R_PAD + 4u * lane) = -0.0f; }      // one pad word per bank
 
@@ -215,39 +292,33 @@ __global__ __launch_bounds__(kLdpcThreads, WAVES) void ldpc_totals_kernel(
             bool all_hold = it > 0 || (!WANT_TOTAL && max_iterations > 0);     // wave-uniform
             ldpc_static_for(std::make_integer_sequence<int, RR>{}, [&](auto round) {
                 constexpr int r = decltype(round)::value;
+                constexpr int S = ldpc_prof(RPROF, r);                         // information-edge slots of this round; the parity edge is edge S
                 float v[7], mn[7], tot[6];
                 bool ng[7], par = false;
                 // total of the parity bit after the previous iteration: llr_in + c2v (:206-213; the bit has one edge)
-                const float tp = llr_p[r] + c2v[r][6];
+                const float tp = llr_p[r] + c2v[r][S];
                 if (WANT_TOTAL) tpar[r] = tp;
 #pragma unroll
-                for (int t = 0; t < 6; ++t) tot[t] = ldsf(taddr[r][t]);
+                for (int t = 0; t < S; ++t) tot[t] = ldsf(taddr[r][t]);       // a row with fewer edges reads a pad word: FLT_MAX
                 if (all_hold) {                                                // uniform branch
                     bool synd = tp < 0;
 #pragma unroll
-                    for (int t = 0; t < 6; ++t) synd ^= (tot[t] < 0);          // hard decisions of :227-230
+                    for (int t = 0; t < S; ++t) synd ^= (tot[t] < 0);          // hard decisions of :227-230
                     all_hold = (__ballot(synd) & row_mask[r]) == 0ull;
                 }
 #pragma unroll
-                for (int t = 0; t < 6; ++t) v[t] = tot[t] - c2v[r][t];         // var_to_check = llr_total - check_to_var (:216-219)
-                v[6] = tp - c2v[r][6];
+                for (int t = 0; t < S; ++t) v[t] = tot[t] - c2v[r][t];         // var_to_check = llr_total - check_to_var (:216-219)
+                v[S] = tp - c2v[r][S];
 #pragma unroll
-                for (int t = 0; t < 7; ++t) { ng[t] = v[t] < 0; par ^= ng[t]; }
-                leave_one_out_min<7>(v, cap, mn);
+                for (int t = 0; t <= S; ++t) { ng[t] = v[t] < 0; par ^= ng[t]; }
+                leave_one_out_min<S + 1>(v, cap, mn);
 #pragma unroll
-                for (int t = 0; t < 7; ++t) {
+                for (int t = 0; t <= S; ++t) {
                     const float mag = mn[t] * 0.75f;
                     c2v[r][t] = (par != ng[t]) ? -mag : mag;                   // sign * min * 0.75f (:201)
                 }
-                // six lane-linear stores, planes named by immediate offsets behind M0 = 0 (one SALU pair for all six)
-                asm volatile("s_mov_b32 m0, 0\n\ts_nop 0\n\t"
-                             "ds_write_addtid_b32 %0 offset:%6\n\tds_write_addtid_b32 %1 offset:%7\n\t"
-                             "ds_write_addtid_b32 %2 offset:%8\n\tds_write_addtid_b32 %3 offset:%9\n\t"
-                             "ds_write_addtid_b32 %4 offset:%10\n\tds_write_addtid_b32 %5 offset:%11"
-                             :: "v"(c2v[r][0]), "v"(c2v[r][1]), "v"(c2v[r][2]), "v"(c2v[r][3]), "v"(c2v[r][4]), "v"(c2v[r][5]),
-                                "n"(R_BASE + (r * 6 + 0) * 256), "n"(R_BASE + (r * 6 + 1) * 256), "n"(R_BASE + (r * 6 + 2) * 256),
-                                "n"(R_BASE + (r * 6 + 3) * 256), "n"(R_BASE + (r * 6 + 4) * 256), "n"(R_BASE + (r * 6 + 5) * 256)
-                             : "m0", "memory");
+                // S lane-linear stores, planes named by immediate offsets behind M0 = 0
+                tprof_store_planes<S, R_BASE + tprof_planes_before(RPROF, r) * 256>(c2v[r]);
             });
             UH_LD_ACC(3);
 #ifdef UH_LDPC_STAMPS
@@ -265,39 +336,16 @@ __global__ __launch_bounds__(kLdpcThreads, WAVES) void ldpc_totals_kernel(
 #pragma unroll
                 for (int r = 0; r < VR; ++r)
 #pragma unroll
-                    for (int q = 0; q < D; ++q) c[r][q] = ldsf(caddr[r][q]);  // a missing edge reads a pad word: -0.0f
+                    for (int q = 0; q < D; ++q) if (q < ldpc_prof(VPROF, r)) c[r][q] = ldsf(caddr[r][q]);  // a missing edge reads a pad word: -0.0f
 #pragma unroll
                 for (int r = 0; r < VR; ++r) {
                     float tot = llr_v[r];
 #pragma unroll
-                    for (int q = 0; q < D; ++q) tot += c[r][q];
+                    for (int q = 0; q < D; ++q) if (q < ldpc_prof(VPROF, r)) tot += c[r][q];
                     tots[r] = tot;
                 }
             }
-            {
-                static_assert(VR >= 4 && VR <= 7, "variable rounds of the covered codes");
-                // ONE asm statement (M0 must not change between its write and the stores): the phase's lane-linear stores
-                if constexpr (VR == 4)
-                    asm volatile("s_mov_b32 m0, 0\n\ts_nop 0\n\tds_write_addtid_b32 %0\n\tds_write_addtid_b32 %1 offset:256\n\t"
-                                 "ds_write_addtid_b32 %2 offset:512\n\tds_write_addtid_b32 %3 offset:768"
-                                 :: "v"(tots[0]), "v"(tots[1]), "v"(tots[2]), "v"(tots[3]) : "m0", "memory");
-                else if constexpr (VR == 5)
-                    asm volatile("s_mov_b32 m0, 0\n\ts_nop 0\n\tds_write_addtid_b32 %0\n\tds_write_addtid_b32 %1 offset:256\n\t"
-                                 "ds_write_addtid_b32 %2 offset:512\n\tds_write_addtid_b32 %3 offset:768\n\tds_write_addtid_b32 %4 offset:1024"
-                                 :: "v"(tots[0]), "v"(tots[1]), "v"(tots[2]), "v"(tots[3]), "v"(tots[VR > 4 ? 4 : 0]) : "m0", "memory");
-                else if constexpr (VR == 6)
-                    asm volatile("s_mov_b32 m0, 0\n\ts_nop 0\n\tds_write_addtid_b32 %0\n\tds_write_addtid_b32 %1 offset:256\n\t"
-                                 "ds_write_addtid_b32 %2 offset:512\n\tds_write_addtid_b32 %3 offset:768\n\tds_write_addtid_b32 %4 offset:1024\n\t"
-                                 "ds_write_addtid_b32 %5 offset:1280"
-                                 :: "v"(tots[0]), "v"(tots[1]), "v"(tots[2]), "v"(tots[3]), "v"(tots[VR > 4 ? 4 : 0]), "v"(tots[VR > 5 ? 5 : 0])
-                                 : "m0", "memory");
-                else
-                    asm volatile("s_mov_b32 m0, 0\n\ts_nop 0\n\tds_write_addtid_b32 %0\n\tds_write_addtid_b32 %1 offset:256\n\t"
-                                 "ds_write_addtid_b32 %2 offset:512\n\tds_write_addtid_b32 %3 offset:768\n\tds_write_addtid_b32 %4 offset:1024\n\t"
-                                 "ds_write_addtid_b32 %5 offset:1280\n\tds_write_addtid_b32 %6 offset:1536"
-                                 :: "v"(tots[0]), "v"(tots[1]), "v"(tots[2]), "v"(tots[3]), "v"(tots[VR > 4 ? 4 : 0]), "v"(tots[VR > 5 ? 5 : 0]),
-                                    "v"(tots[VR > 6 ? 6 : 0]) : "m0", "memory");
-            }
+            tprof_store_totals<VR>(tots);
             UH_LD_ACC(5);
             __syncthreads();
             UH_LD_ACC(6);

@@ -21,7 +21,6 @@
 #include "demod_kernel.h"
 #include "ldpc_kernel.h"
 #include "ldpc_totals_kernel.h"
-#include "ldpc_totals_prof_kernel.h"
 #include "acquire_kernel.h"
 #include "stimulus_kernel.h"
 #include "chirp_kernel.h"
@@ -383,49 +382,33 @@ int launch_ldpc(ultra_hip_ctx* ctx, const float* d_llr, size_t llr_stride, size_
         if (T.t_pad != T.var_rounds * 256 || T.r_base != T.t_pad + 128 || T.r_pad != T.r_base + T.n_planes * 256 ||
             T.stage_v != T.r_pad + 128 || T.stage_p != T.stage_v + T.var_rounds * 256 || T.lds_bytes != T.stage_p + T.row_rounds * 256)
             return ULTRA_HIP_ERR_UNSUPPORTED;
-#define UH_TOTALS_LAUNCH(RR, VR, D, WV)                                                                           \
+// one instance per code: (row rounds, variable rounds, row profile, variable profile); the plan's profiles select it
+#define UH_TOTALS_LAUNCH(RR, VR, RP, VP, WV)                                                                      \
     do {                                                                                                          \
         LaunchSpan span(ctx, ULTRA_HIP_K_LDPC);                                                                   \
         const size_t per_cu = std::max<size_t>(1, std::min<size_t>(4 * (WV), (size_t)(160 * 1024) / tlds));       \
         const unsigned grid = (unsigned)std::min(n_cw, (size_t)ctx->cu_count * per_cu);                           \
         if (d_llr_total)                                                                                          \
-            hipLaunchKernelGGL((dev::ldpc_totals_kernel<RR, VR, D, true, WV>), dim3(grid), dim3(dev::kLdpcThreads), tlds, \
-                               ctx->stream, ctx->d_tplan, d_llr, llr_stride, (int)n_cw, d_bytes, d_iters, d_ok,   \
-                               d_llr_total, counter, (int)ctx->deint_step, ctx->d_deint_table, block_len, block_stride);                                       \
-        else                                                                                                      \
-            hipLaunchKernelGGL((dev::ldpc_totals_kernel<RR, VR, D, false, WV>), dim3(grid), dim3(dev::kLdpcThreads), tlds, \
-                               ctx->stream, ctx->d_tplan, d_llr, llr_stride, (int)n_cw, d_bytes, d_iters, d_ok,   \
-                               d_llr_total, counter, (int)ctx->deint_step, ctx->d_deint_table, block_len, block_stride);                                       \
-    } while (0)
-        // the codes with irregular rows: the profile-templated twin (ldpc_totals_prof_kernel.h), one instance per placement
-#define UH_TOTALS_PROF_LAUNCH(RR, VR, RP, VP, WV)                                                                 \
-    do {                                                                                                          \
-        LaunchSpan span(ctx, ULTRA_HIP_K_LDPC);                                                                   \
-        const size_t per_cu = std::max<size_t>(1, std::min<size_t>(4 * (WV), (size_t)(160 * 1024) / tlds));       \
-        const unsigned grid = (unsigned)std::min(n_cw, (size_t)ctx->cu_count * per_cu);                           \
-        if (d_llr_total)                                                                                          \
-            hipLaunchKernelGGL((dev::ldpc_totals_prof_kernel<RR, VR, RP, VP, true, WV>), dim3(grid), dim3(dev::kLdpcThreads), tlds, \
+            hipLaunchKernelGGL((dev::ldpc_totals_kernel<RR, VR, RP, VP, true, WV>), dim3(grid), dim3(dev::kLdpcThreads), tlds, \
                                ctx->stream, ctx->d_tplan, d_llr, llr_stride, (int)n_cw, d_bytes, d_iters, d_ok,   \
                                d_llr_total, counter, (int)ctx->deint_step, ctx->d_deint_table, block_len, block_stride); \
         else                                                                                                      \
-            hipLaunchKernelGGL((dev::ldpc_totals_prof_kernel<RR, VR, RP, VP, false, WV>), dim3(grid), dim3(dev::kLdpcThreads), tlds, \
+            hipLaunchKernelGGL((dev::ldpc_totals_kernel<RR, VR, RP, VP, false, WV>), dim3(grid), dim3(dev::kLdpcThreads), tlds, \
                                ctx->stream, ctx->d_tplan, d_llr, llr_stride, (int)n_cw, d_bytes, d_iters, d_ok,   \
                                d_llr_total, counter, (int)ctx->deint_step, ctx->d_deint_table, block_len, block_stride); \
     } while (0)
+        auto is = [&](int rr, int vr, unsigned long long rp, unsigned long long vp) {
+            return T.row_rounds == rr && T.var_rounds == vr && T.row_prof == rp && T.var_prof == vp;
+        };
         bool launched = true;
-        if (T.row_rounds == 8 && T.var_rounds == 3 && T.row_prof == kPlaceRowProf_R1_4 && T.var_prof == kPlaceVarProf_R1_4)
-            UH_TOTALS_PROF_LAUNCH(8, 3, kPlaceRowProf_R1_4, kPlaceVarProf_R1_4, 3);                                // R1/4
-        else if (T.row_rounds == 6 && T.var_rounds == 6 && T.row_prof == kPlaceRowProf_R1_3 && T.var_prof == kPlaceVarProf_R1_3)
-            UH_TOTALS_PROF_LAUNCH(6, 6, kPlaceRowProf_R1_3, kPlaceVarProf_R1_3, 4);                                // R1/3
-        else if (T.row_rounds == 6 && T.var_rounds == 6 && T.row_prof == kPlaceRowProf_R1_2 && T.var_prof == kPlaceVarProf_R1_2)
-            UH_TOTALS_PROF_LAUNCH(6, 6, kPlaceRowProf_R1_2, kPlaceVarProf_R1_2, 4);                                // R1/2
-        else if (T.row_rounds == 3 && T.var_rounds == 6 && T.dmax == 3) UH_TOTALS_LAUNCH(3, 6, 3, 5);             // R3/4
-        else if (T.row_rounds == 2 && T.var_rounds == 4 && T.dmax == 3) UH_TOTALS_LAUNCH(2, 4, 3, 6);             // R5/6
-        else if (T.row_rounds == 4 && T.var_rounds == 7 && T.dmax == 3) UH_TOTALS_LAUNCH(4, 7, 3, 4);             // R2/3
-        else if (T.row_rounds == 4 && T.var_rounds == 7 && T.dmax == 4) UH_TOTALS_LAUNCH(4, 7, 4, 4);
+        if (is(3, 6, 0x666ull, 0x333333ull)) UH_TOTALS_LAUNCH(3, 6, 0x666ull, 0x333333ull, 5);                      // R3/4
+        else if (is(2, 4, 0x66ull, 0x3333ull)) UH_TOTALS_LAUNCH(2, 4, 0x66ull, 0x3333ull, 6);                       // R5/6
+        else if (is(4, 7, 0x6666ull, 0x3333333ull)) UH_TOTALS_LAUNCH(4, 7, 0x6666ull, 0x3333333ull, 4);             // R2/3
+        else if (is(8, 3, kPlaceRowProf_R1_4, kPlaceVarProf_R1_4)) UH_TOTALS_LAUNCH(8, 3, kPlaceRowProf_R1_4, kPlaceVarProf_R1_4, 3);   // R1/4
+        else if (is(6, 6, kPlaceRowProf_R1_3, kPlaceVarProf_R1_3)) UH_TOTALS_LAUNCH(6, 6, kPlaceRowProf_R1_3, kPlaceVarProf_R1_3, 4);   // R1/3
+        else if (is(6, 6, kPlaceRowProf_R1_2, kPlaceVarProf_R1_2)) UH_TOTALS_LAUNCH(6, 6, kPlaceRowProf_R1_2, kPlaceVarProf_R1_2, 4);   // R1/2
         else launched = false;
 #undef UH_TOTALS_LAUNCH
-#undef UH_TOTALS_PROF_LAUNCH
         if (launched) { UH_HIP(hipGetLastError()); return ULTRA_HIP_OK; }
     }
     const size_t lds = dev::ldpc_lds_bytes(P.msg_words);

@@ -155,8 +155,8 @@ def main():
     clk = costs["clock_ghz"] * 1e9
     print(f"# costs (profiles/r02_issue_table.txt, W = 5 wavefronts per SIMD): 2-cycle class {costs['fast']:.2f}, 4-cycle class {costs['slow']:.2f}, "
           f"8-cycle class {costs['eight']:.2f}, readlane {costs['readlane']:.2f}, scalar {costs['salu']:.2f} cycles per wave-instruction; clock {costs['clock_ghz']:.3f} GHz")
-    want = [("ldpc_totals_kernelILi3ELi6ELi3ELb0", "ldpc_totals_kernel<3, 6, 3, false", True),
-            ("ldpc_totals_prof_kernelILi8ELi3E", "ldpc_totals_prof_kernel<8, 3", True),          # R1/4 (cfg4), round 4
+    want = [("ldpc_totals_kernelILi3ELi6ELy1638ELy3355443ELb0", "ldpc_totals_kernel<3, 6, 1638ull, 3355443ull, false", True),    # R3/4
+            ("ldpc_totals_kernelILi8ELi3E", "ldpc_totals_kernel<8, 3", True),          # R1/4 (cfg4), round 4
             ("ldpc_decode_kernelILi3ELi6E", "ldpc_decode_kernel<3, 6", True),
             ("ldpc_decode_kernelILi8ELi3E", "ldpc_decode_kernel<8, 3", True),
             ("mix_fft2_kernelILi10ELb1E", "mix_fft2_kernel<10, true>", False), ("mix_fft2_kernelILi10ELb0E", "mix_fft2_kernel<10, false>", False), ("mix_fft_kernelILi10E", "mix_fft_kernel<10>", False),
@@ -166,7 +166,7 @@ def main():
             ("track_pilot_kernelILi16E", "track_pilot_kernel<16>", False), ("cfo_walk_kernel", "cfo_walk_kernel", False),
             ("acquire_kernelILi10ELb0E", "acquire_kernel<10, false>", False), ("chirp_sync_kernel", "chirp_sync_kernel", False)]
     for key, pmc_key, is_ldpc in want:
-        names = [n for n in fns if key in n and ("Lb0ELi" in n or not is_ldpc or ("totals" in n and "prof" not in n))]
+        names = [n for n in fns if key in n and ("Lb0ELi" in n or not is_ldpc or "totals" in n)]
         if is_ldpc and "decode_kernel" in key:
             names = [n for n in fns if key in n and "Lb0ELi" in n]            # WANT_TOTAL = false instance
         if not names:

@@ -1,5 +1,5 @@
 // tools/ldpc_place_low.cpp — offline placement solver for the totals LDPC kernel on the three LOW-RATE codes (R1/4, R1/3,
-// R1/2): tools/ldpc_place.cpp generalised to irregular rows and variables (csrc/ldpc_totals_prof_kernel.h).
+// R1/2): tools/ldpc_place.cpp generalised to irregular rows and variables (csrc/ldpc_totals_kernel.h, whose degree profiles are template arguments).
 //
 // Rows have 1..6 information edges and variables 4..13 (src/fec/ldpc_decoder.cpp:64-137 builds H = [H_data | I] with a fixed
 // column weight per code and whatever row weights the mt19937 draws give).  The kernel runs round r of its row phase with
@@ -121,7 +121,7 @@ int main(int argc, char** argv) {
     else { const int p0[8] = {6, 6, 6, 5, 5, 4, 3, 2}; for (int r = 0; r < 8; ++r) g_row_profile[0][r] = p0[r]; }
     const char* names[6] = {"R1_4", "R1_3", "R1_2", "R2_3", "R3_4", "R5_6"};
     std::printf("// ldpc_placement_low.h — GENERATED by tools/ldpc_place_low.cpp (simulated annealing, fixed seeds); do not edit.\n"
-                "// Slots of the variables and rows of the profile-templated totals LDPC kernel (csrc/ldpc_totals_prof_kernel.h) for the\n"
+                "// Slots of the variables and rows of the totals LDPC kernel (csrc/ldpc_totals_kernel.h) for the\n"
                 "// codes with irregular rows: var slot = round * 64 + lane, row slot = round * 64 + lane; rows and variables sit in rounds\n"
                 "// whose profile (S_r information-edge slots / D_r edges) covers their degree.  Validated against the code's Tanner graph\n"
                 "// by build_ldpc_tplan (csrc/host_tables.h) at context creation.\n"

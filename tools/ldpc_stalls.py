@@ -35,7 +35,7 @@ def static_phases(flags):
                                    "-fhip-fp32-correctly-rounded-divide-sqrt", "-DUH_LDPC_STAMPS"] + flags + ["-S", "--cuda-device-only", "-o", "-", str(src)],
                                   stderr=subprocess.DEVNULL, cwd=src.parent).decode()
     fns = im.functions(asm)
-    body = next(v for k, v in fns.items() if "ldpc_totals_kernelILi3ELi6ELi3ELb0E" in k)
+    body = next(v for k, v in fns.items() if "ldpc_totals_kernelILi3ELi6ELy1638ELy3355443ELb0E" in k)
     cuts = [(i, int(re.search(r"UHLDSTAMP (\d+)", l).group(1))) for i, l in enumerate(body) if "UHLDSTAMP" in l]
     # the code IN FRONT of marker k belongs to phase k (the accumulation closes the phase); marker order in the loop: 3, 4, 5, 6
     out = {}
@@ -94,7 +94,7 @@ def main():
         res.append(life[m].sum() / (rec[m, 1].max() - rec[m, 0].min()))
     W = float(np.mean(res))
     full = iters == 50
-    print(f"# ldpc_totals_kernel<3,6,3,false,5> (R3/4), {n} codewords of the headline workload; decode with stamps on {e0.elapsed_time(e1):.3f} ms, "
+    print(f"# ldpc_totals_kernel<3, 6, 0x666, 0x333333, false, 5> (R3/4), {n} codewords of the headline workload; decode with stamps on {e0.elapsed_time(e1):.3f} ms, "
           f"the same library with the stamp buffer off {e2.elapsed_time(e3):.3f} ms")
     print(f"# codewords that run all 50 iterations: {full.mean() * 100:.1f} % ({executed[full].sum() / executed.sum() * 100:.1f} % of the executed iterations); "
           f"mean iterations {iters.mean():.2f}; SIMDs seen {len(res)}; wavefronts decoding at a time per SIMD (sum of lifetimes / span): mean {W:.2f}")
