@@ -33,7 +33,7 @@
 extern "C" {
 #endif
 
-#define ULTRA_HIP_ABI_VERSION 6
+#define ULTRA_HIP_ABI_VERSION 7
 
 /* ultra::Modulation (include/ultra/types.hpp:27-39) — same numeric values. */
 enum ultra_hip_modulation {
@@ -91,6 +91,15 @@ typedef struct ultra_hip_config {
     uint32_t n_data_symbols;   /* data symbols per frame fed to the demodulator    */
     uint32_t entry;            /* ultra_hip_entry                                  */
     uint32_t training_symbols; /* ULTRA_ENTRY_PRESYNCED only (reference default 2) */
+    /* The decision-directed adaptive equaliser of the coherent modulations (ModemConfig, include/ultra/types.hpp:170-174;
+     * Impl::equalize's use_adaptive branch, lmsUpdate / rlsUpdate: src/ofdm/channel_equalizer.cpp:569-581,705-722,
+     * 773-805).  All zero (a zero-initialised struct) = off, the state of every preset the reference ships.  The
+     * differential modulations never reach that branch (equalize returns at :769): the fields have no effect on them. */
+    uint32_t adaptive_eq_enabled; /* 0/1: equalise the data carriers against lms_weights instead of channel_estimate  */
+    uint32_t adaptive_eq_use_rls; /* 0 LMS (lms_mu), 1 RLS (rls_lambda)                                               */
+    uint32_t decision_directed;   /* 0/1: update the weights from the hard decision of every equalised carrier        */
+    float lms_mu;                 /* ModemConfig::lms_mu (0.05)                                                       */
+    float rls_lambda;             /* ModemConfig::rls_lambda (0.99)                                                   */
 } ultra_hip_config;
 
 /* Geometry derived from a config (ModemConfig::getCyclicPrefix /

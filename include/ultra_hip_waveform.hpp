@@ -59,6 +59,9 @@ struct ModemConfig {                       // receive-path fields of ultra::Mode
     bool use_pilots = true;
     Modulation modulation = Modulation::QPSK;
     CodeRate code_rate = CodeRate::R1_2;
+    bool adaptive_eq_enabled = false, adaptive_eq_use_rls = false;   // types.hpp:170-174
+    float lms_mu = 0.05f, rls_lambda = 0.99f;
+    bool decision_directed = true;
 };
 struct SyncResult {
     bool detected = false; int start_sample = -1; float correlation = 0.0f; float cfo_hz = 0.0f;
@@ -75,6 +78,8 @@ inline ultra_hip_config to_c_config(const ModemConfig& c, uint32_t entry, uint32
     k.modulation = static_cast<uint32_t>(c.modulation); k.code_rate = static_cast<uint32_t>(c.code_rate);
     k.max_iterations = max_iterations; k.n_data_symbols = n_data_symbols; k.entry = entry;
     k.training_symbols = (entry == ULTRA_ENTRY_PRESYNCED) ? training_symbols : 0;
+    k.adaptive_eq_enabled = c.adaptive_eq_enabled ? 1u : 0u; k.adaptive_eq_use_rls = c.adaptive_eq_use_rls ? 1u : 0u;
+    k.decision_directed = c.decision_directed ? 1u : 0u; k.lms_mu = c.lms_mu; k.rls_lambda = c.rls_lambda;
     return k;
 }
 

@@ -61,6 +61,9 @@ ModemConfig to_cfg(const ultra_hip_config* c) {
     m.use_pilots = c->use_pilots != 0;
     m.modulation = static_cast<Modulation>(c->modulation);
     m.code_rate = static_cast<CodeRate>(c->code_rate);
+    m.adaptive_eq_enabled = c->adaptive_eq_enabled != 0;
+    m.adaptive_eq_use_rls = c->adaptive_eq_use_rls != 0;
+    if (c->adaptive_eq_enabled) { m.decision_directed = c->decision_directed != 0; m.lms_mu = c->lms_mu; m.rls_lambda = c->rls_lambda; }
     return m;
 }
 

@@ -600,6 +600,9 @@ typedef struct demod {
     int n_lts; cf lts_carrier_phases[MAX_CARRIERS];
     int n_dprev; cf dbpsk_prev_equalized[MAX_CARRIERS];
     float carrier_noise_var[MAX_CARRIERS];
+    /* adaptive equaliser (demodulator_impl.hpp:114-116; constructed :35-38 as (1,0) / (0,0) / 1.0) */
+    cf lms_weights[MAX_FFT], last_decisions[MAX_FFT];
+    float rls_P[MAX_FFT];
 
     /* output */
     float* soft; size_t n_soft, soft_cap;
@@ -632,6 +635,13 @@ static void build_interp(demod* d) {
     }
 }
 
+/* the adaptive equaliser's state as the constructor (demodulator.cpp:35-38), reset() (:1014-1016), the processPresynced
+ * reset block (:894-897) and the mid-frame re-sync (:653-655) leave it */
+static void adaptive_eq_reset(demod* d) {
+    for (uint32_t i = 0; i < d->cfg.fft_size; ++i) {
+        d->lms_weights[i] = c_make(1, 0); d->last_decisions[i] = c_make(0, 0); d->rls_P[i] = 1.0f;
+    }
+}
 /* Impl::Impl, src/ofdm/demodulator.cpp:26-43 + member defaults demodulator_impl.hpp */
 static int demod_init(demod* d, const ultra_hip_config* c) {
     memset(d, 0, sizeof(*d));
@@ -647,6 +657,7 @@ static int demod_init(demod* d, const ultra_hip_config* c) {
     d->noise_variance = 0.1f; d->estimated_snr_linear = 1.0f; d->snr_alpha = 0.3f;
     d->pilot_phase_correction = c_make(1, 0);
     d->carrier_phase_correction = c_make(1, 0);
+    adaptive_eq_reset(d);
     build_interp(d);
     return 0;
 }
@@ -848,6 +859,12 @@ static void update_channel_estimate(demod* d, const cf* freq) {
         }
     }
 
+    /* adaptive equaliser weights start from the pilot-based estimate during the first three symbols (:569-581) */
+    if (d->cfg.adaptive_eq_enabled && d->snr_symbol_count < 3) {
+        for (int i = 0; i < cr->n_data; ++i) d->lms_weights[cr->data_idx[i]] = d->channel_estimate[cr->data_idx[i]];
+        for (int i = 0; i < cr->n_pilot; ++i) d->lms_weights[cr->pilot_idx[i]] = d->channel_estimate[cr->pilot_idx[i]];
+    }
+
     /* noise variance + SNR EMA (:583-592) */
     if (noise_count > 1 && noise_power_sum > 0.0f) {
         d->noise_variance = noise_power_sum / (float)(noise_count - 1);
@@ -859,7 +876,50 @@ static void update_channel_estimate(demod* d, const cf* freq) {
     d->snr_symbol_count++;
 }
 
-/* Impl::equalize (adaptive_eq_enabled == false), src/ofdm/channel_equalizer.cpp:728-840 */
+/* Impl::hardDecision, src/ofdm/channel_equalizer.cpp:637-700 */
+static float slice_qam16(float x) { return (x < -0.4f) ? -0.9487f : (x < 0.0f) ? -0.3162f : (x < 0.4f) ? 0.3162f : 0.9487f; }
+static float slice8(float x, float d) {
+    if (x < -6 * d) return -7 * d;
+    if (x < -4 * d) return -5 * d;
+    if (x < -2 * d) return -3 * d;
+    if (x < 0) return -d;
+    if (x < 2 * d) return d;
+    if (x < 4 * d) return 3 * d;
+    if (x < 6 * d) return 5 * d;
+    return 7 * d;
+}
+static cf hard_decision(cf sym, uint32_t mod) {
+    switch (mod) {
+        case ULTRA_MOD_BPSK: return c_make(sym.re > 0 ? 1.0f : -1.0f, 0);
+        case ULTRA_MOD_QAM16: return c_make(slice_qam16(sym.re), slice_qam16(sym.im));
+        case ULTRA_MOD_QAM32: {
+            const float d = 0.1961161351381840f;   /* QAM32_SCALE, demodulator_constants.hpp:90 */
+            float I = (sym.re < -2 * d) ? -3 * d : (sym.re < 0) ? -d : (sym.re < 2 * d) ? d : 3 * d;
+            return c_make(I, slice8(sym.im, d));
+        }
+        case ULTRA_MOD_QAM64: return c_make(slice8(sym.re, 0.1543f), slice8(sym.im, 0.1543f));
+        case ULTRA_MOD_QPSK:
+        default: return c_make(sym.re > 0 ? 0.7071f : -0.7071f, sym.im > 0 ? 0.7071f : -0.7071f);
+    }
+}
+/* Impl::lmsUpdate / rlsUpdate, src/ofdm/channel_equalizer.cpp:705-722 */
+static void lms_update(demod* d, int idx, cf received, cf reference) {
+    float mu = d->cfg.lms_mu;
+    cf error = c_sub(received, c_mul(d->lms_weights[idx], reference));
+    d->lms_weights[idx] = c_add(d->lms_weights[idx], c_mul(c_scale(c_conj(reference), mu), error));
+}
+static void rls_update(demod* d, int idx, cf received, cf reference) {
+    float lambda = d->cfg.rls_lambda;
+    float P = d->rls_P[idx];
+    float ref_norm = c_norm(reference);
+    float k = P / (lambda + P * ref_norm);
+    cf error = c_sub(received, c_mul(d->lms_weights[idx], reference));
+    d->lms_weights[idx] = c_add(d->lms_weights[idx], c_mul(c_scale(c_conj(reference), k), error));
+    d->rls_P[idx] = (P - k * ref_norm * P) / lambda;
+    d->rls_P[idx] = f_max(0.001f, f_min(1000.0f, d->rls_P[idx]));   /* ADAPTIVE_EQ_P_MIN / _MAX */
+}
+
+/* Impl::equalize, src/ofdm/channel_equalizer.cpp:728-840 */
 static void equalize(demod* d, const cf* freq, cf* eq) {
     const carriers* cr = &d->cr;
     const int nd = cr->n_data;
@@ -885,6 +945,25 @@ static void equalize(demod* d, const cf* freq, cf* eq) {
     }
     for (int i = 0; i < nd; ++i) {
         int idx = cr->data_idx[i];
+        if (d->cfg.adaptive_eq_enabled) {                  /* :779-805 — no clamp of the noise variance on this branch */
+            cf received = freq[idx], h = d->lms_weights[idx];
+            float h_power = c_norm(h);
+            float mmse_denom = h_power + d->noise_variance;
+            if (mmse_denom < 1e-10f) {
+                eq[i] = c_make(0, 0);
+                d->carrier_noise_var[i] = 100.0f;
+            } else {
+                eq[i] = c_divf(c_mul(c_conj(h), received), mmse_denom);
+                d->carrier_noise_var[i] = d->noise_variance / (h_power + 1e-6f);
+            }
+            if (d->cfg.decision_directed) {
+                cf decision = hard_decision(eq[i], mod);
+                if (d->cfg.adaptive_eq_use_rls) rls_update(d, idx, received, decision);
+                else lms_update(d, idx, received, decision);
+                d->last_decisions[idx] = decision;
+            }
+            continue;
+        }
         cf received = freq[idx], h = d->channel_estimate[idx];
         float h_power = c_norm(h);
         float mmse_denom = h_power + d->noise_variance;
@@ -1270,6 +1349,7 @@ static int demod_presynced_run(demod* d, const float* audio, size_t n_samples, f
     d->snr_symbol_count = 0; d->estimated_snr_linear = 1.0f; d->noise_variance = 0.1f;
     d->symbols_since_sync = 0; d->n_prev = 0; d->pilot_phase_correction = c_make(1, 0);
     d->n_dprev = 0; d->carrier_phase_initialized = 0; d->carrier_phase_correction = c_make(1, 0);
+    adaptive_eq_reset(d);                                   /* :894-897 */
     const float* ptr = audio; size_t remaining = n_samples;
     if (c->training_symbols > 0) {
         size_t tcount = (size_t)c->training_symbols * d->symbol_samples;
@@ -1356,6 +1436,7 @@ static void* batch_worker(void* arg) {
         d->noise_variance = 0.1f; d->estimated_snr_linear = 1.0f; d->snr_symbol_count = 0;
         d->n_prev = 0; d->pilot_phase_correction = c_make(1, 0); d->timing_offset_samples = 0.0f;
         d->n_lts = 0; d->n_dprev = 0; d->mixer.phase = 0;
+        adaptive_eq_reset(d);
         d->soft = llr; d->soft_cap = g.llrs_per_frame; d->n_soft = 0;
         if (c->entry == ULTRA_ENTRY_PRESYNCED) {
             demod_presynced_run(d, a, g.frame_samples, cfo, ph, bb, freq, eq);

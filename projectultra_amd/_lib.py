@@ -17,7 +17,7 @@ PKG_DIR = Path(__file__).resolve().parent
 LIB_PATH = Path(os.environ["ULTRA_HIP_LIB"]).resolve() if os.environ.get("ULTRA_HIP_LIB") else PKG_DIR / "libultra_hip.so"
 CSRC_DIR = PKG_DIR / "csrc"
 
-ULTRA_HIP_ABI_VERSION = 6
+ULTRA_HIP_ABI_VERSION = 7
 STATE_FLOATS = 8
 
 
@@ -32,7 +32,8 @@ class ultra_hip_config(C.Structure):
     _fields_ = [(n, C.c_uint32) for n in (
         "sample_rate", "center_freq", "fft_size", "num_carriers", "cp_mode", "symbol_guard",
         "pilot_spacing", "use_pilots", "modulation", "code_rate", "max_iterations",
-        "n_data_symbols", "entry", "training_symbols")]
+        "n_data_symbols", "entry", "training_symbols",
+        "adaptive_eq_enabled", "adaptive_eq_use_rls", "decision_directed")] + [("lms_mu", C.c_float), ("rls_lambda", C.c_float)]
 
 
 class ultra_hip_geometry(C.Structure):

@@ -178,7 +178,11 @@ constexpr int kStScal = 0;          // 16 scalars, see st_* below
 constexpr int kStH = 16;            // c32 H[64]
 constexpr int kStPrev = 16 + 128;   // c32 prev_pilot_phases[64]
 constexpr int kStDprev = 16 + 256;  // c32 dbpsk_prev_equalized[64]
-constexpr int kStLts = 16 + 384;    // c32 h_sum_pilot[64] (presynced)
+constexpr int kStLts = 16 + 384;    // c32 h_sum_pilot[<= 32 pilots] (presynced)
+// adaptive equaliser (coherent layouts only, so the differential reference's slot is free): lms_weights by data carrier,
+// rls_P by data carrier in the unused half of the LTS sums' slot
+constexpr int kStLms = kStDprev;    // c32 lms_weights[64]
+constexpr int kStRlsP = kStLts + 64; // float rls_P[64]
 // Coherent layouts with pilots: between symbols only the PILOTS' channel estimates are state (every other carrier is
 // interpolated afresh per symbol, channel_equalizer.cpp:515-567), so they travel by pilot index in one cache line of
 // their own — the pilot half then reads and writes 128 contiguous bytes instead of every fourth entry of H[64], and the
@@ -974,13 +978,44 @@ __device__ __forceinline__ void demap_carrier(c32 sym, c32 prev, float nv, float
     }
 }
 
-// equalize (channel_equalizer.cpp:728-840, adaptive_eq off) + demodulateSymbol
+// Impl::hardDecision (channel_equalizer.cpp:637-700): the slicer of the adaptive equaliser's decisions
+__device__ __forceinline__ float slice8(float x, float d) {
+    if (x < -6 * d) return -7 * d;
+    if (x < -4 * d) return -5 * d;
+    if (x < -2 * d) return -3 * d;
+    if (x < 0) return -d;
+    if (x < 2 * d) return d;
+    if (x < 4 * d) return 3 * d;
+    if (x < 6 * d) return 5 * d;
+    return 7 * d;
+}
+template <int MOD>
+__device__ __forceinline__ c32 hard_decision(c32 sym) {
+    if (MOD == ULTRA_MOD_BPSK) return mk(sym.re > 0 ? 1.0f : -1.0f, 0.0f);
+    if (MOD == ULTRA_MOD_QAM16) {
+        auto slice = [](float x) { return (x < -0.4f) ? -0.9487f : (x < 0.0f) ? -0.3162f : (x < 0.4f) ? 0.3162f : 0.9487f; };
+        return mk(slice(sym.re), slice(sym.im));
+    }
+    if (MOD == ULTRA_MOD_QAM32) {
+        const float d = 0.1961161351381840f;                // QAM32_SCALE, demodulator_constants.hpp:90
+        const float I = (sym.re < -2 * d) ? -3 * d : (sym.re < 0) ? -d : (sym.re < 2 * d) ? d : 3 * d;
+        return mk(I, slice8(sym.im, d));
+    }
+    if (MOD == ULTRA_MOD_QAM64) return mk(slice8(sym.re, 0.1543f), slice8(sym.im, 0.1543f));
+    return mk(sym.re > 0 ? 0.7071f : -0.7071f, sym.im > 0 ? 0.7071f : -0.7071f);      // QPSK and every other value
+}
+// The adaptive equaliser's per-carrier state, held by the lane of the data carrier (track_kernel)
+struct AdaptiveEq { c32 w; float P; };
+
+// equalize (channel_equalizer.cpp:728-840) + demodulateSymbol
 // (demodulator.cpp:199-435) for one symbol; dprev = dbpsk_prev_equalized[lane]
 template <int MOD>
 __device__ __forceinline__ void equalize_demap(TrackShared& sh, const DemodConst& D, const LaneConst& lc, Track& tr,
                                                c32& dprev, const c32* __restrict__ fq, float* __restrict__ llr_sym,
                                                float* dprev_abs = nullptr, const c32* tc_fixed = nullptr,
-                                               const c32* received_in = nullptr) {
+                                               const c32* received_in = nullptr, AdaptiveEq* ad = nullptr) {
+    // ad (coherent layouts, nullable): equalise against lms_weights instead of channel_estimate and update them from the
+    // hard decisions (use_adaptive branch, :779-805; lmsUpdate / rlsUpdate :705-722)
     // received_in (nullable): this lane's bin, where the caller has requested it ahead of time (track_all_kernel)
     // dprev_abs (differential layouts, nullable): |dprev| carried from symbol to symbol by the caller (negative: not known)
     // — the previous symbol's |sym| is this symbol's |prev|.  tc_fixed (nullable): the timing-phase factor of this lane
@@ -1014,6 +1049,30 @@ __device__ __forceinline__ void equalize_demap(TrackShared& sh, const DemodConst
         if (is_data) {
             const c32 received = received_in ? *received_in : fq[lc.data_fq], h = sh.H[lc.data_slot];
             h_power = cnorm(h);
+            if (ad) {
+                const c32 w = ad->w;
+                const float w_power = cnorm(w), denom = w_power + tr.noise_variance;
+                if (denom < 1e-10f) {
+                    eq = mk(0.0f, 0.0f);
+                    nv = 100.0f;
+                } else {
+                    eq = cdivf(cmul(cconj(w), received), denom);
+                    nv = tr.noise_variance / (w_power + 1e-6f);           // not clamped on this branch (:789-791)
+                }
+                if (D.decision_directed) {
+                    const c32 ref = hard_decision<MOD>(eq);
+                    const c32 err = csub(received, cmul(w, ref));
+                    if (D.adaptive_eq == 2) {
+                        const float lambda = D.rls_lambda, P = ad->P, ref_norm = cnorm(ref);
+                        const float k = P / (lambda + P * ref_norm);
+                        ad->w = cadd(w, cmul(cscale(cconj(ref), k), err));
+                        const float Pn = (P - k * ref_norm * P) / lambda;
+                        ad->P = fmax_std(0.001f, fmin_std(1000.0f, Pn));    // ADAPTIVE_EQ_P_MIN / _MAX
+                    } else {
+                        ad->w = cadd(w, cmul(cscale(cconj(ref), D.lms_mu), err));
+                    }
+                }
+            } else {
             const float mmse_denom = h_power + tr.noise_variance;
             if (mmse_denom < 1e-10f) {
                 eq = mk(0.0f, 0.0f);
@@ -1022,6 +1081,7 @@ __device__ __forceinline__ void equalize_demap(TrackShared& sh, const DemodConst
                 eq = cdivf(cmul(cconj(h), received), mmse_denom);
                 nv = tr.noise_variance / (h_power + 1e-6f);
                 nv = fmax_std(1e-6f, fmin_std(100.0f, nv));
+            }
             }
         }
         float avg = ordered_sum(sh.fbuf, h_power, nd);          // deep-fade soft erasure (:822-837)
@@ -1109,10 +1169,14 @@ __device__ __forceinline__ void lts_finish(TrackShared& sh, const DemodConst& D,
 // block of processPresynced :868-905).
 __global__ __launch_bounds__(kWave) void init_state_kernel(const float* __restrict__ cfo_hz,
                                                            const float* __restrict__ cfo_phase, int n_frames,
-                                                           float* __restrict__ state, int compact) {
+                                                           float* __restrict__ state, int compact, int adaptive) {
     const int lane = threadIdx.x;
     for (int frame = blockIdx.x; frame < n_frames; frame += gridDim.x) {
         float* st = state + (size_t)frame * kStFloats;
+        if (adaptive) {                                     // lms_weights = (1, 0), rls_P = 1 (demodulator.cpp:35-38,894-897)
+            reinterpret_cast<c32*>(st + kStLms)[lane] = mk(1.0f, 0.0f);
+            st[kStRlsP + lane] = 1.0f;
+        }
         // channel_estimate = (1, 0) everywhere: the pilots' line for the compact layouts (the training kernel, where there
         // is one, works on the full array and fills both), the whole array otherwise
         if (!compact) reinterpret_cast<c32*>(st + kStH)[lane] = mk(1.0f, 0.0f);
@@ -1401,6 +1465,11 @@ __global__ __launch_bounds__(kWave, 6) void track_kernel(
         if (!compact) sh.H[lane] = reinterpret_cast<const c32*>(st + kStH)[lane];
         else if (lane < D.n_pilot) sh.H[lc.pilot_slot] = reinterpret_cast<const c32*>(st + kStHp)[lane];   // the rest is interpolated before it is read
         c32 dprev = D.differential ? reinterpret_cast<const c32*>(st + kStDprev)[lane] : mk(1.0f, 0.0f);
+        // adaptive equaliser (coherent layouts): the data carrier's weight and RLS gain live in its lane between symbols
+        const bool adaptive = D.adaptive_eq != 0 && !D.differential;
+        AdaptiveEq ad;
+        ad.w = mk(1.0f, 0.0f); ad.P = 1.0f;
+        if (adaptive) { ad.w = reinterpret_cast<const c32*>(st + kStLms)[lane]; ad.P = st[kStRlsP + lane]; }
         wave_sync();
         // differential layouts: |dprev| travels with dprev through the symbols of this launch; without pilots the timing
         // estimate never moves, so its phase factor is evaluated once per frame (equalize_demap)
@@ -1411,10 +1480,15 @@ __global__ __launch_bounds__(kWave, 6) void track_kernel(
         for (int ds = 0; ds < n_sym_batch; ++ds) {
             const c32* fq = fq_all + ((size_t)ds * n_frames + frame) * (2 * D.fq_half);
             if (scalar_pilot_half) { tr.ppc = mk(1.0f, 0.0f); tr.has_prev = 0; tr.snr_symbol_count++; }
-            if (!D.presynced || D.n_pilot != 0) finish_channel_estimate(sh, D, lc, tr);
+            if (!D.presynced || D.n_pilot != 0) {
+                finish_channel_estimate(sh, D, lc, tr);
+                // updateChannelEstimate seeds the weights from its estimate while snr_symbol_count < 3 (:569-581) — the
+                // count BEFORE its increment at the end of the update, which the pilot half has already taken
+                if (adaptive && tr.snr_symbol_count - 1 < 3 && lane < D.n_data) ad.w = sh.H[lc.data_slot];
+            }
             equalize_demap<MOD>(sh, D, lc, tr, dprev, fq,
                                 llr + (size_t)frame * llr_stride + (size_t)(data_sym + ds) * D.llrs_per_symbol,
-                                &dprev_abs, tc_is_fixed ? &tc0 : nullptr);
+                                &dprev_abs, tc_is_fixed ? &tc0 : nullptr, nullptr, adaptive ? &ad : nullptr);
             wave_sync();
         }
         // write the record back
@@ -1422,6 +1496,7 @@ __global__ __launch_bounds__(kWave, 6) void track_kernel(
         else if (lane < ((D.n_pilot + 15) & ~15))               // whole 128-byte lines: no partial-sector writes
             reinterpret_cast<c32*>(st + kStHp)[lane] = (lane < D.n_pilot) ? sh.H[lc.pilot_slot] : mk(0.0f, 0.0f);
         if (D.differential) reinterpret_cast<c32*>(st + kStDprev)[lane] = dprev;
+        if (adaptive) { reinterpret_cast<c32*>(st + kStLms)[lane] = ad.w; st[kStRlsP + lane] = ad.P; }
         if (lane == 0) {
             // only what the carrier half owns (equalize_demap: pilot_phase_correction, has_dprev); the rest of the
             // record's scalars belong to the pilot half and to cfo_walk_kernel — one partial store instead of the line

@@ -30,6 +30,10 @@ struct DemodConst {
     float max_timing;           // 50.0f * (fft_size / 512.0f)
     float fft_f;                // (float) fft_size
     float mixer_phase_end;      // NCO::phase_ after a whole frame
+    // ModemConfig::adaptive_eq_* (types.hpp:170-174): 0 off (also for the differential modulations, which never reach
+    // the branch: channel_equalizer.cpp:769), 1 LMS, 2 RLS; decision_directed 0/1
+    int32_t adaptive_eq, decision_directed;
+    float lms_mu, rls_lambda;
     double two_pi_symbol_duration;  // 2.0f * M_PI * symbol_duration (double)
     int16_t bin[kMaxCarriers];        // slot -> fft bin
     int16_t k_of[kMaxCarriers];       // slot -> signed carrier number (k > fft/2 -> k - fft)

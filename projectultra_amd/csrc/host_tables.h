@@ -102,6 +102,7 @@ inline int validate_config(const ultra_hip_config& c) {
     if (c.n_data_symbols == 0 || c.n_data_symbols > 251) return ULTRA_HIP_ERR_INVALID_ARG;
     if (c.entry == ULTRA_ENTRY_PRESYNCED && c.training_symbols > 8) return ULTRA_HIP_ERR_INVALID_ARG;
     if (c.max_iterations > 1000) return ULTRA_HIP_ERR_INVALID_ARG;
+    if (c.adaptive_eq_enabled > 1 || c.adaptive_eq_use_rls > 1 || c.decision_directed > 1) return ULTRA_HIP_ERR_INVALID_ARG;
     return ULTRA_HIP_OK;
 }
 
@@ -658,6 +659,10 @@ inline int build_demod(const ultra_hip_config& c, DemodConst& D, std::vector<c32
     D.differential = (c.modulation == ULTRA_MOD_DBPSK || c.modulation == ULTRA_MOD_DQPSK ||
                       c.modulation == ULTRA_MOD_D8PSK);
     D.presynced = (c.entry == ULTRA_ENTRY_PRESYNCED);
+    D.adaptive_eq = (c.adaptive_eq_enabled && !D.differential) ? (c.adaptive_eq_use_rls ? 2 : 1) : 0;
+    D.decision_directed = c.decision_directed ? 1 : 0;
+    D.lms_mu = c.lms_mu;
+    D.rls_lambda = c.rls_lambda;
     D.frame_samples = (int)g.frame_samples;
     D.ce_margin = ce_margin(c.modulation);
     D.sample_rate = (float)c.sample_rate;

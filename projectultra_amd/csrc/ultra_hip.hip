@@ -218,7 +218,7 @@ int launch_demod(ultra_hip_ctx* ctx, const float* d_audio, size_t frame_stride, 
         // compact pilot state (demod_kernel.h, kStHp) and no training symbols that read the full H array first
         const int compact = (!D.differential && D.n_pilot > 0 && D.n_train == 0) ? 1 : 0;
         hipLaunchKernelGGL(dev::init_state_kernel, dim3(grid_trk), dim3(dev::kWave), 0, st, d_cfo_hz, d_cfo_phase,
-                           (int)n_frames, ctx->d_ws_state, compact);
+                           (int)n_frames, ctx->d_ws_state, compact, (D.adaptive_eq != 0 && !D.differential) ? 1 : 0);
     }
     if (s_begin == 0 && D.presynced && d_cfo_hz) {
         // frames whose initial CFO is NaN ("never set"): estimateCFOFromTraining, demodulator.cpp:920-925
@@ -237,8 +237,9 @@ int launch_demod(ultra_hip_ctx* ctx, const float* d_audio, size_t frame_stride, 
     // Coherent layouts with pilots entered SYNCED: the carrier half does not feed back into the tracker, so it runs once,
     // behind the last symbol, over every (symbol, frame) — track_all_kernel, demod_kernel.h; per symbol only
     // cfo_walk -> mix_fft -> track_pilot remain.  Needs every symbol's bins and a record per (symbol, frame).
+    // (not with the adaptive equaliser: its weights are per-carrier state that the carrier half carries from symbol to symbol)
     bool deferred = !ctx->old_chain && !D.differential && D.n_pilot > 0 && D.n_pilot <= dev::kPwPilots && D.n_train == 0 &&
-                    !D.presynced && n_frames * (size_t)n_sym < 0x7fffffffull;
+                    !D.presynced && D.adaptive_eq == 0 && n_frames * (size_t)n_sym < 0x7fffffffull;
     // n_sym rows of workspace per frame instead of one: if that cannot be had, fall back to the per-symbol launches
     if ((all_symbols_at_once || deferred) && ensure_fq_workspace(ctx, n_frames * (size_t)n_sym) != ULTRA_HIP_OK) {
         (void)hipGetLastError();
@@ -713,7 +714,7 @@ int ultra_hip_reserve(ultra_hip_ctx* ctx, size_t n_frames) {
         const DemodConst& D = ctx->h_demod;
         const size_t syms = (size_t)std::max(1, D.n_train + D.n_data_sym);
         const bool zero_cfo_layout = !D.presynced && D.n_pilot == 0;
-        const bool deferred_layout = !ctx->old_chain && !D.differential && D.n_pilot > 0 && D.n_train == 0 && !D.presynced;
+        const bool deferred_layout = !ctx->old_chain && !D.differential && D.n_pilot > 0 && D.n_train == 0 && !D.presynced && D.adaptive_eq == 0;
         if ((zero_cfo_layout || deferred_layout) && syms > 1) {
             if (ensure_fq_workspace(ctx, n_frames * syms) != ULTRA_HIP_OK) (void)hipGetLastError();
             else if (deferred_layout && ensure_trk_workspace(ctx, n_frames * syms) != ULTRA_HIP_OK) (void)hipGetLastError();

@@ -32,6 +32,8 @@ def make_c_config(config: ModemConfig, *, entry: Entry = Entry.SYNCED, n_data_sy
         bps = config.getDataCarriers() * getBitsPerSymbol(config.modulation)
         n_data_symbols = -(-LDPC_BLOCK_SIZE // bps)
     c.n_data_symbols = n_data_symbols
+    c.adaptive_eq_enabled, c.adaptive_eq_use_rls = int(bool(config.adaptive_eq_enabled)), int(bool(config.adaptive_eq_use_rls))
+    c.decision_directed, c.lms_mu, c.rls_lambda = int(bool(config.decision_directed)), config.lms_mu, config.rls_lambda
     return c
 
 
@@ -51,8 +53,6 @@ class ReceiveContext:
 
     def __init__(self, config: ModemConfig, *, entry: Entry = Entry.SYNCED, n_data_symbols: Optional[int] = None,
                  training_symbols: int = 2, max_iterations: int = 50, device: Optional[int] = None):
-        if getattr(config, "adaptive_eq_enabled", False):
-            raise _lib.UltraHipError(-2, "adaptive_eq_enabled (LMS/RLS) is not part of the built path")
         torch = _torch()
         self.config = config
         self.cfg = make_c_config(config, entry=entry, n_data_symbols=n_data_symbols,

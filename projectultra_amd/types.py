@@ -80,7 +80,11 @@ class ModemConfig:                  # include/ultra/types.hpp:139-234 (receive-p
     scattered_pilots: bool = True       # never read by the reference either
     modulation: Modulation = Modulation.QPSK
     code_rate: CodeRate = CodeRate.R1_2
-    adaptive_eq_enabled: bool = False   # LMS/RLS equaliser: off in every preset; not built
+    adaptive_eq_enabled: bool = False   # LMS/RLS equaliser of the coherent modulations (types.hpp:170-174): off in every preset
+    adaptive_eq_use_rls: bool = False
+    lms_mu: float = 0.05
+    rls_lambda: float = 0.99
+    decision_directed: bool = True
 
     def getCyclicPrefix(self) -> int:
         base = {CyclicPrefixMode.SHORT: 32, CyclicPrefixMode.MEDIUM: 48, CyclicPrefixMode.LONG: 64}[

@@ -6,9 +6,12 @@ from oracle.bindings import Config, INFO_BITS, make_config, geometry  # noqa: F4
 
 
 def cfg_from_array(arr) -> Config:
+    """A fixture's ultra_hip_config: the struct's 32-bit words (older fixtures hold the first 14: adaptive equaliser off)."""
+    import ctypes as C
     c = Config()
-    for (name, _), v in zip(Config._fields_, arr.tolist()):
-        setattr(c, name, int(v))
+    words = np.ascontiguousarray(arr, np.uint32)
+    assert words.size * 4 <= C.sizeof(c)
+    C.memmove(C.byref(c), words.ctypes.data, words.size * 4)
     return c
 
 
@@ -18,7 +21,9 @@ def modem_config_from_c(c):
     mc = ModemConfig(sample_rate=c.sample_rate, center_freq=c.center_freq, fft_size=c.fft_size,
                      num_carriers=c.num_carriers, cp_mode=CyclicPrefixMode(c.cp_mode), symbol_guard=c.symbol_guard,
                      pilot_spacing=c.pilot_spacing, use_pilots=bool(c.use_pilots),
-                     modulation=Modulation(c.modulation), code_rate=CodeRate(c.code_rate))
+                     modulation=Modulation(c.modulation), code_rate=CodeRate(c.code_rate),
+                     adaptive_eq_enabled=bool(c.adaptive_eq_enabled), adaptive_eq_use_rls=bool(c.adaptive_eq_use_rls),
+                     decision_directed=bool(c.decision_directed), lms_mu=c.lms_mu, rls_lambda=c.rls_lambda)
     kw = dict(entry=Entry(c.entry), n_data_symbols=c.n_data_symbols, training_symbols=c.training_symbols or 2,
               max_iterations=c.max_iterations)
     return mc, kw

@@ -99,7 +99,7 @@ MODES = [  # name, fft, mod, rate, extra kwargs
 
 
 def cfg_array(cfg):
-    return np.array([getattr(cfg, n) for n, _ in cfg._fields_], np.uint32)
+    return np.frombuffer(bytes(cfg), np.uint32).copy()      # the struct's words (the two float fields as their bits)
 
 
 def tables():
@@ -320,9 +320,50 @@ def setcfo():
     d["cases"] = np.array(cases)
     np.savez_compressed(OUT / "setcfo.npz", **d)
 
+def adaptive():
+    """ModemConfig::adaptive_eq_enabled (LMS / RLS, channel_equalizer.cpp:569-581,705-722,773-805): SYNCED-entry and
+    processPresynced frames long enough for the weights to leave their seed, AWGN and Watterson."""
+    d = {}
+    cases = [("lms_qpsk", 512, "QPSK", "R1_2", dict(n_data_symbols=14), dict(adaptive_eq="lms")),
+             ("rls_qam16", 1024, "QAM16", "R3_4", dict(n_data_symbols=10), dict(adaptive_eq="rls", rls_lambda=0.97)),
+             ("lms_qam64", 512, "QAM64", "R3_4", dict(n_data_symbols=9), dict(adaptive_eq="lms", lms_mu=0.1)),
+             ("rls_bpsk", 512, "BPSK", "R1_2", dict(n_data_symbols=12), dict(adaptive_eq="rls")),
+             ("lms_qam32_nodd", 1024, "QAM32", "R3_4", dict(n_data_symbols=8), dict(adaptive_eq="lms", decision_directed=False)),
+             ("rls_qam256", 512, "QAM256", "R5_6", dict(n_data_symbols=8), dict(adaptive_eq="rls"))]
+    for name, fft, mod, rate, kw, akw in cases:
+        for entry in (0, 1):
+            cfg = make_config(fft, mod, rate, entry=entry, **kw, **akw)
+            g = geometry(cfg)
+            audio, par, llrs, scals = [], [], [], []
+            for t in range(4):
+                nbytes = (g.llrs_per_frame // 648 + 1) * (INFO_BITS[cfg.code_rate] // 8)
+                payload = bytes(rng.integers(0, 256, nbytes, dtype=np.uint8))
+                cfo, ph = [(0.0, 0.0), (3.0, 0.5), (-6.0, -2.0), (0.4, 0.1)][t]
+                if entry == 0:
+                    a, pre = r.harness_awgn(cfg, payload, [30, 14, 20, 8][t], 7000 + t)
+                    if t >= 2:
+                        a = r.watterson(a, 20.0, 0.5, 1.0, 950 + t)
+                    x = a[pre: pre + g.frame_samples]
+                    l, st = r.demod_synced(cfg, x, cfo, stages=True)
+                    sc = st["scal"][-1]
+                    ph = 0.0
+                else:
+                    x = r.modulate_presynced(cfg, r.ldpc_encode(cfg.code_rate, payload))
+                    x = x * np.float32(0.5 / np.abs(x).max())
+                    x = r.watterson(x, [30, 16, 9, 24][t], 0.5, 0.1, 330 + t, fading=t % 2, multipath=t % 2)[:g.frame_samples]
+                    l, H, sc = r.demod_presynced(cfg, x, cfo, ph)
+                audio.append(x); par.append([cfo, ph]); llrs.append(l); scals.append(sc)
+            key = f"{name}_e{entry}"
+            d[f"{key}__cfg"] = cfg_array(cfg)
+            d[f"{key}__audio"] = np.stack(audio).astype(np.float32)
+            d[f"{key}__cfo_phase"] = np.array(par, np.float32)
+            d[f"{key}__llr"] = np.stack(llrs)
+            d[f"{key}__scal"] = np.stack(scals)
+    np.savez_compressed(OUT / "adaptive.npz", **d)
+
 
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["ldpc", "tables", "demod", "presynced", "fullsync", "sync", "frames", "stream", "setcfo"]
+    which = sys.argv[1:] or ["ldpc", "tables", "demod", "presynced", "fullsync", "sync", "frames", "stream", "setcfo", "adaptive"]
     for name in which:
         globals()[name]()
     for f in sorted(OUT.glob("*.npz")):

@@ -381,3 +381,50 @@ def test_headline_workload_is_the_references_channel(ref):
         assert abs(o[k] - r[k]) <= t, (k, r[k], o[k], t)
     for k in ("noise_var_median", "noise_var_mean", "snr_linear_median"):
         assert abs(o[k] - r[k]) <= 0.10 * r[k], (k, r[k], o[k])
+
+
+ADAPTIVE = [("QPSK", "R1_2", 512, dict(n_data_symbols=14), "lms", {}), ("QPSK", "R1_2", 512, dict(n_data_symbols=14), "rls", {}),
+            ("QAM16", "R3_4", 1024, dict(n_data_symbols=10), "lms", dict(lms_mu=0.1)), ("QAM16", "R3_4", 1024, dict(n_data_symbols=10), "rls", dict(rls_lambda=0.97)),
+            ("BPSK", "R1_2", 512, dict(n_data_symbols=12), "rls", {}), ("QAM32", "R3_4", 1024, dict(n_data_symbols=8), "lms", {}),
+            ("QAM64", "R3_4", 512, dict(n_data_symbols=9), "rls", {}), ("QAM256", "R5_6", 512, dict(n_data_symbols=8), "lms", {}),
+            ("QAM16", "R1_2", 1024, dict(n_data_symbols=8), "lms", dict(decision_directed=False)),
+            ("QPSK", "R1_2", 512, dict(n_data_symbols=10, use_pilots=0), "rls", {}),
+            ("DQPSK", "R1_2", 512, dict(n_data_symbols=8), "lms", {})]       # differential: the branch is never reached
+
+
+@pytest.mark.parametrize("mod,rate,fft,kw,kind,akw", ADAPTIVE)
+def test_adaptive_equaliser(oracle, ref, mod, rate, fft, kw, kind, akw):
+    """ModemConfig::adaptive_eq_enabled (types.hpp:170-174): Impl::equalize's LMS / RLS branch (channel_equalizer.cpp:569-581,
+    705-722,773-805), off in every preset the reference ships — the restatement against the compiled reference, both entries,
+    frames long enough for the weights to run free (they are re-seeded from the pilots' estimate during the first three symbols)."""
+    for entry in (0, 1):
+        cfg = make_config(fft, mod, rate, entry=entry, adaptive_eq=kind, **kw, **akw)
+        plain = make_config(fft, mod, rate, entry=entry, **kw)
+        g = geometry(cfg)
+        rng = np.random.default_rng(77 + entry)
+        differs = False
+        for trial in range(4):
+            nbytes = (g.llrs_per_frame // 648 + 1) * (INFO_BITS[cfg.code_rate] // 8)
+            payload = bytes(rng.integers(0, 256, nbytes, dtype=np.uint8))
+            enc = oracle.ldpc_encode(cfg.code_rate, payload)
+            if entry == 0:
+                audio, pre = ref.harness_awgn(cfg, payload, [30, 12, 20, 6][trial], 10 + trial)
+                if trial >= 2:
+                    audio = ref.watterson(audio, 20.0, 0.5, 1.0, 70 + trial)
+                x = audio[pre: pre + g.frame_samples]
+                la, sa = oracle.demod_synced(cfg, x, [0.0, 1.7, -3.2, 0.4][trial], stages=True)
+                lb, sb = ref.demod_synced(cfg, x, [0.0, 1.7, -3.2, 0.4][trial], stages=True)
+                for k in sa:
+                    assert beq(sa[k], sb[k]), (mod, kind, trial, k)
+                assert beq(la, lb), (mod, kind, trial)
+                differs |= not beq(lb, ref.demod_synced(plain, x, [0.0, 1.7, -3.2, 0.4][trial])[0])
+            else:
+                a = ref.modulate_presynced(cfg, enc)
+                x = a * np.float32(0.5 / np.abs(a).max())
+                x = ref.watterson(x, [30, 18, 10, 24][trial], 0.5, 0.1, 5 + trial, fading=trial % 2, multipath=trial % 2)[:g.frame_samples]
+                la, Ha, sa = oracle.demod_presynced(cfg, x, 3.0 * trial, 0.5 * trial)
+                lb, Hb, sb = ref.demod_presynced(cfg, x, 3.0 * trial, 0.5 * trial)
+                assert beq(la, lb) and beq(Ha, Hb) and beq(sa, sb), (mod, kind, trial)
+                differs |= not beq(lb, ref.demod_presynced(plain, x, 3.0 * trial, 0.5 * trial)[0])
+        # the switch does something (coherent modulations) or nothing at all (differential ones)
+        assert differs == (mod not in ("DQPSK", "D8PSK", "DBPSK")), (mod, kind, entry)
