@@ -89,6 +89,8 @@ def parse():
                     help="process-group backend of the counter all-reduce: nccl (= RCCL over xGMI, one GPU per rank) or gloo "
                          "(counters reduced through host memory; ranks may then SHARE a card, rank r on device r %% device_count: "
                          "the many-ranks-one-card rehearsal of tests/test_gpu_multirank.py)")
+    ap.add_argument("--sync-collective", action="store_true",
+                    help="issue the per-step all-reduce synchronously on the launch stream (default: asynchronously, one step deep)")
     ap.add_argument("--no-build", action="store_true",
                     help="do not (re)build the checker libraries; REQUIRED under rocprofv3, whose preloaded library "
                          "initialises the GPU before main() — the compiler must never be started from such a process")
@@ -206,6 +208,35 @@ def best_of(fn, runs=3):
 # ------------------------------------------------------------------------------------------------------------------
 # workloads
 # ------------------------------------------------------------------------------------------------------------------
+class CounterRing:
+    """Two counter blocks used by alternate steps, so that the all-reduce of step k (asynchronous on RCCL's own stream) runs
+    under the kernels of step k + 1 instead of holding the launch stream until every rank has arrived.  A block is reused two
+    steps later; next() first makes the launch stream wait for the collectives that were issued on it (long finished by then)."""
+
+    def __init__(self, torch, shape, depth=2, device="cuda"):
+        self.bufs = [torch.zeros(shape, dtype=torch.int64, device=device) for _ in range(depth)]
+        self.works = [[] for _ in range(depth)]
+        self.k = 0
+
+    def next(self):
+        self.k = (self.k + 1) % len(self.bufs)
+        self.wait(self.k)
+        return self.bufs[self.k]
+
+    def note(self, work):
+        if work is not None:
+            self.works[self.k].append(work)
+
+    def wait(self, k):
+        for w in self.works[k]:
+            w.wait()
+        self.works[k] = []
+
+    def drain(self):
+        for k in range(len(self.bufs)):
+            self.wait(k)
+
+
 class ModemWorkload:
     """cfg2 / cfg3: post-sync demodulate + decode + count of n frames (ultra_hip_demod_decode_batch)."""
 
@@ -248,7 +279,8 @@ class ModemWorkload:
                         iters=torch.empty(self.n, dtype=torch.int32, device="cuda"),
                         ok=torch.empty(self.n, dtype=torch.uint8, device="cuda"),
                         llr=torch.empty((self.n, g.llrs_per_frame), dtype=torch.float32, device="cuda"))
-        self.counters = torch.zeros(8, dtype=torch.int64, device="cuda")
+        self.ring = CounterRing(torch, 8)
+        self.counters = self.ring.bufs[0]
         self.units_per_step = self.n
         self.points_per_step = 1
         # audio in + cfo in; 648 LLRs + decoded bytes + iters/status out
@@ -270,10 +302,11 @@ class ModemWorkload:
         self.parallelism = f"frames sharded over {world} GPU(s), one counter all-reduce per step"
 
     def step(self, allreduce):
+        self.counters = self.ring.next()
         self.counters.zero_()
         r = self.ctx.demod_decode(self.d_audio, out=self.out)
         self.ctx.count_errors(r, self.d_payload, self.counters)
-        allreduce(self.counters)
+        self.ring.note(allreduce(self.counters))
 
     def contexts(self):
         return [self.ctx]
@@ -352,7 +385,8 @@ class RawWorkload(ModemWorkload):
         self.t_gen = time.time() - t0
         self.n_samples = self.d_audio.shape[1]
         self.out = None
-        self.counters = torch.zeros(8, dtype=torch.int64, device="cuda")
+        self.ring = CounterRing(torch, 8)
+        self.counters = self.ring.bufs[0]
         self.units_per_step = self.n
         self.points_per_step = 1
         self.bytes_audio = self.n_samples * 4
@@ -370,10 +404,11 @@ class RawWorkload(ModemWorkload):
         self.parallelism = f"streams sharded over {world} GPU(s), one counter all-reduce per step"
 
     def step(self, allreduce):
+        self.counters = self.ring.next()
         self.counters.zero_()
         self.out = self.ctx.receive(self.d_audio, chunk=960)
         self.ctx.count_errors(self.out, self.d_payload, self.counters)
-        allreduce(self.counters)
+        self.ring.note(allreduce(self.counters))
 
     def cpu_baseline(self, cores, sample):
         """The whole receive of a raw stream on the host: the compiled reference's OFDMDemodulator::process fed 960 samples per
@@ -436,7 +471,8 @@ class LdpcSweepWorkload:
         self.out = dict(bytes=torch.empty((P, self.n, g.decoded_bytes), dtype=torch.uint8, device="cuda"),
                         iters=torch.empty((P, self.n), dtype=torch.int32, device="cuda"),
                         ok=torch.empty((P, self.n), dtype=torch.uint8, device="cuda"))
-        self.counters = torch.zeros((P, 8), dtype=torch.int64, device="cuda")
+        self.ring = CounterRing(torch, (P, 8))
+        self.counters = self.ring.bufs[0]
         self.units_per_step = self.n * P
         self.points_per_step = P
         self.metric = "LDPC R1/4 codewords decoded/sec over the Es/N0 sweep -11..+30 dB"
@@ -451,11 +487,12 @@ class LdpcSweepWorkload:
         self.parallelism = f"codewords of every point sharded over {world} GPU(s), one counter all-reduce per point"
 
     def step(self, allreduce):
+        self.counters = self.ring.next()
         self.counters.zero_()
         for i in range(len(self.snrs)):
             r = self.ctx.ldpc_decode(self.d_llr[i], out={k: v[i] for k, v in self.out.items()})
             self.ctx.count_errors(r, self.d_payload[i], self.counters[i])
-            allreduce(self.counters[i])
+            self.ring.note(allreduce(self.counters[i]))
 
     def contexts(self):
         return [self.ctx]
@@ -515,7 +552,8 @@ class ModeSweepWorkload:
         self.t_gen = time.time() - t0
         resident = self.grid.audio_bytes
         P = len(self.cells) * S
-        self.counters = torch.zeros((P, 8), dtype=torch.int64, device="cuda")
+        self.ring = CounterRing(torch, (P, 8))
+        self.counters = self.ring.bufs[0]
         self.units_per_step = n * P
         self.points_per_step = P
         self.collectives_per_step = 1
@@ -538,8 +576,9 @@ class ModeSweepWorkload:
 
     def step(self, allreduce):
         c = self.grid.receive()                                   # [modulation][rate][point][8]
+        self.counters = self.ring.next()
         self.counters.copy_(c.reshape(-1, 8))
-        allreduce(self.counters)
+        self.ring.note(allreduce(self.counters))
 
     def contexts(self):
         return self.grid.contexts()
@@ -675,8 +714,10 @@ def main():
         return float(t.item())
 
     def allreduce(t):
+        """SUM over the ranks, in place.  Returns the collective's handle where it was issued asynchronously (RCCL, outside the
+        profiled pass): the caller's CounterRing waits for it before the block is used again, barrier() before the clock stops."""
         if not distributed:
-            return
+            return None
         if via_host:
             t0 = time.perf_counter()
             h = t.cpu()
@@ -684,16 +725,20 @@ def main():
             t.copy_(h)
             if allreduce.timed:
                 ar_host.append(time.perf_counter() - t0)
-            return
+            return None
         if ar_events is not None and allreduce.timed:
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record(); dist.all_reduce(t, op=dist.ReduceOp.SUM); e1.record()
             ar_events.append((e0, e1))
-        else:
+            return None
+        if args.sync_collective:
             dist.all_reduce(t, op=dist.ReduceOp.SUM)
+            return None
+        return dist.all_reduce(t, op=dist.ReduceOp.SUM, async_op=True)
     allreduce.timed = False
 
     def barrier():
+        wl.ring.drain()             # every collective issued so far is ordered in front of what follows on the launch stream
         if distributed:
             dist.barrier()
         torch.cuda.synchronize()
@@ -740,6 +785,7 @@ def main():
     if ar_host:
         ar_us = float(np.mean(ar_host) * 1e6)
     elapsed = reduce_max(elapsed)
+    wl.ring.drain()
     last = wl.counters.reshape(-1, 8).sum(dim=0).cpu()
     stats = counters_dict(last)
     expect = getattr(wl, "total_units", wl.units_per_step * world)
@@ -884,7 +930,10 @@ def main():
             "collective": {"backend": backend or "none (single process, no process group)", "world_size": dist.get_world_size() if distributed else 1,
                            "ranks_per_device": -(-world // n_dev) if distributed else 1,
                            "op": getattr(wl, "collective_op", "all_reduce(SUM) of 8 x int64"),
-                           "per_step": getattr(wl, "collectives_per_step", wl.points_per_step), "allreduce_us": ar_us},
+                           "per_step": getattr(wl, "collectives_per_step", wl.points_per_step), "allreduce_us": ar_us,
+                           "issued": ("no process group" if not distributed else "through host memory, synchronous" if via_host else
+                                      "synchronous on the launch stream" if args.sync_collective else
+                                      "asynchronous (RCCL's stream), awaited when its counter block is reused two steps later and at the closing barrier")},
             "roofline": roofline, "cpu_baseline": cpu,
         }
         if hasattr(wl, "curves"):

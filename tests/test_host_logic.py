@@ -86,6 +86,43 @@ print("rank", rank, "ok")
 '''
 
 
+RING_WORKER = r'''
+import os, sys, importlib.util, torch, torch.distributed as dist
+spec = importlib.util.spec_from_file_location("bench", os.path.join(sys.argv[1], "bench.py"))
+bench = importlib.util.module_from_spec(spec); spec.loader.exec_module(bench)
+rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+dist.init_process_group("gloo", rank=rank, world_size=world)
+ring = bench.CounterRing(torch, (3, 8), device="cpu")
+seen = []
+for step in range(7):                       # bench.py's step: take the next block, fill it, issue the all-reduce, move on
+    c = ring.next()
+    if step >= 2:                           # the block of step - 2 comes back reduced: next() waited for its collectives
+        assert c.tolist() == seen[step - 2], (step, c.tolist(), seen[step - 2])
+    c.zero_()
+    for point in range(3):
+        c[point] += torch.arange(8) * (step + 1) + point + rank
+        ring.note(dist.all_reduce(c[point], op=dist.ReduceOp.SUM, async_op=True))
+    seen.append([[world * (k * (step + 1) + point) + sum(range(world)) for k in range(8)] for point in range(3)])
+ring.drain()
+assert ring.bufs[ring.k].tolist() == seen[-1] and all(not w for w in ring.works)
+dist.destroy_process_group()
+print("rank", rank, "ok")
+'''
+
+
+def test_counter_ring_overlaps_the_allreduce_gloo(tmp_path):
+    """bench.py's CounterRing (two counter blocks used by alternate steps, the all-reduce of a step issued asynchronously and
+    awaited when its block comes round again): world size 2 on gloo, three collectives per step as in the cfg4 sweep."""
+    script = tmp_path / "ring_worker.py"
+    script.write_text(RING_WORKER)
+    port = 29500 + os.getpid() % 2000 + 7
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), str(script), str(ROOT)]
+    r = subprocess.run(cmd, env=dict(os.environ, OMP_NUM_THREADS="1"), capture_output=True, text=True, timeout=240)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    assert r.stdout.count("ok") == 2
+
+
 @pytest.mark.parametrize("world", [2, 3])
 def test_counter_allreduce_across_ranks_gloo(tmp_path, world):
     """N>1 path: contiguous shards, one all-reduce of the 8 counters (gloo on CPU; RCCL on the GPUs)."""
