@@ -59,6 +59,25 @@ for (fft, mod, rate, kw), (chan, snr) in itertools.product(modes, (("watterson",
                          and np.array_equal(r0["ok"].cpu().numpy(), want0["ok"]))
             total += n
         total += n
+        if mod not in ("DQPSK", "D8PSK", "DBPSK"):
+            # the adaptive equaliser (ModemConfig::adaptive_eq_enabled, off in every preset): LMS or RLS with random step
+            # sizes, frames three symbols longer so that the weights run free behind their re-seeding, a quarter of the frames
+            from _util import geometry
+            kind = "lms" if rng.random() < 0.5 else "rls"
+            nsym = int(geometry(cfg).llrs_per_frame // geometry(cfg).llrs_per_symbol) + 3
+            acfg = make_config(fft, mod, rate, entry=entry, adaptive_eq=kind, lms_mu=float(rng.uniform(0.01, 0.2)),
+                               rls_lambda=float(rng.uniform(0.95, 0.999)), decision_directed=bool(rng.random() < 0.9),
+                               n_data_symbols=nsym, **kw)
+            na = max(n // 4, 64)
+            a_audio, _ = o.make_batch(acfg, na, seed=int(rng.integers(1 << 30)), channel=chan, snr_db=snr, n_threads=64)
+            a_cfo = rng.normal(0, 6.0, na).astype(np.float32)
+            a_ph = rng.uniform(-3.1, 3.1, na).astype(np.float32) if entry == 1 else None
+            wa = o.demod_decode_batch(acfg, a_audio, cfo_hz=a_cfo, cfo_phase=a_ph, n_threads=64)
+            ra = context_for(acfg).demod_decode(a_audio, cfo_hz=a_cfo, cfo_phase=a_ph, want_llr=True)
+            torch.cuda.synchronize()
+            ok = ok and (np.array_equal(ra["llr"].cpu().numpy().view(np.uint32), wa["llr"].view(np.uint32))
+                         and np.array_equal(ra["bytes"].cpu().numpy(), wa["bytes"]) and np.array_equal(ra["iters"].cpu().numpy(), wa["iters"]))
+            total += na
         if not ok:
             bad += 1
             print("MISMATCH", fft, mod, rate, kw, chan, snr, "entry", entry)
