@@ -359,6 +359,29 @@ def adaptive():
             d[f"{key}__cfo_phase"] = np.array(par, np.float32)
             d[f"{key}__llr"] = np.stack(llrs)
             d[f"{key}__scal"] = np.stack(scals)
+    # whole frames through OFDMDemodulator::process (Schmidl-Cox search, 960-sample chunks) with the equaliser switched on:
+    # what a live caller of the waveform sees (fullsync.npz's shape)
+    # (frames of many symbols: the weights leave their seed behind the third symbol, and a waveform hands out a frame's
+    # first 648 soft bits only — OFDMNvisWaveform::process, ofdm_cox_waveform.cpp:129-131)
+    for name, fft, mod, rate, akw, snrs in [("live_lms_qam256", 512, "QAM256", "R5_6", dict(adaptive_eq="lms", lms_mu=0.1), [20.0, 22.0, 18.0]),
+                                            ("live_rls_qam64", 512, "QAM64", "R3_4", dict(adaptive_eq="rls", rls_lambda=0.97), [15.0, 16.0, 17.0])]:
+        cfg = make_config(fft, mod, rate, **akw)
+        plain = make_config(fft, mod, rate)
+        g = geometry(cfg)
+        rows = []
+        for t in range(3):
+            payload = bytes(rng.integers(0, 256, INFO_BITS[cfg.code_rate] // 8, dtype=np.uint8))
+            a, pre = r.harness_awgn(cfg, payload, snrs[t], 22345 + t)
+            l_full, sync_off, cfo, final_cfo, fed = r.demod_process_coarse(cfg, a, 960)
+            l_plain = r.demod_process_coarse(plain, a, 960)[0]
+            assert l_full.size >= g.llrs_per_frame
+            rows.append((a, pre, sync_off, cfo, l_full[:g.llrs_per_frame], not np.array_equal(l_full[:648], l_plain[:648])))
+        assert any(x[5] for x in rows), name        # the switch shows in the soft bits a waveform hands out
+        d[f"{name}__cfg"] = cfg_array(cfg)
+        d[f"{name}__audio"] = np.stack([x[0] for x in rows]).astype(np.float32)
+        d[f"{name}__meta"] = np.array([[x[1], x[2]] for x in rows], np.int32)
+        d[f"{name}__cfo"] = np.array([x[3] for x in rows], np.float32)
+        d[f"{name}__llr"] = np.stack([x[4] for x in rows])
     np.savez_compressed(OUT / "adaptive.npz", **d)
 
 

@@ -335,3 +335,61 @@ def test_cox_waveform_live_stream(tmp_path, name):
         assert np.array_equal(trace[:, 1], want[f"{name}__{sc}__synced"]), (name, sc, "synced")
         assert np.array_equal(trace[:, 2], want[f"{name}__{sc}__drained"]), (name, sc, "drained")
         assert beq(soft, want[f"{name}__{sc}__soft"]), (name, sc, "soft bits")
+
+
+SRC_ADAPTIVE = r'''
+#include "ultra_hip_waveform.hpp"
+#include <cstdio>
+#include <vector>
+using namespace ultra_hip;
+int main(int argc, char** argv) {
+    // argv: in.f32 n_samples out.f32 fft carriers cp_mode guard pilot_spacing use_pilots mod rate use_rls lms_mu rls_lambda
+    FILE* f = std::fopen(argv[1], "rb");
+    const size_t n = std::stoul(argv[2]);
+    std::vector<float> audio(n);
+    if (std::fread(audio.data(), 4, n, f) != n) return 2;
+    std::fclose(f);
+    ModemConfig c;
+    c.fft_size = std::stoul(argv[4]); c.num_carriers = std::stoul(argv[5]);
+    c.cp_mode = static_cast<decltype(c.cp_mode)>(std::stoi(argv[6])); c.symbol_guard = std::stoul(argv[7]);
+    c.pilot_spacing = std::stoul(argv[8]); c.use_pilots = std::stoi(argv[9]) != 0;
+    c.modulation = static_cast<Modulation>(std::stoi(argv[10])); c.code_rate = static_cast<CodeRate>(std::stoi(argv[11]));
+    c.adaptive_eq_enabled = true;                               // ModemConfig's own fields (types.hpp:170-174)
+    c.adaptive_eq_use_rls = std::stoi(argv[12]) != 0; c.lms_mu = std::stof(argv[13]); c.rls_lambda = std::stof(argv[14]);
+    HipOfdmCoxWaveform rx(c);
+    bool ready = false;
+    for (size_t i = 0; i < n; i += 960) ready = rx.process(SampleSpan(audio.data() + i, std::min<size_t>(960, n - i)));
+    if (!ready) return 3;
+    std::vector<float> soft = rx.getSoftBits();                 // the frame's first 648, as OFDMNvisWaveform hands them out
+    FILE* g = std::fopen(argv[3], "wb"); std::fwrite(soft.data(), 4, soft.size(), g); std::fclose(g);
+    return 0;
+}
+'''
+
+
+@pytest.mark.parametrize("name", ["live_lms_qam256", "live_rls_qam64"])
+def test_cpp_adapter_with_the_adaptive_equaliser(tmp_path, name):
+    """ModemConfig::adaptive_eq_enabled through the C++ adapter: whole frames the compiled reference received with the switch
+    on (OFDMDemodulator::process in 960-sample chunks; tests/golden/adaptive.npz, live_*) — to_c_config carries the five fields
+    into ultra_hip_config, the live path keeps the weights in the stream's tracker record from call to call."""
+    g = np.load(GOLDEN / "adaptive.npz")
+    cfg = cfg_from_array(g[f"{name}__cfg"])
+    src = tmp_path / "rxa.cpp"
+    src.write_text(SRC_ADAPTIVE)
+    exe = tmp_path / "rxa"
+    lib = ROOT / "projectultra_amd"
+    subprocess.check_call(["g++", "-O1", "-std=c++20", f"-I{ROOT / 'include'}", str(src), f"-L{lib}", "-lultra_hip",
+                           f"-Wl,-rpath,{lib}", "-o", str(exe)])
+    for t, (a, want) in enumerate(zip(g[f"{name}__audio"], g[f"{name}__llr"])):
+        fin, fl = tmp_path / f"in{t}.f32", tmp_path / f"llr{t}.f32"
+        a.astype(np.float32).tofile(fin)
+        args = [str(exe), str(fin), str(a.size), str(fl)] + [str(int(x)) for x in (
+            cfg.fft_size, cfg.num_carriers, cfg.cp_mode, cfg.symbol_guard, cfg.pilot_spacing, cfg.use_pilots,
+            cfg.modulation, cfg.code_rate, cfg.adaptive_eq_use_rls)] + [repr(float(np.float32(cfg.lms_mu))), repr(float(np.float32(cfg.rls_lambda)))]
+        r = subprocess.run(args, capture_output=True, text=True, timeout=300)
+        assert r.returncode == 0, (r.returncode, r.stderr[-400:])
+        got = np.fromfile(fl, np.float32)
+        assert got.size == 648, (name, t, got.size)
+        bad = np.flatnonzero(got.view(np.uint32) != want[:648].view(np.uint32))
+        assert bad.size == 0, (name, t, bad[:8], got[bad[:4]], want[bad[:4]])
+
