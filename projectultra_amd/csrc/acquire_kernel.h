@@ -125,8 +125,21 @@ __device__ __forceinline__ void acq_fft(AcqShared<LOG2N>& sh, const AcqLaneTw<LO
 #pragma unroll
         for (int q = 0; q < P; ++q) {
             if (q & half) continue;
-            const c32 w = tw(sh.twA[(half - 1) + (q & (half - 1))]);
-            UH_BUTTERFLY(v[q], v[q + half], w);
+            const int k = q & (half - 1);                    // compile-time (unrolled): twiddle[k << (LOG2N - 1 - s)]
+            const c32 w = tw(sh.twA[(half - 1) + k]);
+            // twiddle[0] = (1, -0) and twiddle[N/4] = (cos(-pi/2), -1) (host_tables.h checks both): two products instead of
+            // four, the same values bit for bit — see the group A of symbol_to_freq2 (demod_kernel.h)
+            if (k == 0) {
+                const c32 b_ = v[q + half];
+                const c32 t_ = mk(b_.re - w.im * b_.im, b_.im + w.im * b_.re);
+                v[q + half] = csub(v[q], t_); v[q] = cadd(v[q], t_);
+            } else if (2 * k == half) {
+                const c32 b_ = v[q + half];
+                const c32 t_ = INVERSE ? mk(w.re * b_.re - b_.im, w.re * b_.im + b_.re) : mk(w.re * b_.re + b_.im, w.re * b_.im - b_.re);
+                v[q + half] = csub(v[q], t_); v[q] = cadd(v[q], t_);
+            } else {
+                UH_BUTTERFLY(v[q], v[q + half], w);
+            }
         }
     }
 #pragma unroll

@@ -568,8 +568,23 @@ __device__ __forceinline__ void symbol_to_freq2(Fft2Shared<LOG2N, ROT>& sh, cons
 #pragma unroll
         for (int q = 0; q < P; ++q) {
             if (q & half) continue;
-            const c32 w = lc.wA[(q & (half - 1)) << (A - 1 - s)];         // twiddle[k << (LOG2N-1-s)], wave-uniform
-            UH_BUTTERFLY(v[q], v[q + half], w);
+            const int j = (q & (half - 1)) << (A - 1 - s);                  // compile-time: the loops are unrolled
+            const c32 w = lc.wA[j];                                         // twiddle[k << (LOG2N-1-s)], wave-uniform
+            // Ten of the group's twelve butterflies multiply by twiddle[0] = (1, -0) or twiddle[N/4] = (cos(-pi/2), -1)
+            // (build_demod_tables checks both): 1 * x and -1 * x are exact, so w * b keeps two products instead of four —
+            // (b.re - w.im b.im, b.im + w.im b.re) and (w.re b.re + b.im, w.re b.im - b.re), the SAME values bit for bit
+            // (x - (-y) == x + y, x + (-y) == x - y), signed zeros, infinities and NaNs included.
+            if (j == 0) {
+                const c32 b_ = v[q + half];
+                const c32 t_ = mk(b_.re - w.im * b_.im, b_.im + w.im * b_.re);
+                v[q + half] = csub(v[q], t_); v[q] = cadd(v[q], t_);
+            } else if (j == (P / 4)) {
+                const c32 b_ = v[q + half];
+                const c32 t_ = mk(w.re * b_.re + b_.im, w.re * b_.im - b_.re);
+                v[q + half] = csub(v[q], t_); v[q] = cadd(v[q], t_);
+            } else {
+                UH_BUTTERFLY(v[q], v[q + half], w);
+            }
         }
     }
 #pragma unroll

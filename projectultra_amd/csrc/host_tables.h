@@ -753,6 +753,9 @@ inline int build_demod(const ultra_hip_config& c, DemodConst& D, std::vector<c32
         const float angle = (float)(((-2.0 * M_PI) * (double)k) / (double)c.fft_size);
         twiddle[k] = c32{cosf(angle), sinf(angle)};
     }
+    // what the transform's first three stages rely on (demod_kernel.h, group A): the real part of twiddle[0] is exactly 1,
+    // the imaginary part of twiddle[N/4] exactly -1 (true for any libm: cos(0) and sin of the float next to -pi/2)
+    if (twiddle[0].re != 1.0f || twiddle[c.fft_size / 4].im != -1.0f) return ULTRA_HIP_ERR_UNSUPPORTED;
     return ULTRA_HIP_OK;
 }
 
