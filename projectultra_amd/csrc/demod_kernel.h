@@ -435,11 +435,20 @@ __device__ __forceinline__ void symbol_to_freq2(Fft2Shared<LOG2N, ROT>& sh, cons
                 nxt.start = from_lane(my_start, sg + 1); nxt.base = __int_as_float(from_lane(__float_as_int(my_base), sg + 1));
                 nxt.step = __int_as_float(from_lane(__float_as_int(my_step), sg + 1));
                 const int n2 = from_lane(my_start, sg + 2);                 // lanes >= ns hold INT_MAX (sg + 2 <= kPhaseCap + 1 < 64)
+                // Inside a segment every phase lies on the grid of ONE binade and so does the step (phase_table.h): the
+                // neighbour W positions on is value +- W step EXACTLY, a single addition instead of subtract / convert / fma.
+                // `cur` holds the lane's first position: its chain runs forward from there (values behind the segment's end
+                // are wrong and not selected); `nxt` is entered somewhere inside the run, if at all: its chain runs
+                // BACKWARD from the run's last position (values in front of its start are wrong and not selected).
+                {
+                    float a[P], b[P];
+                    const float step_a = cur.step * (float)W, step_b = nxt.step * (float)W;     // exact (W = 1 or 2)
+                    a[0] = um::phase_table_eval(cur, i0);
+                    b[P - 1] = um::phase_table_eval(nxt, ilast);
 #pragma unroll
-                for (int j = 0; j < P; ++j) {
-                    const int i = i0 + W * j;
-                    const float a = um::phase_table_eval(cur, i), b = um::phase_table_eval(nxt, i);
-                    ph[j] = (i < nxt.start) ? a : b;
+                    for (int j = 1; j < P; ++j) { a[j] = a[j - 1] + step_a; b[P - 1 - j] = b[P - j] - step_b; }
+#pragma unroll
+                    for (int j = 0; j < P; ++j) ph[j] = (i0 + W * j < nxt.start) ? a[j] : b[j];
                 }
                 const bool more = !(ilast < n2 && ilast < covered);
 #ifdef UH_MIXFFT_STAMPS
@@ -518,22 +527,22 @@ __device__ __forceinline__ void symbol_to_freq2(Fft2Shared<LOG2N, ROT>& sh, cons
             if (__builtin_expect(one_quadrant, 1)) {
                 double m_n; float y_sign, cos_sign; bool swap;
                 um::sincosf_quadrant_setup(n_lo, &m_n, &y_sign, &cos_sign, &swap);
-                if (swap) {
+                (void)y_sign; (void)cos_sign; (void)swap;              // compile-time in the four instances below (Q = n & 3)
+                auto block = [&](auto q_) {
+                    constexpr int Q = decltype(q_)::value;
 #pragma unroll
                     for (int j = 0; j < P; ++j) {
                         float sn, cs;
-                        um::sincosf_quadrant_<true>(ph[j], m_n, y_sign, cos_sign, &sn, &cs);
+                        um::sincosf_quadrant_q<Q>(ph[j], m_n, &sn, &cs);
                         const int m = P * lane + j;
                         rot[m + (m >> A)] = mk(cs, sn);
                     }
-                } else {
-#pragma unroll
-                    for (int j = 0; j < P; ++j) {
-                        float sn, cs;
-                        um::sincosf_quadrant_<false>(ph[j], m_n, y_sign, cos_sign, &sn, &cs);
-                        const int m = P * lane + j;
-                        rot[m + (m >> A)] = mk(cs, sn);
-                    }
+                };
+                switch (n_lo & 3) {                                    // wave-uniform
+                    case 0: block(std::integral_constant<int, 0>{}); break;
+                    case 1: block(std::integral_constant<int, 1>{}); break;
+                    case 2: block(std::integral_constant<int, 2>{}); break;
+                    default: block(std::integral_constant<int, 3>{}); break;
                 }
             } else {
 #pragma unroll
