@@ -136,6 +136,17 @@ __device__ __forceinline__ float ordered_sum(float* buf, float v, int n) {
     wave_sync();
     return s;
 }
+// sum over the 64 lanes in NO particular order (DPP operands inside the 16-lane rows, then four readlanes), wave-uniform:
+// for screens whose exact value is settled elsewhere
+__device__ __forceinline__ float wave_sum_unordered(float v) {
+    v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0xB1, 0xF, 0xF, true));    // quad_perm [1,0,3,2]
+    v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x4E, 0xF, 0xF, true));    // quad_perm [2,3,0,1]
+    v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x141, 0xF, 0xF, true));   // row_half_mirror
+    v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x140, 0xF, 0xF, true));   // row_mirror
+    const float a = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 0)), b = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 16));
+    const float c = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 32)), d = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 48));
+    return (a + b) + (c + d);
+}
 // buf: 64 c32 of LDS
 __device__ __forceinline__ c32 ordered_csum(c32* buf, c32 v, int n) {
     buf[threadIdx.x] = v;
@@ -1108,9 +1119,26 @@ __device__ __forceinline__ void equalize_demap(TrackShared& sh, const DemodConst
             }
             }
         }
-        float avg = ordered_sum(sh.fbuf, h_power, nd);          // deep-fade soft erasure (:822-837)
-        avg /= (float)nd;
-        if (is_data && h_power < 0.1f * avg) nv = 100.0f;
+        // Deep-fade soft erasure (:822-837): nv = 100 where |H|^2 < 0.1f * (avg_h_power / nd), avg_h_power the SERIAL float
+        // sum of the nd values — 44 dependent additions that every lane would repeat, to decide a comparison that is almost
+        // never close.  Screen: T = the same nd non-negative values summed in any order differs from the serial sum S by
+        // |S - T| <= 2 gamma_63 T (1 + gamma) < 2^-17 T (both are within gamma_63 = 63 u / (1 - 63 u) of the true sum, no
+        // underflow in additions); the reference's threshold fl(0.1f * fl(S / nd)) and thr = fl(T * fl(0.1f / nd)) add
+        // four roundings: they differ by less than 2^-16 relatively, so the threshold lies strictly inside
+        // (thr (1 - 2^-14), thr (1 + 2^-14)) even with those two products rounded.  A carrier outside that band is decided
+        // by the screen exactly as the reference decides it; if any carrier of the item is inside it (or T is not a
+        // comfortable normal number: zero, denormal, infinite, NaN) the serial sum settles the whole item.
+        const float T = wave_sum_unordered(is_data ? h_power : 0.0f);
+        const float thr = T * D.fade_k, lo = thr * 0.99993896484375f, hi = thr * 1.00006103515625f;    // 1 -+ 2^-14
+        const bool t_plain = T >= 0x1p-60f && T <= 0x1p60f;                                        // wave-uniform
+        const bool close = is_data && !(h_power < lo) && !(h_power >= hi);
+        if (__builtin_expect(t_plain && !__any(close), 1)) {
+            if (is_data && h_power < lo) nv = 100.0f;
+        } else {
+            float avg = ordered_sum(sh.fbuf, h_power, nd);
+            avg /= (float)nd;
+            if (is_data && h_power < 0.1f * avg) nv = 100.0f;
+        }
     }
 
     if (kDiff && !tr.has_dprev) { dprev = mk(1.0f, 0.0f); if (dprev_abs) *dprev_abs = -1.0f; }   // (1,0) reference on every path

@@ -34,6 +34,8 @@ struct DemodConst {
     // the branch: channel_equalizer.cpp:769), 1 LMS, 2 RLS; decision_directed 0/1
     int32_t adaptive_eq, decision_directed;
     float lms_mu, rls_lambda;
+    float fade_k;               // 0.1f / (float)n_data (FADE_THRESHOLD_RATIO over the carrier count): the erasure test's screen
+    float _pad0;
     double two_pi_symbol_duration;  // 2.0f * M_PI * symbol_duration (double)
     int16_t bin[kMaxCarriers];        // slot -> fft bin
     int16_t k_of[kMaxCarriers];       // slot -> signed carrier number (k > fft/2 -> k - fft)

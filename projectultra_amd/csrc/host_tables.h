@@ -663,6 +663,7 @@ inline int build_demod(const ultra_hip_config& c, DemodConst& D, std::vector<c32
     D.decision_directed = c.decision_directed ? 1 : 0;
     D.lms_mu = c.lms_mu;
     D.rls_lambda = c.rls_lambda;
+    D.fade_k = 0.1f / (float)g.n_data_carriers;
     D.frame_samples = (int)g.frame_samples;
     D.ce_margin = ce_margin(c.modulation);
     D.sample_rate = (float)c.sample_rate;

@@ -769,3 +769,30 @@ def test_set_cfo_between_stream_calls_golden():
         rest = ctx.demod_stream(np.ascontiguousarray(audio[:, set_at * geo.symbol_samples:]), set_at, nsym - set_at)
         got = np.concatenate([first.cpu().numpy(), rest.cpu().numpy()], axis=1)
         _check_llr(got, want, key)
+
+
+@pytest.mark.parametrize("mod,rate,fft", [("QAM16", "R3_4", 1024), ("QPSK", "R1_2", 512), ("QAM64", "R3_4", 512)])
+def test_degenerate_audio_vs_oracle(oracle, mod, rate, fft):
+    """Audio far outside the normal range — silence, amplitudes of 1e-19 and 1e+17 (the channel powers leave the range in which
+    the deep-fade erasure's unordered screen sum is trusted: the serial sum of equalize_demap decides), a NaN and an infinity
+    inside a frame: soft bits against the oracle, NaNs in the same places and everything else bit for bit."""
+    cfg = make_config(fft, mod, rate)
+    n = 48
+    audio, _ = oracle.make_batch(cfg, n, seed=0xDE6, channel="watterson", snr_db=20.0)
+    audio[0:4] = 0.0
+    audio[4:12] *= np.float32(1e-19)
+    audio[12:20] *= np.float32(1e17)
+    audio[20:24, 1000] = np.nan
+    audio[24:28, 3000] = np.inf
+    audio[28:32, ::2] = 0.0
+    cfo = np.where(np.arange(n) % 2 == 0, 0.0, 2.5).astype(np.float32)
+    import warnings
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        want = oracle.demod_decode_batch(cfg, audio, cfo_hz=cfo, n_threads=8, decode=False)["llr"]
+    ctx = context_for(cfg)
+    got = ctx.demod(audio, cfo_hz=cfo).cpu().numpy()
+    nan_w, nan_g = np.isnan(want), np.isnan(got)
+    assert np.array_equal(nan_w, nan_g), (mod, np.flatnonzero((nan_w != nan_g).any(axis=1)))
+    same = (got.view(np.uint32) == want.view(np.uint32)) | nan_w
+    assert same.all(), (mod, "frames", np.flatnonzero(~same.all(axis=1)))
