@@ -709,10 +709,13 @@ __device__ __forceinline__ void finish_channel_estimate(TrackShared& sh, const D
 // one-frame-per-wavefront layout it kept 15 of 64 lanes busy for half of the instructions of a symbol.  Every
 // serial sum of the reference keeps its order; the record in HBM carries the result to track_kernel, which
 // interpolates, equalises and demaps.
-template <int G>
+template <int G, bool FRESH>
 __global__ __launch_bounds__(kWave, 5) void track_pilot_kernel(const DemodConst* __restrict__ Dp, int n_frames,
                                                                float* __restrict__ state, const c32* __restrict__ fq_all,
                                                                float* __restrict__ trk_rec) {
+    constexpr bool fresh = FRESH;
+    // FRESH: the frame's first symbol on a demodulator as its constructor leaves it and without initial offsets (launch_demod:
+    // no init_state_kernel ran) — the record is not read, every field of it is written.
     constexpr int FPW = kWave / G;
     constexpr int kRow = G * 8 + 8;                            // floats per group: 8 terms per pilot, padded (banks)
     __shared__ __attribute__((aligned(16))) float s_terms[FPW][kRow];   // also the staging of the carrier-phase sum
@@ -732,16 +735,26 @@ __global__ __launch_bounds__(kWave, 5) void track_pilot_kernel(const DemodConst*
         float* st = state + (size_t)frame * kStFloats;
         const c32* fq = fq_all + (size_t)frame * (2 * D.fq_half);
         Track tr;
-        tr.freq_offset_hz = st[st_cfo]; tr.freq_offset_filtered = st[st_cfo_filt]; tr.cfo_phase = st[st_cfo_phase];
-        tr.noise_variance = st[st_noise]; tr.snr_linear = st[st_snr]; tr.timing = st[st_timing];
-        tr.ppc = mk(st[st_ppc_re], st[st_ppc_im]); tr.cpc = mk(st[st_cpc_re], st[st_cpc_im]);
-        const int flags = (int)st[st_flags];
-        tr.cpc_init = flags & 1; tr.has_prev = (flags >> 1) & 1; tr.has_dprev = (flags >> 2) & 1;
-        tr.snr_symbol_count = (int)st[st_count]; tr.symbols_since_sync = (int)st[st_since];
         const bool compact = compact_pilot_state(D);
-        const c32 h_old = !is_pilot ? mk(0.0f, 0.0f)
-                          : compact ? reinterpret_cast<const c32*>(st + kStHp)[sub] : reinterpret_cast<const c32*>(st + kStH)[ps];
-        const c32 prev = is_pilot ? reinterpret_cast<const c32*>(st + kStPrev)[sub] : mk(0.0f, 0.0f);
+        c32 h_old = mk(0.0f, 0.0f), prev = mk(0.0f, 0.0f);
+        if (fresh) {                                            // init_state_kernel's values (demodulator.cpp:26-43)
+            tr.freq_offset_hz = 0.0f; tr.freq_offset_filtered = 0.0f; tr.cfo_phase = 0.0f;
+            tr.noise_variance = 0.1f; tr.snr_linear = 1.0f; tr.timing = 0.0f;
+            tr.ppc = mk(1.0f, 0.0f); tr.cpc = mk(1.0f, 0.0f);
+            tr.cpc_init = 0; tr.has_prev = 0; tr.has_dprev = 0; tr.snr_symbol_count = 0; tr.symbols_since_sync = 0;
+            if (is_pilot) h_old = mk(1.0f, 0.0f);
+        } else {
+            tr.freq_offset_hz = st[st_cfo]; tr.freq_offset_filtered = st[st_cfo_filt]; tr.cfo_phase = st[st_cfo_phase];
+            tr.noise_variance = st[st_noise]; tr.snr_linear = st[st_snr]; tr.timing = st[st_timing];
+            tr.ppc = mk(st[st_ppc_re], st[st_ppc_im]); tr.cpc = mk(st[st_cpc_re], st[st_cpc_im]);
+            const int flags = (int)st[st_flags];
+            tr.cpc_init = flags & 1; tr.has_prev = (flags >> 1) & 1; tr.has_dprev = (flags >> 2) & 1;
+            tr.snr_symbol_count = (int)st[st_count]; tr.symbols_since_sync = (int)st[st_since];
+            if (is_pilot) {
+                h_old = compact ? reinterpret_cast<const c32*>(st + kStHp)[sub] : reinterpret_cast<const c32*>(st + kStH)[ps];
+                prev = reinterpret_cast<const c32*>(st + kStPrev)[sub];
+            }
+        }
         const float alpha = (tr.snr_symbol_count == 0) ? 1.0f : 0.9f;
 
         c32 h = mk(0.0f, 0.0f);
@@ -893,7 +906,8 @@ __global__ __launch_bounds__(kWave, 5) void track_pilot_kernel(const DemodConst*
             mine = (sub == st_flags) ? (float)(tr.cpc_init | (tr.has_prev << 1) | (tr.has_dprev << 2)) : mine;
             mine = (sub == st_count) ? (float)tr.snr_symbol_count : mine;
             mine = (sub == st_since) ? (float)tr.symbols_since_sync : mine;
-            if (sub <= st_since && sub != st_cfo_phase) st[sub] = mine;
+            mine = (sub == st_cfo_phase) ? tr.cfo_phase : mine;    // cfo_walk_kernel's, but for the record's first write
+            if (sub <= st_since && (fresh || sub != st_cfo_phase)) st[sub] = mine;
             if (trk_rec) {
                 float* rec = trk_rec + (size_t)frame * kTrkRecFloats;
                 if (is_pilot) reinterpret_cast<c32*>(rec + kTrkRecHp)[sub] = h_derot;

@@ -213,19 +213,6 @@ int launch_demod(ultra_hip_ctx* ctx, const float* d_audio, size_t frame_stride, 
     const unsigned grid_trk = (unsigned)std::min(n_frames, (size_t)ctx->cu_count * 128);
     hipStream_t st = ctx->stream;
     if (D.log2_fft != 10 && D.log2_fft != 9) return ULTRA_HIP_ERR_UNSUPPORTED;
-    if (s_begin == 0) {
-        LaunchSpan span(ctx, ULTRA_HIP_K_INIT_STATE);
-        // compact pilot state (demod_kernel.h, kStHp) and no training symbols that read the full H array first
-        const int compact = (!D.differential && D.n_pilot > 0 && D.n_train == 0) ? 1 : 0;
-        hipLaunchKernelGGL(dev::init_state_kernel, dim3(grid_trk), dim3(dev::kWave), 0, st, d_cfo_hz, d_cfo_phase,
-                           (int)n_frames, ctx->d_ws_state, compact, (D.adaptive_eq != 0 && !D.differential) ? 1 : 0);
-    }
-    if (s_begin == 0 && D.presynced && d_cfo_hz) {
-        // frames whose initial CFO is NaN ("never set"): estimateCFOFromTraining, demodulator.cpp:920-925
-        LaunchSpan span(ctx, ULTRA_HIP_K_INIT_STATE);
-        hipLaunchKernelGGL(dev::train_cfo_kernel, dim3((unsigned)((n_frames + 255) / 256)), dim3(256), 0, st, ctx->d_demod, ctx->d_nco,
-                           d_audio, frame_stride, d_frame_offset, d_cfo_hz, (int)n_frames, ctx->d_ws_state);
-    }
     const int n_sym = s_end - s_begin;
     // No pilots, SYNCED entry, no initial offsets: nothing on the path ever estimates a CFO (that is the pilot half's job),
     // it is 0 for every frame and every symbol, mix_fft_kernel never rotates — no phase tables to walk.
@@ -247,6 +234,23 @@ int launch_demod(ultra_hip_ctx* ctx, const float* d_audio, size_t frame_stride, 
     }
     if (deferred && ensure_trk_workspace(ctx, n_frames * (size_t)n_sym) != ULTRA_HIP_OK) { (void)hipGetLastError(); deferred = false; }
     { const int rc_fq = ensure_fq_workspace(ctx, n_frames); if (rc_fq != ULTRA_HIP_OK) return rc_fq; }
+    // A batch that starts at symbol 0 of the deferred chain without initial offsets: the pilot half of symbol 0 starts from the
+    // constructor's values itself (track_pilot_kernel, `fresh`) and writes the whole record — no initialisation launch, and
+    // no record read in that launch.  (With offsets given the walk of symbol 0 reads them from the record first.)
+    const bool fresh_pilot = deferred && s_begin == 0 && !cfo_given;
+    if (s_begin == 0 && !fresh_pilot) {
+        LaunchSpan span(ctx, ULTRA_HIP_K_INIT_STATE);
+        // compact pilot state (demod_kernel.h, kStHp) and no training symbols that read the full H array first
+        const int compact = (!D.differential && D.n_pilot > 0 && D.n_train == 0) ? 1 : 0;
+        hipLaunchKernelGGL(dev::init_state_kernel, dim3(grid_trk), dim3(dev::kWave), 0, st, d_cfo_hz, d_cfo_phase,
+                           (int)n_frames, ctx->d_ws_state, compact, (D.adaptive_eq != 0 && !D.differential) ? 1 : 0);
+    }
+    if (s_begin == 0 && D.presynced && d_cfo_hz) {
+        // frames whose initial CFO is NaN ("never set"): estimateCFOFromTraining, demodulator.cpp:920-925
+        LaunchSpan span(ctx, ULTRA_HIP_K_INIT_STATE);
+        hipLaunchKernelGGL(dev::train_cfo_kernel, dim3((unsigned)((n_frames + 255) / 256)), dim3(256), 0, st, ctx->d_demod, ctx->d_nco,
+                           d_audio, frame_stride, d_frame_offset, d_cfo_hz, (int)n_frames, ctx->d_ws_state);
+    }
     // The transform of symbol `sym` (n_sym_batch symbols from it on) of every frame: 512 points per wavefront, software-
     // pipelined (mix_fft2_kernel: two wavefronts per frame at N = 1024, one at N = 512), with or without the CFO rotation.
     auto launch_mix = [&](unsigned g, int sym, c32* fq, const unsigned* tab, int n_sym_batch) {
@@ -300,12 +304,20 @@ int launch_demod(ultra_hip_ctx* ctx, const float* d_audio, size_t frame_stride, 
             LaunchSpan span(ctx, ULTRA_HIP_K_PILOT);
             if (D.n_pilot <= 16) {
                 const unsigned g = (unsigned)std::min((n_frames + 3) / 4, (size_t)ctx->cu_count * 256);
-                hipLaunchKernelGGL(dev::track_pilot_kernel<16>, dim3(g), dim3(dev::kWave), 0, st, ctx->d_demod, (int)n_frames,
-                                   ctx->d_ws_state, fq_s, rec_s);
+                if (fresh_pilot && s == 0)
+                    hipLaunchKernelGGL((dev::track_pilot_kernel<16, true>), dim3(g), dim3(dev::kWave), 0, st, ctx->d_demod, (int)n_frames,
+                                       ctx->d_ws_state, fq_s, rec_s);
+                else
+                    hipLaunchKernelGGL((dev::track_pilot_kernel<16, false>), dim3(g), dim3(dev::kWave), 0, st, ctx->d_demod, (int)n_frames,
+                                       ctx->d_ws_state, fq_s, rec_s);
             } else {
                 const unsigned g = (unsigned)std::min((n_frames + 1) / 2, (size_t)ctx->cu_count * 512);
-                hipLaunchKernelGGL(dev::track_pilot_kernel<32>, dim3(g), dim3(dev::kWave), 0, st, ctx->d_demod, (int)n_frames,
-                                   ctx->d_ws_state, fq_s, rec_s);
+                if (fresh_pilot && s == 0)
+                    hipLaunchKernelGGL((dev::track_pilot_kernel<32, true>), dim3(g), dim3(dev::kWave), 0, st, ctx->d_demod, (int)n_frames,
+                                       ctx->d_ws_state, fq_s, rec_s);
+                else
+                    hipLaunchKernelGGL((dev::track_pilot_kernel<32, false>), dim3(g), dim3(dev::kWave), 0, st, ctx->d_demod, (int)n_frames,
+                                       ctx->d_ws_state, fq_s, rec_s);
             }
         }
         if (deferred) {
