@@ -386,8 +386,35 @@ __device__ __forceinline__ void symbol_to_freq2(Fft2Shared<LOG2N, ROT>& sh, cons
 #pragma unroll
     for (int j = 0; j < P; ++j) ph[j] = 0.0f;
     bool bounded = true;
-    if (cfo_on) {
-        bounded = (hw0 >> 31) != 0u;                         // walk_to_table: |start phase| <= 4 and |increment| <= 1
+    if (cfo_on) bounded = (hw0 >> 31) != 0u;                 // walk_to_table: |start phase| <= 4 and |increment| <= 1
+    // The common symbol: its whole window lies in ONE or TWO segments of the phase table (a CFO of a few hertz moves the
+    // phase by a fraction of a radian per symbol: at most one binade boundary or wrap).  Then every lane's run is "segment 0
+    // up to the start of segment 1, segment 1 from there on" with the SAME two segments — read once from the owners' lanes
+    // as scalars; no table in LDS, no claims, no ballots, no cross-lane fetches.
+    const bool two_segments = cfo_on && it_covered >= sym_len && tab_ns >= 1 && tab_ns <= 2;       // wave-uniform
+    if (two_segments) {
+        um::PhaseSeg s0, s1;
+        s0.start = __builtin_amdgcn_readlane(it.tab_start, 0);
+        s0.base = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(it.tab_base), 0));
+        s0.step = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(it.tab_step), 0));
+        s1.start = (tab_ns == 2) ? __builtin_amdgcn_readlane(it.tab_start, 1) : 0x7fffffff;
+        s1.base = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(it.tab_base), 1));
+        s1.step = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(it.tab_step), 1));
+        const int i0 = cp + W * P * lane + h, ilast = i0 + W * (P - 1);
+        float a[P], b[P];
+        const float step_a = s0.step * (float)W, step_b = s1.step * (float)W;      // exact (W = 1 or 2)
+        a[0] = um::phase_table_eval(s0, i0);               // forward from the run's first position: right while in segment 0
+        b[P - 1] = um::phase_table_eval(s1, ilast);        // backward from its last: right while in segment 1 (see below)
+#pragma unroll
+        for (int j = 1; j < P; ++j) { a[j] = a[j - 1] + step_a; b[P - 1 - j] = b[P - j] - step_b; }
+#pragma unroll
+        for (int j = 0; j < P; ++j) ph[j] = (i0 + W * j < s1.start) ? a[j] : b[j];
+#ifdef UH_MIXFFT_STAMPS
+        stamps.t[kStampPhases + 4] = 1ull;
+#endif
+        UH_STAMP(11);
+        UH_STAMP(12);
+    } else if (cfo_on) {
         int done = 0;
         float pcur = cfo_phase;
         const bool have_tab = it_covered > 0;
