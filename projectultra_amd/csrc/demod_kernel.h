@@ -392,6 +392,7 @@ __device__ __forceinline__ void symbol_to_freq2(Fft2Shared<LOG2N, ROT>& sh, cons
     // up to the start of segment 1, segment 1 from there on" with the SAME two segments — read once from the owners' lanes
     // as scalars; no table in LDS, no claims, no ballots, no cross-lane fetches.
     const bool two_segments = cfo_on && it_covered >= sym_len && tab_ns >= 1 && tab_ns <= 2;       // wave-uniform
+    float range_lo = 0.0f, range_hi = 0.0f;               // two_segments: bounds of every phase of the window (see there)
     if (two_segments) {
         um::PhaseSeg s0, s1;
         s0.start = __builtin_amdgcn_readlane(it.tab_start, 0);
@@ -409,6 +410,25 @@ __device__ __forceinline__ void symbol_to_freq2(Fft2Shared<LOG2N, ROT>& sh, cons
         for (int j = 1; j < P; ++j) { a[j] = a[j - 1] + step_a; b[P - 1 - j] = b[P - j] - step_b; }
 #pragma unroll
         for (int j = 0; j < P; ++j) ph[j] = (i0 + W * j < s1.start) ? a[j] : b[j];
+        // Inside a segment the phases are an arithmetic progression: over the window's positions cp .. cp + N - 1 (both
+        // parities: a superset of this wavefront's, which is all the one-quadrant test below needs) they are bounded by the
+        // values at the ends of the segments' parts — four scalar evaluations instead of two reductions over 512 phases.
+        {
+            constexpr int N = Fft2Shared<LOG2N>::N;
+            const int first = cp, last = cp + N - 1;
+            float lo = 3.402823466e+38f, hi = -3.402823466e+38f;
+            if (s1.start > first) {                              // part of the window in segment 0
+                const int e = (s1.start - 1 < last) ? s1.start - 1 : last;
+                const float x = um::phase_table_eval(s0, first), y = um::phase_table_eval(s0, e);
+                lo = fminf(x, y); hi = fmaxf(x, y);
+            }
+            if (s1.start <= last) {                              // part in segment 1
+                const int b0 = (s1.start > first) ? s1.start : first;
+                const float x = um::phase_table_eval(s1, b0), y = um::phase_table_eval(s1, last);
+                lo = fminf(lo, fminf(x, y)); hi = fmaxf(hi, fmaxf(x, y));
+            }
+            range_lo = lo; range_hi = hi;
+        }
 #ifdef UH_MIXFFT_STAMPS
         stamps.t[kStampPhases + 4] = 1ull;
 #endif
@@ -542,10 +562,13 @@ __device__ __forceinline__ void symbol_to_freq2(Fft2Shared<LOG2N, ROT>& sh, cons
             // select of sincosf_bounded_ (sign of the reduced argument, sign of the cosine, swap, the |y| < 2^-12 case) is then a
             // scalar choice made once (um::sincosf_quadrant_: the same fused operations on the same operands) — 22
             // instead of 61 vector instructions per sample.
-            float plo = fminf(fminf(fminf(ph[0], ph[1]), fminf(ph[2], ph[3])), fminf(fminf(ph[4], ph[5]), fminf(ph[6], ph[7])));
-            float phi = fmaxf(fmaxf(fmaxf(ph[0], ph[1]), fmaxf(ph[2], ph[3])), fmaxf(fmaxf(ph[4], ph[5]), fmaxf(ph[6], ph[7])));
             static_assert(P == 8, "eight phases per lane");
-            const float wlo = wave_fmin(plo), whi = wave_fmax(phi);
+            float wlo = range_lo, whi = range_hi;
+            if (!two_segments) {
+                const float plo = fminf(fminf(fminf(ph[0], ph[1]), fminf(ph[2], ph[3])), fminf(fminf(ph[4], ph[5]), fminf(ph[6], ph[7])));
+                const float phi = fmaxf(fmaxf(fmaxf(ph[0], ph[1]), fmaxf(ph[2], ph[3])), fmaxf(fmaxf(ph[4], ph[5]), fmaxf(ph[6], ph[7])));
+                wlo = wave_fmin(plo); whi = wave_fmax(phi);
+            }
             int n_lo, n_hi;
             (void)um::reduce_fast((double)wlo, &n_lo);
             (void)um::reduce_fast((double)whi, &n_hi);
