@@ -38,6 +38,7 @@
 #define ULTRA_DEMOD_KERNEL_H
 
 #include <hip/hip_runtime.h>
+#include <utility>
 #include "device_types.h"
 #include "pinned_math.h"
 #include "phase_table.h"
@@ -322,6 +323,12 @@ __device__ __forceinline__ void request_item(MixItem& it, const unsigned* __rest
     }
 }
 
+template <int W, int... Q>
+__device__ __forceinline__ void prefetch_copies(const float* g0, unsigned zone, std::integer_sequence<int, Q...>) {
+    using lds_f32 = __attribute__((address_space(3))) float;
+    (__builtin_amdgcn_global_load_lds(g0, (lds_f32*)(size_t)(zone + 256u * (unsigned)Q - 256u * (unsigned)(W * Q)), 4, 256 * W * Q, 0), ...);
+}
+
 // staging of the samples of parity h of one symbol's FFT window: stage[64 q + l] = window[2 (64 q + l) + h] (W = 1: all
 // samples, window[64 q + l])
 template <int LOG2N, bool ROT>
@@ -329,9 +336,17 @@ __device__ __forceinline__ void prefetch_symbol2(Fft2Shared<LOG2N, ROT>& sh, con
                                                  const float* __restrict__ audio_sym) {
     constexpr int P = Fft2Shared<LOG2N>::P, W = Fft2Shared<LOG2N>::W;
     float* stage = sh.stage[h];
-#pragma unroll
-    for (int q = 0; q < P; ++q)
-        __builtin_amdgcn_global_load_lds(audio_sym + cp + W * (64 * q + lane) + h, stage + 64 * q, 4, 0, 0);
+    // ONE base kept alive across the items: left to itself the compiler precomputes the eight LDS addresses (M0 values) of the
+    // copies once per workgroup, holds them in eight scalar registers the rotating instance does not have, spills them into
+    // VGPR lanes and reads each back with a v_readlane per copy and item.  Behind this barrier an address is base + constant.
+    using lds_f32 = __attribute__((address_space(3))) float;
+    unsigned zone = (unsigned)(size_t)(lds_f32*)stage;      // the zone's 32-bit LDS address
+    asm volatile("" : "+s"(zone));
+    // Copy q reads 256 W bytes behind copy q - 1 and lands 256 bytes behind it.  The instruction's immediate offset moves
+    // BOTH addresses, so it carries the global stride (256 W q <= 3584: fits the 13-bit field) and M0 takes the difference
+    // back (the zone lies behind the exchange buffer: zone - 256 (W - 1) q stays a valid LDS address): one global address
+    // for the eight copies instead of eight 64-bit vector additions per item.
+    prefetch_copies<W>(audio_sym + cp + W * lane + h, zone, std::make_integer_sequence<int, P>{});
 }
 
 // per-lane values that do not change from item to item: the oscillator at the lane's 8 samples (for one symbol index)
