@@ -959,29 +959,34 @@ __global__ __launch_bounds__(kWave, 5) void track_pilot_kernel(const DemodConst*
             // instruction per wavefront writing 52 contiguous bytes per record, where lane 0 storing all twelve was
             // twelve instructions of four 4-byte writes each.  st_cfo_phase belongs to cfo_walk_kernel.
             static_assert(st_since == 12 && st_cfo_phase == 2 && G >= 13, "scalar block layout");
+            // (the lane index made opaque HERE: left to itself the compiler computes the seventeen lane masks `sub == k` of
+            // the two select chains below once per workgroup, holds them in 34 scalar registers it does not have, spills them
+            // into VGPR lanes and reads every one back with two v_readlane per group of frames — a compare is cheaper)
+            int subw = sub;
+            asm volatile("" : "+v"(subw));
             float mine = tr.freq_offset_hz;
-            mine = (sub == st_cfo_filt) ? tr.freq_offset_filtered : mine;
-            mine = (sub == st_noise) ? tr.noise_variance : mine;
-            mine = (sub == st_snr) ? tr.snr_linear : mine;
-            mine = (sub == st_timing) ? tr.timing : mine;
-            mine = (sub == st_ppc_re) ? tr.ppc.re : mine;
-            mine = (sub == st_ppc_im) ? tr.ppc.im : mine;
-            mine = (sub == st_cpc_re) ? tr.cpc.re : mine;
-            mine = (sub == st_cpc_im) ? tr.cpc.im : mine;
-            mine = (sub == st_flags) ? (float)(tr.cpc_init | (tr.has_prev << 1) | (tr.has_dprev << 2)) : mine;
-            mine = (sub == st_count) ? (float)tr.snr_symbol_count : mine;
-            mine = (sub == st_since) ? (float)tr.symbols_since_sync : mine;
-            mine = (sub == st_cfo_phase) ? tr.cfo_phase : mine;    // cfo_walk_kernel's, but for the record's first write
+            mine = (subw == st_cfo_filt) ? tr.freq_offset_filtered : mine;
+            mine = (subw == st_noise) ? tr.noise_variance : mine;
+            mine = (subw == st_snr) ? tr.snr_linear : mine;
+            mine = (subw == st_timing) ? tr.timing : mine;
+            mine = (subw == st_ppc_re) ? tr.ppc.re : mine;
+            mine = (subw == st_ppc_im) ? tr.ppc.im : mine;
+            mine = (subw == st_cpc_re) ? tr.cpc.re : mine;
+            mine = (subw == st_cpc_im) ? tr.cpc.im : mine;
+            mine = (subw == st_flags) ? (float)(tr.cpc_init | (tr.has_prev << 1) | (tr.has_dprev << 2)) : mine;
+            mine = (subw == st_count) ? (float)tr.snr_symbol_count : mine;
+            mine = (subw == st_since) ? (float)tr.symbols_since_sync : mine;
+            mine = (subw == st_cfo_phase) ? tr.cfo_phase : mine;    // cfo_walk_kernel's, but for the record's first write
             if (sub <= st_since && (fresh || sub != st_cfo_phase)) st[sub] = mine;
             if (trk_rec) {
                 float* rec = trk_rec + (size_t)frame * kTrkRecFloats;
                 if (is_pilot) reinterpret_cast<c32*>(rec + kTrkRecHp)[sub] = h_derot;
                 float v = tr.noise_variance;                    // lane sub stores scalar sub of the record's tail
-                v = (sub == tk_timing - tk_noise) ? tr.timing : v;
-                v = (sub == tk_cfo - tk_noise) ? tr.freq_offset_hz : v;
-                v = (sub == tk_snr - tk_noise) ? tr.snr_linear : v;
-                v = (sub == tk_phase - tk_noise) ? tr.cfo_phase : v;
-                v = (sub == tk_count - tk_noise) ? (float)tr.snr_symbol_count : v;
+                v = (subw == tk_timing - tk_noise) ? tr.timing : v;
+                v = (subw == tk_cfo - tk_noise) ? tr.freq_offset_hz : v;
+                v = (subw == tk_snr - tk_noise) ? tr.snr_linear : v;
+                v = (subw == tk_phase - tk_noise) ? tr.cfo_phase : v;
+                v = (subw == tk_count - tk_noise) ? (float)tr.snr_symbol_count : v;
                 if (sub < 8) rec[tk_noise + sub] = (sub <= tk_count - tk_noise) ? v : 0.0f;
             }
         }
