@@ -1450,7 +1450,9 @@ __global__ __launch_bounds__(Fft2Shared<LOG2N>::W * kWave) __attribute__((amdgpu
     // load looks cheaper to it than a spill) and waits for them, ~1000 cycles per item in the stamps of that version.
     int sym_len = D.sym_len, cp = D.cp, grid_step = (int)gridDim.x;
     asm volatile("" : "+s"(sym_len), "+s"(cp), "+s"(grid_step));
-    auto ds_of = [&](int w) { return (n_sym_batch > 1) ? w / n_frames : 0; };
+    // (the rotating instance is launched for ONE symbol index at a time — its symbols depend on the tracker, launch_demod —,
+    // so it carries neither the division nor its constants)
+    auto ds_of = [&](int w) { return (!ROT && n_sym_batch > 1) ? w / n_frames : 0; };
     auto request = [&](MixItem& it, int w) {
         const int ds = ds_of(w), f = w - ds * n_frames;
         const float* audio_sym = audio + (size_t)f * frame_stride + (frame_offset ? frame_offset[f] : 0u) + (size_t)(sym + ds) * sym_len;

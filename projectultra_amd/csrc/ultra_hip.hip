@@ -258,6 +258,7 @@ int launch_demod(ultra_hip_ctx* ctx, const float* d_audio, size_t frame_stride, 
             hipLaunchKernelGGL(kernel, dim3(g), dim3(threads), 0, st, ctx->d_demod, ctx->d_nco, ctx->d_twiddle, d_audio, frame_stride,
                                d_frame_offset, (int)n_frames, sym, fq, tab, n_sym_batch);
         };
+        if (tab && n_sym_batch != 1) std::abort();     // mix_fft2_kernel<.., true> takes one symbol index per launch (ds_of)
         if (D.log2_fft == 10) {
             if (tab) go(dev::mix_fft2_kernel<10, true>, 2 * dev::kWave);
             else go(dev::mix_fft2_kernel<10, false>, 2 * dev::kWave);
