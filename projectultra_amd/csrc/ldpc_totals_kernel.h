@@ -38,6 +38,7 @@
 
 namespace ultra_hip {
 namespace dev {
+typedef float pk2 __attribute__((ext_vector_type(2)));     // two single-precision lanes of one v_pk_* instruction
 
 // Diagnostic build only (-DUH_LDPC_STAMPS, tools/ldpc_stalls.py): shader-clock time of one codeword split over the phases of
 // the loop below, summed over its iterations — record of kLdpcStampWords 64-bit words per codeword: [0] start, [1] end,
@@ -138,6 +139,7 @@ __global__ __launch_bounds__(kLdpcThreads, WAVES) void ldpc_totals_kernel(
     uint8_t* __restrict__ bytes, int32_t* __restrict__ iters, uint8_t* __restrict__ okv,
     float* __restrict__ llr_total, unsigned int* __restrict__ work_counter, int llr_step,
     const uint16_t* __restrict__ llr_perm, int block_len, int block_stride) {
+    constexpr bool kPacked = RR >= 8;          // R1/4's instance: packed single-precision subtract / multiply / add (row phase below)
     // block_len > 0 (ultra_hip_ldpc_decode_blocks): codeword c is row (c / block_len) * block_stride + c % block_len of the
     // LLR array — several equally long runs of rows inside a larger array (one code rate's share of a mode grid) decoded
     // by ONE launch; results stay dense (row c).
@@ -306,16 +308,45 @@ __global__ __launch_bounds__(kLdpcThreads, WAVES) void ldpc_totals_kernel(
                     for (int t = 0; t < S; ++t) synd ^= (tot[t] < 0);          // hard decisions of :227-230
                     all_hold = (__ballot(synd) & row_mask[r]) == 0ull;
                 }
+                // var_to_check = llr_total - check_to_var (:216-219).  kPacked (R1/4's instance): two edges per instruction — a
+                // packed single-precision subtraction is two IEEE subtractions in one 4-cycle issue slot (two 2-cycle ones cost
+                // 4.6).  Measured: R1/4 4.74 -> 4.53 ms per 2^17 codewords; the instances that already saturate the vector unit
+                // at 4-5 wavefronts per SIMD lose 1-4 % with it (register pairs), so they keep the scalar form.
+                {
+                    float full[7];
 #pragma unroll
-                for (int t = 0; t < S; ++t) v[t] = tot[t] - c2v[r][t];         // var_to_check = llr_total - check_to_var (:216-219)
-                v[S] = tp - c2v[r][S];
+                    for (int t = 0; t < S; ++t) full[t] = tot[t];
+                    full[S] = tp;
+                    if constexpr (kPacked) {
+#pragma unroll
+                        for (int t = 0; t + 1 <= S; t += 2) {
+                            const pk2 d = pk2{full[t], full[t + 1]} - pk2{c2v[r][t], c2v[r][t + 1]};
+                            v[t] = d.x; v[t + 1] = d.y;
+                        }
+                        if (((S + 1) & 1) != 0) v[S] = full[S] - c2v[r][S];
+                    } else {
+#pragma unroll
+                        for (int t = 0; t <= S; ++t) v[t] = full[t] - c2v[r][t];
+                    }
+                }
 #pragma unroll
                 for (int t = 0; t <= S; ++t) { ng[t] = v[t] < 0; par ^= ng[t]; }
                 leave_one_out_min<S + 1>(v, cap, mn);
+                {
+                    float mag[7];
+                    if constexpr (kPacked) {
 #pragma unroll
-                for (int t = 0; t <= S; ++t) {
-                    const float mag = mn[t] * 0.75f;
-                    c2v[r][t] = (par != ng[t]) ? -mag : mag;                   // sign * min * 0.75f (:201)
+                        for (int t = 0; t + 1 <= S; t += 2) {
+                            const pk2 m = pk2{mn[t], mn[t + 1]} * pk2{0.75f, 0.75f};
+                            mag[t] = m.x; mag[t + 1] = m.y;
+                        }
+                        if (((S + 1) & 1) != 0) mag[S] = mn[S] * 0.75f;
+                    } else {
+#pragma unroll
+                        for (int t = 0; t <= S; ++t) mag[t] = mn[t] * 0.75f;
+                    }
+#pragma unroll
+                    for (int t = 0; t <= S; ++t) c2v[r][t] = (par != ng[t]) ? -mag[t] : mag[t];   // sign * min * 0.75f (:201)
                 }
                 // S lane-linear stores, planes named by immediate offsets behind M0 = 0
                 tprof_store_planes<S, R_BASE + tprof_planes_before(RPROF, r) * 256>(c2v[r]);
@@ -337,13 +368,24 @@ __global__ __launch_bounds__(kLdpcThreads, WAVES) void ldpc_totals_kernel(
                 for (int r = 0; r < VR; ++r)
 #pragma unroll
                     for (int q = 0; q < D; ++q) if (q < ldpc_prof(VPROF, r)) c[r][q] = ldsf(caddr[r][q]);  // a missing edge reads a pad word: -0.0f
+                // the sums of two rounds side by side where their degrees agree (packed additions), in ascending check order each
+                ldpc_static_for(std::make_integer_sequence<int, (VR + 1) / 2>{}, [&](auto pair) {
+                    constexpr int r = 2 * decltype(pair)::value;
+                    if constexpr (kPacked && r + 1 < VR && ldpc_prof(VPROF, r) == ldpc_prof(VPROF, r + 1)) {
+                        pk2 tot = pk2{llr_v[r], llr_v[r + 1]};
 #pragma unroll
-                for (int r = 0; r < VR; ++r) {
-                    float tot = llr_v[r];
+                        for (int q = 0; q < D; ++q) if (q < ldpc_prof(VPROF, r)) tot += pk2{c[r][q], c[r + 1][q]};
+                        tots[r] = tot.x; tots[r + 1] = tot.y;
+                    } else {
 #pragma unroll
-                    for (int q = 0; q < D; ++q) if (q < ldpc_prof(VPROF, r)) tot += c[r][q];
-                    tots[r] = tot;
-                }
+                        for (int rr = r; rr < r + 2 && rr < VR; ++rr) {
+                            float tot = llr_v[rr];
+#pragma unroll
+                            for (int q = 0; q < D; ++q) if (q < ldpc_prof(VPROF, rr)) tot += c[rr][q];
+                            tots[rr] = tot;
+                        }
+                    }
+                });
             }
             tprof_store_totals<VR>(tots);
             UH_LD_ACC(5);
