@@ -272,6 +272,7 @@ int launch_demod(ultra_hip_ctx* ctx, const float* d_audio, size_t frame_stride, 
         const unsigned g = mix_grid(n_frames * (size_t)n_sym);
         launch_mix(g, s_begin, ctx->d_ws_fq, nullptr, n_sym);       // cfo_is_zero: no table, the instance without the rotation
     }
+    int mixed_upto = 0;                                  // symbols below this index are transformed already
     for (int s = s_begin; s < s_end; ++s) {
         c32* fq_s = ctx->d_ws_fq + ((all_symbols_at_once || deferred) ? (size_t)(s - s_begin) * n_frames * (size_t)(2 * D.fq_half) : (size_t)0);
         float* rec_s = deferred ? ctx->d_ws_trk + (size_t)(s - s_begin) * n_frames * dev::kTrkRecFloats : nullptr;
@@ -286,9 +287,17 @@ int launch_demod(ultra_hip_ctx* ctx, const float* d_audio, size_t frame_stride, 
             hipLaunchKernelGGL(dev::cfo_walk_kernel, dim3((unsigned)((n_frames + 255) / 256)), dim3(256), 0, st, ctx->d_demod,
                                (int)n_frames, ctx->d_ws_state, ctx->d_ws_seg);
         }
-        if (!all_symbols_at_once) {
+        if (!all_symbols_at_once && s >= mixed_upto) {
             LaunchSpan span(ctx, ULTRA_HIP_K_MIX_FFT);
-            launch_mix(grid_fft, s, fq_s, seg_tab_s, 1);        // no table: CFO 0 in every frame, the instance without the rotation
+            // Symbols 0 and 1 of a fresh batch on the deferred chain are both at CFO 0 and their bins go to consecutive row
+            // blocks: ONE launch over 2 n_frames items transforms both (the tracker of symbol 0 does not feed symbol 1's
+            // transform) — one ramp-up and drain less, which is what a rank's share of the strong-scaling batch notices.
+            if (deferred && s == 0 && first_at_zero && s + 1 < s_end && n_frames * (size_t)2 < 0x7fffffffull) {
+                launch_mix(mix_grid(n_frames * 2), s, fq_s, nullptr, 2);
+                mixed_upto = 2;
+            } else {
+                launch_mix(grid_fft, s, fq_s, seg_tab_s, 1);    // no table: CFO 0 in every frame, the instance without the rotation
+            }
         }
         const bool training = s < D.n_train;
         const bool last = (s == s_end - 1);
