@@ -112,14 +112,15 @@ def source_hash() -> str:
     tell whether they were collected on the code that is in the tree now; it works on the GPU box, where no .git exists."""
     import hashlib
     h = hashlib.sha256()
-    for f in sorted(list(CSRC_DIR.glob("*.h")) + list(CSRC_DIR.glob("*.hip")) + [PKG_DIR.parent / "include" / "ultra_hip.h"]):
+    # (the Makefile too: the compile flags decide the kernels' code as much as the sources do)
+    for f in sorted(list(CSRC_DIR.glob("*.h")) + list(CSRC_DIR.glob("*.hip")) + [CSRC_DIR / "Makefile", PKG_DIR.parent / "include" / "ultra_hip.h"]):
         h.update(f.name.encode()); h.update(b"\0"); h.update(f.read_bytes())
     return h.hexdigest()[:16]
 
 
 def build(force: bool = False) -> Path:
     """Compile libultra_hip.so for gfx950 in-tree (hipcc cross-compiles without a GPU)."""
-    srcs = [CSRC_DIR / "ultra_hip.hip"] + sorted(CSRC_DIR.glob("*.h")) + [PKG_DIR.parent / "include" / "ultra_hip.h"]
+    srcs = [CSRC_DIR / "ultra_hip.hip", CSRC_DIR / "Makefile"] + sorted(CSRC_DIR.glob("*.h")) + [PKG_DIR.parent / "include" / "ultra_hip.h"]
     stale = (not LIB_PATH.exists()) or any(s.stat().st_mtime > LIB_PATH.stat().st_mtime for s in srcs)
     if force or stale:
         subprocess.check_call(["make", "-C", str(CSRC_DIR)] + (["-B"] if force else []))

@@ -4,7 +4,7 @@
 #   build/v_<name>.so               one per "name=flags" argument, e.g.  bash tools/build_variants.sh occ4="-DUH_MIX2_WAVES=4"
 cd "$(dirname "$0")/../projectultra_amd/csrc" || exit 1
 mkdir -p ../../build
-FL="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -shared -ffp-contract=off -fno-fast-math -fhip-fp32-correctly-rounded-divide-sqrt -ldl"
+FL="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -shared -ffp-contract=off -fno-fast-math -fno-slp-vectorize -fhip-fp32-correctly-rounded-divide-sqrt -ldl"
 /opt/rocm/bin/hipcc $FL -DUH_MIXFFT_STAMPS $STAMP_FLAGS -o ../../build/stamps.so ultra_hip.hip 2>&1 | grep -E "error"
 for a in "$@"; do
   name=${a%%=*}; flags=${a#*=}

@@ -143,7 +143,7 @@ def main():
         asm = Path(args.asm).read_text()
     else:
         src = ROOT / "projectultra_amd" / "csrc" / "ultra_hip.hip"
-        asm = subprocess.check_output(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fno-fast-math",
+        asm = subprocess.check_output(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fno-fast-math", "-fno-slp-vectorize",
                                        "-fhip-fp32-correctly-rounded-divide-sqrt", "-S", "--cuda-device-only", "-o", "-", str(src)],
                                       stderr=subprocess.DEVNULL, cwd=src.parent).decode()
     fns = functions(asm)

@@ -3,7 +3,7 @@
 # -Rpass-analysis=kernel-resource-usage.  usage: bash tools/kernel_resources.sh [regex] [extra hipcc flags]
 cd "$(dirname "$0")/../projectultra_amd/csrc" || exit 1
 PAT=${1:-.}; shift
-/opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -shared -ffp-contract=off -fno-fast-math \
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -shared -ffp-contract=off -fno-fast-math -fno-slp-vectorize \
   -fhip-fp32-correctly-rounded-divide-sqrt -Rpass-analysis=kernel-resource-usage "$@" -o /dev/null ultra_hip.hip 2>&1 |
 python3 -c "
 import re,sys,subprocess

@@ -31,7 +31,7 @@ def static_phases(flags):
     import issue_model as im
     costs, _ = im.parse_issue_table(ROOT / "profiles" / "r02_issue_table.txt")
     src = ROOT / "projectultra_amd" / "csrc" / "ultra_hip.hip"
-    asm = subprocess.check_output(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fno-fast-math",
+    asm = subprocess.check_output(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fno-fast-math", "-fno-slp-vectorize",
                                    "-fhip-fp32-correctly-rounded-divide-sqrt", "-DUH_LDPC_STAMPS"] + flags + ["-S", "--cuda-device-only", "-o", "-", str(src)],
                                   stderr=subprocess.DEVNULL, cwd=src.parent).decode()
     fns = im.functions(asm)
