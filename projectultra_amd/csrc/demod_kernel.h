@@ -300,6 +300,10 @@ struct Fft2Shared {
     um::PhaseSeg seg[W][ROT ? kPhaseCap + 2 : 1];           // two entries behind the last segment: start = INT_MAX
     int seg_start[W][ROT ? kPhaseCap + 4 : 4] __attribute__((aligned(16)));
     c32 xch[W == 2 ? 2 : 1][2][W == 2 ? kWave : 1];         // [frame parity][writer][lane]: E_hi from wavefront 0, O_lo from 1
+    // The rotating instance keeps the oscillator at the lane's eight samples HERE instead of in sixteen registers it does not
+    // have (the rotation factors stay in registers since round 4): osc[h][64 q + lane], written and read by the same lane.
+    // 8 KB (N = 1024): six workgroups per CU still fit, which is what its registers allow anyway.
+    c32 osc[ROT ? W : 1][ROT ? M : 1];
 };
 
 // What an item needs from memory besides its samples: the tracker's CFO and phase and this lane's entry of the frame's
@@ -322,6 +326,12 @@ __device__ __forceinline__ void request_item(MixItem& it, const unsigned* __rest
         it.tab_start = (int)e[0]; it.tab_base = __uint_as_float(e[1]); it.tab_step = __uint_as_float(e[2]);
     }
 }
+
+// compile-time loop: f(std::integral_constant<int, 0>{}), ..., f(<N - 1>)
+template <class F, int... Is>
+__device__ __forceinline__ void static_for_n_(F&& f, std::integer_sequence<int, Is...>) { (f(std::integral_constant<int, Is>{}), ...); }
+template <int N, class F>
+__device__ __forceinline__ void static_for_n(F&& f) { static_for_n_(f, std::make_integer_sequence<int, N>{}); }
 
 template <int W, int... Q>
 __device__ __forceinline__ void prefetch_copies(const float* g0, unsigned zone, std::integer_sequence<int, Q...>) {
@@ -416,15 +426,18 @@ __device__ __forceinline__ void symbol_to_freq2(Fft2Shared<LOG2N, ROT>& sh, cons
         s1.start = (tab_ns == 2) ? __builtin_amdgcn_readlane(it.tab_start, 1) : 0x7fffffff;
         s1.base = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(it.tab_base), 1));
         s1.step = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(it.tab_step), 1));
-        const int i0 = cp + W * P * lane + h, ilast = i0 + W * (P - 1);
+        // ... and with only two segments ANY eight ascending positions are "segment 0 up to a point, segment 1 from there":
+        // the lane takes the phases of the very samples it mixes (window positions W (rl + 64 q) + h, 64 W apart) — the
+        // rotation factors then never leave its registers: no exchange through LDS between the evaluation and the mixing.
+        const int i0 = cp + W * rl + h, ilast = i0 + W * 64 * (P - 1);
         float a[P], b[P];
-        const float step_a = s0.step * (float)W, step_b = s1.step * (float)W;      // exact (W = 1 or 2)
-        a[0] = um::phase_table_eval(s0, i0);               // forward from the run's first position: right while in segment 0
-        b[P - 1] = um::phase_table_eval(s1, ilast);        // backward from its last: right while in segment 1 (see below)
+        const float step_a = s0.step * (float)(64 * W), step_b = s1.step * (float)(64 * W);      // exact (powers of two)
+        a[0] = um::phase_table_eval(s0, i0);               // forward from the lane's first position: right while in segment 0
+        b[P - 1] = um::phase_table_eval(s1, ilast);        // backward from its last: right while in segment 1
 #pragma unroll
         for (int j = 1; j < P; ++j) { a[j] = a[j - 1] + step_a; b[P - 1 - j] = b[P - j] - step_b; }
 #pragma unroll
-        for (int j = 0; j < P; ++j) ph[j] = (i0 + W * j < s1.start) ? a[j] : b[j];
+        for (int j = 0; j < P; ++j) ph[j] = (i0 + W * 64 * j < s1.start) ? a[j] : b[j];
         // Inside a segment the phases are an arithmetic progression: over the window's positions cp .. cp + N - 1 (both
         // parities: a superset of this wavefront's, which is all the one-quadrant test below needs) they are bounded by the
         // values at the ends of the segments' parts — four scalar evaluations instead of two reductions over 512 phases.
@@ -569,13 +582,17 @@ __device__ __forceinline__ void symbol_to_freq2(Fft2Shared<LOG2N, ROT>& sh, cons
     UH_STAMP(13);
     request_next();
     UH_STAMP(2);
-    if (cfo_on) {
+    // The rotation factors of the lane's eight phases, handed one by one to `sink(j, factor)` (j a compile-time index).
+    // Two sinks: with one or two segments the phases are those of the lane's OWN samples (see above) and the factor is mixed
+    // in at once — it never leaves the registers; otherwise the phases are a run of consecutive samples and the factors go
+    // through LDS to the lanes that mix them.
+    auto for_each_factor = [&](auto sink) {
         if (bounded) {
             // Do all 512 phases of this wavefront-item reduce to the same quadrant?  reduce_fast is monotone in y, so the
             // quadrants of the smallest and of the largest phase settle it —
             // true for most items: a symbol's phases span |2 pi CFO 1024 / fs|, a fraction of a radian.  Every per-lane
             // select of sincosf_bounded_ (sign of the reduced argument, sign of the cosine, swap, the |y| < 2^-12 case) is then a
-            // scalar choice made once (um::sincosf_quadrant_: the same fused operations on the same operands) — 22
+            // scalar choice made once (um::sincosf_quadrant_: the same fused operations on the same operands) — 17
             // instead of 61 vector instructions per sample.
             static_assert(P == 8, "eight phases per lane");
             float wlo = range_lo, whi = range_hi;
@@ -606,13 +623,12 @@ __device__ __forceinline__ void symbol_to_freq2(Fft2Shared<LOG2N, ROT>& sh, cons
                 (void)y_sign; (void)cos_sign; (void)swap;              // compile-time in the four instances below (Q = n & 3)
                 auto block = [&](auto q_) {
                     constexpr int Q = decltype(q_)::value;
-#pragma unroll
-                    for (int j = 0; j < P; ++j) {
+                    static_for_n<P>([&](auto jc) {
+                        constexpr int j = decltype(jc)::value;
                         float sn, cs;
                         um::sincosf_quadrant_q<Q>(ph[j], m_n, &sn, &cs);
-                        const int m = P * lane + j;
-                        rot[m + (m >> A)] = mk(cs, sn);
-                    }
+                        sink(jc, mk(cs, sn));
+                    });
                 };
                 switch (n_lo & 3) {                                    // wave-uniform
                     case 0: block(std::integral_constant<int, 0>{}); break;
@@ -621,27 +637,41 @@ __device__ __forceinline__ void symbol_to_freq2(Fft2Shared<LOG2N, ROT>& sh, cons
                     default: block(std::integral_constant<int, 3>{}); break;
                 }
             } else {
-#pragma unroll
-                for (int j = 0; j < P; ++j) {
+                static_for_n<P>([&](auto jc) {
+                    constexpr int j = decltype(jc)::value;
                     float sn, cs;
                     um::sincosf_bounded_(ph[j], &sn, &cs);
-                    const int m = P * lane + j;
-                    rot[m + (m >> A)] = mk(cs, sn);
-                }
+                    sink(jc, mk(cs, sn));
+                });
             }
         } else {
-#pragma unroll 2
-            for (int j = 0; j < P; ++j) { const int m = P * lane + j; rot[m + (m >> A)] = cexpj(ph[j]); }
+            static_for_n<P>([&](auto jc) { sink(jc, cexpj(ph[decltype(jc)::value])); });
         }
-        wave_sync();
-    }
-    UH_STAMP(3);
+    };
     // ---- mix: samples[i] * conj(osc) (* rotation) ----
+    if (cfo_on && two_segments) {
+        c32 rv[P];
+        for_each_factor([&](auto jc, c32 r) { rv[decltype(jc)::value] = r; });
+        UH_STAMP(3);
 #pragma unroll
-    for (int qp = 0; qp < P; ++qp) {
-        c32 mixed = mk(lc.os[qp].re * xs[qp], (-lc.os[qp].im) * xs[qp]);
-        if (cfo_on) { const int m = rl + 64 * qp; mixed = cmul(mixed, rot[m + (m >> A)]); }
-        v[bitrev_small<A>(qp)] = mixed;
+        for (int qp = 0; qp < P; ++qp) {
+            const c32 o = ROT ? sh.osc[ROT ? h : 0][ROT ? 64 * qp + lane : 0] : lc.os[qp];
+            const c32 mixed = mk(o.re * xs[qp], (-o.im) * xs[qp]);
+            v[bitrev_small<A>(qp)] = cmul(mixed, rv[qp]);
+        }
+    } else {
+        if (cfo_on) {
+            for_each_factor([&](auto jc, c32 r) { const int m = P * lane + decltype(jc)::value; rot[m + (m >> A)] = r; });
+            wave_sync();
+        }
+        UH_STAMP(3);
+#pragma unroll
+        for (int qp = 0; qp < P; ++qp) {
+            const c32 o = ROT ? sh.osc[ROT ? h : 0][ROT ? 64 * qp + lane : 0] : lc.os[qp];
+            c32 mixed = mk(o.re * xs[qp], (-o.im) * xs[qp]);
+            if (cfo_on) { const int m = rl + 64 * qp; mixed = cmul(mixed, rot[m + (m >> A)]); }
+            v[bitrev_small<A>(qp)] = mixed;
+        }
     }
     if (cfo_on) wave_sync();
     UH_STAMP(4);
@@ -1499,6 +1529,10 @@ __global__ __launch_bounds__(Fft2Shared<LOG2N>::W * kWave) __attribute__((amdgpu
             // also wait for the requests of the next item issued in between
 #pragma unroll
             for (int qp = 0; qp < P; ++qp) asm volatile("" ::"v"(lc.os[qp].re), "v"(lc.os[qp].im));
+            if constexpr (ROT) {                               // ... into the lane's LDS slots; the registers are free again
+#pragma unroll
+                for (int qp = 0; qp < P; ++qp) { sh.osc[h][64 * qp + lane] = lc.os[qp]; lc.os[qp] = mk(0.0f, 0.0f); }
+            }
         }
         const int next = w + grid_step;
         Stamps stamps;
