@@ -242,3 +242,17 @@ def test_bench_starts_its_own_ranks_and_a_failing_rank_fails_the_run():
     env.update(RANK="0", LOCAL_RANK="0", WORLD_SIZE="1", MASTER_ADDR="127.0.0.1", MASTER_PORT="29533")
     p = subprocess.run([sys.executable, str(ROOT / "bench.py"), "--gpus", "4", "--no-build"], capture_output=True, text=True, timeout=600, env=env)
     assert p.returncode != 0 and "refusing" in p.stderr and not p.stdout.strip()
+
+
+def test_device_build_flags():
+    """The flags the parity and the measured rates depend on (csrc/Makefile): no contraction, no fast-math, correctly rounded
+    division, and no SLP vectoriser (its packed pairs cost 4.6 % of the headline step: profiles/r04_ab_no_slp_vectorize.txt);
+    the variant builds and the ISA tools use the same set."""
+    from conftest import ROOT
+    mk = (ROOT / "projectultra_amd" / "csrc" / "Makefile").read_text()
+    flags = ("-ffp-contract=off", "-fno-fast-math", "-fno-slp-vectorize", "-fhip-fp32-correctly-rounded-divide-sqrt", "--offload-arch=$(ARCH)")
+    for f in flags:
+        assert f in mk, f
+    for tool in ("build_variants.sh", "kernel_isa.sh", "kernel_resources.sh", "mix_fft_stalls.py", "ldpc_stalls.py", "issue_model.py"):
+        text = (ROOT / "tools" / tool).read_text()
+        assert "-fno-slp-vectorize" in text and "-ffp-contract=off" in text.replace('", "', " ").replace('"', ""), tool
