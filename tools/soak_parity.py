@@ -20,6 +20,7 @@ modes = [(1024, "QAM16", "R3_4", {}), (1024, "QAM16", "R1_2", {}), (1024, "QAM32
          (512, "DQPSK", "R1_4", dict(use_pilots=1)), (1024, "QPSK", "R1_2", dict(pilot_spacing=3))]
 total = bad = 0
 t0 = time.time()
+t_last = t0
 for (fft, mod, rate, kw), (chan, snr) in itertools.product(modes, (("watterson", 30.0), ("watterson", 14.0), ("awgn", 22.0), ("awgn", 6.0))):
     for entry in (0, 1):
         cfg = make_config(fft, mod, rate, entry=entry, **kw)
@@ -81,5 +82,8 @@ for (fft, mod, rate, kw), (chan, snr) in itertools.product(modes, (("watterson",
         if not ok:
             bad += 1
             print("MISMATCH", fft, mod, rate, kw, chan, snr, "entry", entry)
+        if time.time() - t_last > 60.0:                      # a line a minute: a silent run looks hung to the GPU box's watchdog
+            t_last = time.time()
+            print(f"... {total} frames, {bad} mismatching cases, {time.time() - t0:.0f} s", flush=True)
 print(f"soak: {total} frames in {len(modes) * 8} cases, {bad} mismatching cases, {time.time() - t0:.0f} s")
 sys.exit(1 if bad else 0)
