@@ -209,6 +209,13 @@ constexpr int kPwPilots = 32;                               // pilots per frame 
 constexpr int kTrkRecFloats = 96;                           // three cache lines: 8 scalars (below), then c32 Hp_derotated[<= 32]
 constexpr int kTrkRecHp = 8;                                // (<= 12 pilots touch one line, the headline's 15 two)
 enum { tk_noise = 0, tk_timing, tk_cfo, tk_snr, tk_phase, tk_count };
+// Up to 15 pilots (the 59-carrier presets) the record is ONE cache line: the two scalars the carrier half reads (noise
+// variance, timing) and the pilots' estimates, 2 + 2 x 15 = 32 floats — the other scalars only ever fed state_out, which
+// track_all_kernel now takes from the tracker record.  One line less written per (symbol, frame) by the pilot half and one
+// less read by the carrier half: 1.1 GB of the headline step's 36.
+constexpr int kTrkRecFloatsCompact = 32, kTrkRecHpCompact = 2, kTrkRecCompactPilots = 15;
+__host__ __device__ inline int trk_rec_floats(int n_pilot) { return n_pilot <= kTrkRecCompactPilots ? kTrkRecFloatsCompact : kTrkRecFloats; }
+__host__ __device__ inline int trk_rec_hp(int n_pilot) { return n_pilot <= kTrkRecCompactPilots ? kTrkRecHpCompact : kTrkRecHp; }
 // Fq row of a frame (and symbol): c32[2 * D.fq_half] = bins [0, fq_half) then [N - fq_half, N), fq_half = 32 or 64
 __device__ __forceinline__ int fq_natural(const DemodConst& D, int bin) { return (bin < D.fq_half) ? bin : D.fq_half + (bin - (D.fft - D.fq_half)); }
 __device__ __forceinline__ int fq_index(const DemodConst& D, int bin) { return D.fq_pos[fq_natural(D, bin)]; }      // pilots first: DemodConst::fq_pos
@@ -1009,15 +1016,15 @@ __global__ __launch_bounds__(kWave, 5) void track_pilot_kernel(const DemodConst*
             mine = (subw == st_cfo_phase) ? tr.cfo_phase : mine;    // cfo_walk_kernel's, but for the record's first write
             if (sub <= st_since && (fresh || sub != st_cfo_phase)) st[sub] = mine;
             if (trk_rec) {
-                float* rec = trk_rec + (size_t)frame * kTrkRecFloats;
-                if (is_pilot) reinterpret_cast<c32*>(rec + kTrkRecHp)[sub] = h_derot;
+                float* rec = trk_rec + (size_t)frame * trk_rec_floats(np);
+                if (is_pilot) reinterpret_cast<c32*>(rec + trk_rec_hp(np))[sub] = h_derot;
                 float v = tr.noise_variance;                    // lane sub stores scalar sub of the record's tail
                 v = (subw == tk_timing - tk_noise) ? tr.timing : v;
                 v = (subw == tk_cfo - tk_noise) ? tr.freq_offset_hz : v;
                 v = (subw == tk_snr - tk_noise) ? tr.snr_linear : v;
                 v = (subw == tk_phase - tk_noise) ? tr.cfo_phase : v;
                 v = (subw == tk_count - tk_noise) ? (float)tr.snr_symbol_count : v;
-                if (sub < 8) rec[tk_noise + sub] = (sub <= tk_count - tk_noise) ? v : 0.0f;
+                if (sub < ((np <= kTrkRecCompactPilots) ? 2 : 8)) rec[tk_noise + sub] = (sub <= tk_count - tk_noise) ? v : 0.0f;
             }
         }
     }
@@ -1820,26 +1827,28 @@ __global__ __launch_bounds__(kWave, 6) void track_diff_pair_kernel(
 template <int MOD>
 __global__ __launch_bounds__(kWave, 6) void track_all_kernel(const DemodConst* __restrict__ Dp, int n_frames, int sym0, int n_sym_batch,
                                                              const float* __restrict__ trk_rec, const c32* __restrict__ fq_all,
-                                                             float* __restrict__ llr, size_t llr_stride, float* __restrict__ state_out) {
+                                                             float* __restrict__ llr, size_t llr_stride, float* __restrict__ state_out,
+                                                             const float* __restrict__ state) {
     __shared__ TrackShared sh;
     const DemodConst& D = *Dp;
     const int lane = threadIdx.x;
     const LaneConst lc = lane_constants(D);
     const int total = n_frames * n_sym_batch;
+    const int rec_floats = trk_rec_floats(D.n_pilot), rec_hp = trk_rec_hp(D.n_pilot);
+    const int rec_mask = (D.n_pilot <= kTrkRecCompactPilots) ? 1 : 7;
     // What an item reads — the record's scalars, the pilots' estimates, this lane's bin — is requested one item ahead, as
     // per-lane words (a uniform load would be waited for on the spot): the item then starts on data that has arrived.
     float nx_rec = 0.0f;
     c32 nx_hp = mk(0.0f, 0.0f), nx_fq = mk(0.0f, 0.0f);
     auto request = [&](int w) {
-        const float* rec = trk_rec + (size_t)w * kTrkRecFloats;
-        nx_rec = rec[lane & 7];
-        if (lane < D.n_pilot) nx_hp = reinterpret_cast<const c32*>(rec + kTrkRecHp)[lane];
+        const float* rec = trk_rec + (size_t)w * rec_floats;
+        nx_rec = rec[lane & rec_mask];
+        if (lane < D.n_pilot) nx_hp = reinterpret_cast<const c32*>(rec + rec_hp)[lane];
         if (lane < D.n_data) nx_fq = fq_all[(size_t)w * (2 * D.fq_half) + lc.data_fq];
     };
     if ((int)blockIdx.x < total) request((int)blockIdx.x);
     for (int w = blockIdx.x; w < total; w += gridDim.x) {
         const int frame = w % n_frames, ds = w / n_frames;
-        const float* rec = trk_rec + (size_t)w * kTrkRecFloats;
         Track tr;
         const float my_rec = nx_rec;
         const c32 my_hp = nx_hp, my_fq = nx_fq;
@@ -1854,15 +1863,17 @@ __global__ __launch_bounds__(kWave, 6) void track_all_kernel(const DemodConst* _
         finish_channel_estimate(sh, D, lc, tr);
         equalize_demap<MOD>(sh, D, lc, tr, dprev, fq_all + (size_t)w * (2 * D.fq_half),
                             llr + (size_t)frame * llr_stride + (size_t)(sym0 + ds) * D.llrs_per_symbol, nullptr, nullptr, &my_fq);
-        if (state_out && lane == 0 && ds == n_sym_batch - 1) {   // the tracker after the last symbol of the launch
+        if (state_out && lane == 0 && ds == n_sym_batch - 1) {   // the tracker after the last symbol of the launch:
+            // the frame's tracker record as the last pilot launch left it (every pilot launch of the call ran before this one)
+            const float* st = state + (size_t)frame * kStFloats;
             float* so = state_out + (size_t)frame * ULTRA_HIP_STATE_FLOATS;
-            so[ULTRA_HIP_STATE_FREQ_OFFSET_HZ] = rec[tk_cfo];
-            so[ULTRA_HIP_STATE_NOISE_VARIANCE] = rec[tk_noise];
-            so[ULTRA_HIP_STATE_SNR_LINEAR] = rec[tk_snr];
-            so[ULTRA_HIP_STATE_TIMING_OFFSET] = rec[tk_timing];
-            so[ULTRA_HIP_STATE_CFO_PHASE] = rec[tk_phase];
+            so[ULTRA_HIP_STATE_FREQ_OFFSET_HZ] = st[st_cfo];
+            so[ULTRA_HIP_STATE_NOISE_VARIANCE] = st[st_noise];
+            so[ULTRA_HIP_STATE_SNR_LINEAR] = st[st_snr];
+            so[ULTRA_HIP_STATE_TIMING_OFFSET] = st[st_timing];
+            so[ULTRA_HIP_STATE_CFO_PHASE] = st[st_cfo_phase];
             so[ULTRA_HIP_STATE_MIXER_PHASE] = D.mixer_phase_end;
-            so[ULTRA_HIP_STATE_SYMBOLS] = rec[tk_count];
+            so[ULTRA_HIP_STATE_SYMBOLS] = st[st_count];
             so[ULTRA_HIP_STATE_RESERVED] = 0.0f;
         }
         wave_sync();

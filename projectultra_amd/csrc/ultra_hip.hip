@@ -275,7 +275,7 @@ int launch_demod(ultra_hip_ctx* ctx, const float* d_audio, size_t frame_stride, 
     int mixed_upto = 0;                                  // symbols below this index are transformed already
     for (int s = s_begin; s < s_end; ++s) {
         c32* fq_s = ctx->d_ws_fq + ((all_symbols_at_once || deferred) ? (size_t)(s - s_begin) * n_frames * (size_t)(2 * D.fq_half) : (size_t)0);
-        float* rec_s = deferred ? ctx->d_ws_trk + (size_t)(s - s_begin) * n_frames * dev::kTrkRecFloats : nullptr;
+        float* rec_s = deferred ? ctx->d_ws_trk + (size_t)(s - s_begin) * n_frames * dev::trk_rec_floats(D.n_pilot) : nullptr;
         // The first TWO symbols of a SYNCED batch without initial offsets are at CFO 0 in every frame: the tracker estimates
         // a CFO from the phase differences of the pilots between two symbols (channel_equalizer.cpp:421-470: only with
         // prev_pilot_phases from an earlier symbol), so the first estimate exists after the second symbol.  No table to
@@ -336,7 +336,7 @@ int launch_demod(ultra_hip_ctx* ctx, const float* d_audio, size_t frame_stride, 
             const unsigned g = (unsigned)std::min(n_frames * (size_t)n_sym, (size_t)ctx->cu_count * 128);
 #define UH_TRACK_ALL(MOD)                                                                                                  \
     hipLaunchKernelGGL(dev::track_all_kernel<MOD>, dim3(g), dim3(dev::kWave), 0, st, ctx->d_demod, (int)n_frames, s_begin, n_sym, \
-                       ctx->d_ws_trk, ctx->d_ws_fq, d_llr, llr_stride, d_state)
+                       ctx->d_ws_trk, ctx->d_ws_fq, d_llr, llr_stride, d_state, ctx->d_ws_state)
             switch (D.modulation) {
                 case ULTRA_MOD_BPSK: UH_TRACK_ALL(ULTRA_MOD_BPSK); break;
                 case ULTRA_MOD_QPSK: UH_TRACK_ALL(ULTRA_MOD_QPSK); break;
