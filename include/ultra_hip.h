@@ -33,7 +33,7 @@
 extern "C" {
 #endif
 
-#define ULTRA_HIP_ABI_VERSION 7
+#define ULTRA_HIP_ABI_VERSION 8
 
 /* ultra::Modulation (include/ultra/types.hpp:27-39) — same numeric values. */
 enum ultra_hip_modulation {
@@ -100,6 +100,9 @@ typedef struct ultra_hip_config {
     uint32_t decision_directed;   /* 0/1: update the weights from the hard decision of every equalised carrier        */
     float lms_mu;                 /* ModemConfig::lms_mu (0.05)                                                       */
     float rls_lambda;             /* ModemConfig::rls_lambda (0.99)                                                   */
+    /* ABI 8.  ModemConfig::sync_threshold (include/ultra/types.hpp:188): the Schmidl-Cox metric a search offset must exceed
+     * (Impl::sync_threshold, src/ofdm/demodulator.cpp:30,503,614).  0 (a zero-initialised struct) = the default 0.80. */
+    float sync_threshold;
 } ultra_hip_config;
 
 /* Geometry derived from a config (ModemConfig::getCyclicPrefix /
@@ -254,11 +257,36 @@ int ultra_hip_ldpc_decode_blocks(ultra_hip_ctx* ctx, const float* d_llr, size_t 
 int ultra_hip_demod_stream_batch(ultra_hip_ctx* ctx, const float* d_audio, size_t frame_stride, const float* d_cfo_hz,
                                  const float* d_cfo_phase, size_t n_frames, uint32_t first_symbol, uint32_t n_symbols,
                                  float* d_llr, float* d_state);
+/* How the NEXT first_symbol == 0 call of ultra_hip_demod_stream_batch on this context starts its frames (consumed by that
+ * call; ultra_hip_demod_batch and friends always start fresh).  One ultra::OFDMDemodulator object lives through many
+ * frames, and not every way into a new frame resets the tracker:
+ *   ULTRA_STREAM_START_FRESH   the constructor's state / after OFDMDemodulator::reset() — the default.
+ *   ULTRA_STREAM_START_SYNC    SEARCHING -> SYNCED on a demodulator that demodulated frames before and was not reset in
+ *                              between (src/ofdm/demodulator.cpp:533-591; the legacy Modem never calls reset():
+ *                              src/modem/modem.cpp:153-166).  The transition sets freq_offset_hz = freq_offset_filtered =
+ *                              the coarse CFO (d_cfo_hz of the stream call), the correction phase, symbols_since_sync and
+ *                              timing_offset_samples to 0, restarts the mixer, clears dbpsk_prev_equalized and (unless
+ *                              the layout is differential without pilots) the carrier phase correction.  EVERYTHING
+ *                              ELSE is carried from the records the previous frame left in this context: channel_estimate,
+ *                              noise_variance, estimated_snr_linear, snr_symbol_count, prev_pilot_phases,
+ *                              pilot_phase_correction, the adaptive equaliser's weights.  ULTRA_ENTRY_SYNCED only; the
+ *                              context must hold records of at least n_frames frames.
+ *   ULTRA_STREAM_START_TIMING  a fresh tracker whose Impl::timing_offset_samples starts at d_timing[frame] — the one value
+ *                              that neither reset() (:987-1017), nor the reset block of processPresynced (:868-905), nor the
+ *                              mid-frame preamble (:626-655) clears.  d_timing [n_frames] f32 must stay valid until the
+ *                              stream call has been issued.
+ * d_timing is ignored (may be NULL) for the other two modes. */
+enum ultra_hip_stream_start { ULTRA_STREAM_START_FRESH = 0, ULTRA_STREAM_START_SYNC = 1, ULTRA_STREAM_START_TIMING = 2 };
+int ultra_hip_demod_stream_start(ultra_hip_ctx* ctx, int mode, const float* d_timing);
+
 /* OFDMDemodulator::setFrequencyOffset (demodulator.cpp:805-815) between two ultra_hip_demod_stream_batch calls:
  * freq_offset_hz = freq_offset_filtered = cfo_hz, correction phase 0, for frame `frame` of the stream in flight, applied
  * from the next symbol on — also when the frame started without offsets (d_cfo_hz == NULL at first_symbol 0): the batch
  * then leaves the zero-offset fast paths for the rest of the frame (tests/golden/setcfo.npz). */
 int ultra_hip_demod_stream_set_cfo(ultra_hip_ctx* ctx, size_t frame, float cfo_hz);
+/* ... and OFDMDemodulator::setFrequencyOffsetWithPhase (demodulator.cpp:816-825): the same with freq_correction_phase =
+ * cfo_phase instead of 0 (ABI 8). */
+int ultra_hip_demod_stream_set_cfo_phase(ultra_hip_ctx* ctx, size_t frame, float cfo_hz, float cfo_phase);
 
 #define ULTRA_HIP_STATE_FLOATS 8
 #define ULTRA_HIP_STATE_FREQ_OFFSET_HZ 0   /* OFDMDemodulator::getFrequencyOffset     */
@@ -518,6 +546,11 @@ int ultra_hip_set_deinterleave(ultra_hip_ctx* ctx, uint32_t bits_per_symbol);
  * (i % cols) * rows + i / cols — e.g. Interleaver(6, 108) of tools/test_throughput.cpp:78-134 and any other 648-entry
  * layout).  Takes precedence over ultra_hip_set_deinterleave; h_index = NULL or n = 0 switches the table off. */
 int ultra_hip_set_deinterleave_table(ultra_hip_ctx* ctx, const uint16_t* h_index, uint32_t n);
+/* The step of ChannelInterleaver(bits_per_symbol, total) (findCoprimeStep, src/fec/ldpc_decoder.cpp:547-573): permutation[i]
+ * = (i * step) % total.  Host arithmetic, no context: what ultra_hip_set_deinterleave fuses into the decoder, handed out
+ * for callers that need the permutation itself (the transmit side's interleave; projectultra_amd/host/hip_ldpc_decoder.cpp).
+ * ABI 8. */
+int ultra_hip_channel_interleaver_step(uint32_t bits_per_symbol, uint32_t total, uint32_t* step);
 
 /* Per-kernel timing (diagnostics; bench.py's roofline object uses it): while enabled, every kernel
  * launch of this context is bracketed by a pair of HIP events on the context's stream.  read()

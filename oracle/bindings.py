@@ -27,7 +27,7 @@ class Config(C.Structure):
         "sample_rate", "center_freq", "fft_size", "num_carriers", "cp_mode", "symbol_guard",
         "pilot_spacing", "use_pilots", "modulation", "code_rate", "max_iterations",
         "n_data_symbols", "entry", "training_symbols",
-        "adaptive_eq_enabled", "adaptive_eq_use_rls", "decision_directed")] + [("lms_mu", C.c_float), ("rls_lambda", C.c_float)]
+        "adaptive_eq_enabled", "adaptive_eq_use_rls", "decision_directed")] + [("lms_mu", C.c_float), ("rls_lambda", C.c_float), ("sync_threshold", C.c_float)]
 
     def copy(self, **kw):
         c = Config()

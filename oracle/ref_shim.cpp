@@ -64,6 +64,7 @@ ModemConfig to_cfg(const ultra_hip_config* c) {
     m.adaptive_eq_enabled = c->adaptive_eq_enabled != 0;
     m.adaptive_eq_use_rls = c->adaptive_eq_use_rls != 0;
     if (c->adaptive_eq_enabled) { m.decision_directed = c->decision_directed != 0; m.lms_mu = c->lms_mu; m.rls_lambda = c->rls_lambda; }
+    if (c->sync_threshold != 0.0f) m.sync_threshold = c->sync_threshold;
     return m;
 }
 

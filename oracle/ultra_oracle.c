@@ -1525,7 +1525,7 @@ typedef struct acq {
 /* LTS passband templates of the constructor, src/ofdm/demodulator.cpp:100-133 */
 static int acq_init(acq* a, const ultra_hip_config* c) {
     if (demod_init(&a->d, c) != 0) return -1;
-    a->sync_threshold = 0.80f;
+    a->sync_threshold = (c->sync_threshold != 0.0f) ? c->sync_threshold : 0.80f;
     a->noise_floor_energy = 0.0f;
     const uint32_t N = c->fft_size, cp = a->d.cp;
     if (cp + N > ACQ_LTS_MAX) return -1;

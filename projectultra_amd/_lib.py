@@ -17,7 +17,7 @@ PKG_DIR = Path(__file__).resolve().parent
 LIB_PATH = Path(os.environ["ULTRA_HIP_LIB"]).resolve() if os.environ.get("ULTRA_HIP_LIB") else PKG_DIR / "libultra_hip.so"
 CSRC_DIR = PKG_DIR / "csrc"
 
-ULTRA_HIP_ABI_VERSION = 7
+ULTRA_HIP_ABI_VERSION = 8
 STATE_FLOATS = 8
 
 
@@ -33,7 +33,7 @@ class ultra_hip_config(C.Structure):
         "sample_rate", "center_freq", "fft_size", "num_carriers", "cp_mode", "symbol_guard",
         "pilot_spacing", "use_pilots", "modulation", "code_rate", "max_iterations",
         "n_data_symbols", "entry", "training_symbols",
-        "adaptive_eq_enabled", "adaptive_eq_use_rls", "decision_directed")] + [("lms_mu", C.c_float), ("rls_lambda", C.c_float)]
+        "adaptive_eq_enabled", "adaptive_eq_use_rls", "decision_directed")] + [("lms_mu", C.c_float), ("rls_lambda", C.c_float), ("sync_threshold", C.c_float)]
 
 
 class ultra_hip_geometry(C.Structure):
@@ -70,6 +70,8 @@ PROTOTYPES = {
     "ultra_hip_ldpc_decode_blocks": (_i, [_vp, _vp, _sz, _sz, _sz, _sz, _vp, _vp, _vp]),
     "ultra_hip_demod_stream_batch": (_i, [_vp, _vp, _sz, _vp, _vp, _sz, C.c_uint32, C.c_uint32, _vp, _vp]),
     "ultra_hip_demod_stream_set_cfo": (_i, [_vp, _sz, C.c_float]),
+    "ultra_hip_demod_stream_start": (_i, [_vp, _i, _vp]),
+    "ultra_hip_demod_stream_set_cfo_phase": (_i, [_vp, _sz, C.c_float, C.c_float]),
     "ultra_hip_acquire_stream_batch": (_i, [_vp, _vp, _sz, C.c_uint32, C.c_uint32, _sz, _vp, _vp, _vp, _vp, _vp]),
     "ultra_hip_resync_stream_batch": (_i, [_vp, _vp, _sz, C.c_uint32, C.c_uint32, _sz, _vp, _vp, _vp, _vp, _vp]),
     "ultra_hip_demod_decode_batch": (_i, [_vp, _vp, _sz, _vp, _vp, _sz, _vp, _vp, _vp, _vp]),
@@ -93,6 +95,7 @@ PROTOTYPES = {
     "ultra_hip_make_llr_batch": (_i, [_vp, C.c_uint64, C.c_uint64, _sz, C.c_float, _vp, _vp]),
     "ultra_hip_set_deinterleave": (_i, [_vp, C.c_uint32]),
     "ultra_hip_set_deinterleave_table": (_i, [_vp, _vp, C.c_uint32]),
+    "ultra_hip_channel_interleaver_step": (_i, [C.c_uint32, C.c_uint32, _u32p]),
     "ultra_hip_profile_enable": (_i, [_vp, _i]),
     "ultra_hip_profile_read": (_i, [_vp, C.POINTER(C.c_float), C.POINTER(C.c_uint32)]),
     "ultra_hip_malloc": (_i, [_vp, _sz, C.POINTER(_vp)]),

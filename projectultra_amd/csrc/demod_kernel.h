@@ -1340,9 +1340,13 @@ __device__ __forceinline__ void lts_finish(TrackShared& sh, const DemodConst& D,
 
 // Fresh demodulator per frame (demodulator.cpp:26-43 + SYNCED transition :533-591, or the reset
 // block of processPresynced :868-905).
+// `timing` (nullable): Impl::timing_offset_samples the frame starts with — the one tracker value neither
+// OFDMDemodulator::reset (:987-1017), nor the reset block of processPresynced, nor the mid-frame preamble (:626-655) clears
+// (ultra_hip_demod_stream_start, ULTRA_STREAM_START_TIMING).
 __global__ __launch_bounds__(kWave) void init_state_kernel(const float* __restrict__ cfo_hz,
                                                            const float* __restrict__ cfo_phase, int n_frames,
-                                                           float* __restrict__ state, int compact, int adaptive) {
+                                                           float* __restrict__ state, int compact, int adaptive,
+                                                           const float* __restrict__ timing = nullptr) {
     const int lane = threadIdx.x;
     for (int frame = blockIdx.x; frame < n_frames; frame += gridDim.x) {
         float* st = state + (size_t)frame * kStFloats;
@@ -1361,7 +1365,38 @@ __global__ __launch_bounds__(kWave) void init_state_kernel(const float* __restri
             else if (lane == st_cfo_phase) v = cfo_phase ? cfo_phase[frame] : 0.0f;
             else if (lane == st_noise) v = 0.1f;
             else if (lane == st_snr) v = 1.0f;
+            else if (lane == st_timing) v = timing ? timing[frame] : 0.0f;
             else if (lane == st_ppc_re || lane == st_cpc_re) v = 1.0f;
+            st[lane] = v;
+        }
+    }
+}
+
+// SEARCHING -> SYNCED on a demodulator that has demodulated frames before and was not reset() in between
+// (demodulator.cpp:533-591; the legacy Modem never resets: src/modem/modem.cpp:153-166): the transition sets the
+// frequency offset (and its filter) to the coarse estimate, the correction phase, symbols_since_sync and
+// timing_offset_samples to 0, restarts the oscillator (the symbol index does that here), forgets the differential
+// reference and — unless the layout is differential without pilots — the carrier phase correction.  Everything else the
+// tracker holds is carried into the new frame: channel_estimate, noise_variance, estimated_snr_linear, snr_symbol_count,
+// prev_pilot_phases, pilot_phase_correction, the adaptive equaliser's weights.
+// (cfo_phase: OFDMDemodulator::setFrequencyOffsetWithPhase between the transition and the first symbol; NULL = 0)
+__global__ __launch_bounds__(kWave) void resync_state_kernel(const float* __restrict__ cfo_hz, const float* __restrict__ cfo_phase,
+                                                             int n_frames, float* __restrict__ state, int reset_carrier_phase) {
+    const int lane = threadIdx.x;
+    for (int frame = blockIdx.x; frame < n_frames; frame += gridDim.x) {
+        float* st = state + (size_t)frame * kStFloats;
+        if (lane < 16) {
+            float v = st[lane];
+            const float cfo = cfo_hz ? cfo_hz[frame] : 0.0f;
+            if (lane == st_cfo || lane == st_cfo_filt) v = cfo;
+            else if (lane == st_cfo_phase) v = cfo_phase ? cfo_phase[frame] : 0.0f;
+            else if (lane == st_timing || lane == st_since) v = 0.0f;
+            else if (lane == st_flags) {
+                int flags = (int)v & ~4;                        // dbpsk_prev_equalized.clear()
+                if (reset_carrier_phase) flags &= ~1;           // carrier_phase_initialized = false
+                v = (float)flags;
+            } else if (reset_carrier_phase && lane == st_cpc_re) v = 1.0f;
+            else if (reset_carrier_phase && lane == st_cpc_im) v = 0.0f;
             st[lane] = v;
         }
     }

@@ -103,6 +103,7 @@ inline int validate_config(const ultra_hip_config& c) {
     if (c.entry == ULTRA_ENTRY_PRESYNCED && c.training_symbols > 8) return ULTRA_HIP_ERR_INVALID_ARG;
     if (c.max_iterations > 1000) return ULTRA_HIP_ERR_INVALID_ARG;
     if (c.adaptive_eq_enabled > 1 || c.adaptive_eq_use_rls > 1 || c.decision_directed > 1) return ULTRA_HIP_ERR_INVALID_ARG;
+    if (!(c.sync_threshold >= 0.0f)) return ULTRA_HIP_ERR_INVALID_ARG;   // 0 = the default 0.80; NaN and negatives are the caller's error
     return ULTRA_HIP_OK;
 }
 

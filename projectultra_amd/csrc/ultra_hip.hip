@@ -79,6 +79,8 @@ struct ultra_hip_ctx {
     uint16_t* d_deint_table = nullptr;   // general gather table of the fused deinterleave (nullptr = use the step)
     int mix_wg_per_cu = 0;               // variant builds only (-DUH_AB_SWITCHES, ULTRA_HIP_MIX_WG_PER_CU): workgroups per CU of the transform's grid
     bool stream_cfo_given = false;       // launch_demod: whether the frame in flight started with caller-supplied offsets
+    int stream_start_mode = 0;           // ultra_hip_demod_stream_start: how the next first_symbol == 0 stream call starts (consumed by it)
+    const float* stream_start_timing = nullptr;
     // ULTRA_HIP_FALLBACK_CHAIN=1: the fall-back kernels for every layout — track_pilot_kernel + track_kernel per symbol instead
     // of the deferred carrier half and the pair tracker (what launch_demod drops to when the n_sym-fold workspace cannot be
     // had), and with ULTRA_HIP_LDPC_MESSAGES=1 the message-passing decoder for every rate (what the totals decoder drops to
@@ -190,7 +192,13 @@ int launch_demod(ultra_hip_ctx* ctx, const float* d_audio, size_t frame_stride, 
     const int s_begin = sym_begin, s_end = (sym_count < 0) ? D.n_train + D.n_data_sym : sym_begin + sym_count;
     if (s_begin < 0 || s_end > D.n_train + D.n_data_sym || s_end <= s_begin) return ULTRA_HIP_ERR_INVALID_ARG;
     if (s_begin > 0 && ctx->ws_demod_frames < n_frames) return ULTRA_HIP_ERR_INVALID_ARG;      // nothing to continue from
-    const bool cfo_given = (s_begin == 0) ? d_cfo_hz != nullptr : ctx->stream_cfo_given;
+    // ultra_hip_demod_stream_start: a frame that starts on a USED demodulator (carried tracker) or with a timing offset may
+    // hold a frequency offset or a previous symbol's pilots from its first symbol on — none of the fresh-start short cuts
+    const int start_mode = (s_begin == 0 && sym_count >= 0) ? ctx->stream_start_mode : ULTRA_STREAM_START_FRESH;
+    const float* start_timing = (start_mode == ULTRA_STREAM_START_TIMING) ? ctx->stream_start_timing : nullptr;
+    if (s_begin == 0 && sym_count >= 0) { ctx->stream_start_mode = ULTRA_STREAM_START_FRESH; ctx->stream_start_timing = nullptr; }
+    if (start_mode == ULTRA_STREAM_START_SYNC && (ctx->ws_demod_frames < n_frames || D.presynced)) return ULTRA_HIP_ERR_INVALID_ARG;   // nothing to carry
+    const bool cfo_given = (s_begin == 0) ? (d_cfo_hz != nullptr || start_mode != ULTRA_STREAM_START_FRESH) : ctx->stream_cfo_given;
     if (s_begin == 0) ctx->stream_cfo_given = cfo_given;
     { const int rc_ws = ensure_demod_workspace(ctx, n_frames); if (rc_ws != ULTRA_HIP_OK) return rc_ws; }
     // one wavefront per frame in every kernel; grids are capped (grid-stride over frames) so a huge
@@ -238,12 +246,17 @@ int launch_demod(ultra_hip_ctx* ctx, const float* d_audio, size_t frame_stride, 
     // constructor's values itself (track_pilot_kernel, `fresh`) and writes the whole record — no initialisation launch, and
     // no record read in that launch.  (With offsets given the walk of symbol 0 reads them from the record first.)
     const bool fresh_pilot = deferred && s_begin == 0 && !cfo_given;
-    if (s_begin == 0 && !fresh_pilot) {
+    if (s_begin == 0 && start_mode == ULTRA_STREAM_START_SYNC) {
+        LaunchSpan span(ctx, ULTRA_HIP_K_INIT_STATE);
+        // if (!is_differential || config.use_pilots) the carrier phase correction starts over (demodulator.cpp:583-586)
+        hipLaunchKernelGGL(dev::resync_state_kernel, dim3(grid_trk), dim3(dev::kWave), 0, st, d_cfo_hz, d_cfo_phase, (int)n_frames, ctx->d_ws_state,
+                           (!D.differential || D.n_pilot > 0) ? 1 : 0);
+    } else if (s_begin == 0 && !fresh_pilot) {
         LaunchSpan span(ctx, ULTRA_HIP_K_INIT_STATE);
         // compact pilot state (demod_kernel.h, kStHp) and no training symbols that read the full H array first
         const int compact = (!D.differential && D.n_pilot > 0 && D.n_train == 0) ? 1 : 0;
         hipLaunchKernelGGL(dev::init_state_kernel, dim3(grid_trk), dim3(dev::kWave), 0, st, d_cfo_hz, d_cfo_phase,
-                           (int)n_frames, ctx->d_ws_state, compact, (D.adaptive_eq != 0 && !D.differential) ? 1 : 0);
+                           (int)n_frames, ctx->d_ws_state, compact, (D.adaptive_eq != 0 && !D.differential) ? 1 : 0, start_timing);
     }
     if (s_begin == 0 && D.presynced && d_cfo_hz) {
         // frames whose initial CFO is NaN ("never set"): estimateCFOFromTraining, demodulator.cpp:920-925
@@ -824,11 +837,24 @@ int ultra_hip_demod_stream_batch(ultra_hip_ctx* ctx, const float* d_audio, size_
                         (size_t)data_in_call * (size_t)D.llrs_per_symbol, d_state, nullptr, (int)first_symbol, (int)n_symbols);
 }
 
+int ultra_hip_demod_stream_start(ultra_hip_ctx* ctx, int mode, const float* d_timing) {
+    if (!ctx || mode < ULTRA_STREAM_START_FRESH || mode > ULTRA_STREAM_START_TIMING) return ULTRA_HIP_ERR_INVALID_ARG;
+    if (mode == ULTRA_STREAM_START_TIMING && !d_timing) return ULTRA_HIP_ERR_INVALID_ARG;
+    if (mode == ULTRA_STREAM_START_SYNC && ctx->h_demod.presynced) return ULTRA_HIP_ERR_INVALID_ARG;   // processPresynced resets the tracker (:868-905)
+    ctx->stream_start_mode = mode;
+    ctx->stream_start_timing = (mode == ULTRA_STREAM_START_TIMING) ? d_timing : nullptr;
+    return ULTRA_HIP_OK;
+}
+
 int ultra_hip_demod_stream_set_cfo(ultra_hip_ctx* ctx, size_t frame, float cfo_hz) {
+    return ultra_hip_demod_stream_set_cfo_phase(ctx, frame, cfo_hz, 0.0f);
+}
+
+int ultra_hip_demod_stream_set_cfo_phase(ultra_hip_ctx* ctx, size_t frame, float cfo_hz, float cfo_phase) {
     if (!ctx || frame >= ctx->ws_demod_frames) return ULTRA_HIP_ERR_INVALID_ARG;
     DeviceGuard guard(ctx->device);
-    // OFDMDemodulator::setFrequencyOffset (demodulator.cpp:805-815): freq_offset_hz = filtered = cfo, correction phase 0
-    const float v[3] = {cfo_hz, cfo_hz, 0.0f};
+    // OFDMDemodulator::setFrequencyOffset[WithPhase] (demodulator.cpp:805-825): freq_offset_hz = filtered = cfo, correction phase 0 or given
+    const float v[3] = {cfo_hz, cfo_hz, cfo_phase};
     static_assert(dev::st_cfo == 0 && dev::st_cfo_filt == 1 && dev::st_cfo_phase == 2, "record layout");
     UH_HIP(hipMemcpyAsync(ctx->d_ws_state + frame * (size_t)dev::kStFloats, v, sizeof(v), hipMemcpyHostToDevice, ctx->stream));
     UH_HIP(hipStreamSynchronize(ctx->stream));
@@ -870,7 +896,7 @@ int launch_acquire(ultra_hip_ctx* ctx, const float* d_audio, size_t stream_strid
     LaunchSpan span(ctx, ULTRA_HIP_K_ACQUIRE);
     const float* lts_I = ctx->d_lts;
     const float* lts_Q = ctx->d_lts + ctx->lts_len;
-    const float sync_threshold = 0.80f;          // ModemConfig::sync_threshold default (types.hpp:188)
+    const float sync_threshold = ctx->cfg.sync_threshold != 0.0f ? ctx->cfg.sync_threshold : 0.80f;   // ModemConfig::sync_threshold (types.hpp:188)
     auto launch = [&](auto kernel) {
         hipLaunchKernelGGL(kernel, dim3(grid), dim3(dev::kWave), 0, ctx->stream, ctx->d_demod, ctx->d_twiddle, lts_I, lts_Q,
                            ctx->lts_energy_ref, sync_threshold, d_audio, stream_stride, n_samples, chunk, (int)n_streams, d_found,
@@ -1260,6 +1286,12 @@ int ultra_hip_set_deinterleave(ultra_hip_ctx* ctx, uint32_t bits_per_symbol) {
     if (!ctx) return ULTRA_HIP_ERR_INVALID_ARG;
     if (bits_per_symbol >= (uint32_t)kLdpcN) return ULTRA_HIP_ERR_INVALID_ARG;
     ctx->deint_step = bits_per_symbol ? channel_interleaver_step(bits_per_symbol, (uint32_t)kLdpcN) : 1u;
+    return ULTRA_HIP_OK;
+}
+
+int ultra_hip_channel_interleaver_step(uint32_t bits_per_symbol, uint32_t total, uint32_t* step) {
+    if (!step || bits_per_symbol == 0 || total == 0) return ULTRA_HIP_ERR_INVALID_ARG;
+    *step = channel_interleaver_step(bits_per_symbol, total);
     return ULTRA_HIP_OK;
 }
 

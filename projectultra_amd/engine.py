@@ -34,6 +34,7 @@ def make_c_config(config: ModemConfig, *, entry: Entry = Entry.SYNCED, n_data_sy
     c.n_data_symbols = n_data_symbols
     c.adaptive_eq_enabled, c.adaptive_eq_use_rls = int(bool(config.adaptive_eq_enabled)), int(bool(config.adaptive_eq_use_rls))
     c.decision_directed, c.lms_mu, c.rls_lambda = int(bool(config.decision_directed)), config.lms_mu, config.rls_lambda
+    c.sync_threshold = getattr(config, "sync_threshold", 0.80)
     return c
 
 

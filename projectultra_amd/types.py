@@ -85,6 +85,7 @@ class ModemConfig:                  # include/ultra/types.hpp:139-234 (receive-p
     lms_mu: float = 0.05
     rls_lambda: float = 0.99
     decision_directed: bool = True
+    sync_threshold: float = 0.80        # Schmidl-Cox metric a search offset must exceed (types.hpp:188)
 
     def getCyclicPrefix(self) -> int:
         base = {CyclicPrefixMode.SHORT: 32, CyclicPrefixMode.MEDIUM: 48, CyclicPrefixMode.LONG: 64}[
