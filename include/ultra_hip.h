@@ -251,7 +251,12 @@ int ultra_hip_ldpc_decode_blocks(ultra_hip_ctx* ctx, const float* d_llr, size_t 
  *   d_audio   [n_frames] rows of frame_stride floats, row f starting at symbol first_symbol of frame f
  *   d_llr     [n_frames][n_data * llrs_per_symbol] f32, n_data = the data symbols among those of this call
  *   d_state   [n_frames][ULTRA_HIP_STATE_FLOATS] or NULL: the tracker after the last symbol of this call
- * ULTRA_ENTRY_PRESYNCED: the first call takes all training symbols (n_symbols >= training_symbols), later calls start behind them.
+ * ULTRA_ENTRY_PRESYNCED: the first call (first_symbol 0) is processPresynced — it takes all training symbols (n_symbols >=
+ * training_symbols) and whatever data symbols the caller hands processPresynced; later calls start behind them and are the
+ * rest of the frame arriving through process(), as it does in the reference (the object is SYNCED after processPresynced):
+ * process()'s loop runs updateChannelEstimate for every layout (:676), processPresynced's own loop only with pilots
+ * (:954-960) — without pilots the two differ (pilot_phase_correction is reset per symbol, snr_symbol_count counts), and so do
+ * a frame handed over whole and a frame handed over in two pieces, exactly as in the reference.
  * The context must have been created with n_data_symbols >= the frame's length (<= 251: process() gives up after
  * MAX_SYMBOLS_BEFORE_TIMEOUT + 1 symbols) and must not run another batch in between. */
 int ultra_hip_demod_stream_batch(ultra_hip_ctx* ctx, const float* d_audio, size_t frame_stride, const float* d_cfo_hz,

@@ -1658,7 +1658,10 @@ template <int MOD>
 __global__ __launch_bounds__(kWave, 6) void track_kernel(
     const DemodConst* __restrict__ Dp, int n_frames, int data_sym, float* __restrict__ state,
     const c32* __restrict__ fq_all, float* __restrict__ llr, size_t llr_stride, float* __restrict__ state_out,
-    int n_sym_batch) {
+    int n_sym_batch, int synced_loop) {
+    // synced_loop: these symbols reach the demodulator through process()'s SYNCED loop (demodulator.cpp:672-697), which calls
+    // updateChannelEstimate for EVERY layout, although the context is of the presynced entry — the tail of a frame whose head
+    // went through processPresynced (whose own loop skips the update without pilots, :954-960).
     // n_sym_batch > 1 (zero-CFO layouts, whose bins of ALL symbols are already there: launch_demod): the wavefront walks
     // data symbols data_sym .. data_sym + n_sym_batch - 1 of its frame with the tracker state in registers and LDS —
     // one record read and one record write per frame instead of one of each per symbol, one launch instead of n_sym.
@@ -1674,7 +1677,8 @@ __global__ __launch_bounds__(kWave, 6) void track_kernel(
         // differences: pilot_phase_correction = 1, :421-470; prev_pilot_phases stays empty; ++snr_symbol_count, :595) —
         // taken here instead of in a track_pilot_kernel launch of their own (SYNCED entry; the presynced entry without
         // pilots never ran the estimate, demodulator.cpp:936-960).
-        const bool scalar_pilot_half = D.n_pilot == 0 && !D.presynced;
+        const bool presynced_loop = D.presynced && !synced_loop;
+        const bool scalar_pilot_half = D.n_pilot == 0 && !presynced_loop;
         const bool compact = compact_pilot_state(D);
         if (!compact) sh.H[lane] = reinterpret_cast<const c32*>(st + kStH)[lane];
         else if (lane < D.n_pilot) sh.H[lc.pilot_slot] = reinterpret_cast<const c32*>(st + kStHp)[lane];   // the rest is interpolated before it is read
@@ -1694,7 +1698,7 @@ __global__ __launch_bounds__(kWave, 6) void track_kernel(
         for (int ds = 0; ds < n_sym_batch; ++ds) {
             const c32* fq = fq_all + ((size_t)ds * n_frames + frame) * (2 * D.fq_half);
             if (scalar_pilot_half) { tr.ppc = mk(1.0f, 0.0f); tr.has_prev = 0; tr.snr_symbol_count++; }
-            if (!D.presynced || D.n_pilot != 0) {
+            if (!presynced_loop || D.n_pilot != 0) {
                 finish_channel_estimate(sh, D, lc, tr);
                 // updateChannelEstimate seeds the weights from its estimate while snr_symbol_count < 3 (:569-581) — the
                 // count BEFORE its increment at the end of the update, which the pilot half has already taken

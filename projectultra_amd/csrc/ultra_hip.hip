@@ -246,6 +246,9 @@ int launch_demod(ultra_hip_ctx* ctx, const float* d_audio, size_t frame_stride, 
     // constructor's values itself (track_pilot_kernel, `fresh`) and writes the whole record — no initialisation launch, and
     // no record read in that launch.  (With offsets given the walk of symbol 0 reads them from the record first.)
     const bool fresh_pilot = deferred && s_begin == 0 && !cfo_given;
+    // A presynced context's symbols behind its first call arrive through process() (ultra_hip.h, ultra_hip_demod_stream_batch):
+    // the SYNCED loop updates the channel estimate for every layout, processPresynced's own loop only with pilots
+    const int synced_loop = (D.presynced && s_begin > 0) ? 1 : 0;
     if (s_begin == 0 && start_mode == ULTRA_STREAM_START_SYNC) {
         LaunchSpan span(ctx, ULTRA_HIP_K_INIT_STATE);
         // if (!is_differential || config.use_pilots) the carrier phase correction starts over (demodulator.cpp:583-586)
@@ -368,7 +371,7 @@ int launch_demod(ultra_hip_ctx* ctx, const float* d_audio, size_t frame_stride, 
         const bool last_launch = last || all_symbols_at_once;
 #define UH_TRACK(MOD)                                                                                            \
     hipLaunchKernelGGL(dev::track_kernel<MOD>, dim3(grid_trk), dim3(dev::kWave), 0, st, ctx->d_demod, (int)n_frames,  \
-                       s - D.n_train, ctx->d_ws_state, fq_s, d_llr, llr_stride, last_launch ? d_state : nullptr, track_batch)
+                       s - D.n_train, ctx->d_ws_state, fq_s, d_llr, llr_stride, last_launch ? d_state : nullptr, track_batch, synced_loop)
         LaunchSpan span(ctx, ULTRA_HIP_K_TRACK);
         // differential layouts without pilots on at most 32 carriers (the 512-point presets): two frames per wavefront
         const bool pair_frames = !ctx->old_chain && D.differential && D.n_pilot == 0 && !D.presynced && D.n_carriers <= 32 &&

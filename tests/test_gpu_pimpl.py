@@ -12,6 +12,7 @@ classes over the C-ABI; oracle/Makefile compiles each of the reference's program
 Same arguments, same seeds: stdout must be IDENTICAL, byte for byte — success counts, the demodulator's SNR estimates as the
 programs print them, sync offsets, decoded bytes, and the programs' own PASS / FAIL verdicts (where the reference's test
 fails on the reference, it must fail the same way on the GPU)."""
+import re
 import subprocess
 from pathlib import Path
 
@@ -70,3 +71,94 @@ def test_the_hip_builds_do_not_link_the_reference_receive_path():
     deps = subprocess.run(["ldd", str(exe)], capture_output=True, text=True).stdout
     assert "libultra_hip.so" in deps and "libultra_ref_tx.so" in deps
     assert "libultra_ref.so" not in deps
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# tools/test_hf_modem.cpp: the reference's whole-boundary tool.  TX and RX waveforms come from WaveformFactory::create
+# (:408,565), frames are LDPC-encoded, interleaved, modulated through IWaveform (generatePreamble + modulate), laid into 30+ s of
+# audio, sent through CFO / Watterson / AWGN, and ONE gui::RxPipeline receives the stream in 960-sample chunks.  Three builds of
+# the unmodified source (oracle/Makefile): .ref (the reference), .pimpl (the reference's factory and waveform classes over the
+# two pimpl drop-ins — no source change at all), .hip (projectultra_amd/host/hip_waveform_factory.cpp: the HIP adapters, chirp
+# detection on the GPU too).  With -v the reference's RxPipeline logs every decision it takes on the waveform's answers
+# ("Sync detected at N, CFO=x Hz, corr=y", "process() returned false", trims, decode results: LOG_MODEM lines of the
+# unmodified rx_pipeline.cpp, present in all three builds): stdout AND that log must be identical.
+HF_CASES = [
+    ["-w", "ofdm", "--snr", "25", "--frames", "3"],
+    ["-w", "ofdm", "--snr", "30", "--frames", "3", "-m", "16qam", "-r", "3/4", "--cfo", "12"],
+    ["-w", "ofdm", "--snr", "20", "--frames", "2", "-c", "good", "--seed", "5"],
+    ["-w", "chirp", "--snr", "20", "--frames", "3"],
+    ["-w", "chirp", "--snr", "18", "--frames", "2", "--cfo", "20", "-c", "moderate", "--seed", "9", "-m", "d8psk", "-r", "2/3"],
+    ["-w", "chirp", "--snr", "15", "--frames", "2", "-r", "1/4", "--no-interleave"],
+    ["-w", "dpsk", "--snr", "10", "--frames", "2"],                 # MC-DPSK: the reference's waveform, RxPipeline's decoder on the GPU
+]
+_STAMP = re.compile(r"^\[\s*\d+\.\d+\]")
+
+
+def _pipeline_log(stderr):
+    return [_STAMP.sub("", l) for l in stderr.splitlines() if "RxPipeline" in l]
+
+
+def _stdout(out):
+    """The reference's header-only ChirpSync printf()s its intermediate peaks to stdout ("[CHIRP-RX] ...",
+    src/sync/chirp_sync.hpp); the .hip build detects the chirps on the GPU and has no such debug print.  What the detection
+    RETURNS is in the pipeline log ("Sync detected at N, CFO=x Hz, corr=y") and is compared there."""
+    return [l for l in out.splitlines() if not l.startswith("[CHIRP-RX]")]
+
+
+@pytest.mark.parametrize("args", HF_CASES, ids=["_".join(a).replace("/", "") for a in HF_CASES])
+def test_hf_modem_through_the_factory(args):
+    exes = {k: TOOLS / f"test_hf_modem.{k}" for k in ("ref", "pimpl", "hip")}
+    if not all(e.exists() for e in exes.values()):
+        pytest.skip("oracle/_ref/tools/test_hf_modem.* not built (needs /root/reference: `make -C oracle tools`)")
+    rc_ref, out_ref, err_ref = _run(exes["ref"], args + ["-v"])
+    log_ref = _pipeline_log(err_ref)
+    assert any("Sync detected" in l for l in log_ref), "the reference's pipeline must at least synchronise for the comparison to mean anything"
+    for kind in ("pimpl", "hip"):
+        rc, out, err = _run(exes[kind], args + ["-v"])
+        assert _stdout(out) == _stdout(out_ref), (kind, args, out[-600:], out_ref[-600:], err[-600:])
+        log = _pipeline_log(err)
+        for i, (x, y) in enumerate(zip(log_ref, log)):
+            assert x == y, f"{kind} {args}: RxPipeline log line {i} differs\n  reference: {x}\n  {kind}: {y}\n  before: {log_ref[max(0, i - 3):i]}"
+        assert len(log) == len(log_ref), (kind, len(log), len(log_ref))
+        assert rc == rc_ref
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# oracle/demod_pimpl_harness.cpp: scripted use of the two pimpl classes' PUBLIC interface where the reference's tools do not go
+# (several frames on one object without reset(), setTimingOffset, setFrequencyOffset[WithPhase] at every point of a frame,
+# processPresynced in all its branches with the frame's tail through process(), mid-frame preambles, the three exits of SYNCED,
+# getData / getChannelQuality, the decoder's multi-block and limit semantics, both interleavers) — one source, linked against
+# the compiled reference and against the drop-ins; every answer with floats as bit patterns; outputs identical.
+MOD = dict(DBPSK=0, BPSK=1, DQPSK=2, QPSK=3, D8PSK=4, QAM16=6, QAM32=7, QAM64=8)
+RATE = dict(R1_4=0, R1_3=1, R1_2=2, R2_3=3, R3_4=4, R5_6=5)
+HARNESS_CASES = [
+    ("carry", 1024, "QAM16", "R3_4", 1), ("carry", 512, "DQPSK", "R1_2", 2), ("carry", 512, "QPSK", "R1_2", 3), ("carry", 1024, "D8PSK", "R2_3", 4),
+    ("timing", 1024, "QAM16", "R3_4", 5), ("timing", 512, "DQPSK", "R1_2", 6),
+    ("setcfo", 1024, "QAM16", "R3_4", 7), ("setcfo", 512, "DQPSK", "R1_2", 8), ("setcfo", 512, "QAM64", "R5_6", 9),
+    ("presynced", 512, "DQPSK", "R1_2", 10), ("presynced", 512, "QPSK", "R1_2", 11), ("presynced", 1024, "QAM16", "R3_4", 12), ("presynced", 512, "DBPSK", "R1_4", 13),
+    ("midframe", 1024, "QAM16", "R3_4", 14), ("midframe", 512, "DQPSK", "R1_2", 15), ("midframe", 512, "QPSK", "R2_3", 16),
+    ("exits", 512, "DQPSK", "R1_2", 17), ("exits", 1024, "QAM32", "R3_4", 18),
+    ("getdata", 512, "DQPSK", "R1_2", 19), ("getdata", 1024, "QAM16", "R3_4", 20),
+    ("decoder", 512, "QPSK", "R1_4", 21), ("decoder", 512, "QPSK", "R1_2", 22), ("decoder", 512, "QPSK", "R2_3", 23), ("decoder", 512, "QPSK", "R3_4", 24),
+    ("decoder", 512, "QPSK", "R5_6", 25), ("decoder", 512, "QPSK", "R1_3", 26),
+    ("interleave", 512, "QPSK", "R1_2", 27),
+]
+
+
+@pytest.mark.parametrize("sc,fft,mod,rate,seed", HARNESS_CASES, ids=[f"{c[0]}_{c[1]}_{c[2]}_{c[3]}" for c in HARNESS_CASES])
+def test_pimpl_classes_scripted(sc, fft, mod, rate, seed):
+    ref, hip = TOOLS / "demod_pimpl_harness.ref", TOOLS / "demod_pimpl_harness.hip"
+    if not ref.exists() or not hip.exists():
+        pytest.skip("oracle/_ref/tools/demod_pimpl_harness.* not built (needs /root/reference: `make -C oracle tools`)")
+    args = [sc, str(fft), str(MOD[mod]), str(RATE[rate]), str(seed)]
+    rc_ref, out_ref, err_ref = _run(ref, args)
+    assert rc_ref == 0, err_ref[-800:]
+    rc_hip, out_hip, err_hip = _run(hip, args)
+    assert rc_hip == 0, err_hip[-1500:]
+    a, b = out_ref.splitlines(), out_hip.splitlines()
+    assert len(a) > 5
+    if sc not in ("decoder", "interleave", "getdata"):
+        assert any("soft 648" in l for l in a), "the reference must deliver codewords for the comparison to mean anything"
+    for i, (x, y) in enumerate(zip(a, b)):
+        assert x == y, f"{args}: line {i} differs\n  reference: {x[:260]}\n  hip:       {y[:260]}\n  before: {[l[:120] for l in a[max(0, i - 4):i]]}"
+    assert len(a) == len(b), (args, len(a), len(b))
