@@ -139,6 +139,11 @@ typedef struct ultra_hip_counters {
 
 typedef struct ultra_hip_ctx ultra_hip_ctx;
 
+/* Number of blocking host-on-device waits the library has issued so far in this process (its copies to and from host
+ * memory, ultra_hip_synchronize, a workspace growing): what a latency-bound caller — one live stream, one process() call at
+ * a time — pays per call beside the kernels.  Diagnostic; oracle/live_latency.cpp reports it per call.  ABI 8. */
+unsigned long long ultra_hip_host_sync_count(void);
+
 /* ABI version of the loaded library (== ULTRA_HIP_ABI_VERSION). */
 int ultra_hip_abi_version(void);
 
@@ -582,6 +587,11 @@ int ultra_hip_malloc(ultra_hip_ctx* ctx, size_t bytes, void** d_ptr);
 int ultra_hip_free(ultra_hip_ctx* ctx, void* d_ptr);
 int ultra_hip_memcpy_h2d(ultra_hip_ctx* ctx, void* d_dst, const void* h_src, size_t bytes);
 int ultra_hip_memcpy_d2h(ultra_hip_ctx* ctx, void* h_dst, const void* d_src, size_t bytes);
+/* ultra_hip_memcpy_h2d without the wait: the bytes are copied into a pinned staging ring of the context before the call
+ * returns (h_src is the caller's again at once) and travel to the device in stream order, ahead of every launch issued
+ * after it.  For the live adapters, whose process() call then costs ONE blocking wait — the download of its answer — instead
+ * of one per transfer.  Transfers above 256 KB take the blocking copy.  ABI 8. */
+int ultra_hip_memcpy_h2d_async(ultra_hip_ctx* ctx, void* d_dst, const void* h_src, size_t bytes);
 int ultra_hip_memset(ultra_hip_ctx* ctx, void* d_dst, int value, size_t bytes);
 
 /* Device self-test of the pinned libm restatement (projectultra_amd/csrc/

@@ -234,7 +234,7 @@ public:
         const size_t out_bytes = it_bytes + by_bytes + n_cw;
         char* d = static_cast<char*>(slot_.buf(0, llr_bytes + out_bytes));
         char* d_out = d + llr_bytes;
-        detail::check(ultra_hip_memcpy_h2d(slot_.ctx(), d, llr, llr_bytes), "h2d");
+        detail::check(ultra_hip_memcpy_h2d_async(slot_.ctx(), d, llr, llr_bytes), "h2d");
         detail::check(ultra_hip_ldpc_decode_batch(slot_.ctx(), reinterpret_cast<const float*>(d), n_cw,
                                                   reinterpret_cast<uint8_t*>(d_out + it_bytes), reinterpret_cast<int32_t*>(d_out),
                                                   reinterpret_cast<uint8_t*>(d_out + it_bytes + by_bytes), nullptr), "ldpc_decode_batch");
@@ -406,7 +406,7 @@ public:
         float cp[3] = {freq_offset_hz_, freq_correction_phase_, timing_};
         if (!chirp_cfo_estimated_ && n_train >= 2 && std::fabs(freq_offset_hz_) < 0.1f) { cp[0] = std::nanf(""); cp[1] = 0.0f; }
         float* d_in = reinterpret_cast<float*>(small() + 16);
-        detail::check(ultra_hip_memcpy_h2d(slot_.ctx(), d_in, cp, sizeof(cp)), "h2d");
+        detail::check(ultra_hip_memcpy_h2d_async(slot_.ctx(), d_in, cp, sizeof(cp)), "h2d");
         if (timing_ != 0.0f) detail::check(ultra_hip_demod_stream_start(ps_slot_.ctx(), ULTRA_STREAM_START_TIMING, d_in + 2), "stream_start");
         const uint32_t n_data = n_sym - n_train;
         float* d_out = outDev(size_t(n_data) * geo_.llrs_per_symbol);
@@ -481,7 +481,7 @@ private:
     // the search restarts on whatever is still buffered: rx_buffer = [origin_, fed_)
     void restartSearch() {
         const uint32_t r[4] = {origin_, fed_, noise_floor_bits_, 0u};
-        detail::check(ultra_hip_memcpy_h2d(slot_.ctx(), small(), r, sizeof(r)), "h2d");
+        detail::check(ultra_hip_memcpy_h2d_async(slot_.ctx(), small(), r, sizeof(r)), "h2d");
     }
     // sample indices are 32-bit and absolute: long before they run out (6 h of audio) the origin moves to rx_buffer's start
     void rebase() {
@@ -504,8 +504,8 @@ private:
             d_origin_ = origin_;
             if (live) detail::check(ultra_hip_memcpy_h2d(slot_.ctx(), const_cast<float*>(rxDev()), rx_.data(), live * sizeof(float)), "h2d");
         } else if (!samples.empty()) {
-            detail::check(ultra_hip_memcpy_h2d(slot_.ctx(), const_cast<float*>(rxDev()) + (fed_ - d_origin_), samples.data(),
-                                               samples.size() * sizeof(float)), "h2d");
+            detail::check(ultra_hip_memcpy_h2d_async(slot_.ctx(), const_cast<float*>(rxDev()) + (fed_ - d_origin_), samples.data(),
+                                                     samples.size() * sizeof(float)), "h2d");
         }
         fed_ += static_cast<uint32_t>(samples.size());
     }
@@ -523,7 +523,7 @@ private:
         ultra_hip_ctx* ctx = liveCtx();
         if (synced_symbols_ == 0) {                                      // symbol 0 of a Schmidl-Cox frame
             const float cp[3] = {pending_cfo_ ? freq_offset_hz_ : coarse_cfo_, pending_cfo_ ? freq_correction_phase_ : 0.0f, timing_};
-            detail::check(ultra_hip_memcpy_h2d(ctx, d_in, cp, sizeof(cp)), "h2d");
+            detail::check(ultra_hip_memcpy_h2d_async(ctx, d_in, cp, sizeof(cp)), "h2d");
             if (start_mode_ != ULTRA_STREAM_START_FRESH) detail::check(ultra_hip_demod_stream_start(ctx, start_mode_, d_in + 2), "stream_start");
             start_mode_ = ULTRA_STREAM_START_FRESH;
         }

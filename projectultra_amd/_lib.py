@@ -57,6 +57,7 @@ _cfgp, _geop = C.POINTER(ultra_hip_config), C.POINTER(ultra_hip_geometry)
 # name -> (restype, argtypes); exactly the prototypes of include/ultra_hip.h
 PROTOTYPES = {
     "ultra_hip_abi_version": (_i, []),
+    "ultra_hip_host_sync_count": (C.c_ulonglong, []),
     "ultra_hip_strerror": (C.c_char_p, [_i]),
     "ultra_hip_device_count": (_i, []),
     "ultra_hip_geometry_for": (_i, [_cfgp, _geop]),
@@ -102,6 +103,7 @@ PROTOTYPES = {
     "ultra_hip_free": (_i, [_vp, _vp]),
     "ultra_hip_memcpy_h2d": (_i, [_vp, _vp, _vp, _sz]),
     "ultra_hip_memcpy_d2h": (_i, [_vp, _vp, _vp, _sz]),
+    "ultra_hip_memcpy_h2d_async": (_i, [_vp, _vp, _vp, _sz]),
     "ultra_hip_memset": (_i, [_vp, _vp, _i, _sz]),
     "ultra_hip_selftest_math": (_i, [_vp, _i, _vp, _vp, _vp, _sz]),
 }

@@ -13,6 +13,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <new>
+#include <atomic>
 #include <vector>
 
 #include "../../include/ultra_hip.h"
@@ -79,6 +80,8 @@ struct ultra_hip_ctx {
     uint16_t* d_deint_table = nullptr;   // general gather table of the fused deinterleave (nullptr = use the step)
     int mix_wg_per_cu = 0;               // variant builds only (-DUH_AB_SWITCHES, ULTRA_HIP_MIX_WG_PER_CU): workgroups per CU of the transform's grid
     bool stream_cfo_given = false;       // launch_demod: whether the frame in flight started with caller-supplied offsets
+    char* h_stage = nullptr;             // ultra_hip_memcpy_h2d_async: pinned staging ring
+    size_t stage_cap = 0, stage_off = 0;
     int stream_start_mode = 0;           // ultra_hip_demod_stream_start: how the next first_symbol == 0 stream call starts (consumed by it)
     const float* stream_start_timing = nullptr;
     // ULTRA_HIP_FALLBACK_CHAIN=1: the fall-back kernels for every layout — track_pilot_kernel + track_kernel per symbol instead
@@ -96,6 +99,11 @@ struct ultra_hip_ctx {
 };
 
 namespace {
+
+// every blocking wait of the host on the device that the library itself issues (ultra_hip_host_sync_count): what a
+// latency-bound caller — one stream, one process() call at a time — pays per call beside the kernels
+std::atomic<unsigned long long> g_host_syncs{0};
+inline hipError_t uh_stream_sync(hipStream_t s) { g_host_syncs.fetch_add(1, std::memory_order_relaxed); return hipStreamSynchronize(s); }
 
 #define UH_HIP(call)                                                                          \
     do {                                                                                      \
@@ -144,7 +152,7 @@ struct DeviceGuard {
 // them); ultra_hip_reserve sizes them up front.
 int ensure_demod_workspace(ultra_hip_ctx* ctx, size_t n_frames) {
     if (ctx->ws_demod_frames >= n_frames) return ULTRA_HIP_OK;
-    UH_HIP(hipStreamSynchronize(ctx->stream));
+    UH_HIP(uh_stream_sync(ctx->stream));
     if (ctx->d_ws_state) { (void)hipFree(ctx->d_ws_state); ctx->d_ws_state = nullptr; }
     if (ctx->d_ws_seg) { (void)hipFree(ctx->d_ws_seg); ctx->d_ws_seg = nullptr; }
     ctx->ws_demod_frames = 0;
@@ -156,7 +164,7 @@ int ensure_demod_workspace(ultra_hip_ctx* ctx, size_t n_frames) {
 // used FFT bins: one row of 2 * fq_half (64 or 128) per frame — per frame AND symbol where all symbols are transformed in one launch
 int ensure_fq_workspace(ultra_hip_ctx* ctx, size_t rows) {
     if (ctx->ws_fq_rows >= rows) return ULTRA_HIP_OK;
-    UH_HIP(hipStreamSynchronize(ctx->stream));
+    UH_HIP(uh_stream_sync(ctx->stream));
     if (ctx->d_ws_fq) { (void)hipFree(ctx->d_ws_fq); ctx->d_ws_fq = nullptr; }
     ctx->ws_fq_rows = 0;
     UH_HIP(hipMalloc(&ctx->d_ws_fq, rows * (size_t)(2 * ctx->h_demod.fq_half) * sizeof(c32)));
@@ -165,7 +173,7 @@ int ensure_fq_workspace(ultra_hip_ctx* ctx, size_t rows) {
 }
 int ensure_trk_workspace(ultra_hip_ctx* ctx, size_t rows) {
     if (ctx->ws_trk_rows >= rows) return ULTRA_HIP_OK;
-    UH_HIP(hipStreamSynchronize(ctx->stream));
+    UH_HIP(uh_stream_sync(ctx->stream));
     if (ctx->d_ws_trk) { (void)hipFree(ctx->d_ws_trk); ctx->d_ws_trk = nullptr; }
     ctx->ws_trk_rows = 0;
     UH_HIP(hipMalloc(&ctx->d_ws_trk, rows * (size_t)dev::kTrkRecFloats * sizeof(float)));
@@ -174,7 +182,7 @@ int ensure_trk_workspace(ultra_hip_ctx* ctx, size_t rows) {
 }
 int ensure_llr_workspace(ultra_hip_ctx* ctx, size_t n_frames) {
     if (ctx->ws_llr_frames >= n_frames) return ULTRA_HIP_OK;
-    if (ctx->d_ws_llr) { UH_HIP(hipStreamSynchronize(ctx->stream)); (void)hipFree(ctx->d_ws_llr); ctx->d_ws_llr = nullptr; }
+    if (ctx->d_ws_llr) { UH_HIP(uh_stream_sync(ctx->stream)); (void)hipFree(ctx->d_ws_llr); ctx->d_ws_llr = nullptr; }
     ctx->ws_llr_frames = 0;
     UH_HIP(hipMalloc(&ctx->d_ws_llr, n_frames * (size_t)ctx->geo.llrs_per_frame * sizeof(float)));
     ctx->ws_llr_frames = n_frames;
@@ -553,7 +561,7 @@ int launch_stimulus(ultra_hip_ctx* ctx, uint64_t seed, uint64_t first_frame, siz
                     uint8_t* d_payload) {
     const DemodConst& D = ctx->h_demod;
     if (ctx->ws_fstats_frames < n_frames) {
-        if (ctx->d_ws_fstats) { UH_HIP(hipStreamSynchronize(ctx->stream)); (void)hipFree(ctx->d_ws_fstats); ctx->d_ws_fstats = nullptr; }
+        if (ctx->d_ws_fstats) { UH_HIP(uh_stream_sync(ctx->stream)); (void)hipFree(ctx->d_ws_fstats); ctx->d_ws_fstats = nullptr; }
         ctx->ws_fstats_frames = 0;
         UH_HIP(hipMalloc(&ctx->d_ws_fstats, n_frames * 2 * sizeof(float)));
         ctx->ws_fstats_frames = n_frames;
@@ -579,6 +587,7 @@ int launch_stimulus(ultra_hip_ctx* ctx, uint64_t seed, uint64_t first_frame, siz
 extern "C" {
 
 int ultra_hip_abi_version(void) { return ULTRA_HIP_ABI_VERSION; }
+unsigned long long ultra_hip_host_sync_count(void) { return g_host_syncs.load(std::memory_order_relaxed); }
 
 #ifdef UH_MIXFFT_STAMPS
 // diagnostic build only (tools/mix_fft_stalls.py): where mix_fft_kernel / mix_fft2_kernel leave their phase stamps
@@ -680,7 +689,7 @@ int ultra_hip_create(const ultra_hip_config* cfg, int device, void* stream, ultr
         // ldpc_totals_kernel.h: dynamic LDS must start at LDS address 0 for the totals kernel; d_work doubles as the probe's word
         unsigned base = 1u;
         hipLaunchKernelGGL(dev::ldpc_lds_base_probe_kernel, dim3(1), dim3(dev::kLdpcThreads), (size_t)ctx->h_tplan.lds_bytes, ctx->stream, ctx->d_work);
-        if (hipGetLastError() != hipSuccess || hipStreamSynchronize(ctx->stream) != hipSuccess ||
+        if (hipGetLastError() != hipSuccess || uh_stream_sync(ctx->stream) != hipSuccess ||
             hipMemcpy(&base, ctx->d_work, sizeof(base), hipMemcpyDeviceToHost) != hipSuccess)
             return fail(ULTRA_HIP_ERR_HIP);
         if (base != 0u) {
@@ -735,6 +744,7 @@ void ultra_hip_destroy(ultra_hip_ctx* ctx) {
     if (ctx->d_ws_trk) (void)hipFree(ctx->d_ws_trk);
     if (ctx->d_ws_fq) (void)hipFree(ctx->d_ws_fq);
     if (ctx->d_ws_seg) (void)hipFree(ctx->d_ws_seg);
+    if (ctx->h_stage) (void)hipHostFree(ctx->h_stage);
     if (ctx->ev_begin) (void)hipEventDestroy(ctx->ev_begin);
     if (ctx->ev_end) (void)hipEventDestroy(ctx->ev_end);
     delete ctx;
@@ -860,7 +870,7 @@ int ultra_hip_demod_stream_set_cfo_phase(ultra_hip_ctx* ctx, size_t frame, float
     const float v[3] = {cfo_hz, cfo_hz, cfo_phase};
     static_assert(dev::st_cfo == 0 && dev::st_cfo_filt == 1 && dev::st_cfo_phase == 2, "record layout");
     UH_HIP(hipMemcpyAsync(ctx->d_ws_state + frame * (size_t)dev::kStFloats, v, sizeof(v), hipMemcpyHostToDevice, ctx->stream));
-    UH_HIP(hipStreamSynchronize(ctx->stream));
+    UH_HIP(uh_stream_sync(ctx->stream));
     // From the next symbol on some frame of the batch carries an offset nothing on the path estimated: the short cuts
     // launch_demod takes for frames that started without one (no phase table on layouts without pilots, the first two
     // symbols at CFO 0 on layouts with them) no longer hold for the rest of this frame.
@@ -965,7 +975,7 @@ int ultra_hip_receive_batch(ultra_hip_ctx* ctx, const float* d_audio, size_t str
     if (ctx->cfg.entry != ULTRA_ENTRY_SYNCED || ctx->geo.llrs_per_frame < (uint32_t)kLdpcN) return ULTRA_HIP_ERR_UNSUPPORTED;
     DeviceGuard guard(ctx->device);
     if (ctx->ws_acq_frames < n_streams) {
-        if (ctx->d_ws_acq) { UH_HIP(hipStreamSynchronize(ctx->stream)); (void)hipFree(ctx->d_ws_acq); ctx->d_ws_acq = nullptr; }
+        if (ctx->d_ws_acq) { UH_HIP(uh_stream_sync(ctx->stream)); (void)hipFree(ctx->d_ws_acq); ctx->d_ws_acq = nullptr; }
         ctx->ws_acq_frames = 0;
         UH_HIP(hipMalloc(&ctx->d_ws_acq, n_streams * 5 * sizeof(unsigned)));
         ctx->ws_acq_frames = n_streams;
@@ -1006,7 +1016,7 @@ int ultra_hip_chirp_receive_batch(ultra_hip_ctx* ctx, const float* d_audio, size
     if (ctx->cfg.entry != ULTRA_ENTRY_PRESYNCED || ctx->geo.llrs_per_frame < (uint32_t)kLdpcN) return ULTRA_HIP_ERR_UNSUPPORTED;
     DeviceGuard guard(ctx->device);
     if (ctx->ws_chirp_streams < n_streams) {
-        if (ctx->d_ws_chirp) { UH_HIP(hipStreamSynchronize(ctx->stream)); (void)hipFree(ctx->d_ws_chirp); ctx->d_ws_chirp = nullptr; }
+        if (ctx->d_ws_chirp) { UH_HIP(uh_stream_sync(ctx->stream)); (void)hipFree(ctx->d_ws_chirp); ctx->d_ws_chirp = nullptr; }
         ctx->ws_chirp_streams = 0;
         UH_HIP(hipMalloc(&ctx->d_ws_chirp, n_streams * 8 * sizeof(unsigned)));
         ctx->ws_chirp_streams = n_streams;
@@ -1057,7 +1067,7 @@ int ultra_hip_decode_frames_batch(ultra_hip_ctx* ctx, const float* d_soft, size_
     DeviceGuard guard(ctx->device);
     const size_t total_cw = n_frames * num_cw, db = ctx->geo.decoded_bytes;
     if (ctx->ws_frame_cw < total_cw) {
-        if (ctx->d_ws_frame) { UH_HIP(hipStreamSynchronize(ctx->stream)); (void)hipFree(ctx->d_ws_frame); ctx->d_ws_frame = nullptr; }
+        if (ctx->d_ws_frame) { UH_HIP(uh_stream_sync(ctx->stream)); (void)hipFree(ctx->d_ws_frame); ctx->d_ws_frame = nullptr; }
         ctx->ws_frame_cw = 0;
         UH_HIP(hipMalloc(&ctx->d_ws_frame, total_cw * (db + 1 + sizeof(int32_t)) + 16));
         ctx->ws_frame_cw = total_cw;
@@ -1134,7 +1144,7 @@ int ultra_hip_channel_cfo_batch(ultra_hip_ctx* ctx, const float* d_in, size_t in
         return ULTRA_HIP_OK;
     }
     if (ctx->ws_cfo_samples < n_samples) {
-        if (ctx->d_ws_cfo) { UH_HIP(hipStreamSynchronize(ctx->stream)); (void)hipFree(ctx->d_ws_cfo); ctx->d_ws_cfo = nullptr; }
+        if (ctx->d_ws_cfo) { UH_HIP(uh_stream_sync(ctx->stream)); (void)hipFree(ctx->d_ws_cfo); ctx->d_ws_cfo = nullptr; }
         ctx->ws_cfo_samples = 0;
         UH_HIP(hipMalloc(&ctx->d_ws_cfo, 2 * (size_t)n_samples * sizeof(c32)));
         ctx->ws_cfo_samples = n_samples;
@@ -1302,14 +1312,14 @@ int ultra_hip_set_deinterleave_table(ultra_hip_ctx* ctx, const uint16_t* h_index
     if (!ctx) return ULTRA_HIP_ERR_INVALID_ARG;
     DeviceGuard guard(ctx->device);
     if (!h_index || n == 0) {                                   // off: back to the step (ultra_hip_set_deinterleave)
-        if (ctx->d_deint_table) { UH_HIP(hipStreamSynchronize(ctx->stream)); (void)hipFree(ctx->d_deint_table); ctx->d_deint_table = nullptr; }
+        if (ctx->d_deint_table) { UH_HIP(uh_stream_sync(ctx->stream)); (void)hipFree(ctx->d_deint_table); ctx->d_deint_table = nullptr; }
         return ULTRA_HIP_OK;
     }
     if (n != (uint32_t)kLdpcN) return ULTRA_HIP_ERR_INVALID_ARG;
     for (uint32_t j = 0; j < n; ++j) if (h_index[j] >= (uint16_t)kLdpcN) return ULTRA_HIP_ERR_INVALID_ARG;   // the kernel gathers through it
     if (!ctx->d_deint_table) UH_HIP(hipMalloc(&ctx->d_deint_table, kLdpcN * sizeof(uint16_t)));
     UH_HIP(hipMemcpyAsync(ctx->d_deint_table, h_index, kLdpcN * sizeof(uint16_t), hipMemcpyHostToDevice, ctx->stream));
-    UH_HIP(hipStreamSynchronize(ctx->stream));
+    UH_HIP(uh_stream_sync(ctx->stream));
     return ULTRA_HIP_OK;
 }
 
@@ -1362,7 +1372,7 @@ int ultra_hip_counters_allreduce(ultra_hip_ctx* ctx, void* rccl_comm, ultra_hip_
 int ultra_hip_synchronize(ultra_hip_ctx* ctx) {
     if (!ctx) return ULTRA_HIP_ERR_INVALID_ARG;
     DeviceGuard guard(ctx->device);
-    UH_HIP(hipStreamSynchronize(ctx->stream));
+    UH_HIP(uh_stream_sync(ctx->stream));
     return ULTRA_HIP_OK;
 }
 
@@ -1400,7 +1410,30 @@ int ultra_hip_memcpy_h2d(ultra_hip_ctx* ctx, void* d_dst, const void* h_src, siz
     if (!ctx || (bytes && (!d_dst || !h_src))) return ULTRA_HIP_ERR_INVALID_ARG;
     DeviceGuard guard(ctx->device);
     UH_HIP(hipMemcpyAsync(d_dst, h_src, bytes, hipMemcpyHostToDevice, ctx->stream));
-    UH_HIP(hipStreamSynchronize(ctx->stream));
+    UH_HIP(uh_stream_sync(ctx->stream));
+    return ULTRA_HIP_OK;
+}
+
+int ultra_hip_memcpy_h2d_async(ultra_hip_ctx* ctx, void* d_dst, const void* h_src, size_t bytes) {
+    if (!ctx || (bytes && (!d_dst || !h_src))) return ULTRA_HIP_ERR_INVALID_ARG;
+    if (bytes == 0) return ULTRA_HIP_OK;
+    constexpr size_t kRing = size_t(1) << 20;
+    if (bytes > kRing / 4) return ultra_hip_memcpy_h2d(ctx, d_dst, h_src, bytes);      // large transfers: the blocking copy
+    DeviceGuard guard(ctx->device);
+    if (!ctx->h_stage) {
+        void* p = nullptr;
+        if (hipHostMalloc(&p, kRing, hipHostMallocDefault) != hipSuccess) { (void)hipGetLastError(); return ultra_hip_memcpy_h2d(ctx, d_dst, h_src, bytes); }
+        ctx->h_stage = static_cast<char*>(p); ctx->stage_cap = kRing; ctx->stage_off = 0;
+    }
+    const size_t need = (bytes + 255) & ~size_t(255);
+    if (ctx->stage_off + need > ctx->stage_cap) {              // wrap: the ring's earlier copies must have left it
+        UH_HIP(uh_stream_sync(ctx->stream));
+        ctx->stage_off = 0;
+    }
+    char* slot = ctx->h_stage + ctx->stage_off;
+    std::memcpy(slot, h_src, bytes);                           // the caller's buffer is free again when this call returns
+    ctx->stage_off += need;
+    UH_HIP(hipMemcpyAsync(d_dst, slot, bytes, hipMemcpyHostToDevice, ctx->stream));
     return ULTRA_HIP_OK;
 }
 
@@ -1408,7 +1441,7 @@ int ultra_hip_memcpy_d2h(ultra_hip_ctx* ctx, void* h_dst, const void* d_src, siz
     if (!ctx || (bytes && (!h_dst || !d_src))) return ULTRA_HIP_ERR_INVALID_ARG;
     DeviceGuard guard(ctx->device);
     UH_HIP(hipMemcpyAsync(h_dst, d_src, bytes, hipMemcpyDeviceToHost, ctx->stream));
-    UH_HIP(hipStreamSynchronize(ctx->stream));
+    UH_HIP(uh_stream_sync(ctx->stream));
     return ULTRA_HIP_OK;
 }
 
