@@ -52,21 +52,26 @@ HBM_PEAK_GBPS = 8000.0          # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
 CLOCK_HZ = 2.4e9                # MI355X peak engine clock (MI355X_MICROARCH.md); the chip holds ~2.3 GHz under these kernels
 # LDS-pipeline cycles per wave-instruction (MI355X_MICROARCH.md, LDS table; re-measured in profiles/r02_issue_table.txt)
 LDS_CYC = dict(read_b32=2, write_b32=4, write_addtid_b32=2)
-# Compute-side roofline: issue cycles per unit of work and kernel, = (dynamic instruction counts per unit from rocprofv3
-# --pmc SQ_INSTS_VALU / _SALU / _LDS, profiles/r03_sq_counters.txt) x (measured cost per instruction of the kernel's own
-# opcode mix, profiles/r02_issue_table.txt), as tools/issue_model.py derives them into profiles/r04_issue_model.txt.
-#   valu / salu: cycles of ONE SIMD per unit (a CU has 4 SIMDs); lds: cycles of the CU's single LDS pipeline per unit.
-#   unit: "cw_iteration" = one executed BP iteration of one codeword; "frame" = one frame of one launch.
-ISSUE_CYCLES = {
-    "ldpc_totals R3/4": dict(unit="cw_iteration", valu=162.5 * 3.38, salu=80.4 * 4.19, lds=61.5 * 2.13),
-    # round 3 (profiles/r03_sq_counters.txt -> profiles/r04_issue_model.txt): the two-wavefront transform, the deferred
-    # carrier half (unit: one symbol of one frame), the pilot half with its record for the carrier half
-    "mix_fft_kernel": dict(unit="frame", valu=1095.7 * 3.47, salu=236.4 * 4.19, lds=106.7 * 3.48),    # mean of the rotating (1505 VALU) and the no-rotation instance (686): two launches each per step
-    "track_kernel": dict(unit="frame_symbol", valu=182.4 * 3.29, salu=118.3 * 4.19, lds=19.9 * 4.01),
-    "track_pilot_kernel": dict(unit="frame", valu=164.7 * 3.54, salu=64.1 * 4.19, lds=4.75 * 5.08),
-    # per raw stream of 14,400 samples at 30 dB (profiles/r03_sq_counters_raw.txt: 65,536 streams per launch)
-    "acquire_kernel": dict(unit="stream", valu=936.6e3 * 3.38, salu=135.3e3 * 4.19, lds=161.4e3 * 3.33),
-}
+# Compute-side roofline: profiles/issue.json (tools/issue_model.py --json: dynamic VALU / SALU / LDS wave-instructions per
+# launch of every kernel INSTANCE from rocprofv3 --pmc, the work items those launches covered, the measured cost per
+# instruction of the instance's own opcode mix, and the hash of the kernel sources they were collected on).  Quoted only when
+# that hash is the tree's; scaled by the work items this run's launches covered (ultra_hip_profile_read_items).
+def load_issue_model(config):
+    """(model, None) or (None, why) — the per-class issue cycles per work item of profiles/issue.json, if it describes THESE kernels."""
+    f = ROOT / "profiles" / "issue.json"
+    if not f.exists():
+        return None, "profiles/issue.json absent (tools/issue_model.py --json after a PMC sweep of this build)"
+    try:
+        from projectultra_amd._lib import source_hash
+        m = json.loads(f.read_text())
+        if m.get("csrc_sha") != source_hash():
+            return None, (f"profiles/issue.json was collected on kernel sources {m.get('csrc_sha')} (commit {m.get('commit')}), the tree holds "
+                          f"{source_hash()}: instruction counts of another kernel are not quoted")
+        if config not in m.get("configs", {}):
+            return None, f"profiles/issue.json holds {sorted(m.get('configs', {}))}, this line is {config}"
+        return m, None
+    except Exception as e:
+        return None, f"profiles/issue.json unreadable: {e}"
 
 
 def parse():
@@ -641,15 +646,21 @@ def self_launch(args) -> int:
     touched the GPU).  The child's rank 0 prints the JSON line on the stdout it inherits; the exit code is the child's, so a
     rank that fails fails the run."""
     import socket
-    with socket.socket() as s:                      # a free rendezvous port on the loopback interface
-        s.bind(("127.0.0.1", 0))
-        port = s.getsockname()[1]
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
-           "--master-addr", "127.0.0.1", "--master-port", str(port), str(Path(__file__).resolve())] + sys.argv[1:] + ["--no-build"]
-    print(f"bench.py: --gpus {args.gpus} and no RANK in the environment: starting {args.gpus} ranks ({' '.join(cmd[1:8])} ...)",
-          file=sys.stderr, flush=True)
     env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
-    return subprocess.call(cmd, env=env)
+    rc = 1
+    for attempt in range(2):                        # the port is free when we look, not necessarily when the child binds it: one retry
+        with socket.socket() as s:                  # a free rendezvous port on the loopback interface
+            s.bind(("127.0.0.1", 0))
+            port = s.getsockname()[1]
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+               "--master-addr", "127.0.0.1", "--master-port", str(port), str(Path(__file__).resolve())] + sys.argv[1:] + ["--no-build"]
+        print(f"bench.py: --gpus {args.gpus} and no RANK in the environment: starting {args.gpus} ranks ({' '.join(cmd[1:8])} ...)",
+              file=sys.stderr, flush=True)
+        t0 = time.time()
+        rc = subprocess.call(cmd, env=env)
+        if rc == 0 or time.time() - t0 > 20.0:      # a rendezvous that cannot bind fails within seconds; anything later is the run's own failure
+            break
+    return rc
 
 
 # ------------------------------------------------------------------------------------------------------------------
@@ -767,7 +778,7 @@ def main():
     # The same K steps once more (all ranks: the step holds the collective) with, on rank 0, every kernel launch
     # bracketed by HIP events on the launch stream (ultra_hip_profile_enable) and every all-reduce by a pair of stream
     # events: per-kernel durations for the roofline object.  Kept out of the timed region: the event records cost ~2 %.
-    prof = {}
+    prof, prof_items = {}, {}
     if rank == 0:
         for c in wl.contexts():
             c.profile_read(); c.profile_enable(True)
@@ -779,8 +790,10 @@ def main():
     if rank == 0:
         for c in wl.contexts():
             c.profile_enable(False)
-            for k, (ms, cnt) in c.profile_read().items():
-                a = prof.setdefault(k, [0.0, 0]); a[0] += ms; a[1] += cnt
+            for k, (ms, cnt, items) in c.profile_read_items().items():
+                a = prof_items.setdefault(k, [0.0, 0, 0]); a[0] += ms; a[1] += cnt; a[2] += items
+                # the HBM view keeps the nine classes: the rotating transform is part of mix_fft_kernel there
+                a = prof.setdefault("mix_fft_kernel" if k == "mix_fft_rot_kernel" else k, [0.0, 0]); a[0] += ms; a[1] += cnt
     ar_us = float(np.mean([a.elapsed_time(b) for a, b in ar_events]) * 1e3) if ar_events else None
     if ar_host:
         ar_us = float(np.mean(ar_host) * 1e6)
@@ -836,42 +849,45 @@ def main():
                     roofline["traffic_dropped"] = why
             except Exception as e:
                 roofline["traffic_dropped"] = f"profiles/traffic.json unreadable: {e}"
-        # What actually bounds the decoder: the CU's single LDS pipeline.  One codeword-iteration of the lane-linear
-        # instances (R2/3, R3/4, R5/6) issues E gather reads + E scattered stores (check step) and E lane-linear reads +
-        # E add-TID stores (variable step), E = information-edge slots of the instance's degree profile; the other
-        # instances issue one read and one address+data store per slot and step.  Cycles per wave-instruction: MI355X_MICROARCH.md's LDS
-        # table, re-measured in profiles/r02_issue_table.txt.  A codeword that converges at iteration `it` executes
-        # it + 1 iterations, a failing one max_iterations.
-        # compute-side view of every kernel with a derived issue model: which unit is busiest, and how busy
-        def issue_view(name, key, units, ms):
-            m = ISSUE_CYCLES[key]
-            t = ms * 1e-3 * CLOCK_HZ
+        # Compute-side view: which unit of the dominant kernel is busiest, and how busy.  Issue cycles per work item come from
+        # profiles/issue.json (per kernel CLASS of ultra_hip_profile_read_items — the rotating transform apart from the one
+        # without rotation), guarded by the hash of the kernel sources like the traffic; they are scaled by the work items
+        # THIS run's launches covered and set against the cycles the measured launches had.
+        roofline["work_items"] = {cls: {"launches_per_step": l / args.steps, "items_per_step": it / args.steps, "ms_per_step": ms / args.steps}
+                                  for cls, (ms, l, it) in prof_items.items() if l}
+        model, why = load_issue_model(args.config)
+        if model is None:
+            roofline["compute"] = None
+            roofline["compute_dropped"] = why
+        else:
             cu = props.multi_processor_count
-            u = dict(valu=m["valu"] * units / (4 * cu * t), salu=m["salu"] * units / (4 * cu * t), lds=m["lds"] * units / (cu * t))
-            kernels[name]["issue"] = dict(unit=m["unit"], units_per_step=units, cycles_per_unit={k: m[k] for k in ("valu", "salu", "lds")},
-                                          busy_frac=u, clock_hz=CLOCK_HZ, source="profiles/r04_issue_model.txt")
-            return u
-        if wl.name == "cfg3":
-            executed = stats["iters_sum"] / world + (stats["frames"] - stats["ldpc_fail"]) / world
-            views = {"ldpc_decode_kernel": issue_view("ldpc_decode_kernel", "ldpc_totals R3/4", executed, kernels["ldpc_decode_kernel"]["ms_per_step"])}
-            for kname in ("mix_fft_kernel", "track_kernel", "track_pilot_kernel"):
-                if kname in kernels:
-                    # the carrier half is ONE launch over every (symbol, frame): its unit is a frame-symbol
-                    units = (wl.launch_units * wl.ctx.cfg.n_data_symbols if kname == "track_kernel"
-                             else wl.launch_units * kernels[kname]["launches_per_step"])
-                    views[kname] = issue_view(kname, kname, units, kernels[kname]["ms_per_step"])
-            if dom in views:
-                res = max(views[dom], key=views[dom].get)
+            clock = float(model.get("clock_hz", CLOCK_HZ))
+            per_item = model["configs"][args.config]["classes"]
+            views = {}
+            for cls, (ms_total, launches, items) in prof_items.items():
+                if launches == 0 or items == 0 or cls not in per_item:
+                    continue
+                m = per_item[cls]
+                t = ms_total * 1e-3 * clock                          # cycles the class's launches had, all steps
+                u = dict(valu=m["valu_cycles_per_item"] * items / (4 * cu * t), salu=m["salu_cycles_per_item"] * items / (4 * cu * t),
+                         lds=m["lds_cycles_per_item"] * items / (cu * t))
+                views[cls] = u
+                host = "mix_fft_kernel" if cls == "mix_fft_rot_kernel" else cls
+                kernels[host].setdefault("issue", {})[cls] = dict(
+                    item=m["item"], items_per_step=items / args.steps, launches_per_step=launches / args.steps, ms_per_step=ms_total / args.steps,
+                    cycles_per_item={k: m[k + "_cycles_per_item"] for k in ("valu", "salu", "lds")}, busy_frac=u, clock_hz=clock,
+                    instances=m.get("instances"), items_per_launch_at_collection=m.get("items_per_launch"))
+            # the dominant CLASS of the HBM view may be two instances here (mix_fft_kernel): the busier one speaks for it
+            cands = [c for c in views if c == dom or (dom == "mix_fft_kernel" and c == "mix_fft_rot_kernel")]
+            if cands:
+                best = max(cands, key=lambda c: prof_items[c][0])
+                res = max(views[best], key=views[best].get)
                 roofline.update({"bound": res, "compute": {"resource": {"valu": "vector issue (4 SIMDs per CU)", "salu": "scalar issue",
-                                                                        "lds": "LDS pipeline"}[res],
-                                                           "frac": views[dom][res], "all": views[dom]},
+                                                                        "lds": "LDS pipeline"}[res], "class": best,
+                                                           "frac": views[best][res], "all": views[best]},
                                  "hbm_frac": kernels[dom]["frac"]})
-        if wl.name == "raw" and dom == "acquire_kernel":
-            v = issue_view(dom, "acquire_kernel", wl.launch_units * kernels[dom]["launches_per_step"], kernels[dom]["ms_per_step"])
-            res = max(v, key=v.get)
-            roofline.update({"bound": res, "compute": {"resource": {"valu": "vector issue (4 SIMDs per CU)", "salu": "scalar issue",
-                                                                    "lds": "LDS pipeline"}[res], "frac": v[res], "all": v},
-                             "hbm_frac": kernels[dom]["frac"]})
+            roofline["compute_source"] = {"file": "profiles/issue.json", "commit": model.get("commit"), "csrc_sha": model.get("csrc_sha"),
+                                          "collected": model.get("collected")}
         if dom == "ldpc_decode_kernel" and wl.name == "cfg4":
             # R1/4 on the totals kernel with its degree profile (round 4; ldpc_totals_kernel.h): per codeword-iteration the row
             # phase issues one gather and one lane-linear store per R plane (37: row profile 6 6 6 5 5 4 3 2), the variable
@@ -891,8 +907,9 @@ def main():
                              "hbm_frac": kernels[dom]["frac"]})
         roofline["note"] = ("achieved/peak/frac = HBM view: algorithmic bytes per launch / mean launch duration (HIP events around every "
                             "launch of a repeat of the timed steps) against 8 TB/s. bound = the busiest unit of the dominant kernel where an "
-                            "issue model exists (compute.frac: issue cycles from PMC instruction counts x measured per-opcode costs, "
-                            "profiles/r04_issue_model.txt, over the cycles the launch had; kernels.*.issue for the others); 'lds' with the "
+                            "issue model exists (compute.frac: issue cycles per work item from PMC instruction counts x measured per-opcode costs, "
+                            "profiles/issue.json — quoted only when its source hash is the tree's, else compute = null —, times the work items "
+                            "this run's launches covered, over the cycles those launches had; kernels.*.issue for the others); 'lds' with the "
                             "instruction count of the totals decoder's profile for R1/4 (cfg4); 'hbm' otherwise")
 
     # ---- CPU baseline: the compiled reference on the host's physical cores, bounded sample (rank 0, N=1 only) ----

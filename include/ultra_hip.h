@@ -576,10 +576,20 @@ enum ultra_hip_kernel_class {
     ULTRA_HIP_K_CHIRP = 6,      /* chirp_sync_kernel */
     ULTRA_HIP_K_PILOT = 7,      /* track_pilot_kernel: pilot half of the channel update, one per data symbol */
     ULTRA_HIP_K_WALK = 8,       /* cfo_walk_kernel: phase table of the next symbol's CFO rotation, one per symbol */
-    ULTRA_HIP_K_N = 9
+    ULTRA_HIP_K_N = 9,
+    /* ABI 8, ultra_hip_profile_read_items only: the transform's ROTATING instance (mix_fft2_kernel<N, true>: a CFO phase table
+     * per frame, bit-exact sincosf per sample) apart from the instance without rotation, which stays class 1 — two kernels for
+     * an issue model, five times apart in instructions per item (profiles/issue.json, tools/issue_model.py). */
+    ULTRA_HIP_K_MIX_FFT_ROT = 9,
+    ULTRA_HIP_K_N2 = 10
 };
 int ultra_hip_profile_enable(ultra_hip_ctx* ctx, int enable);
 int ultra_hip_profile_read(ultra_hip_ctx* ctx, float* ms, uint32_t* launches);
+/* ... with ULTRA_HIP_K_N2 entries per array and the WORK ITEMS the recorded launches covered (items[]): frame-symbols for the
+ * transform, the walk and the two tracking kernels (a launch may cover one symbol of every frame, two, or all), codewords for
+ * the decoder, streams for the acquisition; 0 where a class has no natural item.  What an instruction count collected at one
+ * batch size and launch structure is scaled by when it is quoted for another (bench.py). */
+int ultra_hip_profile_read_items(ultra_hip_ctx* ctx, float* ms, uint32_t* launches, uint64_t* items);
 
 /* Convenience for hosts without their own device allocator (the C++ adapter
  * and the ctypes tests): hipMalloc/hipFree/hipMemcpy on the context's device. */

@@ -99,6 +99,7 @@ PROTOTYPES = {
     "ultra_hip_channel_interleaver_step": (_i, [C.c_uint32, C.c_uint32, _u32p]),
     "ultra_hip_profile_enable": (_i, [_vp, _i]),
     "ultra_hip_profile_read": (_i, [_vp, C.POINTER(C.c_float), C.POINTER(C.c_uint32)]),
+    "ultra_hip_profile_read_items": (_i, [_vp, C.POINTER(C.c_float), C.POINTER(C.c_uint32), C.POINTER(C.c_uint64)]),
     "ultra_hip_malloc": (_i, [_vp, _sz, C.POINTER(_vp)]),
     "ultra_hip_free": (_i, [_vp, _vp]),
     "ultra_hip_memcpy_h2d": (_i, [_vp, _vp, _vp, _sz]),

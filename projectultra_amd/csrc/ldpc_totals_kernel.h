@@ -199,27 +199,46 @@ __global__ __launch_bounds__(kLdpcThreads, WAVES) void ldpc_totals_kernel(
     auto src_index = [&](int j) -> unsigned { return llr_perm ? (unsigned)llr_perm[j] : (unsigned)(j * llr_step) % (unsigned)kLdpcN; };
     // Source element of each staging slot of this lane: a property of the launch, not of the codeword — computed once
     // (the plan lookup, the table lookup or the modulo would otherwise sit in front of every asynchronous copy).
-    unsigned short src_v[VR], src_p[RR];
+    // kRowStage (round 5; the instances whose VR + RR staging planes hold a whole row anyway — R1/4, R1/3, R1/2, R2/3; for R3/4
+    // and R5/6 the 648-float row would cost a workgroup per CU): the next codeword's channel values are copied AS THEY LIE IN
+    // MEMORY by 11 coalesced wave-wide copies, and the permutation to slots (with the channel deinterleaver's) is the LDS read
+    // that moves a value into its variable's total.  Before, every lane fetched the value of ITS variable: 11 wave-instructions
+    // of 64 scattered 4-byte reads per codeword, each touching most of the row's 21 cache lines; a codeword that converges at
+    // once waited 11,800 cycles for them, 9,100 now (profiles/r05_ldpc_stalls_r14*.txt).
+#ifdef UH_NO_ROW_STAGE                         // variant build for the A/B (tools/ab_ldpc.sh)
+    constexpr bool kRowStage = false;
+#else
+    constexpr bool kRowStage = (VR + RR) * 64 >= kLdpcN;
+#endif
+    unsigned short src_v[VR], src_p[RR];        // kRowStage: byte address of the slot's value in the staged row; else its index in the row
 #pragma unroll
     for (int r = 0; r < VR; ++r) {
         const unsigned j = P.var_id[r * 64 + lane];
-        src_v[r] = (j != 0xFFFFu) ? (unsigned short)src_index((int)j) : (unsigned short)0xFFFFu;
+        if constexpr (kRowStage) src_v[r] = (unsigned short)(STAGE_V + 4u * ((j != 0xFFFFu) ? src_index((int)j) : 0u));
+        else src_v[r] = (j != 0xFFFFu) ? (unsigned short)src_index((int)j) : (unsigned short)0xFFFFu;
     }
 #pragma unroll
     for (int r = 0; r < RR; ++r) {
         const unsigned i = P.row_check[r * 64 + lane];
-        src_p[r] = (i != 0xFFFFu) ? (unsigned short)src_index(k + (int)i) : (unsigned short)0xFFFFu;
+        if constexpr (kRowStage) src_p[r] = (unsigned short)(STAGE_V + 4u * ((i != 0xFFFFu) ? src_index(k + (int)i) : 0u));
+        else src_p[r] = (i != 0xFFFFu) ? (unsigned short)src_index(k + (int)i) : (unsigned short)0xFFFFu;
     }
     auto fetch = [&](int c) {
         const float* src = llr + llr_row(c) * llr_stride;
         float* stage_v = reinterpret_cast<float*>(lds_raw + STAGE_V);
-        float* stage_p = reinterpret_cast<float*>(lds_raw + STAGE_P);
+        if constexpr (kRowStage) {
 #pragma unroll
-        for (int r = 0; r < VR; ++r)
-            if (src_v[r] != 0xFFFFu) __builtin_amdgcn_global_load_lds(src + src_v[r], stage_v + r * 64, 4, 0, 0);
+            for (int i = 0; i < (kLdpcN + 63) / 64; ++i)
+                if (i * 64 + lane < kLdpcN) __builtin_amdgcn_global_load_lds(src + lane + i * 64, stage_v + i * 64, 4, 0, 0);
+        } else {
+            float* stage_p = reinterpret_cast<float*>(lds_raw + STAGE_P);
 #pragma unroll
-        for (int r = 0; r < RR; ++r)
-            if (src_p[r] != 0xFFFFu) __builtin_amdgcn_global_load_lds(src + src_p[r], stage_p + r * 64, 4, 0, 0);
+            for (int r = 0; r < VR; ++r)
+                if (src_v[r] != 0xFFFFu) __builtin_amdgcn_global_load_lds(src + src_v[r], stage_v + r * 64, 4, 0, 0);
+#pragma unroll
+            for (int r = 0; r < RR; ++r)
+                if (src_p[r] != 0xFFFFu) __builtin_amdgcn_global_load_lds(src + src_p[r], stage_p + r * 64, 4, 0, 0);
+        }
     };
 
     // Lanes without a row / variable in some round run the SAME instruction stream on harmless operands (their gather
@@ -265,12 +284,12 @@ __global__ __launch_bounds__(kLdpcThreads, WAVES) void ldpc_totals_kernel(
         float llr_v[VR], llr_p[RR], c2v[RR][7];
 #pragma unroll
         for (int r = 0; r < VR; ++r) {
-            llr_v[r] = ldsf(STAGE_V + (unsigned)(r * 64 + lane) * 4u);        // an empty slot reads a stale word: never used
+            llr_v[r] = ldsf(kRowStage ? (unsigned)src_v[r] : STAGE_V + (unsigned)(r * 64 + lane) * 4u);   // an empty slot reads a stale word: never used
             store_linear((unsigned)(r * 256), llr_v[r]);                       // total before any iteration = llr_in
         }
 #pragma unroll
         for (int r = 0; r < RR; ++r) {
-            llr_p[r] = ldsf(STAGE_P + (unsigned)(r * 64 + lane) * 4u);
+            llr_p[r] = ldsf(kRowStage ? (unsigned)src_p[r] : STAGE_P + (unsigned)(r * 64 + lane) * 4u);
 #pragma unroll
             for (int t = 0; t < 7; ++t) c2v[r][t] = 0.0f;                      // check_to_var starts at 0 (:175)
         }

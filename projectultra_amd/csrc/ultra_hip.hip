@@ -93,7 +93,7 @@ struct ultra_hip_ctx {
     float* d_ws_trk = nullptr;           // deferred carrier half: one record per (symbol, frame) from track_pilot_kernel to track_all_kernel
     size_t ws_trk_rows = 0;
     bool profiling = false;
-    struct Span { int kind; hipEvent_t e0, e1; };
+    struct Span { int kind; hipEvent_t e0, e1; unsigned long long items; };
     std::vector<Span> spans;
     std::vector<hipEvent_t> spare_events;
 };
@@ -120,13 +120,14 @@ struct LaunchSpan {
     ultra_hip_ctx* ctx;
     hipEvent_t e0 = nullptr, e1 = nullptr;
     int kind;
+    unsigned long long items;                      // work items of the launch (frame-symbols, codewords, streams): ultra_hip_profile_read_items
     static hipEvent_t take(ultra_hip_ctx* c) {
         hipEvent_t e = nullptr;
         if (!c->spare_events.empty()) { e = c->spare_events.back(); c->spare_events.pop_back(); }
         else if (hipEventCreate(&e) != hipSuccess) e = nullptr;
         return e;
     }
-    LaunchSpan(ultra_hip_ctx* c, int k) : ctx(c), kind(k) {
+    LaunchSpan(ultra_hip_ctx* c, int k, unsigned long long n_items = 0) : ctx(c), kind(k), items(n_items) {
         if (!ctx->profiling) return;
         e0 = take(ctx); e1 = take(ctx);
         if (e0) (void)hipEventRecord(e0, ctx->stream);
@@ -134,7 +135,7 @@ struct LaunchSpan {
     ~LaunchSpan() {
         if (!ctx->profiling || !e0 || !e1) return;
         (void)hipEventRecord(e1, ctx->stream);
-        ctx->spans.push_back({kind, e0, e1});
+        ctx->spans.push_back({kind, e0, e1, items});
     }
 };
 
@@ -172,11 +173,12 @@ int ensure_fq_workspace(ultra_hip_ctx* ctx, size_t rows) {
     return ULTRA_HIP_OK;
 }
 int ensure_trk_workspace(ultra_hip_ctx* ctx, size_t rows) {
+    // rows of dev::trk_rec_floats(n_pilot) floats: ONE cache line per (symbol, frame) for layouts with <= 15 pilots, three otherwise
     if (ctx->ws_trk_rows >= rows) return ULTRA_HIP_OK;
     UH_HIP(uh_stream_sync(ctx->stream));
     if (ctx->d_ws_trk) { (void)hipFree(ctx->d_ws_trk); ctx->d_ws_trk = nullptr; }
     ctx->ws_trk_rows = 0;
-    UH_HIP(hipMalloc(&ctx->d_ws_trk, rows * (size_t)dev::kTrkRecFloats * sizeof(float)));
+    UH_HIP(hipMalloc(&ctx->d_ws_trk, rows * (size_t)dev::trk_rec_floats(ctx->h_demod.n_pilot) * sizeof(float)));
     ctx->ws_trk_rows = rows;
     return ULTRA_HIP_OK;
 }
@@ -282,7 +284,7 @@ int launch_demod(ultra_hip_ctx* ctx, const float* d_audio, size_t frame_stride, 
             hipLaunchKernelGGL(kernel, dim3(g), dim3(threads), 0, st, ctx->d_demod, ctx->d_nco, ctx->d_twiddle, d_audio, frame_stride,
                                d_frame_offset, (int)n_frames, sym, fq, tab, n_sym_batch);
         };
-        if (tab && n_sym_batch != 1) std::abort();     // mix_fft2_kernel<.., true> takes one symbol index per launch (ds_of)
+        if (tab && n_sym_batch != 1) return (int)ULTRA_HIP_ERR_UNSUPPORTED;   // mix_fft2_kernel<.., true> takes one symbol index per launch (ds_of)
         if (D.log2_fft == 10) {
             if (tab) go(dev::mix_fft2_kernel<10, true>, 2 * dev::kWave);
             else go(dev::mix_fft2_kernel<10, false>, 2 * dev::kWave);
@@ -290,11 +292,13 @@ int launch_demod(ultra_hip_ctx* ctx, const float* d_audio, size_t frame_stride, 
             if (tab) go(dev::mix_fft2_kernel<9, true>, dev::kWave);
             else go(dev::mix_fft2_kernel<9, false>, dev::kWave);
         }
+        return (int)ULTRA_HIP_OK;
     };
     if (all_symbols_at_once) {
-        LaunchSpan span(ctx, ULTRA_HIP_K_MIX_FFT);
+        LaunchSpan span(ctx, ULTRA_HIP_K_MIX_FFT, n_frames * (unsigned long long)n_sym);
         const unsigned g = mix_grid(n_frames * (size_t)n_sym);
-        launch_mix(g, s_begin, ctx->d_ws_fq, nullptr, n_sym);       // cfo_is_zero: no table, the instance without the rotation
+        const int rc_mix = launch_mix(g, s_begin, ctx->d_ws_fq, nullptr, n_sym);       // cfo_is_zero: no table, the instance without the rotation
+        if (rc_mix != ULTRA_HIP_OK) return rc_mix;
     }
     int mixed_upto = 0;                                  // symbols below this index are transformed already
     for (int s = s_begin; s < s_end; ++s) {
@@ -307,26 +311,30 @@ int launch_demod(ultra_hip_ctx* ctx, const float* d_audio, size_t frame_stride, 
         const bool first_at_zero = s <= 1 && !D.presynced && !cfo_given;
         const unsigned* seg_tab_s = first_at_zero ? nullptr : seg_tab;
         if (!cfo_is_zero && !first_at_zero) {
-            LaunchSpan span(ctx, ULTRA_HIP_K_WALK);
+            LaunchSpan span(ctx, ULTRA_HIP_K_WALK, n_frames);
             hipLaunchKernelGGL(dev::cfo_walk_kernel, dim3((unsigned)((n_frames + 255) / 256)), dim3(256), 0, st, ctx->d_demod,
                                (int)n_frames, ctx->d_ws_state, ctx->d_ws_seg);
         }
         if (!all_symbols_at_once && s >= mixed_upto) {
-            LaunchSpan span(ctx, ULTRA_HIP_K_MIX_FFT);
+            const bool two = deferred && s == 0 && first_at_zero && s + 1 < s_end && n_frames * (size_t)2 < 0x7fffffffull;
+            // the rotating instance (a phase table per frame) is a kernel of its own for the issue model: its own class
+            LaunchSpan span(ctx, seg_tab_s ? ULTRA_HIP_K_MIX_FFT_ROT : ULTRA_HIP_K_MIX_FFT, n_frames * (two ? 2ull : 1ull));
             // Symbols 0 and 1 of a fresh batch on the deferred chain are both at CFO 0 and their bins go to consecutive row
             // blocks: ONE launch over 2 n_frames items transforms both (the tracker of symbol 0 does not feed symbol 1's
             // transform) — one ramp-up and drain less, which is what a rank's share of the strong-scaling batch notices.
-            if (deferred && s == 0 && first_at_zero && s + 1 < s_end && n_frames * (size_t)2 < 0x7fffffffull) {
-                launch_mix(mix_grid(n_frames * 2), s, fq_s, nullptr, 2);
+            int rc_mix;
+            if (two) {
+                rc_mix = launch_mix(mix_grid(n_frames * 2), s, fq_s, nullptr, 2);
                 mixed_upto = 2;
             } else {
-                launch_mix(grid_fft, s, fq_s, seg_tab_s, 1);    // no table: CFO 0 in every frame, the instance without the rotation
+                rc_mix = launch_mix(grid_fft, s, fq_s, seg_tab_s, 1);    // no table: CFO 0 in every frame, the instance without the rotation
             }
+            if (rc_mix != ULTRA_HIP_OK) return rc_mix;
         }
         const bool training = s < D.n_train;
         const bool last = (s == s_end - 1);
         if (training) {
-            LaunchSpan span(ctx, ULTRA_HIP_K_TRACK);
+            LaunchSpan span(ctx, ULTRA_HIP_K_TRACK, n_frames);
             hipLaunchKernelGGL(dev::train_kernel, dim3(grid_trk), dim3(dev::kWave), 0, st, ctx->d_demod, (int)n_frames, s,
                                ctx->d_ws_state, fq_s);
             continue;
@@ -335,7 +343,7 @@ int launch_demod(ultra_hip_ctx* ctx, const float* d_audio, size_t frame_stride, 
         // configuration, validate_config) frames per wavefront in its own kernel, the carrier half + equalise
         // + demap one frame per wavefront.
         if (D.n_pilot != 0) {                          // without pilots the half is three scalar updates: track_kernel takes them
-            LaunchSpan span(ctx, ULTRA_HIP_K_PILOT);
+            LaunchSpan span(ctx, ULTRA_HIP_K_PILOT, n_frames);
             if (D.n_pilot <= 16) {
                 const unsigned g = (unsigned)std::min((n_frames + 3) / 4, (size_t)ctx->cu_count * 256);
                 if (fresh_pilot && s == 0)
@@ -356,7 +364,7 @@ int launch_demod(ultra_hip_ctx* ctx, const float* d_audio, size_t frame_stride, 
         }
         if (deferred) {
             if (!last) continue;
-            LaunchSpan span(ctx, ULTRA_HIP_K_TRACK);
+            LaunchSpan span(ctx, ULTRA_HIP_K_TRACK, n_frames * (unsigned long long)n_sym);
             const unsigned g = (unsigned)std::min(n_frames * (size_t)n_sym, (size_t)ctx->cu_count * 128);
 #define UH_TRACK_ALL(MOD)                                                                                                  \
     hipLaunchKernelGGL(dev::track_all_kernel<MOD>, dim3(g), dim3(dev::kWave), 0, st, ctx->d_demod, (int)n_frames, s_begin, n_sym, \
@@ -380,7 +388,7 @@ int launch_demod(ultra_hip_ctx* ctx, const float* d_audio, size_t frame_stride, 
 #define UH_TRACK(MOD)                                                                                            \
     hipLaunchKernelGGL(dev::track_kernel<MOD>, dim3(grid_trk), dim3(dev::kWave), 0, st, ctx->d_demod, (int)n_frames,  \
                        s - D.n_train, ctx->d_ws_state, fq_s, d_llr, llr_stride, last_launch ? d_state : nullptr, track_batch, synced_loop)
-        LaunchSpan span(ctx, ULTRA_HIP_K_TRACK);
+        LaunchSpan span(ctx, ULTRA_HIP_K_TRACK, n_frames * (unsigned long long)track_batch);
         // differential layouts without pilots on at most 32 carriers (the 512-point presets): two frames per wavefront
         const bool pair_frames = !ctx->old_chain && D.differential && D.n_pilot == 0 && !D.presynced && D.n_carriers <= 32 &&
                                  D.n_train == 0;      // (without pilots every interpolation entry is empty: nothing to interpolate)
@@ -432,7 +440,7 @@ int launch_ldpc(ultra_hip_ctx* ctx, const float* d_llr, size_t llr_stride, size_
 // one instance per code: (row rounds, variable rounds, row profile, variable profile); the plan's profiles select it
 #define UH_TOTALS_LAUNCH(RR, VR, RP, VP, WV)                                                                      \
     do {                                                                                                          \
-        LaunchSpan span(ctx, ULTRA_HIP_K_LDPC);                                                                   \
+        LaunchSpan span(ctx, ULTRA_HIP_K_LDPC, n_cw);                                                             \
         const size_t per_cu = std::max<size_t>(1, std::min<size_t>(4 * (WV), (size_t)(160 * 1024) / tlds));       \
         const unsigned grid = (unsigned)std::min(n_cw, (size_t)ctx->cu_count * per_cu);                           \
         if (d_llr_total)                                                                                          \
@@ -463,7 +471,7 @@ int launch_ldpc(ultra_hip_ctx* ctx, const float* d_llr, size_t llr_stride, size_
     // (bounded by LDS: one codeword's messages + staging per workgroup)
 #define UH_LDPC_LAUNCH(RR, VR, RMAX, RMIN, VMAX, VMIN, RID, LIN, WV)                                                 \
     do {                                                                                                        \
-        LaunchSpan span(ctx, ULTRA_HIP_K_LDPC);                                                                 \
+        LaunchSpan span(ctx, ULTRA_HIP_K_LDPC, n_cw);                                                           \
         const size_t per_cu = std::max<size_t>(1, std::min<size_t>(4 * (WV), (size_t)(160 * 1024) / lds));      \
         const unsigned grid = (unsigned)std::min(n_cw, (size_t)ctx->cu_count * per_cu);                         \
         if (d_llr_total)                                                                                        \
@@ -906,7 +914,7 @@ int launch_acquire(ultra_hip_ctx* ctx, const float* d_audio, size_t stream_strid
                    size_t n_streams, uint32_t* d_found, uint32_t* d_data_start, float* d_cfo_hz, uint32_t* d_sync_offset,
                    uint32_t* d_fed_at_sync, uint32_t origin, uint32_t* d_resume, uint32_t midframe = 0u) {
     const unsigned grid = (unsigned)std::min(n_streams, (size_t)ctx->cu_count * 64);
-    LaunchSpan span(ctx, ULTRA_HIP_K_ACQUIRE);
+    LaunchSpan span(ctx, ULTRA_HIP_K_ACQUIRE, n_streams);
     const float* lts_I = ctx->d_lts;
     const float* lts_Q = ctx->d_lts + ctx->lts_len;
     const float sync_threshold = ctx->cfg.sync_threshold != 0.0f ? ctx->cfg.sync_threshold : 0.80f;   // ModemConfig::sync_threshold (types.hpp:188)
@@ -1330,14 +1338,25 @@ int ultra_hip_profile_enable(ultra_hip_ctx* ctx, int enable) {
 }
 
 int ultra_hip_profile_read(ultra_hip_ctx* ctx, float* ms, uint32_t* launches) {
+    // the nine classes of ABI <= 7: the rotating transform's launches are part of ULTRA_HIP_K_MIX_FFT here
     if (!ctx || !ms || !launches) return ULTRA_HIP_ERR_INVALID_ARG;
+    float m[ULTRA_HIP_K_N2]; uint32_t l[ULTRA_HIP_K_N2]; uint64_t it[ULTRA_HIP_K_N2];
+    const int rc = ultra_hip_profile_read_items(ctx, m, l, it);
+    if (rc != ULTRA_HIP_OK) return rc;
+    for (int k = 0; k < ULTRA_HIP_K_N; ++k) { ms[k] = m[k]; launches[k] = l[k]; }
+    ms[ULTRA_HIP_K_MIX_FFT] += m[ULTRA_HIP_K_MIX_FFT_ROT]; launches[ULTRA_HIP_K_MIX_FFT] += l[ULTRA_HIP_K_MIX_FFT_ROT];
+    return ULTRA_HIP_OK;
+}
+
+int ultra_hip_profile_read_items(ultra_hip_ctx* ctx, float* ms, uint32_t* launches, uint64_t* items) {
+    if (!ctx || !ms || !launches || !items) return ULTRA_HIP_ERR_INVALID_ARG;
     DeviceGuard guard(ctx->device);
-    for (int k = 0; k < ULTRA_HIP_K_N; ++k) { ms[k] = 0.0f; launches[k] = 0; }
+    for (int k = 0; k < ULTRA_HIP_K_N2; ++k) { ms[k] = 0.0f; launches[k] = 0; items[k] = 0; }
     for (const auto& sp : ctx->spans) {
         float t = 0.0f;
         UH_HIP(hipEventSynchronize(sp.e1));
         UH_HIP(hipEventElapsedTime(&t, sp.e0, sp.e1));
-        if (sp.kind >= 0 && sp.kind < ULTRA_HIP_K_N) { ms[sp.kind] += t; launches[sp.kind]++; }
+        if (sp.kind >= 0 && sp.kind < ULTRA_HIP_K_N2) { ms[sp.kind] += t; launches[sp.kind]++; items[sp.kind] += sp.items; }
         ctx->spare_events.push_back(sp.e0);
         ctx->spare_events.push_back(sp.e1);
     }

@@ -545,6 +545,16 @@ class ReceiveContext:
         check(self.lib.ultra_hip_profile_read(self._ctx, ms, cnt), "ultra_hip_profile_read")
         return {k: (float(ms[i]), int(cnt[i])) for i, k in enumerate(self.KERNEL_CLASSES)}
 
+    KERNEL_CLASSES_ITEMS = KERNEL_CLASSES + ("mix_fft_rot_kernel",)
+
+    def profile_read_items(self):
+        """{kernel class: (total ms, launches, work items)} — ultra_hip_profile_read_items: the rotating transform apart from
+        the instance without rotation, and the frame-symbols / codewords / streams the recorded launches covered."""
+        n = len(self.KERNEL_CLASSES_ITEMS)
+        ms, cnt, items = (C.c_float * n)(), (C.c_uint32 * n)(), (C.c_uint64 * n)()
+        check(self.lib.ultra_hip_profile_read_items(self._ctx, ms, cnt, items), "ultra_hip_profile_read_items")
+        return {k: (float(ms[i]), int(cnt[i]), int(items[i])) for i, k in enumerate(self.KERNEL_CLASSES_ITEMS)}
+
     def count_errors(self, result, payload, counters=None):
         """Accumulate the Monte-Carlo counters (device int64[8]) for a decoded batch."""
         torch = _torch()

@@ -116,7 +116,7 @@ class OFDMDemodulator:
         # Absolute sample indices travel to the device as 32-bit words (and ultra_hip_acquire_stream_batch refuses more than
         # 2^30 - 1 samples): a long-lived stream rebases them on the start of its buffer, as HipOfdmCoxWaveform::rebase() does
         # — while SEARCHING, where nothing but the resume words refers to them.
-        if not self._synced and self._fed > (1 << 29):
+        if not self._synced and self._origin > 0 and self._fed > (1 << 29):
             shift = self._origin
             words = self._resume[0].cpu().tolist()
             self._resume.copy_(torch.tensor([[_i32((words[0] & 0xffffffff) - shift), _i32((words[1] & 0xffffffff) - shift), words[2], words[3]]],

@@ -123,6 +123,7 @@ def parse_pmc(path):
         m = re.match(r"== (.+?) launches/pass (\d+)", l)
         if m:
             cur = out.setdefault(m.group(1), {})
+            cur["_launches"] = int(m.group(2))
             continue
         m = re.match(r"\s+(\S+)\s+([\d.]+)$", l)
         if m and cur is not None:
@@ -130,8 +131,118 @@ def parse_pmc(path):
     return out
 
 
+CLASS_OF = (("ldpc_totals_kernel", "ldpc_decode_kernel", "codeword"), ("ldpc_decode_kernel", "ldpc_decode_kernel", "codeword"),
+            ("mix_fft2_kernel", None, "frame-symbol"), ("track_all_kernel", "track_kernel", "frame-symbol"),
+            ("track_diff_pair_kernel", "track_kernel", "frame-symbol"), ("track_pilot_kernel", "track_pilot_kernel", "frame-symbol"),
+            ("track_kernel", "track_kernel", "frame-symbol"), ("train_kernel", "track_kernel", "frame-symbol"),
+            ("cfo_walk_kernel", "cfo_walk_kernel", "frame-symbol"), ("acquire_kernel", "acquire_kernel", "stream"))
+
+
+def class_of(instance):
+    """(kernel class of ultra_hip_profile_read_items, work item) of a kernel instance name as rocprofv3 prints it"""
+    for key, cls, item in CLASS_OF:
+        if key in instance:
+            if cls is None:                                   # the transform: the rotating instance is a class of its own
+                cls = "mix_fft_rot_kernel" if re.search(r"mix_fft2_kernel<\d+, true>", instance) else "mix_fft_kernel"
+            return cls, item
+    return None, None
+
+
+def bench_line(pmc_dir):
+    """the JSON line bench.py printed under the profiler (pass 0 of tools/pmc_sweep.sh): work items per class and launch"""
+    import json
+    for log in sorted(Path(pmc_dir).glob("p*.log")):
+        for l in log.read_text(errors="ignore").splitlines():
+            if l.startswith("{") and '"work_items"' in l:
+                return json.loads(l)
+    return None
+
+
+def write_json(args, costs, fns):
+    """profiles/issue.json: per config and kernel class the issue cycles per work item, with the instances they come from, the
+    hash of the kernel sources they were collected on and the commit — bench.py quotes them only when the hash is the tree's."""
+    import json, time
+    sys.path.insert(0, str(ROOT))
+    from projectultra_amd._lib import source_hash
+    out = {"csrc_sha": source_hash(), "commit": args.commit, "collected": time.strftime("%Y-%m-%dT%H:%M:%SZ", time.gmtime()),
+           "clock_hz": costs["clock_ghz"] * 1e9,
+           "costs": {k: costs[k] for k in ("fast", "slow", "eight", "readlane", "salu")},
+           "method": "rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS per kernel instance (tools/pmc_sweep.sh, mean per launch) x "
+                     "cycles per wave-instruction of the instance's own opcode mix (static ISA of this build — the BP iteration loop for the "
+                     "decoders — weighted with profiles/r02_issue_table.txt, W = 5 wavefronts per SIMD), summed over the instances of a "
+                     "kernel class and divided by the work items their launches covered (the bench line of the same profiled run). "
+                     "valu / salu: cycles of ONE SIMD per item (4 SIMDs per CU share a CU's items); lds: cycles of the CU's LDS pipeline.",
+           "configs": {}}
+    for spec in args.json_from:
+        config, _, d = spec.partition("=")
+        pmc = parse_pmc(Path(d) / "summary.txt")
+        line = bench_line(d)
+        if line is None:
+            print(f"issue_model: no bench line with work_items under {d}", file=sys.stderr); continue
+        items = line["roofline"]["work_items"]
+        classes = {}
+        for inst, p in pmc.items():
+            cls, item = class_of(inst)
+            if cls is None or not p.get("SQ_INSTS_VALU") or cls not in items:
+                continue
+            key = next((k for k in fns if inst.split("<")[0] in k and _inst_match(inst, k)), None)
+            body = fns.get(key, []) if key else []
+            whole = mix(body, costs) if body else None
+            is_ldpc = cls == "ldpc_decode_kernel"
+            part = mix(hot_loop(body), costs) if (is_ldpc and body) else whole
+            v_cost = part["valu_cycles"] / max(1, part["valu"]) if part else costs["slow"]
+            l_cost = part["lds_cycles"] / max(1, part["lds"]) if part and part["lds"] else 3.0
+            launches = p.get("_launches", 0)
+            c = classes.setdefault(cls, {"item": item, "instances": {}, "_v": 0.0, "_s": 0.0, "_l": 0.0, "_launches": 0})
+            c["instances"][inst] = {"launches_per_pass": launches, "insts_valu_per_launch": p.get("SQ_INSTS_VALU", 0), "insts_salu_per_launch": p.get("SQ_INSTS_SALU", 0),
+                                    "insts_lds_per_launch": p.get("SQ_INSTS_LDS", 0), "valu_cost": v_cost, "salu_cost": costs["salu"], "lds_cost": l_cost,
+                                    "dur_ms_under_profiler": p.get("_dur_ns", 0) * 1e-6, "isa_function": key}
+            c["_v"] += p.get("SQ_INSTS_VALU", 0) * launches * v_cost
+            c["_s"] += p.get("SQ_INSTS_SALU", 0) * launches * costs["salu"]
+            c["_l"] += p.get("SQ_INSTS_LDS", 0) * launches * l_cost
+            c["_launches"] += launches
+        for cls, c in classes.items():
+            per_launch = items[cls]["items_per_step"] / items[cls]["launches_per_step"]
+            total = c["_launches"] * per_launch
+            c.update(items_per_launch=per_launch, valu_cycles_per_item=c.pop("_v") / total, salu_cycles_per_item=c.pop("_s") / total,
+                     lds_cycles_per_item=c.pop("_l") / total)
+            c.pop("_launches")
+        out["configs"][config] = {"launch_units": line["config"].get("launch_units"), "classes": classes}
+    Path(args.json).write_text(json.dumps(out, indent=1))
+    done = ", ".join("%s (%d classes)" % (k, len(v["classes"])) for k, v in out["configs"].items())
+    print(f"wrote {args.json}: {done}", file=sys.stderr)
+
+
+def _inst_match(inst, mangled):
+    """does the mangled name belong to the instance rocprofv3 names?  template arguments in order, as ILi<n>E / Lb<0|1>E / ILy<n>E"""
+    m = re.search(r"<(.*)>", inst)
+    if not m:
+        return True
+    pos = 0
+    for a in [x.strip() for x in m.group(1).split(",")]:
+        tok = None
+        if a in ("true", "false"):
+            tok = "Lb1E" if a == "true" else "Lb0E"
+        elif re.fullmatch(r"\d+ull", a):
+            tok = "Ly" + a[:-3] + "E"
+        elif re.fullmatch(r"\d+", a):
+            tok = "Li" + a + "E"
+        elif re.fullmatch(r"\(\w+\)\d+", a):               # (ultra_hip_modulation)6
+            tok = "E" + a.split(")")[1] + "E"
+        if tok is None:
+            continue
+        i = mangled.find(tok, pos)
+        if i < 0:
+            return False
+        pos = i + 1
+    return True
+
+
 def main():
     ap = argparse.ArgumentParser()
+    ap.add_argument("--json", default="", help="write the per-class issue cycles per work item here (profiles/issue.json)")
+    ap.add_argument("--json-from", nargs="*", default=[], help="config=pmc_sweep directory (summary.txt + p0.log), e.g. cfg3=gpurun_out/r05sq/cfg3")
+    ap.add_argument("--commit", default=None)
     ap.add_argument("--pmc", nargs="*", default=[str(ROOT / "profiles" / f) for f in ("r04_sq_counters.txt", "r04_sq_counters_cfg2.txt", "r04_sq_counters_cfg4.txt",
                                                                                      "r04_sq_counters_cfg5.txt", "r04_sq_counters_raw.txt", "r02_sq_counters_chirp.txt")],
                     help="pmc_sweep.sh summaries (kernels of later files do not replace those of earlier ones)")
@@ -147,6 +258,9 @@ def main():
                                        "-fhip-fp32-correctly-rounded-divide-sqrt", "-S", "--cuda-device-only", "-o", "-", str(src)],
                                       stderr=subprocess.DEVNULL, cwd=src.parent).decode()
     fns = functions(asm)
+    if args.json:
+        write_json(args, costs, fns)
+        return 0
     pmc = {}
     for f in args.pmc:
         if Path(f).exists():
