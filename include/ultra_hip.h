@@ -378,8 +378,13 @@ int ultra_hip_acquire_batch(ultra_hip_ctx* ctx, const float* d_audio, size_t str
  *                 what the search can still look at (at least everything from d_resume[4 s] on)
  *   n_samples     samples fed so far, this call's included (absolute, as are all sample indices below)
  *   d_resume      [n_streams][4] u32, in/out: {start of rx_buffer, samples fed, noise floor of the energy gate (float
- *                 bits), reserved} — what Impl carries between process() calls while SEARCHING; zero it for a fresh
- *                 demodulator, keep the noise floor across frames (OFDMDemodulator::reset does not clear it)
+ *                 bits), epoch} — what Impl carries between process() calls while SEARCHING; zero it for a fresh
+ *                 demodulator, keep the noise floor across frames (OFDMDemodulator::reset does not clear it).  The library
+ *                 keeps each stream's Schmidl-Cox metrics in HBM between the calls, keyed by absolute sample index, so that a
+ *                 call evaluates only the windows its new samples completed (the reference re-evaluates its whole buffer on
+ *                 every call: demodulator.cpp:497): a stream whose `samples fed` is 0 or smaller than at the previous call
+ *                 starts with an empty cache, and an owner that restarts its sample indices any other way (a new stream laid
+ *                 over the old indices) says so by CHANGING the epoch word
  *   outputs as in ultra_hip_acquire_batch; on d_found[s] = 1 the stream enters SYNCED at d_data_start[s]. */
 int ultra_hip_acquire_stream_batch(ultra_hip_ctx* ctx, const float* d_audio, size_t stream_stride, uint32_t origin,
                                    uint32_t n_samples, size_t n_streams, uint32_t* d_resume, uint32_t* d_found,

@@ -389,7 +389,7 @@ public:
         // the reset block (:868-905): soft bits, buffer, counters, the tracker (the stream starts at symbol 0) — the preset
         // frequency offset and phase stay, and so does timing_offset_samples
         demod_soft_.clear();
-        rx_.clear(); origin_ = fed_ = d_origin_ = 0;
+        rx_.clear(); origin_ = fed_ = d_origin_ = 0; ++epoch_;         // sample indices start over (ultra_hip.h: the resume record's epoch)
         synced_symbols_ = 0; idle_calls_ = 0; pending_cfo_ = false;
         state_[ULTRA_HIP_STATE_SNR_LINEAR] = 1.0f;
         synced_ = true; live_ps_ = true; carry_ = false;
@@ -480,7 +480,7 @@ private:
     uint32_t clampIndex(int64_t i) const { return uint32_t(std::min<int64_t>(std::max<int64_t>(i, origin_), fed_)); }
     // the search restarts on whatever is still buffered: rx_buffer = [origin_, fed_)
     void restartSearch() {
-        const uint32_t r[4] = {origin_, fed_, noise_floor_bits_, 0u};
+        const uint32_t r[4] = {origin_, fed_, noise_floor_bits_, epoch_};
         detail::check(ultra_hip_memcpy_h2d_async(slot_.ctx(), small(), r, sizeof(r)), "h2d");
     }
     // sample indices are 32-bit and absolute: long before they run out (6 h of audio) the origin moves to rx_buffer's start
@@ -488,7 +488,7 @@ private:
         uint32_t r[4];
         detail::check(ultra_hip_memcpy_d2h(slot_.ctx(), r, small(), sizeof(r)), "d2h");
         const uint32_t shift = origin_;
-        r[0] -= shift; r[1] -= shift;
+        r[0] -= shift; r[1] -= shift; r[3] = ++epoch_;                  // the indices move: the library's metric cache of the stream starts over
         detail::check(ultra_hip_memcpy_h2d(slot_.ctx(), small(), r, sizeof(r)), "h2d");
         fed_ -= shift; origin_ = 0; d_origin_ = 0;
         if (!rx_.empty()) detail::check(ultra_hip_memcpy_h2d(slot_.ctx(), const_cast<float*>(rxDev()), rx_.data(), rx_.size() * sizeof(float)), "h2d");
@@ -556,7 +556,7 @@ private:
     size_t rx_cap_ = 0;
     std::vector<float> rx_;                  // rx_buffer = samples [origin_, fed_)
     uint32_t origin_ = 0, fed_ = 0, d_origin_ = 0;   // the device window holds samples from d_origin_ <= origin_ on
-    uint32_t noise_floor_bits_ = 0, last_sync_offset_ = 0, synced_symbols_ = 0;
+    uint32_t noise_floor_bits_ = 0, last_sync_offset_ = 0, synced_symbols_ = 0, epoch_ = 0;
     int idle_calls_ = 0, manual_timing_offset_ = 0, start_mode_ = ULTRA_STREAM_START_FRESH;
     bool synced_ = false, pending_cfo_ = false, chirp_cfo_estimated_ = false;
     bool carry_ = false;                     // the SYNCED context holds a frame's tracker of THIS object (no reset() since)

@@ -35,6 +35,14 @@ namespace dev {
 constexpr unsigned kAcqMinSearch = 4000u, kAcqMaxBuffer = 240000u, kAcqOverlap = 20000u, kAcqStep = 8u,
                    kAcqPlateauWindow = 300u, kAcqMinPlateau = 15u;
 constexpr int kAcqCache = 256;
+// LIVE streams (ultra_hip_acquire_stream_batch, one process() call per launch): the metric cache of a stream lives in HBM
+// between the launches, direct-mapped by absolute window start / 8 like the LDS cache of the batch kernel but covering
+// 65,536 samples — more than rx_buffer holds between two trims (2 x OVERLAP_SAMPLES), so nothing the search can still reach
+// is ever evicted.  Per stream: [tags kAcqGCache u32][values kAcqGCache f32][header kAcqGHeader u32: samples fed after the
+// last launch].  The reference re-evaluates every candidate of its buffer on every call (the search restarts at offset 0:
+// demodulator.cpp:497); here a call evaluates only the candidates whose window the new chunk completed — in parallel, one
+// wavefront each (acq_prepass_kernel) — and the sequential walk reads everything else back, 64 entries at a time.
+constexpr int kAcqGCache = 8192, kAcqGHeader = 16, kAcqGWords = 2 * kAcqGCache + kAcqGHeader;
 
 template <int LOG2N>
 struct AcqShared {
@@ -416,13 +424,15 @@ __device__ __attribute__((noinline)) void acq_window_metric_call(AcqShared<LOG2N
                                                                  float* R1, float* R2) {
     acq_window_metric<LOG2N>(sh, ltw, win, dc_sum, P_out, R1, R2);
 }
-template <int LOG2N, bool MIDFRAME>
+template <int LOG2N, bool MIDFRAME, bool GC = false>
 __global__ __launch_bounds__(kWave, (LOG2N == 10) ? 3 : 4) void acquire_kernel(
     const DemodConst* __restrict__ Dp, const c32* __restrict__ twiddle, const float* __restrict__ lts_I,
     const float* __restrict__ lts_Q, float energy_ref, float sync_threshold, const float* __restrict__ audio,
     size_t stream_stride, unsigned n_samples, unsigned chunk, int n_streams, unsigned* __restrict__ found_out,
     unsigned* __restrict__ data_start_out, float* __restrict__ cfo_out, unsigned* __restrict__ sync_offset_out,
-    unsigned* __restrict__ fed_out, unsigned origin, unsigned* __restrict__ resume) {
+    unsigned* __restrict__ fed_out, unsigned origin, unsigned* __restrict__ resume, unsigned* __restrict__ gcache = nullptr) {
+    // GC (live streams only): the metric cache of stream s is gcache + s * kAcqGWords in HBM (see kAcqGCache) instead of the
+    // launch's LDS; acq_prepass_kernel has filled it for every candidate of the buffer before this kernel starts.
     // origin / resume (ultra_hip_acquire_stream_batch): the search of a LIVE stream, one process() call per launch.
     // Sample index i of stream s lives at audio[s * stream_stride + i - origin] (the caller keeps only the part the
     // search can still look at), and resume[s] = {base, fed, noise floor, -} is what OFDMDemodulator::Impl carries
@@ -463,8 +473,14 @@ __global__ __launch_bounds__(kWave, (LOG2N == 10) ? 3 : 4) void acquire_kernel(
         float gate_sum = 0.0f;                                // lane g: sum of squares of the gate window at gate_first + 8 g
         unsigned grp_first = 0xffffffffu;                     // window start of lane 0 of the current DC group
         float grp_dc = 0.0f;                                  // lane g: dc sum of the window at grp_first + 8 g
-        for (int c = lane; c < kAcqCache; c += kWave) sh.ctag[c] = 0xffffffffu;
+        if constexpr (!GC) { for (int c = lane; c < kAcqCache; c += kWave) sh.ctag[c] = 0xffffffffu; }
         wave_sync();
+        // GC: 64 consecutive entries of the stream's cache in registers — lane g holds the entry of the window that starts
+        // 8 g samples behind gc_first (one coalesced load per 64 candidates of the walk)
+        unsigned* gtags = GC ? gcache + (size_t)stream * kAcqGWords : nullptr;
+        float* gvals = GC ? reinterpret_cast<float*>(gtags + kAcqGCache) : nullptr;
+        unsigned gc_first = 0xffffffffu, gc_tag = 0xffffffffu;
+        float gc_val = 0.0f;
         if (midframe) fed = base;                             // one call over everything buffered
         while (fed < n_samples && !found) {
             fed += (midframe || n_samples - fed < chunk) ? (n_samples - fed) : chunk;
@@ -503,7 +519,7 @@ __global__ __launch_bounds__(kWave, (LOG2N == 10) ? 3 : 4) void acquire_kernel(
                         const unsigned gabs = base + i, d = gabs - gate_first;
                         if (gabs < gate_first || (d & 7u) != 0u || d >= 8u * kWave) {
                             gate_first = gabs;
-                            if constexpr (kCalls) gate_sum = acq_group_energy_call<LOG2N, MIDFRAME>(sh, all, gabs, gate_count, n_samples);
+                            if constexpr (kCalls) gate_sum = acq_group_energy_call<LOG2N, (int)MIDFRAME + 2 * (int)GC>(sh, all, gabs, gate_count, n_samples);
                             else gate_sum = acq_group_energy<LOG2N>(sh, all, gabs, gate_count, n_samples);
                         }
                         energetic = acq_energy_gate(lane_f(gate_sum, (int)((gabs - gate_first) >> 3)), gate_count, noise_floor);
@@ -528,9 +544,21 @@ __global__ __launch_bounds__(kWave, (LOG2N == 10) ? 3 : 4) void acquire_kernel(
                 bool cached = false;
                 float corr = 0.0f;
                 if (in_range && mode != kCfo) {                          // wave-uniform (broadcast reads made scalar)
-                    const unsigned tag = (unsigned)__builtin_amdgcn_readfirstlane((int)sh.ctag[slot]);
-                    const float val = __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(sh.cval[slot])));
-                    if (tag == wabs) { cached = true; corr = val; }
+                    if constexpr (GC) {
+                        const unsigned d = wabs - gc_first;
+                        if (wabs < gc_first || (d & 7u) != 0u || d >= 8u * kWave) {
+                            gc_first = wabs;
+                            const unsigned e = ((wabs >> 3) + (unsigned)lane) & (unsigned)(kAcqGCache - 1);
+                            gc_tag = gtags[e]; gc_val = gvals[e];
+                        }
+                        const int l = (int)((wabs - gc_first) >> 3);
+                        const unsigned tag = (unsigned)__builtin_amdgcn_readlane((int)gc_tag, l);
+                        if (tag == wabs) { cached = true; corr = lane_f(gc_val, l); }
+                    } else {
+                        const unsigned tag = (unsigned)__builtin_amdgcn_readfirstlane((int)sh.ctag[slot]);
+                        const float val = __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(sh.cval[slot])));
+                        if (tag == wabs) { cached = true; corr = val; }
+                    }
                 }
                 if (in_range && !cached) {
                     float dc_sum = 0.0f;
@@ -538,12 +566,12 @@ __global__ __launch_bounds__(kWave, (LOG2N == 10) ? 3 : 4) void acquire_kernel(
                         const unsigned d = wabs - grp_first;              // candidate (d / 8) of the current group?
                         if (wabs < grp_first || (d & 7u) != 0u || d >= 8u * kWave) {
                             grp_first = wabs;
-                            if constexpr (kCalls) grp_dc = acq_group_dc_call<LOG2N, MIDFRAME>(sh, all, wabs, n_samples);
+                            if constexpr (kCalls) grp_dc = acq_group_dc_call<LOG2N, (int)MIDFRAME + 2 * (int)GC>(sh, all, wabs, n_samples);
                             else grp_dc = acq_group_dc<LOG2N>(sh, all, wabs, n_samples);
                         }
                         dc_sum = lane_f(grp_dc, (int)((wabs - grp_first) >> 3));
                     }
-                    if constexpr (kCalls) acq_window_metric_call<LOG2N, MIDFRAME>(sh, ltw, all + wabs, dc_sum, &Pm, &R1, &R2);
+                    if constexpr (kCalls) acq_window_metric_call<LOG2N, (int)MIDFRAME + 2 * (int)GC>(sh, ltw, all + wabs, dc_sum, &Pm, &R1, &R2);
                     else acq_window_metric<LOG2N>(sh, ltw, all + wabs, dc_sum, &Pm, &R1, &R2);
                 }
                 if (mode == kCfo) {
@@ -560,9 +588,18 @@ __global__ __launch_bounds__(kWave, (LOG2N == 10) ? 3 : 4) void acquire_kernel(
                 if (in_range && !cached) {
                     const float normalization = sqrtf(R1 * R2);
                     corr = (normalization < 1e-10f) ? 0.0f : cabs_(Pm) / normalization;
-                    wave_sync();
-                    if (lane == 0) { sh.ctag[slot] = wabs; sh.cval[slot] = corr; }
-                    wave_sync();
+                    if constexpr (GC) {
+                        // a candidate the prepass did not cover (a buffer longer than the cache's span): into the cache and,
+                        // if it belongs to the group in registers, into its lane
+                        const unsigned e = (wabs >> 3) & (unsigned)(kAcqGCache - 1);
+                        if (lane == 0) { gtags[e] = wabs; gvals[e] = corr; }
+                        const unsigned d = wabs - gc_first;
+                        if (wabs >= gc_first && (d & 7u) == 0u && d < 8u * kWave && lane == (int)(d >> 3)) { gc_tag = wabs; gc_val = corr; }
+                    } else {
+                        wave_sync();
+                        if (lane == 0) { sh.ctag[slot] = wabs; sh.cval[slot] = corr; }
+                        wave_sync();
+                    }
                 }
                 if (mode == kSearch) {
                     if (corr > sync_threshold) {
@@ -603,6 +640,74 @@ __global__ __launch_bounds__(kWave, (LOG2N == 10) ? 3 : 4) void acquire_kernel(
             if (fed_out) fed_out[stream] = fed_at;
         }
     }
+}
+
+// Guard of the live streams' metric caches, one wavefront per stream, in front of every launch of the pair below: a stream
+// that starts afresh (resume fed == 0: a new demodulator, or a recycled context) or whose sample indices went backwards (the
+// host rebased them) must not find the previous occupant's entries — tags are absolute sample indices.
+__global__ __launch_bounds__(kWave) void acq_cache_guard_kernel(const unsigned* __restrict__ resume, unsigned n_samples,
+                                                                int n_streams, unsigned* __restrict__ gcache) {
+    const int lane = threadIdx.x;
+    for (int stream = blockIdx.x; stream < n_streams; stream += gridDim.x) {
+        unsigned* g = gcache + (size_t)stream * kAcqGWords;
+        unsigned* hdr = g + 2 * kAcqGCache;
+        // ... or whose owner says so: word 3 of the resume record is an epoch the owner changes whenever it restarts its sample
+        // indices for any other reason (ultra_hip.h)
+        const unsigned fed = resume[4 * stream + 1], epoch = resume[4 * stream + 3], last = hdr[0], last_epoch = hdr[1];
+        if (fed == 0u || fed < last || last == 0u || epoch != last_epoch)
+            for (int e = lane; e < kAcqGCache; e += kWave) g[e] = 0xffffffffu;
+        wave_sync();
+        if (lane == 0) { hdr[0] = (n_samples > 0u) ? n_samples : 1u; hdr[1] = epoch; }
+    }
+}
+
+// The metric of every candidate of the buffers that the caches do not hold yet — in practice those whose window the call's
+// new samples completed — one wavefront per candidate, in parallel (the walk would evaluate them one after the other):
+// candidate c of stream s = the window that starts at base + 8 c + cp, in range iff it ends inside the samples fed
+// (acquire_kernel: in_range).  Same functions, same operands as the walk's own evaluation — the in-order DC sum
+// (acq_group_dc, lane 0), Impl::toAnalytic, the half-symbol sums — so the cached value IS the value the walk would compute.
+// Candidates the energy gate would have skipped are evaluated too: the price of not walking.
+template <int LOG2N>
+__global__ __launch_bounds__(kWave, (LOG2N == 10) ? 3 : 4) void acq_prepass_kernel(
+    const DemodConst* __restrict__ Dp, const c32* __restrict__ twiddle, const float* __restrict__ audio, size_t stream_stride,
+    unsigned n_samples, unsigned origin, const unsigned* __restrict__ resume, unsigned* __restrict__ gcache, unsigned cand_per_stream) {
+    constexpr int N = 1 << LOG2N;
+    __shared__ AcqShared<LOG2N> sh;
+    const DemodConst& D = *Dp;
+    const int lane = threadIdx.x;
+    const unsigned stream = blockIdx.x / cand_per_stream, c = blockIdx.x % cand_per_stream;
+    const unsigned base = resume[4 * stream];
+    unsigned size = n_samples - base;
+    if (size > kAcqMaxBuffer) return;                                  // the walk trims first (:478-483): it evaluates what it needs itself
+    const unsigned off = 8u * c;
+    if (size < kAcqMinSearch || off + (unsigned)D.cp + (unsigned)N > size) return;
+    const unsigned wabs = base + off + (unsigned)D.cp;
+    unsigned* gtags = gcache + (size_t)stream * kAcqGWords;
+    float* gvals = reinterpret_cast<float*>(gtags + kAcqGCache);
+    const unsigned e = (wabs >> 3) & (unsigned)(kAcqGCache - 1);
+    if (gtags[e] == wabs) return;                                      // evaluated by an earlier call (wave-uniform)
+    AcqLaneTw<LOG2N> ltw;
+    ltw.table = twiddle;
+    {
+        constexpr int P = AcqShared<LOG2N>::P, A = AcqShared<LOG2N>::A;
+        for (int idx = lane; idx < AcqShared<LOG2N>::kTwB; idx += kWave) {
+            const int sA = 31 - __clz(idx / P + 1);
+            const int k = idx - P * ((1 << sA) - 1);
+            sh.twB[idx] = twiddle[k << (LOG2N - 1 - (A + sA))];
+        }
+        if (lane < AcqShared<LOG2N>::kTwA) {
+            const int s0 = 31 - __clz(lane + 1);
+            sh.twA[lane] = twiddle[(lane - ((1 << s0) - 1)) << (LOG2N - 1 - s0)];
+        }
+        wave_sync();
+    }
+    const float* all = audio + (size_t)stream * stream_stride - origin;
+    const float dc_sum = lane_f(acq_group_dc<LOG2N>(sh, all, wabs, n_samples), 0);
+    c32 Pm; float R1, R2;
+    acq_window_metric<LOG2N>(sh, ltw, all + wabs, dc_sum, &Pm, &R1, &R2);
+    const float normalization = sqrtf(R1 * R2);
+    const float corr = (normalization < 1e-10f) ? 0.0f : cabs_(Pm) / normalization;
+    if (lane == 0) { gvals[e] = corr; gtags[e] = wabs; }
 }
 
 }  // namespace dev

@@ -60,6 +60,8 @@ struct ultra_hip_ctx {
     size_t ws_chirp_streams = 0;
     float* d_chirp = nullptr;            // chirp templates: up sin, up cos, down sin, down cos
     ChirpHostTables h_chirp{};
+    unsigned* d_acq_gcache = nullptr;    // live streams (ultra_hip_acquire_stream_batch): metric caches, dev::kAcqGWords words per stream
+    size_t acq_gcache_streams = 0;
     unsigned* d_ws_acq = nullptr;        // receive_batch workspace: found, data_start, entry, offset [n] + cfo [n]
     size_t ws_acq_frames = 0;
     uint32_t lts_len = 0;
@@ -740,6 +742,7 @@ void ultra_hip_destroy(ultra_hip_ctx* ctx) {
     if (ctx->d_twiddle) (void)hipFree(ctx->d_twiddle);
     if (ctx->d_lts) (void)hipFree(ctx->d_lts);
     if (ctx->d_ws_acq) (void)hipFree(ctx->d_ws_acq);
+    if (ctx->d_acq_gcache) (void)hipFree(ctx->d_acq_gcache);
     if (ctx->d_chirp) (void)hipFree(ctx->d_chirp);
     if (ctx->d_ws_chirp) (void)hipFree(ctx->d_ws_chirp);
     if (ctx->d_ws_frame) (void)hipFree(ctx->d_ws_frame);
@@ -912,7 +915,7 @@ int ultra_hip_demod_decode_batch(ultra_hip_ctx* ctx, const float* d_audio, size_
 namespace {
 int launch_acquire(ultra_hip_ctx* ctx, const float* d_audio, size_t stream_stride, uint32_t n_samples, uint32_t chunk,
                    size_t n_streams, uint32_t* d_found, uint32_t* d_data_start, float* d_cfo_hz, uint32_t* d_sync_offset,
-                   uint32_t* d_fed_at_sync, uint32_t origin, uint32_t* d_resume, uint32_t midframe = 0u) {
+                   uint32_t* d_fed_at_sync, uint32_t origin, uint32_t* d_resume, uint32_t midframe = 0u, unsigned* d_gcache = nullptr) {
     const unsigned grid = (unsigned)std::min(n_streams, (size_t)ctx->cu_count * 64);
     LaunchSpan span(ctx, ULTRA_HIP_K_ACQUIRE, n_streams);
     const float* lts_I = ctx->d_lts;
@@ -921,9 +924,14 @@ int launch_acquire(ultra_hip_ctx* ctx, const float* d_audio, size_t stream_strid
     auto launch = [&](auto kernel) {
         hipLaunchKernelGGL(kernel, dim3(grid), dim3(dev::kWave), 0, ctx->stream, ctx->d_demod, ctx->d_twiddle, lts_I, lts_Q,
                            ctx->lts_energy_ref, sync_threshold, d_audio, stream_stride, n_samples, chunk, (int)n_streams, d_found,
-                           d_data_start, d_cfo_hz, d_sync_offset, d_fed_at_sync, origin, d_resume);
+                           d_data_start, d_cfo_hz, d_sync_offset, d_fed_at_sync, origin, d_resume, d_gcache);
     };
-    if (ctx->h_demod.log2_fft == 10) { if (midframe) launch(dev::acquire_kernel<10, true>); else launch(dev::acquire_kernel<10, false>); }
+    if (d_gcache && !midframe) {                             // live streams: the metric cache in HBM (acquire_kernel.h, GC)
+        if (ctx->h_demod.log2_fft == 10) launch(dev::acquire_kernel<10, false, true>);
+        else if (ctx->h_demod.log2_fft == 9) launch(dev::acquire_kernel<9, false, true>);
+        else return ULTRA_HIP_ERR_UNSUPPORTED;
+    }
+    else if (ctx->h_demod.log2_fft == 10) { if (midframe) launch(dev::acquire_kernel<10, true>); else launch(dev::acquire_kernel<10, false>); }
     else if (ctx->h_demod.log2_fft == 9) { if (midframe) launch(dev::acquire_kernel<9, true>); else launch(dev::acquire_kernel<9, false>); }
     else
         return ULTRA_HIP_ERR_UNSUPPORTED;
@@ -954,9 +962,37 @@ int ultra_hip_acquire_stream_batch(ultra_hip_ctx* ctx, const float* d_audio, siz
         stream_stride < (size_t)(n_samples - origin) || n_streams > 0x7fffffffull || n_samples > 0x3fffffffu)
         return ULTRA_HIP_ERR_INVALID_ARG;
     DeviceGuard guard(ctx->device);
-    // one process() call: everything fed since the last launch is one chunk
+    // One process() call: everything fed since the last launch is one chunk.  The streams' metric caches live in HBM between
+    // the calls (acquire_kernel.h, kAcqGCache): a guard launch (fresh streams start with an empty cache), the metrics of the
+    // candidates the caches do not hold yet — one wavefront each, in parallel —, then the sequential walk, which finds them all.
+    const size_t cand = (n_samples - origin) / 8u + 1u;                    // candidates per stream, at most (base >= origin)
+    if (n_streams * cand > 0x3fffffffull)                                   // (a grid that large is not a live adapter's: the plain walk)
+        return launch_acquire(ctx, d_audio, stream_stride, n_samples, 0xffffffffu, n_streams, d_found, d_data_start, d_cfo_hz,
+                              d_sync_offset, nullptr, origin, d_resume);
+    if (ctx->acq_gcache_streams < n_streams) {
+        if (ctx->d_acq_gcache) { UH_HIP(uh_stream_sync(ctx->stream)); (void)hipFree(ctx->d_acq_gcache); ctx->d_acq_gcache = nullptr; }
+        ctx->acq_gcache_streams = 0;
+        UH_HIP(hipMalloc(&ctx->d_acq_gcache, n_streams * (size_t)dev::kAcqGWords * sizeof(unsigned)));
+        UH_HIP(hipMemsetAsync(ctx->d_acq_gcache, 0, n_streams * (size_t)dev::kAcqGWords * sizeof(unsigned), ctx->stream));   // header 0: "never used"
+        ctx->acq_gcache_streams = n_streams;
+    }
+    {
+        LaunchSpan span(ctx, ULTRA_HIP_K_ACQUIRE, n_streams);
+        hipLaunchKernelGGL(dev::acq_cache_guard_kernel, dim3((unsigned)std::min(n_streams, (size_t)4096)), dim3(dev::kWave), 0, ctx->stream,
+                           d_resume, n_samples, (int)n_streams, ctx->d_acq_gcache);
+        const unsigned grid = (unsigned)(n_streams * cand);
+        if (ctx->h_demod.log2_fft == 10)
+            hipLaunchKernelGGL(dev::acq_prepass_kernel<10>, dim3(grid), dim3(dev::kWave), 0, ctx->stream, ctx->d_demod, ctx->d_twiddle, d_audio,
+                               stream_stride, n_samples, origin, d_resume, ctx->d_acq_gcache, (unsigned)cand);
+        else if (ctx->h_demod.log2_fft == 9)
+            hipLaunchKernelGGL(dev::acq_prepass_kernel<9>, dim3(grid), dim3(dev::kWave), 0, ctx->stream, ctx->d_demod, ctx->d_twiddle, d_audio,
+                               stream_stride, n_samples, origin, d_resume, ctx->d_acq_gcache, (unsigned)cand);
+        else
+            return ULTRA_HIP_ERR_UNSUPPORTED;
+        UH_HIP(hipGetLastError());
+    }
     return launch_acquire(ctx, d_audio, stream_stride, n_samples, 0xffffffffu, n_streams, d_found, d_data_start, d_cfo_hz,
-                          d_sync_offset, nullptr, origin, d_resume);
+                          d_sync_offset, nullptr, origin, d_resume, 0u, ctx->d_acq_gcache);
 }
 
 int ultra_hip_resync_stream_batch(ultra_hip_ctx* ctx, const float* d_audio, size_t stream_stride, uint32_t origin,
