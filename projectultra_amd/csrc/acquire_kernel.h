@@ -35,6 +35,22 @@ namespace dev {
 constexpr unsigned kAcqMinSearch = 4000u, kAcqMaxBuffer = 240000u, kAcqOverlap = 20000u, kAcqStep = 8u,
                    kAcqPlateauWindow = 300u, kAcqMinPlateau = 15u;
 constexpr int kAcqCache = 256;
+// Diagnostic build only (-DUH_ACQ_STAMPS, tools/acquire_stalls.py): shader-clock time of one stream's search split over its
+// phases — record of kAcqStampWords 64-bit words per stream: [0] whole search, [1] energy-gate groups, [2] DC groups,
+// [3] window metrics of the search and the plateau scans (analytic-signal transform pair + half-symbol sums), [4] the CFO
+// metric, [5] LTS matched filter, [6] metrics evaluated, [7] gate groups, [8] DC groups, [9] candidates visited (turns of the
+// state machine), [10] process() calls, [11] metric-cache hits.  The product build contains none of it.
+constexpr int kAcqStampWords = 12;
+#ifdef UH_ACQ_STAMPS
+__device__ unsigned long long* g_acq_stamps = nullptr;
+#define UH_AQ_T0() const unsigned long long aq_t_ = __builtin_readcyclecounter()
+#define UH_AQ_ADD(k) aq_acc[k] += __builtin_readcyclecounter() - aq_t_
+#define UH_AQ_CNT(k) ++aq_acc[k]
+#else
+#define UH_AQ_T0() do {} while (0)
+#define UH_AQ_ADD(k) do {} while (0)
+#define UH_AQ_CNT(k) do {} while (0)
+#endif
 // LIVE streams (ultra_hip_acquire_stream_batch, one process() call per launch): the metric cache of a stream lives in HBM
 // between the launches, direct-mapped by absolute window start / 8 like the LDS cache of the batch kernel but covering
 // 65,536 samples — more than rx_buffer holds between two trims (2 x OVERLAP_SAMPLES), so nothing the search can still reach
@@ -469,6 +485,10 @@ __global__ __launch_bounds__(kWave, (LOG2N == 10) ? 3 : 4) void acquire_kernel(
         unsigned base = 0, fed = 0, found = 0, so_out = 0, ds_out = 0, fed_at = 0;
         float cfo = 0.0f, noise_floor = 0.0f;
         if (resume) { base = resume[4 * stream]; fed = resume[4 * stream + 1]; noise_floor = __uint_as_float(resume[4 * stream + 2]); }
+#ifdef UH_ACQ_STAMPS
+        unsigned long long aq_acc[kAcqStampWords] = {};
+        const unsigned long long aq_start = __builtin_readcyclecounter();
+#endif
         unsigned gate_first = 0xffffffffu;                    // window start of lane 0 of the current energy-gate group
         float gate_sum = 0.0f;                                // lane g: sum of squares of the gate window at gate_first + 8 g
         unsigned grp_first = 0xffffffffu;                     // window start of lane 0 of the current DC group
@@ -484,6 +504,7 @@ __global__ __launch_bounds__(kWave, (LOG2N == 10) ? 3 : 4) void acquire_kernel(
         if (midframe) fed = base;                             // one call over everything buffered
         while (fed < n_samples && !found) {
             fed += (midframe || n_samples - fed < chunk) ? (n_samples - fed) : chunk;
+            UH_AQ_CNT(10);
             unsigned size = fed - base;
             if (midframe) {
                 if (size < preamble_total) break;
@@ -519,8 +540,10 @@ __global__ __launch_bounds__(kWave, (LOG2N == 10) ? 3 : 4) void acquire_kernel(
                         const unsigned gabs = base + i, d = gabs - gate_first;
                         if (gabs < gate_first || (d & 7u) != 0u || d >= 8u * kWave) {
                             gate_first = gabs;
+                            UH_AQ_T0();
                             if constexpr (kCalls) gate_sum = acq_group_energy_call<LOG2N, (int)MIDFRAME + 2 * (int)GC>(sh, all, gabs, gate_count, n_samples);
                             else gate_sum = acq_group_energy<LOG2N>(sh, all, gabs, gate_count, n_samples);
+                            UH_AQ_ADD(1); UH_AQ_CNT(7);
                         }
                         energetic = acq_energy_gate(lane_f(gate_sum, (int)((gabs - gate_first) >> 3)), gate_count, noise_floor);
                     }
@@ -535,6 +558,7 @@ __global__ __launch_bounds__(kWave, (LOG2N == 10) ? 3 : 4) void acquire_kernel(
                 } else {
                     off = so;
                 }
+                UH_AQ_CNT(9);
                 // measureSchmidlCoxCorrelation / estimateCoarseCFO: window starts cp after the offset
                 const bool in_range = off + (unsigned)D.cp + (unsigned)N <= size;
                 c32 Pm = mk(0.0f, 0.0f);
@@ -560,19 +584,28 @@ __global__ __launch_bounds__(kWave, (LOG2N == 10) ? 3 : 4) void acquire_kernel(
                         if (tag == wabs) { cached = true; corr = val; }
                     }
                 }
+#ifdef UH_ACQ_STAMPS
+                if (cached) UH_AQ_CNT(11);
+#endif
                 if (in_range && !cached) {
                     float dc_sum = 0.0f;
                     if (mode != kCfo) {
                         const unsigned d = wabs - grp_first;              // candidate (d / 8) of the current group?
                         if (wabs < grp_first || (d & 7u) != 0u || d >= 8u * kWave) {
                             grp_first = wabs;
+                            UH_AQ_T0();
                             if constexpr (kCalls) grp_dc = acq_group_dc_call<LOG2N, (int)MIDFRAME + 2 * (int)GC>(sh, all, wabs, n_samples);
                             else grp_dc = acq_group_dc<LOG2N>(sh, all, wabs, n_samples);
+                            UH_AQ_ADD(2); UH_AQ_CNT(8);
                         }
                         dc_sum = lane_f(grp_dc, (int)((wabs - grp_first) >> 3));
                     }
+                    UH_AQ_T0();
                     if constexpr (kCalls) acq_window_metric_call<LOG2N, (int)MIDFRAME + 2 * (int)GC>(sh, ltw, all + wabs, dc_sum, &Pm, &R1, &R2);
                     else acq_window_metric<LOG2N>(sh, ltw, all + wabs, dc_sum, &Pm, &R1, &R2);
+#ifdef UH_ACQ_STAMPS
+                    if (mode == kCfo) { UH_AQ_ADD(4); } else { UH_AQ_ADD(3); UH_AQ_CNT(6); }
+#endif
                 }
                 if (mode == kCfo) {
                     if (in_range) {
@@ -615,7 +648,9 @@ __global__ __launch_bounds__(kWave, (LOG2N == 10) ? 3 : 4) void acquire_kernel(
             if (found_sync) {
                 // inlined in both instances: its templates then come through scalar loads (kernel arguments), out of
                 // line they are per-lane flat loads the loop waits for at every tap (22.2 against 20.1 ms)
+                UH_AQ_T0();
                 const unsigned refined = acq_refine_lts<LOG2N>(sh, D, lts_I, lts_Q, energy_ref, buf, size, so);
+                UH_AQ_ADD(5);
                 if (refined == 0xffffffffu) {
                     if (midframe) { i = so + kAcqStep; mode = kSearch; goto rescan; }     // "continue" of :621-624
                     if (size > kAcqOverlap * 2u) {
@@ -631,6 +666,12 @@ __global__ __launch_bounds__(kWave, (LOG2N == 10) ? 3 : 4) void acquire_kernel(
                 base += size - kAcqOverlap;
             }
         }
+#ifdef UH_ACQ_STAMPS
+        if (g_acq_stamps != nullptr && lane == 0) {
+            aq_acc[0] = __builtin_readcyclecounter() - aq_start;
+            for (int q = 0; q < kAcqStampWords; ++q) g_acq_stamps[(size_t)stream * kAcqStampWords + q] = aq_acc[q];
+        }
+#endif
         if (lane == 0 && resume && !midframe) { resume[4 * stream] = base; resume[4 * stream + 1] = fed; resume[4 * stream + 2] = __float_as_uint(noise_floor); }
         if (lane == 0) {
             found_out[stream] = found;
@@ -653,7 +694,8 @@ __global__ __launch_bounds__(kWave) void acq_cache_guard_kernel(const unsigned* 
         unsigned* hdr = g + 2 * kAcqGCache;
         // ... or whose owner says so: word 3 of the resume record is an epoch the owner changes whenever it restarts its sample
         // indices for any other reason (ultra_hip.h)
-        const unsigned fed = resume[4 * stream + 1], epoch = resume[4 * stream + 3], last = hdr[0], last_epoch = hdr[1];
+        // (resume == nullptr: the batch entry — every stream is a fresh demodulator)
+        const unsigned fed = resume ? resume[4 * stream + 1] : 0u, epoch = resume ? resume[4 * stream + 3] : 0u, last = hdr[0], last_epoch = hdr[1];
         if (fed == 0u || fed < last || last == 0u || epoch != last_epoch)
             for (int e = lane; e < kAcqGCache; e += kWave) g[e] = 0xffffffffu;
         wave_sync();

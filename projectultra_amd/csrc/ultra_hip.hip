@@ -609,6 +609,15 @@ int ultra_hip_debug_set_stamps(ultra_hip_ctx* ctx, void* d_buf) {
 }
 #endif
 
+#ifdef UH_ACQ_STAMPS
+// diagnostic build only (tools/acquire_stalls.py): where acquire_kernel leaves its phase stamps
+int ultra_hip_debug_set_acq_stamps(ultra_hip_ctx* ctx, void* d_buf) {
+    if (!ctx) return ULTRA_HIP_ERR_INVALID_ARG;
+    DeviceGuard guard(ctx->device);
+    unsigned long long* p = static_cast<unsigned long long*>(d_buf);
+    return hipMemcpyToSymbol(HIP_SYMBOL(ultra_hip::dev::g_acq_stamps), &p, sizeof(p)) == hipSuccess ? ULTRA_HIP_OK : ULTRA_HIP_ERR_HIP;
+}
+#endif
 #ifdef UH_LDPC_STAMPS
 // diagnostic build only (tools/ldpc_stalls.py): where ldpc_totals_kernel leaves its per-codeword phase times
 int ultra_hip_debug_set_ldpc_stamps(ultra_hip_ctx* ctx, void* d_buf) {
@@ -913,6 +922,15 @@ int ultra_hip_demod_decode_batch(ultra_hip_ctx* ctx, const float* d_audio, size_
 }
 
 namespace {
+int ensure_acq_gcache(ultra_hip_ctx* ctx, size_t n_streams) {
+    if (ctx->acq_gcache_streams >= n_streams) return ULTRA_HIP_OK;
+    if (ctx->d_acq_gcache) { UH_HIP(uh_stream_sync(ctx->stream)); (void)hipFree(ctx->d_acq_gcache); ctx->d_acq_gcache = nullptr; }
+    ctx->acq_gcache_streams = 0;
+    UH_HIP(hipMalloc(&ctx->d_acq_gcache, n_streams * (size_t)dev::kAcqGWords * sizeof(unsigned)));
+    UH_HIP(hipMemsetAsync(ctx->d_acq_gcache, 0, n_streams * (size_t)dev::kAcqGWords * sizeof(unsigned), ctx->stream));   // header 0: "never used"
+    ctx->acq_gcache_streams = n_streams;
+    return ULTRA_HIP_OK;
+}
 int launch_acquire(ultra_hip_ctx* ctx, const float* d_audio, size_t stream_stride, uint32_t n_samples, uint32_t chunk,
                    size_t n_streams, uint32_t* d_found, uint32_t* d_data_start, float* d_cfo_hz, uint32_t* d_sync_offset,
                    uint32_t* d_fed_at_sync, uint32_t origin, uint32_t* d_resume, uint32_t midframe = 0u, unsigned* d_gcache = nullptr) {
@@ -969,13 +987,7 @@ int ultra_hip_acquire_stream_batch(ultra_hip_ctx* ctx, const float* d_audio, siz
     if (n_streams * cand > 0x3fffffffull)                                   // (a grid that large is not a live adapter's: the plain walk)
         return launch_acquire(ctx, d_audio, stream_stride, n_samples, 0xffffffffu, n_streams, d_found, d_data_start, d_cfo_hz,
                               d_sync_offset, nullptr, origin, d_resume);
-    if (ctx->acq_gcache_streams < n_streams) {
-        if (ctx->d_acq_gcache) { UH_HIP(uh_stream_sync(ctx->stream)); (void)hipFree(ctx->d_acq_gcache); ctx->d_acq_gcache = nullptr; }
-        ctx->acq_gcache_streams = 0;
-        UH_HIP(hipMalloc(&ctx->d_acq_gcache, n_streams * (size_t)dev::kAcqGWords * sizeof(unsigned)));
-        UH_HIP(hipMemsetAsync(ctx->d_acq_gcache, 0, n_streams * (size_t)dev::kAcqGWords * sizeof(unsigned), ctx->stream));   // header 0: "never used"
-        ctx->acq_gcache_streams = n_streams;
-    }
+    { const int rc_gc = ensure_acq_gcache(ctx, n_streams); if (rc_gc != ULTRA_HIP_OK) return rc_gc; }
     {
         LaunchSpan span(ctx, ULTRA_HIP_K_ACQUIRE, n_streams);
         hipLaunchKernelGGL(dev::acq_cache_guard_kernel, dim3((unsigned)std::min(n_streams, (size_t)4096)), dim3(dev::kWave), 0, ctx->stream,
