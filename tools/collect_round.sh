@@ -20,6 +20,8 @@ c) for c in cfg4 raw; do bash tools/collect_profiles.sh $TAG $c $C > $O/c_$c.log
 d) timeout -k 10 300 python3 tools/mix_fft_stalls.py > $O/mix_fft_stalls_two_wave.txt 2> $O/stalls_two.err
    timeout -k 10 300 python3 tools/mix_fft_stalls.py --norot > $O/mix_fft_stalls_norot.txt 2> $O/stalls_norot.err
    timeout -k 10 300 python3 tools/ldpc_stalls.py > $O/ldpc_stalls.txt 2> $O/ldpc_stalls.err      # needs build/v_ldstamps.so (build_variants.sh ldstamps="-DUH_LDPC_STAMPS")
+   timeout -k 10 300 python3 tools/ldpc_stalls_rate.py --rate 0 --esn0 -11 -3 10 > $O/ldpc_stalls_r14.txt 2>> $O/ldpc_stalls.err
+   (cd oracle/_ref/tools && for cfg in "1024 6 4 8 30" "512 2 2 8 20"; do echo "=== reference build (CPU), $(grep -m1 "model name" /proc/cpuinfo | cut -d: -f2)"; ./live_latency.ref $cfg 2>/dev/null; echo "=== drop-in build (MI355X)"; ./live_latency.hip $cfg 2>/dev/null; done) > $O/live_latency.txt 2>&1
    timeout -k 10 400 python3 bench.py --config raw --raw-channel watterson > $O/bench_raw_watterson.json 2> $O/bench_raw_watterson.err
    # the N > 1 path on the one card (gloo): strong-scaling cfg3 at 2 and 4 ranks next to 1
    for n in 1 2 4; do timeout -k 10 400 python3 bench.py --gpus $n --backend gloo --total-frames 131072 --steps 5 --warmup 2 --no-cpu-baseline 2>/dev/null | python3 -c "

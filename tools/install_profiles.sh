@@ -17,5 +17,9 @@ cat $O/soak_parity.txt $O/soak_sync.txt > $P/${TAG}_soak_parity.txt
 cp $O/ldpc_bench.txt $P/${TAG}_ldpc_bench.txt
 cp $O/batch_size_series.txt $P/${TAG}_batch_size_series.txt
 for c in cfg4 cfg5; do cp $O/sweep_$c.json $P/${TAG}_sweep_$c.json; cp $O/sweep_$c.txt $P/${TAG}_sweep_$c.txt; done
-python3 tools/issue_model.py > $P/${TAG}_issue_model.txt
+python3 tools/issue_model.py --pmc $P/${TAG}_sq_counters.txt $P/${TAG}_sq_counters_cfg2.txt $P/${TAG}_sq_counters_cfg4.txt $P/${TAG}_sq_counters_cfg5.txt $P/${TAG}_sq_counters_raw.txt $P/r02_sq_counters_chirp.txt > $P/${TAG}_issue_model.txt
+# the guarded compute roofline bench.py quotes (hash of the kernel sources inside): per-class issue cycles per work item
+python3 tools/issue_model.py --json $P/issue.json --commit ${2:-unknown} --json-from cfg3=$SQ/cfg3 cfg2=$SQ/cfg2 cfg4=$SQ/cfg4 cfg5=$SQ/cfg5 raw=$SQ/raw
+cp $O/ldpc_stalls_r14.txt $P/${TAG}_ldpc_stalls_r14.txt 2>/dev/null
+cp $O/live_latency.txt $P/${TAG}_live_latency.txt 2>/dev/null
 grep -l csrc_sha $P/${TAG}_traffic_*.json $P/traffic.json | xargs grep -h '"csrc_sha"' | sort | uniq -c
