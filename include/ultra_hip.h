@@ -141,7 +141,7 @@ typedef struct ultra_hip_ctx ultra_hip_ctx;
 
 /* Number of blocking host-on-device waits the library has issued so far in this process (its copies to and from host
  * memory, ultra_hip_synchronize, a workspace growing): what a latency-bound caller — one live stream, one process() call at
- * a time — pays per call beside the kernels.  Diagnostic; oracle/live_latency.cpp reports it per call.  ABI 8. */
+ * a time — pays per call beside the kernels.  Diagnostic (the live-latency harness reports it per call: INTEGRATION.md 0).  ABI 8. */
 unsigned long long ultra_hip_host_sync_count(void);
 
 /* ABI version of the loaded library (== ULTRA_HIP_ABI_VERSION). */

@@ -53,7 +53,7 @@ INFO_BITS = {0: 162, 1: 324, 2: 324, 3: 432, 4: 486, 5: 540}
 
 def make_config(fft=1024, mod="QAM16", rate="R3_4", *, carriers=None, pilot_spacing=None,
                 use_pilots=None, guard=None, entry=0, training=2, n_data_symbols=None,
-                max_iterations=50, cp_mode=1, adaptive_eq=None, decision_directed=True, lms_mu=0.05, rls_lambda=0.99):
+                max_iterations=50, cp_mode=1, adaptive_eq=None, decision_directed=True, lms_mu=0.05, rls_lambda=0.99, sync_threshold=0.80):
     """ModemConfig as the reference harnesses build it (tools/test_nvis_mode.cpp:35-41,
     198-212): 512-FFT = ModemConfig defaults (30 carriers, guard 4, spacing 2);
     1024-FFT = presets::nvis_mode() with pilot_spacing 4; use_pilots = !differential."""
@@ -76,6 +76,7 @@ def make_config(fft=1024, mod="QAM16", rate="R3_4", *, carriers=None, pilot_spac
     # ModemConfig::adaptive_eq_* (include/ultra/types.hpp:170-174): adaptive_eq = None (off), "lms" or "rls"
     c.adaptive_eq_enabled, c.adaptive_eq_use_rls = int(adaptive_eq is not None), int(adaptive_eq == "rls")
     c.decision_directed, c.lms_mu, c.rls_lambda = int(bool(decision_directed)), lms_mu, rls_lambda
+    c.sync_threshold = sync_threshold               # ModemConfig::sync_threshold (types.hpp:188); 0 would mean the same default
     return c
 
 

@@ -115,8 +115,17 @@ struct LdpcPlan {
 //   T pad words  32 at t_pad (one per bank): +FLT_MAX (the phantom operand of a row with fewer than six information edges)
 //   R words      [r_base, r_base + row_rounds * 6 * 256)   word ((round * 6 + t) * 64 + lane) = edge slot t of the row
 //   R pad words  32 at r_pad (one per bank): -0.0f (the neutral addend of a variable with fewer than dmax edges)
-//   staging      stage_v [var_rounds][64], stage_p [row_rounds][64]: channel LLRs of the NEXT codeword, slot-indexed
+//   staging      channel LLRs of the NEXT codeword: slot-indexed planes stage_v [var_rounds][64], stage_p [row_rounds][64], or —
+//                ldpc_row_stage — the 648 values as they lie in memory at stage_v (ldpc_totals_kernel.h, kRowStage)
 constexpr int kTPlanRowRounds = 8, kTPlanVarRounds = 7, kTPlanDmax = 13;
+// Instances that stage the next codeword's row in memory order: those whose slot planes hold 648 values anyway, and R3/4
+// (nine planes, 2,304 B), whose staging grows to the row's 2,592 B and still fits 18 workgroups per CU (8,992 B of
+// 163,840 / 18 = 9,102: tools/ubench/lds_granule.hip — the allocation has no coarser granule than that).  R5/6's six planes
+// would have to grow by 1,056 B and lose a workgroup per CU.
+constexpr bool ldpc_row_stage(int var_rounds, int row_rounds) { return var_rounds + row_rounds >= 9; }
+constexpr int ldpc_stage_bytes(int var_rounds, int row_rounds) {
+    return (ldpc_row_stage(var_rounds, row_rounds) && (var_rounds + row_rounds) * 256 < 648 * 4) ? 648 * 4 : (var_rounds + row_rounds) * 256;
+}
 struct LdpcTPlan {
     int32_t valid, k, m, n, max_iterations, decoded_bytes, row_rounds, var_rounds, dmax;
     int32_t t_pad, r_base, r_pad, stage_v, stage_p, lds_bytes, extra_cycles;

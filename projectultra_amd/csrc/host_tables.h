@@ -449,7 +449,7 @@ inline int build_ldpc_tplan(const LdpcConst& L, uint32_t rate, LdpcTPlan& P) {
     P.n_planes = P.plane_base[RR];
     // pads: 32 words each (one per bank), so that a pad read can sit in a bank the instruction's real reads leave free
     P.t_pad = VR * 256; P.r_base = P.t_pad + 128; P.r_pad = P.r_base + P.n_planes * 256; P.stage_v = P.r_pad + 128;
-    P.stage_p = P.stage_v + VR * 256; P.lds_bytes = P.stage_p + RR * 256;
+    P.stage_p = P.stage_v + VR * 256; P.lds_bytes = P.stage_v + ldpc_stage_bytes(VR, RR);
     for (auto& x : P.row_check) x = 0xFFFF;
     for (auto& x : P.var_id) x = 0xFFFF;
     for (auto& x : P.var_slot_of) x = 0xFFFF;

@@ -199,8 +199,9 @@ __global__ __launch_bounds__(kLdpcThreads, WAVES) void ldpc_totals_kernel(
     auto src_index = [&](int j) -> unsigned { return llr_perm ? (unsigned)llr_perm[j] : (unsigned)(j * llr_step) % (unsigned)kLdpcN; };
     // Source element of each staging slot of this lane: a property of the launch, not of the codeword — computed once
     // (the plan lookup, the table lookup or the modulo would otherwise sit in front of every asynchronous copy).
-    // kRowStage (round 5; the instances whose VR + RR staging planes hold a whole row anyway — R1/4, R1/3, R1/2, R2/3; for R3/4
-    // and R5/6 the 648-float row would cost a workgroup per CU): the next codeword's channel values are copied AS THEY LIE IN
+    // kRowStage (round 5; the instances whose VR + RR staging planes hold a whole row anyway — R1/4, R1/3, R1/2, R2/3 — and
+    // R3/4, whose nine planes grow by 288 bytes to the row's 2,592 and still fit 18 workgroups per CU: ldpc_stage_bytes; for
+    // R5/6 the row would cost a workgroup per CU): the next codeword's channel values are copied AS THEY LIE IN
     // MEMORY by 11 coalesced wave-wide copies, and the permutation to slots (with the channel deinterleaver's) is the LDS read
     // that moves a value into its variable's total.  Before, every lane fetched the value of ITS variable: 11 wave-instructions
     // of 64 scattered 4-byte reads per codeword, each touching most of the row's 21 cache lines; a codeword that converges at
@@ -208,7 +209,7 @@ __global__ __launch_bounds__(kLdpcThreads, WAVES) void ldpc_totals_kernel(
 #ifdef UH_NO_ROW_STAGE                         // variant build for the A/B (tools/ab_ldpc.sh)
     constexpr bool kRowStage = false;
 #else
-    constexpr bool kRowStage = (VR + RR) * 64 >= kLdpcN;
+    constexpr bool kRowStage = ldpc_row_stage(VR, RR);
 #endif
     unsigned short src_v[VR], src_p[RR];        // kRowStage: byte address of the slot's value in the staged row; else its index in the row
 #pragma unroll

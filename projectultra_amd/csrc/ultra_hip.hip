@@ -437,7 +437,8 @@ int launch_ldpc(ultra_hip_ctx* ctx, const float* d_llr, size_t llr_stride, size_
         const size_t tlds = (size_t)T.lds_bytes;
         // the kernel derives its LDS offsets from its template arguments with the builder's formulas
         if (T.t_pad != T.var_rounds * 256 || T.r_base != T.t_pad + 128 || T.r_pad != T.r_base + T.n_planes * 256 ||
-            T.stage_v != T.r_pad + 128 || T.stage_p != T.stage_v + T.var_rounds * 256 || T.lds_bytes != T.stage_p + T.row_rounds * 256)
+            T.stage_v != T.r_pad + 128 || T.stage_p != T.stage_v + T.var_rounds * 256 ||
+            T.lds_bytes != T.stage_v + ldpc_stage_bytes(T.var_rounds, T.row_rounds))
             return ULTRA_HIP_ERR_UNSUPPORTED;
 // one instance per code: (row rounds, variable rounds, row profile, variable profile); the plan's profiles select it
 #define UH_TOTALS_LAUNCH(RR, VR, RP, VP, WV)                                                                      \

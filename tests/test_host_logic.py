@@ -256,3 +256,39 @@ def test_device_build_flags():
     for tool in ("build_variants.sh", "kernel_isa.sh", "kernel_resources.sh", "mix_fft_stalls.py", "ldpc_stalls.py", "issue_model.py"):
         text = (ROOT / "tools" / tool).read_text()
         assert "-fno-slp-vectorize" in text and "-ffp-contract=off" in text.replace('", "', " ").replace('"', ""), tool
+
+
+def test_issue_model_instances_map_to_profile_classes():
+    """tools/issue_model.py: a kernel INSTANCE as rocprofv3 names it -> the class of ultra_hip_profile_read_items and the mangled
+    name of its ISA (the rotating transform is a class of its own; template arguments select the function)."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("issue_model", ROOT / "tools" / "issue_model.py")
+    im = importlib.util.module_from_spec(spec); spec.loader.exec_module(im)
+    assert im.class_of("mix_fft2_kernel<10, true>") == ("mix_fft_rot_kernel", "frame-symbol")
+    assert im.class_of("mix_fft2_kernel<10, false>") == ("mix_fft_kernel", "frame-symbol")
+    assert im.class_of("ldpc_totals_kernel<3, 6, 1638ull, 3355443ull, false, 5>")[0] == "ldpc_decode_kernel"
+    assert im.class_of("track_all_kernel<6>")[0] == "track_kernel" and im.class_of("track_pilot_kernel<16, true>")[0] == "track_pilot_kernel"
+    assert im.class_of("stimulus_kernel<10>") == (None, None)
+    m = "_ZN9ultra_hip3dev18ldpc_totals_kernelILi3ELi6ELy1638ELy3355443ELb0ELi5EEEvPKNS_9LdpcTPlanE"
+    assert im._inst_match("ldpc_totals_kernel<3, 6, 1638ull, 3355443ull, false, 5>", m)
+    assert not im._inst_match("ldpc_totals_kernel<3, 6, 1638ull, 3355443ull, true, 5>", m)
+    assert not im._inst_match("ldpc_totals_kernel<8, 3, 591746662ull, 3277ull, false, 3>", m)
+
+
+def test_bench_quotes_the_issue_model_only_for_the_tree_it_was_collected_on(tmp_path, monkeypatch):
+    """bench.load_issue_model: profiles/issue.json is quoted only when its csrc_sha is the tree's and it holds the config."""
+    import json
+    import bench
+    from projectultra_amd._lib import source_hash
+    prof = tmp_path / "profiles"; prof.mkdir()
+    monkeypatch.setattr(bench, "ROOT", tmp_path)
+    m, why = bench.load_issue_model("cfg3")
+    assert m is None and "absent" in why
+    (prof / "issue.json").write_text(json.dumps({"csrc_sha": "0000", "commit": "x", "configs": {"cfg3": {"classes": {}}}}))
+    m, why = bench.load_issue_model("cfg3")
+    assert m is None and "another kernel" in why
+    (prof / "issue.json").write_text(json.dumps({"csrc_sha": source_hash(), "commit": "x", "configs": {"cfg4": {"classes": {}}}}))
+    m, why = bench.load_issue_model("cfg3")
+    assert m is None and "cfg4" in why
+    m, why = bench.load_issue_model("cfg4")
+    assert m is not None and why is None
