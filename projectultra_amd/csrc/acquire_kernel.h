@@ -53,12 +53,13 @@ __device__ unsigned long long* g_acq_stamps = nullptr;
 #endif
 // LIVE streams (ultra_hip_acquire_stream_batch, one process() call per launch): the metric cache of a stream lives in HBM
 // between the launches, direct-mapped by absolute window start / 8 like the LDS cache of the batch kernel but covering
-// 65,536 samples — more than rx_buffer holds between two trims (2 x OVERLAP_SAMPLES), so nothing the search can still reach
-// is ever evicted.  Per stream: [tags kAcqGCache u32][values kAcqGCache f32][header kAcqGHeader u32: samples fed after the
+// 262,144 samples — more than rx_buffer can ever hold (MAX_BUFFER_SAMPLES = 240,000; between two trims of a chunk-fed stream
+// it holds 2 x OVERLAP_SAMPLES, and RxPipeline hands detectSync up to two seconds = 96,000 at once), so nothing the search can
+// still reach is ever evicted.  Per stream: [tags kAcqGCache u32][values kAcqGCache f32][header kAcqGHeader u32: samples fed after the
 // last launch].  The reference re-evaluates every candidate of its buffer on every call (the search restarts at offset 0:
 // demodulator.cpp:497); here a call evaluates only the candidates whose window the new chunk completed — in parallel, one
 // wavefront each (acq_prepass_kernel) — and the sequential walk reads everything else back, 64 entries at a time.
-constexpr int kAcqGCache = 8192, kAcqGHeader = 16, kAcqGWords = 2 * kAcqGCache + kAcqGHeader;
+constexpr int kAcqGCache = 32768, kAcqGHeader = 16, kAcqGWords = 2 * kAcqGCache + kAcqGHeader;
 
 template <int LOG2N>
 struct AcqShared {
