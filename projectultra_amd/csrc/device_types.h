@@ -144,5 +144,16 @@ struct LdpcTPlan {
     uint16_t var_slot_of[kLdpcN];                         // variable -> slot; 0xFFFF: the variable has no check
 };
 
+// The decoder's screen (ldpc_screen_kernel.h): where in a codeword's row AS IT LIES IN MEMORY (the fused channel deinterleaver
+// applied) the hard bits of each parity equation and of each output bit sit.  Made on the device from the Tanner graph and the
+// context's deinterleaver setting (ldpc_screen_prepare_kernel), re-made when that setting changes.
+constexpr int kScreenEdges = 7;              // edges of a row, the parity bit's included (max_check_degree 6 + identity part)
+constexpr int kScreenZeroBit = 660;          // a position beyond the 648 of a row: its hard bit is always 0 ("no edge")
+constexpr int kScreenOutPos = 656;           // 8 positions for each of up to 82 output bytes
+struct LdpcScreenPos {
+    uint16_t row_pos[kTPlanRowRounds * kScreenEdges * 64];   // [round][edge][lane]: row = round * 64 + lane
+    uint16_t out_pos[kScreenOutPos];                          // information bit j -> position; j >= k: kScreenZeroBit
+};
+
 }  // namespace ultra_hip
 #endif

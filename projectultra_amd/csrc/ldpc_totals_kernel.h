@@ -35,6 +35,7 @@
 #include <hip/hip_runtime.h>
 #include "device_types.h"
 #include "ldpc_kernel.h"
+#include "ldpc_screen_kernel.h"
 
 namespace ultra_hip {
 namespace dev {
@@ -138,7 +139,14 @@ __global__ __launch_bounds__(kLdpcThreads, WAVES) void ldpc_totals_kernel(
     const LdpcTPlan* __restrict__ Pp, const float* __restrict__ llr, size_t llr_stride, int n_cw,
     uint8_t* __restrict__ bytes, int32_t* __restrict__ iters, uint8_t* __restrict__ okv,
     float* __restrict__ llr_total, unsigned int* __restrict__ work_counter, int llr_step,
-    const uint16_t* __restrict__ llr_perm, int block_len, int block_stride) {
+    const uint16_t* __restrict__ llr_perm, int block_len, int block_stride, const unsigned* __restrict__ work_list, unsigned gate) {
+    // work_list (nullable; ldpc_screen_kernel.h): with the screen's gate on, the codewords to decode are work_list[0 .. n_work) —
+    // those whose channel values do not already satisfy every row; the screen has finished the others.  Both words were written
+    // by earlier launches of the stream and no wavefront of this one changes them.
+    int n_work = n_cw;
+    const unsigned* lst = nullptr;
+    if (work_list != nullptr && work_counter[kScreenCtlSample] >= gate) { lst = work_list; n_work = (int)work_counter[kScreenCtlDirty]; }
+    if ((int)blockIdx.x >= n_work) return;         // any one wavefront drains every queue: the others are not needed
     constexpr bool kPacked = RR >= 8;          // R1/4's instance: packed single-precision subtract / multiply / add (row phase below)
     // block_len > 0 (ultra_hip_ldpc_decode_blocks): codeword c is row (c / block_len) * block_stride + c % block_len of the
     // LLR array — several equally long runs of rows inside a larger array (one code rate's share of a mode grid) decoded
@@ -188,7 +196,7 @@ __global__ __launch_bounds__(kLdpcThreads, WAVES) void ldpc_totals_kernel(
             int ticket = 0;
             if (lane == 0) ticket = (int)atomicAdd(work_counter + queue * kLdpcQueueStride, 1u);
             const int c = __builtin_amdgcn_readfirstlane(ticket) * kLdpcQueues + queue;
-            if (c < n_cw) return c;
+            if (c < n_work) return lst ? (int)lst[c] : c;
             if (++dry == kLdpcQueues) return -1;
             queue = (queue + 1) % kLdpcQueues;
         }
@@ -267,7 +275,7 @@ __global__ __launch_bounds__(kLdpcThreads, WAVES) void ldpc_totals_kernel(
     };
     auto take = [&]() -> int {
         const int c = __builtin_amdgcn_readfirstlane(ticket_v) * kLdpcQueues + ticket_queue;
-        if (c < n_cw) return c;
+        if (c < n_work) return lst ? (int)lst[c] : c;
         if (dry >= kLdpcQueues) return -1;
         return claim();             // counts the dry queue again at worst: `dry` only has to reach kLdpcQueues eventually
     };

@@ -21,6 +21,7 @@
 #include "host_tables.h"
 #include "demod_kernel.h"
 #include "ldpc_kernel.h"
+#include "ldpc_screen_kernel.h"
 #include "ldpc_totals_kernel.h"
 #include "acquire_kernel.h"
 #include "stimulus_kernel.h"
@@ -43,6 +44,15 @@ struct ultra_hip_ctx {
     LdpcTPlan* d_tplan = nullptr;
     unsigned int* d_work = nullptr;      // work-queue heads of the LDPC kernel (one per launch slot)
     int work_slot = 0;
+    // the decoder's screen (ldpc_screen_kernel.h).  screen_mode: 1 = on where the sample says it pays (default), 0 = off
+    // (ULTRA_HIP_LDPC_SCREEN=0), 2 = the full pass for every launch of any size (=2: parity tests).  d_screen_var: the rows'
+    // variables (host-made); d_screen_pos: their positions under the current deinterleaver setting (device-made when stale).
+    int screen_mode = 1;
+    uint16_t* d_screen_var = nullptr;
+    LdpcScreenPos* d_screen_pos = nullptr;
+    bool screen_pos_stale = true;
+    unsigned* d_ws_list = nullptr;       // work list of the iterating kernel: the codewords the screen did not finish
+    size_t ws_list_cw = 0;
     c32* d_nco = nullptr;
     c32* d_twiddle = nullptr;
     float* d_lts = nullptr;              // LTS passband templates I then Q (acquisition)
@@ -101,6 +111,10 @@ struct ultra_hip_ctx {
 };
 
 namespace {
+
+// launches smaller than this are decoded without the screen: the iterating kernel's own resident set (a few thousand
+// wavefronts) covers them in one round, and three more launches would only add their boundaries
+constexpr size_t kScreenMinCodewords = 8192;
 
 // every blocking wait of the host on the device that the library itself issues (ultra_hip_host_sync_count): what a
 // latency-bound caller — one stream, one process() call at a time — pays per call beside the kernels
@@ -182,6 +196,14 @@ int ensure_trk_workspace(ultra_hip_ctx* ctx, size_t rows) {
     ctx->ws_trk_rows = 0;
     UH_HIP(hipMalloc(&ctx->d_ws_trk, rows * (size_t)dev::trk_rec_floats(ctx->h_demod.n_pilot) * sizeof(float)));
     ctx->ws_trk_rows = rows;
+    return ULTRA_HIP_OK;
+}
+int ensure_list_workspace(ultra_hip_ctx* ctx, size_t n_cw) {
+    if (ctx->ws_list_cw >= n_cw) return ULTRA_HIP_OK;
+    if (ctx->d_ws_list) { UH_HIP(uh_stream_sync(ctx->stream)); (void)hipFree(ctx->d_ws_list); ctx->d_ws_list = nullptr; }
+    ctx->ws_list_cw = 0;
+    UH_HIP(hipMalloc(&ctx->d_ws_list, n_cw * sizeof(unsigned)));
+    ctx->ws_list_cw = n_cw;
     return ULTRA_HIP_OK;
 }
 int ensure_llr_workspace(ultra_hip_ctx* ctx, size_t n_frames) {
@@ -443,29 +465,75 @@ int launch_ldpc(ultra_hip_ctx* ctx, const float* d_llr, size_t llr_stride, size_
 // one instance per code: (row rounds, variable rounds, row profile, variable profile); the plan's profiles select it
 #define UH_TOTALS_LAUNCH(RR, VR, RP, VP, WV)                                                                      \
     do {                                                                                                          \
-        LaunchSpan span(ctx, ULTRA_HIP_K_LDPC, n_cw);                                                             \
         const size_t per_cu = std::max<size_t>(1, std::min<size_t>(4 * (WV), (size_t)(160 * 1024) / tlds));       \
         const unsigned grid = (unsigned)std::min(n_cw, (size_t)ctx->cu_count * per_cu);                           \
         if (d_llr_total)                                                                                          \
             hipLaunchKernelGGL((dev::ldpc_totals_kernel<RR, VR, RP, VP, true, WV>), dim3(grid), dim3(dev::kLdpcThreads), tlds, \
                                ctx->stream, ctx->d_tplan, d_llr, llr_stride, (int)n_cw, d_bytes, d_iters, d_ok,   \
-                               d_llr_total, counter, (int)ctx->deint_step, ctx->d_deint_table, block_len, block_stride); \
+                               d_llr_total, counter, (int)ctx->deint_step, ctx->d_deint_table, block_len, block_stride, \
+                               (const unsigned*)nullptr, 0u);                                                     \
         else                                                                                                      \
             hipLaunchKernelGGL((dev::ldpc_totals_kernel<RR, VR, RP, VP, false, WV>), dim3(grid), dim3(dev::kLdpcThreads), tlds, \
                                ctx->stream, ctx->d_tplan, d_llr, llr_stride, (int)n_cw, d_bytes, d_iters, d_ok,   \
-                               d_llr_total, counter, (int)ctx->deint_step, ctx->d_deint_table, block_len, block_stride); \
+                               d_llr_total, counter, (int)ctx->deint_step, ctx->d_deint_table, block_len, block_stride, \
+                               (const unsigned*)work_list, gate);                                                 \
     } while (0)
         auto is = [&](int rr, int vr, unsigned long long rp, unsigned long long vp) {
             return T.row_rounds == rr && T.var_rounds == vr && T.row_prof == rp && T.var_prof == vp;
         };
-        bool launched = true;
-        if (is(3, 6, 0x666ull, 0x333333ull)) UH_TOTALS_LAUNCH(3, 6, 0x666ull, 0x333333ull, 5);                      // R3/4
-        else if (is(2, 4, 0x66ull, 0x3333ull)) UH_TOTALS_LAUNCH(2, 4, 0x66ull, 0x3333ull, 6);                       // R5/6
-        else if (is(4, 7, 0x6666ull, 0x3333333ull)) UH_TOTALS_LAUNCH(4, 7, 0x6666ull, 0x3333333ull, 4);             // R2/3
-        else if (is(8, 3, kPlaceRowProf_R1_4, kPlaceVarProf_R1_4)) UH_TOTALS_LAUNCH(8, 3, kPlaceRowProf_R1_4, kPlaceVarProf_R1_4, 3);   // R1/4
-        else if (is(6, 6, kPlaceRowProf_R1_3, kPlaceVarProf_R1_3)) UH_TOTALS_LAUNCH(6, 6, kPlaceRowProf_R1_3, kPlaceVarProf_R1_3, 4);   // R1/3
-        else if (is(6, 6, kPlaceRowProf_R1_2, kPlaceVarProf_R1_2)) UH_TOTALS_LAUNCH(6, 6, kPlaceRowProf_R1_2, kPlaceVarProf_R1_2, 4);   // R1/2
-        else launched = false;
+        const bool r34 = is(3, 6, 0x666ull, 0x333333ull), r56 = is(2, 4, 0x66ull, 0x3333ull), r23 = is(4, 7, 0x6666ull, 0x3333333ull),
+                   r14 = is(8, 3, kPlaceRowProf_R1_4, kPlaceVarProf_R1_4), r13 = is(6, 6, kPlaceRowProf_R1_3, kPlaceVarProf_R1_3),
+                   r12 = is(6, 6, kPlaceRowProf_R1_2, kPlaceVarProf_R1_2);
+        const bool launched = r34 || r56 || r23 || r14 || r13 || r12;
+        if (launched) {
+            LaunchSpan span(ctx, ULTRA_HIP_K_LDPC, n_cw);
+            // The screen (ldpc_screen_kernel.h): codewords whose channel values already satisfy every row are finished at
+            // memory speed and the iterating kernel decodes the list of the others.  Only where a launch is large enough for
+            // three more (mostly empty) launches not to show, an iteration may run at all, and the caller does not want the
+            // a-posteriori values (those of a clean codeword are one iteration's, which the screen does not compute).
+            unsigned* work_list = nullptr;
+            unsigned gate = 0u;
+            const bool screen = ctx->screen_mode != 0 && ctx->d_screen_pos && T.max_iterations > 0 && !d_llr_total &&
+                                (ctx->screen_mode == 2 || n_cw >= kScreenMinCodewords) && n_cw <= 0x7fffffffull;
+            if (screen && ensure_list_workspace(ctx, n_cw) != ULTRA_HIP_OK) (void)hipGetLastError();   // no list: plain decode
+            else if (screen) {
+                if (ctx->screen_pos_stale) {
+                    hipLaunchKernelGGL(dev::ldpc_screen_prepare_kernel, dim3(1), dim3(512), 0, ctx->stream, ctx->d_screen_var, T.m, T.k,
+                                       (int)ctx->deint_step, ctx->d_deint_table, ctx->d_screen_pos);
+                    ctx->screen_pos_stale = false;
+                }
+                const int sample_n = (int)std::min<size_t>(n_cw, (size_t)dev::kScreenSampleMax);
+                const int sample_stride = (int)(n_cw / (size_t)sample_n);
+                gate = ctx->screen_mode == 2 ? 0u : (unsigned)((sample_n + 2) / 3);     // a third of the sample clean: the pass pays
+                work_list = ctx->d_ws_list;
+                const unsigned gs = (unsigned)((sample_n + dev::kScreenWaves - 1) / dev::kScreenWaves);
+                const unsigned gf = (unsigned)((n_cw + dev::kScreenChunk - 1) / dev::kScreenChunk);
+#define UH_SCREEN_LAUNCH(RR)                                                                                                     \
+    do {                                                                                                                         \
+        hipLaunchKernelGGL((dev::ldpc_screen_kernel<RR, true>), dim3(gs), dim3(dev::kScreenThreads), 0, ctx->stream, ctx->d_screen_pos, \
+                           d_llr, llr_stride, (int)n_cw, block_len, block_stride, T.decoded_bytes, d_bytes, d_iters, d_ok, counter,     \
+                           work_list, gate, sample_n, sample_stride);                                                            \
+        hipLaunchKernelGGL((dev::ldpc_screen_kernel<RR, false>), dim3(gf), dim3(dev::kScreenThreads), 0, ctx->stream, ctx->d_screen_pos, \
+                           d_llr, llr_stride, (int)n_cw, block_len, block_stride, T.decoded_bytes, d_bytes, d_iters, d_ok, counter,     \
+                           work_list, gate, sample_n, sample_stride);                                                            \
+    } while (0)
+                switch (T.row_rounds) {
+                    case 2: UH_SCREEN_LAUNCH(2); break;
+                    case 3: UH_SCREEN_LAUNCH(3); break;
+                    case 4: UH_SCREEN_LAUNCH(4); break;
+                    case 6: UH_SCREEN_LAUNCH(6); break;
+                    case 8: UH_SCREEN_LAUNCH(8); break;
+                    default: work_list = nullptr; break;
+                }
+#undef UH_SCREEN_LAUNCH
+            }
+            if (r34) UH_TOTALS_LAUNCH(3, 6, 0x666ull, 0x333333ull, 5);
+            else if (r56) UH_TOTALS_LAUNCH(2, 4, 0x66ull, 0x3333ull, 6);
+            else if (r23) UH_TOTALS_LAUNCH(4, 7, 0x6666ull, 0x3333333ull, 4);
+            else if (r14) UH_TOTALS_LAUNCH(8, 3, kPlaceRowProf_R1_4, kPlaceVarProf_R1_4, 3);
+            else if (r13) UH_TOTALS_LAUNCH(6, 6, kPlaceRowProf_R1_3, kPlaceVarProf_R1_3, 4);
+            else UH_TOTALS_LAUNCH(6, 6, kPlaceRowProf_R1_2, kPlaceVarProf_R1_2, 4);
+        }
 #undef UH_TOTALS_LAUNCH
         if (launched) { UH_HIP(hipGetLastError()); return ULTRA_HIP_OK; }
     }
@@ -705,6 +773,24 @@ int ultra_hip_create(const ultra_hip_config* cfg, int device, void* stream, ultr
     if (hipMalloc(&ctx->d_work, 16 * dev::kLdpcQueueWords * sizeof(unsigned int)) != hipSuccess) return fail(ULTRA_HIP_ERR_OOM);
     if (hipMalloc(&ctx->d_nco, nco.size() * sizeof(c32)) != hipSuccess) return fail(ULTRA_HIP_ERR_OOM);
     if (hipMalloc(&ctx->d_twiddle, tw.size() * sizeof(c32)) != hipSuccess) return fail(ULTRA_HIP_ERR_OOM);
+    {   // the decoder's screen: the rows' variables (<= kScreenEdges each, the parity bit's included); a graph that does not fit
+        // decodes without it
+        const char* e = std::getenv("ULTRA_HIP_LDPC_SCREEN");
+        if (e && (e[0] == '0' || e[0] == '2') && e[1] == 0) ctx->screen_mode = e[0] - '0';
+        std::vector<uint16_t> rv((size_t)kTPlanRowRounds * 64 * kScreenEdges, (uint16_t)0xFFFF);
+        bool fits = ctx->h_ldpc.m <= kTPlanRowRounds * 64;
+        for (int i = 0; fits && i < ctx->h_ldpc.m; ++i) {
+            const int e0 = ctx->h_ldpc.row_ptr[i], e1 = ctx->h_ldpc.row_ptr[i + 1];
+            if (e1 - e0 > kScreenEdges) { fits = false; break; }
+            for (int q = e0; q < e1; ++q) rv[(size_t)i * kScreenEdges + (q - e0)] = ctx->h_ldpc.col[q];
+        }
+        if (fits && ctx->screen_mode != 0) {
+            if (hipMalloc(&ctx->d_screen_var, rv.size() * sizeof(uint16_t)) != hipSuccess) return fail(ULTRA_HIP_ERR_OOM);
+            if (hipMalloc(&ctx->d_screen_pos, sizeof(LdpcScreenPos)) != hipSuccess) return fail(ULTRA_HIP_ERR_OOM);
+            if (hipMemcpy(ctx->d_screen_var, rv.data(), rv.size() * sizeof(uint16_t), hipMemcpyHostToDevice) != hipSuccess)
+                return fail(ULTRA_HIP_ERR_HIP);
+        }
+    }
     if (ctx->h_tplan.valid) {
         // ldpc_totals_kernel.h: dynamic LDS must start at LDS address 0 for the totals kernel; d_work doubles as the probe's word
         unsigned base = 1u;
@@ -746,6 +832,9 @@ void ultra_hip_destroy(ultra_hip_ctx* ctx) {
     if (ctx->d_tplan) (void)hipFree(ctx->d_tplan);
     if (ctx->d_deint_table) (void)hipFree(ctx->d_deint_table);
     if (ctx->d_work) (void)hipFree(ctx->d_work);
+    if (ctx->d_screen_var) (void)hipFree(ctx->d_screen_var);
+    if (ctx->d_screen_pos) (void)hipFree(ctx->d_screen_pos);
+    if (ctx->d_ws_list) (void)hipFree(ctx->d_ws_list);
     for (auto& sp : ctx->spans) { (void)hipEventDestroy(sp.e0); (void)hipEventDestroy(sp.e1); }
     for (auto e : ctx->spare_events) (void)hipEventDestroy(e);
     if (ctx->d_nco) (void)hipFree(ctx->d_nco);
@@ -1356,6 +1445,7 @@ int ultra_hip_set_deinterleave(ultra_hip_ctx* ctx, uint32_t bits_per_symbol) {
     if (!ctx) return ULTRA_HIP_ERR_INVALID_ARG;
     if (bits_per_symbol >= (uint32_t)kLdpcN) return ULTRA_HIP_ERR_INVALID_ARG;
     ctx->deint_step = bits_per_symbol ? channel_interleaver_step(bits_per_symbol, (uint32_t)kLdpcN) : 1u;
+    ctx->screen_pos_stale = true;
     return ULTRA_HIP_OK;
 }
 
@@ -1368,6 +1458,7 @@ int ultra_hip_channel_interleaver_step(uint32_t bits_per_symbol, uint32_t total,
 int ultra_hip_set_deinterleave_table(ultra_hip_ctx* ctx, const uint16_t* h_index, uint32_t n) {
     if (!ctx) return ULTRA_HIP_ERR_INVALID_ARG;
     DeviceGuard guard(ctx->device);
+    ctx->screen_pos_stale = true;
     if (!h_index || n == 0) {                                   // off: back to the step (ultra_hip_set_deinterleave)
         if (ctx->d_deint_table) { UH_HIP(uh_stream_sync(ctx->stream)); (void)hipFree(ctx->d_deint_table); ctx->d_deint_table = nullptr; }
         return ULTRA_HIP_OK;

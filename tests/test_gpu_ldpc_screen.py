@@ -1,0 +1,148 @@
+"""GPU parity of the decoder's SCREEN (projectultra_amd/csrc/ldpc_screen_kernel.h): codewords whose channel hard decisions
+already satisfy every row are finished by a memory-speed pass and the iterating kernel decodes the list of the others.
+
+libultra_hip.so reads ULTRA_HIP_LDPC_SCREEN at ultra_hip_create: unset = on for launches of >= 8,192 codewords whose sample
+says the pass pays, 0 = off, 2 = the full pass for EVERY launch whatever its size or sample.  Whatever the switch, results
+are the reference's bit for bit: every case below is compared with the oracle (pinned against the compiled reference),
+and the gated launches also with the same launch decoded without the screen."""
+import os
+
+import numpy as np
+import pytest
+
+from _util import INFO_BITS, beq, noisy_codewords, nonfinite_cases, valid_special_codewords
+
+pytestmark = pytest.mark.gpu
+RATES = [0, 1, 2, 3, 4, 5]
+# noise levels per rate: the first two leave (nearly) no raw bit error — Q(1 / 0.18) = 1e-8, Q(1 / 0.24) = 2e-5 per bit —, the
+# last two are the waterfall of tests/test_gpu_ldpc.py (some iterations, some failures)
+SIG = {0: [0.18, 0.24, 1.7, 2.2], 1: [0.18, 0.24, 1.0, 1.3], 2: [0.18, 0.24, 1.0, 1.3], 3: [0.18, 0.24, 0.75, 0.9],
+       4: [0.18, 0.24, 0.6, 0.75], 5: [0.18, 0.24, 0.5, 0.6]}
+
+
+@pytest.fixture
+def screen(request):
+    old = os.environ.get("ULTRA_HIP_LDPC_SCREEN")
+    if request.param is None:
+        os.environ.pop("ULTRA_HIP_LDPC_SCREEN", None)
+    else:
+        os.environ["ULTRA_HIP_LDPC_SCREEN"] = request.param     # read by ultra_hip_create
+    yield request.param
+    if old is None:
+        os.environ.pop("ULTRA_HIP_LDPC_SCREEN", None)
+    else:
+        os.environ["ULTRA_HIP_LDPC_SCREEN"] = old
+
+
+def _decoder(rate, max_iter=50):
+    from projectultra_amd import CodeRate, LDPCDecoder
+    d = LDPCDecoder(CodeRate(rate))
+    if max_iter != 50:
+        d.setMaxIterations(max_iter)
+    return d
+
+
+def _same(r, want, what):
+    ob, oi, ook = want[:3]
+    assert np.array_equal(r["iters"], oi), (what, np.flatnonzero(r["iters"] != oi)[:8])
+    assert np.array_equal(r["ok"], ook), what
+    assert np.array_equal(r["bytes"], ob), (what, np.flatnonzero((r["bytes"] != ob).any(axis=1))[:8])
+
+
+@pytest.mark.parametrize("screen", ["2"], indirect=True)
+@pytest.mark.parametrize("rate", RATES)
+def test_forced_screen_every_rate(oracle, screen, rate):
+    """The pass on every launch: clean and dirty codewords mixed (two noise levels that converge at once, two that iterate or
+    fail), valid codewords with wild magnitudes (NaN, -0.0, denormals, infinities on the right side of `x < 0`) and their
+    one-flip neighbours, non-finite values sprinkled over noisy codewords; a ragged count (not a multiple of the 64-codeword
+    chunk) and a single codeword."""
+    llr, _ = noisy_codewords(oracle, rate, 715, SIG[rate], seed=700 + rate)
+    rng = np.random.default_rng(900 + rate)
+    llr = np.concatenate([llr, valid_special_codewords(rng, oracle, rate, n=96), nonfinite_cases(rng, oracle, rate, n=40)])
+    llr = llr[rng.permutation(len(llr))]
+    d = _decoder(rate)
+    want = oracle.ldpc_decode_batch(rate, llr)
+    _same(d.decode_batch(llr), want, "mixed")
+    clean = (want[1] == 0) & (want[2] == 1)
+    assert 100 < clean.sum() < len(llr) - 100, "case mix too narrow"
+    _same(d.decode_batch(llr[:1]), [w[:1] for w in want[:3]], "one codeword")
+    _same(d.decode_batch(llr[clean]), [w[clean] for w in want[:3]], "all clean: empty work list")
+    _same(d.decode_batch(llr[~clean]), [w[~clean] for w in want[:3]], "all dirty")
+    # with the a-posteriori values the screen stays out of the way (a clean codeword's totals are one iteration's)
+    r = d.decode_batch(llr[:128], want_total=True)
+    ob, oi, ook, ototal = oracle.ldpc_decode_batch(rate, llr[:128], want_total=True)
+    _same(r, (ob, oi, ook), "want_total")
+    assert beq(r["llr_total"], ototal)
+
+
+@pytest.mark.parametrize("screen", ["2"], indirect=True)
+@pytest.mark.parametrize("max_iter", [0, 1, 200])
+def test_forced_screen_iteration_limits(oracle, screen, max_iter):
+    """max_iterations 0: the reference runs no iteration and reports failure even for a valid word — no screen; 1 and 200."""
+    for rate in (0, 4):
+        llr, _ = noisy_codewords(oracle, rate, 300, SIG[rate], seed=40 + rate)
+        d = _decoder(rate, max_iter)
+        _same(d.decode_batch(llr), oracle.ldpc_decode_batch(rate, llr, max_iters=max_iter), (rate, max_iter))
+
+
+@pytest.mark.parametrize("screen", ["2"], indirect=True)
+@pytest.mark.parametrize("rate,bps", [(4, 4), (0, 2), (5, 6)])
+def test_forced_screen_with_the_fused_deinterleaver(oracle, screen, rate, bps):
+    """The positions the pass gathers are positions in the row AS IT LIES IN MEMORY: the channel deinterleaver's step, then a
+    general table, then off again — the table of positions is re-made on each change."""
+    from projectultra_amd import ChannelInterleaver, Interleaver
+    clean_llr, _ = noisy_codewords(oracle, rate, 333, SIG[rate], seed=55 + rate)
+    want = oracle.ldpc_decode_batch(rate, clean_llr)
+    d = _decoder(rate)
+    il = ChannelInterleaver(bps)
+    d.setDeinterleave(bps)
+    _same(d.decode_batch(np.stack([il.interleave(r) for r in clean_llr])), want, "step")
+    d.setDeinterleave(0)
+    it = Interleaver(6, 108)                                              # out[j] = in[permutation[j]] (test_fused_deinterleave_table)
+    d.setDeinterleaveTable(it.permutation)
+    _same(d.decode_batch(np.stack([it.interleave(r) for r in clean_llr])), want, "table")
+    d.setDeinterleaveTable(None)
+    _same(d.decode_batch(clean_llr), want, "off again")
+
+
+@pytest.mark.parametrize("screen", ["2"], indirect=True)
+def test_forced_screen_block_runs(oracle, screen):
+    """ultra_hip_ldpc_decode_blocks: runs of rows inside a larger array, dense results."""
+    import torch
+    rate, block_len, stride_rows, n_blocks = 4, 150, 200, 3
+    llr, _ = noisy_codewords(oracle, rate, stride_rows * n_blocks, SIG[rate], seed=77)
+    d = _decoder(rate)
+    r = d.context.ldpc_decode_blocks(torch.from_numpy(llr).cuda(), block_len, stride_rows, n_blocks)
+    d.context.synchronize()
+    rows = np.concatenate([np.arange(b * stride_rows, b * stride_rows + block_len) for b in range(n_blocks)])
+    _same({k: v.cpu().numpy() for k, v in r.items()}, oracle.ldpc_decode_batch(rate, llr[rows]), "blocks")
+
+
+@pytest.mark.parametrize("rate,clean_share", [(0, 0.9), (4, 0.5), (4, 0.1), (5, 1.0)])
+def test_gated_screen_equals_plain_decode(oracle, rate, clean_share):
+    """The default switch on launches large enough for the gate: 16,421 codewords drawn from 512 distinct ones with the given
+    share converging at once — gate on for 0.5 / 0.9 / 1.0, off for 0.1 — against the same launch with ULTRA_HIP_LDPC_SCREEN=0
+    (bitwise) and against the oracle on the distinct codewords."""
+    sig = SIG[rate]
+    hi, _ = noisy_codewords(oracle, rate, 256, sig[:1], seed=11 + rate)
+    lo, _ = noisy_codewords(oracle, rate, 256, sig[2:], seed=12 + rate)
+    base = np.concatenate([hi, lo])
+    want = oracle.ldpc_decode_batch(rate, base)
+    assert ((want[1][:256] == 0) & (want[2][:256] == 1)).all(), "the high-SNR half must converge at once"
+    rng = np.random.default_rng(5)
+    n = 16421
+    pick = np.where(rng.random(n) < clean_share, rng.integers(0, 256, n), rng.integers(256, 512, n))
+    llr = base[pick]
+    old = os.environ.pop("ULTRA_HIP_LDPC_SCREEN", None)
+    try:
+        r = _decoder(rate).decode_batch(llr)
+        os.environ["ULTRA_HIP_LDPC_SCREEN"] = "0"
+        plain = _decoder(rate).decode_batch(llr)
+    finally:
+        if old is None:
+            os.environ.pop("ULTRA_HIP_LDPC_SCREEN", None)
+        else:
+            os.environ["ULTRA_HIP_LDPC_SCREEN"] = old
+    for k in ("bytes", "iters", "ok"):
+        assert np.array_equal(r[k], plain[k]), k
+    _same(r, [w[pick] for w in want[:3]], "oracle")
