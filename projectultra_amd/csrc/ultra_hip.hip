@@ -112,9 +112,10 @@ struct ultra_hip_ctx {
 
 namespace {
 
-// launches smaller than this are decoded without the screen: the iterating kernel's own resident set (a few thousand
-// wavefronts) covers them in one round, and three more launches would only add their boundaries
-constexpr size_t kScreenMinCodewords = 8192;
+// launches smaller than this are decoded without the screen: what the sample and the two launch boundaries cost when the gate
+// stays shut (~13 us measured: profiles/r05_variants/r05_screen_kernel_split.txt) is 0.1 % of the headline step but would be a
+// fifth of a 16,384-codeword launch of codewords that need one or two iterations each
+constexpr size_t kScreenMinCodewords = 32768;
 
 // every blocking wait of the host on the device that the library itself issues (ultra_hip_host_sync_count): what a
 // latency-bound caller — one stream, one process() call at a time — pays per call beside the kernels

@@ -1,7 +1,7 @@
 """GPU parity of the decoder's SCREEN (projectultra_amd/csrc/ldpc_screen_kernel.h): codewords whose channel hard decisions
 already satisfy every row are finished by a memory-speed pass and the iterating kernel decodes the list of the others.
 
-libultra_hip.so reads ULTRA_HIP_LDPC_SCREEN at ultra_hip_create: unset = on for launches of >= 8,192 codewords whose sample
+libultra_hip.so reads ULTRA_HIP_LDPC_SCREEN at ultra_hip_create: unset = on for launches of >= 32,768 codewords whose sample
 says the pass pays, 0 = off, 2 = the full pass for EVERY launch whatever its size or sample.  Whatever the switch, results
 are the reference's bit for bit: every case below is compared with the oracle (pinned against the compiled reference),
 and the gated launches also with the same launch decoded without the screen."""
@@ -120,7 +120,7 @@ def test_forced_screen_block_runs(oracle, screen):
 
 @pytest.mark.parametrize("rate,clean_share", [(0, 0.9), (4, 0.5), (4, 0.1), (5, 1.0)])
 def test_gated_screen_equals_plain_decode(oracle, rate, clean_share):
-    """The default switch on launches large enough for the gate: 16,421 codewords drawn from 512 distinct ones with the given
+    """The default switch on launches large enough for the gate: 40,037 codewords drawn from 512 distinct ones with the given
     share converging at once — gate on for 0.5 / 0.9 / 1.0, off for 0.1 — against the same launch with ULTRA_HIP_LDPC_SCREEN=0
     (bitwise) and against the oracle on the distinct codewords."""
     sig = SIG[rate]
@@ -130,7 +130,7 @@ def test_gated_screen_equals_plain_decode(oracle, rate, clean_share):
     want = oracle.ldpc_decode_batch(rate, base)
     assert ((want[1][:256] == 0) & (want[2][:256] == 1)).all(), "the high-SNR half must converge at once"
     rng = np.random.default_rng(5)
-    n = 16421
+    n = 40037
     pick = np.where(rng.random(n) < clean_share, rng.integers(0, 256, n), rng.integers(256, 512, n))
     llr = base[pick]
     old = os.environ.pop("ULTRA_HIP_LDPC_SCREEN", None)
