@@ -35,6 +35,12 @@
 namespace ultra_hip {
 namespace dev {
 
+__host__ __device__ constexpr int tprof_planes_before(unsigned long long p, int r) {     // edge slots of the rounds before r
+    int s = 0;
+    for (int i = 0; i < r; ++i) s += ldpc_prof(p, i);
+    return s;
+}
+
 constexpr int kScreenWaves = 4, kScreenThreads = 64 * kScreenWaves;
 constexpr int kScreenChunk = 64;             // codewords per workgroup of the full pass (16 per wavefront, the next one's loads in flight)
 constexpr int kScreenSampleMax = 2048;       // codewords of the sample
@@ -57,7 +63,10 @@ __global__ __launch_bounds__(512) void ldpc_screen_prepare_kernel(const uint16_t
         out->out_pos[j] = (uint16_t)((j < k) ? src_index(j) : (unsigned)kScreenZeroBit);
 }
 
-template <int RR, bool SAMPLE>
+// RR row rounds; EPROF: edges per row round, four bits each (ldpc_prof) — the rows sit in the table by degree, highest first
+// (ultra_hip_create), so round r gathers E_r = the degree of its first row: 41 edge slots per lane instead of 56 for R1/4,
+// 30 instead of 42 for R1/3 and R1/2; a shorter row of the round gathers the always-zero bit.
+template <int RR, unsigned long long EPROF, bool SAMPLE>
 __global__ __launch_bounds__(kScreenThreads) void ldpc_screen_kernel(
     const LdpcScreenPos* __restrict__ Sp, const float* __restrict__ llr, size_t llr_stride, int n_cw, int block_len, int block_stride,
     int decoded_bytes, uint8_t* __restrict__ bytes, int32_t* __restrict__ iters, uint8_t* __restrict__ okv,
@@ -72,21 +81,21 @@ __global__ __launch_bounds__(kScreenThreads) void ldpc_screen_kernel(
         return block_len > 0 ? (size_t)(c / block_len) * (size_t)block_stride + (size_t)(c % block_len) : (size_t)c;
     };
 
-    // per-lane gather words of the rows lane, lane + 64, ...: (byte offset of the word inside `bits`) << 5 | bit — 15 bits, two
-    // edges per register (56 edge slots in 28 registers for R1/4: the pass wants wavefronts in flight, not registers)
-    constexpr int NQ = (RR * kScreenEdges + 1) / 2;
+    // per-lane gather words of the rows in slots lane, lane + 64, ...: (byte offset of the word inside `bits`) << 5 | bit — 15
+    // bits, two edges per register (the pass wants wavefronts in flight, not registers)
+    constexpr int NE = tprof_planes_before(EPROF, RR), NQ = (NE + 1) / 2;
     unsigned qq[NQ];
 #pragma unroll
-    for (int e = 0; e < NQ; ++e) {
-        unsigned two = 0u;
+    for (int e = 0; e < NQ; ++e) qq[e] = 0u;
+    ldpc_static_for(std::make_integer_sequence<int, RR>{}, [&](auto round) {
+        constexpr int r = decltype(round)::value;
 #pragma unroll
-        for (int h = 0; h < 2; ++h) {
-            const int idx = 2 * e + h;                                         // = r * kScreenEdges + t
-            const unsigned p = (idx < RR * kScreenEdges) ? (unsigned)Sp->row_pos[idx * 64 + lane] : (unsigned)kScreenZeroBit;
-            two |= ((((unsigned)wave * 128u + (p >> 5) * 4u) << 5) | (p & 31u)) << (16 * h);
+        for (int t = 0; t < ldpc_prof(EPROF, r); ++t) {
+            const int idx = tprof_planes_before(EPROF, r) + t;
+            const unsigned p = (unsigned)Sp->row_pos[(r * kScreenEdges + t) * 64 + lane];
+            qq[idx >> 1] |= ((((unsigned)wave * 128u + (p >> 5) * 4u) << 5) | (p & 31u)) << (16 * (idx & 1));
         }
-        qq[e] = two;
-    }
+    });
     // positions of the eight bits of output byte `lane` (16 bytes of the table per lane)
     uint4 op = make_uint4(0, 0, 0, 0);
     if (!SAMPLE) op = *reinterpret_cast<const uint4*>(Sp->out_pos + 8 * lane);
@@ -117,17 +126,17 @@ __global__ __launch_bounds__(kScreenThreads) void ldpc_screen_kernel(
 #pragma unroll
         for (int e = 0; e < NQ; ++e) asm volatile("" : "+v"(qq[e]));
         unsigned bad = 0u;
-#pragma unroll
-        for (int r = 0; r < RR; ++r) {
+        ldpc_static_for(std::make_integer_sequence<int, RR>{}, [&](auto round) {
+            constexpr int r = decltype(round)::value;
             unsigned acc = 0u;
 #pragma unroll
-            for (int t = 0; t < kScreenEdges; ++t) {
-                const int idx = r * kScreenEdges + t;
+            for (int t = 0; t < ldpc_prof(EPROF, r); ++t) {
+                const int idx = tprof_planes_before(EPROF, r) + t;
                 const unsigned q = (idx & 1) ? (qq[idx >> 1] >> 16) : (qq[idx >> 1] & 0xFFFFu);
                 acc ^= word_at(q >> 5) >> (q & 31u);
             }
             bad |= acc;
-        }
+        });
         return __ballot((bad & 1u) != 0u) != 0ull;
     };
 

@@ -57,12 +57,6 @@ __device__ unsigned long long* g_ldpc_stamps = nullptr;
 #define UH_LD_ACC(k) do {} while (0)
 #endif
 
-__host__ __device__ constexpr int tprof_planes_before(unsigned long long p, int r) {
-    int s = 0;
-    for (int i = 0; i < r; ++i) s += ldpc_prof(p, i);
-    return s;
-}
-
 // S lane-linear stores of c[0..S-1] to the planes at byte offsets BASE, BASE + 256, ...: ONE asm statement (M0 must not change
 // between its write and the stores)
 template <int S, unsigned BASE>

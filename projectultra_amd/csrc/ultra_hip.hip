@@ -49,6 +49,7 @@ struct ultra_hip_ctx {
     // variables (host-made); d_screen_pos: their positions under the current deinterleaver setting (device-made when stale).
     int screen_mode = 1;
     uint16_t* d_screen_var = nullptr;
+    unsigned long long screen_prof = 0;  // edges per row round of the table (rows by degree, highest first), four bits each
     LdpcScreenPos* d_screen_pos = nullptr;
     bool screen_pos_stale = true;
     unsigned* d_ws_list = nullptr;       // work list of the iterating kernel: the codewords the screen did not finish
@@ -509,21 +510,29 @@ int launch_ldpc(ultra_hip_ctx* ctx, const float* d_llr, size_t llr_stride, size_
                 work_list = ctx->d_ws_list;
                 const unsigned gs = (unsigned)((sample_n + dev::kScreenWaves - 1) / dev::kScreenWaves);
                 const unsigned gf = (unsigned)((n_cw + dev::kScreenChunk - 1) / dev::kScreenChunk);
-#define UH_SCREEN_LAUNCH(RR)                                                                                                     \
+#define UH_SCREEN_LAUNCH(RR, EP)                                                                                                 \
     do {                                                                                                                         \
-        hipLaunchKernelGGL((dev::ldpc_screen_kernel<RR, true>), dim3(gs), dim3(dev::kScreenThreads), 0, ctx->stream, ctx->d_screen_pos, \
+        hipLaunchKernelGGL((dev::ldpc_screen_kernel<RR, EP, true>), dim3(gs), dim3(dev::kScreenThreads), 0, ctx->stream, ctx->d_screen_pos, \
                            d_llr, llr_stride, (int)n_cw, block_len, block_stride, T.decoded_bytes, d_bytes, d_iters, d_ok, counter,     \
                            work_list, gate, sample_n, sample_stride);                                                            \
-        hipLaunchKernelGGL((dev::ldpc_screen_kernel<RR, false>), dim3(gf), dim3(dev::kScreenThreads), 0, ctx->stream, ctx->d_screen_pos, \
+        hipLaunchKernelGGL((dev::ldpc_screen_kernel<RR, EP, false>), dim3(gf), dim3(dev::kScreenThreads), 0, ctx->stream, ctx->d_screen_pos, \
                            d_llr, llr_stride, (int)n_cw, block_len, block_stride, T.decoded_bytes, d_bytes, d_iters, d_ok, counter,     \
                            work_list, gate, sample_n, sample_stride);                                                            \
     } while (0)
+                // one instance per (row rounds, sorted degree profile) of the reference's six codes; any other graph of the same
+                // number of rounds gathers seven edge slots in every round
+                const unsigned long long ep = ctx->screen_prof;
                 switch (T.row_rounds) {
-                    case 2: UH_SCREEN_LAUNCH(2); break;
-                    case 3: UH_SCREEN_LAUNCH(3); break;
-                    case 4: UH_SCREEN_LAUNCH(4); break;
-                    case 6: UH_SCREEN_LAUNCH(6); break;
-                    case 8: UH_SCREEN_LAUNCH(8); break;
+                    case 2: UH_SCREEN_LAUNCH(2, 0x77ull); break;
+                    case 3: UH_SCREEN_LAUNCH(3, 0x777ull); break;
+                    case 4: UH_SCREEN_LAUNCH(4, 0x7777ull); break;
+                    case 6: if (ep == 0x244677ull) UH_SCREEN_LAUNCH(6, 0x244677ull);            // R1/3
+                            else if (ep == 0x235677ull) UH_SCREEN_LAUNCH(6, 0x235677ull);       // R1/2
+                            else UH_SCREEN_LAUNCH(6, 0x777777ull);
+                            break;
+                    case 8: if (ep == 0x33456677ull) UH_SCREEN_LAUNCH(8, 0x33456677ull);        // R1/4
+                            else UH_SCREEN_LAUNCH(8, 0x77777777ull);
+                            break;
                     default: work_list = nullptr; break;
                 }
 #undef UH_SCREEN_LAUNCH
@@ -779,11 +788,19 @@ int ultra_hip_create(const ultra_hip_config* cfg, int device, void* stream, ultr
         const char* e = std::getenv("ULTRA_HIP_LDPC_SCREEN");
         if (e && (e[0] == '0' || e[0] == '2') && e[1] == 0) ctx->screen_mode = e[0] - '0';
         std::vector<uint16_t> rv((size_t)kTPlanRowRounds * 64 * kScreenEdges, (uint16_t)0xFFFF);
-        bool fits = ctx->h_ldpc.m <= kTPlanRowRounds * 64;
-        for (int i = 0; fits && i < ctx->h_ldpc.m; ++i) {
-            const int e0 = ctx->h_ldpc.row_ptr[i], e1 = ctx->h_ldpc.row_ptr[i + 1];
-            if (e1 - e0 > kScreenEdges) { fits = false; break; }
-            for (int q = e0; q < e1; ++q) rv[(size_t)i * kScreenEdges + (q - e0)] = ctx->h_ldpc.col[q];
+        const LdpcConst& L = ctx->h_ldpc;
+        bool fits = L.m <= kTPlanRowRounds * 64;
+        // rows by degree, highest first (stable): round r of the pass then gathers as many edges as its FIRST row has
+        std::vector<int> order((size_t)std::max(0, L.m));
+        for (int i = 0; i < L.m; ++i) order[(size_t)i] = i;
+        std::stable_sort(order.begin(), order.end(), [&](int a, int b) {
+            return (L.row_ptr[a + 1] - L.row_ptr[a]) > (L.row_ptr[b + 1] - L.row_ptr[b]);
+        });
+        for (int s = 0; fits && s < L.m; ++s) {
+            const int i = order[(size_t)s], e0 = L.row_ptr[i], e1 = L.row_ptr[i + 1];
+            if (e1 - e0 > kScreenEdges || e1 - e0 < 1) { fits = false; break; }
+            for (int q = e0; q < e1; ++q) rv[(size_t)s * kScreenEdges + (q - e0)] = L.col[q];
+            if (s % 64 == 0) ctx->screen_prof |= (unsigned long long)(e1 - e0) << (4 * (s / 64));
         }
         if (fits && ctx->screen_mode != 0) {
             if (hipMalloc(&ctx->d_screen_var, rv.size() * sizeof(uint16_t)) != hipSuccess) return fail(ULTRA_HIP_ERR_OOM);
