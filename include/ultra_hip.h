@@ -33,7 +33,7 @@
 extern "C" {
 #endif
 
-#define ULTRA_HIP_ABI_VERSION 8
+#define ULTRA_HIP_ABI_VERSION 9
 
 /* ultra::Modulation (include/ultra/types.hpp:27-39) — same numeric values. */
 enum ultra_hip_modulation {
@@ -267,6 +267,16 @@ int ultra_hip_ldpc_decode_blocks(ultra_hip_ctx* ctx, const float* d_llr, size_t 
 int ultra_hip_demod_stream_batch(ultra_hip_ctx* ctx, const float* d_audio, size_t frame_stride, const float* d_cfo_hz,
                                  const float* d_cfo_phase, size_t n_frames, uint32_t first_symbol, uint32_t n_symbols,
                                  float* d_llr, float* d_state);
+/* The same call, which also delivers what OFDMDemodulator::Impl::demodulateSymbol appends to constellation_symbols
+ * (src/ofdm/demodulator.cpp:199-208; read by getConstellationSymbols(), :827-830 — the GUI's scatter plot): the equalized
+ * data carriers of every data symbol of this call (ABI 9).
+ *   d_equalized  [n_frames][data symbols of this call][ULTRA_HIP_MAX_CARRIERS] (re, im) f32 pairs, the first
+ *                ultra_hip_geometry::n_data_carriers of each row written; NULL = ultra_hip_demod_stream_batch.
+ * Such a call runs the carrier half per symbol (the chain ULTRA_HIP_FALLBACK_CHAIN=1 selects): same soft bits, same state. */
+#define ULTRA_HIP_MAX_CARRIERS 64
+int ultra_hip_demod_stream_batch_eq(ultra_hip_ctx* ctx, const float* d_audio, size_t frame_stride, const float* d_cfo_hz,
+                                    const float* d_cfo_phase, size_t n_frames, uint32_t first_symbol, uint32_t n_symbols,
+                                    float* d_llr, float* d_state, float* d_equalized);
 /* How the NEXT first_symbol == 0 call of ultra_hip_demod_stream_batch on this context starts its frames (consumed by that
  * call; ultra_hip_demod_batch and friends always start fresh).  One ultra::OFDMDemodulator object lives through many
  * frames, and not every way into a new frame resets the tracker:

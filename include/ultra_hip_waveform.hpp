@@ -301,6 +301,7 @@ class HipOfdmDemodulator {
 public:
     static constexpr int kMaxSymbolsBeforeTimeout = 250, kMaxIdleCallsBeforeReset = 10;   // demodulator_constants.hpp:37-38
     static constexpr size_t kLdpcBlock = 648;                                             // LDPC_BLOCK_SIZE (:14)
+    static constexpr size_t kMaxConstellationSymbols = 500;                               // MAX_CONSTELLATION_SYMBOLS (:122)
     explicit HipOfdmDemodulator(const ModemConfig& config, int device = 0) : config_(config), device_(device) {
         const ultra_hip_config k = to_c_config(config_, ULTRA_ENTRY_SYNCED, kMaxSymbolsBeforeTimeout + 1, 0);
         detail::check(ultra_hip_geometry_for(&k, &geo_), "ultra_hip_geometry_for");       // host arithmetic: no GPU yet
@@ -409,10 +410,11 @@ public:
         detail::check(ultra_hip_memcpy_h2d_async(slot_.ctx(), d_in, cp, sizeof(cp)), "h2d");
         if (timing_ != 0.0f) detail::check(ultra_hip_demod_stream_start(ps_slot_.ctx(), ULTRA_STREAM_START_TIMING, d_in + 2), "stream_start");
         const uint32_t n_data = n_sym - n_train;
-        float* d_out = outDev(size_t(n_data) * geo_.llrs_per_symbol);
-        detail::check(ultra_hip_demod_stream_batch(ps_slot_.ctx(), rxDev(), size_t(n_sym) * sym, d_in, d_in + 1, 1, 0, n_sym,
-                                                   d_out + ULTRA_HIP_STATE_FLOATS, d_out), "demod_stream");
-        if (n_data > 0) fetch(size_t(n_data) * geo_.llrs_per_symbol);
+        const size_t n_llr_ps = size_t(n_data) * geo_.llrs_per_symbol;
+        float* d_out = outDev(n_llr_ps, n_data);
+        detail::check(ultra_hip_demod_stream_batch_eq(ps_slot_.ctx(), rxDev(), size_t(n_sym) * sym, d_in, d_in + 1, 1, 0, n_sym,
+                                                      d_out + ULTRA_HIP_STATE_FLOATS, d_out, d_out + eqOffset(n_llr_ps)), "demod_stream");
+        if (n_data > 0) fetch(n_llr_ps, n_data);
         consumeTo(origin_ + n_sym * sym);
         synced_symbols_ = n_sym;
         return demod_soft_.size() >= kLdpcBlock;
@@ -446,7 +448,8 @@ public:
             detail::check(ultra_hip_demod_stream_set_cfo_phase(liveCtx(), 0, cfo_hz, initial_phase_rad), "stream_set_cfo");
         else pending_cfo_ = true;                                       // SYNCED before the first symbol: symbol 0 starts from it (a sync found later overwrites it: :535-537)
     }
-    std::vector<std::complex<float>> getConstellationSymbols() const { return {}; }   // GUI ring (:201-208): not produced
+    // the GUI's scatter plot (:827-830): the newest MAX_CONSTELLATION_SYMBOLS equalized data carriers; never cleared, as in the reference
+    std::vector<std::complex<float>> getConstellationSymbols() const { return constellation_; }
     bool isSynced() const { return synced_; }
     bool hasPendingData() const {                                       // :836-844
         return synced_ && (!demod_soft_.empty() || fed_ - origin_ >= symbolSamples());
@@ -475,7 +478,11 @@ private:
     uint32_t* small() { return static_cast<uint32_t*>(slot_.buf(0, 32 * sizeof(uint32_t))); }
     const float* rxDev() { return static_cast<const float*>(slot_.buf(1, rx_cap_ * sizeof(float))); }
     // [tracker state (8 floats) | soft bits of this call]: one download brings both
-    float* outDev(size_t n_llr) { return static_cast<float*>(slot_.buf(2, (ULTRA_HIP_STATE_FLOATS + std::max<size_t>(n_llr, 4096)) * sizeof(float))); }
+    // ... and behind them (8-byte aligned) the equalized data carriers of the call's symbols, ULTRA_HIP_MAX_CARRIERS pairs each
+    static size_t eqOffset(size_t n_llr) { return (ULTRA_HIP_STATE_FLOATS + n_llr + 1) & ~size_t(1); }
+    float* outDev(size_t n_llr, size_t n_sym = 0) {
+        return static_cast<float*>(slot_.buf(2, (eqOffset(std::max<size_t>(n_llr, 4096)) + std::max<size_t>(n_sym, 8) * 2 * ULTRA_HIP_MAX_CARRIERS) * sizeof(float)));
+    }
     ultra_hip_ctx* liveCtx() { return live_ps_ ? ps_slot_.ctx() : slot_.ctx(); }
     uint32_t clampIndex(int64_t i) const { return uint32_t(std::min<int64_t>(std::max<int64_t>(i, origin_), fed_)); }
     // the search restarts on whatever is still buffered: rx_buffer = [origin_, fed_)
@@ -518,7 +525,7 @@ private:
     void demodulate(uint32_t n_new) {
         const uint32_t sym = symbolSamples();
         const size_t n_llr = size_t(n_new) * geo_.llrs_per_symbol;
-        float* d_out = outDev(n_llr);
+        float* d_out = outDev(n_llr, n_new);
         float* d_in = reinterpret_cast<float*>(small() + 16);
         ultra_hip_ctx* ctx = liveCtx();
         if (synced_symbols_ == 0) {                                      // symbol 0 of a Schmidl-Cox frame
@@ -527,19 +534,27 @@ private:
             if (start_mode_ != ULTRA_STREAM_START_FRESH) detail::check(ultra_hip_demod_stream_start(ctx, start_mode_, d_in + 2), "stream_start");
             start_mode_ = ULTRA_STREAM_START_FRESH;
         }
-        detail::check(ultra_hip_demod_stream_batch(ctx, rxDev() + (origin_ - d_origin_), size_t(n_new) * sym, d_in, d_in + 1, 1,
-                                                   synced_symbols_, n_new, d_out + ULTRA_HIP_STATE_FLOATS, d_out), "demod_stream");
-        fetch(n_llr);
+        detail::check(ultra_hip_demod_stream_batch_eq(ctx, rxDev() + (origin_ - d_origin_), size_t(n_new) * sym, d_in, d_in + 1, 1,
+                                                      synced_symbols_, n_new, d_out + ULTRA_HIP_STATE_FLOATS, d_out, d_out + eqOffset(n_llr)),
+                      "demod_stream");
+        fetch(n_llr, n_new);
         consumeTo(origin_ + n_new * sym);
         synced_symbols_ += n_new; pending_cfo_ = false;
         if (!live_ps_) carry_ = true;                                   // the SYNCED context's records now hold this object's tracker
     }
     // [state | soft bits] of the call just issued; the host's copies of what the reference reads back from Impl
-    void fetch(size_t n_llr) {
-        stage_.resize(ULTRA_HIP_STATE_FLOATS + n_llr);
-        detail::check(ultra_hip_memcpy_d2h(slot_.ctx(), stage_.data(), outDev(n_llr), stage_.size() * sizeof(float)), "d2h");
+    void fetch(size_t n_llr, size_t n_sym) {
+        stage_.resize(eqOffset(n_llr) + n_sym * 2 * ULTRA_HIP_MAX_CARRIERS);
+        detail::check(ultra_hip_memcpy_d2h(slot_.ctx(), stage_.data(), outDev(n_llr, n_sym), stage_.size() * sizeof(float)), "d2h");
         std::memcpy(state_, stage_.data(), sizeof(state_));
-        demod_soft_.insert(demod_soft_.end(), stage_.begin() + ULTRA_HIP_STATE_FLOATS, stage_.end());
+        demod_soft_.insert(demod_soft_.end(), stage_.begin() + ULTRA_HIP_STATE_FLOATS, stage_.begin() + ULTRA_HIP_STATE_FLOATS + n_llr);
+        // demodulateSymbol (demodulator.cpp:199-208): every data symbol appends its equalized carriers; the newest 500 stay
+        for (size_t s = 0; s < n_sym; ++s) {
+            const float* row = stage_.data() + eqOffset(n_llr) + s * 2 * ULTRA_HIP_MAX_CARRIERS;
+            for (uint32_t i = 0; i < geo_.n_data_carriers; ++i) constellation_.emplace_back(row[2 * i], row[2 * i + 1]);
+            if (constellation_.size() > kMaxConstellationSymbols)
+                constellation_.erase(constellation_.begin(), constellation_.begin() + (constellation_.size() - kMaxConstellationSymbols));
+        }
         freq_offset_hz_ = state_[ULTRA_HIP_STATE_FREQ_OFFSET_HZ];
         freq_correction_phase_ = state_[ULTRA_HIP_STATE_CFO_PHASE];
         timing_ = state_[ULTRA_HIP_STATE_TIMING_OFFSET];
@@ -563,6 +578,7 @@ private:
     bool live_ps_ = false;                   // the frame in flight lives in the PRESYNCED context
     float coarse_cfo_ = 0.0f, freq_offset_hz_ = 0.0f, freq_correction_phase_ = 0.0f, timing_ = 0.0f;
     std::vector<float> demod_soft_, stage_;
+    std::vector<std::complex<float>> constellation_;
     HipChannelQuality quality_{};
     float state_[ULTRA_HIP_STATE_FLOATS] = {0, 0, 1, 0, 0, 0, 0, 0};
 };

@@ -90,9 +90,14 @@ struct Rx {                                     // logs every answer of the demo
         // Impl::quality is uninitialised memory in the reference until the first symbol has been demodulated (updateQuality)
         demodulated = demodulated || r || d.hasPendingData();
         const ChannelQuality q = d.getChannelQuality();
-        std::printf("%s#%d -> %d synced=%d pending=%d snr=%08x cfo=%08x sync_off=%zu q=%08x,%08x\n", what, call++, (int)r, (int)d.isSynced(),
-                    (int)d.hasPendingData(), bits(d.getEstimatedSNR()), bits(d.getFrequencyOffset()), d.getLastSyncOffset(),
-                    demodulated ? bits(q.snr_db) : 0u, demodulated ? bits(q.ber_estimate) : 0u);
+        // getConstellationSymbols() (demodulator.cpp:827-830): the ring's size and an FNV-1a digest of its bit patterns
+        const Symbol ring = d.getConstellationSymbols();
+        unsigned long long fnv = 1469598103934665603ull;
+        for (const Complex& z : ring)
+            for (float v : {z.real(), z.imag()}) { fnv ^= bits(v); fnv *= 1099511628211ull; }
+        std::printf("%s#%d -> %d synced=%d pending=%d snr=%08x cfo=%08x sync_off=%zu q=%08x,%08x ring=%zu:%016llx\n", what, call++, (int)r,
+                    (int)d.isSynced(), (int)d.hasPendingData(), bits(d.getEstimatedSNR()), bits(d.getFrequencyOffset()), d.getLastSyncOffset(),
+                    demodulated ? bits(q.snr_db) : 0u, demodulated ? bits(q.ber_estimate) : 0u, ring.size(), fnv);
     }
     void drain(bool decode = true) {
         std::vector<float> s = d.getSoftBits();

@@ -17,7 +17,7 @@ PKG_DIR = Path(__file__).resolve().parent
 LIB_PATH = Path(os.environ["ULTRA_HIP_LIB"]).resolve() if os.environ.get("ULTRA_HIP_LIB") else PKG_DIR / "libultra_hip.so"
 CSRC_DIR = PKG_DIR / "csrc"
 
-ULTRA_HIP_ABI_VERSION = 8
+ULTRA_HIP_ABI_VERSION = 9
 STATE_FLOATS = 8
 
 
@@ -70,6 +70,7 @@ PROTOTYPES = {
     "ultra_hip_demod_batch_strided": (_i, [_vp, _vp, _sz, _vp, _vp, _sz, _vp, _sz, _vp]),
     "ultra_hip_ldpc_decode_blocks": (_i, [_vp, _vp, _sz, _sz, _sz, _sz, _vp, _vp, _vp]),
     "ultra_hip_demod_stream_batch": (_i, [_vp, _vp, _sz, _vp, _vp, _sz, C.c_uint32, C.c_uint32, _vp, _vp]),
+    "ultra_hip_demod_stream_batch_eq": (_i, [_vp, _vp, _sz, _vp, _vp, _sz, C.c_uint32, C.c_uint32, _vp, _vp, _vp]),
     "ultra_hip_demod_stream_set_cfo": (_i, [_vp, _sz, C.c_float]),
     "ultra_hip_demod_stream_start": (_i, [_vp, _i, _vp]),
     "ultra_hip_demod_stream_set_cfo_phase": (_i, [_vp, _sz, C.c_float, C.c_float]),

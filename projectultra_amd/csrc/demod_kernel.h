@@ -1169,7 +1169,9 @@ template <int MOD>
 __device__ __forceinline__ void equalize_demap(TrackShared& sh, const DemodConst& D, const LaneConst& lc, Track& tr,
                                                c32& dprev, const c32* __restrict__ fq, float* __restrict__ llr_sym,
                                                float* dprev_abs = nullptr, const c32* tc_fixed = nullptr,
-                                               const c32* received_in = nullptr, AdaptiveEq* ad = nullptr) {
+                                               const c32* received_in = nullptr, AdaptiveEq* ad = nullptr, c32* eq_out = nullptr) {
+    // eq_out (nullable; live streams): the symbol's row of equalized data carriers — what demodulateSymbol appends to
+    // constellation_symbols (demodulator.cpp:199-208), the GUI's scatter plot
     // ad (coherent layouts, nullable): equalise against lms_weights instead of channel_estimate and update them from the
     // hard decisions (use_adaptive branch, :779-805; lmsUpdate / rlsUpdate :705-722)
     // received_in (nullable): this lane's bin, where the caller has requested it ahead of time (track_all_kernel)
@@ -1262,6 +1264,7 @@ __device__ __forceinline__ void equalize_demap(TrackShared& sh, const DemodConst
         }
     }
 
+    if (eq_out && is_data) eq_out[lane] = eq;
     if (kDiff && !tr.has_dprev) { dprev = mk(1.0f, 0.0f); if (dprev_abs) *dprev_abs = -1.0f; }   // (1,0) reference on every path
     float eq_abs = -1.0f;
     if (is_data) {
@@ -1654,11 +1657,14 @@ __global__ __launch_bounds__(kWave, 4) void train_kernel(const DemodConst* __res
 // Data symbol, carrier half: the pilot half of updateChannelEstimate already ran in track_pilot_kernel; here
 // the interpolation between the pilots, the equaliser and the demapper — one wavefront per frame, one lane per
 // carrier.
-template <int MOD>
+// EQ (live streams that feed a constellation display, ultra_hip_demod_stream_batch_eq): also write each symbol's equalized
+// data carriers, eq_out[frame * eq_stride + ds * kMaxCarriers + carrier] — an instance of its own, so that the batch path's
+// kernels stay what they were.
+template <int MOD, bool EQ = false>
 __global__ __launch_bounds__(kWave, 6) void track_kernel(
     const DemodConst* __restrict__ Dp, int n_frames, int data_sym, float* __restrict__ state,
     const c32* __restrict__ fq_all, float* __restrict__ llr, size_t llr_stride, float* __restrict__ state_out,
-    int n_sym_batch, int synced_loop) {
+    int n_sym_batch, int synced_loop, c32* __restrict__ eq_out = nullptr, size_t eq_stride = 0) {
     // synced_loop: these symbols reach the demodulator through process()'s SYNCED loop (demodulator.cpp:672-697), which calls
     // updateChannelEstimate for EVERY layout, although the context is of the presynced entry — the tail of a frame whose head
     // went through processPresynced (whose own loop skips the update without pilots, :954-960).
@@ -1706,7 +1712,8 @@ __global__ __launch_bounds__(kWave, 6) void track_kernel(
             }
             equalize_demap<MOD>(sh, D, lc, tr, dprev, fq,
                                 llr + (size_t)frame * llr_stride + (size_t)(data_sym + ds) * D.llrs_per_symbol,
-                                &dprev_abs, tc_is_fixed ? &tc0 : nullptr, nullptr, adaptive ? &ad : nullptr);
+                                &dprev_abs, tc_is_fixed ? &tc0 : nullptr, nullptr, adaptive ? &ad : nullptr,
+                                EQ ? eq_out + (size_t)frame * eq_stride + (size_t)ds * kMaxCarriers : nullptr);
             wave_sync();
         }
         // write the record back

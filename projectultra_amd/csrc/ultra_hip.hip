@@ -219,7 +219,9 @@ int ensure_llr_workspace(ultra_hip_ctx* ctx, size_t n_frames) {
 
 int launch_demod(ultra_hip_ctx* ctx, const float* d_audio, size_t frame_stride, const float* d_cfo_hz,
                  const float* d_cfo_phase, size_t n_frames, float* d_llr, size_t llr_stride, float* d_state,
-                 const unsigned* d_frame_offset = nullptr, int sym_begin = 0, int sym_count = -1) {
+                 const unsigned* d_frame_offset = nullptr, int sym_begin = 0, int sym_count = -1, c32* d_eq = nullptr) {
+    // d_eq (ultra_hip_demod_stream_batch_eq, nullable): [n_frames][data symbols of this call][kMaxCarriers] equalized data
+    // carriers; such a call takes the per-symbol chain (track_kernel's EQ instance), whose results are the other chains'.
     // sym_begin / sym_count (ultra_hip_demod_stream_batch): symbols [sym_begin, sym_begin + sym_count) of every frame,
     // continuing from the tracker records the previous call left in the context's workspace (sym_begin > 0: no
     // initialisation; d_audio and d_llr then address the frame as if it were complete — the caller shifts its pointers)
@@ -269,7 +271,7 @@ int launch_demod(ultra_hip_ctx* ctx, const float* d_audio, size_t frame_stride, 
     // behind the last symbol, over every (symbol, frame) — track_all_kernel, demod_kernel.h; per symbol only
     // cfo_walk -> mix_fft -> track_pilot remain.  Needs every symbol's bins and a record per (symbol, frame).
     // (not with the adaptive equaliser: its weights are per-carrier state that the carrier half carries from symbol to symbol)
-    bool deferred = !ctx->old_chain && !D.differential && D.n_pilot > 0 && D.n_pilot <= dev::kPwPilots && D.n_train == 0 &&
+    bool deferred = !ctx->old_chain && !d_eq && !D.differential && D.n_pilot > 0 && D.n_pilot <= dev::kPwPilots && D.n_train == 0 &&
                     !D.presynced && D.adaptive_eq == 0 && n_frames * (size_t)n_sym < 0x7fffffffull;
     // n_sym rows of workspace per frame instead of one: if that cannot be had, fall back to the per-symbol launches
     if ((all_symbols_at_once || deferred) && ensure_fq_workspace(ctx, n_frames * (size_t)n_sym) != ULTRA_HIP_OK) {
@@ -412,11 +414,20 @@ int launch_demod(ultra_hip_ctx* ctx, const float* d_audio, size_t frame_stride, 
         const int track_batch = all_symbols_at_once ? s_end - s : 1;
         const bool last_launch = last || all_symbols_at_once;
 #define UH_TRACK(MOD)                                                                                            \
-    hipLaunchKernelGGL(dev::track_kernel<MOD>, dim3(grid_trk), dim3(dev::kWave), 0, st, ctx->d_demod, (int)n_frames,  \
-                       s - D.n_train, ctx->d_ws_state, fq_s, d_llr, llr_stride, last_launch ? d_state : nullptr, track_batch, synced_loop)
+    do {                                                                                                         \
+        if (d_eq)                                                                                                \
+            hipLaunchKernelGGL((dev::track_kernel<MOD, true>), dim3(grid_trk), dim3(dev::kWave), 0, st, ctx->d_demod, (int)n_frames, \
+                               s - D.n_train, ctx->d_ws_state, fq_s, d_llr, llr_stride, last_launch ? d_state : nullptr, track_batch, \
+                               synced_loop, d_eq + (size_t)(s - std::max(s_begin, (int)D.n_train)) * kMaxCarriers, eq_stride);        \
+        else                                                                                                     \
+            hipLaunchKernelGGL((dev::track_kernel<MOD, false>), dim3(grid_trk), dim3(dev::kWave), 0, st, ctx->d_demod, (int)n_frames, \
+                               s - D.n_train, ctx->d_ws_state, fq_s, d_llr, llr_stride, last_launch ? d_state : nullptr, track_batch, \
+                               synced_loop, (c32*)nullptr, (size_t)0);                                           \
+    } while (0)
         LaunchSpan span(ctx, ULTRA_HIP_K_TRACK, n_frames * (unsigned long long)track_batch);
         // differential layouts without pilots on at most 32 carriers (the 512-point presets): two frames per wavefront
-        const bool pair_frames = !ctx->old_chain && D.differential && D.n_pilot == 0 && !D.presynced && D.n_carriers <= 32 &&
+        const size_t eq_stride = (size_t)(s_end - std::max(s_begin, (int)D.n_train)) * kMaxCarriers;   // data symbols of this call
+        const bool pair_frames = !ctx->old_chain && !d_eq && D.differential && D.n_pilot == 0 && !D.presynced && D.n_carriers <= 32 &&
                                  D.n_train == 0;      // (without pilots every interpolation entry is empty: nothing to interpolate)
 #define UH_TRACK_PAIR(MOD)                                                                                                         \
     hipLaunchKernelGGL(dev::track_diff_pair_kernel<MOD>, dim3((unsigned)std::min((n_frames + 1) / 2, (size_t)ctx->cu_count * 128)),  \
@@ -958,6 +969,13 @@ int ultra_hip_ldpc_decode_blocks(ultra_hip_ctx* ctx, const float* d_llr, size_t 
 int ultra_hip_demod_stream_batch(ultra_hip_ctx* ctx, const float* d_audio, size_t frame_stride, const float* d_cfo_hz,
                                  const float* d_cfo_phase, size_t n_frames, uint32_t first_symbol, uint32_t n_symbols,
                                  float* d_llr, float* d_state) {
+    return ultra_hip_demod_stream_batch_eq(ctx, d_audio, frame_stride, d_cfo_hz, d_cfo_phase, n_frames, first_symbol, n_symbols, d_llr,
+                                           d_state, nullptr);
+}
+
+int ultra_hip_demod_stream_batch_eq(ultra_hip_ctx* ctx, const float* d_audio, size_t frame_stride, const float* d_cfo_hz,
+                                    const float* d_cfo_phase, size_t n_frames, uint32_t first_symbol, uint32_t n_symbols,
+                                    float* d_llr, float* d_state, float* d_equalized) {
     if (!ctx) return ULTRA_HIP_ERR_INVALID_ARG;
     if (n_frames == 0 || n_symbols == 0) return ULTRA_HIP_OK;
     const DemodConst& D = ctx->h_demod;
@@ -975,7 +993,8 @@ int ultra_hip_demod_stream_batch(ultra_hip_ctx* ctx, const float* d_audio, size_
     const float* audio0 = d_audio - (size_t)first_symbol * (size_t)D.sym_len;
     float* llr0 = d_llr - (size_t)first_data * (size_t)D.llrs_per_symbol;
     return launch_demod(ctx, audio0, frame_stride, d_cfo_hz, d_cfo_phase, n_frames, llr0,
-                        (size_t)data_in_call * (size_t)D.llrs_per_symbol, d_state, nullptr, (int)first_symbol, (int)n_symbols);
+                        (size_t)data_in_call * (size_t)D.llrs_per_symbol, d_state, nullptr, (int)first_symbol, (int)n_symbols,
+                        data_in_call ? reinterpret_cast<c32*>(d_equalized) : nullptr);
 }
 
 int ultra_hip_demod_stream_start(ultra_hip_ctx* ctx, int mode, const float* d_timing) {

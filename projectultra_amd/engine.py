@@ -194,11 +194,14 @@ class ReceiveContext:
                                              state.data_ptr() if want_state else None), "ultra_hip_demod_batch")
         return (llr, state) if want_state else llr
 
-    def demod_stream(self, audio, first_symbol: int, n_symbols: int, cfo_hz=None, cfo_phase=None, want_state: bool = False):
+    def demod_stream(self, audio, first_symbol: int, n_symbols: int, cfo_hz=None, cfo_phase=None, want_state: bool = False,
+                     want_equalized: bool = False):
         """Symbols [first_symbol, first_symbol + n_symbols) of every frame, continuing from the tracker the previous call on
         this context left behind (ultra_hip_demod_stream_batch; first_symbol == 0 starts afresh from cfo_hz / cfo_phase).
         audio rows start AT symbol first_symbol.  Returns the LLRs of the data symbols among them [n][n_data * llrs_per_symbol]
-        (+ the tracker after the last symbol [n][8])."""
+        (+ the tracker after the last symbol [n][8]) (+ with want_equalized the equalized data carriers of every data symbol,
+        complex64 [n][n_data][data carriers]: what demodulateSymbol appends to the constellation ring, demodulator.cpp:199-208 —
+        ultra_hip_demod_stream_batch_eq)."""
         torch = _torch()
         self._check_stream()
         audio = self._dev(audio, torch.float32, "audio")
@@ -214,13 +217,24 @@ class ReceiveContext:
         cfo, cph = self._opt(cfo_hz, n), self._opt(cfo_phase, n)
         llr = torch.empty((n, max(n_data, 1) * g.llrs_per_symbol), dtype=torch.float32, device=self.device)
         state = torch.empty((n, _lib.STATE_FLOATS), dtype=torch.float32, device=self.device) if want_state else None
-        check(self.lib.ultra_hip_demod_stream_batch(self._ctx, audio.data_ptr(), self._row_stride(audio),
-                                                    cfo.data_ptr() if cfo is not None else None,
-                                                    cph.data_ptr() if cph is not None else None, n, int(first_symbol), int(n_symbols),
-                                                    llr.data_ptr(), state.data_ptr() if want_state else None),
-              "ultra_hip_demod_stream_batch")
+        if want_equalized:
+            eq = torch.zeros((n, max(n_data, 1), 64, 2), dtype=torch.float32, device=self.device)
+            check(self.lib.ultra_hip_demod_stream_batch_eq(self._ctx, audio.data_ptr(), self._row_stride(audio),
+                                                           cfo.data_ptr() if cfo is not None else None,
+                                                           cph.data_ptr() if cph is not None else None, n, int(first_symbol),
+                                                           int(n_symbols), llr.data_ptr(), state.data_ptr() if want_state else None,
+                                                           eq.data_ptr()), "ultra_hip_demod_stream_batch_eq")
+        else:
+            check(self.lib.ultra_hip_demod_stream_batch(self._ctx, audio.data_ptr(), self._row_stride(audio),
+                                                        cfo.data_ptr() if cfo is not None else None,
+                                                        cph.data_ptr() if cph is not None else None, n, int(first_symbol), int(n_symbols),
+                                                        llr.data_ptr(), state.data_ptr() if want_state else None),
+                  "ultra_hip_demod_stream_batch")
         llr = llr[:, :n_data * g.llrs_per_symbol]
-        return (llr, state) if want_state else llr
+        out = (llr, state) if want_state else (llr,)
+        if want_equalized:
+            out = out + (torch.view_as_complex(eq[:, :n_data, :g.n_data_carriers, :].contiguous()),)
+        return out if len(out) > 1 else out[0]
 
     def demod_into(self, audio, llr, cfo_hz=None, cfo_phase=None):
         """Demodulate into the rows of a caller-owned LLR array whose row stride may exceed llrs_per_frame

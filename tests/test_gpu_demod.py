@@ -593,6 +593,41 @@ def test_streamed_symbols_equal_the_batch(oracle, fft, mod, rate, kw):
             assert beq(st.cpu().numpy(), st_whole.cpu().numpy()), (mod, with_cfo, split)
 
 
+@pytest.mark.parametrize("fft,mod,rate,kw", [(1024, "QAM16", "R3_4", {}), (512, "DQPSK", "R1_2", {}), (1024, "DQPSK", "R1_4", dict(pilot_spacing=2, use_pilots=1)),
+                                             (1024, "QAM32", "R1_2", dict(entry=1))])
+def test_streamed_equalized_symbols(oracle, fft, mod, rate, kw):
+    """ultra_hip_demod_stream_batch_eq (ABI 9): the equalized data carriers of every data symbol — what demodulateSymbol
+    appends to constellation_symbols (demodulator.cpp:199-208).  The values themselves are held to the compiled reference's
+    getConstellationSymbols() by the scripted harness (tests/test_gpu_pimpl.py: the ring's digest in every log line); here:
+    the call's LLRs and tracker are those of the plain stream call (= the oracle's), the rows do not depend on how the frame
+    is split into calls, and padding beyond the data carriers is not written."""
+    cfg = make_config(fft, mod, rate, n_data_symbols=7, **kw)
+    g = geometry(cfg)
+    n = 40
+    audio, _ = oracle.make_batch(cfg, n, seed=91, channel="watterson", snr_db=22.0)
+    cfo = np.random.default_rng(8).normal(0, 5.0, n).astype(np.float32)
+    n_train = int(cfg.training_symbols)
+    total = n_train + 7
+    want = oracle.demod_decode_batch(cfg, audio, cfo_hz=cfo, n_threads=16)
+    first = max(n_train, 1)
+    rows = {}
+    for split in ([total], [first] + [1] * (total - first), [first, 2, total - first - 2]):
+        ctx = context_for(cfg)
+        parts, eqs, s0 = [], [], 0
+        for k in split:
+            a = np.ascontiguousarray(audio[:, s0 * g.symbol_samples:(s0 + k) * g.symbol_samples])
+            llr, st, eq = ctx.demod_stream(a, s0, k, cfo_hz=cfo if s0 == 0 else None, want_state=True, want_equalized=True)
+            parts.append(llr.cpu().numpy()); eqs.append(eq.cpu().numpy()); s0 += k
+        got = np.concatenate([p for p in parts if p.shape[1]], axis=1)
+        assert beq(got, want["llr"]), (mod, split)
+        rows[tuple(split)] = np.concatenate([e for e in eqs if e.shape[1]], axis=1)
+        assert rows[tuple(split)].shape == (n, 7, g.n_data_carriers)
+    ref = rows[(total,)]
+    for k, v in rows.items():
+        assert beq(v, ref), (mod, k)
+    assert np.isfinite(ref.view(np.float32)).all() and np.abs(ref).mean() > 0.1      # symbols, not zeros
+
+
 def test_stream_and_block_entries_refuse_bad_arguments():
     """The round-3 entries validate before they launch: a resume without a previous call, symbol ranges outside the frame,
     rows too short for the symbols, block runs that overlap or leave the LLR array."""
