@@ -42,13 +42,17 @@ __host__ __device__ constexpr int tprof_planes_before(unsigned long long p, int 
 }
 
 constexpr int kScreenWaves = 4, kScreenThreads = 64 * kScreenWaves;
-constexpr int kScreenChunk = 64;             // codewords per workgroup of the full pass (16 per wavefront, the next one's loads in flight)
+#ifndef UH_SCREEN_CHUNK
+#define UH_SCREEN_CHUNK 64
+#endif
+constexpr int kScreenChunk = UH_SCREEN_CHUNK;   // codewords per workgroup of the full pass (<= 64: one ballot appends them), the next one's loads in flight
 constexpr int kScreenSampleMax = 2048;       // codewords of the sample
 constexpr int kScreenLoads = (kLdpcN + 63) / 64;     // 11 wave-wide loads per row
 // words of the launch's counter block (ultra_hip_ctx::d_work; word 0 is queue 0's head, zeroed with the queues before every launch)
 constexpr int kScreenCtlSample = 1, kScreenCtlDirty = 2;
 
-// positions -> gather words: one VGPR per edge, (byte offset of the bit's word in the workgroup's LDS) << 5 | bit index
+// The table of positions under the context's current deinterleaver setting (one workgroup; launched when the setting changed):
+// row_pos[round][edge][lane] for the rows in their slots, out_pos[j] for the output bits.
 __global__ __launch_bounds__(512) void ldpc_screen_prepare_kernel(const uint16_t* __restrict__ row_var, int m, int k, int llr_step,
                                                                   const uint16_t* __restrict__ llr_perm, LdpcScreenPos* __restrict__ out) {
     auto src_index = [&](int j) -> unsigned { return llr_perm ? (unsigned)llr_perm[j] : (unsigned)(j * llr_step) % (unsigned)kLdpcN; };
@@ -198,7 +202,7 @@ __global__ __launch_bounds__(kScreenThreads) void ldpc_screen_kernel(
     }
     __syncthreads();
     if (wave == 0) {                                                           // append the chunk's dirty codewords, order kept
-        const bool f = flags[lane] != 0u;
+        const bool f = lane < kScreenChunk && flags[lane] != 0u;
         const unsigned long long mask = __ballot(f);
         const unsigned n = (unsigned)__popcll(mask);
         if (n != 0u) {                                                         // uniform

@@ -909,6 +909,10 @@ int ultra_hip_reserve(ultra_hip_ctx* ctx, size_t n_frames) {
         rc = ensure_fq_workspace(ctx, n_frames);
     }
     if (rc == ULTRA_HIP_OK) rc = ensure_llr_workspace(ctx, n_frames);
+    // the decoder's work list (ldpc_screen_kernel.h): best effort — without it such launches decode without the screen
+    if (rc == ULTRA_HIP_OK && ctx->screen_mode != 0 && ctx->d_screen_pos && (n_frames >= kScreenMinCodewords || ctx->screen_mode == 2) &&
+        ensure_list_workspace(ctx, n_frames) != ULTRA_HIP_OK)
+        (void)hipGetLastError();
     return rc;
 }
 
