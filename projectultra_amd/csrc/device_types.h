@@ -122,9 +122,15 @@ constexpr int kTPlanRowRounds = 8, kTPlanVarRounds = 7, kTPlanDmax = 13;
 // (nine planes, 2,304 B), whose staging grows to the row's 2,592 B and still fits 18 workgroups per CU (8,992 B of
 // 163,840 / 18 = 9,102: tools/ubench/lds_granule.hip — the allocation has no coarser granule than that).  R5/6's six planes
 // would have to grow by 1,056 B and lose a workgroup per CU.
+#ifdef UH_NO_ROW_STAGE                         // variant build for the A/B (tools/ab_ldpc.sh): slot-indexed fetch everywhere
+constexpr bool ldpc_row_stage(int, int) { return false; }
+#else
 constexpr bool ldpc_row_stage(int var_rounds, int row_rounds) { return var_rounds + row_rounds >= 9; }
+#endif
+// A row-staged instance never touches the slot planes, so its staging area is the row's 2,592 B exactly — 224 to 480 B less than
+// the planes of R2/3, R1/2 and R1/3 took until round 5, which is one more workgroup per CU for each of them (14 -> 15).
 constexpr int ldpc_stage_bytes(int var_rounds, int row_rounds) {
-    return (ldpc_row_stage(var_rounds, row_rounds) && (var_rounds + row_rounds) * 256 < 648 * 4) ? 648 * 4 : (var_rounds + row_rounds) * 256;
+    return ldpc_row_stage(var_rounds, row_rounds) ? 648 * 4 : (var_rounds + row_rounds) * 256;
 }
 struct LdpcTPlan {
     int32_t valid, k, m, n, max_iterations, decoded_bytes, row_rounds, var_rounds, dmax;

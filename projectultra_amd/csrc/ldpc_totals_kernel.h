@@ -128,7 +128,12 @@ __global__ void ldpc_lds_base_probe_kernel(unsigned* __restrict__ out) {
     if (threadIdx.x == 0) { lds_raw[0] = 1; out[0] = (unsigned)(size_t)lds_raw; }
 }
 
-template <int RR, int VR, unsigned long long RPROF, unsigned long long VPROF, bool WANT_TOTAL, int WAVES>
+// COMPACT (launches without a fused deinterleaver; R3/4): only the values the decoder reads are staged — the n_checked
+// information bits that have checks and the m parity bits, 487 of R3/4's 648: 1,948 B instead of 2,592, which is the
+// difference between 18 and 19 workgroups per CU (8,348 B each) — measured -4 % on codewords that run all 50 iterations
+// (profiles/r05_variants/r05_probe_ldpc_r34_workgroups_per_cu.txt) — and a quarter less to fetch.  Word w of the staged
+// row = position w of the memory row for w < n_checked, position w + (k - n_checked) behind that.
+template <int RR, int VR, unsigned long long RPROF, unsigned long long VPROF, bool WANT_TOTAL, int WAVES, bool COMPACT = false>
 __global__ __launch_bounds__(kLdpcThreads, WAVES) void ldpc_totals_kernel(
     const LdpcTPlan* __restrict__ Pp, const float* __restrict__ llr, size_t llr_stride, int n_cw,
     uint8_t* __restrict__ bytes, int32_t* __restrict__ iters, uint8_t* __restrict__ okv,
@@ -208,28 +213,45 @@ __global__ __launch_bounds__(kLdpcThreads, WAVES) void ldpc_totals_kernel(
     // that moves a value into its variable's total.  Before, every lane fetched the value of ITS variable: 11 wave-instructions
     // of 64 scattered 4-byte reads per codeword, each touching most of the row's 21 cache lines; a codeword that converges at
     // once waited 11,800 cycles for them, 9,100 now (profiles/r05_ldpc_stalls_r14*.txt).
-#ifdef UH_NO_ROW_STAGE                         // variant build for the A/B (tools/ab_ldpc.sh)
-    constexpr bool kRowStage = false;
-#else
-    constexpr bool kRowStage = ldpc_row_stage(VR, RR);
-#endif
+    constexpr bool kRowStage = ldpc_row_stage(VR, RR);     // (false everywhere in the UH_NO_ROW_STAGE variant build: device_types.h)
+    static_assert(!COMPACT || (kRowStage && RR == 3 && VR == 6), "the compact row is R3/4's staged row");
+    // COMPACT: the memory row's positions [n_checked, k) = [325, 486) are not staged (R3/4: ldpc_decoder.cpp:64-137 connects the
+    // first 325 information bits: 323 with three checks, one with two, one with one); where position p of the memory row sits in the staged row (no deinterleaver: src_index = identity)
+    constexpr int kCompactK = 486, kCompactChecked = 325, kCompactGap = kCompactK - kCompactChecked;
+    auto staged_word = [&](unsigned p) -> unsigned { return (COMPACT && (int)p >= kCompactChecked) ? p - (unsigned)kCompactGap : p; };
     unsigned short src_v[VR], src_p[RR];        // kRowStage: byte address of the slot's value in the staged row; else its index in the row
 #pragma unroll
     for (int r = 0; r < VR; ++r) {
         const unsigned j = P.var_id[r * 64 + lane];
-        if constexpr (kRowStage) src_v[r] = (unsigned short)(STAGE_V + 4u * ((j != 0xFFFFu) ? src_index((int)j) : 0u));
+        if constexpr (kRowStage) src_v[r] = (unsigned short)(STAGE_V + 4u * ((j != 0xFFFFu) ? staged_word(src_index((int)j)) : 0u));
         else src_v[r] = (j != 0xFFFFu) ? (unsigned short)src_index((int)j) : (unsigned short)0xFFFFu;
     }
 #pragma unroll
     for (int r = 0; r < RR; ++r) {
         const unsigned i = P.row_check[r * 64 + lane];
-        if constexpr (kRowStage) src_p[r] = (unsigned short)(STAGE_V + 4u * ((i != 0xFFFFu) ? src_index(k + (int)i) : 0u));
+        if constexpr (kRowStage) src_p[r] = (unsigned short)(STAGE_V + 4u * ((i != 0xFFFFu) ? staged_word(src_index(k + (int)i)) : 0u));
         else src_p[r] = (i != 0xFFFFu) ? (unsigned short)src_index(k + (int)i) : (unsigned short)0xFFFFu;
     }
     auto fetch = [&](int c) {
         const float* src = llr + llr_row(c) * llr_stride;
         float* stage_v = reinterpret_cast<float*>(lds_raw + STAGE_V);
-        if constexpr (kRowStage) {
+        if constexpr (COMPACT) {
+            // a copy lands its lanes at consecutive words behind ONE base: the part of a 64-position piece in front of the gap
+            // and the part behind it are copies of their own.  The instance is R3/4's: k and n_checked are ITS constants
+            // (launch_ldpc checks the plan against them), so which lanes of which piece copy is decided at compile time —
+            // pieces 0-4 whole, piece 5 its first five lanes, piece 6 nothing, piece 7 from lane 38 on, 8 and 9 whole, 10 eight lanes.
+            ldpc_static_for(std::make_integer_sequence<int, (kLdpcN + 63) / 64>{}, [&](auto piece) {
+                constexpr int i = decltype(piece)::value;
+                constexpr int a_hi = kCompactChecked - 64 * i;                 // lanes [0, a_hi) lie in front of the gap
+                constexpr int b_lo = kCompactK - 64 * i, b_hi = kLdpcN - 64 * i;   // lanes [b_lo, b_hi) lie behind it
+                if constexpr (a_hi >= 64) __builtin_amdgcn_global_load_lds(src + lane + i * 64, stage_v + i * 64, 4, 0, 0);
+                else if constexpr (a_hi > 0) { if (lane < a_hi) __builtin_amdgcn_global_load_lds(src + lane + i * 64, stage_v + i * 64, 4, 0, 0); }
+                if constexpr (b_lo <= 0 && b_hi >= 64) __builtin_amdgcn_global_load_lds(src + lane + i * 64, stage_v + i * 64 - kCompactGap, 4, 0, 0);
+                else if constexpr (b_lo < 64 && b_hi > 0) {
+                    if (lane >= b_lo && lane < b_hi) __builtin_amdgcn_global_load_lds(src + lane + i * 64, stage_v + i * 64 - kCompactGap, 4, 0, 0);
+                }
+            });
+        } else if constexpr (kRowStage) {
 #pragma unroll
             for (int i = 0; i < (kLdpcN + 63) / 64; ++i)
                 if (i * 64 + lane < kLdpcN) __builtin_amdgcn_global_load_lds(src + lane + i * 64, stage_v + i * 64, 4, 0, 0);

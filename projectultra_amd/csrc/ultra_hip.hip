@@ -476,17 +476,18 @@ int launch_ldpc(ultra_hip_ctx* ctx, const float* d_llr, size_t llr_stride, size_
             T.lds_bytes != T.stage_v + ldpc_stage_bytes(T.var_rounds, T.row_rounds))
             return ULTRA_HIP_ERR_UNSUPPORTED;
 // one instance per code: (row rounds, variable rounds, row profile, variable profile); the plan's profiles select it
-#define UH_TOTALS_LAUNCH(RR, VR, RP, VP, WV)                                                                      \
+#define UH_TOTALS_LAUNCH(RR, VR, RP, VP, WV, CP)                                                                  \
     do {                                                                                                          \
-        const size_t per_cu = std::max<size_t>(1, std::min<size_t>(4 * (WV), (size_t)(160 * 1024) / tlds));       \
+        const size_t lds_wg = (CP) ? (size_t)T.stage_v + 4 * (size_t)(T.n_checked + T.m) : tlds;                  \
+        const size_t per_cu = std::max<size_t>(1, std::min<size_t>(4 * (WV), (size_t)(160 * 1024) / lds_wg));     \
         const unsigned grid = (unsigned)std::min(n_cw, (size_t)ctx->cu_count * per_cu);                           \
         if (d_llr_total)                                                                                          \
-            hipLaunchKernelGGL((dev::ldpc_totals_kernel<RR, VR, RP, VP, true, WV>), dim3(grid), dim3(dev::kLdpcThreads), tlds, \
+            hipLaunchKernelGGL((dev::ldpc_totals_kernel<RR, VR, RP, VP, true, WV, false>), dim3(grid), dim3(dev::kLdpcThreads), tlds, \
                                ctx->stream, ctx->d_tplan, d_llr, llr_stride, (int)n_cw, d_bytes, d_iters, d_ok,   \
                                d_llr_total, counter, (int)ctx->deint_step, ctx->d_deint_table, block_len, block_stride, \
                                (const unsigned*)nullptr, 0u);                                                     \
         else                                                                                                      \
-            hipLaunchKernelGGL((dev::ldpc_totals_kernel<RR, VR, RP, VP, false, WV>), dim3(grid), dim3(dev::kLdpcThreads), tlds, \
+            hipLaunchKernelGGL((dev::ldpc_totals_kernel<RR, VR, RP, VP, false, WV, CP>), dim3(grid), dim3(dev::kLdpcThreads), lds_wg, \
                                ctx->stream, ctx->d_tplan, d_llr, llr_stride, (int)n_cw, d_bytes, d_iters, d_ok,   \
                                d_llr_total, counter, (int)ctx->deint_step, ctx->d_deint_table, block_len, block_stride, \
                                (const unsigned*)work_list, gate);                                                 \
@@ -548,12 +549,17 @@ int launch_ldpc(ultra_hip_ctx* ctx, const float* d_llr, size_t llr_stride, size_
                 }
 #undef UH_SCREEN_LAUNCH
             }
-            if (r34) UH_TOTALS_LAUNCH(3, 6, 0x666ull, 0x333333ull, 5);
-            else if (r56) UH_TOTALS_LAUNCH(2, 4, 0x66ull, 0x3333ull, 6);
-            else if (r23) UH_TOTALS_LAUNCH(4, 7, 0x6666ull, 0x3333333ull, 4);
-            else if (r14) UH_TOTALS_LAUNCH(8, 3, kPlaceRowProf_R1_4, kPlaceVarProf_R1_4, 3);
-            else if (r13) UH_TOTALS_LAUNCH(6, 6, kPlaceRowProf_R1_3, kPlaceVarProf_R1_3, 4);
-            else UH_TOTALS_LAUNCH(6, 6, kPlaceRowProf_R1_2, kPlaceVarProf_R1_2, 4);
+            // R3/4 without a fused deinterleaver stages only the 487 values its decoder reads: 8,348 B per workgroup, 19 per CU
+            // instead of 18 (ldpc_totals_kernel.h, COMPACT).
+            const bool compact = r34 && !d_llr_total && ctx->deint_step == 1u && !ctx->d_deint_table && T.k == 486 && T.n_checked == 325 &&
+                                 T.m == 162;            // the instance's own constants (ldpc_totals_kernel.h, kCompactK / kCompactChecked)
+            if (r34 && compact) UH_TOTALS_LAUNCH(3, 6, 0x666ull, 0x333333ull, 5, true);
+            else if (r34) UH_TOTALS_LAUNCH(3, 6, 0x666ull, 0x333333ull, 5, false);
+            else if (r56) UH_TOTALS_LAUNCH(2, 4, 0x66ull, 0x3333ull, 6, false);
+            else if (r23) UH_TOTALS_LAUNCH(4, 7, 0x6666ull, 0x3333333ull, 4, false);
+            else if (r14) UH_TOTALS_LAUNCH(8, 3, kPlaceRowProf_R1_4, kPlaceVarProf_R1_4, 3, false);
+            else if (r13) UH_TOTALS_LAUNCH(6, 6, kPlaceRowProf_R1_3, kPlaceVarProf_R1_3, 4, false);
+            else UH_TOTALS_LAUNCH(6, 6, kPlaceRowProf_R1_2, kPlaceVarProf_R1_2, 4, false);
         }
 #undef UH_TOTALS_LAUNCH
         if (launched) { UH_HIP(hipGetLastError()); return ULTRA_HIP_OK; }
