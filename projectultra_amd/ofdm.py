@@ -18,8 +18,11 @@ from .types import Entry, LDPC_BLOCK_SIZE, ModemConfig
 
 
 class OFDMDemodulator:
+    MAX_CONSTELLATION_SYMBOLS = 500          # demodulator_constants.hpp:122
+
     def __init__(self, config: ModemConfig, n_data_symbols=None, device=None, max_iterations: int = 50):
         self.config = config
+        self._constellation = np.zeros(0, np.complex64)    # never cleared, as in the reference (not even by reset())
         self._device = device
         self._n_data_symbols = n_data_symbols
         self._max_iterations = max_iterations
@@ -153,11 +156,13 @@ class OFDMDemodulator:
         n_new = min(self._rx.size // sym, self.MAX_SYMBOLS_BEFORE_TIMEOUT + 1 - self._synced_symbols)
         before = self._soft_bits.size
         if n_new > 0:
-            llr, state = ctx.demod_stream(self._rx[:n_new * sym].reshape(1, -1), self._synced_symbols, n_new,
-                                          cfo_hz=np.array([self._cfo_hz], np.float32) if self._synced_symbols == 0 else None,
-                                          want_state=True)
+            llr, state, eq = ctx.demod_stream(self._rx[:n_new * sym].reshape(1, -1), self._synced_symbols, n_new,
+                                              cfo_hz=np.array([self._cfo_hz], np.float32) if self._synced_symbols == 0 else None,
+                                              want_state=True, want_equalized=True)
             ctx.synchronize()
             self._soft_bits = np.concatenate([self._soft_bits, llr[0].cpu().numpy()])
+            # demodulateSymbol (demodulator.cpp:199-208): every data symbol appends its equalized carriers, the newest 500 stay
+            self._constellation = np.concatenate([self._constellation, eq[0].cpu().numpy().reshape(-1)])[-self.MAX_CONSTELLATION_SYMBOLS:]
             self._state = state[0].cpu().numpy()
             self._consume_to(self._origin + n_new * sym)
             self._synced_symbols += n_new
@@ -187,6 +192,9 @@ class OFDMDemodulator:
         self._synced, self._synced_symbols, self._idle_calls = False, 0, 0
         noise = int(self._resume[0, 2].item())
         self._resume.copy_(torch.tensor([[_i32(self._origin), _i32(self._fed), noise, 0]], dtype=torch.int32))
+
+    def getConstellationSymbols(self) -> np.ndarray:      # demodulator.cpp:827-830 (the live process() path feeds it)
+        return self._constellation.copy()
 
     def getLastSyncOffset(self) -> int:      # demodulator.cpp:846-848
         return self._last_sync_offset

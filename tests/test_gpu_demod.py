@@ -730,6 +730,11 @@ def test_demodulator_mirror_live_stream(name):
         assert synced == want[f"{name}__{sc}__synced"].tolist(), (name, sc)
         assert drained == want[f"{name}__{sc}__drained"].tolist(), (name, sc)
         assert beq(np.concatenate(soft).astype(np.float32), want[f"{name}__{sc}__soft"]), (name, sc)
+        # getConstellationSymbols() (demodulator.cpp:827-830): the newest <= 500 equalized data carriers of the symbols demodulated so
+        # far (the values themselves are held to the compiled reference by the C++ harness, tests/test_gpu_pimpl.py)
+        ring = d.getConstellationSymbols()
+        assert ring.dtype == np.complex64 and ring.size <= 500 and (ring.size > 0 or sum(drained) == 0), (name, sc, ring.size)
+        assert np.isfinite(ring.view(np.float32)).all()
 
 
 def test_headline_batch_whole(oracle):
