@@ -298,6 +298,14 @@ int ultra_hip_demod_stream_batch_eq(ultra_hip_ctx* ctx, const float* d_audio, si
  * d_timing is ignored (may be NULL) for the other two modes. */
 enum ultra_hip_stream_start { ULTRA_STREAM_START_FRESH = 0, ULTRA_STREAM_START_SYNC = 1, ULTRA_STREAM_START_TIMING = 2 };
 int ultra_hip_demod_stream_start(ultra_hip_ctx* ctx, int mode, const float* d_timing);
+/* One ultra::OFDMDemodulator object is ONE tracker (Impl) whichever way its frames come in: a Schmidl-Cox frame found by process()
+ * right after a processPresynced() frame — no reset() in between — carries that frame's channel estimate, noise variance, SNR,
+ * pilot history and equaliser weights through the SEARCHING -> SYNCED transition (demodulator.cpp:533-591).  The two entries are
+ * two contexts here; this call copies the tracker records of frames 0 .. n_frames - 1 from `src` (the context the previous frame
+ * was demodulated in) to `dst` (same device, same carrier layout and modulation: otherwise ULTRA_HIP_ERR_INVALID_ARG), on dst's
+ * stream, behind what src's stream has in flight.  Follow it with ultra_hip_demod_stream_start(dst, ULTRA_STREAM_START_SYNC, ..)
+ * (ABI 9). */
+int ultra_hip_stream_adopt(ultra_hip_ctx* dst, ultra_hip_ctx* src, size_t n_frames);
 
 /* OFDMDemodulator::setFrequencyOffset (demodulator.cpp:805-815) between two ultra_hip_demod_stream_batch calls:
  * freq_offset_hz = freq_offset_filtered = cfo_hz, correction phase 0, for frame `frame` of the stream in flight, applied

@@ -326,6 +326,13 @@ public:
                 consumeTo(clampIndex(int64_t(h[5]) + manual_timing_offset_));   // consume = refined_lts + 2 preamble symbols + manual offset (:572)
                 synced_ = true; synced_symbols_ = 0; pending_cfo_ = false; live_ps_ = false;
                 timing_ = 0.0f;                                          // timing_offset_samples = 0 (:588)
+                // a used demodulator carries its tracker into the new frame (:533-591) — from the SYNCED context's own records, or,
+                // when the frame before came through processPresynced, from the PRESYNCED context's (one Impl, two contexts here)
+                if (!carry_ && ps_carry_ && ps_slot_) {
+                    detail::check(ultra_hip_stream_adopt(slot_.ctx(), ps_slot_.ctx(), 1), "stream_adopt");
+                    carry_ = true;
+                }
+                ps_carry_ = false;
                 start_mode_ = carry_ ? ULTRA_STREAM_START_SYNC : ULTRA_STREAM_START_FRESH;
             } else if (h[0] > origin_) {
                 consumeTo(h[0]);                                         // what the search trimmed off the buffer
@@ -393,7 +400,7 @@ public:
         rx_.clear(); origin_ = fed_ = d_origin_ = 0; ++epoch_;         // sample indices start over (ultra_hip.h: the resume record's epoch)
         synced_symbols_ = 0; idle_calls_ = 0; pending_cfo_ = false;
         state_[ULTRA_HIP_STATE_SNR_LINEAR] = 1.0f;
-        synced_ = true; live_ps_ = true; carry_ = false;
+        synced_ = true; live_ps_ = true; carry_ = false; ps_carry_ = true;   // this frame's tracker lives in the PRESYNCED context
         appendSamples(samples);
         uint32_t n_sym = static_cast<uint32_t>(samples.size() / sym);
         if (n_sym < n_train || n_sym == 0) return false;                 // (the reference reads past the span here)
@@ -461,7 +468,7 @@ public:
         rx_.clear(); origin_ = fed_; d_origin_ = fed_; demod_soft_.clear();
         freq_offset_hz_ = 0.0f; freq_correction_phase_ = 0.0f; chirp_cfo_estimated_ = false; pending_cfo_ = false;
         state_[ULTRA_HIP_STATE_SNR_LINEAR] = 1.0f; state_[ULTRA_HIP_STATE_FREQ_OFFSET_HZ] = 0.0f;
-        carry_ = false; live_ps_ = false; start_mode_ = ULTRA_STREAM_START_FRESH;
+        carry_ = false; ps_carry_ = false; live_ps_ = false; start_mode_ = ULTRA_STREAM_START_FRESH;
         if (slot_) restartSearch();
     }
     uint32_t symbolSamples() const { return geo_.symbol_samples; }
@@ -575,6 +582,7 @@ private:
     int idle_calls_ = 0, manual_timing_offset_ = 0, start_mode_ = ULTRA_STREAM_START_FRESH;
     bool synced_ = false, pending_cfo_ = false, chirp_cfo_estimated_ = false;
     bool carry_ = false;                     // the SYNCED context holds a frame's tracker of THIS object (no reset() since)
+    bool ps_carry_ = false;                  // ... the PRESYNCED context does: the last frame came through processPresynced
     bool live_ps_ = false;                   // the frame in flight lives in the PRESYNCED context
     float coarse_cfo_ = 0.0f, freq_offset_hz_ = 0.0f, freq_correction_phase_ = 0.0f, timing_ = 0.0f;
     std::vector<float> demod_soft_, stage_;

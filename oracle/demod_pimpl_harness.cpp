@@ -211,6 +211,26 @@ void presynced(const ModemConfig& c, unsigned seed) {
     }
 }
 
+// processPresynced and process() on ONE object without reset() in between: the SEARCHING -> SYNCED transition of the Schmidl-Cox
+// frame (demodulator.cpp:533-591) carries what the presynced frame's tracker left (channel estimate, noise variance, SNR, pilot
+// history, equaliser weights); then a presynced frame again (its reset block, :868-905), then a reset() and a last Schmidl-Cox frame
+void mixed(const ModemConfig& c, unsigned seed) {
+    Tx tx(c, seed); Rx rx(c);
+    for (int round = 0; round < 2; ++round) {
+        Samples fr = tx.frame(1, 24.0f - 2 * round, 3.0f, true, 2);
+        rx.d.setFrequencyOffsetWithPhase(3.0f, 0.2f); std::printf("setFrequencyOffsetWithPhase\n");
+        const bool r = rx.d.processPresynced(SampleSpan(fr.data(), fr.size()), 2);
+        rx.status("presynced", r);
+        while (rx.d.hasPendingData()) rx.drain();
+        rx.idle(14);
+        Samples audio = tx.noise(8000, 0.01f); append(audio, tx.frame(2 - round, 26.0f, -5.0f + 9.0f * round)); append(audio, tx.noise(20000, 0.01f));
+        rx.feed(audio); rx.idle(3);
+    }
+    rx.d.reset(); std::printf("reset\n");
+    Samples audio = tx.noise(6000, 0.01f); append(audio, tx.frame(1, 28.0f, 1.5f)); append(audio, tx.noise(16000, 0.01f));
+    rx.feed(audio); rx.idle(3);
+}
+
 void midframe(const ModemConfig& c, unsigned seed) {
     Tx tx(c, seed); Rx rx(c);
     Samples f1 = tx.frame(3, 28.0f, 2.0f);
@@ -330,6 +350,7 @@ int main(int argc, char** argv) {
     else if (sc == "setcfo") setcfo(c, seed);
     else if (sc == "presynced") presynced(c, seed);
     else if (sc == "midframe") midframe(c, seed);
+    else if (sc == "mixed") mixed(c, seed);
     else if (sc == "exits") exits(c, seed);
     else if (sc == "getdata") getdata(c, seed);
     else if (sc == "decoder") decoder(rate, seed);

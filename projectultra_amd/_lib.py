@@ -70,6 +70,7 @@ PROTOTYPES = {
     "ultra_hip_demod_batch_strided": (_i, [_vp, _vp, _sz, _vp, _vp, _sz, _vp, _sz, _vp]),
     "ultra_hip_ldpc_decode_blocks": (_i, [_vp, _vp, _sz, _sz, _sz, _sz, _vp, _vp, _vp]),
     "ultra_hip_demod_stream_batch": (_i, [_vp, _vp, _sz, _vp, _vp, _sz, C.c_uint32, C.c_uint32, _vp, _vp]),
+    "ultra_hip_stream_adopt": (_i, [_vp, _vp, _sz]),
     "ultra_hip_demod_stream_batch_eq": (_i, [_vp, _vp, _sz, _vp, _vp, _sz, C.c_uint32, C.c_uint32, _vp, _vp, _vp]),
     "ultra_hip_demod_stream_set_cfo": (_i, [_vp, _sz, C.c_float]),
     "ultra_hip_demod_stream_start": (_i, [_vp, _i, _vp]),

@@ -1016,6 +1016,26 @@ int ultra_hip_demod_stream_start(ultra_hip_ctx* ctx, int mode, const float* d_ti
     return ULTRA_HIP_OK;
 }
 
+int ultra_hip_stream_adopt(ultra_hip_ctx* dst, ultra_hip_ctx* src, size_t n_frames) {
+    // One ultra::OFDMDemodulator object is ONE tracker whatever entry its frames come through; here the two entries are two
+    // contexts with records of the same layout (demod_kernel.h, kStFloats: the compact pilot state does not depend on the entry).
+    if (!dst || !src || dst == src || n_frames == 0 || n_frames > 0x7fffffffull) return ULTRA_HIP_ERR_INVALID_ARG;
+    const DemodConst &A = dst->h_demod, &B = src->h_demod;
+    if (dst->device != src->device || src->ws_demod_frames < n_frames || A.fft != B.fft || A.n_carriers != B.n_carriers ||
+        A.n_pilot != B.n_pilot || A.n_data != B.n_data || A.modulation != B.modulation || A.differential != B.differential ||
+        A.adaptive_eq != B.adaptive_eq || std::memcmp(A.pilot_slot, B.pilot_slot, sizeof(A.pilot_slot)) != 0)
+        return ULTRA_HIP_ERR_INVALID_ARG;
+    DeviceGuard guard(dst->device);
+    { const int rc = ensure_demod_workspace(dst, n_frames); if (rc != ULTRA_HIP_OK) return rc; }
+    if (src->stream != dst->stream) {                       // what src's stream still has in flight comes first
+        UH_HIP(hipEventRecord(src->ev_end, src->stream));
+        UH_HIP(hipStreamWaitEvent(dst->stream, src->ev_end, 0));
+    }
+    UH_HIP(hipMemcpyAsync(dst->d_ws_state, src->d_ws_state, n_frames * (size_t)dev::kStFloats * sizeof(float), hipMemcpyDeviceToDevice,
+                          dst->stream));
+    return ULTRA_HIP_OK;
+}
+
 int ultra_hip_demod_stream_set_cfo(ultra_hip_ctx* ctx, size_t frame, float cfo_hz) {
     return ultra_hip_demod_stream_set_cfo_phase(ctx, frame, cfo_hz, 0.0f);
 }

@@ -142,6 +142,8 @@ HARNESS_CASES = [
     ("decoder", 512, "QPSK", "R1_4", 21), ("decoder", 512, "QPSK", "R1_2", 22), ("decoder", 512, "QPSK", "R2_3", 23), ("decoder", 512, "QPSK", "R3_4", 24),
     ("decoder", 512, "QPSK", "R5_6", 25), ("decoder", 512, "QPSK", "R1_3", 26),
     ("interleave", 512, "QPSK", "R1_2", 27),
+    # processPresynced and process() frames on one object without reset(): the Schmidl-Cox frame carries the presynced frame's tracker
+    ("mixed", 1024, "QAM16", "R3_4", 31), ("mixed", 512, "DQPSK", "R1_2", 32), ("mixed", 512, "QPSK", "R1_2", 33), ("mixed", 1024, "D8PSK", "R2_3", 34),
 ]
 
 
