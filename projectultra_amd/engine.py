@@ -236,6 +236,12 @@ class ReceiveContext:
             out = out + (torch.view_as_complex(eq[:, :n_data, :g.n_data_carriers, :].contiguous()),)
         return out if len(out) > 1 else out[0]
 
+    def adopt_tracker(self, src: "ReceiveContext", n_frames: int = 1) -> None:
+        """ultra_hip_stream_adopt: the tracker records of frames 0 .. n_frames - 1 of `src` (another entry of the same carrier
+        layout and modulation, whose last stream calls demodulated them) become this context's — what ONE OFDMDemodulator object
+        carries from a processPresynced() frame into the Schmidl-Cox frame that follows it without reset()."""
+        check(self.lib.ultra_hip_stream_adopt(self._ctx, src._ctx, int(n_frames)), "ultra_hip_stream_adopt")
+
     def demod_into(self, audio, llr, cfo_hz=None, cfo_phase=None):
         """Demodulate into the rows of a caller-owned LLR array whose row stride may exceed llrs_per_frame
         (ultra_hip_demod_batch_strided): llr = a [n][>= llrs_per_frame] f32 view with unit column stride — e.g. a row

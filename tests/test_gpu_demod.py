@@ -652,6 +652,18 @@ def test_stream_and_block_entries_refuse_bad_arguments():
         ctx.demod_into(a, llr[:4, :600])                                  # rows shorter than llrs_per_frame
     r = ctx.ldpc_decode_blocks(llr, 16, 32, 2)
     assert r["ok"].shape[0] == 32
+    # ultra_hip_stream_adopt: records travel between the two entries of ONE layout only, and only records that exist
+    ps = context_for(make_config(1024, "QAM16", "R3_4", entry=1))
+    other = context_for(make_config(512, "DQPSK", "R1_2"))
+    with pytest.raises(UltraHipError):
+        ctx.adopt_tracker(other)                                          # another carrier layout
+    with pytest.raises(UltraHipError):
+        ctx.adopt_tracker(ctx)                                            # itself
+    with pytest.raises(UltraHipError):
+        ctx.adopt_tracker(ps, 4)                                          # the presynced context has demodulated nothing yet
+    a_ps = torch.zeros((4, geometry(make_config(1024, "QAM16", "R3_4", entry=1)).frame_samples), dtype=torch.float32, device="cuda")
+    ps.demod(a_ps)
+    ctx.adopt_tracker(ps, 4)
     # the mid-frame check: a window that does not reach n_samples, samples fed before the window's origin; a buffer shorter
     # than six preamble symbols is not an error — nothing is found
     resume = torch.tensor([[100, 9000, 0, 0]] * 4, dtype=torch.int32, device="cuda")
