@@ -18,6 +18,7 @@
 #pragma once
 
 #include <algorithm>
+#include <atomic>
 #include <cmath>
 #include <complex>
 #include <cstdint>
@@ -95,6 +96,19 @@ namespace detail {
 inline void check(int rc, const char* what) {
     if (rc != ULTRA_HIP_OK) throw std::runtime_error(std::string(what) + ": " + ultra_hip_strerror(rc));
 }
+// The reference's receive interface reports failure as false / empty and never throws ("Errors"); its callers —
+// RxPipeline on the audio thread, ModemEngine's decode thread — have no handler, so an exception there is std::terminate.  Every
+// entry the reference's callers reach (the IWaveform overrides, the pimpl classes' members) runs through this: a failing C-ABI
+// call (device lost, out of memory) is reported on stderr — loudly, every time — and becomes the interface's failure value.
+template <class R, class F>
+inline R guarded(const char* what, R failure, F&& body) noexcept {
+    try { return body(); }
+    catch (const std::exception& e) { std::fprintf(stderr, "ultra_hip: %s FAILED: %s\n", what, e.what()); }
+    catch (...) { std::fprintf(stderr, "ultra_hip: %s FAILED\n", what); }
+    return failure;
+}
+template <class F>
+inline void guarded_void(const char* what, F&& body) noexcept { (void)guarded<int>(what, 0, [&] { body(); return 0; }); }
 struct Ctx {                               // RAII owner of an ultra_hip_ctx
     ultra_hip_ctx* p = nullptr;
     Ctx() = default;
@@ -191,7 +205,8 @@ public:
     // (src/fec/ldpc_decoder.cpp:283-428): <= 648 LLRs one block (zero padded), more -> every full block
     // contributes exactly k bits, a zero-padded tail block is decoded too, bits packed once at the end.
     Bytes decodeSoft(std::span<const float> llrs) {
-        if (llrs.empty()) { last_success_ = false; return {}; }
+        last_success_ = false;                                           // (stays false if the launch below fails)
+        if (llrs.empty()) return {};
         const size_t n = 648, nblocks = (llrs.size() + n - 1) / n;
         const ultra_hip_geometry& g = geometry();
         padded_.assign(nblocks * n, 0.0f);
@@ -390,6 +405,11 @@ public:
         if (samples.size() < sym) return false;
         ensure();
         const uint32_t n_train = training_symbols > 0 ? uint32_t(training_symbols) : 0u;
+        if (samples.size() / sym < n_train) {
+            // fewer whole symbols than training symbols: the reference reads past the span here (:935-941) — undefined there; here
+            // the call is refused before it touches the object's state, like the too-short call above
+            return false;
+        }
         if (!ps_slot_ || ps_train_ != n_train) {
             ps_slot_ = detail::PooledSlot(to_c_config(config_, ULTRA_ENTRY_PRESYNCED, kMaxSymbolsBeforeTimeout + 1, n_train), device_);
             ps_train_ = n_train;
@@ -403,7 +423,7 @@ public:
         synced_ = true; live_ps_ = true; carry_ = false; ps_carry_ = true;   // this frame's tracker lives in the PRESYNCED context
         appendSamples(samples);
         uint32_t n_sym = static_cast<uint32_t>(samples.size() / sym);
-        if (n_sym < n_train || n_sym == 0) return false;                 // (the reference reads past the span here)
+        if (n_sym == 0) return false;
         if (n_sym > n_train + uint32_t(kMaxSymbolsBeforeTimeout + 1)) {
             std::fprintf(stderr, "ultra_hip: processPresynced: %u data symbols in one call, %d demodulated (context capacity)\n",
                          n_sym - n_train, kMaxSymbolsBeforeTimeout + 1);
@@ -444,7 +464,7 @@ public:
         demod_soft_.clear();
         return data;
     }
-    HipChannelQuality getChannelQuality() const { return quality_; }    // Impl::updateQuality (:437-451) after every symbol
+    HipChannelQuality getChannelQuality() const { std::lock_guard<std::mutex> l(gui_m_); return quality_; }   // Impl::updateQuality (:437-451) after every symbol
     float getEstimatedSNR() const { return 10.0f * std::log10(state_[ULTRA_HIP_STATE_SNR_LINEAR]); }   // :797-799
     float getFrequencyOffset() const { return freq_offset_hz_; }
     float coarseCFO() const { return coarse_cfo_; }                     // Impl::estimateCoarseCFO at the last sync
@@ -456,8 +476,8 @@ public:
         else pending_cfo_ = true;                                       // SYNCED before the first symbol: symbol 0 starts from it (a sync found later overwrites it: :535-537)
     }
     // the GUI's scatter plot (:827-830): the newest MAX_CONSTELLATION_SYMBOLS equalized data carriers; never cleared, as in the reference
-    std::vector<std::complex<float>> getConstellationSymbols() const { return constellation_; }
-    bool isSynced() const { return synced_; }
+    std::vector<std::complex<float>> getConstellationSymbols() const { std::lock_guard<std::mutex> l(gui_m_); return constellation_; }
+    bool isSynced() const { return synced_.load(); }
     bool hasPendingData() const {                                       // :836-844
         return synced_ && (!demod_soft_.empty() || fed_ - origin_ >= symbolSamples());
     }
@@ -556,6 +576,7 @@ private:
         std::memcpy(state_, stage_.data(), sizeof(state_));
         demod_soft_.insert(demod_soft_.end(), stage_.begin() + ULTRA_HIP_STATE_FLOATS, stage_.begin() + ULTRA_HIP_STATE_FLOATS + n_llr);
         // demodulateSymbol (demodulator.cpp:199-208): every data symbol appends its equalized carriers; the newest 500 stay
+        std::lock_guard<std::mutex> l(gui_m_);
         for (size_t s = 0; s < n_sym; ++s) {
             const float* row = stage_.data() + eqOffset(n_llr) + s * 2 * ULTRA_HIP_MAX_CARRIERS;
             for (uint32_t i = 0; i < geo_.n_data_carriers; ++i) constellation_.emplace_back(row[2 * i], row[2 * i + 1]);
@@ -580,7 +601,12 @@ private:
     uint32_t origin_ = 0, fed_ = 0, d_origin_ = 0;   // the device window holds samples from d_origin_ <= origin_ on
     uint32_t noise_floor_bits_ = 0, last_sync_offset_ = 0, synced_symbols_ = 0, epoch_ = 0;
     int idle_calls_ = 0, manual_timing_offset_ = 0, start_mode_ = ULTRA_STREAM_START_FRESH;
-    bool synced_ = false, pending_cfo_ = false, chirp_cfo_estimated_ = false;
+    // read by the GUI thread while the audio thread runs process() (ModemEngine::isSynced / getChannelQuality /
+    // getConstellationSymbols, modem_engine.cpp:812-827); the reference keeps its sync state atomic and its constellation buffer
+    // behind a mutex (demodulator_impl.hpp:28-32,54) — so does this
+    std::atomic<bool> synced_{false};
+    mutable std::mutex gui_m_;               // constellation_, quality_
+    bool pending_cfo_ = false, chirp_cfo_estimated_ = false;
     bool carry_ = false;                     // the SYNCED context holds a frame's tracker of THIS object (no reset() since)
     bool ps_carry_ = false;                  // ... the PRESYNCED context does: the last frame came through processPresynced
     bool live_ps_ = false;                   // the frame in flight lives in the PRESYNCED context
@@ -625,14 +651,25 @@ public:
         config_.use_pilots = false;
         initComponents();
     }
-    void setFrequencyOffset(float cfo_hz) { cfo_hz_ = cfo_hz; demod_->setFrequencyOffset(cfo_hz); }   // :86-91
+    void setFrequencyOffset(float cfo_hz) {                            // :86-91
+        cfo_hz_ = cfo_hz;
+        detail::guarded_void("HipOfdmWaveform::setFrequencyOffset", [&] { demod_->setFrequencyOffset(cfo_hz); });
+    }
     Modulation getModulation() const { return config_.modulation; }
     CodeRate getCodeRate() const { return config_.code_rate; }
     float getFrequencyOffset() const { return cfo_hz_; }
 
     // OFDMChirpWaveform::detectSync (src/waveform/ofdm_chirp_waveform.cpp:129-172): dual-chirp detection on the
     // device (scope row f4, ultra_hip_chirp_sync_batch); start_sample = where the two training symbols start.
+    // No exception leaves an IWaveform: a failing C-ABI call is reported on stderr and reads as "not detected" / "not ready".
     bool detectSync(SampleSpan samples, SyncResult& result, float threshold = 0.15f) {
+        return detail::guarded<bool>("HipOfdmWaveform::detectSync", false, [&] { return detectSyncImpl(samples, result, threshold); });
+    }
+    bool process(SampleSpan samples) {
+        return detail::guarded<bool>("HipOfdmWaveform::process", false, [&] { return processImpl(samples); });
+    }
+private:
+    bool detectSyncImpl(SampleSpan samples, SyncResult& result, float threshold) {
         if (!sync_slot_) sync_slot_ = detail::PooledSlot(to_c_config(config_, ULTRA_ENTRY_PRESYNCED, 1, 2), device_);
         char* d = static_cast<char*>(sync_slot_.buf(0, 4 * sizeof(uint32_t) + std::max<size_t>(samples.size(), 1) * sizeof(float)));
         uint32_t* o = reinterpret_cast<uint32_t*>(d);
@@ -656,14 +693,16 @@ public:
         last_sync_ = result;
         return result.detected;
     }
+public:
     // ... or an external synchroniser hands in what detectSync would have filled
     void acceptSync(const SyncResult& r) {
         last_sync_ = r; synced_ = r.detected; cfo_hz_ = r.cfo_hz; training_start_ = r.start_sample > 0 ? r.start_sample : 0;
-        demod_->setFrequencyOffset(r.cfo_hz);
+        detail::guarded_void("HipOfdmWaveform::acceptSync", [&] { demod_->setFrequencyOffset(r.cfo_hz); });
     }
 
+private:
     // samples start at the first of two training symbols (OFDMChirpWaveform::process, :174-215)
-    bool process(SampleSpan samples) {
+    bool processImpl(SampleSpan samples) {
         // float initial_phase_rad = -2.0f * M_PI * cfo_hz_ * training_start_sample_ / sample_rate (double expr)
         float phase = static_cast<float>((((-2.0 * M_PI) * double(cfo_hz_)) * double(training_start_)) /
                                          double(config_.sample_rate));
@@ -681,9 +720,10 @@ public:
         }
         return ready;
     }
+public:
     std::vector<float> getSoftBits() { return std::move(soft_bits_); }
     void reset() {                                                        // :221-230; the preset CFO survives
-        demod_->reset();
+        detail::guarded_void("HipOfdmWaveform::reset", [&] { demod_->reset(); });
         soft_bits_.clear(); synced_ = false;
     }
     bool isSynced() const { return synced_ || demod_->isSynced(); }    // :232-234
@@ -844,14 +884,18 @@ public:
         config_.use_pilots = !(mod == Modulation::DBPSK || mod == Modulation::DQPSK || mod == Modulation::D8PSK);
         initComponents();
     }
-    void setFrequencyOffset(float cfo_hz) { cfo_hz_ = cfo_hz; demod_->setFrequencyOffset(cfo_hz); }   // :70-75
+    void setFrequencyOffset(float cfo_hz) {                            // :70-75
+        cfo_hz_ = cfo_hz;
+        detail::guarded_void("HipOfdmCoxWaveform::setFrequencyOffset", [&] { demod_->setFrequencyOffset(cfo_hz); });
+    }
     Modulation getModulation() const { return config_.modulation; }
     CodeRate getCodeRate() const { return config_.code_rate; }
     float getFrequencyOffset() const { return cfo_hz_; }
 
     // OFDMNvisWaveform::detectSync (:98-120): feed the demodulator, report whether it is synced
+    // No exception leaves an IWaveform: a failing C-ABI call is reported on stderr and reads as "not detected" / "not ready".
     bool detectSync(SampleSpan samples, SyncResult& result, float /*threshold*/ = 0.3f) {
-        demod_->process(samples);
+        detail::guarded_void("HipOfdmCoxWaveform::detectSync", [&] { demod_->process(samples); });
         if (!demod_->isSynced()) return false;
         result.detected = true;
         result.start_sample = static_cast<int>(demod_->getLastSyncOffset());
@@ -861,12 +905,15 @@ public:
         return true;
     }
     bool process(SampleSpan samples) {                                  // :122-134
-        const bool ready = demod_->process(samples);
+        const bool ready = detail::guarded<bool>("HipOfdmCoxWaveform::process", false, [&] { return demod_->process(samples); });
         if (ready) soft_bits_ = demod_->getSoftBits();
         return ready;
     }
     std::vector<float> getSoftBits() { return std::move(soft_bits_); }
-    void reset() { demod_->reset(); soft_bits_.clear(); }              // :140-147 -> OFDMDemodulator::reset (:987-1017)
+    void reset() {                                                      // :140-147 -> OFDMDemodulator::reset (:987-1017)
+        detail::guarded_void("HipOfdmCoxWaveform::reset", [&] { demod_->reset(); });
+        soft_bits_.clear();
+    }
     bool isSynced() const { return demod_->isSynced(); }
     bool hasData() const { return !soft_bits_.empty() || demod_->hasPendingData(); }   // :153-155
     float estimatedSNR() const { return demod_->getEstimatedSNR(); }

@@ -69,8 +69,15 @@ struct LDPCDecoder::Impl {
 LDPCDecoder::LDPCDecoder(CodeRate rate) : impl_(std::make_unique<Impl>(rate)) {}
 LDPCDecoder::~LDPCDecoder() = default;
 
-Bytes LDPCDecoder::decode(ByteSpan coded_data) { return impl_->d.decode(std::span<const uint8_t>(coded_data.data(), coded_data.size())); }
-Bytes LDPCDecoder::decodeSoft(std::span<const float> llrs) { return impl_->d.decodeSoft(llrs); }
+// No exception leaves the class: a failing C-ABI call is reported on stderr and the decode counts as failed (empty result,
+// lastDecodeSuccess() false) — the reference's decoder does not throw, and RxPipeline calls it on the audio thread.
+Bytes LDPCDecoder::decode(ByteSpan coded_data) {
+    return ultra_hip::detail::guarded<Bytes>("LDPCDecoder::decode", Bytes{}, [&] {
+        return impl_->d.decode(std::span<const uint8_t>(coded_data.data(), coded_data.size())); });
+}
+Bytes LDPCDecoder::decodeSoft(std::span<const float> llrs) {
+    return ultra_hip::detail::guarded<Bytes>("LDPCDecoder::decodeSoft", Bytes{}, [&] { return impl_->d.decodeSoft(llrs); });
+}
 bool LDPCDecoder::lastDecodeSuccess() const { return impl_->d.lastDecodeSuccess(); }
 int LDPCDecoder::lastIterations() const { return impl_->d.lastIterations(); }
 void LDPCDecoder::setRate(CodeRate rate) { impl_->d.setRate(rate); }

@@ -42,8 +42,17 @@ struct OFDMDemodulator::Impl {
 OFDMDemodulator::OFDMDemodulator(const ModemConfig& config) : impl_(std::make_unique<Impl>(config)) {}
 OFDMDemodulator::~OFDMDemodulator() = default;
 
-bool OFDMDemodulator::process(SampleSpan samples) { return impl_->d.process(samples); }
-bool OFDMDemodulator::processPresynced(SampleSpan samples, int training_symbols) { return impl_->d.processPresynced(samples, training_symbols); }
+// No exception leaves the class (the reference's members do not throw, and its callers run them on threads without a handler):
+// a failing C-ABI call is reported on stderr and becomes the member's failure value (ultra_hip::detail::guarded).
+using ultra_hip::detail::guarded;
+using ultra_hip::detail::guarded_void;
+
+bool OFDMDemodulator::process(SampleSpan samples) {
+    return guarded<bool>("OFDMDemodulator::process", false, [&] { return impl_->d.process(samples); });
+}
+bool OFDMDemodulator::processPresynced(SampleSpan samples, int training_symbols) {
+    return guarded<bool>("OFDMDemodulator::processPresynced", false, [&] { return impl_->d.processPresynced(samples, training_symbols); });
+}
 Bytes OFDMDemodulator::getData() { return impl_->d.getData(); }
 std::vector<float> OFDMDemodulator::getSoftBits() { return impl_->d.getSoftBits(); }
 
@@ -55,16 +64,18 @@ ChannelQuality OFDMDemodulator::getChannelQuality() const {
 }
 float OFDMDemodulator::getEstimatedSNR() const { return impl_->d.getEstimatedSNR(); }
 float OFDMDemodulator::getFrequencyOffset() const { return impl_->d.getFrequencyOffset(); }
-void OFDMDemodulator::setFrequencyOffset(float cfo_hz) { impl_->d.setFrequencyOffset(cfo_hz); }
+void OFDMDemodulator::setFrequencyOffset(float cfo_hz) {
+    guarded_void("OFDMDemodulator::setFrequencyOffset", [&] { impl_->d.setFrequencyOffset(cfo_hz); });
+}
 void OFDMDemodulator::setFrequencyOffsetWithPhase(float cfo_hz, float initial_phase_rad) {
-    impl_->d.setFrequencyOffsetWithPhase(cfo_hz, initial_phase_rad);
+    guarded_void("OFDMDemodulator::setFrequencyOffsetWithPhase", [&] { impl_->d.setFrequencyOffsetWithPhase(cfo_hz, initial_phase_rad); });
 }
 Symbol OFDMDemodulator::getConstellationSymbols() const { return impl_->d.getConstellationSymbols(); }
 bool OFDMDemodulator::isSynced() const { return impl_->d.isSynced(); }
 bool OFDMDemodulator::hasPendingData() const { return impl_->d.hasPendingData(); }
 size_t OFDMDemodulator::getLastSyncOffset() const { return impl_->d.getLastSyncOffset(); }
 void OFDMDemodulator::setTimingOffset(int offset) { impl_->d.setTimingOffset(offset); }
-void OFDMDemodulator::reset() { impl_->d.reset(); }
+void OFDMDemodulator::reset() { guarded_void("OFDMDemodulator::reset", [&] { impl_->d.reset(); }); }
 
 // ---------------------------------------------------------------------------------------------
 // ultra::ChannelEstimator (include/ultra/ofdm.hpp:134-156): per-index one-tap estimate, h <- (h + rx / expected) / 2 where the

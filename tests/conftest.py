@@ -29,6 +29,18 @@ def pytest_collection_modifyitems(config, items):
             item.add_marker(skip)
 
 
+def pytest_terminal_summary(terminalreporter):
+    """ONE line for every test skipped because a checker binary of oracle/_ref was not built (tests/_refprogs.py: with
+    oracle/_ref/MANIFEST present or ULTRA_REQUIRE_REF=1 those are failures instead)."""
+    try:
+        from _refprogs import SKIPPED
+    except Exception:
+        return
+    if SKIPPED:
+        terminalreporter.write_line(f"checker binaries missing: {len(SKIPPED)} tests SKIPPED for lack of oracle/_ref programs "
+                                    f"(no oracle/_ref/MANIFEST, ULTRA_REQUIRE_REF unset) — first: {SKIPPED[0]}", yellow=True)
+
+
 @pytest.fixture(scope="session")
 def oracle():
     from oracle.bindings import oracle as get

@@ -18,6 +18,8 @@ from pathlib import Path
 
 import pytest
 
+from _refprogs import require
+
 pytestmark = pytest.mark.gpu
 ROOT = Path(__file__).resolve().parent.parent
 TOOLS = ROOT / "oracle" / "_ref" / "tools"
@@ -50,8 +52,7 @@ def _run(exe, args):
 @pytest.mark.parametrize("name,args", CASES, ids=[f"{n}{'_'.join([''] + a)}" for n, a in CASES])
 def test_reference_tool_runs_unmodified_on_the_hip_path(name, args):
     ref, hip = TOOLS / f"{name}.ref", TOOLS / f"{name}.hip"
-    if not ref.exists() or not hip.exists():
-        pytest.skip(f"oracle/_ref/tools/{name}.* not built (needs /root/reference: `make -C oracle tools`)")
+    require(ref, hip)                                                # missing: fails when oracle/_ref/MANIFEST exists, else skips
     rc_ref, out_ref, _ = _run(ref, args)
     rc_hip, out_hip, err_hip = _run(hip, args)
     assert out_ref.strip(), "the reference build must print something for the comparison to mean anything"
@@ -63,14 +64,14 @@ def test_reference_tool_runs_unmodified_on_the_hip_path(name, args):
 
 
 def test_the_hip_builds_do_not_link_the_reference_receive_path():
-    """The .hip binaries must get OFDMDemodulator / LDPCDecoder from the drop-ins: no libultra_ref.so among their
-    dependencies (it holds the reference's demodulator and decoder), libultra_hip.so present."""
+    """The .hip binaries must get OFDMDemodulator / LDPCDecoder from the drop-ins: neither libultra_ref.so nor
+    libultra_ref_rx.so among their dependencies (they hold the reference's demodulator and decoder), libultra_hip.so and the
+    drop-in library present.  (tests/test_gpu_ref_programs.py checks this for every program of the manifest.)"""
     exe = TOOLS / "test_nvis_mode.hip"
-    if not exe.exists():
-        pytest.skip("oracle/_ref/tools not built")
+    require(exe)
     deps = subprocess.run(["ldd", str(exe)], capture_output=True, text=True).stdout
-    assert "libultra_hip.so" in deps and "libultra_ref_tx.so" in deps
-    assert "libultra_ref.so" not in deps
+    assert "libultra_hip.so" in deps and "libultra_hip_rx.so" in deps and "libultra_ref_core.so" in deps
+    assert "libultra_ref.so " not in deps and "libultra_ref_rx.so" not in deps
 
 
 # ---------------------------------------------------------------------------------------------------------------------
@@ -108,8 +109,7 @@ def _stdout(out):
 @pytest.mark.parametrize("args", HF_CASES, ids=["_".join(a).replace("/", "") for a in HF_CASES])
 def test_hf_modem_through_the_factory(args):
     exes = {k: TOOLS / f"test_hf_modem.{k}" for k in ("ref", "pimpl", "hip")}
-    if not all(e.exists() for e in exes.values()):
-        pytest.skip("oracle/_ref/tools/test_hf_modem.* not built (needs /root/reference: `make -C oracle tools`)")
+    require(*exes.values())
     rc_ref, out_ref, err_ref = _run(exes["ref"], args + ["-v"])
     log_ref = _pipeline_log(err_ref)
     assert any("Sync detected" in l for l in log_ref), "the reference's pipeline must at least synchronise for the comparison to mean anything"
@@ -150,8 +150,7 @@ HARNESS_CASES = [
 @pytest.mark.parametrize("sc,fft,mod,rate,seed", HARNESS_CASES, ids=[f"{c[0]}_{c[1]}_{c[2]}_{c[3]}" for c in HARNESS_CASES])
 def test_pimpl_classes_scripted(sc, fft, mod, rate, seed):
     ref, hip = TOOLS / "demod_pimpl_harness.ref", TOOLS / "demod_pimpl_harness.hip"
-    if not ref.exists() or not hip.exists():
-        pytest.skip("oracle/_ref/tools/demod_pimpl_harness.* not built (needs /root/reference: `make -C oracle tools`)")
+    require(ref, hip)
     args = [sc, str(fft), str(MOD[mod]), str(RATE[rate]), str(seed)]
     rc_ref, out_ref, err_ref = _run(ref, args)
     assert rc_ref == 0, err_ref[-800:]

@@ -1,0 +1,251 @@
+"""Every program of the reference that constructs the replaced classes — its ctest suite, its command-line tools, its
+ModemEngine programs — built UNMODIFIED from one manifest (oracle/ref_programs.txt, oracle/Makefile) and run side by side:
+
+    .ref    the reference throughout (CPU)
+    .hip    the product's link-time drop-ins + the product's waveform factory over libultra_hip.so (MI355X)
+    .pimpl  (ModemEngine programs) the drop-ins under the REFERENCE's factory and waveform classes
+
+Same arguments, same seeds.  Programs that run on one thread must print IDENTICAL stdout and return the same exit code —
+the reference's own PASS / FAIL verdicts included (where a reference test fails on the reference, it must fail the same way on
+the GPU).  ModemEngine programs run an acquisition thread and a decode thread beside the caller's (modem_rx.cpp:18-36,153-256),
+so WHEN things are printed varies; for those the comparison is over what is deterministic — which frames were decoded, payload
+bytes, the pipeline's logged decisions, the verdict and the exit code — as each case's normaliser states.
+
+(tests/test_gpu_pimpl.py holds the five programs and the scripted harness of the earlier rounds; this file holds the rest of the
+manifest.  tests/test_manifest.py, CPU, checks that the manifest covers the reference's tests/ and tools/.)"""
+import os
+import re
+
+import pytest
+
+from _refprogs import VARIANTS, exe, kind_of, require, run_all
+
+pytestmark = pytest.mark.gpu
+
+
+def _no_chirp_debug(out):
+    """The reference's header-only ChirpSync printf()s its intermediate peaks to stdout ("[CHIRP-RX] ...",
+    src/sync/chirp_sync.hpp); the product's factory detects the chirps on the GPU and has no such debug print.  What the
+    detection RETURNS (start sample, CFO) is printed by the programs themselves and compared."""
+    return [l for l in out.splitlines() if not l.startswith("[CHIRP-RX] Dual chirp") and not l.startswith("[CHIRP-RX] Position")
+            and not re.match(r"\[CHIRP-RX\] CFO estimate: .* \(cfo_to_samples", l)]
+
+
+def _compare(name, args, outs, normalise=_no_chirp_debug, same_rc=True):
+    rc_ref, out_ref, err_ref = outs["ref"]
+    a = normalise(out_ref)
+    assert a, f"{name}: the reference build must print something for the comparison to mean anything\n{err_ref[-600:]}"
+    for v, (rc, out, err) in outs.items():
+        if v == "ref":
+            continue
+        b = normalise(out)
+        for i, (x, y) in enumerate(zip(a, b)):
+            assert x == y, (f"{name}.{v} {args}: line {i} differs\n  reference: {x[:300]}\n  {v}: {y[:300]}\n"
+                            f"  before: {[l[:100] for l in a[max(0, i - 3):i]]}\n  stderr tail: {err[-800:]}")
+        assert len(a) == len(b), (name, v, len(a), len(b), b[-3:], err[-800:])
+        if same_rc:
+            assert rc == rc_ref, (name, v, rc_ref, rc, err[-800:])
+
+
+def _run(name, args, tmp_path, **kw):
+    variants = VARIANTS[kind_of(name)]
+    require(*[exe(name, v) for v in variants])
+    return run_all(name, args, variants, cwd=tmp_path, **kw)
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# One thread, fixed seeds: stdout byte for byte.
+EXACT = [
+    # --- the reference's ctest suite (/root/reference/tests/CMakeLists.txt:8-108), as ctest runs it
+    ("test_multiblock_ldpc", []),            # exact byte round trips, all rates, multi-codeword, interleaved (:104-488)
+    ("test_comprehensive_modem", []),        # decoder behaviours, DQPSK LLR sign table, full chain (:59-768)
+    ("test_layers", []),                     # layer-by-layer OFDM verification (:668-912 construct the demodulator)
+    ("test_ofdm", []),
+    ("test_modem_loopback", []),
+    ("test_wav_loopback", ["--loopback"]),
+    ("test_interleaver", []),                # the drop-in DEFINES Interleaver / ChannelInterleaver (:20-147)
+    ("test_frame_v2_modem", []),             # fails 1 of 3 on the reference: the same one must fail here
+    ("test_protocol_modem", []),             # 10/11 on the reference
+    ("test_adaptive_link", []),
+    # --- command-line tools (CMakeLists.txt:145-305)
+    ("test_throughput", []),                 # north_star names it: TX-only (tools/test_throughput.cpp:78-134), Interleaver(6,108) from the drop-in
+    ("test_otfs_vs_ofdm", ["--snr", "20", "--trials", "5"]),        # SURVEY 3.1's Watterson harness; src/otfs/otfs.cpp compiled where it lies
+    ("test_otfs_vs_ofdm", ["--snr", "12", "--trials", "4", "--awgn"]),
+    ("test_coherent_quick", []),
+    ("test_hf_reality", ["--frames", "4", "--duration", "20", "-o", "hf.f32"]),
+    ("test_hf_reality", ["--frames", "3", "--duration", "15", "--mode", "16qam", "--snr", "28", "-o", "hf.f32"]),
+    ("test_single_frame", []),
+    ("test_simple_noise", []),
+    ("test_nvis_data", []),
+    ("test_ofdm_chirp_waveform", []),
+    ("test_ofdm_chirp_cfo", ["200", "0"]),   # its noise is seeded from std::random_device: at 200 dB the draw no longer reaches the printed digits
+    ("test_ofdm_chirp_cfo", ["200", "25"]),
+    ("test_dpsk_snr", []),                   # the decoder alone under the reference's single-carrier DPSK
+    ("test_mc_dpsk", []),
+    ("test_mc_dpsk_frame", []),              # MC-DPSK frames, LDPCDecoder from the drop-in
+    # --- the legacy facade ultra::Modem (src/modem/modem.cpp:79-112,133-194) through oracle/legacy_modem_harness.cpp
+    ("legacy_modem_harness", ["25", "3"]),
+    ("legacy_modem_harness", ["14", "5"]),
+    ("legacy_modem_harness", ["30", "7", "512", "2", "2"]),
+]
+
+
+@pytest.mark.parametrize("name,args", EXACT, ids=[f"{n}{'_'.join([''] + [a.replace('/', '') for a in args])}" for n, args in EXACT])
+def test_reference_program_stdout_identical(name, args, tmp_path):
+    _compare(name, args, _run(name, args, tmp_path))
+
+
+def test_ofdm_chirp_cfo_default_noise(tmp_path):
+    """tools/test_ofdm_chirp_cfo.cpp at its default 15 dB: the noise comes from std::random_device (:81-82), so two runs of the
+    REFERENCE differ in the estimated SNR and the correlation; everything else — sync position, CFO estimate, soft-bit count, decode
+    and verification verdicts — must agree."""
+    def norm(out):
+        return [l for l in _no_chirp_debug(out) if not l.startswith("Estimated SNR") and "Correlation:" not in l]
+    _compare("test_ofdm_chirp_cfo", [], _run("test_ofdm_chirp_cfo", [], tmp_path), normalise=norm)
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# tools/test_iwaveform.cpp — what /root/reference/tests/regression_matrix.sh:16-23 calls its PRIMARY tool.  The quick matrix
+# (:138-185): the five OFDM_CHIRP rows (a TX ModemEngine with its threads alive while ONE OFDMChirpWaveform + LDPCDecoder
+# receive the stream) and two MC-DPSK rows (RX through ModemEngine::feedAudio: acquisition thread -> frame queue -> decode
+# thread -> LDPC), plus one OFDM_COX scenario.  Deterministic: everything the program prints, with the decode thread's
+# "[RX] Decoded" lines — printed when the thread gets there — compared as a set.
+IWAVEFORM = [
+    ["--snr", "17", "--cfo", "0", "--channel", "awgn", "-w", "ofdm_chirp", "--frames", "5"],
+    ["--snr", "17", "--cfo", "30", "--channel", "awgn", "-w", "ofdm_chirp", "--frames", "5"],
+    ["--snr", "17", "--cfo", "50", "--channel", "awgn", "-w", "ofdm_chirp", "--frames", "5"],
+    ["--snr", "15", "--cfo", "0", "--channel", "moderate", "-w", "ofdm_chirp", "--rate", "r1_4", "--frames", "5"],
+    ["--snr", "15", "--cfo", "30", "--channel", "moderate", "-w", "ofdm_chirp", "--rate", "r1_4", "--frames", "5"],
+    ["--snr", "5", "--cfo", "30", "--channel", "awgn", "-w", "mc_dpsk", "--frames", "3"],
+    ["--snr", "5", "--cfo", "0", "--channel", "moderate", "-w", "mc_dpsk", "--frames", "3"],
+    ["--snr", "20", "--cfo", "0", "--channel", "awgn", "-w", "ofdm_cox", "--frames", "1"],
+]
+
+
+def _iwaveform_norm(out):
+    lines = _no_chirp_debug(out)
+    threaded = sorted(l for l in lines if l.startswith("  [RX] Decoded"))
+    return [l for l in lines if not l.startswith("  [RX] Decoded")] + threaded
+
+
+@pytest.mark.parametrize("args", IWAVEFORM, ids=["_".join(a).replace("--", "") for a in IWAVEFORM])
+def test_iwaveform_regression_matrix(args, tmp_path):
+    outs = _run("test_iwaveform", args, tmp_path)
+    _compare("test_iwaveform", args, outs, normalise=_iwaveform_norm)
+    if "ofdm_chirp" in args or "mc_dpsk" in args:
+        assert "Decoded: 0/" not in outs["ref"][1], "the reference must decode something for the row to mean anything"
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# oracle/engine_thread_harness.cpp: two ModemEngines alive, audio on a feeder thread, the GUI's getters polled from another,
+# mode changes from a third, MC-DPSK through the acquisition and decode threads.  stdout (delivered frames in hex, counts) and
+# the RX pipeline's logged decisions must be identical across the three builds.
+_STAMP = re.compile(r"^\[\s*\d+\.\d+\]")
+
+
+def _pipeline_log(stderr):
+    # "[RX] RxPipeline: Frame decoded/failed" is the decode thread's 10 ms poll (modem_rx.cpp:197-222): whether the last one is
+    # printed before the engine is destroyed is a matter of timing; the pipeline's own lines come from the feeding thread
+    return [_STAMP.sub("", l) for l in stderr.splitlines() if "] RxPipeline: " in l and "RxPipeline: Frame decoded," not in l
+            and "RxPipeline: Frame failed," not in l]
+
+
+@pytest.mark.parametrize("scenario,seed,snr", [("cox", 3, "28"), ("chirp", 5, "26"), ("dpsk", 7, "28"), ("all", 11, "30")])
+def test_engine_thread_harness(scenario, seed, snr, tmp_path):
+    outs = _run("engine_thread_harness", [scenario, str(seed), snr], tmp_path)
+    _compare("engine_thread_harness", [scenario, seed], outs)
+    log_ref = _pipeline_log(outs["ref"][2])
+    if scenario != "dpsk":
+        assert any("Sync detected" in l for l in log_ref), "the reference's pipeline must at least synchronise"
+    if scenario in ("chirp", "all"):
+        assert any("Frame decode SUCCESS" in l for l in log_ref), log_ref[-5:]
+    if scenario in ("dpsk", "all"):
+        assert "delivered 2" in outs["ref"][1]
+    for v in ("pimpl", "hip"):
+        log = _pipeline_log(outs[v][2])
+        for i, (x, y) in enumerate(zip(log_ref, log)):
+            assert x == y, f"{v} {scenario}: RxPipeline log line {i} differs\n  reference: {x}\n  {v}: {y}\n  before: {log_ref[max(0, i - 3):i]}"
+        assert len(log) == len(log_ref), (v, len(log), len(log_ref))
+        assert "[harness]" in outs[v][2]                              # the GUI polls ran beside the feed
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# The reference's other ModemEngine programs.  They sleep in real time and print as their threads get there; compared: the
+# lines that state results, and the exit code.
+def _verdicts(patterns):
+    rx = re.compile("|".join(patterns))
+    return lambda out: [l.rstrip() for l in _no_chirp_debug(out) if rx.search(l)]
+
+
+def test_modem_engine_loopback(tmp_path):
+    """tools/test_modem_engine_loopback.cpp: ten RX engines built and destroyed in turn beside one TX engine.  (On the reference it
+    receives 0/10 — RxPipeline only searches every 48,000 fed samples, rx_pipeline.cpp:70-76, and the program feeds 30,476 — so
+    what this compares is ten constructions and destructions of engines with live threads, and the same verdict.)"""
+    outs = _run("test_modem_engine_loopback", [], tmp_path)
+    _compare("test_modem_engine_loopback", [], outs)
+
+
+def test_profile_acquisition(tmp_path):
+    """tools/profile_acquisition.cpp:1-35 — per-trial OK / FAIL of OFDM, DPSK and PING acquisition through ModemEngine; the
+    timings it prints are dropped."""
+    def norm(out):
+        keep = []
+        for l in _no_chirp_debug(out):
+            if re.search(r"feed=|Feed time|Wall time|Real-time factor", l):
+                m = re.match(r"\s*\[\s*(\d+)\].*\b(OK|FAIL)\b", l)
+                if m:
+                    keep.append(f"[{m.group(1)}] {m.group(2)}")
+                continue
+            keep.append(l)
+        return keep
+    outs = _run("profile_acquisition", ["--trials", "2"], tmp_path)
+    _compare("profile_acquisition", ["--trials", "2"], outs, normalise=norm)
+    assert "Decoded: 2/2" in outs["ref"][1]
+
+
+LONG = pytest.mark.skipif(os.environ.get("ULTRA_LONG_TESTS") != "1",
+                          reason="real-time programs, 30-130 s per build: ULTRA_LONG_TESTS=1 (run once per round: profiles/r06_long_programs.txt)")
+
+
+@LONG
+def test_cli_simulator(tmp_path):
+    """tools/cli_simulator.cpp: two stations (ModemEngine + ProtocolEngine each) over a simulated channel."""
+    norm = _verdicts([r"PHASE", r"✓", r"✗", r"connected", r"Connected", r"received", r"Received", r"timeout", r"PASS", r"FAIL"])
+    outs = _run("cli_simulator", ["--snr", "20"], tmp_path, timeout=600)
+    _compare("cli_simulator", ["--snr", "20"], outs, normalise=norm)
+
+
+@LONG
+def test_threaded_simulator(tmp_path):
+    norm = _verdicts([r"TEST \d", r"SUCCESS", r"FAILED", r"TIMEOUT", r"PASS"])
+    outs = _run("threaded_simulator", [], tmp_path, timeout=900)
+    _compare("threaded_simulator", [], outs, normalise=norm)
+
+
+@LONG
+def test_sync_robustness(tmp_path):
+    norm = _verdicts([r"PASS", r"FAIL", r"passed", r"failed", r"Result", r"RESULT", r"Summary", r"SUMMARY", r"\d+/\d+"])
+    outs = _run("test_sync_robustness", [], tmp_path, timeout=1500)
+    _compare("test_sync_robustness", [], outs, normalise=norm)
+
+
+def test_hip_builds_link_no_file_of_the_reference_receive_path():
+    """Every .hip / .pimpl binary gets OFDMDemodulator / LDPCDecoder from the drop-ins: libultra_hip_rx.so and libultra_hip.so
+    among its dependencies, libultra_ref_rx.so (the reference's four receive-path files) and libultra_ref.so not; .hip builds
+    take the product's factory, .pimpl builds the reference's."""
+    import subprocess
+    from _refprogs import programs, name_of
+    checked = 0
+    for src, kind in programs():
+        for v in VARIANTS[kind]:
+            if v == "ref":
+                continue
+            path = exe(name_of(src), v)
+            require(path)
+            deps = subprocess.run(["ldd", str(path)], capture_output=True, text=True).stdout
+            assert "libultra_hip_rx.so" in deps and "libultra_hip.so" in deps, (path.name, deps)
+            assert "libultra_ref_rx.so" not in deps and "libultra_ref.so " not in deps, (path.name, deps)
+            assert ("libultra_hip_factory.so" in deps) == (v == "hip"), (path.name, deps)
+            assert ("libultra_ref_factory.so" in deps) == (v == "pimpl"), (path.name, deps)
+            checked += 1
+    assert checked >= 60
