@@ -724,6 +724,15 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         return float(t.item())
 
+    def gather_ranks(values):
+        """every rank's list of host scalars, on every rank: [[rank 0's], [rank 1's], ...]"""
+        if not distributed:
+            return [list(values)]
+        t = torch.tensor(list(values), dtype=torch.float64, device="cpu" if via_host else "cuda")
+        out = [torch.empty_like(t) for _ in range(world)]
+        dist.all_gather(out, t)
+        return [[float(v) for v in o.tolist()] for o in out]
+
     def allreduce(t):
         """SUM over the ranks, in place.  Returns the collective's handle where it was issued asynchronously (RCCL, outside the
         profiled pass): the caller's CounterRing waits for it before the block is used again, barrier() before the clock stops."""
@@ -797,6 +806,13 @@ def main():
     ar_us = float(np.mean([a.elapsed_time(b) for a, b in ar_events]) * 1e3) if ar_events else None
     if ar_host:
         ar_us = float(np.mean(ar_host) * 1e6)
+    # Every rank's own clock over the timed region and the fall-back paths its contexts took (ultra_hip_get_status): a straggler,
+    # or one rank on a slower chain, is visible in the line instead of hidden in the maximum.
+    my_status = [c.status() for c in wl.contexts()]
+    my_flags = 0
+    for st in my_status:
+        my_flags |= st["flags"]
+    per_rank = gather_ranks([elapsed / args.steps * 1e3, float(my_flags)])
     elapsed = reduce_max(elapsed)
     wl.ring.drain()
     last = wl.counters.reshape(-1, 8).sum(dim=0).cpu()
@@ -928,11 +944,31 @@ def main():
                    gpu_matches_cpu_bitwise=head["gpu_matches_bitwise"], verified=getattr(wl, "verified", None), legs=res)
 
     if rank == 0:
+        from projectultra_amd._lib import STATUS_FLAGS
+        rank_ms = [r[0] for r in per_rank]
+        rank_flags = [int(r[1]) for r in per_rank]
+        all_flags = 0
+        for f in rank_flags:
+            all_flags |= f
+        path_status = {"default_path": all_flags == 0, "flags": all_flags,
+                       "paths": [name for bit, name in sorted(STATUS_FLAGS.items()) if all_flags & bit],
+                       "per_rank_flags": rank_flags,
+                       "screen_rank0": [{k: st[k] for k in ("screen_launches", "screen_sample_n", "screen_sample_clean", "screen_gate",
+                                                            "screen_gate_open", "screen_dirty")} for st in my_status],
+                       "note": "ultra_hip_get_status of every context after the timed and the profiled pass: fall-back paths taken (sticky bits, "
+                               "OR over contexts and ranks) and the decoder screen's last decision; a line with default_path false was "
+                               "NOT measured on the kernels DESIGN.md describes as the default"}
+        if roofline is not None:
+            roofline["path_status"] = path_status
+        if all_flags:
+            wl.workload += " [NOT THE DEFAULT PATH: " + ", ".join(path_status["paths"]) + "]"
         total = getattr(wl, "total_units", wl.units_per_step * world) * args.steps
         value = total / elapsed
         line = {
             "metric": wl.metric, "value": value, "unit": wl.unit, "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "untimed_priming_steps": n_prime + 2,
-            "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": getattr(wl, "scaling", "weak"), "vs_baseline": None,
+            "ms_per_step": elapsed / args.steps * 1e3,
+            "ms_per_step_ranks": {"min": min(rank_ms), "max": max(rank_ms), "all": rank_ms},     # each rank's own clock between the two barriers
+            "higher_is_better": True, "scaling": getattr(wl, "scaling", "weak"), "vs_baseline": None,
             "dtype": "f32", "data": wl.data,
             "config": {"workload": wl.workload, "name": args.config, "trials_per_gpu_per_step": wl.units_per_step,
                        "trials_per_step_all_gpus": getattr(wl, "total_units", wl.units_per_step * world),

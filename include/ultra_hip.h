@@ -33,7 +33,7 @@
 extern "C" {
 #endif
 
-#define ULTRA_HIP_ABI_VERSION 9
+#define ULTRA_HIP_ABI_VERSION 10
 
 /* ultra::Modulation (include/ultra/types.hpp:27-39) — same numeric values. */
 enum ultra_hip_modulation {
@@ -613,6 +613,43 @@ int ultra_hip_profile_read(ultra_hip_ctx* ctx, float* ms, uint32_t* launches);
  * the decoder, streams for the acquisition; 0 where a class has no natural item.  What an instruction count collected at one
  * batch size and launch structure is scaled by when it is quoted for another (bench.py). */
 int ultra_hip_profile_read_items(ultra_hip_ctx* ctx, float* ms, uint32_t* launches, uint64_t* items);
+
+/* Which of its own FALL-BACK paths a context has taken, and what the decoder's screen last decided.  ABI 10.
+ *
+ * Every path below computes the same results bit for bit (tests/test_gpu_fallbacks.py, tests/test_gpu_status.py) but not at the
+ * same speed, and none of them used to be visible to the caller — the reference's convention is "failure = false / empty, never
+ * silent" ("Errors"), and a batch that quietly runs on the slower chain is a silent failure of a performance
+ * contract.  `flags` is sticky: a bit stays set from the first launch that took the path until ultra_hip_clear_status.
+ * bench.py prints the word and does not call a line "default path" with any bit set. */
+enum {
+    ULTRA_HIP_ST_DEMOD_WORKSPACE_FALLBACK = 0x01, /* the per-(frame, symbol) bin / tracker workspace could not be had (allocation failed, or
+                                                    * above ultra_hip_set_workspace_limit): the batch ran the per-symbol launch chain */
+    ULTRA_HIP_ST_LDPC_MESSAGE_KERNEL = 0x02,      /* a decode launch ran the message-passing kernel instead of the totals kernel */
+    ULTRA_HIP_ST_LDS_PROBE_FAILED = 0x04,         /* ... because ultra_hip_create's probe found dynamic LDS not at address 0 */
+    ULTRA_HIP_ST_SCREEN_LIST_UNAVAILABLE = 0x08,  /* a launch that qualified for the decoder's screen ran without it: no work list */
+    ULTRA_HIP_ST_ACQ_CACHE_UNAVAILABLE = 0x10,    /* ultra_hip_acquire_stream_batch searched without its per-stream metric cache */
+    ULTRA_HIP_ST_FORCED_FALLBACK_CHAIN = 0x20,    /* ULTRA_HIP_FALLBACK_CHAIN=1 in the environment when the context was created */
+    ULTRA_HIP_ST_FORCED_MESSAGE_KERNEL = 0x40,    /* ULTRA_HIP_LDPC_MESSAGES=1 */
+    ULTRA_HIP_ST_SCREEN_OVERRIDDEN = 0x80         /* ULTRA_HIP_LDPC_SCREEN=0 or =2 */
+};
+typedef struct ultra_hip_path_status {
+    uint32_t flags;                /* ULTRA_HIP_ST_* */
+    uint32_t screen_launches;      /* decode launches that ran the screen's sample since the context was created */
+    uint32_t screen_sample_n;      /* of the LAST such launch: codewords sampled, */
+    uint32_t screen_sample_clean;  /*   how many of them satisfied every parity row as received, */
+    uint32_t screen_gate;          /*   the count at which the full pass runs (0 = forced), */
+    uint32_t screen_gate_open;     /*   whether it ran, */
+    uint32_t screen_dirty;         /*   and, if so, how many codewords it left to the iterating kernel */
+    uint32_t reserved;
+} ultra_hip_path_status;
+/* Synchronises the context's stream (the screen's counters live on the device). */
+int ultra_hip_get_status(ultra_hip_ctx* ctx, ultra_hip_path_status* out);
+int ultra_hip_clear_status(ultra_hip_ctx* ctx);
+/* Cap, in bytes, on EACH of the two per-(frame, symbol) demodulator workspaces (bins: n_frames * n_symbols * 128 or 256 complex
+ * values; tracker records likewise).  A batch that would need more runs the per-symbol chain on per-frame buffers instead —
+ * same results, ULTRA_HIP_ST_DEMOD_WORKSPACE_FALLBACK set.  0 = no cap (default).  For hosts that share the card, and for the
+ * test that must see the flag. */
+int ultra_hip_set_workspace_limit(ultra_hip_ctx* ctx, size_t bytes);
 
 /* Convenience for hosts without their own device allocator (the C++ adapter
  * and the ctypes tests): hipMalloc/hipFree/hipMemcpy on the context's device. */

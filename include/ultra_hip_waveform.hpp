@@ -162,7 +162,16 @@ public:
         {
             std::lock_guard<std::mutex> lock(m_);
             auto it = idle_.find(Key{c, device});
-            if (it != idle_.end()) { auto s = std::move(it->second); idle_.erase(it); return s; }
+            if (it != idle_.end()) {
+                auto s = std::move(it->second); idle_.erase(it);
+                // a recycled context starts like a new one: nothing sticky of its previous user (fused deinterleaver, profiling
+                // brackets, status bits) — host-side settings, no launch
+                (void)ultra_hip_set_deinterleave(s->ctx, 0);
+                (void)ultra_hip_set_deinterleave_table(s->ctx, nullptr, 0);
+                (void)ultra_hip_profile_enable(s->ctx, 0);
+                (void)ultra_hip_clear_status(s->ctx);
+                return s;
+            }
         }
         return std::make_unique<Slot>(c, device);
     }

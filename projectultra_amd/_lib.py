@@ -17,7 +17,7 @@ PKG_DIR = Path(__file__).resolve().parent
 LIB_PATH = Path(os.environ["ULTRA_HIP_LIB"]).resolve() if os.environ.get("ULTRA_HIP_LIB") else PKG_DIR / "libultra_hip.so"
 CSRC_DIR = PKG_DIR / "csrc"
 
-ULTRA_HIP_ABI_VERSION = 9
+ULTRA_HIP_ABI_VERSION = 10
 STATE_FLOATS = 8
 
 
@@ -47,6 +47,20 @@ class ultra_hip_counters(C.Structure):
     _fields_ = [(n, C.c_uint64) for n in (
         "frames", "frame_errors", "bit_errors", "info_bits", "ldpc_fail", "iters_sum",
         "undetected_errors", "reserved")]
+
+
+class ultra_hip_path_status(C.Structure):
+    """ultra_hip_get_status (ABI 10): fall-back paths a context has taken + the decoder screen's last decision."""
+    _fields_ = [(n, C.c_uint32) for n in (
+        "flags", "screen_launches", "screen_sample_n", "screen_sample_clean", "screen_gate", "screen_gate_open",
+        "screen_dirty", "reserved")]
+
+
+# ULTRA_HIP_ST_* (include/ultra_hip.h)
+STATUS_FLAGS = {
+    0x01: "demod_workspace_fallback", 0x02: "ldpc_message_kernel", 0x04: "lds_probe_failed", 0x08: "screen_list_unavailable",
+    0x10: "acq_cache_unavailable", 0x20: "forced_fallback_chain", 0x40: "forced_message_kernel", 0x80: "screen_overridden",
+}
 
 
 COUNTER_NAMES = tuple(n for n, _ in ultra_hip_counters._fields_)
@@ -99,6 +113,9 @@ PROTOTYPES = {
     "ultra_hip_set_deinterleave": (_i, [_vp, C.c_uint32]),
     "ultra_hip_set_deinterleave_table": (_i, [_vp, _vp, C.c_uint32]),
     "ultra_hip_channel_interleaver_step": (_i, [C.c_uint32, C.c_uint32, _u32p]),
+    "ultra_hip_get_status": (_i, [_vp, C.POINTER(ultra_hip_path_status)]),
+    "ultra_hip_clear_status": (_i, [_vp]),
+    "ultra_hip_set_workspace_limit": (_i, [_vp, _sz]),
     "ultra_hip_profile_enable": (_i, [_vp, _i]),
     "ultra_hip_profile_read": (_i, [_vp, C.POINTER(C.c_float), C.POINTER(C.c_uint32)]),
     "ultra_hip_profile_read_items": (_i, [_vp, C.POINTER(C.c_float), C.POINTER(C.c_uint32), C.POINTER(C.c_uint64)]),

@@ -105,6 +105,11 @@ struct ultra_hip_ctx {
     bool old_chain = false;
     float* d_ws_trk = nullptr;           // deferred carrier half: one record per (symbol, frame) from track_pilot_kernel to track_all_kernel
     size_t ws_trk_rows = 0;
+    // ultra_hip_get_status: fall-back paths taken (sticky), the n_sym-fold workspace cap, the screen's last decision
+    uint32_t status_flags = 0;
+    size_t ws_limit_bytes = 0;
+    unsigned* d_status = nullptr;        // copy of the last screened launch's control words (sample clean, dirty)
+    uint32_t screen_launches = 0, last_screen_gate = 0, last_screen_sample_n = 0;
     bool profiling = false;
     struct Span { int kind; hipEvent_t e0, e1; unsigned long long items; };
     std::vector<Span> spans;
@@ -274,11 +279,19 @@ int launch_demod(ultra_hip_ctx* ctx, const float* d_audio, size_t frame_stride, 
     bool deferred = !ctx->old_chain && !d_eq && !D.differential && D.n_pilot > 0 && D.n_pilot <= dev::kPwPilots && D.n_train == 0 &&
                     !D.presynced && D.adaptive_eq == 0 && n_frames * (size_t)n_sym < 0x7fffffffull;
     // n_sym rows of workspace per frame instead of one: if that cannot be had, fall back to the per-symbol launches
-    if ((all_symbols_at_once || deferred) && ensure_fq_workspace(ctx, n_frames * (size_t)n_sym) != ULTRA_HIP_OK) {
+    // (or is above the caller's cap, ultra_hip_set_workspace_limit).  Either way the caller can see it: ultra_hip_get_status.
+    const size_t fold_rows = n_frames * (size_t)n_sym;
+    auto over_limit = [&](size_t bytes) { return ctx->ws_limit_bytes != 0 && bytes > ctx->ws_limit_bytes; };
+    if ((all_symbols_at_once || deferred) &&
+        (over_limit(fold_rows * (size_t)(2 * D.fq_half) * sizeof(c32)) || ensure_fq_workspace(ctx, fold_rows) != ULTRA_HIP_OK)) {
         (void)hipGetLastError();
         all_symbols_at_once = false; deferred = false;
+        ctx->status_flags |= ULTRA_HIP_ST_DEMOD_WORKSPACE_FALLBACK;
     }
-    if (deferred && ensure_trk_workspace(ctx, n_frames * (size_t)n_sym) != ULTRA_HIP_OK) { (void)hipGetLastError(); deferred = false; }
+    if (deferred && (over_limit(fold_rows * (size_t)dev::trk_rec_floats(D.n_pilot) * sizeof(float)) || ensure_trk_workspace(ctx, fold_rows) != ULTRA_HIP_OK)) {
+        (void)hipGetLastError(); deferred = false;
+        ctx->status_flags |= ULTRA_HIP_ST_DEMOD_WORKSPACE_FALLBACK;
+    }
     { const int rc_fq = ensure_fq_workspace(ctx, n_frames); if (rc_fq != ULTRA_HIP_OK) return rc_fq; }
     // A batch that starts at symbol 0 of the deferred chain without initial offsets: the pilot half of symbol 0 starts from the
     // constructor's values itself (track_pilot_kernel, `fresh`) and writes the whole record — no initialisation launch, and
@@ -509,8 +522,10 @@ int launch_ldpc(ultra_hip_ctx* ctx, const float* d_llr, size_t llr_stride, size_
             unsigned gate = 0u;
             const bool screen = ctx->screen_mode != 0 && ctx->d_screen_pos && T.max_iterations > 0 && !d_llr_total &&
                                 (ctx->screen_mode == 2 || n_cw >= kScreenMinCodewords) && n_cw <= 0x7fffffffull;
-            if (screen && ensure_list_workspace(ctx, n_cw) != ULTRA_HIP_OK) (void)hipGetLastError();   // no list: plain decode
-            else if (screen) {
+            if (screen && ensure_list_workspace(ctx, n_cw) != ULTRA_HIP_OK) {                            // no list: plain decode, and the caller can see it
+                (void)hipGetLastError();
+                ctx->status_flags |= ULTRA_HIP_ST_SCREEN_LIST_UNAVAILABLE;
+            } else if (screen) {
                 if (ctx->screen_pos_stale) {
                     hipLaunchKernelGGL(dev::ldpc_screen_prepare_kernel, dim3(1), dim3(512), 0, ctx->stream, ctx->d_screen_var, T.m, T.k,
                                        (int)ctx->deint_step, ctx->d_deint_table, ctx->d_screen_pos);
@@ -548,6 +563,7 @@ int launch_ldpc(ultra_hip_ctx* ctx, const float* d_llr, size_t llr_stride, size_
                     default: work_list = nullptr; break;
                 }
 #undef UH_SCREEN_LAUNCH
+                if (work_list) { ++ctx->screen_launches; ctx->last_screen_gate = gate; ctx->last_screen_sample_n = (uint32_t)sample_n; }
             }
             // R3/4 without a fused deinterleaver stages only the 487 values its decoder reads: 8,348 B per workgroup, 19 per CU
             // instead of 18 (ldpc_totals_kernel.h, COMPACT).
@@ -560,10 +576,13 @@ int launch_ldpc(ultra_hip_ctx* ctx, const float* d_llr, size_t llr_stride, size_
             else if (r14) UH_TOTALS_LAUNCH(8, 3, kPlaceRowProf_R1_4, kPlaceVarProf_R1_4, 3, false);
             else if (r13) UH_TOTALS_LAUNCH(6, 6, kPlaceRowProf_R1_3, kPlaceVarProf_R1_3, 4, false);
             else UH_TOTALS_LAUNCH(6, 6, kPlaceRowProf_R1_2, kPlaceVarProf_R1_2, 4, false);
+            // the launch's counter block is recycled sixteen launches on: what the screen decided is kept for ultra_hip_get_status
+            if (work_list) (void)hipMemcpyAsync(ctx->d_status, counter, 4 * sizeof(unsigned), hipMemcpyDeviceToDevice, ctx->stream);
         }
 #undef UH_TOTALS_LAUNCH
         if (launched) { UH_HIP(hipGetLastError()); return ULTRA_HIP_OK; }
     }
+    ctx->status_flags |= ULTRA_HIP_ST_LDPC_MESSAGE_KERNEL;              // not the totals kernel: visible to the caller
     const size_t lds = dev::ldpc_lds_bytes(P.msg_words);
     // WV = wavefronts per SIMD the instance's registers are budgeted for; the grid is one resident set
     // (bounded by LDS: one codeword's messages + staging per workgroup)
@@ -783,8 +802,10 @@ int ultra_hip_create(const ultra_hip_config* cfg, int device, void* stream, ultr
     { const char* e = std::getenv("ULTRA_HIP_MIX_WG_PER_CU"); if (e && std::atoi(e) > 0) ctx->mix_wg_per_cu = std::atoi(e); }
 #endif
     { const char* e = std::getenv("ULTRA_HIP_FALLBACK_CHAIN"); ctx->old_chain = (e && e[0] == '1'); }
+    if (ctx->old_chain) ctx->status_flags |= ULTRA_HIP_ST_FORCED_FALLBACK_CHAIN;
     const char* force_messages = std::getenv("ULTRA_HIP_LDPC_MESSAGES");
     if (!(force_messages && force_messages[0] == '1')) (void)build_ldpc_tplan(ctx->h_ldpc, cfg->code_rate, ctx->h_tplan);
+    else ctx->status_flags |= ULTRA_HIP_ST_FORCED_MESSAGE_KERNEL;
     ctx->h_tplan.max_iterations = ctx->h_ldpc.max_iterations;
 
     DeviceGuard guard(device);
@@ -798,12 +819,14 @@ int ultra_hip_create(const ultra_hip_config* cfg, int device, void* stream, ultr
     if (hipMalloc(&ctx->d_plan, sizeof(LdpcPlan)) != hipSuccess) return fail(ULTRA_HIP_ERR_OOM);
     if (hipMalloc(&ctx->d_tplan, sizeof(LdpcTPlan)) != hipSuccess) return fail(ULTRA_HIP_ERR_OOM);
     if (hipMalloc(&ctx->d_work, 16 * dev::kLdpcQueueWords * sizeof(unsigned int)) != hipSuccess) return fail(ULTRA_HIP_ERR_OOM);
+    if (hipMalloc(&ctx->d_status, 4 * sizeof(unsigned)) != hipSuccess) return fail(ULTRA_HIP_ERR_OOM);
+    if (hipMemset(ctx->d_status, 0, 4 * sizeof(unsigned)) != hipSuccess) return fail(ULTRA_HIP_ERR_HIP);
     if (hipMalloc(&ctx->d_nco, nco.size() * sizeof(c32)) != hipSuccess) return fail(ULTRA_HIP_ERR_OOM);
     if (hipMalloc(&ctx->d_twiddle, tw.size() * sizeof(c32)) != hipSuccess) return fail(ULTRA_HIP_ERR_OOM);
     {   // the decoder's screen: the rows' variables (<= kScreenEdges each, the parity bit's included); a graph that does not fit
         // decodes without it
         const char* e = std::getenv("ULTRA_HIP_LDPC_SCREEN");
-        if (e && (e[0] == '0' || e[0] == '2') && e[1] == 0) ctx->screen_mode = e[0] - '0';
+        if (e && (e[0] == '0' || e[0] == '2') && e[1] == 0) { ctx->screen_mode = e[0] - '0'; ctx->status_flags |= ULTRA_HIP_ST_SCREEN_OVERRIDDEN; }
         std::vector<uint16_t> rv((size_t)kTPlanRowRounds * 64 * kScreenEdges, (uint16_t)0xFFFF);
         const LdpcConst& L = ctx->h_ldpc;
         bool fits = L.m <= kTPlanRowRounds * 64;
@@ -836,6 +859,7 @@ int ultra_hip_create(const ultra_hip_config* cfg, int device, void* stream, ultr
         if (base != 0u) {
             std::fprintf(stderr, "ultra_hip: dynamic LDS starts at %u, not 0: this context decodes with the message-passing kernel\n", base);
             ctx->h_tplan.valid = 0;
+            ctx->status_flags |= ULTRA_HIP_ST_LDS_PROBE_FAILED;
         }
     }
     if (hipMemcpy(ctx->d_demod, &ctx->h_demod, sizeof(DemodConst), hipMemcpyHostToDevice) != hipSuccess ||
@@ -867,6 +891,7 @@ void ultra_hip_destroy(ultra_hip_ctx* ctx) {
     if (ctx->d_tplan) (void)hipFree(ctx->d_tplan);
     if (ctx->d_deint_table) (void)hipFree(ctx->d_deint_table);
     if (ctx->d_work) (void)hipFree(ctx->d_work);
+    if (ctx->d_status) (void)hipFree(ctx->d_status);
     if (ctx->d_screen_var) (void)hipFree(ctx->d_screen_var);
     if (ctx->d_screen_pos) (void)hipFree(ctx->d_screen_pos);
     if (ctx->d_ws_list) (void)hipFree(ctx->d_ws_list);
@@ -920,6 +945,46 @@ int ultra_hip_reserve(ultra_hip_ctx* ctx, size_t n_frames) {
         ensure_list_workspace(ctx, n_frames) != ULTRA_HIP_OK)
         (void)hipGetLastError();
     return rc;
+}
+
+int ultra_hip_get_status(ultra_hip_ctx* ctx, ultra_hip_path_status* out) {
+    if (!ctx || !out) return ULTRA_HIP_ERR_INVALID_ARG;
+    DeviceGuard guard(ctx->device);
+    unsigned ctl[4] = {0, 0, 0, 0};
+    if (ctx->screen_launches) {
+        UH_HIP(uh_stream_sync(ctx->stream));
+        UH_HIP(hipMemcpy(ctl, ctx->d_status, sizeof(ctl), hipMemcpyDeviceToHost));
+    }
+    std::memset(out, 0, sizeof(*out));
+    out->flags = ctx->status_flags;
+    out->screen_launches = ctx->screen_launches;
+    out->screen_sample_n = ctx->last_screen_sample_n;
+    out->screen_sample_clean = ctl[dev::kScreenCtlSample];
+    out->screen_gate = ctx->last_screen_gate;
+    out->screen_gate_open = (ctx->screen_launches && ctl[dev::kScreenCtlSample] >= ctx->last_screen_gate) ? 1u : 0u;
+    out->screen_dirty = out->screen_gate_open ? ctl[dev::kScreenCtlDirty] : 0u;
+    return ULTRA_HIP_OK;
+}
+
+int ultra_hip_clear_status(ultra_hip_ctx* ctx) {
+    if (!ctx) return ULTRA_HIP_ERR_INVALID_ARG;
+    // what the environment forced when the context was created stays true of every launch: those bits are not cleared
+    ctx->status_flags &= (ULTRA_HIP_ST_FORCED_FALLBACK_CHAIN | ULTRA_HIP_ST_FORCED_MESSAGE_KERNEL | ULTRA_HIP_ST_SCREEN_OVERRIDDEN | ULTRA_HIP_ST_LDS_PROBE_FAILED);
+    return ULTRA_HIP_OK;
+}
+
+int ultra_hip_set_workspace_limit(ultra_hip_ctx* ctx, size_t bytes) {
+    if (!ctx) return ULTRA_HIP_ERR_INVALID_ARG;
+    DeviceGuard guard(ctx->device);
+    ctx->ws_limit_bytes = bytes;
+    // buffers already above the cap go back now, so the next batch really runs within it
+    if (bytes != 0) {
+        UH_HIP(uh_stream_sync(ctx->stream));
+        const size_t fq_row = (size_t)(2 * ctx->h_demod.fq_half) * sizeof(c32), trk_row = (size_t)dev::trk_rec_floats(ctx->h_demod.n_pilot) * sizeof(float);
+        if (ctx->ws_fq_rows * fq_row > bytes) { (void)hipFree(ctx->d_ws_fq); ctx->d_ws_fq = nullptr; ctx->ws_fq_rows = 0; }
+        if (ctx->ws_trk_rows * trk_row > bytes) { (void)hipFree(ctx->d_ws_trk); ctx->d_ws_trk = nullptr; ctx->ws_trk_rows = 0; }
+    }
+    return ULTRA_HIP_OK;
 }
 
 int ultra_hip_get_geometry(const ultra_hip_ctx* ctx, ultra_hip_geometry* geo) {
@@ -1079,6 +1144,7 @@ int ultra_hip_demod_decode_batch(ultra_hip_ctx* ctx, const float* d_audio, size_
 }
 
 namespace {
+constexpr size_t kAcqCacheMaxStreams = 4096;                 // 1 GB of metric caches: above that a batch is not a set of live adapters
 int ensure_acq_gcache(ultra_hip_ctx* ctx, size_t n_streams) {
     if (ctx->acq_gcache_streams >= n_streams) return ULTRA_HIP_OK;
     if (ctx->d_acq_gcache) { UH_HIP(uh_stream_sync(ctx->stream)); (void)hipFree(ctx->d_acq_gcache); ctx->d_acq_gcache = nullptr; }
@@ -1144,7 +1210,14 @@ int ultra_hip_acquire_stream_batch(ultra_hip_ctx* ctx, const float* d_audio, siz
     if (n_streams * cand > 0x3fffffffull)                                   // (a grid that large is not a live adapter's: the plain walk)
         return launch_acquire(ctx, d_audio, stream_stride, n_samples, 0xffffffffu, n_streams, d_found, d_data_start, d_cfo_hz,
                               d_sync_offset, nullptr, origin, d_resume);
-    { const int rc_gc = ensure_acq_gcache(ctx, n_streams); if (rc_gc != ULTRA_HIP_OK) return rc_gc; }
+    // the cache is 262 KB per stream and lives until destroy: best effort, like the decoder's work list — a call that needed no
+    // memory before the cache existed does not fail for want of it (and says so: ULTRA_HIP_ST_ACQ_CACHE_UNAVAILABLE)
+    if (n_streams > kAcqCacheMaxStreams || ensure_acq_gcache(ctx, n_streams) != ULTRA_HIP_OK) {
+        (void)hipGetLastError();
+        ctx->status_flags |= ULTRA_HIP_ST_ACQ_CACHE_UNAVAILABLE;
+        return launch_acquire(ctx, d_audio, stream_stride, n_samples, 0xffffffffu, n_streams, d_found, d_data_start, d_cfo_hz,
+                              d_sync_offset, nullptr, origin, d_resume);
+    }
     {
         LaunchSpan span(ctx, ULTRA_HIP_K_ACQUIRE, n_streams);
         hipLaunchKernelGGL(dev::acq_cache_guard_kernel, dim3((unsigned)std::min(n_streams, (size_t)4096)), dim3(dev::kWave), 0, ctx->stream,

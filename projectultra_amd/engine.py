@@ -476,6 +476,23 @@ class ReceiveContext:
         more, with a stream synchronisation and an allocation)."""
         check(self.lib.ultra_hip_reserve(self._ctx, int(n_frames)), "ultra_hip_reserve")
 
+    def status(self) -> dict:
+        """ultra_hip_get_status: which of the context's own fall-back paths it has taken since creation (or clear_status) —
+        `paths`: names of the ULTRA_HIP_ST_* bits set, empty on the default path — and what the decoder's screen decided on the
+        last launch that sampled.  Synchronises the stream."""
+        st = _lib.ultra_hip_path_status()
+        check(self.lib.ultra_hip_get_status(self._ctx, C.byref(st)), "ultra_hip_get_status")
+        out = {n: int(getattr(st, n)) for n, _ in st._fields_ if n != "reserved"}
+        out["paths"] = [name for bit, name in sorted(_lib.STATUS_FLAGS.items()) if st.flags & bit]
+        return out
+
+    def clear_status(self):
+        check(self.lib.ultra_hip_clear_status(self._ctx), "ultra_hip_clear_status")
+
+    def set_workspace_limit(self, n_bytes: int):
+        """Cap each per-(frame, symbol) demodulator workspace (ultra_hip_set_workspace_limit); 0 = none."""
+        check(self.lib.ultra_hip_set_workspace_limit(self._ctx, int(n_bytes)), "ultra_hip_set_workspace_limit")
+
     def channel_cfo(self, audio, cfo_hz: float):
         """The channel's carrier frequency offset (WattersonChannel::applyCFO, hf_channel.hpp:161-232; every row by a fresh
         channel) applied to a batch of audio rows -> new tensor.  Bit-identical to the reference."""

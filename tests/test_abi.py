@@ -24,7 +24,7 @@ def test_every_declared_symbol_is_exported_and_bound(hiplib):
     for n in names:
         assert hasattr(hiplib, n), f"{n} declared in include/ultra_hip.h but not exported"
     assert set(names) == set(_lib.PROTOTYPES), "ctypes prototypes out of sync with the header"
-    assert hiplib.ultra_hip_abi_version() == _lib.ULTRA_HIP_ABI_VERSION == 9
+    assert hiplib.ultra_hip_abi_version() == _lib.ULTRA_HIP_ABI_VERSION == 10
     assert hiplib.ultra_hip_strerror(-2).decode().startswith("configuration not supported")
 
 
