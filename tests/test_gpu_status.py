@@ -96,7 +96,7 @@ def test_environment_overrides_are_reported(oracle):
             os.environ["ULTRA_HIP_LDPC_SCREEN"] = old
 
 
-@pytest.mark.parametrize("sigma,expect_open", [(0.35, True), (1.4, False)])
+@pytest.mark.parametrize("sigma,expect_open", [(0.28, True), (1.4, False)])
 def test_screen_decision_is_reported(oracle, sigma, expect_open):
     """A launch large enough for the screen: the status carries the sample (how many of <= 2,048 sampled codewords were clean
     as received), the gate, whether the full pass ran, and how many codewords it left to the iterating kernel — clean channel:
