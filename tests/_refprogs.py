@@ -25,17 +25,24 @@ VARIANTS = {"core": ("ref", "hip"), "own": ("ref", "hip"), "engine": ("ref", "pi
 SKIPPED = []                                   # (test id, file) of every skip this session: conftest prints the count
 
 
-def programs():
-    """[(source relative to the reference root — or to oracle/ for own kinds —, kind)] in manifest order."""
-    rows = []
+def _rows():
     for line in MANIFEST_TXT.read_text().splitlines():
         line = line.strip()
         if not line or line[0] in "#!":
             continue
-        src, kind = line.split()[:2]
-        assert kind in VARIANTS, (src, kind)
-        rows.append((src, kind))
-    return rows
+        cols = line.split()
+        assert cols[1] in VARIANTS and cols[2:] in ([], ["san"]), cols
+        yield cols[0], cols[1], cols[2:] == ["san"]
+
+
+def programs():
+    """[(source relative to the reference root — or to oracle/ for own kinds —, kind)] in manifest order."""
+    return [(src, kind) for src, kind, _ in _rows()]
+
+
+def hardened():
+    """Names of the programs that also have a .san build (drop-ins under UBSan + libstdc++ assertions + _FORTIFY_SOURCE=3)."""
+    return [name_of(src) for src, _, san in _rows() if san]
 
 
 def exclusions():
@@ -64,6 +71,7 @@ def expected_files():
     out = ["libultra_ref.so", "rx_pipeline_harness"]
     for src, kind in programs():
         out += [f"tools/{name_of(src)}.{v}" for v in VARIANTS[kind]]
+    out += [f"tools/{n}.san" for n in hardened()]
     return out
 
 

@@ -96,3 +96,4 @@ def test_product_never_touches_the_oracle():
             text = p.read_text(errors="ignore")
             assert "oracle/" not in text and "oracle." not in text and "libultra_oracle" not in text, p
             assert "import oracle" not in text and "from oracle" not in text, p
+            assert "teststub" not in text, p                          # tests/stub: the sanitizer runs' C-ABI stand-in is test-only too

@@ -49,6 +49,74 @@ def test_cfg3_strong_scaling_counters_equal_one_rank():
         assert got["config"]["trials_per_step_all_gpus"] == total
 
 
+def test_cfg3_headline_batch_eight_ranks_rehearsed_in_one_process():
+    """north_star's N = 8 case at FULL size — the 2^20-frame batch, a rank's share 2^17 — without eight processes (the box
+    allows six on its card): bench.py's own workload object built for (rank r, world 8), r = 0..7, one step each, the eight
+    counter blocks summed the way the all-reduce sums them; must equal the N = 1 batch's counters exactly.  Everything an
+    8-GPU run executes except the transport: shard_range(2^20, r, 8), the generators keyed on the global trial index, the
+    kernels at a 2^17 launch, the counting launch."""
+    import argparse
+    import importlib.util
+    import torch
+    spec = importlib.util.spec_from_file_location("bench_mod", ROOT / "bench.py")
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    total = 1 << 20
+    args = argparse.Namespace(config="cfg3", gpus=8, steps=1, warmup=0, frames=0, total_frames=total, snr_db=None, raw_channel="awgn",
+                              no_cpu_baseline=True, cpu_sample=0, backend="gloo", sync_collective=False, no_build=True)
+
+    def one_step(rank, world):
+        wl = bench.ModemWorkload("cfg3", args, rank, world, torch)
+        wl.step(lambda t: None)
+        wl.ring.drain()
+        torch.cuda.synchronize()
+        c = wl.counters.reshape(-1, 8).sum(dim=0).cpu()
+        n, st = wl.n, wl.ctx.status()
+        del wl
+        torch.cuda.empty_cache()
+        return c, n, st
+
+    whole, n1, st1 = one_step(0, 1)
+    assert n1 == total and int(whole[0]) == total and int(whole[1]) > 0 and st1["paths"] == []
+    acc = torch.zeros(8, dtype=whole.dtype)
+    for r in range(8):
+        c, n, st = one_step(r, 8)
+        assert n == total // 8 and int(c[0]) == n and st["paths"] == [], (r, n, st)
+        acc += c
+    assert acc.tolist() == whole.tolist(), (acc.tolist(), whole.tolist())
+
+
+def test_cfg3_five_ranks_on_one_card():
+    """As many real ranks as the box's process guard allows beside this process (six on the card): five, ragged shards of a
+    2^17-frame batch, and the per-rank step times the line now carries."""
+    total = 1 << 17
+    one = run_bench("--gpus", "1", "--total-frames", str(total))
+    got = run_bench("--gpus", "5", "--backend", "gloo", "--total-frames", str(total))
+    assert got["collective"]["world_size"] == 5 and got["counters"] == one["counters"]
+    ranks = got["ms_per_step_ranks"]
+    assert len(ranks["all"]) == 5 and ranks["min"] <= ranks["max"] <= got["ms_per_step"] * 1.0001 + 1e-9
+    assert got["roofline"]["path_status"]["default_path"] is True and got["roofline"]["path_status"]["per_rank_flags"] == [0] * 5
+
+
+def test_a_rank_without_a_device_is_refused_not_moved_to_device_0():
+    """The device-selection code with an index other than 0 — all one card can execute of it: under RCCL a LOCAL_RANK beyond the
+    visible devices gets no line (never a second rank silently sharing device 0), and the drop-ins' ULTRA_HIP_DEVICE
+    (hip_ofdm_demodulator.cpp) naming a device the box does not have fails loudly instead of running on device 0."""
+    p = run_bench("--gpus", "2", "--total-frames", "4096", expect_rc=1,
+                  env={"RANK": "1", "LOCAL_RANK": "1", "WORLD_SIZE": "2", "MASTER_ADDR": "127.0.0.1", "MASTER_PORT": "29513"})
+    assert "has no GPU of its own" in p.stderr and not p.stdout.strip()
+    # the same through HIP_VISIBLE_DEVICES: an empty list leaves the rank no device at all
+    p = run_bench("--gpus", "1", "--total-frames", "4096", expect_rc=1, env={"HIP_VISIBLE_DEVICES": "", "ROCR_VISIBLE_DEVICES": ""})
+    assert not p.stdout.strip()
+    from _refprogs import exe, require
+    tool = exe("test_nvis_mode", "hip")
+    require(tool)
+    r = subprocess.run([str(tool), "--snr", "30", "--trials", "1"], capture_output=True, text=True, timeout=300,
+                       env=dict(os.environ, ULTRA_HIP_DEVICE="1"))
+    assert "ultra_hip" in r.stderr and ("FAILED" in r.stderr or "no device" in r.stderr.lower() or r.returncode != 0), (r.returncode, r.stderr[-600:])
+    assert "100.0%" not in r.stdout and "100%" not in r.stdout, "a device that does not exist must not decode anything"
+
+
 def test_cfg4_points_equal_one_rank():
     """The R1/4 Es/N0 sweep (configs[3]): 42 points x 8,192 codewords, one all-reduce per point; every point's counters."""
     one = run_bench("--config", "cfg4", "--gpus", "1", "--frames", "8192")

@@ -123,9 +123,10 @@ def test_counter_ring_overlaps_the_allreduce_gloo(tmp_path):
     assert r.stdout.count("ok") == 2
 
 
-@pytest.mark.parametrize("world", [2, 3])
+@pytest.mark.parametrize("world", [2, 3, 8])
 def test_counter_allreduce_across_ranks_gloo(tmp_path, world):
-    """N>1 path: contiguous shards, one all-reduce of the 8 counters (gloo on CPU; RCCL on the GPUs)."""
+    """N>1 path: contiguous shards, one all-reduce of the 8 counters (gloo on CPU; RCCL on the GPUs) — at north_star's 2, at a
+    ragged 3, and at its 8 (the collective and the shard arithmetic at the rank count no single card can host)."""
     script = tmp_path / "worker.py"
     script.write_text(WORKER)
     port = 29500 + os.getpid() % 2000 + world
