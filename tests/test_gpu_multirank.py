@@ -47,6 +47,11 @@ def test_cfg3_strong_scaling_counters_equal_one_rank():
         assert got["trials_counted"] == total
         assert got["counters"] == one["counters"], (n, got["counters"], one["counters"])
         assert got["config"]["trials_per_step_all_gpus"] == total
+        # every rank's own clock between the two barriers, and the fall-back paths its contexts took: a straggler or a rank on a
+        # slower chain shows in the line (four ranks is what the box's process guard allows beside this process)
+        ranks = got["ms_per_step_ranks"]
+        assert len(ranks["all"]) == n and ranks["min"] <= ranks["max"] <= got["ms_per_step"] * 1.0001 + 1e-9
+        assert got["roofline"]["path_status"]["default_path"] is True and got["roofline"]["path_status"]["per_rank_flags"] == [0] * n
 
 
 def test_cfg3_headline_batch_eight_ranks_rehearsed_in_one_process():
@@ -84,18 +89,6 @@ def test_cfg3_headline_batch_eight_ranks_rehearsed_in_one_process():
         assert n == total // 8 and int(c[0]) == n and st["paths"] == [], (r, n, st)
         acc += c
     assert acc.tolist() == whole.tolist(), (acc.tolist(), whole.tolist())
-
-
-def test_cfg3_five_ranks_on_one_card():
-    """As many real ranks as the box's process guard allows beside this process (six on the card): five, ragged shards of a
-    2^17-frame batch, and the per-rank step times the line now carries."""
-    total = 1 << 17
-    one = run_bench("--gpus", "1", "--total-frames", str(total))
-    got = run_bench("--gpus", "5", "--backend", "gloo", "--total-frames", str(total))
-    assert got["collective"]["world_size"] == 5 and got["counters"] == one["counters"]
-    ranks = got["ms_per_step_ranks"]
-    assert len(ranks["all"]) == 5 and ranks["min"] <= ranks["max"] <= got["ms_per_step"] * 1.0001 + 1e-9
-    assert got["roofline"]["path_status"]["default_path"] is True and got["roofline"]["path_status"]["per_rank_flags"] == [0] * 5
 
 
 def test_a_rank_without_a_device_is_refused_not_moved_to_device_0():
