@@ -12,8 +12,10 @@
 //
 // and link it INSTEAD OF src/ofdm/demodulator.cpp, src/ofdm/channel_equalizer.cpp and src/ofdm/ofdm_sync.cpp (the three files
 // that define the reference's Impl), with -lultra_hip.  No caller changes: tools, waveforms, RxPipeline and ModemEngine run on
-// the GPU as they are (tests/test_gpu_pimpl.py runs the reference's tools built that way and compares
-// their output with the reference build's).
+// the GPU as they are — INTEGRATION.md 0 / 0b; tests/test_gpu_pimpl.py and tests/test_gpu_ref_programs.py run 34 of the
+// reference's own programs built that way (ModemEngine's among them: tools/test_iwaveform.cpp, test_modem_engine_loopback.cpp,
+// cli_simulator.cpp, threaded_simulator.cpp, oracle/engine_thread_harness.cpp with its feeder / GUI-poll / mode-change threads)
+// and compare their output with the reference build's.
 //
 // ultra::ChannelEstimator — a small stand-alone host class that shares demodulator.cpp (:1019-1066) and the header with the
 // demodulator — is defined here as well so that the replaced file leaves no undefined symbol behind; it is host arithmetic
