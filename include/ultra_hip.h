@@ -664,6 +664,26 @@ int ultra_hip_memcpy_d2h(ultra_hip_ctx* ctx, void* h_dst, const void* d_src, siz
 int ultra_hip_memcpy_h2d_async(ultra_hip_ctx* ctx, void* d_dst, const void* h_src, size_t bytes);
 int ultra_hip_memset(ultra_hip_ctx* ctx, void* d_dst, int value, size_t bytes);
 
+/* The latency path of ONE live stream (ABI 10): a call's answer without a copy command and without hipStreamSynchronize.
+ *   ultra_hip_host_block   pinned host memory the device writes DIRECTLY (zero copy): *h_ptr is the host's view, *d_ptr the device's
+ *                          view of the same bytes — hand d_ptr (+ offsets) to any entry point as an output buffer.  Owned by the
+ *                          context, freed by ultra_hip_destroy.  Small blocks only (a live adapter's soft bits and tracker state):
+ *                          a batch's outputs belong in device memory.
+ *   ultra_hip_stage_input  copies `bytes` from h_src into the context's pinned staging ring and returns the DEVICE view of the slot
+ *                          in *d_view: a kernel launched next reads the bytes from host memory itself — no copy command either
+ *                          (for inputs read once: a codeword's 648 soft bits).  h_src is the caller's again at once; the slot stays
+ *                          valid until the ring wraps (1 MB; a wrap waits for the stream first).
+ *   ultra_hip_stream_post  orders the 32-bit store `*d_flag = value` (d_flag inside a host block) behind everything issued on the
+ *                          context's stream so far, visible to the host when it lands.
+ *   ultra_hip_host_wait    spins on the host view of that word until it equals `value`; after timeout_us microseconds without it,
+ *                          falls back to a stream synchronisation (and returns ULTRA_HIP_ERR_HIP if the word still differs).
+ * What a SYNCED process() call or a single-codeword decodeSoft costs beside its kernels is then one store the host polls for,
+ * instead of a device-to-host copy and its completion wait (profiles/r06_live_latency.txt). */
+int ultra_hip_host_block(ultra_hip_ctx* ctx, size_t bytes, void** h_ptr, void** d_ptr);
+int ultra_hip_stage_input(ultra_hip_ctx* ctx, const void* h_src, size_t bytes, void** d_view);
+int ultra_hip_stream_post(ultra_hip_ctx* ctx, uint32_t* d_flag, uint32_t value);
+int ultra_hip_host_wait(ultra_hip_ctx* ctx, const volatile uint32_t* h_flag, uint32_t value, uint32_t timeout_us);
+
 /* Device self-test of the pinned libm restatement (projectultra_amd/csrc/
  * pinned_math.h): out[i] = fn(a[i] [, b[i]]) evaluated on the GPU, so tests
  * can compare with the host libm the reference calls.

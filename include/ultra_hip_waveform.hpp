@@ -148,6 +148,29 @@ struct Slot {
     ultra_hip_config cfg{}; int device = 0;
     ultra_hip_ctx* ctx = nullptr;
     GrowBuf buf[4];
+    // The answer of a latency-bound call (one live stream: a SYNCED process(), a single-codeword decodeSoft) comes back through a
+    // pinned block the kernels write directly and ONE posted word the host polls for — no device-to-host copy command, no
+    // hipStreamSynchronize (ultra_hip.h: ultra_hip_host_block / ultra_hip_stream_post / ultra_hip_host_wait).  Layout: word 0 the
+    // posted sequence number, payload from byte kMailHead on.  The block lives and dies with the context.
+    static constexpr size_t kMailBytes = size_t(256) << 10, kMailHead = 256;
+    char* mail_h = nullptr; char* mail_d = nullptr; uint32_t mail_seq = 0; bool mail_tried = false;
+    bool mail(size_t payload_bytes) {                                   // true: the payload fits the block and the block exists
+        if (payload_bytes + kMailHead > kMailBytes) return false;
+        if (!mail_tried) {
+            mail_tried = true;
+            void* h = nullptr; void* d = nullptr;
+            if (ultra_hip_host_block(ctx, kMailBytes, &h, &d) == ULTRA_HIP_OK) { mail_h = static_cast<char*>(h); mail_d = static_cast<char*>(d); }
+        }
+        return mail_h != nullptr;
+    }
+    char* mailDev() const { return mail_d + kMailHead; }
+    const char* mailHost() const { return mail_h + kMailHead; }
+    // behind everything issued so far: post the next sequence number, wait for it (20 ms of spinning, then a stream synchronisation)
+    void mailWait() {
+        ++mail_seq;
+        check(ultra_hip_stream_post(ctx, reinterpret_cast<uint32_t*>(mail_d), mail_seq), "stream_post");
+        check(ultra_hip_host_wait(ctx, reinterpret_cast<const volatile uint32_t*>(mail_h), mail_seq, 20000), "host_wait");
+    }
     Slot(const ultra_hip_config& c, int dev) : cfg(c), device(dev) { check(ultra_hip_create(&c, dev, nullptr, &ctx), "ultra_hip_create"); }
     Slot(const Slot&) = delete;
     Slot& operator=(const Slot&) = delete;
@@ -256,6 +279,22 @@ public:
         ensure();
         const size_t llr_bytes = n_cw * 648 * sizeof(float), it_bytes = n_cw * sizeof(int32_t), by_bytes = n_cw * g.decoded_bytes;
         const size_t out_bytes = it_bytes + by_bytes + n_cw;
+        if (n_cw <= kMailCodewords && slot_.s->mail(out_bytes)) {
+            // a handful of codewords (RxPipeline decodes one at a time): the kernel reads the soft bits from the pinned staging
+            // ring and writes its three outputs into the pinned result block — two launches, no copy command, one polled word
+            void* d_in = nullptr;
+            detail::check(ultra_hip_stage_input(slot_.ctx(), llr, llr_bytes, &d_in), "stage_input");
+            char* d_out = slot_.s->mailDev();
+            detail::check(ultra_hip_ldpc_decode_batch(slot_.ctx(), static_cast<const float*>(d_in), n_cw, reinterpret_cast<uint8_t*>(d_out + it_bytes),
+                                                      reinterpret_cast<int32_t*>(d_out), reinterpret_cast<uint8_t*>(d_out + it_bytes + by_bytes), nullptr),
+                          "ldpc_decode_batch");
+            slot_.s->mailWait();
+            const char* h = slot_.s->mailHost();
+            std::memcpy(iters, h, it_bytes);
+            std::memcpy(bytes, h + it_bytes, by_bytes);
+            std::memcpy(ok, h + it_bytes + by_bytes, n_cw);
+            return;
+        }
         char* d = static_cast<char*>(slot_.buf(0, llr_bytes + out_bytes));
         char* d_out = d + llr_bytes;
         detail::check(ultra_hip_memcpy_h2d_async(slot_.ctx(), d, llr, llr_bytes), "h2d");
@@ -288,6 +327,7 @@ private:
         slot_ = detail::PooledSlot(cConfig(), device_);
         detail::check(ultra_hip_set_deinterleave(slot_.ctx(), deinterleave_), "ultra_hip_set_deinterleave");   // a recycled context keeps its last user's
     }
+    static constexpr size_t kMailCodewords = 16;                        // 41 KB of soft bits: well inside the staging ring's per-call share
     CodeRate rate_; int device_; int max_iter_ = 50; bool last_success_ = false; int last_iters_ = 0;
     uint32_t deinterleave_ = 0;
     bool have_geo_ = false; ultra_hip_geometry geo_{};
@@ -516,7 +556,12 @@ private:
     // [tracker state (8 floats) | soft bits of this call]: one download brings both
     // ... and behind them (8-byte aligned) the equalized data carriers of the call's symbols, ULTRA_HIP_MAX_CARRIERS pairs each
     static size_t eqOffset(size_t n_llr) { return (ULTRA_HIP_STATE_FLOATS + n_llr + 1) & ~size_t(1); }
+    // ... in the context's pinned result block when the call's answer fits it (every live call does: a symbol or a few), in
+    // device scratch otherwise (a whole frame handed to processPresynced at once)
+    static size_t outFloats(size_t n_llr, size_t n_sym) { return eqOffset(n_llr) + n_sym * 2 * ULTRA_HIP_MAX_CARRIERS; }
     float* outDev(size_t n_llr, size_t n_sym = 0) {
+        out_in_mail_ = slot_.s->mail(outFloats(n_llr, n_sym) * sizeof(float));
+        if (out_in_mail_) return reinterpret_cast<float*>(slot_.s->mailDev());
         return static_cast<float*>(slot_.buf(2, (eqOffset(std::max<size_t>(n_llr, 4096)) + std::max<size_t>(n_sym, 8) * 2 * ULTRA_HIP_MAX_CARRIERS) * sizeof(float)));
     }
     ultra_hip_ctx* liveCtx() { return live_ps_ ? ps_slot_.ctx() : slot_.ctx(); }
@@ -580,8 +625,13 @@ private:
     }
     // [state | soft bits] of the call just issued; the host's copies of what the reference reads back from Impl
     void fetch(size_t n_llr, size_t n_sym) {
-        stage_.resize(eqOffset(n_llr) + n_sym * 2 * ULTRA_HIP_MAX_CARRIERS);
-        detail::check(ultra_hip_memcpy_d2h(slot_.ctx(), stage_.data(), outDev(n_llr, n_sym), stage_.size() * sizeof(float)), "d2h");
+        stage_.resize(outFloats(n_llr, n_sym));
+        if (out_in_mail_) {                                              // the kernels wrote into the pinned block: wait for the posted word
+            slot_.s->mailWait();
+            std::memcpy(stage_.data(), slot_.s->mailHost(), stage_.size() * sizeof(float));
+        } else {
+            detail::check(ultra_hip_memcpy_d2h(slot_.ctx(), stage_.data(), outDev(n_llr, n_sym), stage_.size() * sizeof(float)), "d2h");
+        }
         std::memcpy(state_, stage_.data(), sizeof(state_));
         demod_soft_.insert(demod_soft_.end(), stage_.begin() + ULTRA_HIP_STATE_FLOATS, stage_.begin() + ULTRA_HIP_STATE_FLOATS + n_llr);
         // demodulateSymbol (demodulator.cpp:199-208): every data symbol appends its equalized carriers; the newest 500 stay
@@ -619,6 +669,7 @@ private:
     bool carry_ = false;                     // the SYNCED context holds a frame's tracker of THIS object (no reset() since)
     bool ps_carry_ = false;                  // ... the PRESYNCED context does: the last frame came through processPresynced
     bool live_ps_ = false;                   // the frame in flight lives in the PRESYNCED context
+    bool out_in_mail_ = false;               // the call in flight writes its answer into the slot's pinned result block
     float coarse_cfo_ = 0.0f, freq_offset_hz_ = 0.0f, freq_correction_phase_ = 0.0f, timing_ = 0.0f;
     std::vector<float> demod_soft_, stage_;
     std::vector<std::complex<float>> constellation_;

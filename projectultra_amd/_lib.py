@@ -125,6 +125,10 @@ PROTOTYPES = {
     "ultra_hip_memcpy_d2h": (_i, [_vp, _vp, _vp, _sz]),
     "ultra_hip_memcpy_h2d_async": (_i, [_vp, _vp, _vp, _sz]),
     "ultra_hip_memset": (_i, [_vp, _vp, _i, _sz]),
+    "ultra_hip_host_block": (_i, [_vp, _sz, C.POINTER(_vp), C.POINTER(_vp)]),
+    "ultra_hip_stage_input": (_i, [_vp, _vp, _sz, C.POINTER(_vp)]),
+    "ultra_hip_stream_post": (_i, [_vp, _vp, C.c_uint32]),
+    "ultra_hip_host_wait": (_i, [_vp, _vp, C.c_uint32, C.c_uint32]),
     "ultra_hip_selftest_math": (_i, [_vp, _i, _vp, _vp, _vp, _sz]),
 }
 

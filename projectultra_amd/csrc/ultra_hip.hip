@@ -14,6 +14,7 @@
 #include <cstring>
 #include <new>
 #include <atomic>
+#include <chrono>
 #include <vector>
 
 #include "../../include/ultra_hip.h"
@@ -94,7 +95,9 @@ struct ultra_hip_ctx {
     int mix_wg_per_cu = 0;               // variant builds only (-DUH_AB_SWITCHES, ULTRA_HIP_MIX_WG_PER_CU): workgroups per CU of the transform's grid
     bool stream_cfo_given = false;       // launch_demod: whether the frame in flight started with caller-supplied offsets
     char* h_stage = nullptr;             // ultra_hip_memcpy_h2d_async: pinned staging ring
+    char* d_stage = nullptr;             // ... and the device's view of it (ultra_hip_stage_input)
     size_t stage_cap = 0, stage_off = 0;
+    std::vector<void*> host_blocks;      // ultra_hip_host_block: pinned, device-mapped result blocks
     int stream_start_mode = 0;           // ultra_hip_demod_stream_start: how the next first_symbol == 0 stream call starts (consumed by it)
     const float* stream_start_timing = nullptr;
     // ULTRA_HIP_FALLBACK_CHAIN=1: the fall-back kernels for every layout — track_pilot_kernel + track_kernel per symbol instead
@@ -915,6 +918,7 @@ void ultra_hip_destroy(ultra_hip_ctx* ctx) {
     if (ctx->d_ws_fq) (void)hipFree(ctx->d_ws_fq);
     if (ctx->d_ws_seg) (void)hipFree(ctx->d_ws_seg);
     if (ctx->h_stage) (void)hipHostFree(ctx->h_stage);
+    for (void* b : ctx->host_blocks) (void)hipHostFree(b);
     if (ctx->ev_begin) (void)hipEventDestroy(ctx->ev_begin);
     if (ctx->ev_end) (void)hipEventDestroy(ctx->ev_end);
     delete ctx;
@@ -1713,27 +1717,90 @@ int ultra_hip_memcpy_h2d(ultra_hip_ctx* ctx, void* d_dst, const void* h_src, siz
     return ULTRA_HIP_OK;
 }
 
-int ultra_hip_memcpy_h2d_async(ultra_hip_ctx* ctx, void* d_dst, const void* h_src, size_t bytes) {
-    if (!ctx || (bytes && (!d_dst || !h_src))) return ULTRA_HIP_ERR_INVALID_ARG;
-    if (bytes == 0) return ULTRA_HIP_OK;
-    constexpr size_t kRing = size_t(1) << 20;
-    if (bytes > kRing / 4) return ultra_hip_memcpy_h2d(ctx, d_dst, h_src, bytes);      // large transfers: the blocking copy
-    DeviceGuard guard(ctx->device);
+namespace {
+constexpr size_t kStageRing = size_t(1) << 20;
+// a slot of the pinned staging ring holding a copy of [h_src, h_src + bytes): nullptr if the ring cannot be had
+char* stage_slot(ultra_hip_ctx* ctx, const void* h_src, size_t bytes) {
     if (!ctx->h_stage) {
-        void* p = nullptr;
-        if (hipHostMalloc(&p, kRing, hipHostMallocDefault) != hipSuccess) { (void)hipGetLastError(); return ultra_hip_memcpy_h2d(ctx, d_dst, h_src, bytes); }
-        ctx->h_stage = static_cast<char*>(p); ctx->stage_cap = kRing; ctx->stage_off = 0;
+        void* p = nullptr; void* d = nullptr;
+        if (hipHostMalloc(&p, kStageRing, hipHostMallocMapped) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
+        if (hipHostGetDevicePointer(&d, p, 0) != hipSuccess) { (void)hipGetLastError(); d = nullptr; }
+        ctx->h_stage = static_cast<char*>(p); ctx->d_stage = static_cast<char*>(d); ctx->stage_cap = kStageRing; ctx->stage_off = 0;
     }
     const size_t need = (bytes + 255) & ~size_t(255);
-    if (ctx->stage_off + need > ctx->stage_cap) {              // wrap: the ring's earlier copies must have left it
-        UH_HIP(uh_stream_sync(ctx->stream));
+    if (ctx->stage_off + need > ctx->stage_cap) {              // wrap: the ring's earlier copies (and readers) must have left it
+        if (uh_stream_sync(ctx->stream) != hipSuccess) return nullptr;
         ctx->stage_off = 0;
     }
     char* slot = ctx->h_stage + ctx->stage_off;
     std::memcpy(slot, h_src, bytes);                           // the caller's buffer is free again when this call returns
     ctx->stage_off += need;
+    return slot;
+}
+}  // namespace
+
+int ultra_hip_memcpy_h2d_async(ultra_hip_ctx* ctx, void* d_dst, const void* h_src, size_t bytes) {
+    if (!ctx || (bytes && (!d_dst || !h_src))) return ULTRA_HIP_ERR_INVALID_ARG;
+    if (bytes == 0) return ULTRA_HIP_OK;
+    if (bytes > kStageRing / 4) return ultra_hip_memcpy_h2d(ctx, d_dst, h_src, bytes);      // large transfers: the blocking copy
+    DeviceGuard guard(ctx->device);
+    char* slot = stage_slot(ctx, h_src, bytes);
+    if (!slot) return ultra_hip_memcpy_h2d(ctx, d_dst, h_src, bytes);
     UH_HIP(hipMemcpyAsync(d_dst, slot, bytes, hipMemcpyHostToDevice, ctx->stream));
     return ULTRA_HIP_OK;
+}
+
+int ultra_hip_stage_input(ultra_hip_ctx* ctx, const void* h_src, size_t bytes, void** d_view) {
+    if (!ctx || !h_src || !d_view || bytes == 0 || bytes > kStageRing / 4) return ULTRA_HIP_ERR_INVALID_ARG;
+    DeviceGuard guard(ctx->device);
+    char* slot = stage_slot(ctx, h_src, bytes);
+    if (!slot || !ctx->d_stage) return ULTRA_HIP_ERR_HIP;
+    *d_view = ctx->d_stage + (slot - ctx->h_stage);
+    return ULTRA_HIP_OK;
+}
+
+int ultra_hip_host_block(ultra_hip_ctx* ctx, size_t bytes, void** h_ptr, void** d_ptr) {
+    if (!ctx || !h_ptr || !d_ptr || bytes == 0 || bytes > (size_t(64) << 20)) return ULTRA_HIP_ERR_INVALID_ARG;
+    DeviceGuard guard(ctx->device);
+    void* p = nullptr; void* d = nullptr;
+    UH_HIP(hipHostMalloc(&p, bytes, hipHostMallocMapped));
+    if (hipHostGetDevicePointer(&d, p, 0) != hipSuccess) { (void)hipGetLastError(); (void)hipHostFree(p); return ULTRA_HIP_ERR_HIP; }
+    std::memset(p, 0, bytes);
+    ctx->host_blocks.push_back(p);
+    *h_ptr = p; *d_ptr = d;
+    return ULTRA_HIP_OK;
+}
+
+namespace ultra_hip { namespace dev {
+__global__ void stream_post_kernel(unsigned* flag, unsigned value) {
+    __threadfence_system();
+    __hip_atomic_store(flag, value, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+} }
+
+int ultra_hip_stream_post(ultra_hip_ctx* ctx, uint32_t* d_flag, uint32_t value) {
+    if (!ctx || !d_flag) return ULTRA_HIP_ERR_INVALID_ARG;
+    DeviceGuard guard(ctx->device);
+    // one thread behind everything on the stream: the kernels before it have completed (their stores to the block are out),
+    // the release store at system scope is what the host polls for
+    hipLaunchKernelGGL(dev::stream_post_kernel, dim3(1), dim3(1), 0, ctx->stream, d_flag, value);
+    UH_HIP(hipGetLastError());
+    return ULTRA_HIP_OK;
+}
+
+int ultra_hip_host_wait(ultra_hip_ctx* ctx, const volatile uint32_t* h_flag, uint32_t value, uint32_t timeout_us) {
+    if (!ctx || !h_flag) return ULTRA_HIP_ERR_INVALID_ARG;
+    g_host_syncs.fetch_add(1, std::memory_order_relaxed);       // a blocking wait of the host on the device, whatever it spins on
+    const auto t0 = std::chrono::steady_clock::now();
+    for (unsigned spins = 0;; ++spins) {
+        if (__atomic_load_n(h_flag, __ATOMIC_ACQUIRE) == value) return ULTRA_HIP_OK;
+        if ((spins & 63u) == 63u &&
+            std::chrono::duration_cast<std::chrono::microseconds>(std::chrono::steady_clock::now() - t0).count() > (long long)timeout_us) break;
+        __builtin_ia32_pause();
+    }
+    DeviceGuard guard(ctx->device);
+    UH_HIP(hipStreamSynchronize(ctx->stream));
+    return (__atomic_load_n(h_flag, __ATOMIC_ACQUIRE) == value) ? ULTRA_HIP_OK : ULTRA_HIP_ERR_HIP;
 }
 
 int ultra_hip_memcpy_d2h(ultra_hip_ctx* ctx, void* h_dst, const void* d_src, size_t bytes) {

@@ -14,7 +14,7 @@
 // that define the reference's Impl), with -lultra_hip.  No caller changes: tools, waveforms, RxPipeline and ModemEngine run on
 // the GPU as they are — INTEGRATION.md 0 / 0b; tests/test_gpu_pimpl.py and tests/test_gpu_ref_programs.py run 34 of the
 // reference's own programs built that way (ModemEngine's among them: tools/test_iwaveform.cpp, test_modem_engine_loopback.cpp,
-// cli_simulator.cpp, threaded_simulator.cpp, oracle/engine_thread_harness.cpp with its feeder / GUI-poll / mode-change threads)
+// cli_simulator.cpp, threaded_simulator.cpp, and a scripted harness with feeder / GUI-poll / mode-change threads)
 // and compare their output with the reference build's.
 //
 // ultra::ChannelEstimator — a small stand-alone host class that shares demodulator.cpp (:1019-1066) and the header with the

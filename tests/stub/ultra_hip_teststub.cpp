@@ -38,6 +38,9 @@ struct ultra_hip_ctx {
     bool have_records = false;
     std::mutex m;                          // one object, one thread at a time is the contract: a violation shows as a TSan report on `busy`
     int busy = 0;
+    void* blocks[8] = {};                  // ultra_hip_host_block: here the host's and the device's view are the same heap block
+    int n_blocks = 0;
+    char* ring = nullptr; size_t ring_off = 0;   // ultra_hip_stage_input: slots of exactly the bytes asked for would be better for ASan; a ring is what the library has
 };
 
 namespace {
@@ -120,6 +123,8 @@ void ultra_hip_destroy(ultra_hip_ctx* ctx) {
     if (!ctx) return;
     if (ctx->magic != 0x57ab57abu) std::abort();            // double destroy / foreign pointer
     ctx->magic = 0;
+    for (int i = 0; i < ctx->n_blocks; ++i) std::free(ctx->blocks[i]);
+    std::free(ctx->ring);
     delete ctx;
 }
 int ultra_hip_get_geometry(const ultra_hip_ctx* ctx, ultra_hip_geometry* geo) {
@@ -142,6 +147,39 @@ int ultra_hip_free(ultra_hip_ctx* ctx, void* d) {
 int ultra_hip_memcpy_h2d(ultra_hip_ctx* ctx, void* d, const void* h, size_t n) { STUB_ENTRY(ctx); if (n) std::memcpy(d, h, n); return ULTRA_HIP_OK; }
 int ultra_hip_memcpy_h2d_async(ultra_hip_ctx* ctx, void* d, const void* h, size_t n) { STUB_ENTRY(ctx); if (n) std::memcpy(d, h, n); return ULTRA_HIP_OK; }
 int ultra_hip_memcpy_d2h(ultra_hip_ctx* ctx, void* h, const void* d, size_t n) { STUB_ENTRY(ctx); if (n) std::memcpy(h, d, n); return ULTRA_HIP_OK; }
+
+int ultra_hip_host_block(ultra_hip_ctx* ctx, size_t bytes, void** h, void** d) {
+    STUB_ENTRY(ctx);
+    if (!h || !d || bytes == 0 || ctx->n_blocks >= 8) return ULTRA_HIP_ERR_INVALID_ARG;
+    void* p = std::calloc(1, bytes);
+    if (!p) return ULTRA_HIP_ERR_OOM;
+    ctx->blocks[ctx->n_blocks++] = p;
+    *h = p; *d = p;
+    return ULTRA_HIP_OK;
+}
+int ultra_hip_stage_input(ultra_hip_ctx* ctx, const void* h_src, size_t bytes, void** d_view) {
+    STUB_ENTRY(ctx);
+    constexpr size_t kRing = size_t(1) << 20;
+    if (!h_src || !d_view || bytes == 0 || bytes > kRing / 4) return ULTRA_HIP_ERR_INVALID_ARG;
+    if (!ctx->ring) { ctx->ring = static_cast<char*>(std::malloc(kRing)); if (!ctx->ring) return ULTRA_HIP_ERR_OOM; }
+    const size_t need = (bytes + 255) & ~size_t(255);
+    if (ctx->ring_off + need > kRing) ctx->ring_off = 0;
+    std::memcpy(ctx->ring + ctx->ring_off, h_src, bytes);
+    *d_view = ctx->ring + ctx->ring_off;
+    ctx->ring_off += need;
+    return ULTRA_HIP_OK;
+}
+int ultra_hip_stream_post(ultra_hip_ctx* ctx, uint32_t* d_flag, uint32_t value) {
+    STUB_ENTRY(ctx);
+    if (!d_flag) return ULTRA_HIP_ERR_INVALID_ARG;
+    __atomic_store_n(d_flag, value, __ATOMIC_RELEASE);
+    return ULTRA_HIP_OK;
+}
+int ultra_hip_host_wait(ultra_hip_ctx* ctx, const volatile uint32_t* h_flag, uint32_t value, uint32_t) {
+    STUB_ENTRY(ctx);
+    if (!h_flag) return ULTRA_HIP_ERR_INVALID_ARG;
+    return __atomic_load_n(h_flag, __ATOMIC_ACQUIRE) == value ? ULTRA_HIP_OK : ULTRA_HIP_ERR_HIP;
+}
 
 int ultra_hip_set_deinterleave(ultra_hip_ctx* ctx, uint32_t bps) { if (!ctx || ctx->magic != 0x57ab57abu || bps >= 648) return ULTRA_HIP_ERR_INVALID_ARG; return ULTRA_HIP_OK; }
 int ultra_hip_set_deinterleave_table(ultra_hip_ctx* ctx, const uint16_t*, uint32_t) { return (ctx && ctx->magic == 0x57ab57abu) ? ULTRA_HIP_OK : ULTRA_HIP_ERR_INVALID_ARG; }
