@@ -98,6 +98,7 @@ struct ultra_hip_ctx {
     char* d_stage = nullptr;             // ... and the device's view of it (ultra_hip_stage_input)
     size_t stage_cap = 0, stage_off = 0;
     std::vector<void*> host_blocks;      // ultra_hip_host_block: pinned, device-mapped result blocks
+    bool post_refused = false;           // hipStreamWriteValue32 refused the block's memory once: ultra_hip_stream_post launches its kernel
     int stream_start_mode = 0;           // ultra_hip_demod_stream_start: how the next first_symbol == 0 stream call starts (consumed by it)
     const float* stream_start_timing = nullptr;
     // ULTRA_HIP_FALLBACK_CHAIN=1: the fall-back kernels for every layout — track_pilot_kernel + track_kernel per symbol instead
@@ -1781,8 +1782,16 @@ __global__ void stream_post_kernel(unsigned* flag, unsigned value) {
 int ultra_hip_stream_post(ultra_hip_ctx* ctx, uint32_t* d_flag, uint32_t value) {
     if (!ctx || !d_flag) return ULTRA_HIP_ERR_INVALID_ARG;
     DeviceGuard guard(ctx->device);
-    // one thread behind everything on the stream: the kernels before it have completed (their stores to the block are out),
-    // the release store at system scope is what the host polls for
+    // A stream memory operation where the runtime has one for this memory (no launch: the command processor writes the word when
+    // the stream gets there) — ULTRA_HIP_POST=kernel or a refusal falls back to one thread behind everything on the stream: the
+    // kernels before it have completed (their stores to the block are out), the release store at system scope is what the host
+    // polls for.
+    static const bool use_kernel = [] { const char* e = std::getenv("ULTRA_HIP_POST"); return e && e[0] == 'k'; }();
+    if (!use_kernel && !ctx->post_refused) {
+        if (hipStreamWriteValue32(ctx->stream, d_flag, value, 0) == hipSuccess) return ULTRA_HIP_OK;
+        (void)hipGetLastError();
+        ctx->post_refused = true;
+    }
     hipLaunchKernelGGL(dev::stream_post_kernel, dim3(1), dim3(1), 0, ctx->stream, d_flag, value);
     UH_HIP(hipGetLastError());
     return ULTRA_HIP_OK;
