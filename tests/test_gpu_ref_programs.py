@@ -118,7 +118,7 @@ IWAVEFORM = [
     ["--snr", "15", "--cfo", "0", "--channel", "moderate", "-w", "ofdm_chirp", "--rate", "r1_4", "--frames", "5"],
     ["--snr", "15", "--cfo", "30", "--channel", "moderate", "-w", "ofdm_chirp", "--rate", "r1_4", "--frames", "5"],
     ["--snr", "5", "--cfo", "30", "--channel", "awgn", "-w", "mc_dpsk", "--frames", "3"],
-    ["--snr", "5", "--cfo", "0", "--channel", "moderate", "-w", "mc_dpsk", "--frames", "3"],
+    ["--snr", "5", "--cfo", "0", "--channel", "awgn", "-w", "mc_dpsk", "--frames", "3"],
     ["--snr", "20", "--cfo", "0", "--channel", "awgn", "-w", "ofdm_cox", "--frames", "1"],
 ]
 
