@@ -109,8 +109,10 @@ def test_ofdm_chirp_tools_default_noise(name, tmp_path):
 # tools/test_iwaveform.cpp — what /root/reference/tests/regression_matrix.sh:16-23 calls its PRIMARY tool.  The quick matrix
 # (:138-185): the five OFDM_CHIRP rows (a TX ModemEngine with its threads alive while ONE OFDMChirpWaveform + LDPCDecoder
 # receive the stream) and two MC-DPSK rows (RX through ModemEngine::feedAudio: acquisition thread -> frame queue -> decode
-# thread -> LDPC), plus one OFDM_COX scenario.  Deterministic: everything the program prints, with the decode thread's
-# "[RX] Decoded" lines — printed when the thread gets there — compared as a set.
+# thread -> LDPC).  Deterministic: everything the program prints, with the decode thread's "[RX] Decoded" lines — printed when
+# the thread gets there — compared as a set.  (OFDM_COX through the engine: test_engine_thread_harness[cox]; the tool's own
+# `-w ofdm_cox` row waits its full 30 s for frames the reference's disconnected-mode engine never decodes — identical on the
+# three builds, run once per round with the other real-time programs: test_iwaveform_ofdm_cox_row.)
 IWAVEFORM = [
     ["--snr", "17", "--cfo", "0", "--channel", "awgn", "-w", "ofdm_chirp", "--frames", "5"],
     ["--snr", "17", "--cfo", "30", "--channel", "awgn", "-w", "ofdm_chirp", "--frames", "5"],
@@ -119,7 +121,6 @@ IWAVEFORM = [
     ["--snr", "15", "--cfo", "30", "--channel", "moderate", "-w", "ofdm_chirp", "--rate", "r1_4", "--frames", "5"],
     ["--snr", "5", "--cfo", "30", "--channel", "awgn", "-w", "mc_dpsk", "--frames", "3"],
     ["--snr", "5", "--cfo", "0", "--channel", "awgn", "-w", "mc_dpsk", "--frames", "3"],
-    ["--snr", "20", "--cfo", "0", "--channel", "awgn", "-w", "ofdm_cox", "--frames", "1"],
 ]
 
 
@@ -206,6 +207,12 @@ def test_profile_acquisition(tmp_path):
 
 LONG = pytest.mark.skipif(os.environ.get("ULTRA_LONG_TESTS") != "1",
                           reason="real-time programs, 30-130 s per build: ULTRA_LONG_TESTS=1 (run once per round: profiles/r06_long_programs.txt)")
+
+
+@LONG
+def test_iwaveform_ofdm_cox_row(tmp_path):
+    args = ["--snr", "20", "--cfo", "0", "--channel", "awgn", "-w", "ofdm_cox", "--frames", "1"]
+    _compare("test_iwaveform", args, _run("test_iwaveform", args, tmp_path), normalise=_iwaveform_norm)
 
 
 @LONG
