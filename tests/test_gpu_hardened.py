@@ -20,13 +20,19 @@ pytestmark = pytest.mark.gpu
 REPORT = re.compile(r"runtime error:|Assertion .* failed|__glibcxx_assert|buffer overflow detected|AddressSanitizer|terminate called")
 
 
-def _pair(name, args, tmp_path, norm=_no_chirp_debug):
+def _pair(name, args, tmp_path, norm=_no_chirp_debug, attempts=1):
+    """attempts > 1: programs whose result depends on how the reference's own engine threads interleave
+    (tests/test_gpu_ref_programs.py::_run_until_the_builds_agree) — a sanitizer report fails at once, whatever the attempt."""
     ref, san = exe(name, "ref"), exe(name, "san")
     require(ref, san)
-    rc_ref, out_ref, err_ref = run(ref, args, cwd=tmp_path)
-    rc, out, err = run(san, args, cwd=tmp_path)
-    assert not REPORT.search(err), f"{name}.san {args}: sanitizer / assertion report\n{[l for l in err.splitlines() if REPORT.search(l)][:5]}"
-    a, b = norm(out_ref), norm(out)
+    for k in range(attempts):
+        rc_ref, out_ref, err_ref = run(ref, args, cwd=tmp_path)
+        rc, out, err = run(san, args, cwd=tmp_path)
+        assert not REPORT.search(err), f"{name}.san {args}: sanitizer / assertion report\n{[l for l in err.splitlines() if REPORT.search(l)][:5]}"
+        a, b = norm(out_ref), norm(out)
+        if a and a == b and rc == rc_ref:
+            return err_ref, err
+        print(f"{name}.san {args}: attempt {k + 1} of {attempts} differs")
     assert a and a == b, (name, args, [(x, y) for x, y in zip(a, b) if x != y][:2], len(a), len(b), err[-600:])
     assert rc == rc_ref, (name, rc_ref, rc, err[-600:])
     return err_ref, err
@@ -66,7 +72,7 @@ def test_hf_modem_hardened(args, tmp_path):
                                   ["--snr", "5", "--cfo", "30", "--channel", "awgn", "-w", "mc_dpsk", "--frames", "3"]],
                          ids=["ofdm_chirp", "mc_dpsk"])
 def test_iwaveform_hardened(args, tmp_path):
-    _pair("test_iwaveform", args, tmp_path, norm=_iwaveform_norm)
+    _pair("test_iwaveform", args, tmp_path, norm=_iwaveform_norm, attempts=3 if "mc_dpsk" in args else 1)
 
 
 def test_headline_harness_and_ctest_pin_hardened(tmp_path):
