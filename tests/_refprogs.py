@@ -108,8 +108,11 @@ def run(path, args, timeout=900, cwd=None, env=None):
     return r.returncode, r.stdout, r.stderr
 
 
-def run_all(name, args, variants, timeout=900, cwd=None, env=None):
-    """The program's builds side by side (one process each): {variant: (rc, stdout, stderr)}."""
+def run_all(name, args, variants, timeout=900, cwd=None, env=None, one_at_a_time=False):
+    """The program's builds side by side (one process each): {variant: (rc, stdout, stderr)}.
+    one_at_a_time: programs whose outcome depends on how their own threads get scheduled run alone on the box."""
+    if one_at_a_time:
+        return {v: run(exe(name, v), args, timeout=timeout, cwd=cwd, env=env) for v in variants}
     out, errs = {}, []
 
     def one(v):

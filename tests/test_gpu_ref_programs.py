@@ -61,10 +61,11 @@ def _run_until_the_builds_agree(name, args, tmp_path, normalise, attempts=3, **k
     burst of 960-sample calls races the acquisition thread inside the reference itself: the same binary can decode 3/3 in one run
     and miss a frame in the next (seen once in five runs of the .pimpl build of tools/test_iwaveform.cpp -w mc_dpsk, the reference's
     MC-DPSK demodulator throughout).  Such a program is run up to `attempts` times; the builds must agree completely in at least
-    one attempt.  A systematic difference between the builds fails every attempt."""
+    one attempt.  A systematic difference between the builds fails every attempt.  The builds run one after the other: side by
+    side, three processes of a dozen threads each made the race common (two of three attempts in one run of the suite)."""
     last = None
     for k in range(attempts):
-        outs = _run(name, args, tmp_path, **kw)
+        outs = _run(name, args, tmp_path, one_at_a_time=True, **kw)     # three builds at once compete for the cores the race is run on
         try:
             _compare(name, args, outs, normalise=normalise)
             return outs
