@@ -49,7 +49,7 @@ def test_scripted_pimpl_cases_hardened(sc, fft, mod, rate, seed, tmp_path):
     _pair("demod_pimpl_harness", [sc, str(fft), str(MOD[mod]), str(RATE[rate]), str(seed)], tmp_path, norm=lambda o: o.splitlines())
 
 
-@pytest.mark.parametrize("scenario,seed", [("all", 11)])
+@pytest.mark.parametrize("scenario,seed", [("chirp", 5), ("dpsk", 7)])
 def test_engine_threads_hardened(scenario, seed, tmp_path):
     """Two ModemEngines, feeder + GUI-poll + mode-change threads (oracle/engine_thread_harness.cpp) over the hardened drop-ins
     and the hardened factory."""
