@@ -104,8 +104,15 @@ def exe(name, variant):
 
 
 def run(path, args, timeout=900, cwd=None, env=None):
-    r = subprocess.run([str(path)] + list(args), capture_output=True, text=True, errors="replace", timeout=timeout, cwd=cwd, env=env)
-    return r.returncode, r.stdout, r.stderr
+    """(rc, stdout, stderr) of one run.  The streams go to FILES, not pipes: the reference's engine logs thousands of DEBUG lines
+    from its acquisition and decode threads, a pipe holds 64 KB, and a thread blocked in fprintf while this process drains the pipe
+    shifts exactly the timing its acquisition loop's snapshot race depends on (with pipes the reference's own build lost frames in
+    a third of its runs under pytest; with files, as from a shell, in none of fourteen)."""
+    import tempfile
+    with tempfile.TemporaryFile(mode="w+b") as out, tempfile.TemporaryFile(mode="w+b") as err:
+        r = subprocess.run([str(path)] + list(args), stdout=out, stderr=err, timeout=timeout, cwd=cwd, env=env)
+        out.seek(0); err.seek(0)
+        return r.returncode, out.read().decode(errors="replace"), err.read().decode(errors="replace")
 
 
 def run_all(name, args, variants, timeout=900, cwd=None, env=None, one_at_a_time=False):

@@ -71,6 +71,12 @@ def _run_until_the_builds_agree(name, args, tmp_path, normalise, attempts=3, **k
             return outs
         except AssertionError as e:
             last = e
+            keep = os.environ.get("ULTRA_KEEP_RACE_LOGS")             # a directory: the attempt's stdout / stderr of every build, for a post-mortem
+            if keep:
+                os.makedirs(keep, exist_ok=True)
+                for v, (rc, out, err) in outs.items():
+                    with open(os.path.join(keep, f"{name}_{abs(hash(tuple(args))) % 10000}_{k}_{v}.txt"), "w") as f:
+                        f.write(f"rc {rc}\n--- stdout\n{out}\n--- stderr\n{err}")
             print(f"{name} {args}: attempt {k + 1} of {attempts}: the builds' threads interleaved differently ({str(e).splitlines()[0][:160]})")
     raise last
 
