@@ -72,7 +72,7 @@ def test_hf_modem_hardened(args, tmp_path):
                                   ["--snr", "5", "--cfo", "30", "--channel", "awgn", "-w", "mc_dpsk", "--frames", "3"]],
                          ids=["ofdm_chirp", "mc_dpsk"])
 def test_iwaveform_hardened(args, tmp_path):
-    _pair("test_iwaveform", args, tmp_path, norm=_iwaveform_norm, attempts=3 if "mc_dpsk" in args else 1)
+    _pair("test_iwaveform", args, tmp_path, norm=_iwaveform_norm, attempts=4 if "mc_dpsk" in args else 1)
 
 
 def test_headline_harness_and_ctest_pin_hardened(tmp_path):
