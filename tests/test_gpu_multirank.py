@@ -95,8 +95,10 @@ def test_a_rank_without_a_device_is_refused_not_moved_to_device_0():
     """The device-selection code with an index other than 0 — all one card can execute of it: under RCCL a LOCAL_RANK beyond the
     visible devices gets no line (never a second rank silently sharing device 0), and the drop-ins' ULTRA_HIP_DEVICE
     (hip_ofdm_demodulator.cpp) naming a device the box does not have fails loudly instead of running on device 0."""
-    p = run_bench("--gpus", "2", "--total-frames", "4096", expect_rc=1,
-                  env={"RANK": "1", "LOCAL_RANK": "1", "WORLD_SIZE": "2", "MASTER_ADDR": "127.0.0.1", "MASTER_PORT": "29513"})
+    import torch
+    n_dev = torch.cuda.device_count()                                 # 1 on the GPU box; the first index that does NOT exist on any box
+    p = run_bench("--gpus", str(n_dev + 1), "--total-frames", "4096", expect_rc=1,
+                  env={"RANK": str(n_dev), "LOCAL_RANK": str(n_dev), "WORLD_SIZE": str(n_dev + 1), "MASTER_ADDR": "127.0.0.1", "MASTER_PORT": "29513"})
     assert "has no GPU of its own" in p.stderr and not p.stdout.strip()
     # the same through HIP_VISIBLE_DEVICES: an empty list leaves the rank no device at all
     p = run_bench("--gpus", "1", "--total-frames", "4096", expect_rc=1, env={"HIP_VISIBLE_DEVICES": "", "ROCR_VISIBLE_DEVICES": ""})
@@ -105,7 +107,7 @@ def test_a_rank_without_a_device_is_refused_not_moved_to_device_0():
     tool = exe("test_nvis_mode", "hip")
     require(tool)
     r = subprocess.run([str(tool), "--snr", "30", "--trials", "1"], capture_output=True, text=True, timeout=300,
-                       env=dict(os.environ, ULTRA_HIP_DEVICE="1"))
+                       env=dict(os.environ, ULTRA_HIP_DEVICE=str(n_dev)))
     assert "ultra_hip" in r.stderr and ("FAILED" in r.stderr or "no device" in r.stderr.lower() or r.returncode != 0), (r.returncode, r.stderr[-600:])
     assert "100.0%" not in r.stdout and "100%" not in r.stdout, "a device that does not exist must not decode anything"
 
