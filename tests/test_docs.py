@@ -27,3 +27,19 @@ def test_cited_paths_exist():
                 continue                                              # a program of the reference, cited by its path there
             missing.append((doc, path))
     assert not missing, missing
+
+
+def test_cited_test_names_exist():
+    """`tests/file.py::test_name` and bare `::test_name` citations name functions that exist."""
+    sources = {p.name: p.read_text() for p in (ROOT / "tests").glob("*.py")}
+    everything = "".join(sources.values())
+    bad = []
+    for doc in DOCS:
+        text = (ROOT / doc).read_text()
+        for m in re.finditer(r"`?tests/([A-Za-z0-9_]+\.py)`?::`?([A-Za-z0-9_]+)", text):
+            if f"def {m.group(2)}" not in sources.get(m.group(1), ""):
+                bad.append((doc, m.group(1), m.group(2)))
+        for m in re.finditer(r"::`?(test_[A-Za-z0-9_]+)", text):
+            if f"def {m.group(1)}" not in everything:
+                bad.append((doc, "?", m.group(1)))
+    assert not bad, bad
