@@ -68,8 +68,12 @@ def test_hf_modem_hardened(args, tmp_path):
     _pair("test_hf_modem", args, tmp_path, norm=lambda o: [l for l in o.splitlines() if not l.startswith("[CHIRP-RX]")])
 
 
+import os
+
+
 @pytest.mark.parametrize("args", [["--snr", "17", "--cfo", "30", "--channel", "awgn", "-w", "ofdm_chirp", "--frames", "5"],
-                                  ["--snr", "5", "--cfo", "30", "--channel", "awgn", "-w", "mc_dpsk", "--frames", "3"]],
+                                  pytest.param(["--snr", "5", "--cfo", "30", "--channel", "awgn", "-w", "mc_dpsk", "--frames", "3"],
+                                               marks=pytest.mark.skipif(os.environ.get("ULTRA_LONG_TESTS") != "1", reason="once per round (ULTRA_LONG_TESTS=1): the reference's acquisition race makes an attempt cost up to 36 s; MC-DPSK through the hardened drop-ins runs in test_engine_threads_hardened[dpsk-7]"))],
                          ids=["ofdm_chirp", "mc_dpsk"])
 def test_iwaveform_hardened(args, tmp_path):
     _pair("test_iwaveform", args, tmp_path, norm=_iwaveform_norm, attempts=4 if "mc_dpsk" in args else 1)

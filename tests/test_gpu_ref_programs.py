@@ -153,7 +153,10 @@ IWAVEFORM = [
     ["--snr", "15", "--cfo", "0", "--channel", "moderate", "-w", "ofdm_chirp", "--rate", "r1_4", "--frames", "5"],
     ["--snr", "15", "--cfo", "30", "--channel", "moderate", "-w", "ofdm_chirp", "--rate", "r1_4", "--frames", "5"],
     ["--snr", "5", "--cfo", "30", "--channel", "awgn", "-w", "mc_dpsk", "--frames", "3"],
+]
+IWAVEFORM_LONG = [                                                   # once per round with the real-time programs (each attempt the race spoils waits 30 s)
     ["--snr", "5", "--cfo", "0", "--channel", "awgn", "-w", "mc_dpsk", "--frames", "3"],
+    ["--snr", "20", "--cfo", "0", "--channel", "awgn", "-w", "ofdm_cox", "--frames", "1"],
 ]
 
 
@@ -303,9 +306,11 @@ LONG = pytest.mark.skipif(os.environ.get("ULTRA_LONG_TESTS") != "1",
 
 
 @LONG
-def test_iwaveform_ofdm_cox_row(tmp_path):
-    args = ["--snr", "20", "--cfo", "0", "--channel", "awgn", "-w", "ofdm_cox", "--frames", "1"]
-    _run_until_the_builds_agree("test_iwaveform", args, tmp_path, _iwaveform_norm, attempts=2)
+@pytest.mark.parametrize("args", IWAVEFORM_LONG, ids=["_".join(a).replace("--", "") for a in IWAVEFORM_LONG])
+def test_iwaveform_ofdm_cox_row(args, tmp_path):
+    """The matrix's second MC-DPSK row and the tool's OFDM_COX row (which waits its full 30 s for frames the reference's
+    disconnected-mode engine never decodes)."""
+    _run_until_the_builds_agree("test_iwaveform", args, tmp_path, _iwaveform_norm, weak=_iwaveform_weak if "mc_dpsk" in args else None)
 
 
 @LONG
